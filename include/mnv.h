@@ -1,0 +1,214 @@
+/*
+ * mnv.h -- C ABI of the MI355X-native N3Tree (PlenOctree) ray-march path.
+ *
+ * This is the drop-in boundary for ONE path of cmusatyalab/mega-nerf-viewer:
+ * the per-ray octree traversal + spherical-harmonic evaluation + front-to-back
+ * alpha compositing that the reference launches through
+ *
+ *     viewer::render_voxels(N3Tree&, const Camera&, const RenderOptions&, ...)
+ *         reference: include/cuda/renderer_kernel.hpp:23-34
+ *                    src/cuda/renderer_kernel.cu:396-437 (launcher), :243-292 (kernel)
+ *
+ * Conventions kept from the reference: non-owning views, caller-owned output
+ * buffers, POD structs by value/pointer, asynchronous on a caller stream.
+ * Conventions changed on purpose: every entry point returns
+ * an int status (0 = ok, otherwise a hipError_t or MNV_E_* code) instead of
+ * cuda_assert's exit(); the c2w matrix travels by value inside mnv_camera
+ * (no hidden default-stream memcpy, camera.cpp:113-123); an explicit tile
+ * rectangle selects the pixels to render (multi-GPU partition); float RGBA is
+ * the primary output, RGBA8 (renderer_kernel.cu:237) an optional second one.
+ *
+ * All pointers named "device" must be HIP device pointers on the current
+ * device.  No torch types cross this boundary.
+ */
+#ifndef MNV_H
+#define MNV_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNV_VERSION 1
+#define MNV_BASIS_MAX 25 /* reference include/render_options.hpp:4 */
+
+/* status codes (positive values are hipError_t) */
+#define MNV_OK 0
+#define MNV_E_INVALID (-1)     /* bad argument */
+#define MNV_E_UNSUPPORTED (-2) /* e.g. N != 2, basis_dim not in {-1,0,1,4,9,16,25} */
+#define MNV_E_NO_DEVICE (-3)   /* no HIP device / extension unusable */
+#define MNV_E_IO (-4)          /* file / npz errors */
+
+#define MNV_FORMAT_RGBA 0 /* reference include/data_format.hpp:8-12 */
+#define MNV_FORMAT_SH 1
+
+/*
+ * Non-owning view of an N3Tree in the reference's own array layout
+ * (replaces viewer::internal::TreeSpec, include/data_spec.hpp:25-50).
+ */
+typedef struct mnv_tree_view {
+    const uint16_t *data;         /* [capacity][N^3][data_dim] binary16, n3tree.cpp:183-188 */
+    const int32_t *child;         /* [capacity][N^3] relative chunk offsets, 0 = leaf, n3tree.cpp:92-97 */
+    const int32_t *parent;        /* [capacity], may be NULL, n3tree.cpp:99-107 */
+    const int16_t *sample_counts; /* [capacity][N^3], may be NULL, n3tree.cpp:191-193 */
+    float offset[3];
+    float scale[3];
+    int32_t N;         /* spatial branching factor; only 2 is supported on the device */
+    int32_t data_dim;  /* halfs per voxel row; sigma is column data_dim-1 */
+    int32_t format;    /* MNV_FORMAT_* */
+    int32_t basis_dim; /* SH basis functions per channel, -1 if none */
+    int32_t capacity;  /* chunks in use */
+} mnv_tree_view;
+
+/* Replaces viewer::internal::CameraSpec (include/data_spec.hpp:9-23). */
+typedef struct mnv_camera {
+    int32_t width, height;
+    float fx, fy, cx, cy;
+    float c2w[12]; /* column-major [right | up | back | center], camera.cpp:55-82 */
+} mnv_camera;
+
+/* viewer::RenderOptions, field for field (include/render_options.hpp:9-56). */
+typedef struct mnv_render_options {
+    float step_size;
+    float sigma_thresh;
+    float stop_thresh;
+    float background_brightness;
+    float render_bbox[6];
+    int32_t basis_minmax[2];
+    float rot_dirs[3];
+    bool show_grid;
+    int32_t grid_max_depth;
+    bool render_depth;
+    bool use_splitting;
+    bool use_guided_sampling;
+    int32_t max_depth;
+    int32_t samples_per_corner;
+    int32_t split_batch_size;
+    int32_t nerf_batch_size;
+    int32_t max_sample_count;
+    bool need_viewdir;
+    int32_t appearance_embedding;
+    int32_t max_guided_samples;
+} mnv_render_options;
+
+/* Tile of the camera image; the full frame is {0, 0, width, height}. */
+typedef struct mnv_rect {
+    int32_t x0, y0, w, h;
+} mnv_rect;
+
+/* ------------------------------------------------------------------ misc */
+
+int mnv_version(void);
+/* Thread-local description of the last non-zero status returned on this thread. */
+const char *mnv_last_error(void);
+/* Number of visible HIP devices (0 when there is none; never fails). */
+int mnv_device_count(void);
+/* struct defaults of include/render_options.hpp:9-56 */
+void mnv_default_render_options(mnv_render_options *opt);
+/* CLI defaults of src/opts.cpp:17-32,49-67 (--bg 0, split/nerf batch 4096) */
+void mnv_cli_render_options(mnv_render_options *opt);
+/* Camera::Camera + Camera::_update pose math (src/camera.cpp:29-82):
+ * fy<0 -> fx, cx<0 -> width/2, cy<0 -> height/2 (integer division as in the reference). */
+void mnv_camera_init(mnv_camera *cam, int32_t width, int32_t height, float fx, float fy, float cx, float cy);
+void mnv_camera_set_pose(mnv_camera *cam, const float center[3], const float v_back[3],
+                         const float v_world_up[3]);
+
+/* ------------------------------------------------- the hot path (device) */
+
+/*
+ * Direct replacement of viewer::render_voxels (offscreen branch,
+ * renderer_kernel.cu:225-229,260,277-280) on the reference array layout.
+ *   tree        device view (all array pointers are device pointers)
+ *   tile        pixels [x0,x0+w) x [y0,y0+h) of cam's image
+ *   rgba_out    device float [tile.h][tile.w][4]: rgb after background
+ *               composite, a = accumulated opacity (the four floats the
+ *               reference holds just before its u8 cast); may be NULL
+ *   rgba8_out   device uint8 [tile.h][tile.w][4], renderer_kernel.cu:237; may be NULL
+ *   split_track device float [tile.h][tile.w][3] (priority, chunk, child) or NULL
+ *   sample_track same for the sample tracker or NULL (rt_core.cuh:237-252,308-321);
+ *               the caller pre-fills both with -1 as cuda_renderer.cpp:97-98 does
+ *   visited     device int32 [capacity] or NULL; marked when track_visit != 0
+ *   hip_stream  hipStream_t; the call is asynchronous on it
+ */
+int mnv_render_voxels(const mnv_tree_view *tree, const mnv_camera *cam, const mnv_render_options *opt,
+                      mnv_rect tile, float *rgba_out, uint8_t *rgba8_out, float *split_track,
+                      float *sample_track, int32_t *visited, int track_visit, void *hip_stream);
+
+/*
+ * Packed device re-layout of a tree ("accel"): one 32-bit word per voxel
+ * (child link or leaf sigma), colour rows padded to 64 B, plus a dense
+ * top-of-tree lookup grid.  Built once per tree upload -- the counterpart of
+ * N3Tree::move_to_device (n3tree.cpp:207-246); results are bit-identical to
+ * mnv_render_voxels.
+ */
+typedef struct mnv_accel mnv_accel;
+int mnv_accel_create(const mnv_tree_view *device_tree, void *hip_stream, mnv_accel **out);
+void mnv_accel_destroy(mnv_accel *accel);
+size_t mnv_accel_device_bytes(const mnv_accel *accel);
+int mnv_render_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,
+                            mnv_rect tile, float *rgba_out, uint8_t *rgba8_out, void *hip_stream);
+
+/* Average device time (ms) of the last `mnv_render_*` launches since the
+ * previous call, measured with HIP events on the launch stream when
+ * mnv_set_timing(1) is active; used by bench.py for roofline.achieved. */
+void mnv_set_timing(int enable);
+int mnv_take_timing(double *total_ms, int32_t *launches);
+
+/* ------------------------------------------ host-side data model (C++ core) */
+
+/* Opaque handle to the C++ viewer::N3Tree (host arrays + optional device copy);
+ * mirrors include/n3tree/n3tree.hpp:17-69. */
+typedef struct mnv_n3tree mnv_n3tree;
+
+int mnv_n3tree_open(const char *npz_path, mnv_n3tree **out);          /* N3Tree::open, n3tree.cpp:16-205 */
+int mnv_n3tree_from_arrays(const mnv_tree_view *host_view, mnv_n3tree **out); /* copies */
+void mnv_n3tree_free(mnv_n3tree *t);
+int mnv_n3tree_host_view(const mnv_n3tree *t, mnv_tree_view *view);
+/* N3Tree::move_to_device (n3tree.cpp:207-246): allocates [max_capacity,...] device
+ * arrays, copies the first `capacity` rows, builds the accel. */
+int mnv_n3tree_move_to_device(mnv_n3tree *t, int64_t max_capacity, int need_parent,
+                              int need_sample_counts, void *hip_stream);
+int mnv_n3tree_device_view(const mnv_n3tree *t, mnv_tree_view *view);
+const mnv_accel *mnv_n3tree_accel(const mnv_n3tree *t);
+int mnv_n3tree_save_npz(const mnv_n3tree *t, const char *npz_path); /* svox layout, stored (no deflate) */
+/* DataFormat::parse / to_string (src/data_format.cpp:5-41) */
+void mnv_data_format_parse(const char *str, int32_t *format, int32_t *basis_dim);
+int mnv_data_format_to_string(int32_t format, int32_t basis_dim, char *buf, size_t buflen);
+
+/* ------------------------------------------------ deterministic synthetic trees */
+/* Integer-hash PRNG, IEEE-only arithmetic: bit-identical on every host. */
+
+typedef struct mnv_synth_random_params {
+    int32_t depth;          /* chunk levels; finest voxel 2^-depth */
+    int32_t format;         /* MNV_FORMAT_* */
+    int32_t basis_dim;      /* SH: 1,4,9,16,25; RGBA: -1 */
+    float refine_prob;      /* probability a non-finest voxel is refined */
+    float empty_prob;       /* probability a leaf has sigma = 0 */
+    float sigma_max;        /* dense leaves: sigma ~ U(0, sigma_max) */
+    float coef_sd;          /* SH-DC ~ approx N(0, coef_sd^2), higher orders decay by 1/2 per degree */
+    float offset[3];
+    float scale[3];         /* invradius3 */
+    uint64_t seed;
+} mnv_synth_random_params;
+
+typedef struct mnv_synth_shell_params {
+    int32_t depth;          /* 10 for the headline config */
+    int32_t basis_dim;      /* 9 for the headline config (format SH) */
+    float radius;           /* 0.35 unit-cube units */
+    float half_thickness;   /* 1.5/1024 */
+    float sigma_lo, sigma_hi; /* 50, 400 */
+    float offset[3];
+    float scale[3];
+    uint64_t seed;
+} mnv_synth_shell_params;
+
+int mnv_synth_random_tree(const mnv_synth_random_params *p, mnv_n3tree **out);
+int mnv_synth_shell_tree(const mnv_synth_shell_params *p, mnv_n3tree **out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MNV_H */

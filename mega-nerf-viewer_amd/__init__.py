@@ -1,0 +1,390 @@
+"""ctypes binding of libmnv.so (include/mnv.h) for the test-suite, bench.py and the
+multi-GPU tile driver.
+
+This is plumbing over the C ABI, not a second implementation: every render call goes
+through ``mnv_render_voxels`` / ``mnv_render_voxels_accel`` into the hand-written HIP
+kernels.  There is no CPU or PyTorch fallback -- if ``libmnv.so`` is missing the import of
+the library raises, and a render call on a machine without a HIP device returns the
+library's error (``MnvError``).
+
+Reference surface mirrored here (cmusatyalab/mega-nerf-viewer):
+  * ``N3Tree``           include/n3tree/n3tree.hpp:17-69
+  * ``Camera``           include/camera.hpp:12-87 (pose model + intrinsics)
+  * ``RenderOptions``    include/render_options.hpp:9-56
+  * ``render_voxels``    include/cuda/renderer_kernel.hpp:23-34
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmnv.so")
+
+MNV_OK = 0
+MNV_E_INVALID = -1
+MNV_E_UNSUPPORTED = -2
+MNV_E_NO_DEVICE = -3
+MNV_E_IO = -4
+FORMAT_RGBA = 0
+FORMAT_SH = 1
+BASIS_MAX = 25
+
+
+class MnvError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"mnv error {code}: {msg}")
+        self.code = code
+
+
+class TreeView(C.Structure):
+    _fields_ = [
+        ("data", C.c_void_p),
+        ("child", C.c_void_p),
+        ("parent", C.c_void_p),
+        ("sample_counts", C.c_void_p),
+        ("offset", C.c_float * 3),
+        ("scale", C.c_float * 3),
+        ("N", C.c_int32),
+        ("data_dim", C.c_int32),
+        ("format", C.c_int32),
+        ("basis_dim", C.c_int32),
+        ("capacity", C.c_int32),
+    ]
+
+
+class CameraStruct(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("fx", C.c_float),
+        ("fy", C.c_float),
+        ("cx", C.c_float),
+        ("cy", C.c_float),
+        ("c2w", C.c_float * 12),
+    ]
+
+
+class RenderOptions(C.Structure):
+    """viewer::RenderOptions, field for field (reference include/render_options.hpp:9-56)."""
+
+    _fields_ = [
+        ("step_size", C.c_float),
+        ("sigma_thresh", C.c_float),
+        ("stop_thresh", C.c_float),
+        ("background_brightness", C.c_float),
+        ("render_bbox", C.c_float * 6),
+        ("basis_minmax", C.c_int32 * 2),
+        ("rot_dirs", C.c_float * 3),
+        ("show_grid", C.c_bool),
+        ("grid_max_depth", C.c_int32),
+        ("render_depth", C.c_bool),
+        ("use_splitting", C.c_bool),
+        ("use_guided_sampling", C.c_bool),
+        ("max_depth", C.c_int32),
+        ("samples_per_corner", C.c_int32),
+        ("split_batch_size", C.c_int32),
+        ("nerf_batch_size", C.c_int32),
+        ("max_sample_count", C.c_int32),
+        ("need_viewdir", C.c_bool),
+        ("appearance_embedding", C.c_int32),
+        ("max_guided_samples", C.c_int32),
+    ]
+
+    @classmethod
+    def defaults(cls) -> "RenderOptions":
+        o = cls()
+        lib().mnv_default_render_options(C.byref(o))
+        return o
+
+    @classmethod
+    def cli_defaults(cls) -> "RenderOptions":
+        o = cls()
+        lib().mnv_cli_render_options(C.byref(o))
+        return o
+
+
+class Rect(C.Structure):
+    _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
+
+
+class SynthRandomParams(C.Structure):
+    _fields_ = [
+        ("depth", C.c_int32),
+        ("format", C.c_int32),
+        ("basis_dim", C.c_int32),
+        ("refine_prob", C.c_float),
+        ("empty_prob", C.c_float),
+        ("sigma_max", C.c_float),
+        ("coef_sd", C.c_float),
+        ("offset", C.c_float * 3),
+        ("scale", C.c_float * 3),
+        ("seed", C.c_uint64),
+    ]
+
+
+class SynthShellParams(C.Structure):
+    _fields_ = [
+        ("depth", C.c_int32),
+        ("basis_dim", C.c_int32),
+        ("radius", C.c_float),
+        ("half_thickness", C.c_float),
+        ("sigma_lo", C.c_float),
+        ("sigma_hi", C.c_float),
+        ("offset", C.c_float * 3),
+        ("scale", C.c_float * 3),
+        ("seed", C.c_uint64),
+    ]
+
+
+# every symbol include/mnv.h declares (tests/test_capi_symbols.py checks the export list)
+_SIGNATURES = {
+    "mnv_version": (C.c_int, []),
+    "mnv_last_error": (C.c_char_p, []),
+    "mnv_device_count": (C.c_int, []),
+    "mnv_default_render_options": (None, [C.POINTER(RenderOptions)]),
+    "mnv_cli_render_options": (None, [C.POINTER(RenderOptions)]),
+    "mnv_camera_init": (None, [C.POINTER(CameraStruct), C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "mnv_camera_set_pose": (None, [C.POINTER(CameraStruct), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mnv_render_voxels": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mnv_accel_create": (C.c_int, [C.POINTER(TreeView), C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mnv_accel_destroy": (None, [C.c_void_p]),
+    "mnv_accel_device_bytes": (C.c_size_t, [C.c_void_p]),
+    "mnv_render_voxels_accel": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mnv_set_timing": (None, [C.c_int]),
+    "mnv_take_timing": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "mnv_n3tree_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "mnv_n3tree_from_arrays": (C.c_int, [C.POINTER(TreeView), C.POINTER(C.c_void_p)]),
+    "mnv_n3tree_free": (None, [C.c_void_p]),
+    "mnv_n3tree_host_view": (C.c_int, [C.c_void_p, C.POINTER(TreeView)]),
+    "mnv_n3tree_move_to_device": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "mnv_n3tree_device_view": (C.c_int, [C.c_void_p, C.POINTER(TreeView)]),
+    "mnv_n3tree_accel": (C.c_void_p, [C.c_void_p]),
+    "mnv_n3tree_save_npz": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "mnv_data_format_parse": (None, [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "mnv_data_format_to_string": (C.c_int, [C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]),
+    "mnv_synth_random_tree": (C.c_int, [C.POINTER(SynthRandomParams), C.POINTER(C.c_void_p)]),
+    "mnv_synth_shell_tree": (C.c_int, [C.POINTER(SynthShellParams), C.POINTER(C.c_void_p)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load libmnv.so (built by ``__graft_entry__.build()`` / ``make``); raises if absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path.")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise MnvError(rc, lib().mnv_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    return int(lib().mnv_device_count())
+
+
+def parse_data_format(s: str):
+    f, b = C.c_int32(), C.c_int32()
+    lib().mnv_data_format_parse(s.encode(), C.byref(f), C.byref(b))
+    return f.value, b.value
+
+
+def data_format_to_string(fmt: int, basis_dim: int) -> str:
+    buf = C.create_string_buffer(64)
+    _check(lib().mnv_data_format_to_string(fmt, basis_dim, buf, 64))
+    return buf.value.decode()
+
+
+def _f3(v: Sequence[float]):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+class Camera:
+    """Pose model + intrinsics of viewer::Camera (reference src/camera.cpp:29-130)."""
+
+    def __init__(self, width=256, height=256, fx=1111.0, fy=-1.0, cx=-1.0, cy=-1.0):
+        self.c = CameraStruct()
+        lib().mnv_camera_init(C.byref(self.c), width, height, fx, fy, cx, cy)
+
+    def set_pose(self, center, v_back, v_world_up=(0.0, 0.0, 1.0)) -> "Camera":
+        lib().mnv_camera_set_pose(C.byref(self.c), _f3(center), _f3(v_back), _f3(v_world_up))
+        return self
+
+    @property
+    def width(self):
+        return self.c.width
+
+    @property
+    def height(self):
+        return self.c.height
+
+    @property
+    def c2w(self) -> np.ndarray:
+        return np.array(list(self.c.c2w), dtype=np.float32)
+
+
+def orbit_camera(width, height, fx, radius, azimuth_deg, elevation_deg, fy=-1.0) -> Camera:
+    """Camera on a sphere of `radius` around the world origin looking at the origin
+    (SURVEY.md 8(d) cfg2 poses).  Pure float64 host trigonometry -> float32 pose vectors."""
+    az, el = np.deg2rad(azimuth_deg), np.deg2rad(elevation_deg)
+    back = np.array([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)])
+    center = (radius * back).astype(np.float32)
+    return Camera(width, height, fx, fy).set_pose(center, back.astype(np.float32))
+
+
+class N3Tree:
+    """Handle to the C++ viewer::N3Tree (host arrays + optional device copy + accel)."""
+
+    def __init__(self, handle: int):
+        self._h = C.c_void_p(handle)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().mnv_n3tree_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    @classmethod
+    def open(cls, path: str) -> "N3Tree":
+        h = C.c_void_p()
+        _check(lib().mnv_n3tree_open(os.fsencode(path), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_arrays(cls, data: np.ndarray, child: np.ndarray, *, data_format: str, offset=(0.5, 0.5, 0.5),
+                    scale=(0.5, 0.5, 0.5), parent: Optional[np.ndarray] = None) -> "N3Tree":
+        data = np.ascontiguousarray(data)
+        child = np.ascontiguousarray(child, dtype=np.int32)
+        if data.dtype == np.float16:
+            data = data.view(np.uint16)
+        assert data.dtype == np.uint16
+        cap = child.shape[0]
+        v = TreeView()
+        v.data = data.ctypes.data
+        v.child = child.ctypes.data
+        if parent is not None:
+            parent = np.ascontiguousarray(parent, dtype=np.int32)
+            v.parent = parent.ctypes.data
+        v.offset = _f3(offset)
+        v.scale = _f3(scale)
+        v.N = 2
+        v.data_dim = data.size // (cap * 8)
+        v.format, v.basis_dim = parse_data_format(data_format)
+        v.capacity = cap
+        h = C.c_void_p()
+        _check(lib().mnv_n3tree_from_arrays(C.byref(v), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def synth_random(cls, depth=4, basis_dim=1, fmt=FORMAT_SH, refine_prob=0.6, empty_prob=0.5, sigma_max=30.0,
+                     coef_sd=1.5, offset=(0.5, 0.5, 0.5), scale=(0.5, 0.5, 0.5), seed=0) -> "N3Tree":
+        p = SynthRandomParams(depth, fmt, basis_dim, refine_prob, empty_prob, sigma_max, coef_sd, _f3(offset), _f3(scale), seed)
+        h = C.c_void_p()
+        _check(lib().mnv_synth_random_tree(C.byref(p), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def synth_shell(cls, depth=10, basis_dim=9, radius=0.35, half_thickness=1.5 / 1024, sigma_lo=50.0, sigma_hi=400.0,
+                    offset=(0.5, 0.5, 0.5), scale=(0.5, 0.5, 0.5), seed=0) -> "N3Tree":
+        p = SynthShellParams(depth, basis_dim, radius, half_thickness, sigma_lo, sigma_hi, _f3(offset), _f3(scale), seed)
+        h = C.c_void_p()
+        _check(lib().mnv_synth_shell_tree(C.byref(p), C.byref(h)))
+        return cls(h.value)
+
+    def host_view(self) -> TreeView:
+        v = TreeView()
+        _check(lib().mnv_n3tree_host_view(self._h, C.byref(v)))
+        return v
+
+    def device_view(self) -> TreeView:
+        v = TreeView()
+        _check(lib().mnv_n3tree_device_view(self._h, C.byref(v)))
+        return v
+
+    def host_arrays(self):
+        """(data uint16 [cap,8,data_dim], child int32 [cap,8], parent int32 [cap]) views of the C++ arrays."""
+        v = self.host_view()
+        cap, dd = v.capacity, v.data_dim
+        data = np.ctypeslib.as_array(C.cast(v.data, C.POINTER(C.c_uint16)), shape=(cap, 8, dd))
+        child = np.ctypeslib.as_array(C.cast(v.child, C.POINTER(C.c_int32)), shape=(cap, 8))
+        parent = np.ctypeslib.as_array(C.cast(v.parent, C.POINTER(C.c_int32)), shape=(cap,))
+        return data, child, parent
+
+    @property
+    def capacity(self) -> int:
+        return self.host_view().capacity
+
+    @property
+    def data_format(self) -> str:
+        v = self.host_view()
+        return data_format_to_string(v.format, v.basis_dim)
+
+    def move_to_device(self, max_capacity: int = 0, need_parent=False, need_sample_counts=False, stream: int = 0):
+        _check(lib().mnv_n3tree_move_to_device(self._h, max_capacity, int(need_parent), int(need_sample_counts), C.c_void_p(stream)))
+        return self
+
+    @property
+    def accel(self) -> int:
+        a = lib().mnv_n3tree_accel(self._h)
+        if not a:
+            raise MnvError(MNV_E_INVALID, "tree has no accel (call move_to_device first)")
+        return a
+
+    def save_npz(self, path: str) -> None:
+        _check(lib().mnv_n3tree_save_npz(self._h, os.fsencode(path)))
+
+
+def _ptr(t) -> Optional[int]:
+    """Device pointer of a torch tensor (or a raw int / None)."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def render_voxels(tree_view: TreeView, cam: Camera, opt: RenderOptions, tile=None, rgba=None, rgba8=None,
+                  split_track=None, sample_track=None, visited=None, track_visit=False, stream: int = 0) -> None:
+    """viewer::render_voxels on reference-layout device arrays (asynchronous on `stream`)."""
+    if tile is None:
+        tile = (0, 0, cam.width, cam.height)
+    _check(lib().mnv_render_voxels(C.byref(tree_view), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba), _ptr(rgba8),
+                                   _ptr(split_track), _ptr(sample_track), _ptr(visited), int(track_visit), C.c_void_p(stream)))
+
+
+def render_voxels_accel(accel: int, cam: Camera, opt: RenderOptions, tile=None, rgba=None, rgba8=None, stream: int = 0) -> None:
+    """The tuned march on the packed layout (asynchronous on `stream`)."""
+    if tile is None:
+        tile = (0, 0, cam.width, cam.height)
+    _check(lib().mnv_render_voxels_accel(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba), _ptr(rgba8),
+                                         C.c_void_p(stream)))
+
+
+def set_timing(enable: bool) -> None:
+    lib().mnv_set_timing(int(enable))
+
+
+def take_timing():
+    ms, n = C.c_double(), C.c_int32()
+    _check(lib().mnv_take_timing(C.byref(ms), C.byref(n)))
+    return ms.value, n.value

@@ -1,0 +1,51 @@
+// mnv_accel.h -- the packed device layout ("accel") behind mnv_render_voxels_accel.
+//
+// HBM layout (built once per tree upload by mnv_accel_create):
+//   nodes [capacity*8] u32   one word per voxel, replacing BOTH the child word
+//                            (rt_core.cuh:146) and the sigma half (rt_core.cuh:231):
+//                              internal: absolute index of the child chunk (1 .. 2^31-1)
+//                              leaf    : 0x80000000 | depth << 16 | sigma(binary16 bits)
+//   rows  [capacity*8][row_bytes]   the 3*basis_dim colour halfs of a voxel, padded to a
+//                            multiple of 16 B (54 -> 64 B for SH9) so that one dense
+//                            sample is row_bytes/16 aligned dwordx4 loads
+//   grid  [2^L]^3 u32        dense top-of-tree lookup at level L = grid_level: the node
+//                            word of the depth-L voxel covering the cell, or the
+//                            (shallower) leaf word that covers it; staged in LDS
+// The in-leaf coordinates the march needs are frac(pos * 2^depth); x*2, floorf and
+// x - floorf(x) are exact in binary32 for x in [0,2), so any traversal that reaches the
+// same leaf reproduces the reference's iterated descent bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mnv_device.h"
+
+namespace mnv {
+
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr int kMaxGridLevel = 5;  // 32^3 * 4 B = 128 KiB of the CU's 160 KiB LDS
+constexpr int kNumQueues = 8;     // one ray queue per XCD
+
+struct AccelView {
+    const uint32_t *nodes;
+    const uint8_t *rows;
+    const uint32_t *grid;
+    int32_t grid_level;
+    int32_t row_bytes;
+    float offset[3], scale[3];
+    int32_t data_dim, basis_dim, format, capacity;
+};
+
+}  // namespace mnv
+
+struct mnv_accel {
+    mnv::AccelView view;
+    uint32_t *nodes = nullptr;
+    uint8_t *rows = nullptr;
+    uint32_t *grid = nullptr;
+    uint32_t *queue = nullptr;  // kNumQueues ray-queue heads (+ pad), reset per launch
+    size_t bytes = 0;
+    int device = 0;
+    int num_cus = 0;
+};

@@ -1,0 +1,201 @@
+// mnv_capi.hip -- the extern "C" entry points of include/mnv.h that touch the device.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "mnv_internal.h"
+
+namespace mnv {
+
+static thread_local std::string g_last_error;
+
+int set_error(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+int check_hip(hipError_t e, const char *what) {
+    if (e == hipSuccess) return MNV_OK;
+    return set_error((int)e, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// ---- launch timing (HIP events on the launch stream) -------------------------------
+static std::mutex g_timing_mu;
+static bool g_timing_on = false;
+static double g_timing_ms = 0.0;
+static int32_t g_timing_launches = 0;
+struct PendingEvents {
+    hipEvent_t e0, e1;
+};
+static std::vector<PendingEvents> g_pending;
+
+LaunchTimer::LaunchTimer(hipStream_t s) : stream(s) {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    if (!g_timing_on) return;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
+    active = true;
+    (void)hipEventRecord(e0, stream);
+}
+
+LaunchTimer::~LaunchTimer() {
+    if (!active) return;
+    (void)hipEventRecord(e1, stream);
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    g_pending.push_back({e0, e1});
+}
+
+// ---- argument block ----------------------------------------------------------------
+int fill_params(MarchParams &P, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile) {
+    if (!cam || !opt) return set_error(MNV_E_INVALID, "camera/options pointer is null");
+    if (cam->width <= 0 || cam->height <= 0) return set_error(MNV_E_INVALID, "camera has no pixels");
+    if (tile.w < 0 || tile.h < 0) return set_error(MNV_E_INVALID, "negative tile extent");
+    P.width = cam->width;
+    P.height = cam->height;
+    P.fx = cam->fx;
+    P.fy = cam->fy;
+    P.cx = cam->cx;
+    P.cy = cam->cy;
+    std::memcpy(P.c2w, cam->c2w, sizeof(P.c2w));
+    P.x0 = tile.x0;
+    P.y0 = tile.y0;
+    P.tw = tile.w;
+    P.th = tile.h;
+    P.step_size = opt->step_size;
+    P.sigma_thresh = opt->sigma_thresh;
+    P.stop_thresh = opt->stop_thresh;
+    P.background_brightness = opt->background_brightness;
+    std::memcpy(P.render_bbox, opt->render_bbox, sizeof(P.render_bbox));
+    P.basis_min = opt->basis_minmax[0];
+    P.basis_max = opt->basis_minmax[1];
+    P.render_depth = opt->render_depth ? 1 : 0;
+    P.max_depth = opt->max_depth;
+    P.max_sample_count = opt->max_sample_count;
+    // rodrigues(opt.rot_dirs, .) frame constants, reference renderer_kernel.cu:43-51
+    const float *aa = opt->rot_dirs;
+    const float angle = sqrtf(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2]);
+    P.rot_enabled = !((double)angle < 1e-6);
+    P.rot_k[0] = P.rot_k[1] = P.rot_k[2] = 0.f;
+    P.rot_cos = 1.f;
+    P.rot_sin = 0.f;
+    if (P.rot_enabled) {
+        for (int i = 0; i < 3; ++i) P.rot_k[i] = aa[i] / angle;
+        P.rot_cos = cosf(angle);
+        P.rot_sin = sinf(angle);
+    }
+    return MNV_OK;
+}
+
+static int fill_tree(MarchParams &P, const mnv_tree_view *t) {
+    if (!t) return set_error(MNV_E_INVALID, "tree view is null");
+    if (t->N != 2 && t->N > 0)
+        return set_error(MNV_E_UNSUPPORTED, "only N == 2 octrees are supported (the reference warns the same, n3tree.cpp:85-87)");
+    if (t->N > 0 && (!t->data || !t->child)) return set_error(MNV_E_INVALID, "tree arrays are null");
+    if (t->N > 0 && t->data_dim < 1) return set_error(MNV_E_INVALID, "data_dim < 1");
+    if (t->N > 0 && t->format == MNV_FORMAT_SH && t->basis_dim >= 0 && 3 * t->basis_dim + 1 > t->data_dim)
+        return set_error(MNV_E_INVALID, "data_dim too small for 3 * basis_dim + sigma");
+    if (t->N > 0 && (t->format != MNV_FORMAT_SH || t->basis_dim < 0) && t->data_dim < 4)
+        return set_error(MNV_E_INVALID, "RGBA rows need data_dim >= 4");
+    P.data = t->data;
+    P.child = t->child;
+    P.sample_counts = t->sample_counts;
+    std::memcpy(P.offset, t->offset, sizeof(P.offset));
+    std::memcpy(P.scale, t->scale, sizeof(P.scale));
+    P.data_dim = t->data_dim;
+    P.basis_dim = t->basis_dim;
+    P.format = t->format;
+    P.capacity = t->capacity;
+    return MNV_OK;
+}
+
+__global__ void fill_background_kernel(const MarchParams P) {
+    // tree.N <= 0: "draw nothing" (renderer_kernel.cu:266-269) -> background only
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (int64_t)P.tw * P.th) return;
+    composite_and_write(P, p, 0.f, 0.f, 0.f, 0.f);
+}
+
+int launch_background(const MarchParams &P, hipStream_t stream) {
+    const int64_t n = (int64_t)P.tw * P.th;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(fill_background_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P);
+    return (int)hipGetLastError();
+}
+
+}  // namespace mnv
+
+using namespace mnv;
+
+extern "C" {
+
+int mnv_version(void) { return MNV_VERSION; }
+
+const char *mnv_last_error(void) { return g_last_error.c_str(); }
+
+int mnv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void mnv_set_timing(int enable) {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    g_timing_on = enable != 0;
+    for (auto &p : g_pending) {
+        (void)hipEventDestroy(p.e0);
+        (void)hipEventDestroy(p.e1);
+    }
+    g_pending.clear();
+    g_timing_ms = 0.0;
+    g_timing_launches = 0;
+}
+
+int mnv_take_timing(double *total_ms, int32_t *launches) {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    for (auto &p : g_pending) {
+        hipError_t e = hipEventSynchronize(p.e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, p.e0, p.e1);
+        (void)hipEventDestroy(p.e0);
+        (void)hipEventDestroy(p.e1);
+        if (e != hipSuccess) {
+            g_pending.clear();
+            return check_hip(e, "mnv_take_timing");
+        }
+        g_timing_ms += ms;
+        g_timing_launches += 1;
+    }
+    g_pending.clear();
+    if (total_ms) *total_ms = g_timing_ms;
+    if (launches) *launches = g_timing_launches;
+    g_timing_ms = 0.0;
+    g_timing_launches = 0;
+    return MNV_OK;
+}
+
+int mnv_render_voxels(const mnv_tree_view *tree, const mnv_camera *cam, const mnv_render_options *opt,
+                      mnv_rect tile, float *rgba_out, uint8_t *rgba8_out, float *split_track,
+                      float *sample_track, int32_t *visited, int track_visit, void *hip_stream) {
+    MarchParams P;
+    std::memset(&P, 0, sizeof(P));
+    int rc = fill_params(P, cam, opt, tile);
+    if (rc) return rc;
+    rc = fill_tree(P, tree);
+    if (rc) return rc;
+    if (track_visit && !visited) return set_error(MNV_E_INVALID, "track_visit set but visited is null");
+    P.rgba = rgba_out;
+    P.rgba8 = rgba8_out;
+    P.split_track = split_track;
+    P.sample_track = sample_track;
+    P.visited = visited;
+    P.track_visit = track_visit ? 1 : 0;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    LaunchTimer timer(stream);
+    if (tree->N <= 0) return check_hip((hipError_t)launch_background(P, stream), "fill_background_kernel");
+    return check_hip((hipError_t)launch_ref_layout(P, stream), "march_ref_layout_kernel");
+}
+
+}  // extern "C"

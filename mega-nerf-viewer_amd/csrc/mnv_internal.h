@@ -1,0 +1,32 @@
+// mnv_internal.h -- host-side declarations shared by the C-ABI translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/mnv.h"
+#include "mnv_device.h"
+#include "mnv_error.h"
+
+namespace mnv {
+
+int check_hip(hipError_t e, const char *what);
+
+// Fill the camera / option / rodrigues part of the kernel argument block.
+int fill_params(MarchParams &P, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile);
+
+int launch_ref_layout(const MarchParams &P, hipStream_t stream);
+int launch_background(const MarchParams &P, hipStream_t stream);
+
+// event-based timing of the render launches (mnv_set_timing / mnv_take_timing)
+struct LaunchTimer {
+    explicit LaunchTimer(hipStream_t s);
+    ~LaunchTimer();
+    hipStream_t stream;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool active = false;
+};
+
+}  // namespace mnv

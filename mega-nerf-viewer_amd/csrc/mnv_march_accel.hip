@@ -1,0 +1,524 @@
+// mnv_march_accel.hip -- the tuned N3Tree march for gfx950 (MI355X) on the packed layout.
+//
+// Replaces, for the RGBA output of one frame or tile, the reference's
+//   render_voxels_kernel          src/cuda/renderer_kernel.cu:243-292
+//   render_voxels_trace_ray       include/cuda/rt_core.cuh:162-332
+//   query_single_from_root        include/cuda/rt_core.cuh:117-159
+// with bit-identical pixels (tests/test_parity_gpu.py).  Design, in CDNA4 terms:
+//   * persistent workgroups (a few per CU); each 64-lane wavefront walks a packet of rays,
+//     one ray per lane, and refills finished lanes from per-XCD ray queues (__ballot +
+//     mbcnt rank + one wave-level atomic), so that early-terminated rays do not leave
+//     lanes idle while the slowest ray of an 8x8 tile finishes;
+//   * the top `grid_level` levels of the octree are a dense grid staged in LDS (up to
+//     128 KiB of the CU's 160 KiB): a step in coarse empty space costs one ds_read and no
+//     global load, and deep descents start at level grid_level + 1;
+//   * one 32-bit node word per voxel carries either the child link or the leaf's sigma,
+//     so the dependent sigma load of the reference disappears; colour rows are fetched
+//     (16-B vector loads from a 64-B padded row) only for dense samples;
+//   * rays are queued in 8x8-pixel tile order and the tile range is split into 8
+//     contiguous bands, one per XCD (workgroup b runs on XCD b % 8), so that each XCD's
+//     4 MiB L2 holds the sub-trees of its own screen region; empty queues steal.
+// MFMA is not used: the inner step is pointer chasing plus a <= 75-term dot in a fixed
+// summation order (DESIGN.md "Why no MFMA").
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+
+#include "mnv_accel.h"
+#include "mnv_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace mnv {
+
+// ------------------------------------------------------------------ accel build kernels
+
+// Level-synchronous depth propagation: depth[child chunk] = depth[chunk] + 1.
+__global__ void accel_depth_pass(const int32_t *child, int32_t *depth, int32_t capacity, int32_t level,
+                                 int32_t *changed) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= (int64_t)capacity * 8) return;
+    const int32_t c = (int32_t)(v >> 3);
+    if (depth[c] != level) return;
+    const int32_t skip = child[v];
+    if (skip != 0) {
+        const int64_t t = (int64_t)c + skip;
+        if (t >= 0 && t < capacity) {
+            depth[t] = level + 1;
+            *changed = 1;
+        }
+    }
+}
+
+__global__ void accel_pack_nodes(const int32_t *child, const uint16_t *data, const int32_t *depth,
+                                 uint32_t *nodes, int32_t capacity, int32_t data_dim) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= (int64_t)capacity * 8) return;
+    const int32_t c = (int32_t)(v >> 3);
+    const int32_t skip = child[v];
+    if (skip != 0) {
+        nodes[v] = (uint32_t)(c + skip);
+    } else {
+        const uint32_t d = (uint32_t)depth[c] & 0x7fu;
+        nodes[v] = kLeafBit | (d << 16) | (uint32_t)data[v * data_dim + data_dim - 1];
+    }
+}
+
+// rows[v][0 .. row_bytes) = data[v][0 .. data_dim-1) zero padded; 16 B per thread
+__global__ void accel_pack_rows(const uint16_t *data, uint8_t *rows, int64_t nvox, int32_t data_dim,
+                                int32_t row_bytes) {
+    const int32_t pieces = row_bytes / 16;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvox * pieces) return;
+    const int64_t v = i / pieces;
+    const int32_t p = (int32_t)(i % pieces);
+    const uint16_t *src = data + v * data_dim;
+    uint16_t h[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int32_t col = p * 8 + k;
+        h[k] = col < data_dim - 1 ? src[col] : (uint16_t)0;
+    }
+    uint4 o;
+    o.x = h[0] | ((uint32_t)h[1] << 16);
+    o.y = h[2] | ((uint32_t)h[3] << 16);
+    o.z = h[4] | ((uint32_t)h[5] << 16);
+    o.w = h[6] | ((uint32_t)h[7] << 16);
+    *reinterpret_cast<uint4 *>(rows + v * row_bytes + p * 16) = o;
+}
+
+// grid[(ix*G + iy)*G + iz] = word of the voxel of depth <= L that covers cell (ix,iy,iz)
+__global__ void accel_build_grid(const uint32_t *nodes, uint32_t *grid, int32_t L) {
+    const int32_t G = 1 << L;
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= G * G * G) return;
+    const int32_t iz = i & (G - 1), iy = (i >> L) & (G - 1), ix = i >> (2 * L);
+    uint32_t chunk = 0, word = 0;
+    for (int32_t l = 1; l <= L; ++l) {
+        const int32_t s = L - l;
+        const int32_t cidx = (((ix >> s) & 1) << 2) | (((iy >> s) & 1) << 1) | ((iz >> s) & 1);
+        word = nodes[(int64_t)chunk * 8 + cidx];
+        if (word & kLeafBit) break;
+        chunk = word;
+    }
+    grid[i] = word;
+}
+
+// ------------------------------------------------------------------------ march kernel
+
+constexpr int kRefillMin = 16;  // refill a wavefront once this many lanes are idle
+
+struct AccelLaunch {
+    MarchParams P;   // camera, tile, options, outputs (tree pointers unused)
+    AccelView A;
+    uint32_t *queue; // kNumQueues heads
+    uint32_t tiles_x, n_tiles;
+    uint32_t band_begin[kNumQueues + 1];  // tile ranges per queue
+    int32_t lds_level;                    // levels staged in LDS (<= A.grid_level)
+};
+
+template <int BASIS, int ROW_BYTES>
+__device__ __forceinline__ void shade(const uint8_t *row, const float *basis, float weight, const uint64_t *s_exp,
+                                      float &o0, float &o1, float &o2) {
+    // the whole padded row in registers: ROW_BYTES/16 dwordx4 loads
+    constexpr int NV = ROW_BYTES / 16;
+    uint4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = reinterpret_cast<const uint4 *>(row)[i];
+    auto coef = [&](int k) -> float {
+        const uint4 q = v[k >> 3];
+        const uint32_t w = ((k >> 1) & 3) == 0 ? q.x : ((k >> 1) & 3) == 1 ? q.y : ((k >> 1) & 3) == 2 ? q.z : q.w;
+        return half_bits_to_float((uint16_t)((k & 1) ? (w >> 16) : (w & 0xffffu)));
+    };
+    if constexpr (BASIS >= 0) {
+        constexpr int stride = BASIS > 0 ? BASIS : 1;
+        const float c0 = sh_channel<BASIS>(basis, coef, 0);
+        const float c1 = sh_channel<BASIS>(basis, coef, stride);
+        const float c2 = sh_channel<BASIS>(basis, coef, 2 * stride);
+        o0 += weight / (1.f + exact_expf(-c0, s_exp));
+        o1 += weight / (1.f + exact_expf(-c1, s_exp));
+        o2 += weight / (1.f + exact_expf(-c2, s_exp));
+    } else {
+        o0 += coef(0) * weight;
+        o1 += coef(1) * weight;
+        o2 += coef(2) * weight;
+    }
+}
+
+template <int BASIS, int ROW_BYTES, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
+    uint64_t *s_exp = reinterpret_cast<uint64_t *>(s_mem);  // 32 x 8 B
+    uint32_t *s_grid = s_mem + 64;                           // (2^lds_level)^3 words
+    const MarchParams &P = K.P;
+    const AccelView &A = K.A;
+
+    const int LL = K.lds_level;
+    const int cells = 1 << (3 * LL);
+    if (threadIdx.x < 32) s_exp[threadIdx.x] = kExp2fTab[threadIdx.x];
+    if (LL == A.grid_level) {
+        for (int i = threadIdx.x; i < cells; i += BLOCK) s_grid[i] = A.grid[i];
+    } else {
+        // coarser LDS grid sampled from the device grid: a cell of level LL is covered by the
+        // word of its first level-grid_level sub-cell only if that word is a leaf of depth <= LL;
+        // otherwise walk down from the root as the builder does
+        for (int i = threadIdx.x; i < cells; i += BLOCK) {
+            const int G = 1 << LL;
+            const int iz = i & (G - 1), iy = (i >> LL) & (G - 1), ix = i >> (2 * LL);
+            uint32_t chunk = 0, word = 0;
+            for (int l = 1; l <= LL; ++l) {
+                const int s = LL - l;
+                const int cidx = (((ix >> s) & 1) << 2) | (((iy >> s) & 1) << 1) | ((iz >> s) & 1);
+                word = A.nodes[(int64_t)chunk * 8 + cidx];
+                if (word & kLeafBit) break;
+                chunk = word;
+            }
+            s_grid[i] = word;
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const float grid_scale = (float)(1 << LL);
+    constexpr int NB = BASIS > 0 ? BASIS : 1;
+
+    // per-lane ray state
+    RaySetup<NB> r;
+    float t = 0.f, T = 1.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    int64_t pix = 0;
+    bool alive = false;
+
+    // ray queues: home queue first, then steal round robin
+    const uint32_t home = blockIdx.x % kNumQueues;
+    uint32_t qsel = 0;            // queues tried so far (wave-uniform)
+    bool exhausted = false;       // all queues empty (wave-uniform)
+
+    for (;;) {
+        const uint64_t idle = __ballot(!alive);
+        const int n_idle = __popcll(idle);
+        if (!exhausted && n_idle >= kRefillMin) {
+            // ---- refill idle lanes from the ray queues
+            const uint32_t q = (home + qsel) % kNumQueues;
+            const uint32_t begin = K.band_begin[q] * 64u, end = K.band_begin[q + 1] * 64u;
+            uint32_t base = 0;
+            if (lane == 0) base = begin + atomicAdd(&K.queue[q * 16], (uint32_t)n_idle);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= end) {
+                if (++qsel >= kNumQueues) exhausted = true;
+                continue;
+            }
+            if (!alive) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                const uint32_t id = base + rank;
+                if (id < end) {
+                    const uint32_t tile = id >> 6, w = id & 63u;
+                    const uint32_t tx = tile % K.tiles_x, ty = tile / K.tiles_x;
+                    const int bx = (int)(tx * 8 + (w & 7u)), by = (int)(ty * 8 + (w >> 3));
+                    if (bx < P.tw && by < P.th) {
+                        pix = (int64_t)by * P.tw + bx;
+                        setup_ray<(BASIS > 0 ? BASIS : 0)>(P, P.x0 + bx, P.y0 + by, r);
+                        if constexpr (BASIS == 0)
+                            r.basis[0] = (0 < P.basis_min || 0 > P.basis_max) ? 0.f : (float)0.28209479177387814;
+                        if (r.in_bbox) {
+                            alive = true;
+                            t = r.tmin;
+                            T = 1.f;
+                            o0 = o1 = o2 = 0.f;
+                        } else {
+                            composite_and_write(P, pix, 0.f, 0.f, 0.f, P.render_depth ? 1.f : 0.f);
+                        }
+                    }
+                }
+            }
+        }
+        if (__ballot(alive) == 0) {
+            if (exhausted) break;
+            continue;
+        }
+        if (alive) {
+            // ---- one march step (rt_core.cuh:220-323)
+            bool done = false;
+            float o3 = 0.f;
+            if (t < r.tmax) {
+                float pos[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    pos[i] = r.cen[i] + t * r.dir[i];
+                    pos[i] = fmaxf(fminf(pos[i], 1.f - 1e-6f), 0.f);
+                }
+                // top of the tree: LDS grid at level LL
+                const float qx = pos[0] * grid_scale, qy = pos[1] * grid_scale, qz = pos[2] * grid_scale;
+                const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
+                uint32_t word = s_grid[(((((int)fx << LL) + (int)fy)) << LL) + (int)fz];
+                float x[3];
+                int depth;
+                uint32_t vox = 0;  // chunk*8 + child of the leaf (valid when found below the grid)
+                if (word & kLeafBit) {
+                    depth = (int)((word >> 16) & 0x7fu);
+                    // frac(pos * 2^depth): exact
+                    const float sc = __uint_as_float((uint32_t)(127 + depth) << 23);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const float pd = pos[i] * sc;
+                        x[i] = pd - floorf(pd);
+                    }
+                    // leaf above the grid level: its voxel index is needed only for a dense sample;
+                    // recover it by walking the (L2-resident) top levels
+                    if (half_bits_to_float((uint16_t)word) > P.sigma_thresh) {
+                        uint32_t chunk = 0;
+                        for (int l = 1;; ++l) {
+                            const float s2 = __uint_as_float((uint32_t)(127 + l) << 23);
+                            const int cx = (int)floorf(pos[0] * s2) & 1, cy = (int)floorf(pos[1] * s2) & 1, cz = (int)floorf(pos[2] * s2) & 1;
+                            vox = chunk * 8u + (uint32_t)((cx << 2) | (cy << 1) | cz);
+                            if (l == depth) break;
+                            chunk = A.nodes[vox];
+                        }
+                    }
+                } else {
+                    depth = LL;
+                    x[0] = qx - fx;
+                    x[1] = qy - fy;
+                    x[2] = qz - fz;
+                    do {
+                        int cidx = 0;
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            x[i] *= 2.f;
+                            const float f = floorf(x[i]);
+                            cidx = cidx * 2 + (int)f;
+                            x[i] -= f;
+                        }
+                        vox = word * 8u + (uint32_t)cidx;
+                        word = A.nodes[vox];
+                        ++depth;
+                    } while (!(word & kLeafBit));
+                }
+                // _dda_unit, rt_core.cuh:88-100
+                float tu = 1e4f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float t1 = -x[i] * r.invdir[i];
+                    const float t2 = t1 + r.invdir[i];
+                    tu = fminf(tu, fmaxf(t1, t2));
+                }
+                const float inv_cube = __uint_as_float((uint32_t)(127 - depth) << 23);  // 2^-depth
+                const float delta_t = tu * inv_cube + P.step_size;
+                const float sigma = half_bits_to_float((uint16_t)word);
+                if (sigma > P.sigma_thresh) {
+                    const float att = exact_expf(-delta_t * r.delta_scale * sigma, s_exp);
+                    const float weight = T * (1.f - att);
+                    if (P.render_depth) {
+                        o0 += weight * t;
+                    } else {
+                        shade<BASIS, ROW_BYTES>(A.rows + (int64_t)vox * ROW_BYTES, r.basis, weight, s_exp, o0, o1, o2);
+                    }
+                    T *= att;
+                    if (T < P.stop_thresh) {
+                        if (P.render_depth) o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
+                        const float s = 1.f / (1.f - T);
+                        o0 *= s;
+                        o1 *= s;
+                        o2 *= s;
+                        o3 = 1.f;
+                        done = true;
+                    }
+                }
+                t += delta_t;
+            }
+            if (!done && !(t < r.tmax)) {
+                if (P.render_depth) {
+                    o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
+                    o3 = 1.f;
+                } else {
+                    o3 = 1.f - T;
+                }
+                done = true;
+            }
+            if (done) {
+                composite_and_write(P, pix, o0, o1, o2, o3);
+                alive = false;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- host side
+
+static int row_bytes_for(int data_dim) {
+    const int b = 2 * (data_dim - 1);
+    return ((b + 15) / 16) * 16;
+}
+
+template <int BASIS, int ROW_BYTES>
+static int launch_variant(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
+    constexpr int BLOCK = 256;
+    auto kern = march_accel_kernel<BASIS, ROW_BYTES, BLOCK>;
+    static thread_local size_t configured = 0;
+    if (lds_bytes > 65536 && configured < lds_bytes) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        configured = lds_bytes;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(BLOCK), lds_bytes, stream, K);
+    return (int)hipGetLastError();
+}
+
+int launch_accel(const mnv_accel *accel, MarchParams &P, hipStream_t stream) {
+    if (P.tw <= 0 || P.th <= 0) return 0;
+    AccelLaunch K;
+    K.P = P;
+    K.A = accel->view;
+    K.tiles_x = (uint32_t)((P.tw + 7) / 8);
+    const uint32_t tiles_y = (uint32_t)((P.th + 7) / 8);
+    K.n_tiles = K.tiles_x * tiles_y;
+    // contiguous bands of tile rows per queue
+    for (int q = 0; q <= kNumQueues; ++q) K.band_begin[q] = (uint32_t)(((uint64_t)tiles_y * q) / kNumQueues) * K.tiles_x;
+    static std::atomic<uint32_t> slot_counter{0};
+    const uint32_t slot = slot_counter.fetch_add(1) % 64u;
+    K.queue = accel->queue + slot * (kNumQueues * 16);
+    hipError_t e = hipMemsetAsync(K.queue, 0, kNumQueues * 16 * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return (int)e;
+
+    const int env_level = getenv("MNV_LDS_LEVEL") ? atoi(getenv("MNV_LDS_LEVEL")) : -1;
+    int lds_level = accel->view.grid_level < 4 ? accel->view.grid_level : 4;
+    if (env_level >= 1 && env_level <= accel->view.grid_level) lds_level = env_level;
+    K.lds_level = lds_level;
+    const size_t lds_bytes = 256 + ((size_t)4 << (3 * lds_level));
+    const int env_bpc = getenv("MNV_BLOCKS_PER_CU") ? atoi(getenv("MNV_BLOCKS_PER_CU")) : 0;
+    int blocks_per_cu = lds_level >= 5 ? 1 : 8;
+    if (env_bpc > 0) blocks_per_cu = env_bpc;
+    int n_blocks = accel->num_cus * blocks_per_cu;
+    const uint32_t n_waves_needed = K.n_tiles;  // one initial 8x8 tile per wave
+    if ((uint32_t)n_blocks * 4u > n_waves_needed) n_blocks = (int)((n_waves_needed + 3) / 4);
+    if (n_blocks < 1) n_blocks = 1;
+
+    const int b = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim >= 0) ? accel->view.basis_dim : -1;
+    switch (b) {
+        case -1: return launch_variant<-1, 16>(K, n_blocks, lds_bytes, stream);
+        case 1: return launch_variant<1, 16>(K, n_blocks, lds_bytes, stream);
+        case 4: return launch_variant<4, 32>(K, n_blocks, lds_bytes, stream);
+        case 9: return launch_variant<9, 64>(K, n_blocks, lds_bytes, stream);
+        case 16: return launch_variant<16, 96>(K, n_blocks, lds_bytes, stream);
+        case 25: return launch_variant<25, 160>(K, n_blocks, lds_bytes, stream);
+        default: return -1000;
+    }
+}
+
+}  // namespace mnv
+
+using namespace mnv;
+
+extern "C" {
+
+int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) {
+    if (!t || !out) return set_error(MNV_E_INVALID, "null argument");
+    if (t->N != 2) return set_error(MNV_E_UNSUPPORTED, "accel needs N == 2");
+    if (!t->data || !t->child || t->capacity < 1 || t->data_dim < 1) return set_error(MNV_E_INVALID, "invalid device tree view");
+    const int b = (t->format == MNV_FORMAT_SH && t->basis_dim >= 0) ? t->basis_dim : -1;
+    if (!(b == -1 || b == 1 || b == 4 || b == 9 || b == 16 || b == 25))
+        return set_error(MNV_E_UNSUPPORTED, "accel supports RGBA and SH1/4/9/16/25 rows; use mnv_render_voxels for others");
+    if (b >= 0 && t->data_dim != 3 * b + 1) return set_error(MNV_E_UNSUPPORTED, "accel needs data_dim == 3 * basis_dim + 1");
+    if (b < 0 && t->data_dim != 4) return set_error(MNV_E_UNSUPPORTED, "accel needs data_dim == 4 for RGBA rows");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    mnv_accel *a = new mnv_accel();
+    int rc = MNV_OK;
+    int32_t *depth = nullptr, *changed = nullptr;
+    auto fail = [&](int code) {
+        if (depth) (void)hipFree(depth);
+        if (changed) (void)hipFree(changed);
+        mnv_accel_destroy(a);
+        return code;
+    };
+    if ((rc = check_hip(hipGetDevice(&a->device), "hipGetDevice"))) return fail(rc);
+    hipDeviceProp_t prop;
+    if ((rc = check_hip(hipGetDeviceProperties(&prop, a->device), "hipGetDeviceProperties"))) return fail(rc);
+    a->num_cus = prop.multiProcessorCount;
+
+    const int64_t cap = t->capacity, nvox = cap * 8;
+    const int row_bytes = row_bytes_for(t->data_dim);
+    if ((rc = check_hip(hipMalloc((void **)&a->nodes, nvox * 4), "hipMalloc(nodes)"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&a->rows, nvox * row_bytes), "hipMalloc(rows)"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&depth, cap * 4), "hipMalloc(depth)"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&changed, 4), "hipMalloc(flag)"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&a->queue, 64 * kNumQueues * 16 * sizeof(uint32_t)), "hipMalloc(queue)"))) return fail(rc);
+
+    // chunk depths: root chunk holds depth-1 voxels
+    if ((rc = check_hip(hipMemsetAsync(depth, 0, cap * 4, stream), "memset depth"))) return fail(rc);
+    const int32_t one = 1;
+    if ((rc = check_hip(hipMemcpyAsync(depth, &one, 4, hipMemcpyHostToDevice, stream), "seed depth"))) return fail(rc);
+    const unsigned nb = (unsigned)((nvox + 255) / 256);
+    int max_depth = 1;
+    for (int level = 1; level < 64; ++level) {
+        int32_t flag = 0;
+        if ((rc = check_hip(hipMemsetAsync(changed, 0, 4, stream), "memset flag"))) return fail(rc);
+        hipLaunchKernelGGL(accel_depth_pass, dim3(nb), dim3(256), 0, stream, t->child, depth, t->capacity, level, changed);
+        if ((rc = check_hip(hipMemcpyAsync(&flag, changed, 4, hipMemcpyDeviceToHost, stream), "read flag"))) return fail(rc);
+        if ((rc = check_hip(hipStreamSynchronize(stream), "accel_depth_pass"))) return fail(rc);
+        if (!flag) break;
+        max_depth = level + 1;
+    }
+    hipLaunchKernelGGL(accel_pack_nodes, dim3(nb), dim3(256), 0, stream, t->child, t->data, depth, a->nodes, t->capacity, t->data_dim);
+    const int64_t pieces = nvox * (row_bytes / 16);
+    hipLaunchKernelGGL(accel_pack_rows, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, t->data, a->rows, nvox, t->data_dim, row_bytes);
+    int L = max_depth < kMaxGridLevel ? max_depth : kMaxGridLevel;
+    const int64_t gcells = (int64_t)1 << (3 * L);
+    if ((rc = check_hip(hipMalloc((void **)&a->grid, gcells * 4), "hipMalloc(grid)"))) return fail(rc);
+    hipLaunchKernelGGL(accel_build_grid, dim3((unsigned)((gcells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid, L);
+    if ((rc = check_hip(hipGetLastError(), "accel build launch"))) return fail(rc);
+    if ((rc = check_hip(hipStreamSynchronize(stream), "accel build"))) return fail(rc);
+    (void)hipFree(depth);
+    (void)hipFree(changed);
+    depth = changed = nullptr;
+
+    a->view.nodes = a->nodes;
+    a->view.rows = a->rows;
+    a->view.grid = a->grid;
+    a->view.grid_level = L;
+    a->view.row_bytes = row_bytes;
+    for (int i = 0; i < 3; ++i) {
+        a->view.offset[i] = t->offset[i];
+        a->view.scale[i] = t->scale[i];
+    }
+    a->view.data_dim = t->data_dim;
+    a->view.basis_dim = t->basis_dim;
+    a->view.format = t->format;
+    a->view.capacity = t->capacity;
+    a->bytes = (size_t)(nvox * 4 + nvox * row_bytes + gcells * 4);
+    *out = a;
+    return MNV_OK;
+}
+
+void mnv_accel_destroy(mnv_accel *a) {
+    if (!a) return;
+    if (a->nodes) (void)hipFree(a->nodes);
+    if (a->rows) (void)hipFree(a->rows);
+    if (a->grid) (void)hipFree(a->grid);
+    if (a->queue) (void)hipFree(a->queue);
+    delete a;
+}
+
+size_t mnv_accel_device_bytes(const mnv_accel *a) { return a ? a->bytes : 0; }
+
+int mnv_render_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,
+                            mnv_rect tile, float *rgba_out, uint8_t *rgba8_out, void *hip_stream) {
+    if (!accel) return set_error(MNV_E_INVALID, "accel is null");
+    MarchParams P;
+    std::memset(&P, 0, sizeof(P));
+    int rc = fill_params(P, cam, opt, tile);
+    if (rc) return rc;
+    std::memcpy(P.offset, accel->view.offset, sizeof(P.offset));
+    std::memcpy(P.scale, accel->view.scale, sizeof(P.scale));
+    P.data_dim = accel->view.data_dim;
+    P.basis_dim = accel->view.basis_dim;
+    P.format = accel->view.format;
+    P.capacity = accel->view.capacity;
+    P.rgba = rgba_out;
+    P.rgba8 = rgba8_out;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    LaunchTimer timer(stream);
+    rc = launch_accel(accel, P, stream);
+    if (rc == -1000) return set_error(MNV_E_UNSUPPORTED, "unsupported basis_dim for the accel path");
+    return check_hip((hipError_t)rc, "march_accel_kernel");
+}
+
+}  // extern "C"

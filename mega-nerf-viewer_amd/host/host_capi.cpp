@@ -1,0 +1,182 @@
+// host_capi.cpp -- extern "C" wrappers of include/mnv.h over the C++ host data model.
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "../../include/mnv.h"
+#include "../csrc/mnv_error.h"
+#include "camera.hpp"
+#include "n3tree.hpp"
+#include "render_options.hpp"
+
+namespace viewer::synth {
+void random_tree(const mnv_synth_random_params &p, N3Tree &out);
+void shell_tree(const mnv_synth_shell_params &p, N3Tree &out);
+}  // namespace viewer::synth
+
+struct mnv_n3tree {
+    viewer::N3Tree tree;
+};
+
+namespace {
+template <typename F>
+int guarded(F f) {
+    try {
+        return f();
+    } catch (const std::exception &e) {
+        return mnv::set_error(MNV_E_IO, e.what());
+    } catch (...) {
+        return mnv::set_error(MNV_E_IO, "unknown C++ exception");
+    }
+}
+}  // namespace
+
+extern "C" {
+
+void mnv_default_render_options(mnv_render_options *opt) {
+    const viewer::RenderOptions d;
+    std::memcpy(opt, &d, sizeof(*opt));
+}
+
+void mnv_cli_render_options(mnv_render_options *opt) {
+    // src/opts.cpp:17-32 defaults mapped as in :49-67
+    viewer::RenderOptions d;
+    d.background_brightness = 0.f;
+    d.step_size = 1e-4f;
+    d.stop_thresh = 1e-2f;
+    d.sigma_thresh = 1e-2f;
+    d.split_batch_size = 4096;
+    d.nerf_batch_size = 4096;
+    d.samples_per_corner = 8;
+    d.appearance_embedding = -1;
+    d.max_guided_samples = 128;
+    std::memcpy(opt, &d, sizeof(*opt));
+}
+
+void mnv_camera_init(mnv_camera *cam, int32_t width, int32_t height, float fx, float fy, float cx, float cy) {
+    const viewer::Camera c(width, height, fx, fy, cx, cy);
+    *cam = c.c_abi();
+}
+
+void mnv_camera_set_pose(mnv_camera *cam, const float center[3], const float v_back[3], const float v_world_up[3]) {
+    viewer::Camera c(cam->width, cam->height, cam->fx, cam->fy, cam->cx, cam->cy);
+    c.center = {center[0], center[1], center[2]};
+    c.v_back = {v_back[0], v_back[1], v_back[2]};
+    c.v_world_up = {v_world_up[0], v_world_up[1], v_world_up[2]};
+    c._update();
+    std::memcpy(cam->c2w, c.transform, sizeof(cam->c2w));
+}
+
+int mnv_n3tree_open(const char *npz_path, mnv_n3tree **out) {
+    if (!npz_path || !out) return mnv::set_error(MNV_E_INVALID, "null argument");
+    return guarded([&] {
+        auto *t = new mnv_n3tree();
+        try {
+            t->tree.open(npz_path);
+        } catch (...) {
+            delete t;
+            throw;
+        }
+        *out = t;
+        return MNV_OK;
+    });
+}
+
+int mnv_n3tree_from_arrays(const mnv_tree_view *host_view, mnv_n3tree **out) {
+    if (!host_view || !out) return mnv::set_error(MNV_E_INVALID, "null argument");
+    return guarded([&] {
+        auto *t = new mnv_n3tree();
+        try {
+            t->tree.assign(*host_view);
+        } catch (...) {
+            delete t;
+            throw;
+        }
+        *out = t;
+        return MNV_OK;
+    });
+}
+
+void mnv_n3tree_free(mnv_n3tree *t) { delete t; }
+
+int mnv_n3tree_host_view(const mnv_n3tree *t, mnv_tree_view *view) {
+    if (!t || !view) return mnv::set_error(MNV_E_INVALID, "null argument");
+    *view = t->tree.host_view();
+    return MNV_OK;
+}
+
+int mnv_n3tree_move_to_device(mnv_n3tree *t, int64_t max_capacity, int need_parent, int need_sample_counts,
+                              void *hip_stream) {
+    if (!t) return mnv::set_error(MNV_E_INVALID, "null argument");
+    if (mnv_device_count() <= 0) return mnv::set_error(MNV_E_NO_DEVICE, "no HIP device visible");
+    return guarded([&] {
+        t->tree.move_to_device((long)max_capacity, need_parent != 0, need_sample_counts != 0, hip_stream);
+        return MNV_OK;
+    });
+}
+
+int mnv_n3tree_device_view(const mnv_n3tree *t, mnv_tree_view *view) {
+    if (!t || !view) return mnv::set_error(MNV_E_INVALID, "null argument");
+    if (!t->tree.on_device()) return mnv::set_error(MNV_E_INVALID, "tree is not on the device");
+    *view = t->tree.device_view();
+    return MNV_OK;
+}
+
+const mnv_accel *mnv_n3tree_accel(const mnv_n3tree *t) { return t ? t->tree.device.accel : nullptr; }
+
+int mnv_n3tree_save_npz(const mnv_n3tree *t, const char *npz_path) {
+    if (!t || !npz_path) return mnv::set_error(MNV_E_INVALID, "null argument");
+    return guarded([&] {
+        t->tree.save_npz(npz_path);
+        return MNV_OK;
+    });
+}
+
+void mnv_data_format_parse(const char *str, int32_t *format, int32_t *basis_dim) {
+    viewer::DataFormat f;
+    f.parse(str ? str : "");
+    if (format) *format = f.format == viewer::DataFormat::SH ? MNV_FORMAT_SH : MNV_FORMAT_RGBA;
+    if (basis_dim) *basis_dim = f.basis_dim;
+}
+
+int mnv_data_format_to_string(int32_t format, int32_t basis_dim, char *buf, size_t buflen) {
+    viewer::DataFormat f;
+    f.format = format == MNV_FORMAT_SH ? viewer::DataFormat::SH : viewer::DataFormat::RGBA;
+    f.basis_dim = basis_dim;
+    const std::string s = f.to_string();
+    if (!buf || buflen <= s.size()) return mnv::set_error(MNV_E_INVALID, "buffer too small");
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+    return MNV_OK;
+}
+
+int mnv_synth_random_tree(const mnv_synth_random_params *p, mnv_n3tree **out) {
+    if (!p || !out) return mnv::set_error(MNV_E_INVALID, "null argument");
+    return guarded([&] {
+        auto *t = new mnv_n3tree();
+        try {
+            viewer::synth::random_tree(*p, t->tree);
+        } catch (...) {
+            delete t;
+            throw;
+        }
+        *out = t;
+        return MNV_OK;
+    });
+}
+
+int mnv_synth_shell_tree(const mnv_synth_shell_params *p, mnv_n3tree **out) {
+    if (!p || !out) return mnv::set_error(MNV_E_INVALID, "null argument");
+    return guarded([&] {
+        auto *t = new mnv_n3tree();
+        try {
+            viewer::synth::shell_tree(*p, t->tree);
+        } catch (...) {
+            delete t;
+            throw;
+        }
+        *out = t;
+        return MNV_OK;
+    });
+}
+
+}  // extern "C"

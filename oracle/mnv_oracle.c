@@ -1,0 +1,537 @@
+/*
+ * mnv_oracle.c -- CPU parity oracle (plain C) for the N3Tree ray-march path.
+ * TEST INFRASTRUCTURE ONLY -- see mnv_oracle.h for scope, citations, the
+ * arithmetic specification and the pinning status.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp (oracle/Makefile).
+ * -ffp-contract=off is part of the specification, not an optimisation choice:
+ * every control-flow-relevant value (cell classification, t < tmax, the
+ * light_intensity < stop_thresh early stop) must be reproduced bit for bit.
+ */
+#include "mnv_oracle.h"
+
+#include <math.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ helpers */
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint64_t d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; }
+static inline double u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
+
+/* CUDA min/max on floats (rt_core.cuh uses the unqualified device overloads). */
+static inline float fminf_(float a, float b) { return a < b ? a : b; }
+static inline float fmaxf_(float a, float b) { return a > b ? a : b; }
+
+float orc_half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp = (h >> 10) & 0x1fu;
+    uint32_t man = h & 0x3ffu;
+    if (exp == 0) {
+        if (man == 0) return u2f(sign);
+        /* subnormal half: normalise */
+        int e = -1;
+        do { man <<= 1; ++e; } while (!(man & 0x400u));
+        man &= 0x3ffu;
+        return u2f(sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13));
+    }
+    if (exp == 31) return u2f(sign | 0x7f800000u | (man << 13));
+    return u2f(sign | ((exp + 127 - 15) << 23) | (man << 13));
+}
+
+uint16_t orc_float_to_half(float f) {
+    const uint32_t x = f2u(f);
+    const uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    const uint32_t ax = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) /* inf / nan */
+        return (uint16_t)(sign | 0x7c00u | (ax > 0x7f800000u ? 0x200u | ((ax >> 13) & 0x3ffu) : 0));
+    if (ax >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u); /* rounds to >= 65520 -> inf */
+    if (ax < 0x33000001u) return sign;                        /* <= 2^-25 -> 0 (ties to even) */
+    int32_t e = (int32_t)(ax >> 23) - 127;
+    uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+    int shift;
+    uint32_t base;
+    if (e < -14) { shift = 13 + (-14 - e); base = 0; }
+    else { shift = 13; base = (uint32_t)(e + 15) << 10; m &= 0x7fffffu; }
+    uint32_t q = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u);
+    const uint32_t half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) ++q;
+    return (uint16_t)(sign | (base + q)); /* carry into the exponent is correct by construction */
+}
+
+/* ---------------------------------------------------------------- orc_expf */
+/*
+ * glibc 2.35 sysdeps/ieee754/flt-32/e_expf.c (the upstream is ARM
+ * optimized-routines math/expf.c, EXP2F_TABLE_BITS = 5, non-TOINT_INTRINSICS
+ * path): everything in binary64, one rounding to binary32 at the end.
+ * tab[i] = asuint64(2^(i/32)) - (i << 47); regenerated from first principles
+ * (tests/test_oracle_math.py re-derives it) and checked against libm's expf.
+ */
+static const uint64_t EXP2F_TAB[32] = {
+    0x3ff0000000000000ULL, 0x3fefd9b0d3158574ULL, 0x3fefb5586cf9890fULL, 0x3fef9301d0125b51ULL,
+    0x3fef72b83c7d517bULL, 0x3fef54873168b9aaULL, 0x3fef387a6e756238ULL, 0x3fef1e9df51fdee1ULL,
+    0x3fef06fe0a31b715ULL, 0x3feef1a7373aa9cbULL, 0x3feedea64c123422ULL, 0x3feece086061892dULL,
+    0x3feebfdad5362a27ULL, 0x3feeb42b569d4f82ULL, 0x3feeab07dd485429ULL, 0x3feea47eb03a5585ULL,
+    0x3feea09e667f3bcdULL, 0x3fee9f75e8ec5f74ULL, 0x3feea11473eb0187ULL, 0x3feea589994cce13ULL,
+    0x3feeace5422aa0dbULL, 0x3feeb737b0cdc5e5ULL, 0x3feec49182a3f090ULL, 0x3feed503b23e255dULL,
+    0x3feee89f995ad3adULL, 0x3feeff76f2fb5e47ULL, 0x3fef199bdd85529cULL, 0x3fef3720dcef9069ULL,
+    0x3fef5818dcfba487ULL, 0x3fef7c97337b9b5fULL, 0x3fefa4afa2a490daULL, 0x3fefd0765b6e4540ULL,
+};
+
+float orc_expf(float x) {
+    const double N = 32.0;
+    const double InvLn2N = 0x1.71547652b82fep+0 * N;
+    const double SHIFT = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / N / N / N;
+    const double C1 = 0x1.ebfce50fac4f3p-3 / N / N;
+    const double C2 = 0x1.62e42ff0c52d6p-1 / N;
+
+    const uint32_t ix = f2u(x);
+    const uint32_t abstop = (ix >> 20) & 0x7ffu;
+    if (abstop >= 0x42bu) { /* |x| >= 88 or nan */
+        if (ix == 0xff800000u) return 0.0f;          /* -inf */
+        if (abstop >= 0x7f8u) return x + x;           /* +inf, nan */
+        if (x > 0x1.62e42ep6f) return INFINITY;       /* overflow */
+        if (x < -0x1.9fe368p6f) return 0.0f;          /* underflow */
+        /* the remaining [-103.97, -88) u (88, 88.72] range takes the main path */
+    }
+    const double xd = (double)x;
+    double z = InvLn2N * xd;
+    double kd = z + SHIFT;
+    const uint64_t ki = d2u(kd);
+    kd -= SHIFT;
+    const double r = z - kd;
+    uint64_t t = EXP2F_TAB[ki % 32u];
+    t += ki << (52 - 5);
+    const double s = u2d(t);
+    z = C0 * r + C1;
+    const double r2 = r * r;
+    double y = C2 * r + 1.0;
+    y = z * r2 + y;
+    y = y * s;
+    return (float)y;
+}
+
+/* -------------------------------------------------------------- SH basis */
+/* rt_core.cuh:12-68.  Double literals promote only the sub-expression they
+ * appear in; xx..xz are scalar_t (float) products.  Entries that the reference
+ * leaves uninitialised are set to 0 here (they are never read: the colour
+ * switch at rt_core.cuh:263-281 uses the same fallthrough structure). */
+void orc_sh_basis(int basis_dim, const float vdir[3], float out[ORC_BASIS_MAX]) {
+    for (int i = 0; i < ORC_BASIS_MAX; ++i) out[i] = 0.f;
+    out[0] = (float)0.28209479177387814;
+    const float x = vdir[0], y = vdir[1], z = vdir[2];
+    const float xx = x * x, yy = y * y, zz = z * z;
+    const float xy = x * y, yz = y * z, xz = x * z;
+    switch (basis_dim) {
+        case 25:
+            out[16] = (float)(2.5033429417967046 * xy * (xx - yy));
+            out[17] = (float)(-1.7701307697799304 * yz * (3 * xx - yy));
+            out[18] = (float)(0.9461746957575601 * xy * (7 * zz - 1.f));
+            out[19] = (float)(-0.6690465435572892 * yz * (7 * zz - 3.f));
+            out[20] = (float)(0.10578554691520431 * (zz * (35 * zz - 30) + 3));
+            out[21] = (float)(-0.6690465435572892 * xz * (7 * zz - 3));
+            out[22] = (float)(0.47308734787878004 * (xx - yy) * (7 * zz - 1.f));
+            out[23] = (float)(-1.7701307697799304 * xz * (xx - 3 * yy));
+            out[24] = (float)(0.6258357354491761 * (xx * (xx - 3 * yy) - yy * (3 * xx - yy)));
+            /* fallthrough */
+        case 16:
+            out[9] = (float)(-0.5900435899266435 * y * (3 * xx - yy));
+            out[10] = (float)(2.890611442640554 * xy * z);
+            out[11] = (float)(-0.4570457994644658 * y * (4 * zz - xx - yy));
+            out[12] = (float)(0.3731763325901154 * z * (2 * zz - 3 * xx - 3 * yy));
+            out[13] = (float)(-0.4570457994644658 * x * (4 * zz - xx - yy));
+            out[14] = (float)(1.445305721320277 * z * (xx - yy));
+            out[15] = (float)(-0.5900435899266435 * x * (xx - 3 * yy));
+            /* fallthrough */
+        case 9:
+            out[4] = (float)(1.0925484305920792 * xy);
+            out[5] = (float)(-1.0925484305920792 * yz);
+            out[6] = (float)(0.31539156525252005 * (2.0 * zz - xx - yy));
+            out[7] = (float)(-1.0925484305920792 * xz);
+            out[8] = (float)(0.5462742152960396 * (xx - yy));
+            /* fallthrough */
+        case 4:
+            out[1] = (float)(-0.4886025119029199 * y);
+            out[2] = (float)(0.4886025119029199 * z);
+            out[3] = (float)(-0.4886025119029199 * x);
+            break;
+        default:
+            break;
+    }
+}
+
+/* ------------------------------------------------------------ camera pose */
+/* camera.cpp:54-82 with glm semantics (3rdparty/glm/glm/detail/func_geometric.inl:
+ * normalize(v) = v * (1/sqrt(dot(v,v))), dot = x*x + y*y + z*z left to right,
+ * cross as at :74-77). */
+static void glm_normalize3(const float v[3], float o[3]) {
+    const float d = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    const float inv = 1.0f / sqrtf(d);
+    o[0] = v[0] * inv; o[1] = v[1] * inv; o[2] = v[2] * inv;
+}
+static void glm_cross3(const float x[3], const float y[3], float o[3]) {
+    o[0] = x[1] * y[2] - y[1] * x[2];
+    o[1] = x[2] * y[0] - y[2] * x[0];
+    o[2] = x[0] * y[1] - y[0] * x[1];
+}
+void orc_camera_pose(const float center[3], const float v_back_in[3], const float v_world_up[3],
+                     float c2w[12]) {
+    float back[3], right[3], up[3], tmp[3];
+    glm_normalize3(v_back_in, back);
+    glm_cross3(v_world_up, back, tmp);
+    glm_normalize3(tmp, right);
+    glm_cross3(back, right, up);
+    for (int i = 0; i < 3; ++i) {
+        c2w[0 + i] = right[i];
+        c2w[3 + i] = up[i];
+        c2w[6 + i] = back[i];
+        c2w[9 + i] = center[i];
+    }
+}
+
+void orc_default_options(orc_options *o) {
+    memset(o, 0, sizeof(*o));
+    o->step_size = 1e-4f;
+    o->sigma_thresh = 1e-2f;
+    o->stop_thresh = 1e-2f;
+    o->background_brightness = 1.f;
+    o->render_bbox[0] = o->render_bbox[1] = o->render_bbox[2] = 0.f;
+    o->render_bbox[3] = o->render_bbox[4] = o->render_bbox[5] = 1.f;
+    o->basis_minmax[0] = 0;
+    o->basis_minmax[1] = ORC_BASIS_MAX - 1;
+    o->show_grid = false;
+    o->grid_max_depth = 4;
+    o->render_depth = false;
+    o->use_splitting = false;
+    o->use_guided_sampling = false;
+    o->max_depth = 16;
+    o->samples_per_corner = 8;
+    o->split_batch_size = 4192;
+    o->nerf_batch_size = 1024;
+    o->max_sample_count = 256;
+    o->need_viewdir = false;
+    o->appearance_embedding = -1;
+    o->max_guided_samples = 128;
+}
+
+uint64_t orc_algorithmic_bytes(const orc_counters *c, int32_t format, int32_t basis_dim) {
+    /* colour halfs read per dense sample: 3*basis_dim in SH mode, 3 in RGBA mode */
+    const uint64_t per_hit = (format == 1 && basis_dim >= 0) ? 6ull * (uint64_t)basis_dim : 6ull;
+    return 16ull * c->rays + 4ull * c->levels + 2ull * c->steps + per_hit * c->hits;
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ----------------------------------------------------------- per-ray march */
+
+typedef struct {
+    uint64_t steps, levels, hits;
+    int in_bbox, early_stop;
+} ray_stats;
+
+/* renderer_kernel.cu:40-61 */
+static void rodrigues(const float aa[3], float dir[3]) {
+    float angle = sqrtf(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2]);
+    if ((double)angle < 1e-6) return;
+    float k[3];
+    for (int i = 0; i < 3; ++i) k[i] = aa[i] / angle;
+    const float cos_angle = cosf(angle), sin_angle = sinf(angle);
+    float cross[3];
+    cross[0] = k[1] * dir[2] - k[2] * dir[1];
+    cross[1] = k[2] * dir[0] - k[0] * dir[2];
+    cross[2] = k[0] * dir[1] - k[1] * dir[0];
+    const float dot = k[0] * dir[0] + k[1] * dir[1] + k[2] * dir[2];
+    for (int i = 0; i < 3; ++i) {
+        dir[i] = (float)((double)(dir[i] * cos_angle + cross[i] * sin_angle) +
+                         (double)(k[i] * dot) * (1.0 - (double)cos_angle));
+    }
+}
+
+/* rt_core.cuh:162-332.  `dir` is modified (as in the reference). */
+static void trace_ray(const orc_tree *tree, int32_t *visited, float dir[3], const float vdir[3],
+                      const float cen[3], const orc_options *opt, float tmax_bg, float out[4],
+                      float *split_chunk, float *split_child, float *split_prio,
+                      float *sample_chunk, float *sample_child, float *sample_prio,
+                      int track_visit, ray_stats *st) {
+    const int N = tree->N;
+    const int N3 = N * N * N;
+    const int data_dim = tree->data_dim;
+    const int basis_dim = tree->basis_dim;
+
+    *split_prio = (float)(opt->max_depth + 1);          /* :179 */
+    *sample_prio = (float)(opt->max_sample_count + 1);  /* :180 */
+
+    /* _get_delta_scale :102-115 */
+    dir[0] *= tree->scale[0];
+    dir[1] *= tree->scale[1];
+    dir[2] *= tree->scale[2];
+    const float delta_scale = 1.f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    dir[0] *= delta_scale;
+    dir[1] *= delta_scale;
+    dir[2] *= delta_scale;
+    tmax_bg /= delta_scale; /* :183 */
+
+    float invdir[3];
+    for (int i = 0; i < 3; ++i) invdir[i] = (float)(1.0 / ((double)dir[i] + 1e-9)); /* :189 */
+
+    /* _dda_world :70-86 */
+    float tmin = 0.0f, tmax = 1e4f;
+    for (int i = 0; i < 3; ++i) {
+        const float t1 = (float)(((double)opt->render_bbox[i] + 1e-6 - (double)cen[i]) * (double)invdir[i]);
+        const float t2 = (float)(((double)opt->render_bbox[i + 3] - 1e-6 - (double)cen[i]) * (double)invdir[i]);
+        tmin = fmaxf_(tmin, fminf_(t1, t2));
+        tmax = fminf_(tmax, fmaxf_(t1, t2));
+    }
+    tmax = fminf_(tmax, tmax_bg); /* :192 */
+
+    if (tmax < 0 || tmin > tmax) { /* :194-197 */
+        if (opt->render_depth) out[3] = 1.f;
+        return;
+    }
+    st->in_bbox = 1;
+
+    float basis_fn[ORC_BASIS_MAX];
+    if (tree->format == 1) orc_sh_basis(basis_dim, vdir, basis_fn); /* :201 */
+    else for (int i = 0; i < ORC_BASIS_MAX; ++i) basis_fn[i] = 0.f;
+    for (int i = 0; i < opt->basis_minmax[0] && i < ORC_BASIS_MAX; ++i) basis_fn[i] = 0.f; /* :203-205 */
+    for (int i = opt->basis_minmax[1] + 1; i < ORC_BASIS_MAX; ++i)                       /* :207-209 */
+        if (i >= 0) basis_fn[i] = 0.f;
+
+    float light_intensity = 1.f;
+    float t = tmin;
+    float max_weight = -1, max_sample_weight = -1;
+
+    while (t < tmax) { /* :220 */
+        float pos[3];
+        pos[0] = cen[0] + t * dir[0];
+        pos[1] = cen[1] + t * dir[1];
+        pos[2] = cen[2] + t * dir[2];
+
+        /* query_single_from_root :117-159 */
+        pos[0] = fmaxf_(fminf_(pos[0], 1.f - 1e-6f), 0.f);
+        pos[1] = fmaxf_(fminf_(pos[1], 1.f - 1e-6f), 0.f);
+        pos[2] = fmaxf_(fminf_(pos[2], 1.f - 1e-6f), 0.f);
+        int32_t chunk = 0, child_idx = 0;
+        int depth = 1;
+        for (;;) {
+            if (track_visit && visited) {
+                if (visited[chunk] == 0) visited[chunk] = 1; /* atomicCAS(&visited[i],0,1) :133 */
+            }
+            int cur = 0;
+            for (int i = 0; i < 3; ++i) {
+                pos[i] *= (float)N;
+                const float idx_dimi = floorf(pos[i]);
+                cur = (int)((float)(cur * N) + idx_dimi);
+                pos[i] -= idx_dimi;
+            }
+            const int32_t skip = tree->child[(int64_t)chunk * N3 + cur];
+            ++st->levels;
+            if (skip == 0) { child_idx = cur; break; }
+            depth += 1;
+            chunk += skip;
+        }
+        /* powf(N, depth) :226 -- exact for the representable powers used here */
+        float cube_size = 1.f;
+        for (int i = 0; i < depth; ++i) cube_size *= (float)N;
+
+        /* _dda_unit :88-100 */
+        float tu = 1e4f;
+        for (int i = 0; i < 3; ++i) {
+            const float t1 = -pos[i] * invdir[i];
+            const float t2 = t1 + invdir[i];
+            tu = fminf_(tu, fmaxf_(t1, t2));
+        }
+        const float t_subcube = tu / cube_size;          /* :229 */
+        const float delta_t = t_subcube + opt->step_size; /* :230 */
+        const uint16_t *row = tree->data + ((int64_t)chunk * N3 + child_idx) * data_dim;
+        const float sigma = orc_half_to_float(row[data_dim - 1]); /* :231 */
+        ++st->steps;
+
+        if (sigma > opt->sigma_thresh) { /* :233 */
+            ++st->hits;
+            const float att = orc_expf(-delta_t * delta_scale * sigma);
+            const float weight = light_intensity * (1.f - att);
+
+            if (weight > max_weight && depth < opt->max_depth) { /* :237-243 */
+                *split_chunk = (float)chunk;
+                *split_child = (float)child_idx;
+                *split_prio = (float)depth;
+                max_weight = weight;
+            }
+            if (tree->sample_counts) { /* :245-252 */
+                const int16_t sc = tree->sample_counts[(int64_t)chunk * N3 + child_idx];
+                if (weight > max_sample_weight && sc < opt->max_sample_count) {
+                    *sample_chunk = (float)chunk;
+                    *sample_child = (float)child_idx;
+                    *sample_prio = (float)sc;
+                    max_sample_weight = weight;
+                }
+            }
+
+            if (opt->render_depth) { /* :254-256 */
+                out[0] += weight * t;
+            } else if (basis_dim >= 0) { /* :257-284 */
+                int off = 0;
+#define MB(k) (basis_fn[k] * orc_half_to_float(row[off + (k)]))
+                for (int c = 0; c < 3; ++c) {
+                    float tmp = basis_fn[0] * orc_half_to_float(row[off]);
+                    switch (basis_dim) {
+                        case 25:
+                            tmp += MB(16) + MB(17) + MB(18) + MB(19) + MB(20) + MB(21) + MB(22) + MB(23) + MB(24);
+                            /* fallthrough */
+                        case 16:
+                            tmp += MB(9) + MB(10) + MB(11) + MB(12) + MB(13) + MB(14) + MB(15);
+                            /* fallthrough */
+                        case 9:
+                            tmp += MB(4) + MB(5) + MB(6) + MB(7) + MB(8);
+                            /* fallthrough */
+                        case 4:
+                            tmp += MB(1) + MB(2) + MB(3);
+                    }
+                    out[c] += weight / (1.f + orc_expf(-tmp));
+                    off += basis_dim;
+                }
+#undef MB
+            } else { /* :285-290 */
+                for (int j = 0; j < 3; ++j) out[j] += orc_half_to_float(row[j]) * weight;
+            }
+
+            light_intensity *= att; /* :293 */
+
+            if (light_intensity < opt->stop_thresh) { /* :295-307 */
+                if (opt->render_depth) out[0] = out[1] = out[2] = fminf_(out[0] * 0.3f, 1.0f);
+                const float scale = 1.f / (1.f - light_intensity);
+                out[0] *= scale;
+                out[1] *= scale;
+                out[2] *= scale;
+                out[3] = 1.f;
+                st->early_stop = 1;
+                return;
+            }
+        } else { /* :308-321 */
+            if (max_weight == -1 && depth < opt->max_depth) {
+                *split_chunk = (float)chunk;
+                *split_child = (float)child_idx;
+                *split_prio = (float)depth;
+            }
+            if (tree->sample_counts) {
+                const int16_t sc = tree->sample_counts[(int64_t)chunk * N3 + child_idx];
+                if (max_sample_weight == -1 && sc < opt->max_sample_count) {
+                    *sample_chunk = (float)chunk;
+                    *sample_child = (float)child_idx;
+                    *sample_prio = (float)sc;
+                }
+            }
+        }
+        t += delta_t; /* :323 */
+    }
+    if (opt->render_depth) { /* :325-330 */
+        out[0] = out[1] = out[2] = fminf_(out[0] * 0.3f, 1.0f);
+        out[3] = 1.f;
+    } else {
+        out[3] = 1.f - light_intensity;
+    }
+}
+
+static inline uint8_t pack_u8(float v) {
+    /* renderer_kernel.cu:237 uint8_t(v * 255): truncation; the CUDA float->u8
+     * conversion saturates, restated here as a clamp to [0, 255]. */
+    const float s = v * 255.f;
+    if (!(s > 0.f)) return 0;
+    if (s >= 255.f) return 255;
+    return (uint8_t)s;
+}
+
+int orc_render_voxels(const orc_tree *tree, const orc_camera *cam, const orc_options *opt,
+                      int32_t x0, int32_t y0, int32_t w, int32_t h,
+                      float *rgba, uint8_t *rgba8, float *split_track, float *sample_track,
+                      int32_t *visited, int track_visit, int32_t *steps_out, orc_counters *ctr,
+                      int n_threads) {
+    if (!tree || !cam || !opt || w < 0 || h < 0) return -1;
+    if (tree->N > 0 && (!tree->data || !tree->child)) return -1;
+    uint64_t c_rays = 0, c_inb = 0, c_hit = 0, c_steps = 0, c_levels = 0, c_hits = 0, c_stop = 0, c_max = 0;
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+    if (track_visit) n_threads = 1; /* serial visited marks, no races */
+#else
+    n_threads = 1;
+#endif
+    (void)n_threads;
+
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads) \
+    reduction(+ : c_rays, c_inb, c_hit, c_steps, c_levels, c_hits, c_stop) reduction(max : c_max)
+    for (int32_t ty = 0; ty < h; ++ty) {
+        for (int32_t tx = 0; tx < w; ++tx) {
+            const int ix = x0 + tx, iy = y0 + ty;
+            const int64_t p = (int64_t)ty * w + tx;
+            float dir[3], cen[3], out[4] = {0.f, 0.f, 0.f, 0.f};
+            float trk[6] = {-1.f, -1.f, -1.f, -1.f, -1.f, -1.f};
+            ray_stats st;
+            memset(&st, 0, sizeof(st));
+            if (tree->N > 0) { /* renderer_kernel.cu:266-269 */
+                /* screen2worlddir :30-38 */
+                const float xyz[3] = {(ix + 0.5f - cam->cx) / cam->fx, -(iy + 0.5f - cam->cy) / cam->fy, -1.0f};
+                const float *m = cam->c2w;
+                dir[0] = m[0] * xyz[0] + m[3] * xyz[1] + m[6] * xyz[2];
+                dir[1] = m[1] * xyz[0] + m[4] * xyz[1] + m[7] * xyz[2];
+                dir[2] = m[2] * xyz[0] + m[5] * xyz[1] + m[8] * xyz[2];
+                const float invnorm = 1.f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+                dir[0] *= invnorm;
+                dir[1] *= invnorm;
+                dir[2] *= invnorm;
+                for (int i = 0; i < 3; ++i) cen[i] = tree->offset[i] + tree->scale[i] * m[9 + i]; /* :272-275 */
+                float vdir[3] = {dir[0], dir[1], dir[2]};
+                rodrigues(opt->rot_dirs, vdir); /* :282-283 */
+                trace_ray(tree, visited, dir, vdir, cen, opt, 1e9f, out, &trk[1], &trk[2], &trk[0],
+                          &trk[4], &trk[5], &trk[3], track_visit, &st);
+            }
+            /* composite_and_write, offscreen branch :224-229 */
+            const float nalpha = 1.f - out[3];
+            const float remain = opt->background_brightness * nalpha;
+            out[0] += remain;
+            out[1] += remain;
+            out[2] += remain;
+            if (rgba) memcpy(rgba + p * 4, out, sizeof(out));
+            if (rgba8) {
+                rgba8[p * 4 + 0] = pack_u8(out[0]);
+                rgba8[p * 4 + 1] = pack_u8(out[1]);
+                rgba8[p * 4 + 2] = pack_u8(out[2]);
+                rgba8[p * 4 + 3] = 255;
+            }
+            if (split_track) memcpy(split_track + p * 3, trk, 3 * sizeof(float));
+            if (sample_track) memcpy(sample_track + p * 3, trk + 3, 3 * sizeof(float));
+            if (steps_out) steps_out[p] = (int32_t)st.steps;
+            c_rays += 1;
+            c_inb += (uint64_t)st.in_bbox;
+            c_hit += st.hits > 0;
+            c_steps += st.steps;
+            c_levels += st.levels;
+            c_hits += st.hits;
+            c_stop += (uint64_t)st.early_stop;
+            if (st.steps > c_max) c_max = st.steps;
+        }
+    }
+    if (ctr) {
+        ctr->rays += c_rays;
+        ctr->rays_in_bbox += c_inb;
+        ctr->rays_hit += c_hit;
+        ctr->steps += c_steps;
+        ctr->levels += c_levels;
+        ctr->hits += c_hits;
+        ctr->early_stops += c_stop;
+        if (c_max > ctr->max_steps) ctr->max_steps = c_max;
+    }
+    return 0;
+}

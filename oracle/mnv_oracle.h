@@ -1,0 +1,140 @@
+/*
+ * mnv_oracle.h -- CPU parity oracle for the N3Tree (PlenOctree) ray-march path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it,
+ * and there only as the checker.  The product (libmnv.so) never links or calls
+ * into this file.
+ *
+ * What it restates (all paths relative to /root/reference):
+ *   src/cuda/renderer_kernel.cu:30-38    screen2worlddir
+ *   src/cuda/renderer_kernel.cu:40-61    rodrigues
+ *   src/cuda/renderer_kernel.cu:215-241  composite_and_write (offscreen branch)
+ *   src/cuda/renderer_kernel.cu:243-292  render_voxels_kernel (per-pixel driver)
+ *   include/cuda/rt_core.cuh:12-68       maybe_precalc_basis
+ *   include/cuda/rt_core.cuh:70-100      _dda_world / _dda_unit
+ *   include/cuda/rt_core.cuh:102-115     _get_delta_scale
+ *   include/cuda/rt_core.cuh:117-159     query_single_from_root
+ *   include/cuda/rt_core.cuh:162-332     render_voxels_trace_ray
+ *   src/camera.cpp:54-82                 Camera::_update pose math
+ *
+ * Arithmetic specification (see DESIGN.md "Arithmetic spec"): the reference
+ * source read literally under C++ usual arithmetic conversions, IEEE-754
+ * binary32/binary64, round-to-nearest-even, NO fused multiply-add contraction,
+ * expf = glibc 2.35 sysdeps/ieee754/flt-32/e_expf.c algorithm (restated in
+ * orc_expf, checked bit-for-bit against this container's libm in
+ * tests/test_oracle_math.py), powf(2, depth) = exact 2^depth.
+ *
+ * Pinning status: the reference ships no tests, golden vectors or fixtures for
+ * this path.  The oracle is pinned against outputs of the
+ * reference's own device code (include/cuda/rt_core.cuh) compiled for gfx950 by
+ * the recipe in oracle/Makefile.ref into oracle/_ref/ and run on an MI355X; the
+ * resulting vectors are committed under tests/golden/ (see tests/golden/README.md).
+ */
+#ifndef MNV_ORACLE_H
+#define MNV_ORACLE_H
+
+#include <stdbool.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_BASIS_MAX 25 /* render_options.hpp:4 VIEWER_GLOBAL_BASIS_MAX */
+
+/* Host view of an N3Tree in the reference's own layout (n3tree.cpp:92-97,183-188). */
+typedef struct {
+    const uint16_t *data;          /* [capacity][N^3][data_dim] IEEE binary16 bits */
+    const int32_t *child;          /* [capacity][N^3] relative chunk offsets, 0 = leaf */
+    const int16_t *sample_counts;  /* [capacity][N^3], may be NULL (trackers then skip it) */
+    float offset[3];
+    float scale[3];
+    int32_t N;
+    int32_t data_dim;
+    int32_t format;                /* 0 = RGBA, 1 = SH (data_format.hpp:8-12) */
+    int32_t basis_dim;             /* data_format.hpp:15 */
+    int32_t capacity;
+} orc_tree;
+
+/* data_spec.hpp:9-23 CameraSpec, with the 12-float c2w by value. */
+typedef struct {
+    int32_t width, height;
+    float fx, fy, cx, cy;
+    float c2w[12];                 /* column-major right|up|back|center (camera.cpp:55-82) */
+} orc_camera;
+
+/* render_options.hpp:9-56, field for field. */
+typedef struct {
+    float step_size;
+    float sigma_thresh;
+    float stop_thresh;
+    float background_brightness;
+    float render_bbox[6];
+    int32_t basis_minmax[2];
+    float rot_dirs[3];
+    bool show_grid;
+    int32_t grid_max_depth;
+    bool render_depth;
+    bool use_splitting;
+    bool use_guided_sampling;
+    int32_t max_depth;
+    int32_t samples_per_corner;
+    int32_t split_batch_size;
+    int32_t nerf_batch_size;
+    int32_t max_sample_count;
+    bool need_viewdir;
+    int32_t appearance_embedding;
+    int32_t max_guided_samples;
+} orc_options;
+
+/* Integer work counters (SURVEY.md section 8(d) algorithmic-bytes formula). */
+typedef struct {
+    uint64_t rays;          /* rays rendered */
+    uint64_t rays_in_bbox;  /* rays that passed the render_bbox slab test */
+    uint64_t rays_hit;      /* rays with >= 1 dense (sigma > sigma_thresh) sample */
+    uint64_t steps;         /* march steps (iterations of rt_core.cuh:220) */
+    uint64_t levels;        /* child-word reads (iterations of rt_core.cuh:131) */
+    uint64_t hits;          /* dense samples (rt_core.cuh:233 taken) */
+    uint64_t early_stops;   /* rays ended by rt_core.cuh:295 */
+    uint64_t max_steps;     /* max steps on one ray */
+} orc_counters;
+
+void orc_default_options(orc_options *opt);        /* struct defaults, render_options.hpp */
+float orc_expf(float x);                           /* glibc 2.35 expf algorithm */
+float orc_half_to_float(uint16_t h);
+uint16_t orc_float_to_half(float f);               /* round-to-nearest-even */
+void orc_sh_basis(int basis_dim, const float vdir[3], float out[ORC_BASIS_MAX]);
+
+/* camera.cpp:54-82: pose vectors -> 12-float column-major c2w. */
+void orc_camera_pose(const float center[3], const float v_back[3], const float v_world_up[3],
+                     float c2w_out[12]);
+
+/* bytes = sum_rays [16 + sum_steps (4 d_s + 2 + hit_s * 6 * basis_dim_eff)]. */
+uint64_t orc_algorithmic_bytes(const orc_counters *c, int32_t format, int32_t basis_dim);
+
+/*
+ * Render the tile [x0,x0+w) x [y0,y0+h) of the camera's image, offscreen branch
+ * (background = opt->background_brightness, t_max = 1e9).
+ *   rgba        [h][w][4] float, the four floats *before* the u8 cast (may be NULL)
+ *   rgba8       [h][w][4] uint8, renderer_kernel.cu:237 pack (may be NULL)
+ *   split_track [h][w][3] float (priority, chunk, child), may be NULL
+ *   sample_track[h][w][3] float, may be NULL
+ *   visited     [capacity] int32, used when track_visit != 0
+ *   steps_out   [h][w] int32 per-ray step count, may be NULL
+ *   ctr         accumulated counters, may be NULL
+ * Returns 0, or -1 on invalid arguments.  n_threads <= 0 means all cores.
+ */
+int orc_render_voxels(const orc_tree *tree, const orc_camera *cam, const orc_options *opt,
+                      int32_t x0, int32_t y0, int32_t w, int32_t h,
+                      float *rgba, uint8_t *rgba8,
+                      float *split_track, float *sample_track,
+                      int32_t *visited, int track_visit,
+                      int32_t *steps_out, orc_counters *ctr, int n_threads);
+
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,116 @@
+"""ctypes binding of the CPU parity oracle (oracle/libmnv_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: import this from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg, never from the product package.  See mnv_oracle.h for what it restates."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmnv_oracle.so")
+
+
+class OrcTree(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("child", C.c_void_p), ("sample_counts", C.c_void_p),
+                ("offset", C.c_float * 3), ("scale", C.c_float * 3), ("N", C.c_int32), ("data_dim", C.c_int32),
+                ("format", C.c_int32), ("basis_dim", C.c_int32), ("capacity", C.c_int32)]
+
+
+class OrcCamera(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("c2w", C.c_float * 12)]
+
+
+class OrcOptions(C.Structure):
+    _fields_ = [("step_size", C.c_float), ("sigma_thresh", C.c_float), ("stop_thresh", C.c_float),
+                ("background_brightness", C.c_float), ("render_bbox", C.c_float * 6), ("basis_minmax", C.c_int32 * 2),
+                ("rot_dirs", C.c_float * 3), ("show_grid", C.c_bool), ("grid_max_depth", C.c_int32),
+                ("render_depth", C.c_bool), ("use_splitting", C.c_bool), ("use_guided_sampling", C.c_bool),
+                ("max_depth", C.c_int32), ("samples_per_corner", C.c_int32), ("split_batch_size", C.c_int32),
+                ("nerf_batch_size", C.c_int32), ("max_sample_count", C.c_int32), ("need_viewdir", C.c_bool),
+                ("appearance_embedding", C.c_int32), ("max_guided_samples", C.c_int32)]
+
+
+class OrcCounters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("rays", "rays_in_bbox", "rays_hit", "steps", "levels", "hits", "early_stops", "max_steps")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} missing: run `make -C oracle` (or __graft_entry__.build())")
+        h = C.CDLL(LIB_PATH)
+        h.orc_expf.restype = C.c_float
+        h.orc_expf.argtypes = [C.c_float]
+        h.orc_half_to_float.restype = C.c_float
+        h.orc_half_to_float.argtypes = [C.c_uint16]
+        h.orc_float_to_half.restype = C.c_uint16
+        h.orc_float_to_half.argtypes = [C.c_float]
+        h.orc_sh_basis.restype = None
+        h.orc_sh_basis.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        h.orc_camera_pose.restype = None
+        h.orc_camera_pose.argtypes = [C.POINTER(C.c_float)] * 4
+        h.orc_default_options.restype = None
+        h.orc_default_options.argtypes = [C.POINTER(OrcOptions)]
+        h.orc_algorithmic_bytes.restype = C.c_uint64
+        h.orc_algorithmic_bytes.argtypes = [C.POINTER(OrcCounters), C.c_int32, C.c_int32]
+        h.orc_num_threads.restype = C.c_int
+        h.orc_render_voxels.restype = C.c_int
+        h.orc_render_voxels.argtypes = [C.POINTER(OrcTree), C.POINTER(OrcCamera), C.POINTER(OrcOptions),
+                                        C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_void_p, C.POINTER(OrcCounters), C.c_int]
+        _lib = h
+    return _lib
+
+
+def _copy_struct(dst, src):
+    """Field-wise copy between layout-compatible ctypes structs (product struct -> oracle struct)."""
+    for name, _ in dst._fields_:
+        setattr(dst, name, getattr(src, name))
+    return dst
+
+
+def tree_from_view(view, sample_counts=None) -> OrcTree:
+    """Build an OrcTree from a *host* mnv TreeView (pointers are borrowed)."""
+    t = OrcTree()
+    t.data, t.child = view.data, view.child
+    t.sample_counts = sample_counts.ctypes.data if sample_counts is not None else None
+    for i in range(3):
+        t.offset[i], t.scale[i] = view.offset[i], view.scale[i]
+    t.N, t.data_dim, t.format, t.basis_dim, t.capacity = view.N, view.data_dim, view.format, view.basis_dim, view.capacity
+    return t
+
+
+def render(tree: OrcTree, cam_struct, opt_struct, tile=None, *, want_rgba8=False, want_trackers=False,
+           want_steps=False, visited=None, track_visit=False, n_threads=0):
+    """Render a tile with the oracle.  Returns dict(rgba, rgba8, split, sample, steps, counters)."""
+    cam = _copy_struct(OrcCamera(), cam_struct)
+    opt = _copy_struct(OrcOptions(), opt_struct)
+    if tile is None:
+        tile = (0, 0, cam.width, cam.height)
+    x0, y0, w, h = tile
+    rgba = np.empty((h, w, 4), np.float32)
+    rgba8 = np.empty((h, w, 4), np.uint8) if want_rgba8 else None
+    split = np.full((h, w, 3), -1, np.float32) if want_trackers else None
+    sample = np.full((h, w, 3), -1, np.float32) if want_trackers else None
+    steps = np.empty((h, w), np.int32) if want_steps else None
+    ctr = OrcCounters()
+    p = lambda a: a.ctypes.data if a is not None else None
+    rc = lib().orc_render_voxels(C.byref(tree), C.byref(cam), C.byref(opt), x0, y0, w, h, p(rgba), p(rgba8), p(split),
+                                 p(sample), p(visited), int(track_visit), p(steps), C.byref(ctr), n_threads)
+    if rc != 0:
+        raise RuntimeError("orc_render_voxels: invalid arguments")
+    return dict(rgba=rgba, rgba8=rgba8, split=split, sample=sample, steps=steps, counters=ctr)
+
+
+def algorithmic_bytes(ctr: OrcCounters, fmt: int, basis_dim: int) -> int:
+    return int(lib().orc_algorithmic_bytes(C.byref(ctr), fmt, basis_dim))

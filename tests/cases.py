@@ -1,0 +1,93 @@
+"""Shared parity cases: (tree parameters, camera, options) triples used by the CPU tests, the GPU
+parity tests and the golden-vector generator.  The list follows SURVEY.md 8(c)'s fixture list:
+cfg1 depth-4 SH1 256x256; depth-6 SH4; depth-7 SH9 anisotropic invradius3; RGBA-format tree;
+render_depth; clipped render_bbox; non-zero rot_dirs; restricted basis_minmax; camera inside the
+volume; ray-misses-everything; plus SH16 / SH25 trees."""
+import numpy as np
+
+
+def make_tree(mnv, spec):
+    kind = spec["kind"]
+    args = {k: v for k, v in spec.items() if k != "kind"}
+    if kind == "random":
+        return mnv.N3Tree.synth_random(**args)
+    if kind == "shell":
+        return mnv.N3Tree.synth_shell(**args)
+    raise ValueError(kind)
+
+
+def make_camera(mnv, spec):
+    if "orbit" in spec:
+        o = spec["orbit"]
+        return mnv.orbit_camera(spec["width"], spec["height"], spec["fx"], o["radius"], o["azimuth"], o["elevation"])
+    cam = mnv.Camera(spec.get("width", 256), spec.get("height", 256), spec.get("fx", 1111.0), spec.get("fy", -1.0),
+                     spec.get("cx", -1.0), spec.get("cy", -1.0))
+    if "center" in spec:
+        cam.set_pose(spec["center"], spec["back"], spec.get("up", (0.0, 0.0, 1.0)))
+    return cam
+
+
+def make_options(mnv, spec):
+    opt = mnv.RenderOptions.cli_defaults() if spec.get("base") == "cli" else mnv.RenderOptions.defaults()
+    for k, v in spec.items():
+        if k == "base":
+            continue
+        cur = getattr(opt, k)
+        if hasattr(cur, "__len__"):
+            for i, x in enumerate(v):
+                cur[i] = x
+        else:
+            setattr(opt, k, v)
+    return opt
+
+
+_CFG1_TREE = dict(kind="random", depth=4, basis_dim=1, refine_prob=0.6, empty_prob=0.5, sigma_max=30.0, coef_sd=1.5, seed=0)
+
+CASES = {
+    # cfg1: BASELINE.json configs[0] -- Camera ctor defaults, struct-default options, basis_minmax {0,0}
+    "cfg1_sh1_d4": dict(tree=_CFG1_TREE, camera=dict(), options=dict(basis_minmax=(0, 0))),
+    "sh4_d6": dict(tree=dict(kind="random", depth=6, basis_dim=4, refine_prob=0.55, empty_prob=0.6, sigma_max=40.0, coef_sd=1.0, seed=1),
+                   camera=dict(width=200, height=160, fx=700.0, center=(-2.4, 1.1, 1.6), back=(-0.72, 0.33, 0.48)),
+                   options=dict(base="cli")),
+    "sh9_d7_aniso": dict(tree=dict(kind="random", depth=7, basis_dim=9, refine_prob=0.5, empty_prob=0.7, sigma_max=60.0, coef_sd=1.0, seed=2,
+                                   offset=(0.5, 0.5, 0.5), scale=(0.5, 0.25, 0.125)),
+                         camera=dict(width=240, height=136, fx=500.0, center=(-3.0, 2.0, 5.0), back=(-0.45, 0.3, 0.75)),
+                         options=dict(base="cli", background_brightness=0.25)),
+    "rgba_d5": dict(tree=dict(kind="random", depth=5, basis_dim=-1, fmt=0, refine_prob=0.6, empty_prob=0.5, sigma_max=25.0, seed=3),
+                    camera=dict(width=192, height=192, fx=900.0), options=dict()),
+    "depth_mode": dict(tree=_CFG1_TREE, camera=dict(), options=dict(render_depth=True)),
+    "bbox_clipped": dict(tree=dict(kind="random", depth=5, basis_dim=4, refine_prob=0.6, empty_prob=0.4, sigma_max=30.0, seed=4),
+                         camera=dict(width=160, height=160, fx=600.0),
+                         options=dict(render_bbox=(0.2, 0.1, 0.3, 0.8, 0.9, 0.75))),
+    "rot_dirs": dict(tree=dict(kind="random", depth=5, basis_dim=9, refine_prob=0.6, empty_prob=0.5, sigma_max=30.0, seed=5),
+                     camera=dict(width=160, height=120, fx=500.0), options=dict(rot_dirs=(0.3, -0.2, 0.5))),
+    "basis_minmax": dict(tree=dict(kind="random", depth=5, basis_dim=9, refine_prob=0.6, empty_prob=0.5, sigma_max=30.0, seed=6),
+                         camera=dict(width=160, height=120, fx=500.0), options=dict(basis_minmax=(1, 5))),
+    "camera_inside": dict(tree=dict(kind="random", depth=6, basis_dim=4, refine_prob=0.5, empty_prob=0.8, sigma_max=20.0, seed=7),
+                          camera=dict(width=160, height=160, fx=120.0, center=(0.1, -0.2, 0.05), back=(0.6, 0.64, 0.48)),
+                          options=dict(base="cli")),
+    "ray_miss": dict(tree=_CFG1_TREE, camera=dict(width=64, height=64, fx=800.0, center=(0.0, 0.0, 5.0), back=(0.0, 0.6, -0.8)),
+                     options=dict()),
+    "sh16_d4": dict(tree=dict(kind="random", depth=4, basis_dim=16, refine_prob=0.6, empty_prob=0.5, sigma_max=30.0, seed=8),
+                    camera=dict(width=128, height=128, fx=600.0), options=dict()),
+    "sh25_d4": dict(tree=dict(kind="random", depth=4, basis_dim=25, refine_prob=0.6, empty_prob=0.5, sigma_max=30.0, seed=9),
+                    camera=dict(width=128, height=128, fx=600.0), options=dict()),
+    "shell_d7_sh9": dict(tree=dict(kind="shell", depth=7, basis_dim=9, radius=0.35, half_thickness=1.5 / 128, seed=0),
+                         camera=dict(width=320, height=180, fx=266.0, orbit=dict(radius=2.6, azimuth=22.5, elevation=20.0)),
+                         options=dict(base="cli")),
+    "thresholds": dict(tree=dict(kind="random", depth=5, basis_dim=4, refine_prob=0.6, empty_prob=0.3, sigma_max=80.0, seed=10),
+                       camera=dict(width=128, height=96, fx=400.0),
+                       options=dict(step_size=1e-3, sigma_thresh=5.0, stop_thresh=0.1, background_brightness=0.5)),
+}
+
+# BASELINE.json configs[1]: depth-10 SH9 shell, 1920x1080, fx 1600, orbit radius 2.6, elevation 20
+CFG2_TREE = dict(kind="shell", depth=10, basis_dim=9, radius=0.35, half_thickness=1.5 / 1024, sigma_lo=50.0, sigma_hi=400.0, seed=0)
+
+
+def cfg2_camera(mnv, pose=0, width=1920, height=1080, fx=1600.0):
+    return mnv.orbit_camera(width, height, fx, 2.6, 22.5 * pose, 20.0)
+
+
+def bits(a):
+    """uint32 view for bit-exact comparison of float32 arrays."""
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
