@@ -183,6 +183,11 @@ def lib() -> C.CDLL:
             raise ImportError(
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path.")
+        # One HIP runtime per process: torch ships its own libamdhip64.so.7 and must load it first;
+        # libmnv.so (linked against the same SONAME) then binds to that copy.  Loading ours first
+        # leaves two half-initialised runtimes and hipGetDeviceCount() == 0.
+        import torch  # noqa: F401
+
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(h, name)
