@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the N3Tree march on BASELINE.json's headline configuration.
+
+Workload (BASELINE.json configs[1]): synthetic depth-10 SH-9 N3Tree
+(spherical shell, 1,499,569 chunks), 1920x1080, fx = fy = 1600, a 16-pose orbit at radius 2.6 /
+elevation 20 deg, CLI-default RenderOptions.  One STEP = one pass over that batch of 16 poses
+(33,177,600 primary rays).  Inputs (tree, cameras) are resident in HBM before the timed region.
+
+N > 1 (one process per GPU, torch.distributed over RCCL): the tree is replicated, each frame is
+cut into interleaved macro tiles (rank = tile % world), every rank renders its tiles into a
+compact buffer with ONE launch per frame, and the tiles are gathered to rank 0 over xGMI
+(dist.gather -> RCCL send/recv) and un-permuted into the frame there.  The gather of frame k
+overlaps the render of frames k+1, k+2 (ring of 3 buffers).  Total work per step is fixed, so
+scaling is "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task description) including
+  roofline      algorithmic bytes of the dominant kernel / its HIP-event launch time vs 8 TB/s
+  cpu_baseline  the CPU oracle (a port of the reference's march; the reference has no CPU
+                renderer) timed on this host's cores on a bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+W, H, FX = 1920, 1080, 1600.0
+N_POSES = 16
+MACRO_W, MACRO_H = 128, 120          # 15 x 9 = 135 macro tiles; 15 is odd -> diagonal rank pattern
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8.0 TB/s spec
+COUNTERS_JSON = os.path.join(ROOT, "tests", "golden", "cfg2_counters.json")
+
+
+def load_counters():
+    """Per-pose integer work counters of the CPU restatement, committed with the fixtures."""
+    if not os.path.exists(COUNTERS_JSON):
+        return None
+    with open(COUNTERS_JSON) as f:
+        return json.load(f)
+
+
+def alg_bytes(c, basis_dim=9):
+    # sum_rays [16 + sum_steps (4 d_s + 2 + hit_s * 6 * basis_dim)]
+    return 16 * c["rays"] + 4 * c["levels"] + 2 * c["steps"] + 6 * basis_dim * c["hits"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--gather", choices=["f32", "u8"], default="f32", help="pixel format gathered to rank 0 when N > 1")
+    ap.add_argument("--cpu-poses", type=int, default=4, help="poses rendered by the CPU baseline (bounded sample)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel", choices=["accel", "ref_layout"], default="accel")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as g
+    g.build_if_missing()
+    import mega_nerf_viewer_amd as mnv
+    import cases
+
+    dev = torch.device("cuda", local_rank)
+    t_setup = time.time()
+    tree = cases.make_tree(mnv, cases.CFG2_TREE)
+    tree.move_to_device()
+    cams = [cases.cfg2_camera(mnv, pose, W, H, FX) for pose in range(N_POSES)]
+    opt = mnv.RenderOptions.cli_defaults()
+    setup_s = time.time() - t_setup
+
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    RING = 3
+    if world == 1:
+        frames = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(RING)]
+        dv = tree.device_view() if args.kernel == "ref_layout" else None
+
+        def render_pose(i, slot):
+            if args.kernel == "accel":
+                mnv.render_voxels_accel(tree.accel, cams[i], opt, rgba=frames[slot], stream=stream)
+            else:
+                mnv.render_voxels(dv, cams[i], opt, rgba=frames[slot], stream=stream)
+
+        def step():
+            for i in range(N_POSES):
+                render_pose(i, i % RING)
+    else:
+        rect = (0, 0, W, H)
+        macros_x, macros_y = (W + MACRO_W - 1) // MACRO_W, (H + MACRO_H - 1) // MACRO_H
+        n_macro = macros_x * macros_y
+        j_max = (n_macro + world - 1) // world
+        n_local = mnv.partition_local_tiles(rect, rank, world, MACRO_W, MACRO_H)
+        dt = torch.float32 if args.gather == "f32" else torch.uint8
+        local = [torch.zeros((j_max, MACRO_H, MACRO_W, 4), dtype=dt, device=dev) for _ in range(RING)]
+        if rank == 0:
+            gathered = [torch.empty((world, j_max, MACRO_H, MACRO_W, 4), dtype=dt, device=dev) for _ in range(RING)]
+            m = torch.arange(n_macro, device=dev)
+            src_index = (m % world) * j_max + m // world          # macro tile m lives at [m % world][m // world]
+            frames = [torch.empty((H, W, 4), dtype=dt, device=dev) for _ in range(RING)]
+        pending = [None] * RING
+
+        def finish(slot):
+            w_ = pending[slot]
+            if w_ is None:
+                return
+            w_.wait()
+            pending[slot] = None
+            if rank == 0:
+                t = gathered[slot].view(world * j_max, MACRO_H, MACRO_W, 4)[src_index]
+                t = t.view(macros_y, macros_x, MACRO_H, MACRO_W, 4).permute(0, 2, 1, 3, 4)
+                frames[slot].copy_(t.reshape(macros_y * MACRO_H, macros_x * MACRO_W, 4)[:H, :W])
+
+        def render_pose(i, slot):
+            finish(slot)  # the slot's previous gather must be done before its buffer is overwritten
+            kw = dict(rgba=local[slot]) if args.gather == "f32" else dict(rgba8=local[slot])
+            if n_local > 0:
+                mnv.render_voxels_accel_part(tree.accel, cams[i], opt, rank, world, MACRO_W, MACRO_H, stream=stream, **kw)
+            glist = [gathered[slot][r] for r in range(world)] if rank == 0 else None
+            pending[slot] = dist.gather(local[slot], glist, dst=0, async_op=True)
+
+        def step():
+            for i in range(N_POSES):
+                render_pose(i, i % RING)
+            for s in range(RING):
+                finish(s)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    mnv.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    kern_ms, launches = mnv.take_timing()
+    mnv.set_timing(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    rays_per_step = N_POSES * W * H
+    value = rays_per_step * args.steps / elapsed / 1e6
+
+    # ---- roofline of the dominant kernel (the march): algorithmic bytes per launch / launch time
+    counters = load_counters()
+    cpu_baseline = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import mnv_oracle as orc
+        ot = orc.tree_from_view(tree.host_view())
+        n_cpu = max(1, min(args.cpu_poses, N_POSES))
+        t_cpu, max_diff, n_bad = 0.0, 0.0, 0
+        fresh = {}
+        for i in range(n_cpu):
+            tc = time.perf_counter()
+            r = orc.render(ot, cams[i].c, opt)
+            t_cpu += time.perf_counter() - tc
+            fresh[str(i)] = r["counters"].as_dict()
+            render_pose(i, 0)
+            torch.cuda.synchronize(dev)
+            gpu = frames[0].cpu().numpy()
+            d = np.abs(gpu - r["rgba"])
+            max_diff = max(max_diff, float(d.max()))
+            n_bad += int((gpu.view(np.uint32) != r["rgba"].view(np.uint32)).any(axis=-1).sum())
+        cpu_baseline = {"value": round(n_cpu * W * H / t_cpu / 1e6, 4), "unit": "Mrays/s", "cores": orc.lib().orc_num_threads(),
+                        "kind": "port", "sample": f"poses 0..{n_cpu - 1} of the 16-pose orbit, full 1920x1080 frames, OpenMP over rows"}
+        parity = {"max_abs_drgba_vs_oracle": max_diff, "pixels_not_bit_identical": n_bad, "frames_checked": n_cpu}
+        if counters is None:
+            counters = {"poses": fresh, "partial": True}
+    roofline = None
+    if counters is not None and launches > 0:
+        poses = counters["poses"]
+        mean_bytes = float(np.mean([alg_bytes(c) for c in poses.values()]))
+        per_launch = mean_bytes / world           # each rank's launch covers 1/world of a frame
+        avg_ms = kern_ms / launches
+        achieved = per_launch / (avg_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "kernel": "march_accel_kernel<9,64,256>" if args.kernel == "accel" else "march_ref_layout_kernel<9>",
+                    "avg_launch_ms": round(avg_ms, 5), "launches": launches,
+                    "algorithmic_bytes_per_launch": int(per_launch)}
+
+    if rank == 0:
+        line = {
+            "metric": "Mrays/sec at 1920x1080 on depth-10 SH-9 N3Tree; max|dRGBA| vs ref",
+            "value": round(value, 2),
+            "unit": "Mrays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "cfg2: depth-10 SH9 shell N3Tree (1,499,569 chunks), 1920x1080, 16-pose orbit per step",
+                       "rays_per_step": rays_per_step, "kernel": args.kernel,
+                       "partition": "none" if world == 1 else f"interleaved {MACRO_W}x{MACRO_H} macro tiles, {args.gather} RCCL gather to rank 0"},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "parity": parity,
+            "setup_s": round(setup_s, 2),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -151,6 +151,24 @@ size_t mnv_accel_device_bytes(const mnv_accel *accel);
 int mnv_render_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,
                             mnv_rect tile, float *rgba_out, uint8_t *rgba8_out, void *hip_stream);
 
+/*
+ * Interleaved macro-tile partition of `tile` for multi-GPU rendering: the
+ * rectangle is cut into macro tiles of tile_w x tile_h pixels (multiples of 8), numbered
+ * row-major; this call renders the macro tiles m with m % world == rank.  Outputs are compact
+ * and local-tile-major: local tile j = m / world is stored at
+ * rgba_out[j][tile_h][tile_w][4] (pixels outside `tile` are left untouched), which is the
+ * contiguous buffer each rank hands to the RCCL gather.  world <= 1 is the plain call.
+ */
+typedef struct mnv_partition {
+    int32_t rank, world;
+    int32_t tile_w, tile_h;
+} mnv_partition;
+/* number of local macro tiles of `rank` (the leading dimension of its output buffer) */
+int32_t mnv_partition_local_tiles(mnv_rect tile, mnv_partition part);
+int mnv_render_voxels_accel_part(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,
+                                 mnv_rect tile, mnv_partition part, float *rgba_out, uint8_t *rgba8_out,
+                                 void *hip_stream);
+
 /* Average device time (ms) of the last `mnv_render_*` launches since the
  * previous call, measured with HIP events on the launch stream when
  * mnv_set_timing(1) is active; used by bench.py for roofline.achieved. */

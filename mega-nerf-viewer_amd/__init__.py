@@ -111,6 +111,10 @@ class Rect(C.Structure):
     _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
 
 
+class Partition(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("tile_w", C.c_int32), ("tile_h", C.c_int32)]
+
+
 class SynthRandomParams(C.Structure):
     _fields_ = [
         ("depth", C.c_int32),
@@ -156,6 +160,9 @@ _SIGNATURES = {
     "mnv_accel_device_bytes": (C.c_size_t, [C.c_void_p]),
     "mnv_render_voxels_accel": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mnv_partition_local_tiles": (C.c_int32, [Rect, Partition]),
+    "mnv_render_voxels_accel_part": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, Partition,
+                                               C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_set_timing": (None, [C.c_int]),
     "mnv_take_timing": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "mnv_n3tree_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -383,6 +390,20 @@ def render_voxels_accel(accel: int, cam: Camera, opt: RenderOptions, tile=None, 
         tile = (0, 0, cam.width, cam.height)
     _check(lib().mnv_render_voxels_accel(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba), _ptr(rgba8),
                                          C.c_void_p(stream)))
+
+
+def partition_local_tiles(tile, rank: int, world: int, tile_w: int, tile_h: int) -> int:
+    return int(lib().mnv_partition_local_tiles(Rect(*tile), Partition(rank, world, tile_w, tile_h)))
+
+
+def render_voxels_accel_part(accel: int, cam: Camera, opt: RenderOptions, rank: int, world: int, tile_w: int, tile_h: int,
+                             tile=None, rgba=None, rgba8=None, stream: int = 0) -> None:
+    """Render the macro tiles m % world == rank of `tile` into a compact local-tile-major buffer
+    [local_tiles][tile_h][tile_w][4] (see mnv_partition in include/mnv.h)."""
+    if tile is None:
+        tile = (0, 0, cam.width, cam.height)
+    _check(lib().mnv_render_voxels_accel_part(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile),
+                                              Partition(rank, world, tile_w, tile_h), _ptr(rgba), _ptr(rgba8), C.c_void_p(stream)))
 
 
 def set_timing(enable: bool) -> None:

@@ -115,7 +115,33 @@ struct AccelLaunch {
     uint32_t tiles_x, n_tiles;
     uint32_t band_begin[kNumQueues + 1];  // tile ranges per queue
     int32_t lds_level;                    // levels staged in LDS (<= A.grid_level)
+    // interleaved macro-tile partition (world <= 1: plain tile)
+    int32_t part_rank, part_world;
+    uint32_t macro_w, macro_h;            // macro tile size in pixels
+    uint32_t macros_x;                    // macro tiles per row of the rectangle
+    uint32_t micro_x, micro_per_macro;    // 8x8 micro tiles per macro-tile row / per macro tile
 };
+
+// ray id -> pixel of the rectangle (bx, by) and index of the pixel in the output buffer
+__device__ __forceinline__ bool ray_pixel(const AccelLaunch &K, uint32_t id, int &bx, int &by, int64_t &pix) {
+    const uint32_t tile = id >> 6, w = id & 63u;
+    if (K.part_world <= 1) {
+        const uint32_t tx = tile % K.tiles_x, ty = tile / K.tiles_x;
+        bx = (int)(tx * 8 + (w & 7u));
+        by = (int)(ty * 8 + (w >> 3));
+        pix = (int64_t)by * K.P.tw + bx;
+    } else {
+        const uint32_t j = tile / K.micro_per_macro, u = tile % K.micro_per_macro;
+        const uint32_t mx = u % K.micro_x, my = u / K.micro_x;
+        const uint32_t m = (uint32_t)K.part_rank + j * (uint32_t)K.part_world;
+        const uint32_t MX = m % K.macros_x, MY = m / K.macros_x;
+        const uint32_t lx = mx * 8 + (w & 7u), ly = my * 8 + (w >> 3);
+        bx = (int)(MX * K.macro_w + lx);
+        by = (int)(MY * K.macro_h + ly);
+        pix = ((int64_t)j * K.macro_h + ly) * K.macro_w + lx;
+    }
+    return bx < K.P.tw && by < K.P.th;
+}
 
 template <int BASIS, int ROW_BYTES>
 __device__ __forceinline__ void shade(const uint8_t *row, const float *basis, float weight, const uint64_t *s_exp,
@@ -211,11 +237,8 @@ __global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K)
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 const uint32_t id = base + rank;
                 if (id < end) {
-                    const uint32_t tile = id >> 6, w = id & 63u;
-                    const uint32_t tx = tile % K.tiles_x, ty = tile / K.tiles_x;
-                    const int bx = (int)(tx * 8 + (w & 7u)), by = (int)(ty * 8 + (w >> 3));
-                    if (bx < P.tw && by < P.th) {
-                        pix = (int64_t)by * P.tw + bx;
+                    int bx, by;
+                    if (ray_pixel(K, id, bx, by, pix)) {
                         setup_ray<(BASIS > 0 ? BASIS : 0)>(P, P.x0 + bx, P.y0 + by, r);
                         if constexpr (BASIS == 0)
                             r.basis[0] = (0 < P.basis_min || 0 > P.basis_max) ? 0.f : (float)0.28209479177387814;
@@ -363,16 +386,42 @@ static int launch_variant(const AccelLaunch &K, int n_blocks, size_t lds_bytes, 
     return (int)hipGetLastError();
 }
 
-int launch_accel(const mnv_accel *accel, MarchParams &P, hipStream_t stream) {
+int32_t partition_local_tiles(mnv_rect tile, mnv_partition part) {
+    if (tile.w <= 0 || tile.h <= 0 || part.world <= 1) return part.world <= 1 ? 1 : 0;
+    const int64_t mx = (tile.w + part.tile_w - 1) / part.tile_w, my = (tile.h + part.tile_h - 1) / part.tile_h;
+    const int64_t total = mx * my;
+    if (part.rank >= total) return 0;
+    return (int32_t)((total - part.rank + part.world - 1) / part.world);
+}
+
+int launch_accel(const mnv_accel *accel, MarchParams &P, mnv_partition part, hipStream_t stream) {
     if (P.tw <= 0 || P.th <= 0) return 0;
     AccelLaunch K;
+    std::memset(&K, 0, sizeof(K));
     K.P = P;
     K.A = accel->view;
-    K.tiles_x = (uint32_t)((P.tw + 7) / 8);
-    const uint32_t tiles_y = (uint32_t)((P.th + 7) / 8);
-    K.n_tiles = K.tiles_x * tiles_y;
-    // contiguous bands of tile rows per queue
-    for (int q = 0; q <= kNumQueues; ++q) K.band_begin[q] = (uint32_t)(((uint64_t)tiles_y * q) / kNumQueues) * K.tiles_x;
+    K.part_rank = part.rank;
+    K.part_world = part.world;
+    if (part.world <= 1) {
+        K.tiles_x = (uint32_t)((P.tw + 7) / 8);
+        const uint32_t tiles_y = (uint32_t)((P.th + 7) / 8);
+        K.n_tiles = K.tiles_x * tiles_y;
+        // contiguous bands of tile rows per queue
+        for (int q = 0; q <= kNumQueues; ++q) K.band_begin[q] = (uint32_t)(((uint64_t)tiles_y * q) / kNumQueues) * K.tiles_x;
+    } else {
+        const mnv_rect rect = {P.x0, P.y0, P.tw, P.th};
+        const uint32_t local = (uint32_t)partition_local_tiles(rect, part);
+        if (local == 0) return 0;
+        K.macro_w = (uint32_t)part.tile_w;
+        K.macro_h = (uint32_t)part.tile_h;
+        K.macros_x = (uint32_t)((P.tw + part.tile_w - 1) / part.tile_w);
+        K.micro_x = K.macro_w / 8;
+        K.micro_per_macro = K.micro_x * (K.macro_h / 8);
+        K.tiles_x = K.micro_x;
+        K.n_tiles = local * K.micro_per_macro;
+        // contiguous runs of micro tiles (in local macro-tile order) per queue
+        for (int q = 0; q <= kNumQueues; ++q) K.band_begin[q] = (uint32_t)(((uint64_t)K.n_tiles * q) / kNumQueues);
+    }
     static std::atomic<uint32_t> slot_counter{0};
     const uint32_t slot = slot_counter.fetch_add(1) % 64u;
     K.queue = accel->queue + slot * (kNumQueues * 16);
@@ -499,9 +548,21 @@ void mnv_accel_destroy(mnv_accel *a) {
 
 size_t mnv_accel_device_bytes(const mnv_accel *a) { return a ? a->bytes : 0; }
 
+int32_t mnv_partition_local_tiles(mnv_rect tile, mnv_partition part) { return partition_local_tiles(tile, part); }
+
 int mnv_render_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,
                             mnv_rect tile, float *rgba_out, uint8_t *rgba8_out, void *hip_stream) {
+    const mnv_partition whole = {0, 1, 0, 0};
+    return mnv_render_voxels_accel_part(accel, cam, opt, tile, whole, rgba_out, rgba8_out, hip_stream);
+}
+
+int mnv_render_voxels_accel_part(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,
+                                 mnv_rect tile, mnv_partition part, float *rgba_out, uint8_t *rgba8_out,
+                                 void *hip_stream) {
     if (!accel) return set_error(MNV_E_INVALID, "accel is null");
+    if (part.world > 1 && (part.rank < 0 || part.rank >= part.world || part.tile_w < 8 || part.tile_h < 8 ||
+                           part.tile_w % 8 || part.tile_h % 8))
+        return set_error(MNV_E_INVALID, "partition needs 0 <= rank < world and macro tiles that are multiples of 8 pixels");
     MarchParams P;
     std::memset(&P, 0, sizeof(P));
     int rc = fill_params(P, cam, opt, tile);
@@ -516,7 +577,7 @@ int mnv_render_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const
     P.rgba8 = rgba8_out;
     hipStream_t stream = (hipStream_t)hip_stream;
     LaunchTimer timer(stream);
-    rc = launch_accel(accel, P, stream);
+    rc = launch_accel(accel, P, part, stream);
     if (rc == -1000) return set_error(MNV_E_UNSUPPORTED, "unsupported basis_dim for the accel path");
     return check_hip((hipError_t)rc, "march_accel_kernel");
 }
