@@ -11,6 +11,7 @@
 //   grid  [2^L]^3 u32        dense top-of-tree lookup at level L = grid_level: the node
 //                            word of the depth-L voxel covering the cell, or the
 //                            (shallower) leaf word that covers it; staged in LDS
+//   grid_vox [2^L]^3 u32     voxel index of that covering leaf (read for dense samples only)
 // The in-leaf coordinates the march needs are frac(pos * 2^depth); x*2, floorf and
 // x - floorf(x) are exact in binary32 for x in [0,2), so any traversal that reaches the
 // same leaf reproduces the reference's iterated descent bit for bit.
@@ -31,6 +32,7 @@ struct AccelView {
     const uint32_t *nodes;
     const uint8_t *rows;
     const uint32_t *grid;
+    const uint32_t *grid_vox;  // [2^L]^3: voxel index (chunk*8+child) of the leaf covering a grid cell
     int32_t grid_level;
     int32_t row_bytes;
     float offset[3], scale[3];
@@ -44,6 +46,8 @@ struct mnv_accel {
     uint32_t *nodes = nullptr;
     uint8_t *rows = nullptr;
     uint32_t *grid = nullptr;
+    uint32_t *grid_vox = nullptr;
+    unsigned long long *stats = nullptr;  // MNV_STATS=1 diagnostics
     uint32_t *queue = nullptr;  // kNumQueues ray-queue heads (+ pad), reset per launch
     size_t bytes = 0;
     int device = 0;

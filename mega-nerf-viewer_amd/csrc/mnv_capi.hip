@@ -49,12 +49,10 @@ LaunchTimer::~LaunchTimer() {
 }
 
 // ---- argument block ----------------------------------------------------------------
-int fill_params(MarchParams &P, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile) {
+int fill_params(FrameParams &P, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile) {
     if (!cam || !opt) return set_error(MNV_E_INVALID, "camera/options pointer is null");
     if (cam->width <= 0 || cam->height <= 0) return set_error(MNV_E_INVALID, "camera has no pixels");
     if (tile.w < 0 || tile.h < 0) return set_error(MNV_E_INVALID, "negative tile extent");
-    P.width = cam->width;
-    P.height = cam->height;
     P.fx = cam->fx;
     P.fy = cam->fy;
     P.cx = cam->cx;
@@ -72,8 +70,6 @@ int fill_params(MarchParams &P, const mnv_camera *cam, const mnv_render_options 
     P.basis_min = opt->basis_minmax[0];
     P.basis_max = opt->basis_minmax[1];
     P.render_depth = opt->render_depth ? 1 : 0;
-    P.max_depth = opt->max_depth;
-    P.max_sample_count = opt->max_sample_count;
     // rodrigues(opt.rot_dirs, .) frame constants, reference renderer_kernel.cu:43-51
     const float *aa = opt->rot_dirs;
     const float angle = sqrtf(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2]);
@@ -111,14 +107,14 @@ static int fill_tree(MarchParams &P, const mnv_tree_view *t) {
     return MNV_OK;
 }
 
-__global__ void fill_background_kernel(const MarchParams P) {
+__global__ void fill_background_kernel(const FrameParams P) {
     // tree.N <= 0: "draw nothing" (renderer_kernel.cu:266-269) -> background only
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= (int64_t)P.tw * P.th) return;
     composite_and_write(P, p, 0.f, 0.f, 0.f, 0.f);
 }
 
-int launch_background(const MarchParams &P, hipStream_t stream) {
+int launch_background(const FrameParams &P, hipStream_t stream) {
     const int64_t n = (int64_t)P.tw * P.th;
     if (n <= 0) return 0;
     hipLaunchKernelGGL(fill_background_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, P);
@@ -180,12 +176,14 @@ int mnv_render_voxels(const mnv_tree_view *tree, const mnv_camera *cam, const mn
                       mnv_rect tile, float *rgba_out, uint8_t *rgba8_out, float *split_track,
                       float *sample_track, int32_t *visited, int track_visit, void *hip_stream) {
     MarchParams P;
-    std::memset(&P, 0, sizeof(P));
+    std::memset(static_cast<void *>(&P), 0, sizeof(P));
     int rc = fill_params(P, cam, opt, tile);
     if (rc) return rc;
     rc = fill_tree(P, tree);
     if (rc) return rc;
     if (track_visit && !visited) return set_error(MNV_E_INVALID, "track_visit set but visited is null");
+    P.max_depth = opt->max_depth;
+    P.max_sample_count = opt->max_sample_count;
     P.rgba = rgba_out;
     P.rgba8 = rgba8_out;
     P.split_track = split_track;

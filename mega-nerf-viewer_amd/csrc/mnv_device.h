@@ -16,26 +16,20 @@
 
 namespace mnv {
 
-// Kernel argument block: the by-value TreeSpec/CameraSpec/RenderOptions of the
-// reference launch (renderer_kernel.cu:431-436) flattened into one POD.
-struct MarchParams {
+// Per-frame part of the kernel argument block: the by-value CameraSpec / RenderOptions of the
+// reference launch (renderer_kernel.cu:431-436) plus the tree's offset/scale and the outputs.
+struct FrameParams {
     // camera (data_spec.hpp:9-23), c2w by value
-    int32_t width, height;
     float fx, fy, cx, cy;
     float c2w[12];
     // tile of the image rendered by this launch
     int32_t x0, y0, tw, th;
-    // tree, reference layout (data_spec.hpp:25-50)
-    const uint16_t *data;
-    const int32_t *child;
-    const int16_t *sample_counts;
     float offset[3], scale[3];
-    int32_t data_dim, basis_dim, format, capacity;
     // march-relevant RenderOptions (render_options.hpp:9-56)
     float step_size, sigma_thresh, stop_thresh, background_brightness;
     float render_bbox[6];
     int32_t basis_min, basis_max;
-    int32_t render_depth, max_depth, max_sample_count;
+    int32_t render_depth;
     // rodrigues(opt.rot_dirs) constants, precomputed on the host with libm
     // (renderer_kernel.cu:43-51): identity when rot_enabled == 0
     int32_t rot_enabled;
@@ -43,6 +37,16 @@ struct MarchParams {
     // outputs
     float *rgba;
     uint8_t *rgba8;
+};
+
+// Full argument block of the reference-layout kernel: + TreeSpec (data_spec.hpp:25-50) and
+// the refinement trackers.
+struct MarchParams : FrameParams {
+    const uint16_t *data;
+    const int32_t *child;
+    const int16_t *sample_counts;
+    int32_t data_dim, basis_dim, format, capacity;
+    int32_t max_depth, max_sample_count;
     float *split_track;
     float *sample_track;
     int32_t *visited;
@@ -164,7 +168,7 @@ struct RaySetup {
 // rt_core.cuh:182-209.  BASIS: number of SH basis functions kept in registers
 // (1 for DC-only / RGBA).
 template <int BASIS>
-__device__ __forceinline__ void setup_ray(const MarchParams &P, int ix, int iy,
+__device__ __forceinline__ void setup_ray(const FrameParams &P, int ix, int iy,
                                           RaySetup<(BASIS > 0 ? BASIS : 1)> &r) {
     const float xyz0 = (ix + 0.5f - P.cx) / P.fx;
     const float xyz1 = -(iy + 0.5f - P.cy) / P.fy;
@@ -269,7 +273,7 @@ __device__ __forceinline__ uint32_t pack_u8(float v) {
 }
 
 // renderer_kernel.cu:215-241 offscreen branch + the two output formats.
-__device__ __forceinline__ void composite_and_write(const MarchParams &P, int64_t p, float o0, float o1,
+__device__ __forceinline__ void composite_and_write(const FrameParams &P, int64_t p, float o0, float o1,
                                                     float o2, float o3) {
     const float nalpha = 1.f - o3;
     const float remain = P.background_brightness * nalpha;

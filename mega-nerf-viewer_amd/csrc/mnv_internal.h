@@ -15,10 +15,10 @@ namespace mnv {
 int check_hip(hipError_t e, const char *what);
 
 // Fill the camera / option / rodrigues part of the kernel argument block.
-int fill_params(MarchParams &P, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile);
+int fill_params(FrameParams &P, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile);
 
 int launch_ref_layout(const MarchParams &P, hipStream_t stream);
-int launch_background(const MarchParams &P, hipStream_t stream);
+int launch_background(const FrameParams &P, hipStream_t stream);
 
 // event-based timing of the render launches (mnv_set_timing / mnv_take_timing)
 struct LaunchTimer {

@@ -21,6 +21,7 @@
 // MFMA is not used: the inner step is pointer chasing plus a <= 75-term dot in a fixed
 // summation order (DESIGN.md "Why no MFMA").
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -88,48 +89,52 @@ __global__ void accel_pack_rows(const uint16_t *data, uint8_t *rows, int64_t nvo
 }
 
 // grid[(ix*G + iy)*G + iz] = word of the voxel of depth <= L that covers cell (ix,iy,iz)
-__global__ void accel_build_grid(const uint32_t *nodes, uint32_t *grid, int32_t L) {
+__global__ void accel_build_grid(const uint32_t *nodes, uint32_t *grid, uint32_t *grid_vox, int32_t L) {
     const int32_t G = 1 << L;
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= G * G * G) return;
     const int32_t iz = i & (G - 1), iy = (i >> L) & (G - 1), ix = i >> (2 * L);
-    uint32_t chunk = 0, word = 0;
+    uint32_t chunk = 0, word = 0, vox = 0;
     for (int32_t l = 1; l <= L; ++l) {
         const int32_t s = L - l;
         const int32_t cidx = (((ix >> s) & 1) << 2) | (((iy >> s) & 1) << 1) | ((iz >> s) & 1);
-        word = nodes[(int64_t)chunk * 8 + cidx];
+        vox = chunk * 8u + (uint32_t)cidx;
+        word = nodes[vox];
         if (word & kLeafBit) break;
         chunk = word;
     }
     grid[i] = word;
+    grid_vox[i] = vox;  // voxel index of the covering leaf (meaningful when `word` is a leaf)
 }
 
 // ------------------------------------------------------------------------ march kernel
 
-constexpr int kRefillMin = 16;  // refill a wavefront once this many lanes are idle
-
 struct AccelLaunch {
-    MarchParams P;   // camera, tile, options, outputs (tree pointers unused)
+    FrameParams P;   // camera, tile, options, outputs
     AccelView A;
     uint32_t *queue; // kNumQueues heads
     uint32_t tiles_x, n_tiles;
     uint32_t band_begin[kNumQueues + 1];  // tile ranges per queue
     int32_t lds_level;                    // levels staged in LDS (<= A.grid_level)
+    int32_t refill_min;                   // refill a wavefront once this many lanes are idle
+    int32_t dense_min;                    // run the dense-sample phase once this many lanes wait in it
     // interleaved macro-tile partition (world <= 1: plain tile)
     int32_t part_rank, part_world;
     uint32_t macro_w, macro_h;            // macro tile size in pixels
     uint32_t macros_x;                    // macro tiles per row of the rectangle
     uint32_t micro_x, micro_per_macro;    // 8x8 micro tiles per macro-tile row / per macro tile
+    unsigned long long *stats;            // STATS builds only: 16 counters
+    int32_t ablate;                       // diagnostics only (breaks results): 1 no colour, 2 no dense samples
 };
 
 // ray id -> pixel of the rectangle (bx, by) and index of the pixel in the output buffer
-__device__ __forceinline__ bool ray_pixel(const AccelLaunch &K, uint32_t id, int &bx, int &by, int64_t &pix) {
+__device__ __forceinline__ bool ray_pixel(const AccelLaunch &K, uint32_t id, int &bx, int &by, uint32_t &pix) {
     const uint32_t tile = id >> 6, w = id & 63u;
     if (K.part_world <= 1) {
         const uint32_t tx = tile % K.tiles_x, ty = tile / K.tiles_x;
         bx = (int)(tx * 8 + (w & 7u));
         by = (int)(ty * 8 + (w >> 3));
-        pix = (int64_t)by * K.P.tw + bx;
+        pix = (uint32_t)by * (uint32_t)K.P.tw + (uint32_t)bx;
     } else {
         const uint32_t j = tile / K.micro_per_macro, u = tile % K.micro_per_macro;
         const uint32_t mx = u % K.micro_x, my = u / K.micro_x;
@@ -138,7 +143,7 @@ __device__ __forceinline__ bool ray_pixel(const AccelLaunch &K, uint32_t id, int
         const uint32_t lx = mx * 8 + (w & 7u), ly = my * 8 + (w >> 3);
         bx = (int)(MX * K.macro_w + lx);
         by = (int)(MY * K.macro_h + ly);
-        pix = ((int64_t)j * K.macro_h + ly) * K.macro_w + lx;
+        pix = (j * K.macro_h + ly) * K.macro_w + lx;
     }
     return bx < K.P.tw && by < K.P.th;
 }
@@ -171,12 +176,19 @@ __device__ __forceinline__ void shade(const uint8_t *row, const float *basis, fl
     }
 }
 
-template <int BASIS, int ROW_BYTES, int BLOCK>
+// BATCH_DENSE : lanes that reach a dense leaf (sigma > sigma_thresh) park until `dense_min`
+//               lanes of the wavefront are parked, then the expensive opacity + SH colour code
+//               runs once for all of them (it is ~4x the cost of a march step and would
+//               otherwise execute for a handful of lanes at a time).
+// PARENT_CACHE: each lane remembers the chunk that held its last deep leaf; if the next sample
+//               point falls into the same chunk the descent restarts there (1 load) instead of
+//               at the LDS grid (up to depth - lds_level loads).
+template <int BASIS, int ROW_BYTES, int BLOCK, bool BATCH_DENSE, bool PARENT_CACHE, bool STATS>
 __global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     uint64_t *s_exp = reinterpret_cast<uint64_t *>(s_mem);  // 32 x 8 B
     uint32_t *s_grid = s_mem + 64;                           // (2^lds_level)^3 words
-    const MarchParams &P = K.P;
+    const FrameParams &P = K.P;
     const AccelView &A = K.A;
 
     const int LL = K.lds_level;
@@ -185,9 +197,7 @@ __global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K)
     if (LL == A.grid_level) {
         for (int i = threadIdx.x; i < cells; i += BLOCK) s_grid[i] = A.grid[i];
     } else {
-        // coarser LDS grid sampled from the device grid: a cell of level LL is covered by the
-        // word of its first level-grid_level sub-cell only if that word is a leaf of depth <= LL;
-        // otherwise walk down from the root as the builder does
+        // coarser LDS grid: walk the top LL levels as the builder does
         for (int i = threadIdx.x; i < cells; i += BLOCK) {
             const int G = 1 << LL;
             const int iz = i & (G - 1), iy = (i >> LL) & (G - 1), ix = i >> (2 * LL);
@@ -211,18 +221,66 @@ __global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K)
     // per-lane ray state
     RaySetup<NB> r;
     float t = 0.f, T = 1.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
-    int64_t pix = 0;
+    uint32_t pix = 0;
     bool alive = false;
+    // parked dense sample
+    bool parked = false;
+    float p_dt = 0.f;
+    uint32_t p_word = 0, p_vox = 0;
+    // parent-chunk cache: chunk `pc_chunk` holds voxels of depth `pc_depth` (0 = invalid) and
+    // covers the cube floor(pos * 2^(pc_depth-1)) == (pc_x, pc_y, pc_z)
+    uint32_t pc_chunk = 0;
+    int pc_depth = 0;
+    float pc_x = 0.f, pc_y = 0.f, pc_z = 0.f;
 
     // ray queues: home queue first, then steal round robin
     const uint32_t home = blockIdx.x % kNumQueues;
-    uint32_t qsel = 0;            // queues tried so far (wave-uniform)
-    bool exhausted = false;       // all queues empty (wave-uniform)
+    uint32_t qsel = 0;       // queues tried so far (wave-uniform)
+    bool exhausted = false;  // all queues empty (wave-uniform)
+
+    auto finish_ray = [&](float a) {
+        composite_and_write(P, (int64_t)pix, o0, o1, o2, a);
+        alive = false;
+    };
+
+    // opacity + colour of one dense sample (rt_core.cuh:233-307); returns true when the ray ended
+    auto dense_sample = [&](float delta_t, uint32_t word, uint32_t vox) {
+        const float sigma = half_bits_to_float((uint16_t)word);
+        const float att = exact_expf(-delta_t * r.delta_scale * sigma, s_exp);
+        const float weight = T * (1.f - att);
+        if (P.render_depth) {
+            o0 += weight * t;
+        } else if (!(K.ablate & 1)) {
+            shade<BASIS, ROW_BYTES>(A.rows + (int64_t)vox * ROW_BYTES, r.basis, weight, s_exp, o0, o1, o2);
+        }
+        T *= att;
+        if (T < P.stop_thresh) {
+            if (P.render_depth) o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
+            const float s = 1.f / (1.f - T);
+            o0 *= s;
+            o1 *= s;
+            o2 *= s;
+            finish_ray(1.f);
+        } else {
+            t += delta_t;
+        }
+    };
+
+    auto stat = [&](int slot, bool pred) {
+        if constexpr (STATS) {
+            const uint64_t m = __ballot(pred);
+            if (m && lane == (int)__builtin_ctzll(m)) {
+                atomicAdd(&K.stats[slot], 1ull);
+                atomicAdd(&K.stats[slot + 1], (unsigned long long)__popcll(m));
+            }
+        }
+    };
 
     for (;;) {
         const uint64_t idle = __ballot(!alive);
         const int n_idle = __popcll(idle);
-        if (!exhausted && n_idle >= kRefillMin) {
+        stat(0, true);
+        if (!exhausted && n_idle >= K.refill_min) {
             // ---- refill idle lanes from the ray queues
             const uint32_t q = (home + qsel) % kNumQueues;
             const uint32_t begin = K.band_begin[q] * 64u, end = K.band_begin[q + 1] * 64u;
@@ -238,71 +296,114 @@ __global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K)
                 const uint32_t id = base + rank;
                 if (id < end) {
                     int bx, by;
+                    stat(2, true);
                     if (ray_pixel(K, id, bx, by, pix)) {
                         setup_ray<(BASIS > 0 ? BASIS : 0)>(P, P.x0 + bx, P.y0 + by, r);
                         if constexpr (BASIS == 0)
                             r.basis[0] = (0 < P.basis_min || 0 > P.basis_max) ? 0.f : (float)0.28209479177387814;
+                        o0 = o1 = o2 = 0.f;
                         if (r.in_bbox) {
                             alive = true;
+                            parked = false;
                             t = r.tmin;
                             T = 1.f;
-                            o0 = o1 = o2 = 0.f;
+                            pc_depth = 0;
                         } else {
-                            composite_and_write(P, pix, 0.f, 0.f, 0.f, P.render_depth ? 1.f : 0.f);
+                            composite_and_write(P, (int64_t)pix, 0.f, 0.f, 0.f, P.render_depth ? 1.f : 0.f);
                         }
                     }
                 }
             }
         }
-        if (__ballot(alive) == 0) {
+        const uint64_t alive_mask = __ballot(alive);
+        if (alive_mask == 0) {
             if (exhausted) break;
             continue;
         }
-        if (alive) {
+        if constexpr (BATCH_DENSE) {
+            const uint64_t parked_mask = __ballot(parked);
+            const int n_parked = __popcll(parked_mask);
+            if (n_parked >= K.dense_min || (n_parked > 0 && parked_mask == alive_mask)) {
+                if (parked) {
+                    stat(8, true);
+                    parked = false;
+                    dense_sample(p_dt, p_word, p_vox);
+                }
+                continue;
+            }
+        }
+        if (alive && !parked) {
             // ---- one march step (rt_core.cuh:220-323)
-            bool done = false;
-            float o3 = 0.f;
-            if (t < r.tmax) {
+            if (!(t < r.tmax)) {
+                // loop exit, rt_core.cuh:325-330
+                if (P.render_depth) {
+                    o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
+                    finish_ray(1.f);
+                } else {
+                    finish_ray(1.f - T);
+                }
+            } else {
+                stat(4, true);
                 float pos[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     pos[i] = r.cen[i] + t * r.dir[i];
                     pos[i] = fmaxf(fminf(pos[i], 1.f - 1e-6f), 0.f);
                 }
-                // top of the tree: LDS grid at level LL
-                const float qx = pos[0] * grid_scale, qy = pos[1] * grid_scale, qz = pos[2] * grid_scale;
-                const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
-                uint32_t word = s_grid[(((((int)fx << LL) + (int)fy)) << LL) + (int)fz];
                 float x[3];
-                int depth;
-                uint32_t vox = 0;  // chunk*8 + child of the leaf (valid when found below the grid)
-                if (word & kLeafBit) {
-                    depth = (int)((word >> 16) & 0x7fu);
-                    // frac(pos * 2^depth): exact
-                    const float sc = __uint_as_float((uint32_t)(127 + depth) << 23);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        const float pd = pos[i] * sc;
-                        x[i] = pd - floorf(pd);
-                    }
-                    // leaf above the grid level: its voxel index is needed only for a dense sample;
-                    // recover it by walking the (L2-resident) top levels
-                    if (half_bits_to_float((uint16_t)word) > P.sigma_thresh) {
-                        uint32_t chunk = 0;
-                        for (int l = 1;; ++l) {
-                            const float s2 = __uint_as_float((uint32_t)(127 + l) << 23);
-                            const int cx = (int)floorf(pos[0] * s2) & 1, cy = (int)floorf(pos[1] * s2) & 1, cz = (int)floorf(pos[2] * s2) & 1;
-                            vox = chunk * 8u + (uint32_t)((cx << 2) | (cy << 1) | cz);
-                            if (l == depth) break;
-                            chunk = A.nodes[vox];
+                int depth = 0;
+                uint32_t word = 0, vox = 0;
+                bool descend = false;
+                if constexpr (PARENT_CACHE) {
+                    if (pc_depth > 0) {
+                        const float sc = __uint_as_float((uint32_t)(126 + pc_depth) << 23);  // 2^(pc_depth-1)
+                        const float px = pos[0] * sc, py = pos[1] * sc, pz = pos[2] * sc;
+                        const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+                        if (fx == pc_x && fy == pc_y && fz == pc_z) {
+                            x[0] = px - fx;
+                            x[1] = py - fy;
+                            x[2] = pz - fz;
+                            word = pc_chunk;
+                            depth = pc_depth - 1;
+                            descend = true;
                         }
                     }
-                } else {
-                    depth = LL;
-                    x[0] = qx - fx;
-                    x[1] = qy - fy;
-                    x[2] = qz - fz;
+                }
+                if (!descend) {
+                    // top of the tree: LDS grid at level LL
+                    const float qx = pos[0] * grid_scale, qy = pos[1] * grid_scale, qz = pos[2] * grid_scale;
+                    const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
+                    word = s_grid[(((((int)fx << LL) + (int)fy)) << LL) + (int)fz];
+                    if (word & kLeafBit) {
+                        depth = (int)((word >> 16) & 0x7fu);
+                        // frac(pos * 2^depth): exact
+                        const float sc = __uint_as_float((uint32_t)(127 + depth) << 23);
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            const float pd = pos[i] * sc;
+                            x[i] = pd - floorf(pd);
+                        }
+                        // leaf at or above the LDS level: its voxel index (needed only for a dense
+                        // sample) comes from the level-grid_level index array
+                        if (half_bits_to_float((uint16_t)word) > P.sigma_thresh) {
+                            const float gs = (float)(1 << A.grid_level);
+                            const int gl = A.grid_level;
+                            const int gi = ((((int)floorf(pos[0] * gs) << gl) + (int)floorf(pos[1] * gs)) << gl) + (int)floorf(pos[2] * gs);
+                            vox = A.grid_vox[gi];
+                        }
+                        if constexpr (PARENT_CACHE) pc_depth = 0;
+                    } else {
+                        depth = LL;
+                        x[0] = qx - fx;
+                        x[1] = qy - fy;
+                        x[2] = qz - fz;
+                        descend = true;
+                    }
+                }
+                if (descend) {
+                    uint32_t chunk;
                     do {
+                        stat(6, true);
                         int cidx = 0;
 #pragma unroll
                         for (int i = 0; i < 3; ++i) {
@@ -311,10 +412,23 @@ __global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K)
                             cidx = cidx * 2 + (int)f;
                             x[i] -= f;
                         }
-                        vox = word * 8u + (uint32_t)cidx;
+                        chunk = word;
+                        vox = chunk * 8u + (uint32_t)cidx;
                         word = A.nodes[vox];
                         ++depth;
                     } while (!(word & kLeafBit));
+                    if constexpr (PARENT_CACHE) {
+                        if (depth > LL + 1) {  // worth caching only below the LDS grid
+                            const float sc = __uint_as_float((uint32_t)(126 + depth) << 23);
+                            pc_x = floorf(pos[0] * sc);
+                            pc_y = floorf(pos[1] * sc);
+                            pc_z = floorf(pos[2] * sc);
+                            pc_chunk = chunk;
+                            pc_depth = depth;
+                        } else {
+                            pc_depth = 0;
+                        }
+                    }
                 }
                 // _dda_unit, rt_core.cuh:88-100
                 float tu = 1e4f;
@@ -326,40 +440,19 @@ __global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K)
                 }
                 const float inv_cube = __uint_as_float((uint32_t)(127 - depth) << 23);  // 2^-depth
                 const float delta_t = tu * inv_cube + P.step_size;
-                const float sigma = half_bits_to_float((uint16_t)word);
-                if (sigma > P.sigma_thresh) {
-                    const float att = exact_expf(-delta_t * r.delta_scale * sigma, s_exp);
-                    const float weight = T * (1.f - att);
-                    if (P.render_depth) {
-                        o0 += weight * t;
+                if (half_bits_to_float((uint16_t)word) > P.sigma_thresh && !(K.ablate & 2)) {
+                    if constexpr (BATCH_DENSE) {
+                        parked = true;
+                        p_dt = delta_t;
+                        p_word = word;
+                        p_vox = vox;
                     } else {
-                        shade<BASIS, ROW_BYTES>(A.rows + (int64_t)vox * ROW_BYTES, r.basis, weight, s_exp, o0, o1, o2);
+                        stat(8, true);
+                        dense_sample(delta_t, word, vox);
                     }
-                    T *= att;
-                    if (T < P.stop_thresh) {
-                        if (P.render_depth) o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
-                        const float s = 1.f / (1.f - T);
-                        o0 *= s;
-                        o1 *= s;
-                        o2 *= s;
-                        o3 = 1.f;
-                        done = true;
-                    }
-                }
-                t += delta_t;
-            }
-            if (!done && !(t < r.tmax)) {
-                if (P.render_depth) {
-                    o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
-                    o3 = 1.f;
                 } else {
-                    o3 = 1.f - T;
+                    t += delta_t;
                 }
-                done = true;
-            }
-            if (done) {
-                composite_and_write(P, pix, o0, o1, o2, o3);
-                alive = false;
             }
         }
     }
@@ -372,10 +465,10 @@ static int row_bytes_for(int data_dim) {
     return ((b + 15) / 16) * 16;
 }
 
-template <int BASIS, int ROW_BYTES>
-static int launch_variant(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
+template <int BASIS, int ROW_BYTES, bool BD, bool PC, bool ST = false>
+static int launch_variant2(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
     constexpr int BLOCK = 256;
-    auto kern = march_accel_kernel<BASIS, ROW_BYTES, BLOCK>;
+    auto kern = march_accel_kernel<BASIS, ROW_BYTES, BLOCK, BD, PC, ST>;
     static thread_local size_t configured = 0;
     if (lds_bytes > 65536 && configured < lds_bytes) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -386,6 +479,21 @@ static int launch_variant(const AccelLaunch &K, int n_blocks, size_t lds_bytes, 
     return (int)hipGetLastError();
 }
 
+// MNV_VARIANT (ablation only): bit 0 = batched dense phase, bit 1 = parent-chunk cache; default 3
+template <int BASIS, int ROW_BYTES>
+static int launch_variant(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
+    static const int variant = getenv("MNV_VARIANT") ? atoi(getenv("MNV_VARIANT")) : 0;
+    if constexpr (BASIS == 9) {
+        if (K.stats) return launch_variant2<BASIS, ROW_BYTES, false, false, true>(K, n_blocks, lds_bytes, stream);
+    }
+    switch (variant & 3) {
+        case 0: return launch_variant2<BASIS, ROW_BYTES, false, false>(K, n_blocks, lds_bytes, stream);
+        case 1: return launch_variant2<BASIS, ROW_BYTES, true, false>(K, n_blocks, lds_bytes, stream);
+        case 2: return launch_variant2<BASIS, ROW_BYTES, false, true>(K, n_blocks, lds_bytes, stream);
+        default: return launch_variant2<BASIS, ROW_BYTES, true, true>(K, n_blocks, lds_bytes, stream);
+    }
+}
+
 int32_t partition_local_tiles(mnv_rect tile, mnv_partition part) {
     if (tile.w <= 0 || tile.h <= 0 || part.world <= 1) return part.world <= 1 ? 1 : 0;
     const int64_t mx = (tile.w + part.tile_w - 1) / part.tile_w, my = (tile.h + part.tile_h - 1) / part.tile_h;
@@ -394,10 +502,10 @@ int32_t partition_local_tiles(mnv_rect tile, mnv_partition part) {
     return (int32_t)((total - part.rank + part.world - 1) / part.world);
 }
 
-int launch_accel(const mnv_accel *accel, MarchParams &P, mnv_partition part, hipStream_t stream) {
+int launch_accel(const mnv_accel *accel, const FrameParams &P, mnv_partition part, hipStream_t stream) {
     if (P.tw <= 0 || P.th <= 0) return 0;
     AccelLaunch K;
-    std::memset(&K, 0, sizeof(K));
+    std::memset(static_cast<void *>(&K), 0, sizeof(K));
     K.P = P;
     K.A = accel->view;
     K.part_rank = part.rank;
@@ -434,7 +542,15 @@ int launch_accel(const mnv_accel *accel, MarchParams &P, mnv_partition part, hip
     K.lds_level = lds_level;
     const size_t lds_bytes = 256 + ((size_t)4 << (3 * lds_level));
     const int env_bpc = getenv("MNV_BLOCKS_PER_CU") ? atoi(getenv("MNV_BLOCKS_PER_CU")) : 0;
-    int blocks_per_cu = lds_level >= 5 ? 1 : 8;
+    static const int env_refill = getenv("MNV_REFILL_MIN") ? atoi(getenv("MNV_REFILL_MIN")) : 0;
+    static const int env_dense = getenv("MNV_DENSE_MIN") ? atoi(getenv("MNV_DENSE_MIN")) : 0;
+    static const int env_ablate = getenv("MNV_ABLATE") ? atoi(getenv("MNV_ABLATE")) : 0;
+    K.ablate = env_ablate;
+    static const bool env_stats = getenv("MNV_STATS") != nullptr;
+    K.stats = env_stats ? accel->stats : nullptr;
+    K.refill_min = env_refill > 0 ? env_refill : 16;
+    K.dense_min = env_dense > 0 ? env_dense : 24;
+    int blocks_per_cu = lds_level >= 5 ? 1 : 6;
     if (env_bpc > 0) blocks_per_cu = env_bpc;
     int n_blocks = accel->num_cus * blocks_per_cu;
     const uint32_t n_waves_needed = K.n_tiles;  // one initial 8x8 tile per wave
@@ -490,6 +606,8 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
     if ((rc = check_hip(hipMalloc((void **)&depth, cap * 4), "hipMalloc(depth)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&changed, 4), "hipMalloc(flag)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&a->queue, 64 * kNumQueues * 16 * sizeof(uint32_t)), "hipMalloc(queue)"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&a->stats, 16 * sizeof(unsigned long long)), "hipMalloc(stats)"))) return fail(rc);
+    if ((rc = check_hip(hipMemsetAsync(a->stats, 0, 16 * sizeof(unsigned long long), stream), "memset stats"))) return fail(rc);
 
     // chunk depths: root chunk holds depth-1 voxels
     if ((rc = check_hip(hipMemsetAsync(depth, 0, cap * 4, stream), "memset depth"))) return fail(rc);
@@ -512,7 +630,8 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
     int L = max_depth < kMaxGridLevel ? max_depth : kMaxGridLevel;
     const int64_t gcells = (int64_t)1 << (3 * L);
     if ((rc = check_hip(hipMalloc((void **)&a->grid, gcells * 4), "hipMalloc(grid)"))) return fail(rc);
-    hipLaunchKernelGGL(accel_build_grid, dim3((unsigned)((gcells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid, L);
+    if ((rc = check_hip(hipMalloc((void **)&a->grid_vox, gcells * 4), "hipMalloc(grid_vox)"))) return fail(rc);
+    hipLaunchKernelGGL(accel_build_grid, dim3((unsigned)((gcells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid, a->grid_vox, L);
     if ((rc = check_hip(hipGetLastError(), "accel build launch"))) return fail(rc);
     if ((rc = check_hip(hipStreamSynchronize(stream), "accel build"))) return fail(rc);
     (void)hipFree(depth);
@@ -522,6 +641,7 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
     a->view.nodes = a->nodes;
     a->view.rows = a->rows;
     a->view.grid = a->grid;
+    a->view.grid_vox = a->grid_vox;
     a->view.grid_level = L;
     a->view.row_bytes = row_bytes;
     for (int i = 0; i < 3; ++i) {
@@ -532,16 +652,27 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
     a->view.basis_dim = t->basis_dim;
     a->view.format = t->format;
     a->view.capacity = t->capacity;
-    a->bytes = (size_t)(nvox * 4 + nvox * row_bytes + gcells * 4);
+    a->bytes = (size_t)(nvox * 4 + nvox * row_bytes + gcells * 8);
     *out = a;
     return MNV_OK;
 }
 
 void mnv_accel_destroy(mnv_accel *a) {
     if (!a) return;
+    if (a->stats && getenv("MNV_STATS")) {
+        unsigned long long h[16];
+        if (hipMemcpy(h, a->stats, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            const char *names[] = {"outer_iter", "refill", "march_step", "descent_trip", "dense"};
+            for (int i = 0; i < 5; ++i)
+                fprintf(stderr, "[mnv stats] %-13s wave-level %llu lane-level %llu (%.1f lanes)\n", names[i], h[2 * i], h[2 * i + 1],
+                        h[2 * i] ? (double)h[2 * i + 1] / (double)h[2 * i] : 0.0);
+        }
+    }
+    if (a->stats) (void)hipFree(a->stats);
     if (a->nodes) (void)hipFree(a->nodes);
     if (a->rows) (void)hipFree(a->rows);
     if (a->grid) (void)hipFree(a->grid);
+    if (a->grid_vox) (void)hipFree(a->grid_vox);
     if (a->queue) (void)hipFree(a->queue);
     delete a;
 }
@@ -563,16 +694,12 @@ int mnv_render_voxels_accel_part(const mnv_accel *accel, const mnv_camera *cam, 
     if (part.world > 1 && (part.rank < 0 || part.rank >= part.world || part.tile_w < 8 || part.tile_h < 8 ||
                            part.tile_w % 8 || part.tile_h % 8))
         return set_error(MNV_E_INVALID, "partition needs 0 <= rank < world and macro tiles that are multiples of 8 pixels");
-    MarchParams P;
+    FrameParams P;
     std::memset(&P, 0, sizeof(P));
     int rc = fill_params(P, cam, opt, tile);
     if (rc) return rc;
     std::memcpy(P.offset, accel->view.offset, sizeof(P.offset));
     std::memcpy(P.scale, accel->view.scale, sizeof(P.scale));
-    P.data_dim = accel->view.data_dim;
-    P.basis_dim = accel->view.basis_dim;
-    P.format = accel->view.format;
-    P.capacity = accel->view.capacity;
     P.rgba = rgba_out;
     P.rgba8 = rgba8_out;
     hipStream_t stream = (hipStream_t)hip_stream;
