@@ -12,6 +12,9 @@
 //                            word of the depth-L voxel covering the cell, or the
 //                            (shallower) leaf word that covers it; staged in LDS
 //   grid_vox [2^L]^3 u32     voxel index of that covering leaf (read for dense samples only)
+//   grid2 / grid2_vox [2^L2]^3 u32   the same two arrays at level L2 = min(max_depth-1, 8), in
+//                            4x4x4-cell brick order; a step below the LDS grid costs one load
+//                            here plus one node load per level below L2
 // The in-leaf coordinates the march needs are frac(pos * 2^depth); x*2, floorf and
 // x - floorf(x) are exact in binary32 for x in [0,2), so any traversal that reaches the
 // same leaf reproduces the reference's iterated descent bit for bit.
@@ -27,6 +30,7 @@ namespace mnv {
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr int kMaxGridLevel = 5;  // 32^3 * 4 B = 128 KiB of the CU's 160 KiB LDS
 constexpr int kNumQueues = 8;     // one ray queue per XCD
+constexpr int kMaxGrid2Level = 8;  // 8^8 * 4 B = 64 MiB per array (MNV_GRID2_LEVEL=9 allowed for experiments)
 
 struct AccelView {
     const uint32_t *nodes;
@@ -34,6 +38,10 @@ struct AccelView {
     const uint32_t *grid;
     const uint32_t *grid_vox;  // [2^L]^3: voxel index (chunk*8+child) of the leaf covering a grid cell
     int32_t grid_level;
+    const uint32_t *grid2;      // [2^L2]^3 brick-ordered second lookup grid (NULL when grid2_level == 0)
+    const uint32_t *grid2_vox;
+    int32_t grid2_level;
+    int32_t max_depth;          // deepest voxel depth of the tree (<= 23)
     int32_t row_bytes;
     float offset[3], scale[3];
     int32_t data_dim, basis_dim, format, capacity;
@@ -47,6 +55,8 @@ struct mnv_accel {
     uint8_t *rows = nullptr;
     uint32_t *grid = nullptr;
     uint32_t *grid_vox = nullptr;
+    uint32_t *grid2 = nullptr;
+    uint32_t *grid2_vox = nullptr;
     unsigned long long *stats = nullptr;  // MNV_STATS=1 diagnostics
     uint32_t *queue = nullptr;  // kNumQueues ray-queue heads (+ pad), reset per launch
     size_t bytes = 0;

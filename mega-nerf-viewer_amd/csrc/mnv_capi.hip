@@ -85,6 +85,15 @@ int fill_params(FrameParams &P, const mnv_camera *cam, const mnv_render_options 
     return MNV_OK;
 }
 
+// renderer_kernel.cu:272-275: cen = offset + scale * c2w[9..11]; identical for every ray, so it is
+// computed once on the host (this file is compiled with -ffp-contract=off: mul then add).
+void fill_origin(FrameParams &P) {
+    for (int i = 0; i < 3; ++i) {
+        const float prod = P.scale[i] * P.c2w[9 + i];
+        P.cen[i] = P.offset[i] + prod;
+    }
+}
+
 static int fill_tree(MarchParams &P, const mnv_tree_view *t) {
     if (!t) return set_error(MNV_E_INVALID, "tree view is null");
     if (t->N != 2 && t->N > 0)
@@ -100,6 +109,7 @@ static int fill_tree(MarchParams &P, const mnv_tree_view *t) {
     P.sample_counts = t->sample_counts;
     std::memcpy(P.offset, t->offset, sizeof(P.offset));
     std::memcpy(P.scale, t->scale, sizeof(P.scale));
+    fill_origin(P);
     P.data_dim = t->data_dim;
     P.basis_dim = t->basis_dim;
     P.format = t->format;

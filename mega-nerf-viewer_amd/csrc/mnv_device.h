@@ -25,6 +25,7 @@ struct FrameParams {
     // tile of the image rendered by this launch
     int32_t x0, y0, tw, th;
     float offset[3], scale[3];
+    float cen[3];  // tree-space ray origin offset + scale * c2w[9..11] (renderer_kernel.cu:272-275), same for every ray
     // march-relevant RenderOptions (render_options.hpp:9-56)
     float step_size, sigma_thresh, stop_thresh, background_brightness;
     float render_bbox[6];
@@ -157,7 +158,6 @@ template <int NB>
 struct RaySetup {
     float dir[3];     // tree-space unit direction (after _get_delta_scale)
     float invdir[3];  // rt_core.cuh:189
-    float cen[3];     // tree-space origin
     float basis[NB];  // SH basis of the (rotated) view direction, minmax-masked
     float delta_scale;
     float tmin, tmax;
@@ -182,8 +182,6 @@ __device__ __forceinline__ void setup_ray(const FrameParams &P, int ix, int iy,
     dir[0] *= invnorm;
     dir[1] *= invnorm;
     dir[2] *= invnorm;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) r.cen[i] = P.offset[i] + P.scale[i] * m[9 + i];
 
     float vdir[3] = {dir[0], dir[1], dir[2]};
     if (P.rot_enabled) {  // renderer_kernel.cu:52-60
@@ -217,8 +215,8 @@ __device__ __forceinline__ void setup_ray(const FrameParams &P, int ix, int iy,
         r.dir[i] = dir[i];
         r.invdir[i] = (float)(1.0 / ((double)dir[i] + 1e-9));  // :189
         const double inv = (double)r.invdir[i];
-        const float t1 = (float)(((double)P.render_bbox[i] + 1e-6 - (double)r.cen[i]) * inv);
-        const float t2 = (float)(((double)P.render_bbox[i + 3] - 1e-6 - (double)r.cen[i]) * inv);
+        const float t1 = (float)(((double)P.render_bbox[i] + 1e-6 - (double)P.cen[i]) * inv);
+        const float t2 = (float)(((double)P.render_bbox[i + 3] - 1e-6 - (double)P.cen[i]) * inv);
         tmin = fmaxf(tmin, fminf(t1, t2));
         tmax = fminf(tmax, fmaxf(t1, t2));
     }

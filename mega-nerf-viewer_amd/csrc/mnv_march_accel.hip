@@ -107,6 +107,34 @@ __global__ void accel_build_grid(const uint32_t *nodes, uint32_t *grid, uint32_t
     grid_vox[i] = vox;  // voxel index of the covering leaf (meaningful when `word` is a leaf)
 }
 
+// Brick-ordered index of cell (cx,cy,cz) of the level-L2 grid: 4x4x4-cell bricks (256 B) in
+// row-major brick order, so that the cells neighbouring rays touch share cache lines.
+__host__ __device__ __forceinline__ uint32_t grid2_index(uint32_t cx, uint32_t cy, uint32_t cz, int L2) {
+    const int LB = L2 - 2;
+    const uint32_t brick = (((((cx >> 2) << LB) + (cy >> 2))) << LB) + (cz >> 2);
+    return (brick << 6) | ((cx & 3u) << 4) | ((cy & 3u) << 2) | (cz & 3u);
+}
+
+// grid2[grid2_index(c)] = word of the voxel of depth <= L2 covering cell c, grid2_vox = its voxel index
+__global__ void accel_build_grid2(const uint32_t *nodes, uint32_t *grid2, uint32_t *grid2_vox, int32_t L2) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;  // natural (x-major) cell number
+    const uint32_t G = 1u << L2;
+    if (i >= (uint64_t)G * G * G) return;
+    const uint32_t iz = i & (G - 1), iy = (i >> L2) & (G - 1), ix = i >> (2 * L2);
+    uint32_t chunk = 0, word = 0, vox = 0;
+    for (int32_t l = 1; l <= L2; ++l) {
+        const int32_t s = L2 - l;
+        const uint32_t cidx = (((ix >> s) & 1u) << 2) | (((iy >> s) & 1u) << 1) | ((iz >> s) & 1u);
+        vox = chunk * 8u + cidx;
+        word = nodes[vox];
+        if (word & kLeafBit) break;
+        chunk = word;
+    }
+    const uint32_t o = grid2_index(ix, iy, iz, L2);
+    grid2[o] = word;
+    grid2_vox[o] = vox;
+}
+
 // ------------------------------------------------------------------------ march kernel
 
 struct AccelLaunch {
@@ -117,7 +145,6 @@ struct AccelLaunch {
     uint32_t band_begin[kNumQueues + 1];  // tile ranges per queue
     int32_t lds_level;                    // levels staged in LDS (<= A.grid_level)
     int32_t refill_min;                   // refill a wavefront once this many lanes are idle
-    int32_t dense_min;                    // run the dense-sample phase once this many lanes wait in it
     // interleaved macro-tile partition (world <= 1: plain tile)
     int32_t part_rank, part_world;
     uint32_t macro_w, macro_h;            // macro tile size in pixels
@@ -176,14 +203,12 @@ __device__ __forceinline__ void shade(const uint8_t *row, const float *basis, fl
     }
 }
 
-// BATCH_DENSE : lanes that reach a dense leaf (sigma > sigma_thresh) park until `dense_min`
-//               lanes of the wavefront are parked, then the expensive opacity + SH colour code
-//               runs once for all of them (it is ~4x the cost of a march step and would
-//               otherwise execute for a handful of lanes at a time).
-// PARENT_CACHE: each lane remembers the chunk that held its last deep leaf; if the next sample
-//               point falls into the same chunk the descent restarts there (1 load) instead of
-//               at the LDS grid (up to depth - lds_level loads).
-template <int BASIS, int ROW_BYTES, int BLOCK, bool BATCH_DENSE, bool PARENT_CACHE, bool STATS>
+// One step of the march on integer cell coordinates.  pos in [0, 1-1e-6] is scaled by 2^Lq
+// (Lq = deepest voxel depth of the tree, <= 23: the product is exact and < 2^24) and truncated;
+// bit (Lq - d) of each coordinate is the child index at depth d, and the cell numbers of the two
+// lookup grids are plain shifts.  The in-leaf coordinates are fract(pos * 2^depth), which equals the
+// reference's iterated x*2 - floor(x*2) bit for bit (all three operations are exact in binary32).
+template <int BASIS, int ROW_BYTES, int BLOCK, bool STATS>
 __global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     uint64_t *s_exp = reinterpret_cast<uint64_t *>(s_mem);  // 32 x 8 B
@@ -215,7 +240,12 @@ __global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K)
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const float grid_scale = (float)(1 << LL);
+    const int Lq = A.max_depth;
+    const float qscale = __uint_as_float((uint32_t)(127 + Lq) << 23);  // 2^Lq
+    const int sh1 = Lq - LL;                                            // q >> sh1 = LDS cell
+    const int L2 = A.grid2_level;                                       // 0: no second grid
+    const int sh2 = Lq - L2;
+    const int shg = Lq - A.grid_level;
     constexpr int NB = BASIS > 0 ? BASIS : 1;
 
     // per-lane ray state
@@ -223,48 +253,11 @@ __global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K)
     float t = 0.f, T = 1.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
     uint32_t pix = 0;
     bool alive = false;
-    // parked dense sample
-    bool parked = false;
-    float p_dt = 0.f;
-    uint32_t p_word = 0, p_vox = 0;
-    // parent-chunk cache: chunk `pc_chunk` holds voxels of depth `pc_depth` (0 = invalid) and
-    // covers the cube floor(pos * 2^(pc_depth-1)) == (pc_x, pc_y, pc_z)
-    uint32_t pc_chunk = 0;
-    int pc_depth = 0;
-    float pc_x = 0.f, pc_y = 0.f, pc_z = 0.f;
 
     // ray queues: home queue first, then steal round robin
     const uint32_t home = blockIdx.x % kNumQueues;
     uint32_t qsel = 0;       // queues tried so far (wave-uniform)
     bool exhausted = false;  // all queues empty (wave-uniform)
-
-    auto finish_ray = [&](float a) {
-        composite_and_write(P, (int64_t)pix, o0, o1, o2, a);
-        alive = false;
-    };
-
-    // opacity + colour of one dense sample (rt_core.cuh:233-307); returns true when the ray ended
-    auto dense_sample = [&](float delta_t, uint32_t word, uint32_t vox) {
-        const float sigma = half_bits_to_float((uint16_t)word);
-        const float att = exact_expf(-delta_t * r.delta_scale * sigma, s_exp);
-        const float weight = T * (1.f - att);
-        if (P.render_depth) {
-            o0 += weight * t;
-        } else if (!(K.ablate & 1)) {
-            shade<BASIS, ROW_BYTES>(A.rows + (int64_t)vox * ROW_BYTES, r.basis, weight, s_exp, o0, o1, o2);
-        }
-        T *= att;
-        if (T < P.stop_thresh) {
-            if (P.render_depth) o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
-            const float s = 1.f / (1.f - T);
-            o0 *= s;
-            o1 *= s;
-            o2 *= s;
-            finish_ray(1.f);
-        } else {
-            t += delta_t;
-        }
-    };
 
     auto stat = [&](int slot, bool pred) {
         if constexpr (STATS) {
@@ -304,10 +297,8 @@ __global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K)
                         o0 = o1 = o2 = 0.f;
                         if (r.in_bbox) {
                             alive = true;
-                            parked = false;
                             t = r.tmin;
                             T = 1.f;
-                            pc_depth = 0;
                         } else {
                             composite_and_write(P, (int64_t)pix, 0.f, 0.f, 0.f, P.render_depth ? 1.f : 0.f);
                         }
@@ -315,144 +306,91 @@ __global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K)
                 }
             }
         }
-        const uint64_t alive_mask = __ballot(alive);
-        if (alive_mask == 0) {
+        if (__ballot(alive) == 0) {
             if (exhausted) break;
             continue;
         }
-        if constexpr (BATCH_DENSE) {
-            const uint64_t parked_mask = __ballot(parked);
-            const int n_parked = __popcll(parked_mask);
-            if (n_parked >= K.dense_min || (n_parked > 0 && parked_mask == alive_mask)) {
-                if (parked) {
-                    stat(8, true);
-                    parked = false;
-                    dense_sample(p_dt, p_word, p_vox);
-                }
-                continue;
-            }
-        }
-        if (alive && !parked) {
+        if (alive) {
             // ---- one march step (rt_core.cuh:220-323)
             if (!(t < r.tmax)) {
                 // loop exit, rt_core.cuh:325-330
+                float a = 1.f - T;
                 if (P.render_depth) {
                     o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
-                    finish_ray(1.f);
-                } else {
-                    finish_ray(1.f - T);
+                    a = 1.f;
                 }
+                composite_and_write(P, (int64_t)pix, o0, o1, o2, a);
+                alive = false;
             } else {
                 stat(4, true);
                 float pos[3];
+                uint32_t q[3];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    pos[i] = r.cen[i] + t * r.dir[i];
+                    pos[i] = P.cen[i] + t * r.dir[i];
                     pos[i] = fmaxf(fminf(pos[i], 1.f - 1e-6f), 0.f);
+                    q[i] = (uint32_t)(pos[i] * qscale);
                 }
-                float x[3];
-                int depth = 0;
-                uint32_t word = 0, vox = 0;
-                bool descend = false;
-                if constexpr (PARENT_CACHE) {
-                    if (pc_depth > 0) {
-                        const float sc = __uint_as_float((uint32_t)(126 + pc_depth) << 23);  // 2^(pc_depth-1)
-                        const float px = pos[0] * sc, py = pos[1] * sc, pz = pos[2] * sc;
-                        const float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
-                        if (fx == pc_x && fy == pc_y && fz == pc_z) {
-                            x[0] = px - fx;
-                            x[1] = py - fy;
-                            x[2] = pz - fz;
-                            word = pc_chunk;
-                            depth = pc_depth - 1;
-                            descend = true;
-                        }
+                // top of the tree: LDS grid at level LL
+                uint32_t word = s_grid[((((q[0] >> sh1) << LL) + (q[1] >> sh1)) << LL) + (q[2] >> sh1)];
+                int src = 0;  // where the leaf word came from: 0 LDS grid, 1 grid2, 2 node array
+                uint32_t vox = 0;
+                if (!(word & kLeafBit)) {
+                    int sh = sh1;  // q >> sh is the cell at the depth `word` describes
+                    if (L2 > LL) {
+                        // middle of the tree: one load from the brick-ordered level-L2 grid
+                        vox = grid2_index(q[0] >> sh2, q[1] >> sh2, q[2] >> sh2, L2);
+                        word = A.grid2[vox];
+                        src = 1;
+                        sh = sh2;
                     }
-                }
-                if (!descend) {
-                    // top of the tree: LDS grid at level LL
-                    const float qx = pos[0] * grid_scale, qy = pos[1] * grid_scale, qz = pos[2] * grid_scale;
-                    const float fx = floorf(qx), fy = floorf(qy), fz = floorf(qz);
-                    word = s_grid[(((((int)fx << LL) + (int)fy)) << LL) + (int)fz];
-                    if (word & kLeafBit) {
-                        depth = (int)((word >> 16) & 0x7fu);
-                        // frac(pos * 2^depth): exact
-                        const float sc = __uint_as_float((uint32_t)(127 + depth) << 23);
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            const float pd = pos[i] * sc;
-                            x[i] = pd - floorf(pd);
-                        }
-                        // leaf at or above the LDS level: its voxel index (needed only for a dense
-                        // sample) comes from the level-grid_level index array
-                        if (half_bits_to_float((uint16_t)word) > P.sigma_thresh) {
-                            const float gs = (float)(1 << A.grid_level);
-                            const int gl = A.grid_level;
-                            const int gi = ((((int)floorf(pos[0] * gs) << gl) + (int)floorf(pos[1] * gs)) << gl) + (int)floorf(pos[2] * gs);
-                            vox = A.grid_vox[gi];
-                        }
-                        if constexpr (PARENT_CACHE) pc_depth = 0;
-                    } else {
-                        depth = LL;
-                        x[0] = qx - fx;
-                        x[1] = qy - fy;
-                        x[2] = qz - fz;
-                        descend = true;
-                    }
-                }
-                if (descend) {
-                    uint32_t chunk;
-                    do {
+                    while (!(word & kLeafBit)) {
                         stat(6, true);
-                        int cidx = 0;
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            x[i] *= 2.f;
-                            const float f = floorf(x[i]);
-                            cidx = cidx * 2 + (int)f;
-                            x[i] -= f;
-                        }
-                        chunk = word;
-                        vox = chunk * 8u + (uint32_t)cidx;
+                        --sh;
+                        const uint32_t cidx = (((q[0] >> sh) & 1u) << 2) | (((q[1] >> sh) & 1u) << 1) | ((q[2] >> sh) & 1u);
+                        vox = word * 8u + cidx;
                         word = A.nodes[vox];
-                        ++depth;
-                    } while (!(word & kLeafBit));
-                    if constexpr (PARENT_CACHE) {
-                        if (depth > LL + 1) {  // worth caching only below the LDS grid
-                            const float sc = __uint_as_float((uint32_t)(126 + depth) << 23);
-                            pc_x = floorf(pos[0] * sc);
-                            pc_y = floorf(pos[1] * sc);
-                            pc_z = floorf(pos[2] * sc);
-                            pc_chunk = chunk;
-                            pc_depth = depth;
-                        } else {
-                            pc_depth = 0;
-                        }
+                        src = 2;
                     }
                 }
-                // _dda_unit, rt_core.cuh:88-100
+                const int depth = (int)((word >> 16) & 0x7fu);
+                const float sc = __uint_as_float((uint32_t)(127 + depth) << 23);        // 2^depth
+                const float inv_cube = __uint_as_float((uint32_t)(127 - depth) << 23);  // 2^-depth
+                // _dda_unit on the in-leaf coordinates, rt_core.cuh:88-100
                 float tu = 1e4f;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    const float t1 = -x[i] * r.invdir[i];
+                    const float x = __builtin_amdgcn_fractf(pos[i] * sc);
+                    const float t1 = -x * r.invdir[i];
                     const float t2 = t1 + r.invdir[i];
                     tu = fminf(tu, fmaxf(t1, t2));
                 }
-                const float inv_cube = __uint_as_float((uint32_t)(127 - depth) << 23);  // 2^-depth
                 const float delta_t = tu * inv_cube + P.step_size;
-                if (half_bits_to_float((uint16_t)word) > P.sigma_thresh && !(K.ablate & 2)) {
-                    if constexpr (BATCH_DENSE) {
-                        parked = true;
-                        p_dt = delta_t;
-                        p_word = word;
-                        p_vox = vox;
-                    } else {
-                        stat(8, true);
-                        dense_sample(delta_t, word, vox);
+                const float sigma = half_bits_to_float((uint16_t)word);
+                if (sigma > P.sigma_thresh && !(K.ablate & 2)) {
+                    stat(8, true);
+                    // opacity + colour of a dense sample, rt_core.cuh:233-307
+                    if (src == 0) vox = A.grid_vox[((((q[0] >> shg) << A.grid_level) + (q[1] >> shg)) << A.grid_level) + (q[2] >> shg)];
+                    else if (src == 1) vox = A.grid2_vox[vox];
+                    const float att = exact_expf(-delta_t * r.delta_scale * sigma, s_exp);
+                    const float weight = T * (1.f - att);
+                    if (P.render_depth) {
+                        o0 += weight * t;
+                    } else if (!(K.ablate & 1)) {
+                        shade<BASIS, ROW_BYTES>(A.rows + (int64_t)vox * ROW_BYTES, r.basis, weight, s_exp, o0, o1, o2);
                     }
-                } else {
-                    t += delta_t;
+                    T *= att;
+                    if (T < P.stop_thresh) {
+                        if (P.render_depth) o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
+                        const float s = 1.f / (1.f - T);
+                        o0 *= s;
+                        o1 *= s;
+                        o2 *= s;
+                        composite_and_write(P, (int64_t)pix, o0, o1, o2, 1.f);
+                        alive = false;
+                    }
                 }
+                t += delta_t;
             }
         }
     }
@@ -465,10 +403,10 @@ static int row_bytes_for(int data_dim) {
     return ((b + 15) / 16) * 16;
 }
 
-template <int BASIS, int ROW_BYTES, bool BD, bool PC, bool ST = false>
+template <int BASIS, int ROW_BYTES, bool ST>
 static int launch_variant2(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
     constexpr int BLOCK = 256;
-    auto kern = march_accel_kernel<BASIS, ROW_BYTES, BLOCK, BD, PC, ST>;
+    auto kern = march_accel_kernel<BASIS, ROW_BYTES, BLOCK, ST>;
     static thread_local size_t configured = 0;
     if (lds_bytes > 65536 && configured < lds_bytes) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -479,19 +417,12 @@ static int launch_variant2(const AccelLaunch &K, int n_blocks, size_t lds_bytes,
     return (int)hipGetLastError();
 }
 
-// MNV_VARIANT (ablation only): bit 0 = batched dense phase, bit 1 = parent-chunk cache; default 3
 template <int BASIS, int ROW_BYTES>
 static int launch_variant(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
-    static const int variant = getenv("MNV_VARIANT") ? atoi(getenv("MNV_VARIANT")) : 0;
-    if constexpr (BASIS == 9) {
-        if (K.stats) return launch_variant2<BASIS, ROW_BYTES, false, false, true>(K, n_blocks, lds_bytes, stream);
+    if constexpr (BASIS == 9) {  // MNV_STATS=1 diagnostics build of the headline variant only
+        if (K.stats) return launch_variant2<BASIS, ROW_BYTES, true>(K, n_blocks, lds_bytes, stream);
     }
-    switch (variant & 3) {
-        case 0: return launch_variant2<BASIS, ROW_BYTES, false, false>(K, n_blocks, lds_bytes, stream);
-        case 1: return launch_variant2<BASIS, ROW_BYTES, true, false>(K, n_blocks, lds_bytes, stream);
-        case 2: return launch_variant2<BASIS, ROW_BYTES, false, true>(K, n_blocks, lds_bytes, stream);
-        default: return launch_variant2<BASIS, ROW_BYTES, true, true>(K, n_blocks, lds_bytes, stream);
-    }
+    return launch_variant2<BASIS, ROW_BYTES, false>(K, n_blocks, lds_bytes, stream);
 }
 
 int32_t partition_local_tiles(mnv_rect tile, mnv_partition part) {
@@ -543,13 +474,11 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, mnv_partition par
     const size_t lds_bytes = 256 + ((size_t)4 << (3 * lds_level));
     const int env_bpc = getenv("MNV_BLOCKS_PER_CU") ? atoi(getenv("MNV_BLOCKS_PER_CU")) : 0;
     static const int env_refill = getenv("MNV_REFILL_MIN") ? atoi(getenv("MNV_REFILL_MIN")) : 0;
-    static const int env_dense = getenv("MNV_DENSE_MIN") ? atoi(getenv("MNV_DENSE_MIN")) : 0;
     static const int env_ablate = getenv("MNV_ABLATE") ? atoi(getenv("MNV_ABLATE")) : 0;
     K.ablate = env_ablate;
     static const bool env_stats = getenv("MNV_STATS") != nullptr;
     K.stats = env_stats ? accel->stats : nullptr;
     K.refill_min = env_refill > 0 ? env_refill : 16;
-    K.dense_min = env_dense > 0 ? env_dense : 24;
     int blocks_per_cu = lds_level >= 5 ? 1 : 6;
     if (env_bpc > 0) blocks_per_cu = env_bpc;
     int n_blocks = accel->num_cus * blocks_per_cu;
@@ -615,7 +544,7 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
     if ((rc = check_hip(hipMemcpyAsync(depth, &one, 4, hipMemcpyHostToDevice, stream), "seed depth"))) return fail(rc);
     const unsigned nb = (unsigned)((nvox + 255) / 256);
     int max_depth = 1;
-    for (int level = 1; level < 64; ++level) {
+    for (int level = 1; level < 25; ++level) {
         int32_t flag = 0;
         if ((rc = check_hip(hipMemsetAsync(changed, 0, 4, stream), "memset flag"))) return fail(rc);
         hipLaunchKernelGGL(accel_depth_pass, dim3(nb), dim3(256), 0, stream, t->child, depth, t->capacity, level, changed);
@@ -624,6 +553,7 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
         if (!flag) break;
         max_depth = level + 1;
     }
+    if (max_depth > 23) return fail(set_error(MNV_E_UNSUPPORTED, "accel supports trees up to depth 23; use mnv_render_voxels"));
     hipLaunchKernelGGL(accel_pack_nodes, dim3(nb), dim3(256), 0, stream, t->child, t->data, depth, a->nodes, t->capacity, t->data_dim);
     const int64_t pieces = nvox * (row_bytes / 16);
     hipLaunchKernelGGL(accel_pack_rows, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, t->data, a->rows, nvox, t->data_dim, row_bytes);
@@ -632,6 +562,18 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
     if ((rc = check_hip(hipMalloc((void **)&a->grid, gcells * 4), "hipMalloc(grid)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&a->grid_vox, gcells * 4), "hipMalloc(grid_vox)"))) return fail(rc);
     hipLaunchKernelGGL(accel_build_grid, dim3((unsigned)((gcells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid, a->grid_vox, L);
+    // second lookup grid at level L2 = min(max_depth - 1, 8): 8^L2 words (64 MiB at level 8)
+    int L2 = max_depth - 1 < kMaxGrid2Level ? max_depth - 1 : kMaxGrid2Level;
+    static const int env_l2 = getenv("MNV_GRID2_LEVEL") ? atoi(getenv("MNV_GRID2_LEVEL")) : -1;
+    if (env_l2 >= 0 && env_l2 <= 9 && env_l2 < max_depth) L2 = env_l2;
+    if (L2 <= L || L2 < 2) L2 = 0;
+    int64_t g2cells = 0;
+    if (L2 > 0) {
+        g2cells = (int64_t)1 << (3 * L2);
+        if ((rc = check_hip(hipMalloc((void **)&a->grid2, g2cells * 4), "hipMalloc(grid2)"))) return fail(rc);
+        if ((rc = check_hip(hipMalloc((void **)&a->grid2_vox, g2cells * 4), "hipMalloc(grid2_vox)"))) return fail(rc);
+        hipLaunchKernelGGL(accel_build_grid2, dim3((unsigned)((g2cells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid2, a->grid2_vox, L2);
+    }
     if ((rc = check_hip(hipGetLastError(), "accel build launch"))) return fail(rc);
     if ((rc = check_hip(hipStreamSynchronize(stream), "accel build"))) return fail(rc);
     (void)hipFree(depth);
@@ -643,6 +585,10 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
     a->view.grid = a->grid;
     a->view.grid_vox = a->grid_vox;
     a->view.grid_level = L;
+    a->view.grid2 = a->grid2;
+    a->view.grid2_vox = a->grid2_vox;
+    a->view.grid2_level = L2;
+    a->view.max_depth = max_depth;
     a->view.row_bytes = row_bytes;
     for (int i = 0; i < 3; ++i) {
         a->view.offset[i] = t->offset[i];
@@ -652,7 +598,7 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
     a->view.basis_dim = t->basis_dim;
     a->view.format = t->format;
     a->view.capacity = t->capacity;
-    a->bytes = (size_t)(nvox * 4 + nvox * row_bytes + gcells * 8);
+    a->bytes = (size_t)(nvox * 4 + nvox * row_bytes + gcells * 8 + g2cells * 8);
     *out = a;
     return MNV_OK;
 }
@@ -662,7 +608,7 @@ void mnv_accel_destroy(mnv_accel *a) {
     if (a->stats && getenv("MNV_STATS")) {
         unsigned long long h[16];
         if (hipMemcpy(h, a->stats, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-            const char *names[] = {"outer_iter", "refill", "march_step", "descent_trip", "dense"};
+            const char *names[] = {"outer_iter", "refill", "march_step", "node_load", "dense"};
             for (int i = 0; i < 5; ++i)
                 fprintf(stderr, "[mnv stats] %-13s wave-level %llu lane-level %llu (%.1f lanes)\n", names[i], h[2 * i], h[2 * i + 1],
                         h[2 * i] ? (double)h[2 * i + 1] / (double)h[2 * i] : 0.0);
@@ -673,6 +619,8 @@ void mnv_accel_destroy(mnv_accel *a) {
     if (a->rows) (void)hipFree(a->rows);
     if (a->grid) (void)hipFree(a->grid);
     if (a->grid_vox) (void)hipFree(a->grid_vox);
+    if (a->grid2) (void)hipFree(a->grid2);
+    if (a->grid2_vox) (void)hipFree(a->grid2_vox);
     if (a->queue) (void)hipFree(a->queue);
     delete a;
 }
@@ -700,6 +648,7 @@ int mnv_render_voxels_accel_part(const mnv_accel *accel, const mnv_camera *cam, 
     if (rc) return rc;
     std::memcpy(P.offset, accel->view.offset, sizeof(P.offset));
     std::memcpy(P.scale, accel->view.scale, sizeof(P.scale));
+    fill_origin(P);
     P.rgba = rgba_out;
     P.rgba8 = rgba8_out;
     hipStream_t stream = (hipStream_t)hip_stream;

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void march_ref_layout_kernel(const MarchParams
             float pos[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                pos[i] = r.cen[i] + t * r.dir[i];
+                pos[i] = P.cen[i] + t * r.dir[i];
                 pos[i] = fmaxf(fminf(pos[i], 1.f - 1e-6f), 0.f);
             }
             int32_t chunk = 0, cidx;
