@@ -5,9 +5,10 @@
 //                            (rt_core.cuh:146) and the sigma half (rt_core.cuh:231):
 //                              internal: absolute index of the child chunk (1 .. 2^31-1)
 //                              leaf    : 0x80000000 | depth << 16 | sigma(binary16 bits)
-//   rows  [capacity*8][row_bytes]   the 3*basis_dim colour halfs of a voxel, padded to a
-//                            multiple of 16 B (54 -> 64 B for SH9) so that one dense
-//                            sample is row_bytes/16 aligned dwordx4 loads
+//   rows  [capacity*8][3][chan_bytes]   the colour halfs of a voxel, one block per channel, each
+//                            padded to a multiple of 8 B (18 -> 24 B for SH9, row = 72 B), so
+//                            that the lane evaluating one (sample, channel) pair fetches its
+//                            coefficients with chan_bytes/8 aligned dwordx2 loads
 //   grid  [2^L]^3 u32        dense top-of-tree lookup at level L = grid_level: the node
 //                            word of the depth-L voxel covering the cell, or the
 //                            (shallower) leaf word that covers it; staged in LDS

@@ -65,27 +65,19 @@ __global__ void accel_pack_nodes(const int32_t *child, const uint16_t *data, con
     }
 }
 
-// rows[v][0 .. row_bytes) = data[v][0 .. data_dim-1) zero padded; 16 B per thread
-__global__ void accel_pack_rows(const uint16_t *data, uint8_t *rows, int64_t nvox, int32_t data_dim,
-                                int32_t row_bytes) {
-    const int32_t pieces = row_bytes / 16;
+// rows[v] = 3 channel blocks of chan_halfs binary16 each (the basis_dim coefficients of the channel,
+// zero padded to a multiple of 8 B); one thread per (voxel, channel)
+__global__ void accel_pack_rows(const uint16_t *data, uint16_t *rows, int64_t nvox, int32_t data_dim,
+                                int32_t per_chan, int32_t chan_halfs, int32_t row_halfs) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nvox * pieces) return;
-    const int64_t v = i / pieces;
-    const int32_t p = (int32_t)(i % pieces);
-    const uint16_t *src = data + v * data_dim;
-    uint16_t h[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int32_t col = p * 8 + k;
-        h[k] = col < data_dim - 1 ? src[col] : (uint16_t)0;
-    }
-    uint4 o;
-    o.x = h[0] | ((uint32_t)h[1] << 16);
-    o.y = h[2] | ((uint32_t)h[3] << 16);
-    o.z = h[4] | ((uint32_t)h[5] << 16);
-    o.w = h[6] | ((uint32_t)h[7] << 16);
-    *reinterpret_cast<uint4 *>(rows + v * row_bytes + p * 16) = o;
+    if (i >= nvox * 3) return;
+    const int64_t v = i / 3;
+    const int32_t c = (int32_t)(i % 3);
+    const uint16_t *src = data + v * data_dim + c * per_chan;
+    uint16_t *dst = rows + v * row_halfs + c * chan_halfs;
+    for (int32_t k = 0; k < chan_halfs; ++k) dst[k] = k < per_chan ? src[k] : (uint16_t)0;
+    if (c == 2)
+        for (int32_t k = 3 * chan_halfs; k < row_halfs; ++k) rows[v * row_halfs + k] = 0;
 }
 
 // grid[(ix*G + iy)*G + iz] = word of the voxel of depth <= L that covers cell (ix,iy,iz)
@@ -175,44 +167,32 @@ __device__ __forceinline__ bool ray_pixel(const AccelLaunch &K, uint32_t id, int
     return bx < K.P.tw && by < K.P.th;
 }
 
-template <int BASIS, int ROW_BYTES>
-__device__ __forceinline__ void shade(const uint8_t *row, const float *basis, float weight, const uint64_t *s_exp,
-                                      float &o0, float &o1, float &o2) {
-    // the whole padded row in registers: ROW_BYTES/16 dwordx4 loads
-    constexpr int NV = ROW_BYTES / 16;
-    uint4 v[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = reinterpret_cast<const uint4 *>(row)[i];
-    auto coef = [&](int k) -> float {
-        const uint4 q = v[k >> 3];
-        const uint32_t w = ((k >> 1) & 3) == 0 ? q.x : ((k >> 1) & 3) == 1 ? q.y : ((k >> 1) & 3) == 2 ? q.z : q.w;
-        return half_bits_to_float((uint16_t)((k & 1) ? (w >> 16) : (w & 0xffffu)));
-    };
-    if constexpr (BASIS >= 0) {
-        constexpr int stride = BASIS > 0 ? BASIS : 1;
-        const float c0 = sh_channel<BASIS>(basis, coef, 0);
-        const float c1 = sh_channel<BASIS>(basis, coef, stride);
-        const float c2 = sh_channel<BASIS>(basis, coef, 2 * stride);
-        o0 += weight / (1.f + exact_expf(-c0, s_exp));
-        o1 += weight / (1.f + exact_expf(-c1, s_exp));
-        o2 += weight / (1.f + exact_expf(-c2, s_exp));
-    } else {
-        o0 += coef(0) * weight;
-        o1 += coef(1) * weight;
-        o2 += coef(2) * weight;
-    }
+__device__ __forceinline__ float lane_read(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
 }
+__device__ __forceinline__ uint32_t lane_read(uint32_t v, int src_lane) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
+
+// bytes of one colour channel block of a packed row: basis_dim halfs padded to 8 B
+__host__ __device__ constexpr int chan_bytes_for(int basis) { return basis > 0 ? ((2 * basis + 7) / 8) * 8 : 8; }
 
 // One step of the march on integer cell coordinates.  pos in [0, 1-1e-6] is scaled by 2^Lq
 // (Lq = deepest voxel depth of the tree, <= 23: the product is exact and < 2^24) and truncated;
 // bit (Lq - d) of each coordinate is the child index at depth d, and the cell numbers of the two
 // lookup grids are plain shifts.  The in-leaf coordinates are fract(pos * 2^depth), which equals the
 // reference's iterated x*2 - floor(x*2) bit for bit (all three operations are exact in binary32).
-template <int BASIS, int ROW_BYTES, int BLOCK, bool STATS>
-__global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K) {
+template <int BASIS, int BLOCK, bool STATS>
+#ifndef MNV_MIN_WAVES
+#define MNV_MIN_WAVES 6  // register budget for 6 waves per SIMD (A/B in DESIGN.md: 1 -> 0.647 ms, 6 -> 0.615 ms, 8 -> 0.615 ms with scratch spills)
+#endif
+__global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const AccelLaunch K) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     uint64_t *s_exp = reinterpret_cast<uint64_t *>(s_mem);  // 32 x 8 B
-    uint32_t *s_grid = s_mem + 64;                           // (2^lds_level)^3 words
+    uint32_t *s_map = s_mem + 64;                            // BLOCK words: dense-sample rank -> lane, per wavefront
+    uint32_t *s_grid = s_mem + 64 + BLOCK;                   // (2^lds_level)^3 words
+    constexpr int CHAN_BYTES = chan_bytes_for(BASIS);
+    constexpr int ROW_BYTES = BASIS > 0 ? 3 * CHAN_BYTES : 8;
     const FrameParams &P = K.P;
     const AccelView &A = K.A;
 
@@ -310,8 +290,11 @@ __global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K)
             if (exhausted) break;
             continue;
         }
+        // ---- one march step (rt_core.cuh:220-323) for every live lane
+        bool dense = false;
+        float delta_t = 0.f, weight = 0.f, att = 1.f;
+        uint32_t vox = 0;
         if (alive) {
-            // ---- one march step (rt_core.cuh:220-323)
             if (!(t < r.tmax)) {
                 // loop exit, rt_core.cuh:325-330
                 float a = 1.f - T;
@@ -334,7 +317,6 @@ __global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K)
                 // top of the tree: LDS grid at level LL
                 uint32_t word = s_grid[((((q[0] >> sh1) << LL) + (q[1] >> sh1)) << LL) + (q[2] >> sh1)];
                 int src = 0;  // where the leaf word came from: 0 LDS grid, 1 grid2, 2 node array
-                uint32_t vox = 0;
                 if (!(word & kLeafBit)) {
                     int sh = sh1;  // q >> sh is the cell at the depth `word` describes
                     if (L2 > LL) {
@@ -365,48 +347,105 @@ __global__ __launch_bounds__(BLOCK) void march_accel_kernel(const AccelLaunch K)
                     const float t2 = t1 + r.invdir[i];
                     tu = fminf(tu, fmaxf(t1, t2));
                 }
-                const float delta_t = tu * inv_cube + P.step_size;
+                delta_t = tu * inv_cube + P.step_size;
                 const float sigma = half_bits_to_float((uint16_t)word);
                 if (sigma > P.sigma_thresh && !(K.ablate & 2)) {
-                    stat(8, true);
-                    // opacity + colour of a dense sample, rt_core.cuh:233-307
+                    // opacity of a dense sample, rt_core.cuh:233-235
+                    dense = true;
                     if (src == 0) vox = A.grid_vox[((((q[0] >> shg) << A.grid_level) + (q[1] >> shg)) << A.grid_level) + (q[2] >> shg)];
                     else if (src == 1) vox = A.grid2_vox[vox];
-                    const float att = exact_expf(-delta_t * r.delta_scale * sigma, s_exp);
-                    const float weight = T * (1.f - att);
-                    if (P.render_depth) {
-                        o0 += weight * t;
-                    } else if (!(K.ablate & 1)) {
-                        shade<BASIS, ROW_BYTES>(A.rows + (int64_t)vox * ROW_BYTES, r.basis, weight, s_exp, o0, o1, o2);
-                    }
-                    T *= att;
-                    if (T < P.stop_thresh) {
-                        if (P.render_depth) o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
-                        const float s = 1.f / (1.f - T);
-                        o0 *= s;
-                        o1 *= s;
-                        o2 *= s;
-                        composite_and_write(P, (int64_t)pix, o0, o1, o2, 1.f);
-                        alive = false;
-                    }
+                    att = exact_expf(-delta_t * r.delta_scale * sigma, s_exp);
+                    weight = T * (1.f - att);
                 }
-                t += delta_t;
             }
         }
+        // ---- colour of the dense samples of this iteration (rt_core.cuh:254-291)
+        const uint64_t dense_mask = __ballot(dense);
+        if (dense_mask != 0) {
+            stat(8, dense);
+            if (P.render_depth) {
+                if (dense) o0 += weight * t;
+            } else if (K.ablate & 1) {
+            } else if constexpr (BASIS >= 1) {
+                // SH: the wavefront evaluates the samples cooperatively, one lane per (sample, channel):
+                // 21 samples x 3 channels per pass.  Each task lane pulls the sample's weight, voxel and
+                // SH basis from the owning lane (ds_bpermute), loads its channel's coefficients, and
+                // returns weight / (1 + exp(-dot)) to the owner, which accumulates in sample order.
+                const int n_dense = __popcll(dense_mask);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(dense_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dense_mask, 0u));
+                uint32_t *map = s_map + (threadIdx.x & ~63);
+                if (dense) map[rank] = (uint32_t)lane;
+                __builtin_amdgcn_wave_barrier();
+                const int my_s = lane / 3, my_c = lane - 3 * my_s;
+                for (int base = 0; base < n_dense; base += 21) {
+                    const int smp = base + my_s;
+                    const bool task = my_s < 21 && smp < n_dense;
+                    const int owner = task ? (int)map[smp] : lane;
+                    const float w = lane_read(weight, owner);
+                    const uint32_t vx = lane_read(vox, owner);
+                    float b[NB];
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) b[k] = lane_read(r.basis[k], owner);
+                    float v = 0.f;
+                    if (task) {
+                        constexpr int NW = CHAN_BYTES / 8;
+                        uint2 cw[NW];
+                        const uint2 *cp = reinterpret_cast<const uint2 *>(A.rows + (int64_t)vx * ROW_BYTES + my_c * CHAN_BYTES);
+#pragma unroll
+                        for (int i = 0; i < NW; ++i) cw[i] = cp[i];
+                        auto coef = [&](int k) -> float {
+                            const uint2 qd = cw[k >> 2];
+                            const uint32_t wd = (k & 2) ? qd.y : qd.x;
+                            return half_bits_to_float((uint16_t)((k & 1) ? (wd >> 16) : (wd & 0xffffu)));
+                        };
+                        const float tmp = sh_channel<BASIS>(b, coef, 0);
+                        v = w / (1.f + exact_expf(-tmp, s_exp));
+                    }
+                    const int rl = rank - base;
+                    const bool mine = dense && rl >= 0 && rl < 21;
+                    const int from = mine ? 3 * rl : lane;
+                    const float v0 = lane_read(v, from), v1 = lane_read(v, mine ? from + 1 : lane), v2 = lane_read(v, mine ? from + 2 : lane);
+                    if (mine) {
+                        o0 += v0;
+                        o1 += v1;
+                        o2 += v2;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                // RGBA rows (rt_core.cuh:285-290): three halfs per voxel, per-lane
+                if (dense) {
+                    const uint2 qd = *reinterpret_cast<const uint2 *>(A.rows + (int64_t)vox * ROW_BYTES);
+                    o0 += half_bits_to_float((uint16_t)(qd.x & 0xffffu)) * weight;
+                    o1 += half_bits_to_float((uint16_t)(qd.x >> 16)) * weight;
+                    o2 += half_bits_to_float((uint16_t)(qd.y & 0xffffu)) * weight;
+                }
+            }
+            if (dense) {
+                T *= att;  // rt_core.cuh:293-307
+                if (T < P.stop_thresh) {
+                    if (P.render_depth) o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
+                    const float sc = 1.f / (1.f - T);
+                    o0 *= sc;
+                    o1 *= sc;
+                    o2 *= sc;
+                    composite_and_write(P, (int64_t)pix, o0, o1, o2, 1.f);
+                    alive = false;
+                }
+            }
+        }
+        t += delta_t;  // 0 for lanes that did not step
     }
 }
 
 // ---------------------------------------------------------------------------- host side
 
-static int row_bytes_for(int data_dim) {
-    const int b = 2 * (data_dim - 1);
-    return ((b + 15) / 16) * 16;
-}
+static int row_bytes_for(int basis) { return basis > 0 ? 3 * chan_bytes_for(basis) : 8; }
 
-template <int BASIS, int ROW_BYTES, bool ST>
+template <int BASIS, bool ST>
 static int launch_variant2(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
     constexpr int BLOCK = 256;
-    auto kern = march_accel_kernel<BASIS, ROW_BYTES, BLOCK, ST>;
+    auto kern = march_accel_kernel<BASIS, BLOCK, ST>;
     static thread_local size_t configured = 0;
     if (lds_bytes > 65536 && configured < lds_bytes) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -417,12 +456,12 @@ static int launch_variant2(const AccelLaunch &K, int n_blocks, size_t lds_bytes,
     return (int)hipGetLastError();
 }
 
-template <int BASIS, int ROW_BYTES>
+template <int BASIS>
 static int launch_variant(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
     if constexpr (BASIS == 9) {  // MNV_STATS=1 diagnostics build of the headline variant only
-        if (K.stats) return launch_variant2<BASIS, ROW_BYTES, true>(K, n_blocks, lds_bytes, stream);
+        if (K.stats) return launch_variant2<BASIS, true>(K, n_blocks, lds_bytes, stream);
     }
-    return launch_variant2<BASIS, ROW_BYTES, false>(K, n_blocks, lds_bytes, stream);
+    return launch_variant2<BASIS, false>(K, n_blocks, lds_bytes, stream);
 }
 
 int32_t partition_local_tiles(mnv_rect tile, mnv_partition part) {
@@ -471,7 +510,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, mnv_partition par
     int lds_level = accel->view.grid_level < 4 ? accel->view.grid_level : 4;
     if (env_level >= 1 && env_level <= accel->view.grid_level) lds_level = env_level;
     K.lds_level = lds_level;
-    const size_t lds_bytes = 256 + ((size_t)4 << (3 * lds_level));
+    const size_t lds_bytes = 256 + 256 * 4 + ((size_t)4 << (3 * lds_level));
     const int env_bpc = getenv("MNV_BLOCKS_PER_CU") ? atoi(getenv("MNV_BLOCKS_PER_CU")) : 0;
     static const int env_refill = getenv("MNV_REFILL_MIN") ? atoi(getenv("MNV_REFILL_MIN")) : 0;
     static const int env_ablate = getenv("MNV_ABLATE") ? atoi(getenv("MNV_ABLATE")) : 0;
@@ -488,12 +527,12 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, mnv_partition par
 
     const int b = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim >= 0) ? accel->view.basis_dim : -1;
     switch (b) {
-        case -1: return launch_variant<-1, 16>(K, n_blocks, lds_bytes, stream);
-        case 1: return launch_variant<1, 16>(K, n_blocks, lds_bytes, stream);
-        case 4: return launch_variant<4, 32>(K, n_blocks, lds_bytes, stream);
-        case 9: return launch_variant<9, 64>(K, n_blocks, lds_bytes, stream);
-        case 16: return launch_variant<16, 96>(K, n_blocks, lds_bytes, stream);
-        case 25: return launch_variant<25, 160>(K, n_blocks, lds_bytes, stream);
+        case -1: return launch_variant<-1>(K, n_blocks, lds_bytes, stream);
+        case 1: return launch_variant<1>(K, n_blocks, lds_bytes, stream);
+        case 4: return launch_variant<4>(K, n_blocks, lds_bytes, stream);
+        case 9: return launch_variant<9>(K, n_blocks, lds_bytes, stream);
+        case 16: return launch_variant<16>(K, n_blocks, lds_bytes, stream);
+        case 25: return launch_variant<25>(K, n_blocks, lds_bytes, stream);
         default: return -1000;
     }
 }
@@ -529,7 +568,7 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
     a->num_cus = prop.multiProcessorCount;
 
     const int64_t cap = t->capacity, nvox = cap * 8;
-    const int row_bytes = row_bytes_for(t->data_dim);
+    const int row_bytes = row_bytes_for(b);
     if ((rc = check_hip(hipMalloc((void **)&a->nodes, nvox * 4), "hipMalloc(nodes)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&a->rows, nvox * row_bytes), "hipMalloc(rows)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&depth, cap * 4), "hipMalloc(depth)"))) return fail(rc);
@@ -555,8 +594,9 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
     }
     if (max_depth > 23) return fail(set_error(MNV_E_UNSUPPORTED, "accel supports trees up to depth 23; use mnv_render_voxels"));
     hipLaunchKernelGGL(accel_pack_nodes, dim3(nb), dim3(256), 0, stream, t->child, t->data, depth, a->nodes, t->capacity, t->data_dim);
-    const int64_t pieces = nvox * (row_bytes / 16);
-    hipLaunchKernelGGL(accel_pack_rows, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, t->data, a->rows, nvox, t->data_dim, row_bytes);
+    hipLaunchKernelGGL(accel_pack_rows, dim3((unsigned)((nvox * 3 + 255) / 256)), dim3(256), 0, stream, t->data,
+                       reinterpret_cast<uint16_t *>(a->rows), nvox, t->data_dim, b > 0 ? b : 1, b > 0 ? chan_bytes_for(b) / 2 : 1,
+                       row_bytes / 2);
     int L = max_depth < kMaxGridLevel ? max_depth : kMaxGridLevel;
     const int64_t gcells = (int64_t)1 << (3 * L);
     if ((rc = check_hip(hipMalloc((void **)&a->grid, gcells * 4), "hipMalloc(grid)"))) return fail(rc);
