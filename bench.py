@@ -104,44 +104,26 @@ def main():
             for i in range(N_POSES):
                 render_pose(i, i % RING)
     else:
-        rect = (0, 0, W, H)
-        macros_x, macros_y = (W + MACRO_W - 1) // MACRO_W, (H + MACRO_H - 1) // MACRO_H
-        n_macro = macros_x * macros_y
-        j_max = (n_macro + world - 1) // world
-        n_local = mnv.partition_local_tiles(rect, rank, world, MACRO_W, MACRO_H)
-        dt = torch.float32 if args.gather == "f32" else torch.uint8
-        local = [torch.zeros((j_max, MACRO_H, MACRO_W, 4), dtype=dt, device=dev) for _ in range(RING)]
-        if rank == 0:
-            gathered = [torch.empty((world, j_max, MACRO_H, MACRO_W, 4), dtype=dt, device=dev) for _ in range(RING)]
-            m = torch.arange(n_macro, device=dev)
-            src_index = (m % world) * j_max + m // world          # macro tile m lives at [m % world][m // world]
-            frames = [torch.empty((H, W, 4), dtype=dt, device=dev) for _ in range(RING)]
-        pending = [None] * RING
+        from mega_nerf_viewer_amd.multigpu import TileGatherer, TilePartition
 
-        def finish(slot):
-            w_ = pending[slot]
-            if w_ is None:
-                return
-            w_.wait()
-            pending[slot] = None
-            if rank == 0:
-                t = gathered[slot].view(world * j_max, MACRO_H, MACRO_W, 4)[src_index]
-                t = t.view(macros_y, macros_x, MACRO_H, MACRO_W, 4).permute(0, 2, 1, 3, 4)
-                frames[slot].copy_(t.reshape(macros_y * MACRO_H, macros_x * MACRO_W, 4)[:H, :W])
+        part = TilePartition(W, H, world, MACRO_W, MACRO_H)
+        n_local = part.local_tiles(rank)
+        assert n_local == mnv.partition_local_tiles((0, 0, W, H), rank, world, MACRO_W, MACRO_H)
+        dt = torch.float32 if args.gather == "f32" else torch.uint8
+        tg = TileGatherer(part, rank, dev, dtype=dt, depth=RING)
+        frames = tg._frames if rank == 0 else None
 
         def render_pose(i, slot):
-            finish(slot)  # the slot's previous gather must be done before its buffer is overwritten
-            kw = dict(rgba=local[slot]) if args.gather == "f32" else dict(rgba8=local[slot])
+            tg.finish(slot)  # the slot's previous gather must be done before its buffer is overwritten
+            kw = dict(rgba=tg.local(slot)) if args.gather == "f32" else dict(rgba8=tg.local(slot))
             if n_local > 0:
                 mnv.render_voxels_accel_part(tree.accel, cams[i], opt, rank, world, MACRO_W, MACRO_H, stream=stream, **kw)
-            glist = [gathered[slot][r] for r in range(world)] if rank == 0 else None
-            pending[slot] = dist.gather(local[slot], glist, dst=0, async_op=True)
+            tg.submit(slot)
 
         def step():
             for i in range(N_POSES):
                 render_pose(i, i % RING)
-            for s in range(RING):
-                finish(s)
+            tg.finish_all()
 
     def sync_all():
         torch.cuda.synchronize(dev)

@@ -1,0 +1,96 @@
+"""Tile partition + gather of one frame across the GPUs of a node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the
+CPU tests).  The tree is replicated, the frame is cut into interleaved macro tiles
+(rank = tile % world, see ``mnv_partition`` in include/mnv.h), each rank renders its tiles into a
+compact local-tile-major buffer with one kernel launch, and the buffers are gathered to rank 0
+and un-permuted into the frame there.  The march itself needs no exchange: this gather is the only
+collective of the path.  The reference has no multi-GPU code; this is new.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class TilePartition:
+    """Index math of the interleaved macro-tile partition (pure host code, mirrors
+    mnv_partition_local_tiles / ray_pixel in csrc/mnv_march_accel.hip)."""
+
+    def __init__(self, width: int, height: int, world: int, tile_w: int = 128, tile_h: int = 120):
+        if tile_w % 8 or tile_h % 8:
+            raise ValueError("macro tiles must be multiples of 8 pixels")
+        self.width, self.height, self.world = width, height, world
+        self.tile_w, self.tile_h = tile_w, tile_h
+        self.macros_x = -(-width // tile_w)
+        self.macros_y = -(-height // tile_h)
+        self.n_macro = self.macros_x * self.macros_y
+        self.j_max = -(-self.n_macro // world)
+
+    def local_tiles(self, rank: int) -> int:
+        return len(range(rank, self.n_macro, self.world))
+
+    def tile_rect(self, m: int):
+        """(x0, y0, w, h) of macro tile m clipped to the frame."""
+        mx, my = m % self.macros_x, m // self.macros_x
+        x0, y0 = mx * self.tile_w, my * self.tile_h
+        return x0, y0, min(self.tile_w, self.width - x0), min(self.tile_h, self.height - y0)
+
+    def tiles_of(self, rank: int) -> List[int]:
+        return list(range(rank, self.n_macro, self.world))
+
+    def source_index(self, device) -> torch.Tensor:
+        """For macro tile m: row of the [world * j_max] gathered tile table that holds it."""
+        m = torch.arange(self.n_macro, device=device)
+        return (m % self.world) * self.j_max + m // self.world
+
+    def unpermute(self, gathered: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """gathered [world, j_max, tile_h, tile_w, C] -> frame [height, width, C]."""
+        c = gathered.shape[-1]
+        t = gathered.reshape(self.world * self.j_max, self.tile_h, self.tile_w, c)[self.source_index(gathered.device)]
+        t = t.view(self.macros_y, self.macros_x, self.tile_h, self.tile_w, c).permute(0, 2, 1, 3, 4)
+        frame = t.reshape(self.macros_y * self.tile_h, self.macros_x * self.tile_w, c)[: self.height, : self.width]
+        if out is None:
+            return frame.contiguous()
+        out.copy_(frame)
+        return out
+
+
+class TileGatherer:
+    """Ring of `depth` in-flight frames: render into ``local(slot)``, then ``submit(slot)`` starts the
+    asynchronous gather to rank 0; ``finish(slot)`` waits for it and (on rank 0) un-permutes into
+    ``frame(slot)``.  With depth >= 2 the gather of frame k overlaps the render of frame k+1."""
+
+    def __init__(self, part: TilePartition, rank: int, device, dtype=torch.float32, channels: int = 4, depth: int = 3, group=None):
+        self.part, self.rank, self.group, self.depth = part, rank, group, depth
+        shape = (part.j_max, part.tile_h, part.tile_w, channels)
+        self._local = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(depth)]
+        self._pending = [None] * depth
+        if rank == 0:
+            self._gathered = [torch.empty((part.world,) + shape, dtype=dtype, device=device) for _ in range(depth)]
+            self._frames = [torch.empty((part.height, part.width, channels), dtype=dtype, device=device) for _ in range(depth)]
+
+    def local(self, slot: int) -> torch.Tensor:
+        return self._local[slot]
+
+    def frame(self, slot: int) -> torch.Tensor:
+        return self._frames[slot]
+
+    def submit(self, slot: int) -> None:
+        glist = [self._gathered[slot][r] for r in range(self.part.world)] if self.rank == 0 else None
+        self._pending[slot] = dist.gather(self._local[slot], glist, dst=0, group=self.group, async_op=True)
+
+    def finish(self, slot: int) -> None:
+        w = self._pending[slot]
+        if w is None:
+            return
+        w.wait()
+        self._pending[slot] = None
+        if self.rank == 0:
+            self.part.unpermute(self._gathered[slot], out=self._frames[slot])
+
+    def finish_all(self) -> None:
+        for s in range(self.depth):
+            self.finish(s)

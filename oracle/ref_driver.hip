@@ -1,0 +1,160 @@
+// ref_driver.hip -- driver that runs the REFERENCE's own ray-march device code on the GPU.
+//
+// TEST INFRASTRUCTURE ONLY (see mnv_oracle.h).  This translation unit is compiled by
+// oracle/Makefile.ref against the reference sources where they lie under /root/reference
+// (hipify-perl'd into a scratch directory; nothing of them is copied into the repository).
+// It includes the reference's include/cuda/rt_core.cuh and calls its
+//     viewer::device::render_voxels_trace_ray<float>        (rt_core.cuh:162-332)
+// through the reference's own N3Tree loader (src/n3tree/n3tree.cpp + 3rdparty/cnpy), its
+// TreeSpec (include/data_spec.hpp:25-50) and its RenderOptions (include/render_options.hpp).
+//
+// The only restated piece is the ~30-line per-pixel wrapper of render_voxels_kernel
+// (src/cuda/renderer_kernel.cu:243-292): that kernel writes through CUDA surface objects
+// (surf2Dwrite), which gfx950 has no hardware for, so it cannot be built as is.  The wrapper
+// below follows :30-38 (screen2worlddir), :40-61 (rodrigues), :272-275, :282-288 and the
+// offscreen branch of composite_and_write (:224-229), and stores the four floats the reference
+// holds just before its u8 cast.
+#include <hip/hip_runtime.h>
+
+#include "cuda/common.cuh"
+#include "cuda/rt_core.cuh"
+#include "data_spec.hpp"
+#include "n3tree/n3tree.hpp"
+#include "render_options.hpp"
+
+namespace viewer {
+// cuda_assert is defined in the reference's src/cuda/common.cu (compiled alongside)
+
+namespace {
+
+struct CamPOD {  // what CameraSpec carries (data_spec.hpp:9-23), c2w by value
+    int width, height;
+    float fx, fy, cx, cy;
+    float transform[12];
+};
+
+template <typename scalar_t>
+__device__ __inline__ void ref_screen2worlddir(int ix, int iy, const CamPOD &cam, scalar_t *out, scalar_t *cen) {
+    scalar_t xyz[3] = {(ix + 0.5f - cam.cx) / cam.fx, -(iy + 0.5f - cam.cy) / cam.fy, -1.0f};
+    _mv3(cam.transform, xyz, out);
+    _normalize(out);
+    _copy3(cam.transform + 9, cen);
+}
+
+template <typename scalar_t>
+__device__ __inline__ void ref_rodrigues(const scalar_t *__restrict__ aa, scalar_t *__restrict__ dir) {
+    scalar_t angle = _norm(aa);
+    if (angle < 1e-6) return;
+    scalar_t k[3];
+    for (int i = 0; i < 3; ++i) k[i] = aa[i] / angle;
+    scalar_t cos_angle = cos(angle), sin_angle = sin(angle);
+    scalar_t cross[3];
+    _cross3(k, dir, cross);
+    scalar_t dot = _dot3(k, dir);
+    for (int i = 0; i < 3; ++i) {
+        dir[i] = dir[i] * cos_angle + cross[i] * sin_angle + k[i] * dot * (1.0 - cos_angle);
+    }
+}
+
+__global__ void ref_render_voxels_kernel(const internal::TreeSpec tree, const CamPOD cam, const RenderOptions opt,
+                                         float *rgba,
+                                         torch::PackedTensorAccessor32<float, 2, torch::RestrictPtrTraits> to_split,
+                                         torch::PackedTensorAccessor32<float, 2, torch::RestrictPtrTraits> to_sample,
+                                         torch::PackedTensorAccessor32<int32_t, 1, torch::RestrictPtrTraits> visited,
+                                         const bool track_visit) {
+    CUDA_GET_THREAD_ID(idx, cam.width * cam.height);
+    const int x = idx % cam.width, y = idx / cam.width;
+    float dir[3], cen[3], out[4];
+    bool enable_draw = tree.N > 0;
+    out[0] = out[1] = out[2] = out[3] = 0.f;
+    if (enable_draw) {
+        ref_screen2worlddir(x, y, cam, dir, cen);
+        for (int i = 0; i < 3; ++i) cen[i] = tree.offset[i] + tree.scale[i] * cen[i];
+        float t_max = 1e9f;
+        float vdir[3] = {dir[0], dir[1], dir[2]};
+        float aa[3] = {opt.rot_dirs[0], opt.rot_dirs[1], opt.rot_dirs[2]};
+        ref_rodrigues(aa, vdir);
+        device::render_voxels_trace_ray(tree, visited, dir, vdir, cen, opt, t_max, out, &to_split[idx][1],
+                                        &to_split[idx][2], &to_split[idx][0], &to_sample[idx][1],
+                                        &to_sample[idx][2], &to_sample[idx][0], track_visit);
+    }
+    const float nalpha = 1.f - out[3];
+    const float remain = opt.background_brightness * nalpha;
+    out[0] += remain;
+    out[1] += remain;
+    out[2] += remain;
+    rgba[idx * 4 + 0] = out[0];
+    rgba[idx * 4 + 1] = out[1];
+    rgba[idx * 4 + 2] = out[2];
+    rgba[idx * 4 + 3] = out[3];
+}
+
+}  // namespace
+}  // namespace viewer
+
+extern "C" {
+
+// Opens `npz_path` with the reference's N3Tree::open, moves it to the device with the reference's
+// move_to_device, renders the full frame and copies float RGBA [h][w][4] to `rgba_host`.
+// `opt_bytes` is a reference-layout RenderOptions (render_options.hpp:9-56).  Also returns the first
+// `n_probe` elements of the loaded data / child / parent arrays for loader parity checks.
+int ref_render_npz(const char *npz_path, int width, int height, float fx, float fy, float cx, float cy,
+                   const float *c2w12, const void *opt_bytes, int opt_size, float *rgba_host,
+                   uint16_t *data_probe, int32_t *child_probe, int32_t *parent_probe, int n_probe,
+                   int *meta /* N, data_dim, format, basis_dim, capacity */) {
+    using namespace viewer;
+    if (opt_size != (int)sizeof(RenderOptions)) return -2;
+    RenderOptions opt;
+    memcpy(&opt, opt_bytes, sizeof(opt));
+    try {
+        N3Tree tree;
+        tree.open(npz_path);
+        if (tree.N == 0) return -3;
+        meta[0] = tree.N;
+        meta[1] = tree.data_dim;
+        meta[2] = (int)tree.data_format.format;
+        meta[3] = tree.data_format.basis_dim;
+        meta[4] = tree.capacity;
+        if (n_probe > 0) {
+            auto d = tree.data.flatten();
+            auto c = tree.child.flatten();
+            auto p = tree.parent.flatten();
+            const int64_t nd = std::min<int64_t>(n_probe, d.numel()), nc = std::min<int64_t>(n_probe, c.numel()), np = std::min<int64_t>(n_probe, p.numel());
+            memcpy(data_probe, d.data_ptr(), nd * 2);
+            memcpy(child_probe, c.data_ptr(), nc * 4);
+            memcpy(parent_probe, p.data_ptr(), np * 4);
+        }
+        tree.move_to_device(tree.capacity, true, true);
+        tree.sample_counts.fill_(8);  // the reference leaves this array uninitialised (n3tree.cpp:235-241)
+        CamPOD cam;
+        cam.width = width;
+        cam.height = height;
+        cam.fx = fx;
+        cam.fy = fy;
+        cam.cx = cx;
+        cam.cy = cy;
+        memcpy(cam.transform, c2w12, sizeof(cam.transform));
+        const int64_t n = (int64_t)width * height;
+        auto fopt = torch::TensorOptions().device(torch::kCUDA).dtype(torch::kFloat32);
+        torch::Tensor out = torch::zeros({n, 4}, fopt);
+        torch::Tensor to_split = torch::full({n, 3}, -1.f, fopt), to_sample = torch::full({n, 3}, -1.f, fopt);
+        torch::Tensor visited = torch::zeros({tree.capacity}, torch::TensorOptions().device(torch::kCUDA).dtype(torch::kInt32));
+        const int threads = 512;  // auto_cuda_threads() picks 512 or 1024 (renderer_kernel.cu:14-28)
+        const int blocks = N_BLOCKS_NEEDED(n, threads);
+        hipLaunchKernelGGL(ref_render_voxels_kernel, dim3(blocks), dim3(threads), 0, 0, viewer::internal::TreeSpec(tree), cam, opt,
+                           out.data_ptr<float>(), to_split.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
+                           to_sample.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
+                           visited.packed_accessor32<int32_t, 1, torch::RestrictPtrTraits>(), false);
+        if (hipDeviceSynchronize() != hipSuccess) return -4;
+        torch::Tensor h = out.cpu();
+        memcpy(rgba_host, h.data_ptr<float>(), n * 4 * sizeof(float));
+    } catch (const std::exception &e) {
+        fprintf(stderr, "ref_render_npz: %s\n", e.what());
+        return -1;
+    }
+    return 0;
+}
+
+int ref_render_options_size(void) { return (int)sizeof(viewer::RenderOptions); }
+
+}  // extern "C"

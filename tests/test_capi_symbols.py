@@ -1,0 +1,53 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/mnv.h declares; the ctypes
+binding covers all of them; POD structs have the layout the header promises."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "mnv.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mnv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(mnv):
+    names = header_functions()
+    assert len(names) >= 25
+    out = subprocess.run(["nm", "-D", "--defined-only", mnv.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (mnv_[a-z0-9_]+)", out))
+    missing = [n for n in names if n not in exported]
+    assert not missing, missing
+    assert set(names) == set(mnv._SIGNATURES), set(names) ^ set(mnv._SIGNATURES)
+
+
+def test_no_torch_or_oracle_in_the_abi(mnv):
+    out = subprocess.run(["ldd", mnv.LIB_PATH], capture_output=True, text=True).stdout
+    assert "torch" not in out and "oracle" not in out and "libamdhip64" in out
+
+
+def test_struct_layouts_and_defaults(mnv):
+    assert C.sizeof(mnv.RenderOptions) == 104          # reference include/render_options.hpp: 104 B by value
+    assert C.sizeof(mnv.CameraStruct) == 72 and C.sizeof(mnv.Rect) == 16 and C.sizeof(mnv.Partition) == 16
+    o = mnv.RenderOptions.defaults()                    # struct defaults, render_options.hpp:9-56
+    assert (o.step_size, o.sigma_thresh, o.stop_thresh, o.background_brightness) == (C.c_float(1e-4).value, C.c_float(1e-2).value, C.c_float(1e-2).value, 1.0)
+    assert list(o.render_bbox) == [0, 0, 0, 1, 1, 1] and list(o.basis_minmax) == [0, 24]
+    assert (o.max_depth, o.samples_per_corner, o.split_batch_size, o.nerf_batch_size, o.max_sample_count) == (16, 8, 4192, 1024, 256)
+    assert (o.appearance_embedding, o.max_guided_samples, o.grid_max_depth) == (-1, 128, 4)
+    c = mnv.RenderOptions.cli_defaults()                # src/opts.cpp:17-32
+    assert c.background_brightness == 0.0 and c.split_batch_size == 4096 and c.nerf_batch_size == 4096
+    assert mnv.lib().mnv_version() == 1
+
+
+def test_device_entry_points_fail_loudly_without_a_gpu(mnv):
+    """No CPU fallback: on a box without a HIP device the product path reports an error."""
+    import pytest
+    if mnv.device_count() > 0:
+        pytest.skip("a GPU is present")
+    t = mnv.N3Tree.synth_random(depth=2, basis_dim=1)
+    with pytest.raises(mnv.MnvError) as e:
+        t.move_to_device()
+    assert e.value.code == mnv.MNV_E_NO_DEVICE
