@@ -5,10 +5,10 @@
 //                            (rt_core.cuh:146) and the sigma half (rt_core.cuh:231):
 //                              internal: absolute index of the child chunk (1 .. 2^31-1)
 //                              leaf    : 0x80000000 | depth << 16 | sigma(binary16 bits)
-//   rows  [capacity*8][3][chan_bytes]   the colour halfs of a voxel, one block per channel, each
-//                            padded to a multiple of 8 B (18 -> 24 B for SH9, row = 72 B), so
-//                            that the lane evaluating one (sample, channel) pair fetches its
-//                            coefficients with chan_bytes/8 aligned dwordx2 loads
+//   rows  [capacity*8][row_bytes]   the colour halfs of a voxel: three channel blocks, each padded
+//                            to whole dwords (18 -> 20 B for SH9), the row rounded up to a power
+//                            of two (60 -> 64 B) so that it never straddles a 128-B line; the lane
+//                            evaluating one (sample, channel) pair loads its block's dwords
 //   grid  [2^L]^3 u32        dense top-of-tree lookup at level L = grid_level: the node
 //                            word of the depth-L voxel covering the cell, or the
 //                            (shallower) leaf word that covers it; staged in LDS

@@ -174,8 +174,21 @@ __device__ __forceinline__ uint32_t lane_read(uint32_t v, int src_lane) {
     return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
 }
 
-// bytes of one colour channel block of a packed row: basis_dim halfs padded to 8 B
-__host__ __device__ constexpr int chan_bytes_for(int basis) { return basis > 0 ? ((2 * basis + 7) / 8) * 8 : 8; }
+// bytes of one colour channel block of a packed row: basis_dim halfs padded to a whole dword
+__host__ __device__ constexpr int chan_bytes_for(int basis) { return basis > 0 ? ((2 * basis + 3) / 4) * 4 : 4; }
+// bytes of a packed row: three channel blocks rounded up to a power of two (16 ... 256), so that a
+// row never straddles a 128-B cache line (SH9: 3 * 20 = 60 -> 64 B)
+__host__ __device__ constexpr int row_bytes_pow2(int basis) {
+    if (basis <= 0) return 8;
+    int r = 16;
+    while (r < 3 * chan_bytes_for(basis)) r *= 2;
+    return r;
+}
+// channel block as dwords with 4-byte alignment (the compiler picks the widest legal loads)
+template <int N>
+struct __attribute__((packed, aligned(4))) ChanWords {
+    uint32_t w[N];
+};
 
 // One step of the march on integer cell coordinates.  pos in [0, 1-1e-6] is scaled by 2^Lq
 // (Lq = deepest voxel depth of the tree, <= 23: the product is exact and < 2^24) and truncated;
@@ -192,7 +205,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
     uint32_t *s_map = s_mem + 64;                            // BLOCK words: dense-sample rank -> lane, per wavefront
     uint32_t *s_grid = s_mem + 64 + BLOCK;                   // (2^lds_level)^3 words
     constexpr int CHAN_BYTES = chan_bytes_for(BASIS);
-    constexpr int ROW_BYTES = BASIS > 0 ? 3 * CHAN_BYTES : 8;
+    constexpr int ROW_BYTES = row_bytes_pow2(BASIS);
     const FrameParams &P = K.P;
     const AccelView &A = K.A;
 
@@ -388,14 +401,10 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                     for (int k = 0; k < NB; ++k) b[k] = lane_read(r.basis[k], owner);
                     float v = 0.f;
                     if (task) {
-                        constexpr int NW = CHAN_BYTES / 8;
-                        uint2 cw[NW];
-                        const uint2 *cp = reinterpret_cast<const uint2 *>(A.rows + (int64_t)vx * ROW_BYTES + my_c * CHAN_BYTES);
-#pragma unroll
-                        for (int i = 0; i < NW; ++i) cw[i] = cp[i];
+                        constexpr int NW = CHAN_BYTES / 4;
+                        const ChanWords<NW> cw = *reinterpret_cast<const ChanWords<NW> *>(A.rows + (int64_t)vx * ROW_BYTES + my_c * CHAN_BYTES);
                         auto coef = [&](int k) -> float {
-                            const uint2 qd = cw[k >> 2];
-                            const uint32_t wd = (k & 2) ? qd.y : qd.x;
+                            const uint32_t wd = cw.w[k >> 1];
                             return half_bits_to_float((uint16_t)((k & 1) ? (wd >> 16) : (wd & 0xffffu)));
                         };
                         const float tmp = sh_channel<BASIS>(b, coef, 0);
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
 
 // ---------------------------------------------------------------------------- host side
 
-static int row_bytes_for(int basis) { return basis > 0 ? 3 * chan_bytes_for(basis) : 8; }
+static int row_bytes_for(int basis) { return row_bytes_pow2(basis); }
 
 template <int BASIS, bool ST>
 static int launch_variant2(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
