@@ -3,6 +3,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <cassert>
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -162,6 +164,22 @@ void N3Tree::assign(const mnv_tree_view &v) {
     }
     check_sizes();
     if (v.sample_counts) sample_counts.assign(v.sample_counts, v.sample_counts + cap * N3_);
+}
+
+void N3Tree::adopt(const mnv_tree_view &meta, std::vector<uint16_t> &&data_in, std::vector<int32_t> &&child_in,
+                   std::vector<int32_t> &&parent_in) {
+    free_device();
+    N = meta.N;
+    N2_ = N * N;
+    N3_ = N * N * N;
+    data_dim = meta.data_dim;
+    data_format.format = meta.format == MNV_FORMAT_SH ? DataFormat::SH : DataFormat::RGBA;
+    data_format.basis_dim = meta.basis_dim;
+    for (int i = 0; i < 3; ++i) { scale[i] = meta.scale[i]; offset[i] = meta.offset[i]; }
+    data = std::move(data_in);
+    child = std::move(child_in);
+    parent = std::move(parent_in);
+    check_sizes();
 }
 
 namespace {

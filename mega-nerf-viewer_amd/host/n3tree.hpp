@@ -76,6 +76,9 @@ struct N3Tree {
 
     // Adopt arrays (copies); validates sizes like load_npz.
     void assign(const mnv_tree_view &host_view);
+    // Same, taking ownership of the vectors (no copy); `meta` supplies N, data_dim, format, scale, offset.
+    void adopt(const mnv_tree_view &meta, std::vector<uint16_t> &&data, std::vector<int32_t> &&child,
+               std::vector<int32_t> &&parent);
 
 private:
     int N2_ = 0, N3_ = 0;

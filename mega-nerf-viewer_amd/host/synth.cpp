@@ -2,7 +2,10 @@
 // (SURVEY.md 8(d)).  Integer-hash PRNG (splitmix64) and IEEE-only float arithmetic:
 // the same parameters give bit-identical trees on every host, so the container that
 // writes the goldens and the GPU box that checks them agree without shipping the data.
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <thread>
@@ -102,16 +105,13 @@ void finish(N3Tree &t, Builder &b, int format, int basis_dim, const float offset
             std::vector<uint16_t> &data, int data_dim) {
     mnv_tree_view v;
     std::memset(&v, 0, sizeof(v));
-    v.data = data.data();
-    v.child = b.child.data();
-    v.parent = b.parent.data();
     v.N = 2;
     v.data_dim = data_dim;
     v.format = format;
     v.basis_dim = basis_dim;
     v.capacity = (int32_t)b.parent.size();
     for (int i = 0; i < 3; ++i) { v.offset[i] = offset[i]; v.scale[i] = scale[i]; }
-    t.assign(v);
+    t.adopt(v, std::move(data), std::move(b.child), std::move(b.parent));
 }
 
 }  // namespace
@@ -146,7 +146,20 @@ void random_tree(const mnv_synth_random_params &p, N3Tree &out) {
     finish(out, b, p.format, sh ? p.basis_dim : -1, p.offset, p.scale, data, data_dim);
 }
 
+namespace {
+struct Timer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!getenv("MNV_SYNTH_TIMING")) return;
+        auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[synth] %s: %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+}  // namespace
+
 void shell_tree(const mnv_synth_shell_params &p, N3Tree &out) {
+    Timer tm;
     if (p.depth < 1 || p.depth > 14) throw std::runtime_error("synth: depth out of range");
     if (p.basis_dim < 1) throw std::runtime_error("synth: shell tree needs an SH basis");
     const int data_dim = 3 * p.basis_dim + 1;
@@ -184,9 +197,11 @@ void shell_tree(const mnv_synth_shell_params &p, N3Tree &out) {
             }
         }
     }
+    tm.lap("structure");
     const size_t nvox = b.child.size();
     dense.resize(nvox, 0);
     std::vector<uint16_t> data(nvox * data_dim, 0);
+    tm.lap("alloc");
     parallel_for(nvox, [&](size_t vox) {
         if (!dense[vox]) return;
         uint16_t *row = data.data() + vox * data_dim;
@@ -194,7 +209,9 @@ void shell_tree(const mnv_synth_shell_params &p, N3Tree &out) {
         row[data_dim - 1] = float_to_half(sigma);
         fill_row(row, MNV_FORMAT_SH, p.basis_dim, 1.0f, p.seed, vox);
     });
+    tm.lap("fill");
     finish(out, b, MNV_FORMAT_SH, p.basis_dim, p.offset, p.scale, data, data_dim);
+    tm.lap("assign");
 }
 
 }  // namespace viewer::synth
