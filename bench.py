@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--cpu-poses", type=int, default=4, help="poses rendered by the CPU baseline (bounded sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", choices=["accel", "ref_layout"], default="accel")
+    ap.add_argument("--per-frame", action="store_true", help="one launch per pose instead of one batched launch per step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,20 +90,27 @@ def main():
     setup_s = time.time() - t_setup
 
     stream = torch.cuda.current_stream(dev).cuda_stream
-    RING = 3
+    RING = 2
     if world == 1:
-        frames = [torch.empty((H, W, 4), dtype=torch.float32, device=dev) for _ in range(RING)]
+        # one launch per step: the 16 poses as a batch (frame f at frames[slot][f])
+        frames = [torch.empty((N_POSES, H, W, 4), dtype=torch.float32, device=dev) for _ in range(RING)]
         dv = tree.device_view() if args.kernel == "ref_layout" else None
-
-        def render_pose(i, slot):
-            if args.kernel == "accel":
-                mnv.render_voxels_accel(tree.accel, cams[i], opt, rgba=frames[slot], stream=stream)
-            else:
-                mnv.render_voxels(dv, cams[i], opt, rgba=frames[slot], stream=stream)
+        counter = [0]
 
         def step():
-            for i in range(N_POSES):
-                render_pose(i, i % RING)
+            slot = counter[0] % RING
+            counter[0] += 1
+            if args.kernel == "accel" and not args.per_frame:
+                mnv.render_voxels_accel_batch(tree.accel, cams, opt, rgba=frames[slot], stream=stream)
+            else:
+                for i in range(N_POSES):
+                    render_pose(i, frames[slot][i])
+
+        def render_pose(i, out):
+            if args.kernel == "accel":
+                mnv.render_voxels_accel(tree.accel, cams[i], opt, rgba=out, stream=stream)
+            else:
+                mnv.render_voxels(dv, cams[i], opt, rgba=out, stream=stream)
     else:
         from mega_nerf_viewer_amd.multigpu import TileGatherer, TilePartition
 
@@ -110,20 +118,22 @@ def main():
         n_local = part.local_tiles(rank)
         assert n_local == mnv.partition_local_tiles((0, 0, W, H), rank, world, MACRO_W, MACRO_H)
         dt = torch.float32 if args.gather == "f32" else torch.uint8
-        tg = TileGatherer(part, rank, dev, dtype=dt, depth=RING)
+        # one launch + one gather per step; the gather of step k overlaps the launch of step k + 1
+        tg = TileGatherer(part, rank, dev, dtype=dt, depth=RING, frames=N_POSES)
         frames = tg._frames if rank == 0 else None
+        counter = [0]
 
-        def render_pose(i, slot):
+        def step():
+            slot = counter[0] % RING
+            counter[0] += 1
             tg.finish(slot)  # the slot's previous gather must be done before its buffer is overwritten
             kw = dict(rgba=tg.local(slot)) if args.gather == "f32" else dict(rgba8=tg.local(slot))
             if n_local > 0:
-                mnv.render_voxels_accel_part(tree.accel, cams[i], opt, rank, world, MACRO_W, MACRO_H, stream=stream, **kw)
+                mnv.render_voxels_accel_batch(tree.accel, cams, opt, part=(rank, world, MACRO_W, MACRO_H), stream=stream, **kw)
             tg.submit(slot)
 
-        def step():
-            for i in range(N_POSES):
-                render_pose(i, i % RING)
-            tg.finish_all()
+        def render_pose(i, out):
+            mnv.render_voxels_accel(tree.accel, cams[i], opt, rgba=out, stream=stream)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -133,11 +143,15 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if world > 1:
+        tg.finish_all()
     sync_all()
     mnv.set_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if world > 1:
+        tg.finish_all()
     sync_all()
     elapsed = time.perf_counter() - t0
     kern_ms, launches = mnv.take_timing()
@@ -165,9 +179,12 @@ def main():
             r = orc.render(ot, cams[i].c, opt)
             t_cpu += time.perf_counter() - tc
             fresh[str(i)] = r["counters"].as_dict()
-            render_pose(i, 0)
+            scratch = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+            render_pose(i, scratch)
             torch.cuda.synchronize(dev)
-            gpu = frames[0].cpu().numpy()
+            gpu = scratch.cpu().numpy()
+            if world == 1 and not args.per_frame and args.kernel == "accel":  # the batched launch wrote the same frame
+                assert np.array_equal(frames[(counter[0] - 1) % RING][i].cpu().numpy().view(np.uint32), gpu.view(np.uint32))
             d = np.abs(gpu - r["rgba"])
             max_diff = max(max_diff, float(d.max()))
             n_bad += int((gpu.view(np.uint32) != r["rgba"].view(np.uint32)).any(axis=-1).sum())
@@ -180,12 +197,14 @@ def main():
     if counters is not None and launches > 0:
         poses = counters["poses"]
         mean_bytes = float(np.mean([alg_bytes(c) for c in poses.values()]))
-        per_launch = mean_bytes / world           # each rank's launch covers 1/world of a frame
+        frames_per_launch = 1 if (args.per_frame or args.kernel != "accel") and world == 1 else N_POSES
+        per_launch = mean_bytes * frames_per_launch / world   # each rank's launch covers 1/world of its frames
         avg_ms = kern_ms / launches
         achieved = per_launch / (avg_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "kernel": "march_accel_kernel<9,64,256>" if args.kernel == "accel" else "march_ref_layout_kernel<9>",
+                    "kernel": "march_accel_kernel<9,256,false>" if args.kernel == "accel" else "march_ref_layout_kernel<9>",
+                    "frames_per_launch": frames_per_launch,
                     "avg_launch_ms": round(avg_ms, 5), "launches": launches,
                     "algorithmic_bytes_per_launch": int(per_launch)}
 
@@ -204,7 +223,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "cfg2: depth-10 SH9 shell N3Tree (1,499,569 chunks), 1920x1080, 16-pose orbit per step",
-                       "rays_per_step": rays_per_step, "kernel": args.kernel,
+                       "rays_per_step": rays_per_step, "kernel": args.kernel, "launches_per_step": 1 if not args.per_frame and args.kernel == "accel" else N_POSES,
                        "partition": "none" if world == 1 else f"interleaved {MACRO_W}x{MACRO_H} macro tiles, {args.gather} RCCL gather to rank 0"},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

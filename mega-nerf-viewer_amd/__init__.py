@@ -163,6 +163,8 @@ _SIGNATURES = {
     "mnv_partition_local_tiles": (C.c_int32, [Rect, Partition]),
     "mnv_render_voxels_accel_part": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, Partition,
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mnv_render_voxels_accel_batch": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.c_int32, C.POINTER(RenderOptions), Rect,
+                                                Partition, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_set_timing": (None, [C.c_int]),
     "mnv_take_timing": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "mnv_n3tree_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -404,6 +406,22 @@ def render_voxels_accel_part(accel: int, cam: Camera, opt: RenderOptions, rank: 
         tile = (0, 0, cam.width, cam.height)
     _check(lib().mnv_render_voxels_accel_part(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile),
                                               Partition(rank, world, tile_w, tile_h), _ptr(rgba), _ptr(rgba8), C.c_void_p(stream)))
+
+
+MAX_BATCH = 64
+
+
+def render_voxels_accel_batch(accel: int, cams, opt: RenderOptions, tile=None, part=None, rgba=None, rgba8=None,
+                              stream: int = 0) -> None:
+    """Several frames (`cams`: list of Camera, same image size) in one launch; frame f is written at
+    rgba[f].  `part` = (rank, world, tile_w, tile_h) selects the interleaved macro-tile partition."""
+    n = len(cams)
+    arr = (CameraStruct * n)(*[c.c for c in cams])
+    if tile is None:
+        tile = (0, 0, cams[0].width, cams[0].height)
+    p = Partition(0, 1, 0, 0) if part is None else Partition(*part)
+    _check(lib().mnv_render_voxels_accel_batch(C.c_void_p(accel), arr, n, C.byref(opt), Rect(*tile), p, _ptr(rgba), _ptr(rgba8),
+                                               C.c_void_p(stream)))
 
 
 def set_timing(enable: bool) -> None:

@@ -13,7 +13,7 @@
 //                            word of the depth-L voxel covering the cell, or the
 //                            (shallower) leaf word that covers it; staged in LDS
 //   grid_vox [2^L]^3 u32     voxel index of that covering leaf (read for dense samples only)
-//   grid2 / grid2_vox [2^L2]^3 u32   the same two arrays at level L2 = min(max_depth-1, 8), in
+//   grid2 / grid2_vox [2^L2]^3 u32   the same two arrays at level L2 <= min(max_depth-1, 9), in
 //                            4x4x4-cell brick order; a step below the LDS grid costs one load
 //                            here plus one node load per level below L2
 // The in-leaf coordinates the march needs are frac(pos * 2^depth); x*2, floorf and
@@ -24,6 +24,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
+#include "../../include/mnv.h"
 #include "mnv_device.h"
 
 namespace mnv {
@@ -31,7 +34,9 @@ namespace mnv {
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr int kMaxGridLevel = 5;  // 32^3 * 4 B = 128 KiB of the CU's 160 KiB LDS
 constexpr int kNumQueues = 8;     // one ray queue per XCD
-constexpr int kMaxGrid2Level = 8;  // 8^8 * 4 B = 64 MiB per array (MNV_GRID2_LEVEL=9 allowed for experiments)
+constexpr int kSlots = 64;        // per-launch parameter slots in flight
+constexpr size_t kSlotBytes = (size_t)MNV_MAX_BATCH * (kNumQueues * 64 + sizeof(mnv::CamBlock));
+constexpr int kMaxGrid2Level = 9;  // 8^9 * 4 B = 512 MiB per array
 
 struct AccelView {
     const uint32_t *nodes;
@@ -59,7 +64,10 @@ struct mnv_accel {
     uint32_t *grid2 = nullptr;
     uint32_t *grid2_vox = nullptr;
     unsigned long long *stats = nullptr;  // MNV_STATS=1 diagnostics
-    uint32_t *queue = nullptr;  // kNumQueues ray-queue heads (+ pad), reset per launch
+    // per-launch slots: [n_frames][kNumQueues] ray-queue heads (64 B apart) + [n_frames] camera blocks,
+    // written on the launch stream by stage_launch_kernel; kSlots launches may be in flight
+    uint8_t *slots_dev = nullptr;
+    std::atomic<uint32_t> slot_counter{0};
     size_t bytes = 0;
     int device = 0;
     int num_cus = 0;

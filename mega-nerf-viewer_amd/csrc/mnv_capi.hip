@@ -49,15 +49,12 @@ LaunchTimer::~LaunchTimer() {
 }
 
 // ---- argument block ----------------------------------------------------------------
+void fill_camera(CamBlock &C, const mnv_camera *cam);
 int fill_params(FrameParams &P, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile) {
     if (!cam || !opt) return set_error(MNV_E_INVALID, "camera/options pointer is null");
     if (cam->width <= 0 || cam->height <= 0) return set_error(MNV_E_INVALID, "camera has no pixels");
     if (tile.w < 0 || tile.h < 0) return set_error(MNV_E_INVALID, "negative tile extent");
-    P.fx = cam->fx;
-    P.fy = cam->fy;
-    P.cx = cam->cx;
-    P.cy = cam->cy;
-    std::memcpy(P.c2w, cam->c2w, sizeof(P.c2w));
+    fill_camera(P.cam, cam);
     P.x0 = tile.x0;
     P.y0 = tile.y0;
     P.tw = tile.w;
@@ -87,11 +84,20 @@ int fill_params(FrameParams &P, const mnv_camera *cam, const mnv_render_options 
 
 // renderer_kernel.cu:272-275: cen = offset + scale * c2w[9..11]; identical for every ray, so it is
 // computed once on the host (this file is compiled with -ffp-contract=off: mul then add).
-void fill_origin(FrameParams &P) {
+void fill_origin(CamBlock &C, const float offset[3], const float scale[3]) {
     for (int i = 0; i < 3; ++i) {
-        const float prod = P.scale[i] * P.c2w[9 + i];
-        P.cen[i] = P.offset[i] + prod;
+        const float prod = scale[i] * C.c2w[9 + i];
+        C.cen[i] = offset[i] + prod;
     }
+    C.pad = 0.f;
+}
+
+void fill_camera(CamBlock &C, const mnv_camera *cam) {
+    C.fx = cam->fx;
+    C.fy = cam->fy;
+    C.cx = cam->cx;
+    C.cy = cam->cy;
+    std::memcpy(C.c2w, cam->c2w, sizeof(C.c2w));
 }
 
 static int fill_tree(MarchParams &P, const mnv_tree_view *t) {
@@ -109,7 +115,7 @@ static int fill_tree(MarchParams &P, const mnv_tree_view *t) {
     P.sample_counts = t->sample_counts;
     std::memcpy(P.offset, t->offset, sizeof(P.offset));
     std::memcpy(P.scale, t->scale, sizeof(P.scale));
-    fill_origin(P);
+    fill_origin(P.cam, P.offset, P.scale);
     P.data_dim = t->data_dim;
     P.basis_dim = t->basis_dim;
     P.format = t->format;

@@ -18,14 +18,21 @@ namespace mnv {
 
 // Per-frame part of the kernel argument block: the by-value CameraSpec / RenderOptions of the
 // reference launch (renderer_kernel.cu:431-436) plus the tree's offset/scale and the outputs.
-struct FrameParams {
-    // camera (data_spec.hpp:9-23), c2w by value
+// One camera (data_spec.hpp:9-23 CameraSpec with the c2w by value) + the tree-space ray origin
+// cen = offset + scale * c2w[9..11] (renderer_kernel.cu:272-275), which is the same for every ray of
+// the frame and therefore computed once on the host.  80 bytes, 16-byte aligned.
+struct __attribute__((aligned(16))) CamBlock {
     float fx, fy, cx, cy;
     float c2w[12];
+    float cen[3];
+    float pad;
+};
+
+struct FrameParams {
+    CamBlock cam;
     // tile of the image rendered by this launch
     int32_t x0, y0, tw, th;
     float offset[3], scale[3];
-    float cen[3];  // tree-space ray origin offset + scale * c2w[9..11] (renderer_kernel.cu:272-275), same for every ray
     // march-relevant RenderOptions (render_options.hpp:9-56)
     float step_size, sigma_thresh, stop_thresh, background_brightness;
     float render_bbox[6];
@@ -168,12 +175,12 @@ struct RaySetup {
 // rt_core.cuh:182-209.  BASIS: number of SH basis functions kept in registers
 // (1 for DC-only / RGBA).
 template <int BASIS>
-__device__ __forceinline__ void setup_ray(const FrameParams &P, int ix, int iy,
+__device__ __forceinline__ void setup_ray(const FrameParams &P, const CamBlock &C, int ix, int iy,
                                           RaySetup<(BASIS > 0 ? BASIS : 1)> &r) {
-    const float xyz0 = (ix + 0.5f - P.cx) / P.fx;
-    const float xyz1 = -(iy + 0.5f - P.cy) / P.fy;
+    const float xyz0 = (ix + 0.5f - C.cx) / C.fx;
+    const float xyz1 = -(iy + 0.5f - C.cy) / C.fy;
     const float xyz2 = -1.0f;
-    const float *m = P.c2w;
+    const float *m = C.c2w;
     float dir[3];
     dir[0] = m[0] * xyz0 + m[3] * xyz1 + m[6] * xyz2;
     dir[1] = m[1] * xyz0 + m[4] * xyz1 + m[7] * xyz2;
@@ -215,8 +222,8 @@ __device__ __forceinline__ void setup_ray(const FrameParams &P, int ix, int iy,
         r.dir[i] = dir[i];
         r.invdir[i] = (float)(1.0 / ((double)dir[i] + 1e-9));  // :189
         const double inv = (double)r.invdir[i];
-        const float t1 = (float)(((double)P.render_bbox[i] + 1e-6 - (double)P.cen[i]) * inv);
-        const float t2 = (float)(((double)P.render_bbox[i + 3] - 1e-6 - (double)P.cen[i]) * inv);
+        const float t1 = (float)(((double)P.render_bbox[i] + 1e-6 - (double)C.cen[i]) * inv);
+        const float t2 = (float)(((double)P.render_bbox[i + 3] - 1e-6 - (double)C.cen[i]) * inv);
         tmin = fmaxf(tmin, fminf(t1, t2));
         tmax = fminf(tmax, fmaxf(t1, t2));
     }

@@ -17,7 +17,8 @@ int check_hip(hipError_t e, const char *what);
 // Fill the camera / option / rodrigues part of the kernel argument block.
 int fill_params(FrameParams &P, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile);
 
-void fill_origin(FrameParams &P);
+void fill_origin(CamBlock &C, const float offset[3], const float scale[3]);
+void fill_camera(CamBlock &C, const mnv_camera *cam);
 int launch_ref_layout(const MarchParams &P, hipStream_t stream);
 int launch_background(const FrameParams &P, hipStream_t stream);
 

@@ -20,6 +20,7 @@
 //     4 MiB L2 holds the sub-trees of its own screen region; empty queues steal.
 // MFMA is not used: the inner step is pointer chasing plus a <= 75-term dot in a fixed
 // summation order (DESIGN.md "Why no MFMA").
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -127,12 +128,28 @@ __global__ void accel_build_grid2(const uint32_t *nodes, uint32_t *grid2, uint32
     grid2_vox[o] = vox;
 }
 
+// Per-launch parameters that live in device memory: zeroes the ray-queue heads of every frame and
+// stores the camera blocks (handed over by value, so no host staging buffer or copy engine is involved).
+constexpr int kStageCams = 32;
+struct StageCams {
+    CamBlock c[kStageCams];
+};
+__global__ void stage_launch_kernel(uint32_t *heads, int32_t head_words, CamBlock *dst, const StageCams cams, int32_t count) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < head_words) heads[i] = 0u;
+    if (i < count * (int32_t)(sizeof(CamBlock) / 4))
+        reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(cams.c)[i];
+}
+
 // ------------------------------------------------------------------------ march kernel
 
 struct AccelLaunch {
-    FrameParams P;   // camera, tile, options, outputs
+    FrameParams P;   // tile, options, outputs (P.cam is unused: cameras come from `cams`)
     AccelView A;
-    uint32_t *queue; // kNumQueues heads
+    const CamBlock *__restrict__ cams;  // [n_frames] device array (written by stage_launch_kernel)
+    uint32_t n_frames;
+    uint32_t frame_stride_px;  // pixels between consecutive frames in the output buffers
+    uint32_t *queue;           // [n_frames][kNumQueues] heads, 64 B apart
     uint32_t tiles_x, n_tiles;
     uint32_t band_begin[kNumQueues + 1];  // tile ranges per queue
     int32_t lds_level;                    // levels staged in LDS (<= A.grid_level)
@@ -247,10 +264,14 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
     uint32_t pix = 0;
     bool alive = false;
 
-    // ray queues: home queue first, then steal round robin
+    // ray queues: home queue first, then steal round robin; frames of a batch are walked in order,
+    // every wavefront at its own pace, so the tail of frame f overlaps the start of frame f + 1
     const uint32_t home = blockIdx.x % kNumQueues;
-    uint32_t qsel = 0;       // queues tried so far (wave-uniform)
-    bool exhausted = false;  // all queues empty (wave-uniform)
+    uint32_t qsel = 0;   // queues of the current frame tried so far (wave-uniform)
+    uint32_t frame = 0;  // frame this wavefront draws rays from (wave-uniform)
+    const CamBlock *__restrict__ Cp = K.cams;  // camera of `frame` (wave-uniform pointer: scalar loads)
+    float cen0 = Cp->cen[0], cen1 = Cp->cen[1], cen2 = Cp->cen[2];
+    uint32_t pix_base = 0;
 
     auto stat = [&](int slot, bool pred) {
         if constexpr (STATS) {
@@ -266,25 +287,44 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
         const uint64_t idle = __ballot(!alive);
         const int n_idle = __popcll(idle);
         stat(0, true);
-        if (!exhausted && n_idle >= K.refill_min) {
+        // Tile-sized refills (refill_min ~ 56 of 64 lanes) keep a wavefront's rays coherent.
+        if (frame < K.n_frames && n_idle >= K.refill_min) {
+            if (qsel >= kNumQueues) {
+                // this frame's queues are empty: finish the rays in flight, then move to the next frame
+                // (camera constants are wave-uniform, so a wavefront never mixes frames)
+                if (n_idle == 64) {
+                    frame = __builtin_amdgcn_readfirstlane(frame + 1);
+                    qsel = 0;
+                    if (frame < K.n_frames) {
+                        Cp = K.cams + frame;
+                        cen0 = Cp->cen[0];
+                        cen1 = Cp->cen[1];
+                        cen2 = Cp->cen[2];
+                        pix_base = frame * K.frame_stride_px;
+                    }
+                    continue;
+                }
+            } else {
             // ---- refill idle lanes from the ray queues
             const uint32_t q = (home + qsel) % kNumQueues;
             const uint32_t begin = K.band_begin[q] * 64u, end = K.band_begin[q + 1] * 64u;
+            const uint32_t grab = (uint32_t)n_idle;
             uint32_t base = 0;
-            if (lane == 0) base = begin + atomicAdd(&K.queue[q * 16], (uint32_t)n_idle);
+            if (lane == 0) base = begin + atomicAdd(&K.queue[(frame * kNumQueues + q) * 16], grab);
             base = __builtin_amdgcn_readfirstlane(base);
             if (base >= end) {
-                if (++qsel >= kNumQueues) exhausted = true;
+                ++qsel;
                 continue;
             }
             if (!alive) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 const uint32_t id = base + rank;
-                if (id < end) {
+                if (rank < grab && id < end) {
                     int bx, by;
                     stat(2, true);
                     if (ray_pixel(K, id, bx, by, pix)) {
-                        setup_ray<(BASIS > 0 ? BASIS : 0)>(P, P.x0 + bx, P.y0 + by, r);
+                        pix += pix_base;
+                        setup_ray<(BASIS > 0 ? BASIS : 0)>(P, *Cp, P.x0 + bx, P.y0 + by, r);
                         if constexpr (BASIS == 0)
                             r.basis[0] = (0 < P.basis_min || 0 > P.basis_max) ? 0.f : (float)0.28209479177387814;
                         o0 = o1 = o2 = 0.f;
@@ -298,9 +338,10 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                     }
                 }
             }
+            }
         }
         if (__ballot(alive) == 0) {
-            if (exhausted) break;
+            if (frame >= K.n_frames) break;
             continue;
         }
         // ---- one march step (rt_core.cuh:220-323) for every live lane
@@ -321,9 +362,11 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                 stat(4, true);
                 float pos[3];
                 uint32_t q[3];
+                pos[0] = cen0 + t * r.dir[0];
+                pos[1] = cen1 + t * r.dir[1];
+                pos[2] = cen2 + t * r.dir[2];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    pos[i] = P.cen[i] + t * r.dir[i];
                     pos[i] = fmaxf(fminf(pos[i], 1.f - 1e-6f), 0.f);
                     q[i] = (uint32_t)(pos[i] * qscale);
                 }
@@ -481,8 +524,9 @@ int32_t partition_local_tiles(mnv_rect tile, mnv_partition part) {
     return (int32_t)((total - part.rank + part.world - 1) / part.world);
 }
 
-int launch_accel(const mnv_accel *accel, const FrameParams &P, mnv_partition part, hipStream_t stream) {
-    if (P.tw <= 0 || P.th <= 0) return 0;
+int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *cams, int n_frames, mnv_partition part,
+                 hipStream_t stream) {
+    if (P.tw <= 0 || P.th <= 0 || n_frames <= 0) return 0;
     AccelLaunch K;
     std::memset(static_cast<void *>(&K), 0, sizeof(K));
     K.P = P;
@@ -509,10 +553,34 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, mnv_partition par
         // contiguous runs of micro tiles (in local macro-tile order) per queue
         for (int q = 0; q <= kNumQueues; ++q) K.band_begin[q] = (uint32_t)(((uint64_t)K.n_tiles * q) / kNumQueues);
     }
-    static std::atomic<uint32_t> slot_counter{0};
-    const uint32_t slot = slot_counter.fetch_add(1) % 64u;
-    K.queue = accel->queue + slot * (kNumQueues * 16);
-    hipError_t e = hipMemsetAsync(K.queue, 0, kNumQueues * 16 * sizeof(uint32_t), stream);
+    static const int env_queues = getenv("MNV_QUEUES") ? atoi(getenv("MNV_QUEUES")) : kNumQueues;
+    if (env_queues >= 1 && env_queues < kNumQueues) {
+        // diagnostics: fewer, larger queues (queue q of the first env_queues covers 1/env_queues of the tiles)
+        const uint32_t total = K.band_begin[kNumQueues];
+        for (int q = 0; q <= kNumQueues; ++q)
+            K.band_begin[q] = q >= env_queues ? total : (uint32_t)(((uint64_t)total * q) / env_queues);
+    }
+    // per-launch slot: zeroed queue heads for every frame + the camera blocks, staged in pinned host
+    // memory and uploaded with one asynchronous copy on the launch stream
+    K.n_frames = (uint32_t)n_frames;
+    K.frame_stride_px = part.world <= 1 ? (uint32_t)P.tw * (uint32_t)P.th
+                                        : (uint32_t)partition_local_tiles({P.x0, P.y0, P.tw, P.th}, part) * K.macro_w * K.macro_h;
+    mnv_accel *mut = const_cast<mnv_accel *>(accel);
+    const uint32_t slot = mut->slot_counter.fetch_add(1) % kSlots;
+    uint8_t *ds = accel->slots_dev + (size_t)slot * kSlotBytes;
+    const size_t heads_bytes = (size_t)n_frames * kNumQueues * 64;
+    K.queue = reinterpret_cast<uint32_t *>(ds);
+    CamBlock *dcams = reinterpret_cast<CamBlock *>(ds + heads_bytes);
+    K.cams = dcams;
+    for (int first = 0; first < n_frames; first += kStageCams) {
+        StageCams sc;
+        const int count = n_frames - first < kStageCams ? n_frames - first : kStageCams;
+        std::memcpy(sc.c, cams + first, (size_t)count * sizeof(CamBlock));
+        const int head_words = first == 0 ? (int)(heads_bytes / 4) : 0;
+        const int n_threads = std::max(head_words, count * (int)(sizeof(CamBlock) / 4));
+        hipLaunchKernelGGL(stage_launch_kernel, dim3((n_threads + 255) / 256), dim3(256), 0, stream, K.queue, head_words, dcams + first, sc, count);
+    }
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
 
     const int env_level = getenv("MNV_LDS_LEVEL") ? atoi(getenv("MNV_LDS_LEVEL")) : -1;
@@ -530,8 +598,8 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, mnv_partition par
     int blocks_per_cu = lds_level >= 5 ? 1 : 6;
     if (env_bpc > 0) blocks_per_cu = env_bpc;
     int n_blocks = accel->num_cus * blocks_per_cu;
-    const uint32_t n_waves_needed = K.n_tiles;  // one initial 8x8 tile per wave
-    if ((uint32_t)n_blocks * 4u > n_waves_needed) n_blocks = (int)((n_waves_needed + 3) / 4);
+    const uint64_t n_waves_needed = (uint64_t)K.n_tiles * (uint64_t)n_frames;  // one initial 8x8 tile per wave
+    if ((uint64_t)n_blocks * 4u > n_waves_needed) n_blocks = (int)((n_waves_needed + 3) / 4);
     if (n_blocks < 1) n_blocks = 1;
 
     const int b = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim >= 0) ? accel->view.basis_dim : -1;
@@ -582,7 +650,8 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
     if ((rc = check_hip(hipMalloc((void **)&a->rows, nvox * row_bytes), "hipMalloc(rows)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&depth, cap * 4), "hipMalloc(depth)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&changed, 4), "hipMalloc(flag)"))) return fail(rc);
-    if ((rc = check_hip(hipMalloc((void **)&a->queue, 64 * kNumQueues * 16 * sizeof(uint32_t)), "hipMalloc(queue)"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&a->slots_dev, (size_t)kSlots * kSlotBytes), "hipMalloc(slots)"))) return fail(rc);
+
     if ((rc = check_hip(hipMalloc((void **)&a->stats, 16 * sizeof(unsigned long long)), "hipMalloc(stats)"))) return fail(rc);
     if ((rc = check_hip(hipMemsetAsync(a->stats, 0, 16 * sizeof(unsigned long long), stream), "memset stats"))) return fail(rc);
 
@@ -611,10 +680,15 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
     if ((rc = check_hip(hipMalloc((void **)&a->grid, gcells * 4), "hipMalloc(grid)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&a->grid_vox, gcells * 4), "hipMalloc(grid_vox)"))) return fail(rc);
     hipLaunchKernelGGL(accel_build_grid, dim3((unsigned)((gcells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid, a->grid_vox, L);
-    // second lookup grid at level L2 = min(max_depth - 1, 8): 8^L2 words (64 MiB at level 8)
+    // second lookup grid at level L2 <= min(max_depth - 1, 9): 8^L2 words per array (64 MiB at level 8,
+    // 512 MiB at level 9).  Pick the deepest level whose two arrays stay below max(128 MiB, 2 x the packed
+    // tree): HBM is 288 GB, and every level moved into the grid removes a dependent load from deep steps
+    // (cfg2: level 8 -> 0.506 ms/frame, level 9 -> 0.471 ms/frame).
     int L2 = max_depth - 1 < kMaxGrid2Level ? max_depth - 1 : kMaxGrid2Level;
+    const int64_t budget = std::max<int64_t>((int64_t)128 << 20, 2 * (nvox * 4 + nvox * row_bytes));
+    while (L2 > L && ((int64_t)8 << (3 * L2)) > budget) --L2;
     static const int env_l2 = getenv("MNV_GRID2_LEVEL") ? atoi(getenv("MNV_GRID2_LEVEL")) : -1;
-    if (env_l2 >= 0 && env_l2 <= 9 && env_l2 < max_depth) L2 = env_l2;
+    if (env_l2 >= 0 && env_l2 <= kMaxGrid2Level && env_l2 < max_depth) L2 = env_l2;
     if (L2 <= L || L2 < 2) L2 = 0;
     int64_t g2cells = 0;
     if (L2 > 0) {
@@ -670,7 +744,8 @@ void mnv_accel_destroy(mnv_accel *a) {
     if (a->grid_vox) (void)hipFree(a->grid_vox);
     if (a->grid2) (void)hipFree(a->grid2);
     if (a->grid2_vox) (void)hipFree(a->grid2_vox);
-    if (a->queue) (void)hipFree(a->queue);
+    if (a->slots_dev) (void)hipFree(a->slots_dev);
+
     delete a;
 }
 
@@ -681,28 +756,42 @@ int32_t mnv_partition_local_tiles(mnv_rect tile, mnv_partition part) { return pa
 int mnv_render_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,
                             mnv_rect tile, float *rgba_out, uint8_t *rgba8_out, void *hip_stream) {
     const mnv_partition whole = {0, 1, 0, 0};
-    return mnv_render_voxels_accel_part(accel, cam, opt, tile, whole, rgba_out, rgba8_out, hip_stream);
+    return mnv_render_voxels_accel_batch(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, hip_stream);
 }
 
 int mnv_render_voxels_accel_part(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,
                                  mnv_rect tile, mnv_partition part, float *rgba_out, uint8_t *rgba8_out,
                                  void *hip_stream) {
+    return mnv_render_voxels_accel_batch(accel, cam, 1, opt, tile, part, rgba_out, rgba8_out, hip_stream);
+}
+
+int mnv_render_voxels_accel_batch(const mnv_accel *accel, const mnv_camera *cams, int32_t n_cams,
+                                  const mnv_render_options *opt, mnv_rect tile, mnv_partition part, float *rgba_out,
+                                  uint8_t *rgba8_out, void *hip_stream) {
     if (!accel) return set_error(MNV_E_INVALID, "accel is null");
+    if (!cams || n_cams < 1 || n_cams > MNV_MAX_BATCH) return set_error(MNV_E_INVALID, "need 1 .. MNV_MAX_BATCH cameras");
     if (part.world > 1 && (part.rank < 0 || part.rank >= part.world || part.tile_w < 8 || part.tile_h < 8 ||
                            part.tile_w % 8 || part.tile_h % 8))
         return set_error(MNV_E_INVALID, "partition needs 0 <= rank < world and macro tiles that are multiples of 8 pixels");
+    for (int i = 1; i < n_cams; ++i)
+        if (cams[i].width != cams[0].width || cams[i].height != cams[0].height)
+            return set_error(MNV_E_INVALID, "all cameras of a batch must have the same image size");
     FrameParams P;
     std::memset(&P, 0, sizeof(P));
-    int rc = fill_params(P, cam, opt, tile);
+    int rc = fill_params(P, &cams[0], opt, tile);
     if (rc) return rc;
     std::memcpy(P.offset, accel->view.offset, sizeof(P.offset));
     std::memcpy(P.scale, accel->view.scale, sizeof(P.scale));
-    fill_origin(P);
     P.rgba = rgba_out;
     P.rgba8 = rgba8_out;
+    CamBlock blocks[MNV_MAX_BATCH];
+    for (int i = 0; i < n_cams; ++i) {
+        fill_camera(blocks[i], &cams[i]);
+        fill_origin(blocks[i], P.offset, P.scale);
+    }
     hipStream_t stream = (hipStream_t)hip_stream;
     LaunchTimer timer(stream);
-    rc = launch_accel(accel, P, part, stream);
+    rc = launch_accel(accel, P, blocks, n_cams, part, stream);
     if (rc == -1000) return set_error(MNV_E_UNSUPPORTED, "unsupported basis_dim for the accel path");
     return check_hip((hipError_t)rc, "march_accel_kernel");
 }

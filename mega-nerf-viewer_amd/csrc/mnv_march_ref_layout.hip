@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void march_ref_layout_kernel(const MarchParams
 
     constexpr int NB = BASIS > 0 ? BASIS : 1;
     RaySetup<NB> r;
-    setup_ray<(BASIS > 0 ? BASIS : 0)>(P, ix, iy, r);
+    setup_ray<(BASIS > 0 ? BASIS : 0)>(P, P.cam, ix, iy, r);
     if constexpr (BASIS == 0) {  // DC only: basis[0] subject to minmax mask
         r.basis[0] = (0 < P.basis_min || 0 > P.basis_max) ? 0.f : (float)0.28209479177387814;
     }
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void march_ref_layout_kernel(const MarchParams
             float pos[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                pos[i] = P.cen[i] + t * r.dir[i];
+                pos[i] = P.cam.cen[i] + t * r.dir[i];
                 pos[i] = fmaxf(fminf(pos[i], 1.f - 1e-6f), 0.f);
             }
             int32_t chunk = 0, cidx;

@@ -47,14 +47,21 @@ class TilePartition:
         return (m % self.world) * self.j_max + m // self.world
 
     def unpermute(self, gathered: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """gathered [world, j_max, tile_h, tile_w, C] -> frame [height, width, C]."""
+        """gathered [world, j_max, tile_h, tile_w, C] -> frame [height, width, C]; with a frame dimension,
+        gathered [world, F, j_max, tile_h, tile_w, C] -> frames [F, height, width, C]."""
         c = gathered.shape[-1]
-        t = gathered.reshape(self.world * self.j_max, self.tile_h, self.tile_w, c)[self.source_index(gathered.device)]
-        t = t.view(self.macros_y, self.macros_x, self.tile_h, self.tile_w, c).permute(0, 2, 1, 3, 4)
-        frame = t.reshape(self.macros_y * self.tile_h, self.macros_x * self.tile_w, c)[: self.height, : self.width]
+        batched = gathered.dim() == 6
+        g = gathered if batched else gathered.unsqueeze(1)
+        f = g.shape[1]
+        t = g.permute(1, 0, 2, 3, 4, 5).reshape(f, self.world * self.j_max, self.tile_h, self.tile_w, c)
+        t = t[:, self.source_index(gathered.device)]
+        t = t.view(f, self.macros_y, self.macros_x, self.tile_h, self.tile_w, c).permute(0, 1, 3, 2, 4, 5)
+        frames = t.reshape(f, self.macros_y * self.tile_h, self.macros_x * self.tile_w, c)[:, : self.height, : self.width]
+        if not batched:
+            frames = frames[0]
         if out is None:
-            return frame.contiguous()
-        out.copy_(frame)
+            return frames.contiguous()
+        out.copy_(frames)
         return out
 
 
@@ -63,14 +70,17 @@ class TileGatherer:
     asynchronous gather to rank 0; ``finish(slot)`` waits for it and (on rank 0) un-permutes into
     ``frame(slot)``.  With depth >= 2 the gather of frame k overlaps the render of frame k+1."""
 
-    def __init__(self, part: TilePartition, rank: int, device, dtype=torch.float32, channels: int = 4, depth: int = 3, group=None):
+    def __init__(self, part: TilePartition, rank: int, device, dtype=torch.float32, channels: int = 4, depth: int = 3, group=None,
+                 frames: int = 0):
+        """`frames` > 0: every slot holds a batch of that many frames (one launch + one gather per batch)."""
         self.part, self.rank, self.group, self.depth = part, rank, group, depth
-        shape = (part.j_max, part.tile_h, part.tile_w, channels)
+        lead = (frames,) if frames > 0 else ()
+        shape = lead + (part.j_max, part.tile_h, part.tile_w, channels)
         self._local = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(depth)]
         self._pending = [None] * depth
         if rank == 0:
             self._gathered = [torch.empty((part.world,) + shape, dtype=dtype, device=device) for _ in range(depth)]
-            self._frames = [torch.empty((part.height, part.width, channels), dtype=dtype, device=device) for _ in range(depth)]
+            self._frames = [torch.empty(lead + (part.height, part.width, channels), dtype=dtype, device=device) for _ in range(depth)]
 
     def local(self, slot: int) -> torch.Tensor:
         return self._local[slot]

@@ -93,6 +93,17 @@ def test_gather_and_unpermute_over_gloo(mnv, orc, world, tile):
         assert ok, f"rank {rank}: {err}"
 
 
+def test_unpermute_with_frame_dimension(mnv):
+    from mega_nerf_viewer_amd.multigpu import TilePartition
+
+    part = TilePartition(100, 60, 3, 24, 16)
+    g = torch.arange(3 * 2 * part.j_max * 16 * 24 * 4, dtype=torch.float32).reshape(3, 2, part.j_max, 16, 24, 4)
+    both = part.unpermute(g)
+    assert both.shape == (2, 60, 100, 4)
+    for f in range(2):
+        assert torch.equal(both[f], part.unpermute(g[:, f].contiguous()))
+
+
 def test_partition_index_math_matches_c_abi(mnv):
     from mega_nerf_viewer_amd.multigpu import TilePartition
 

@@ -222,3 +222,36 @@ def test_cfg2_hip_kernel_vs_live_reference_build(mnv, torch_gpu, cfg2, tmp_path)
     got, _ = _render_gpu(mnv, torch_gpu, cfg2, cam, opt, "accel")
     d = np.abs(got.astype(np.float64) - ref.astype(np.float64)).max(axis=-1)
     assert (d > 1e-4).sum() == 0 and d.max() <= 1e-6, f"max|d| {d.max():.3e}, {(d > 1e-6).sum()} px > 1e-6"
+
+
+def test_cfg2_batched_launch_equals_per_frame_launches(mnv, torch_gpu, cfg2):
+    """mnv_render_voxels_accel_batch: several cameras in one launch (wavefronts walk the frames at their
+    own pace) give exactly the frames of one launch per camera -- plain and under a partition."""
+    torch = torch_gpu
+    opt = mnv.RenderOptions.cli_defaults()
+    cams = [cases.cfg2_camera(mnv, pose=p, width=960, height=544, fx=800.0) for p in (0, 5, 9, 14, 3)]
+    H, W = 544, 960
+    batch = torch.full((len(cams), H, W, 4), float("nan"), dtype=torch.float32, device="cuda")
+    batch8 = torch.zeros((len(cams), H, W, 4), dtype=torch.uint8, device="cuda")
+    mnv.render_voxels_accel_batch(cfg2.accel, cams, opt, rgba=batch, rgba8=batch8)
+    torch.cuda.synchronize()
+    b, b8 = batch.cpu().numpy(), batch8.cpu().numpy()
+    for i, cam in enumerate(cams):
+        one, one8 = _render_gpu(mnv, torch, cfg2, cam, opt, "accel", want_u8=True)
+        assert np.array_equal(cases.bits(b[i]), cases.bits(one)), i
+        assert np.array_equal(b8[i], one8), i
+    # partition: rank 1 of 3, ragged macro tiles
+    tw, th, world, rank = 200, 136, 3, 1
+    n_local = mnv.partition_local_tiles((0, 0, W, H), rank, world, tw, th)
+    pb = torch.full((len(cams), n_local, th, tw, 4), float("nan"), dtype=torch.float32, device="cuda")
+    mnv.render_voxels_accel_batch(cfg2.accel, cams, opt, part=(rank, world, tw, th), rgba=pb)
+    torch.cuda.synchronize()
+    for i, cam in enumerate(cams):
+        single = torch.full((n_local, th, tw, 4), float("nan"), dtype=torch.float32, device="cuda")
+        mnv.render_voxels_accel_part(cfg2.accel, cam, opt, rank, world, tw, th, rgba=single)
+        torch.cuda.synchronize()
+        a, s = pb[i].cpu().numpy(), single.cpu().numpy()
+        assert np.array_equal(np.isnan(a), np.isnan(s))
+        assert np.array_equal(cases.bits(np.nan_to_num(a)), cases.bits(np.nan_to_num(s))), i
+    with pytest.raises(mnv.MnvError):
+        mnv.render_voxels_accel_batch(cfg2.accel, [cams[0], cases.cfg2_camera(mnv, 0)], opt, rgba=batch)  # mixed sizes
