@@ -37,6 +37,7 @@ N_POSES = 16
 MACRO_W, MACRO_H = 128, 120          # 15 x 9 = 135 macro tiles; 15 is odd -> diagonal rank pattern
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8.0 TB/s spec
 COUNTERS_JSON = os.path.join(ROOT, "tests", "golden", "cfg2_counters.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_traffic.json")   # HBM bytes per launch from the committed PMC passes
 
 
 def load_counters():
@@ -201,8 +202,13 @@ def main():
         per_launch = mean_bytes * frames_per_launch / world   # each rank's launch covers 1/world of its frames
         avg_ms = kern_ms / launches
         achieved = per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        if os.path.exists(TRAFFIC_JSON) and world == 1 and args.kernel == "accel":
+            tj = json.load(open(TRAFFIC_JSON))
+            if tj.get("frames_per_launch") == frames_per_launch:
+                traffic = tj["hbm_bytes_per_launch"]   # PMC counters cannot be read from inside this process
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "kernel": "march_accel_kernel<9,256,false>" if args.kernel == "accel" else "march_ref_layout_kernel<9>",
                     "frames_per_launch": frames_per_launch,
                     "avg_launch_ms": round(avg_ms, 5), "launches": launches,
