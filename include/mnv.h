@@ -181,6 +181,45 @@ int mnv_render_voxels_accel_batch(const mnv_accel *accel, const mnv_camera *cams
                                   const mnv_render_options *opt, mnv_rect tile, mnv_partition part, float *rgba_out,
                                   uint8_t *rgba8_out, void *hip_stream);
 
+/* ------------------------------------------------ guided sampling kernels (BASELINE config 5) */
+
+/* Cluster grid over world y,z used to route samples to sub-module MLPs
+ * (model attributes grid_dim / min_position / range, cuda_renderer.cpp:524-539). */
+typedef struct mnv_cluster_grid {
+    int32_t grid_dim[2];
+    float min_position[3];
+    float range[3];
+} mnv_cluster_grid;
+
+/*
+ * viewer::get_samples_from_voxels (include/cuda/renderer_kernel.hpp:36-52,
+ * src/cuda/renderer_kernel.cu:329-363,439-485; rt_core.cuh:418-576), offscreen: the same march as
+ * render_voxels, but every dense step emits (z, world xyz[, view dir][, embedding]) instead of colour.
+ *   num_samples     device int16 [h*w], in/out; the caller zero-fills it (cuda_renderer.cpp:109)
+ *   samples         device float [h*w][opt->max_guided_samples][samples_dim]; only emitted rows are
+ *                   written (the caller pre-fills column 0 with -1, cuda_renderer.cpp:110)
+ *   samples_dim     4 + 3 * need_viewdir + (appearance_embedding != -1)
+ *   cluster_indices device int16 [h*w][max_guided_samples]
+ *   split_track / sample_track / visited as in mnv_render_voxels
+ */
+int mnv_get_samples_from_voxels(const mnv_tree_view *tree, const mnv_camera *cam, const mnv_render_options *opt,
+                                mnv_rect tile, float *split_track, float *sample_track, int32_t *visited,
+                                int track_visit, int16_t *num_samples, float *samples, int32_t samples_dim,
+                                int16_t *cluster_indices, const mnv_cluster_grid *grid, void *hip_stream);
+
+/*
+ * viewer::render_nerf_results (include/cuda/renderer_kernel.hpp:12-21,
+ * src/cuda/renderer_kernel.cu:294-327,365-394; rt_core.cuh:334-416), offscreen: composites
+ * per-sample network outputs along every ray.
+ *   tree          only offset/scale/format/basis_dim are read (host or device view alike)
+ *   sample_values device float [n][value_stride]; sigma is column 3 (rt_core.cuh:365)
+ *   z_vals        device float [n]
+ *   offsets       device int64 [h*w]: inclusive prefix sums of the per-ray sample counts
+ */
+int mnv_render_nerf_results(const mnv_tree_view *tree, const mnv_camera *cam, const mnv_render_options *opt,
+                            mnv_rect tile, const float *sample_values, int32_t value_stride, const float *z_vals,
+                            const int64_t *offsets, float *rgba_out, uint8_t *rgba8_out, void *hip_stream);
+
 /* Average device time (ms) of the last `mnv_render_*` launches since the
  * previous call, measured with HIP events on the launch stream when
  * mnv_set_timing(1) is active; used by bench.py for roofline.achieved. */

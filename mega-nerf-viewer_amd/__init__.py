@@ -115,6 +115,10 @@ class Partition(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("tile_w", C.c_int32), ("tile_h", C.c_int32)]
 
 
+class ClusterGrid(C.Structure):
+    _fields_ = [("grid_dim", C.c_int32 * 2), ("min_position", C.c_float * 3), ("range", C.c_float * 3)]
+
+
 class SynthRandomParams(C.Structure):
     _fields_ = [
         ("depth", C.c_int32),
@@ -165,6 +169,11 @@ _SIGNATURES = {
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_render_voxels_accel_batch": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.c_int32, C.POINTER(RenderOptions), Rect,
                                                 Partition, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mnv_get_samples_from_voxels": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32,
+                                              C.c_void_p, C.POINTER(ClusterGrid), C.c_void_p]),
+    "mnv_render_nerf_results": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
+                                          C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_set_timing": (None, [C.c_int]),
     "mnv_take_timing": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "mnv_n3tree_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -406,6 +415,27 @@ def render_voxels_accel_part(accel: int, cam: Camera, opt: RenderOptions, rank: 
         tile = (0, 0, cam.width, cam.height)
     _check(lib().mnv_render_voxels_accel_part(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile),
                                               Partition(rank, world, tile_w, tile_h), _ptr(rgba), _ptr(rgba8), C.c_void_p(stream)))
+
+
+def get_samples_from_voxels(tree_view: TreeView, cam: Camera, opt: RenderOptions, num_samples, samples, cluster_indices,
+                            grid: ClusterGrid, split_track=None, sample_track=None, visited=None, track_visit=False,
+                            tile=None, stream: int = 0) -> None:
+    """viewer::get_samples_from_voxels (reference include/cuda/renderer_kernel.hpp:36-52)."""
+    if tile is None:
+        tile = (0, 0, cam.width, cam.height)
+    _check(lib().mnv_get_samples_from_voxels(C.byref(tree_view), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(split_track),
+                                             _ptr(sample_track), _ptr(visited), int(track_visit), _ptr(num_samples), _ptr(samples),
+                                             int(samples.shape[-1]), _ptr(cluster_indices), C.byref(grid), C.c_void_p(stream)))
+
+
+def render_nerf_results(tree_view: TreeView, cam: Camera, opt: RenderOptions, sample_values, z_vals, offsets, rgba=None,
+                        rgba8=None, tile=None, stream: int = 0) -> None:
+    """viewer::render_nerf_results (reference include/cuda/renderer_kernel.hpp:12-21)."""
+    if tile is None:
+        tile = (0, 0, cam.width, cam.height)
+    _check(lib().mnv_render_nerf_results(C.byref(tree_view), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(sample_values),
+                                         int(sample_values.shape[-1]), _ptr(z_vals), _ptr(offsets), _ptr(rgba), _ptr(rgba8),
+                                         C.c_void_p(stream)))
 
 
 MAX_BATCH = 64

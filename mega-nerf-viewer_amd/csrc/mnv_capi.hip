@@ -100,7 +100,7 @@ void fill_camera(CamBlock &C, const mnv_camera *cam) {
     std::memcpy(C.c2w, cam->c2w, sizeof(C.c2w));
 }
 
-static int fill_tree(MarchParams &P, const mnv_tree_view *t) {
+int fill_tree_params(MarchParams &P, const mnv_tree_view *t) {
     if (!t) return set_error(MNV_E_INVALID, "tree view is null");
     if (t->N != 2 && t->N > 0)
         return set_error(MNV_E_UNSUPPORTED, "only N == 2 octrees are supported (the reference warns the same, n3tree.cpp:85-87)");
@@ -195,7 +195,7 @@ int mnv_render_voxels(const mnv_tree_view *tree, const mnv_camera *cam, const mn
     std::memset(static_cast<void *>(&P), 0, sizeof(P));
     int rc = fill_params(P, cam, opt, tile);
     if (rc) return rc;
-    rc = fill_tree(P, tree);
+    rc = fill_tree_params(P, tree);
     if (rc) return rc;
     if (track_visit && !visited) return set_error(MNV_E_INVALID, "track_visit set but visited is null");
     P.max_depth = opt->max_depth;

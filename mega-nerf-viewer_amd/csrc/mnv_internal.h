@@ -19,6 +19,7 @@ int fill_params(FrameParams &P, const mnv_camera *cam, const mnv_render_options 
 
 void fill_origin(CamBlock &C, const float offset[3], const float scale[3]);
 void fill_camera(CamBlock &C, const mnv_camera *cam);
+int fill_tree_params(MarchParams &P, const mnv_tree_view *t);
 int launch_ref_layout(const MarchParams &P, hipStream_t stream);
 int launch_background(const FrameParams &P, hipStream_t stream);
 

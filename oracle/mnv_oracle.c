@@ -535,3 +535,235 @@ int orc_render_voxels(const orc_tree *tree, const orc_camera *cam, const orc_opt
     }
     return 0;
 }
+
+/* ------------------------------------------------------------ guided sampling (config 5) */
+
+static void ray_gen(const orc_camera *cam, const orc_options *opt, int ix, int iy, float dir[3], float cen[3],
+                    float vdir[3]) {
+    /* screen2worlddir renderer_kernel.cu:30-38 + rodrigues :40-61 */
+    const float xyz[3] = {(ix + 0.5f - cam->cx) / cam->fx, -(iy + 0.5f - cam->cy) / cam->fy, -1.0f};
+    const float *m = cam->c2w;
+    dir[0] = m[0] * xyz[0] + m[3] * xyz[1] + m[6] * xyz[2];
+    dir[1] = m[1] * xyz[0] + m[4] * xyz[1] + m[7] * xyz[2];
+    dir[2] = m[2] * xyz[0] + m[5] * xyz[1] + m[8] * xyz[2];
+    const float invnorm = 1.f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+    dir[0] *= invnorm;
+    dir[1] *= invnorm;
+    dir[2] *= invnorm;
+    for (int i = 0; i < 3; ++i) {
+        cen[i] = m[9 + i];
+        vdir[i] = dir[i];
+    }
+    rodrigues(opt->rot_dirs, vdir);
+}
+
+int orc_get_samples_from_voxels(const orc_tree *tree, const orc_camera *cam, const orc_options *opt,
+                                float *split_track, float *sample_track, int32_t *visited, int track_visit,
+                                int16_t *num_samples, float *samples, int32_t samples_dim,
+                                int16_t *cluster_indices, const orc_cluster_grid *grid, int n_threads) {
+    if (!tree || !cam || !opt || !num_samples || !samples || !cluster_indices || !grid || tree->N <= 0) return -1;
+    const int need = 4 + (opt->need_viewdir ? 3 : 0) + (opt->appearance_embedding != -1 ? 1 : 0);
+    if (samples_dim < need) return -1;
+    const int N = tree->N, N3 = N * N * N, data_dim = tree->data_dim;
+    const int W = cam->width, H = cam->height, MG = opt->max_guided_samples;
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+    if (track_visit) n_threads = 1;
+#else
+    n_threads = 1;
+#endif
+    (void)n_threads;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads)
+    for (int iy = 0; iy < H; ++iy) {
+        for (int ix = 0; ix < W; ++ix) {
+            const int64_t idx = (int64_t)iy * W + ix;
+            float true_dir[3], true_cen[3], vdir[3];
+            ray_gen(cam, opt, ix, iy, true_dir, true_cen, vdir);
+            float trk[6] = {-1.f, -1.f, -1.f, -1.f, -1.f, -1.f};
+            trk[0] = (float)(opt->max_depth + 1);        /* rt_core.cuh:440 */
+            trk[3] = (float)(opt->max_sample_count + 1); /* :441 */
+            float cen[3];
+            for (int i = 0; i < 3; ++i) cen[i] = tree->offset[i] + tree->scale[i] * true_cen[i]; /* :443-447 */
+            float dir[3] = {true_dir[0], true_dir[1], true_dir[2]};
+            dir[0] *= tree->scale[0];
+            dir[1] *= tree->scale[1];
+            dir[2] *= tree->scale[2];
+            const float delta_scale = 1.f / sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+            dir[0] *= delta_scale;
+            dir[1] *= delta_scale;
+            dir[2] *= delta_scale;
+            float tmax_bg = 1e9f;
+            tmax_bg /= delta_scale;
+            float invdir[3];
+            for (int i = 0; i < 3; ++i) invdir[i] = (float)(1.0 / ((double)dir[i] + 1e-9));
+            float tmin = 0.0f, tmax = 1e4f;
+            for (int i = 0; i < 3; ++i) {
+                const float t1 = (float)(((double)opt->render_bbox[i] + 1e-6 - (double)cen[i]) * (double)invdir[i]);
+                const float t2 = (float)(((double)opt->render_bbox[i + 3] - 1e-6 - (double)cen[i]) * (double)invdir[i]);
+                tmin = fmaxf_(tmin, fminf_(t1, t2));
+                tmax = fminf_(tmax, fmaxf_(t1, t2));
+            }
+            tmax = fminf_(tmax, tmax_bg);
+            int16_t ns = num_samples[idx];
+            if (!(tmax < 0 || tmin > tmax)) {
+                float light_intensity = 1.f, t = tmin, max_weight = -1, max_sample_weight = -1;
+                while (t < tmax) {
+                    float pos[3];
+                    for (int i = 0; i < 3; ++i) {
+                        pos[i] = cen[i] + t * dir[i];
+                        pos[i] = fmaxf_(fminf_(pos[i], 1.f - 1e-6f), 0.f);
+                    }
+                    int32_t chunk = 0, child_idx = 0;
+                    int depth = 1;
+                    for (;;) {
+                        if (track_visit && visited && visited[chunk] == 0) visited[chunk] = 1;
+                        int cur = 0;
+                        for (int i = 0; i < 3; ++i) {
+                            pos[i] *= (float)N;
+                            const float f = floorf(pos[i]);
+                            cur = (int)((float)(cur * N) + f);
+                            pos[i] -= f;
+                        }
+                        const int32_t skip = tree->child[(int64_t)chunk * N3 + cur];
+                        if (skip == 0) { child_idx = cur; break; }
+                        depth += 1;
+                        chunk += skip;
+                    }
+                    float cube_size = 1.f;
+                    for (int i = 0; i < depth; ++i) cube_size *= (float)N;
+                    float tu = 1e4f;
+                    for (int i = 0; i < 3; ++i) {
+                        const float t1 = -pos[i] * invdir[i];
+                        const float t2 = t1 + invdir[i];
+                        tu = fminf_(tu, fmaxf_(t1, t2));
+                    }
+                    const float delta_t = tu / cube_size + opt->step_size;
+                    const float sigma = orc_half_to_float(tree->data[((int64_t)chunk * N3 + child_idx) * data_dim + data_dim - 1]);
+                    const int16_t sc = tree->sample_counts ? tree->sample_counts[(int64_t)chunk * N3 + child_idx] : 0;
+                    if (sigma > opt->sigma_thresh) {
+                        const float att = orc_expf(-delta_t * delta_scale * sigma);
+                        const float weight = light_intensity * (1.f - att);
+                        if (weight > max_weight && depth < opt->max_depth) {
+                            trk[1] = (float)chunk; trk[2] = (float)child_idx; trk[0] = (float)depth;
+                            max_weight = weight;
+                        }
+                        if (tree->sample_counts && weight > max_sample_weight && sc < opt->max_sample_count) {
+                            trk[4] = (float)chunk; trk[5] = (float)child_idx; trk[3] = (float)sc;
+                            max_sample_weight = weight;
+                        }
+                        if (ns < MG) { /* rt_core.cuh:508-549 */
+                            float *row = samples + (idx * MG + ns) * samples_dim;
+                            float tz[3];
+                            for (int i = 0; i < 3; ++i) tz[i] = t * dir[i] / tree->scale[i];
+                            row[0] = sqrtf(tz[0] * tz[0] + tz[1] * tz[1] + tz[2] * tz[2]);
+                            row[1] = true_cen[0] + true_dir[0] * row[0];
+                            row[2] = true_cen[1] + true_dir[1] * row[0];
+                            row[3] = true_cen[2] + true_dir[2] * row[0];
+                            if (opt->need_viewdir) {
+                                row[4] = vdir[0]; row[5] = vdir[1]; row[6] = vdir[2];
+                                if (opt->appearance_embedding != -1) row[7] = (float)opt->appearance_embedding;
+                            } else if (opt->appearance_embedding != -1) {
+                                row[4] = (float)opt->appearance_embedding;
+                            }
+                            const int g1 = (int)fmaxf(fminf((row[2] - grid->min_position[1]) / grid->range[1] * (float)grid->grid_dim[0],
+                                                            (float)grid->grid_dim[0] - 1.0f), 0.0f);
+                            const int g2 = (int)fmaxf(fminf((row[3] - grid->min_position[2]) / grid->range[2] * (float)grid->grid_dim[1],
+                                                            (float)grid->grid_dim[1] - 1.0f), 0.0f);
+                            cluster_indices[idx * MG + ns] = (int16_t)(g1 * grid->grid_dim[1] + g2);
+                            ns += 1;
+                        }
+                        light_intensity *= att;
+                        if (light_intensity < opt->stop_thresh) break;
+                    } else {
+                        if (max_weight == -1 && depth < opt->max_depth) {
+                            trk[1] = (float)chunk; trk[2] = (float)child_idx; trk[0] = (float)depth;
+                        }
+                        if (tree->sample_counts && max_sample_weight == -1 && sc < opt->max_sample_count) {
+                            trk[4] = (float)chunk; trk[5] = (float)child_idx; trk[3] = (float)sc;
+                        }
+                    }
+                    t += delta_t;
+                }
+            }
+            num_samples[idx] = ns;
+            if (split_track) memcpy(split_track + idx * 3, trk, 3 * sizeof(float));
+            if (sample_track) memcpy(sample_track + idx * 3, trk + 3, 3 * sizeof(float));
+        }
+    }
+    return 0;
+}
+
+int orc_render_nerf_results(const orc_tree *tree, const orc_camera *cam, const orc_options *opt,
+                            const float *sample_values, int32_t value_stride, const float *z_vals,
+                            const int64_t *offsets, float *rgba, uint8_t *rgba8, int n_threads) {
+    if (!tree || !cam || !opt || !offsets || value_stride < 4) return -1;
+    const int W = cam->width, H = cam->height, basis_dim = tree->basis_dim;
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+    n_threads = 1;
+#endif
+    (void)n_threads;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads)
+    for (int iy = 0; iy < H; ++iy) {
+        for (int ix = 0; ix < W; ++ix) {
+            const int64_t idx = (int64_t)iy * W + ix;
+            float dir[3], cen[3], vdir[3], out[4] = {0.f, 0.f, 0.f, 1.0f}; /* renderer_kernel.cu:315-316 */
+            ray_gen(cam, opt, ix, iy, dir, cen, vdir);
+            const int64_t start = idx == 0 ? 0 : offsets[idx - 1], end = offsets[idx];
+            if (start != end) { /* rt_core.cuh:344-346 */
+                float basis_fn[ORC_BASIS_MAX];
+                if (tree->format == 1) orc_sh_basis(basis_dim, vdir, basis_fn);
+                else for (int i = 0; i < ORC_BASIS_MAX; ++i) basis_fn[i] = 0.f;
+                for (int i = 0; i < opt->basis_minmax[0] && i < ORC_BASIS_MAX; ++i) basis_fn[i] = 0.f;
+                for (int i = opt->basis_minmax[1] + 1; i < ORC_BASIS_MAX; ++i) if (i >= 0) basis_fn[i] = 0.f;
+                float ti = 1, weight_component = 0.f, weight;
+                for (int64_t i = start; i < end; i++) {
+                    const float *sv = sample_values + i * value_stride;
+                    if (i < end - 1) {
+                        const float delta_i = z_vals[i + 1] - z_vals[i];
+                        weight_component = orc_expf(-sv[3] * delta_i);
+                        weight = ti * (1.0f - weight_component);
+                    } else {
+                        weight = ti;
+                    }
+                    if (opt->render_depth) {
+                        out[0] += weight * ti; /* sic, rt_core.cuh:372 */
+                    } else if (basis_dim >= 0) {
+                        int off = 0;
+#define MB(k) (basis_fn[k] * sv[off + (k)])
+                        for (int c = 0; c < 3; ++c) {
+                            float tmp = basis_fn[0] * sv[off];
+                            switch (basis_dim) {
+                                case 25: tmp += MB(16) + MB(17) + MB(18) + MB(19) + MB(20) + MB(21) + MB(22) + MB(23) + MB(24); /* fallthrough */
+                                case 16: tmp += MB(9) + MB(10) + MB(11) + MB(12) + MB(13) + MB(14) + MB(15); /* fallthrough */
+                                case 9: tmp += MB(4) + MB(5) + MB(6) + MB(7) + MB(8); /* fallthrough */
+                                case 4: tmp += MB(1) + MB(2) + MB(3);
+                            }
+                            out[c] += weight / (1.f + orc_expf(-tmp));
+                            off += basis_dim;
+                        }
+#undef MB
+                    } else {
+                        for (int j = 0; j < 3; ++j) out[j] += weight * sv[j];
+                    }
+                    ti *= weight_component;
+                }
+                if (opt->render_depth) out[0] = out[1] = out[2] = fminf_(out[0] * 0.3f, 1.0f);
+            }
+            const float nalpha = 1.f - out[3];
+            const float remain = opt->background_brightness * nalpha;
+            out[0] += remain;
+            out[1] += remain;
+            out[2] += remain;
+            if (rgba) memcpy(rgba + idx * 4, out, sizeof(out));
+            if (rgba8) {
+                rgba8[idx * 4 + 0] = pack_u8(out[0]);
+                rgba8[idx * 4 + 1] = pack_u8(out[1]);
+                rgba8[idx * 4 + 2] = pack_u8(out[2]);
+                rgba8[idx * 4 + 3] = 255;
+            }
+        }
+    }
+    return 0;
+}

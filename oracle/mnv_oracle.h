@@ -132,6 +132,35 @@ int orc_render_voxels(const orc_tree *tree, const orc_camera *cam, const orc_opt
                       int32_t *visited, int track_visit,
                       int32_t *steps_out, orc_counters *ctr, int n_threads);
 
+/* Cluster grid of the guided-sampling path (cuda_renderer.cpp:524-539 model attributes). */
+typedef struct {
+    int32_t grid_dim[2];
+    float min_position[3];
+    float range[3];
+} orc_cluster_grid;
+
+/*
+ * get_samples_from_voxels_kernel + get_samples_trace_ray (renderer_kernel.cu:329-363,
+ * rt_core.cuh:418-576), offscreen (t_max = 1e9).  Full frame.
+ *   num_samples     [h*w] int16, in/out (the caller zero-fills, cuda_renderer.cpp:109)
+ *   samples         [h*w][max_guided_samples][samples_dim] float; only emitted rows are written
+ *   cluster_indices [h*w][max_guided_samples] int16
+ *   trackers / visited as in orc_render_voxels (full frame, may be NULL)
+ */
+int orc_get_samples_from_voxels(const orc_tree *tree, const orc_camera *cam, const orc_options *opt,
+                                float *split_track, float *sample_track, int32_t *visited, int track_visit,
+                                int16_t *num_samples, float *samples, int32_t samples_dim,
+                                int16_t *cluster_indices, const orc_cluster_grid *grid, int n_threads);
+
+/*
+ * render_nerf_results_kernel + composite_nerf_results (renderer_kernel.cu:294-327, rt_core.cuh:334-416),
+ * offscreen composite.  sample_values [n][value_stride] float, z_vals [n], offsets [h*w] inclusive
+ * prefix sums of the per-ray sample counts (torch::cumsum, cuda_renderer.cpp:116).
+ */
+int orc_render_nerf_results(const orc_tree *tree, const orc_camera *cam, const orc_options *opt,
+                            const float *sample_values, int32_t value_stride, const float *z_vals,
+                            const int64_t *offsets, float *rgba, uint8_t *rgba8, int n_threads);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

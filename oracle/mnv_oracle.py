@@ -39,6 +39,10 @@ class OrcCounters(C.Structure):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
 
 
+class OrcClusterGrid(C.Structure):
+    _fields_ = [("grid_dim", C.c_int32 * 2), ("min_position", C.c_float * 3), ("range", C.c_float * 3)]
+
+
 _lib = None
 
 
@@ -68,6 +72,13 @@ def lib():
                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_void_p, C.POINTER(OrcCounters), C.c_int]
+        h.orc_get_samples_from_voxels.restype = C.c_int
+        h.orc_get_samples_from_voxels.argtypes = [C.POINTER(OrcTree), C.POINTER(OrcCamera), C.POINTER(OrcOptions), C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                                  C.POINTER(OrcClusterGrid), C.c_int]
+        h.orc_render_nerf_results.restype = C.c_int
+        h.orc_render_nerf_results.argtypes = [C.POINTER(OrcTree), C.POINTER(OrcCamera), C.POINTER(OrcOptions), C.c_void_p, C.c_int32,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib = h
     return _lib
 
@@ -114,3 +125,39 @@ def render(tree: OrcTree, cam_struct, opt_struct, tile=None, *, want_rgba8=False
 
 def algorithmic_bytes(ctr: OrcCounters, fmt: int, basis_dim: int) -> int:
     return int(lib().orc_algorithmic_bytes(C.byref(ctr), fmt, basis_dim))
+
+
+def get_samples(tree: OrcTree, cam_struct, opt_struct, grid_struct, samples_dim, visited=None, track_visit=False, n_threads=0):
+    """orc_get_samples_from_voxels on a full frame.  Buffers are initialised the way the reference's
+    host code does (num_samples = 0, samples column 0 = -1, trackers = -1)."""
+    cam = _copy_struct(OrcCamera(), cam_struct)
+    opt = _copy_struct(OrcOptions(), opt_struct)
+    grid = _copy_struct(OrcClusterGrid(), grid_struct)
+    n, mg = cam.width * cam.height, opt.max_guided_samples
+    num = np.zeros(n, np.int16)
+    samples = np.full((n, mg, samples_dim), -1, np.float32)
+    clusters = np.full((n, mg), -1, np.int16)
+    split = np.full((n, 3), -1, np.float32)
+    sample = np.full((n, 3), -1, np.float32)
+    rc = lib().orc_get_samples_from_voxels(C.byref(tree), C.byref(cam), C.byref(opt), split.ctypes.data, sample.ctypes.data,
+                                           visited.ctypes.data if visited is not None else None, int(track_visit), num.ctypes.data,
+                                           samples.ctypes.data, samples_dim, clusters.ctypes.data, C.byref(grid), n_threads)
+    if rc != 0:
+        raise RuntimeError("orc_get_samples_from_voxels: invalid arguments")
+    return dict(num_samples=num, samples=samples, cluster_indices=clusters, split=split, sample=sample)
+
+
+def render_nerf_results(tree: OrcTree, cam_struct, opt_struct, sample_values, z_vals, offsets, want_rgba8=False, n_threads=0):
+    cam = _copy_struct(OrcCamera(), cam_struct)
+    opt = _copy_struct(OrcOptions(), opt_struct)
+    sample_values = np.ascontiguousarray(sample_values, np.float32)
+    z_vals = np.ascontiguousarray(z_vals, np.float32)
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    rgba = np.empty((cam.height, cam.width, 4), np.float32)
+    rgba8 = np.empty((cam.height, cam.width, 4), np.uint8) if want_rgba8 else None
+    rc = lib().orc_render_nerf_results(C.byref(tree), C.byref(cam), C.byref(opt), sample_values.ctypes.data, sample_values.shape[-1],
+                                       z_vals.ctypes.data, offsets.ctypes.data, rgba.ctypes.data,
+                                       rgba8.ctypes.data if want_rgba8 else None, n_threads)
+    if rc != 0:
+        raise RuntimeError("orc_render_nerf_results: invalid arguments")
+    return dict(rgba=rgba, rgba8=rgba8)
