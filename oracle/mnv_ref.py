@@ -48,3 +48,44 @@ def render_npz(npz_path, cam_struct, opt_struct, n_probe=4096, contract=False):
     if rc != 0:
         raise RuntimeError(f"ref_render_npz failed with {rc}")
     return dict(rgba=rgba, data_probe=dp, child_probe=cp, parent_probe=pp, meta=list(meta))
+
+
+def _cam_args(cam_struct):
+    return (cam_struct.width, cam_struct.height, cam_struct.fx, cam_struct.fy, cam_struct.cx, cam_struct.cy,
+            (C.c_float * 12)(*list(cam_struct.c2w)))
+
+
+def get_samples_npz(npz_path, cam_struct, opt_struct, grid_struct, samples_dim):
+    """The reference's get_samples_trace_ray (rt_core.cuh:418-576) on the device, full frame."""
+    h = lib()
+    h.ref_get_samples_npz.restype = C.c_int
+    n, mg = cam_struct.width * cam_struct.height, opt_struct.max_guided_samples
+    num = np.zeros(n, np.int16)
+    samples = np.empty((n, mg, samples_dim), np.float32)
+    clusters = np.empty((n, mg), np.int16)
+    w, ht, fx, fy, cx, cy, c2w = _cam_args(cam_struct)
+    rc = h.ref_get_samples_npz(os.fsencode(npz_path), C.c_int(w), C.c_int(ht), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), c2w,
+                               C.byref(opt_struct), C.c_int(C.sizeof(opt_struct)), (C.c_int32 * 2)(*list(grid_struct.grid_dim)),
+                               (C.c_float * 3)(*list(grid_struct.min_position)), (C.c_float * 3)(*list(grid_struct.range)),
+                               C.c_int(samples_dim), C.c_void_p(num.ctypes.data), C.c_void_p(samples.ctypes.data), C.c_void_p(clusters.ctypes.data))
+    if rc != 0:
+        raise RuntimeError(f"ref_get_samples_npz failed with {rc}")
+    return dict(num_samples=num, samples=samples, cluster_indices=clusters)
+
+
+def render_nerf_results_npz(npz_path, cam_struct, opt_struct, sample_values, z_vals, offsets):
+    """The reference's composite_nerf_results (rt_core.cuh:334-416) on the device, full frame."""
+    h = lib()
+    h.ref_render_nerf_results_npz.restype = C.c_int
+    sample_values = np.ascontiguousarray(sample_values, np.float32)
+    z_vals = np.ascontiguousarray(z_vals, np.float32)
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    rgba = np.empty((cam_struct.height, cam_struct.width, 4), np.float32)
+    w, ht, fx, fy, cx, cy, c2w = _cam_args(cam_struct)
+    rc = h.ref_render_nerf_results_npz(os.fsencode(npz_path), C.c_int(w), C.c_int(ht), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+                                       c2w, C.byref(opt_struct), C.c_int(C.sizeof(opt_struct)), C.c_void_p(sample_values.ctypes.data),
+                                       C.c_int64(sample_values.shape[0]), C.c_int(sample_values.shape[1]), C.c_void_p(z_vals.ctypes.data),
+                                       C.c_void_p(offsets.ctypes.data), C.c_void_p(rgba.ctypes.data))
+    if rc != 0:
+        raise RuntimeError(f"ref_render_nerf_results_npz failed with {rc}")
+    return rgba

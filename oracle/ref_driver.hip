@@ -89,6 +89,53 @@ __global__ void ref_render_voxels_kernel(const internal::TreeSpec tree, const Ca
     rgba[idx * 4 + 3] = out[3];
 }
 
+// restated wrapper of get_samples_from_voxels_kernel (renderer_kernel.cu:329-363), offscreen
+__global__ void ref_get_samples_kernel(internal::TreeSpec tree, const CamPOD cam, const RenderOptions opt,
+                                       torch::PackedTensorAccessor32<float, 2, torch::RestrictPtrTraits> to_split,
+                                       torch::PackedTensorAccessor32<float, 2, torch::RestrictPtrTraits> to_sample,
+                                       torch::PackedTensorAccessor32<int32_t, 1, torch::RestrictPtrTraits> visited,
+                                       torch::PackedTensorAccessor32<short, 1, torch::RestrictPtrTraits> num_samples,
+                                       torch::PackedTensorAccessor64<float, 3, torch::RestrictPtrTraits> samples,
+                                       torch::PackedTensorAccessor64<short, 2, torch::RestrictPtrTraits> cluster_indices,
+                                       const torch::PackedTensorAccessor32<int32_t, 1, torch::RestrictPtrTraits> grid_dim,
+                                       const torch::PackedTensorAccessor32<float, 1, torch::RestrictPtrTraits> min_position,
+                                       const torch::PackedTensorAccessor32<float, 1, torch::RestrictPtrTraits> range) {
+    CUDA_GET_THREAD_ID(idx, cam.width * cam.height);
+    const int x = idx % cam.width, y = idx / cam.width;
+    float dir[3], cen[3];
+    ref_screen2worlddir(x, y, cam, dir, cen);
+    float vdir[3] = {dir[0], dir[1], dir[2]};
+    float aa[3] = {opt.rot_dirs[0], opt.rot_dirs[1], opt.rot_dirs[2]};
+    ref_rodrigues(aa, vdir);
+    float t_max = 1e9f;
+    device::get_samples_trace_ray(tree, visited, dir, vdir, cen, opt, t_max, &to_split[idx][1], &to_split[idx][2],
+                                  &to_split[idx][0], &to_sample[idx][1], &to_sample[idx][2], &to_sample[idx][0], false,
+                                  &num_samples[idx], samples, cluster_indices, idx, grid_dim, min_position, range);
+}
+
+// restated wrapper of render_nerf_results_kernel (renderer_kernel.cu:294-327), offscreen composite
+__global__ void ref_render_nerf_kernel(const internal::TreeSpec tree, const CamPOD cam, const RenderOptions opt, float *rgba,
+                                       const torch::PackedTensorAccessor64<float, 2, torch::RestrictPtrTraits> sample_values,
+                                       const torch::PackedTensorAccessor64<float, 1, torch::RestrictPtrTraits> z_vals,
+                                       const torch::PackedTensorAccessor32<int64_t, 1, torch::RestrictPtrTraits> offsets) {
+    CUDA_GET_THREAD_ID(idx, cam.width * cam.height);
+    const int x = idx % cam.width, y = idx / cam.width;
+    float dir[3], cen[3], out[4];
+    out[0] = out[1] = out[2] = 0.f;
+    out[3] = 1.0f;
+    ref_screen2worlddir(x, y, cam, dir, cen);
+    float vdir[3] = {dir[0], dir[1], dir[2]};
+    float aa[3] = {opt.rot_dirs[0], opt.rot_dirs[1], opt.rot_dirs[2]};
+    ref_rodrigues(aa, vdir);
+    device::composite_nerf_results(tree, vdir, opt, (idx == 0 ? 0 : offsets[idx - 1]), offsets[idx], sample_values, z_vals, out);
+    const float nalpha = 1.f - out[3];
+    const float remain = opt.background_brightness * nalpha;
+    rgba[idx * 4 + 0] = out[0] + remain;
+    rgba[idx * 4 + 1] = out[1] + remain;
+    rgba[idx * 4 + 2] = out[2] + remain;
+    rgba[idx * 4 + 3] = out[3];
+}
+
 }  // namespace
 }  // namespace viewer
 
@@ -150,6 +197,92 @@ int ref_render_npz(const char *npz_path, int width, int height, float fx, float 
         memcpy(rgba_host, h.data_ptr<float>(), n * 4 * sizeof(float));
     } catch (const std::exception &e) {
         fprintf(stderr, "ref_render_npz: %s\n", e.what());
+        return -1;
+    }
+    return 0;
+}
+
+// The reference's get_samples_trace_ray on the tree in `npz_path` (full frame, offscreen).
+int ref_get_samples_npz(const char *npz_path, int width, int height, float fx, float fy, float cx, float cy, const float *c2w12,
+                        const void *opt_bytes, int opt_size, const int32_t *grid_dim2, const float *min_position3,
+                        const float *range3, int samples_dim, int16_t *num_samples_host, float *samples_host,
+                        int16_t *cluster_host) {
+    using namespace viewer;
+    if (opt_size != (int)sizeof(RenderOptions)) return -2;
+    RenderOptions opt;
+    memcpy(&opt, opt_bytes, sizeof(opt));
+    try {
+        N3Tree tree;
+        tree.open(npz_path);
+        if (tree.N == 0) return -3;
+        tree.move_to_device(tree.capacity, true, true);
+        tree.sample_counts.fill_(8);
+        CamPOD cam = {width, height, fx, fy, cx, cy, {}};
+        memcpy(cam.transform, c2w12, sizeof(cam.transform));
+        const int64_t n = (int64_t)width * height;
+        auto dev = torch::kCUDA;
+        auto fopt = torch::TensorOptions().device(dev).dtype(torch::kFloat32);
+        torch::Tensor to_split = torch::full({n, 3}, -1.f, fopt), to_sample = torch::full({n, 3}, -1.f, fopt);
+        torch::Tensor visited = torch::zeros({tree.capacity}, torch::TensorOptions().device(dev).dtype(torch::kInt32));
+        torch::Tensor num_samples = torch::zeros({n}, torch::TensorOptions().device(dev).dtype(torch::kInt16));
+        torch::Tensor samples = torch::full({n, (int64_t)opt.max_guided_samples, (int64_t)samples_dim}, -1.f, fopt);
+        torch::Tensor clusters = torch::full({n, (int64_t)opt.max_guided_samples}, -1, torch::TensorOptions().device(dev).dtype(torch::kInt16));
+        torch::Tensor gd = torch::from_blob((void *)grid_dim2, {2}, torch::kInt32).clone().to(dev);
+        torch::Tensor mp = torch::from_blob((void *)min_position3, {3}, torch::kFloat32).clone().to(dev);
+        torch::Tensor rg = torch::from_blob((void *)range3, {3}, torch::kFloat32).clone().to(dev);
+        const int threads = 512, blocks = N_BLOCKS_NEEDED(n, threads);
+        hipLaunchKernelGGL(ref_get_samples_kernel, dim3(blocks), dim3(threads), 0, 0, viewer::internal::TreeSpec(tree), cam, opt,
+                           to_split.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
+                           to_sample.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
+                           visited.packed_accessor32<int32_t, 1, torch::RestrictPtrTraits>(),
+                           num_samples.packed_accessor32<short, 1, torch::RestrictPtrTraits>(),
+                           samples.packed_accessor64<float, 3, torch::RestrictPtrTraits>(),
+                           clusters.packed_accessor64<short, 2, torch::RestrictPtrTraits>(),
+                           gd.packed_accessor32<int32_t, 1, torch::RestrictPtrTraits>(),
+                           mp.packed_accessor32<float, 1, torch::RestrictPtrTraits>(),
+                           rg.packed_accessor32<float, 1, torch::RestrictPtrTraits>());
+        if (hipDeviceSynchronize() != hipSuccess) return -4;
+        memcpy(num_samples_host, num_samples.cpu().data_ptr(), n * 2);
+        memcpy(samples_host, samples.cpu().data_ptr(), n * opt.max_guided_samples * samples_dim * 4);
+        memcpy(cluster_host, clusters.cpu().data_ptr(), n * opt.max_guided_samples * 2);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "ref_get_samples_npz: %s\n", e.what());
+        return -1;
+    }
+    return 0;
+}
+
+// The reference's composite_nerf_results; the tree in `npz_path` supplies format / basis_dim.
+int ref_render_nerf_results_npz(const char *npz_path, int width, int height, float fx, float fy, float cx, float cy,
+                                const float *c2w12, const void *opt_bytes, int opt_size, const float *sample_values,
+                                int64_t n_samples, int value_stride, const float *z_vals, const int64_t *offsets,
+                                float *rgba_host) {
+    using namespace viewer;
+    if (opt_size != (int)sizeof(RenderOptions)) return -2;
+    RenderOptions opt;
+    memcpy(&opt, opt_bytes, sizeof(opt));
+    try {
+        N3Tree tree;
+        tree.open(npz_path);
+        if (tree.N == 0) return -3;
+        tree.move_to_device(tree.capacity, true, true);
+        CamPOD cam = {width, height, fx, fy, cx, cy, {}};
+        memcpy(cam.transform, c2w12, sizeof(cam.transform));
+        const int64_t n = (int64_t)width * height;
+        auto dev = torch::kCUDA;
+        torch::Tensor sv = torch::from_blob((void *)sample_values, {n_samples, (int64_t)value_stride}, torch::kFloat32).clone().to(dev);
+        torch::Tensor zv = torch::from_blob((void *)z_vals, {n_samples}, torch::kFloat32).clone().to(dev);
+        torch::Tensor of = torch::from_blob((void *)offsets, {n}, torch::kInt64).clone().to(dev);
+        torch::Tensor out = torch::zeros({n, 4}, torch::TensorOptions().device(dev).dtype(torch::kFloat32));
+        const int threads = 512, blocks = N_BLOCKS_NEEDED(n, threads);
+        hipLaunchKernelGGL(ref_render_nerf_kernel, dim3(blocks), dim3(threads), 0, 0, viewer::internal::TreeSpec(tree), cam, opt,
+                           out.data_ptr<float>(), sv.packed_accessor64<float, 2, torch::RestrictPtrTraits>(),
+                           zv.packed_accessor64<float, 1, torch::RestrictPtrTraits>(),
+                           of.packed_accessor32<int64_t, 1, torch::RestrictPtrTraits>());
+        if (hipDeviceSynchronize() != hipSuccess) return -4;
+        memcpy(rgba_host, out.cpu().data_ptr(), n * 16);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "ref_render_nerf_results_npz: %s\n", e.what());
         return -1;
     }
     return 0;

@@ -86,6 +86,33 @@ def main(outdir):
                                 meta=np.int32(ref["meta"]))
         os.remove(path)
         del tree
+    # ---- guided-sampling pair (rt_core.cuh:334-576) against the reference's own device functions
+    import guided_cases
+    tree, cam, opt, dim = guided_cases.get_samples_setup(mnv)
+    path = os.path.join(tmp, "guided.npz")
+    tree.save_npz(path)
+    grid = guided_cases.cluster_grid(mnv.ClusterGrid)
+    ref = mnv_ref.get_samples_npz(path, cam.c, opt, grid, dim)
+    o = orc.get_samples(orc.tree_from_view(tree.host_view()), cam.c, opt, grid, dim)
+    k = np.arange(opt.max_guided_samples)[None, :] < ref["num_samples"][:, None]   # emitted rows only
+    stats["guided_get_samples"] = {
+        "num_samples_equal": bool(np.array_equal(ref["num_samples"], o["num_samples"])),
+        "clusters_equal": bool(np.array_equal(ref["cluster_indices"][k], o["cluster_indices"][k])),
+        "samples_max_abs": float(np.abs(ref["samples"][k].astype(np.float64) - o["samples"][k].astype(np.float64)).max()),
+        "samples_not_bit_identical": int((ref["samples"][k].view(np.uint32) != o["samples"][k].view(np.uint32)).sum()),
+        "total_samples": int(ref["num_samples"].astype(np.int64).sum())}
+    print("guided_get_samples", stats["guided_get_samples"], flush=True)
+    np.savez_compressed(os.path.join(outdir, "ref_guided_get_samples.npz"), num_samples=ref["num_samples"],
+                        samples=np.where(k[..., None], ref["samples"], np.float32(-1)), cluster_indices=np.where(k, ref["cluster_indices"], -1).astype(np.int16))
+    for case in ("sh4_d6", "rgba_d5"):
+        tree, cam, opt, values, z, offsets = guided_cases.nerf_results_setup(mnv, case)
+        path = os.path.join(tmp, f"guided_{case}.npz")
+        tree.save_npz(path)
+        refimg = mnv_ref.render_nerf_results_npz(path, cam.c, opt, values, z, offsets)
+        oimg = orc.render_nerf_results(orc.tree_from_view(tree.host_view()), cam.c, opt, values, z, offsets)["rgba"]
+        stats[f"guided_nerf_results_{case}"] = {"oracle_vs_ref": cmp(oimg, refimg)}
+        print(case, stats[f"guided_nerf_results_{case}"], flush=True)
+        np.savez_compressed(os.path.join(outdir, f"ref_guided_nerf_results_{case}.npz"), rgba=refimg)
     with open(os.path.join(outdir, "ref_stats.json"), "w") as f:
         json.dump(stats, f, indent=1)
 

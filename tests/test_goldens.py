@@ -58,8 +58,33 @@ def test_oracle_matches_reference_on_headline_frame(mnv, orc):
 def test_recorded_stats_are_inside_the_contract():
     st = json.load(open(os.path.join(GOLD, "ref_stats.json")))
     assert set(cases.CASES) <= set(st) and "cfg2_pose3_1920x1080" in st
+    assert st["guided_get_samples"]["num_samples_equal"] and st["guided_get_samples"]["samples_not_bit_identical"] == 0
     for name, s in st.items():
+        if name.startswith("guided_"):
+            continue
         assert s["reference_loader_matches_build_loader"], name
         assert s["oracle_vs_ref"]["px_gt_1e-4"] == 0 and s["hip_vs_ref"]["px_gt_1e-4"] == 0, name
         assert s["oracle_vs_ref"]["max_abs"] <= TOL and s["hip_vs_ref"]["max_abs"] <= TOL, name
         assert s["hip_vs_oracle"]["px_not_bit_identical"] == 0, name
+
+
+def test_guided_get_samples_matches_reference_device_code(mnv, orc):
+    """get_samples_trace_ray (rt_core.cuh:418-576): counts, cluster ids and sample rows bit-identical."""
+    import guided_cases
+    g = np.load(os.path.join(GOLD, "ref_guided_get_samples.npz"))
+    tree, cam, opt, dim = guided_cases.get_samples_setup(mnv)
+    o = orc.get_samples(orc.tree_from_view(tree.host_view()), cam.c, opt, guided_cases.cluster_grid(mnv.ClusterGrid), dim)
+    assert np.array_equal(o["num_samples"], g["num_samples"])
+    k = np.arange(opt.max_guided_samples)[None, :] < g["num_samples"][:, None]
+    assert np.array_equal(o["cluster_indices"][k], g["cluster_indices"][k])
+    assert np.array_equal(o["samples"][k].view(np.uint32), g["samples"][k].view(np.uint32))
+
+
+@pytest.mark.parametrize("case", ["sh4_d6", "rgba_d5"])
+def test_guided_nerf_results_matches_reference_device_code(mnv, orc, case):
+    """composite_nerf_results (rt_core.cuh:334-416); contract 1e-4, asserted 1e-6."""
+    import guided_cases
+    g = np.load(os.path.join(GOLD, f"ref_guided_nerf_results_{case}.npz"))
+    tree, cam, opt, values, z, offsets = guided_cases.nerf_results_setup(mnv, case)
+    o = orc.render_nerf_results(orc.tree_from_view(tree.host_view()), cam.c, opt, values, z, offsets)["rgba"]
+    assert np.abs(o.astype(np.float64) - g["rgba"].astype(np.float64)).max() <= TOL
