@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--cpu-poses", type=int, default=4, help="poses rendered by the CPU baseline (bounded sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", choices=["accel", "ref_layout"], default="accel")
+    ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2",
+                    help="cfg2 = BASELINE.json's headline config (default); cfg3 = merged-Mega-NeRF stand-in (anisotropic terrain, 2.7 M chunks)")
     ap.add_argument("--per-frame", action="store_true", help="one launch per pose instead of one batched launch per step")
     args = ap.parse_args()
 
@@ -84,9 +86,15 @@ def main():
 
     dev = torch.device("cuda", local_rank)
     t_setup = time.time()
-    tree = cases.make_tree(mnv, cases.CFG2_TREE)
+    if args.workload == "cfg2":
+        tree = cases.make_tree(mnv, cases.CFG2_TREE)
+        cams = [cases.cfg2_camera(mnv, pose, W, H, FX) for pose in range(N_POSES)]
+        workload = "cfg2: depth-10 SH9 shell N3Tree (1,499,569 chunks), 1920x1080, 16-pose orbit per step"
+    else:
+        tree = cases.make_tree(mnv, cases.CFG3_TREE)
+        cams = [cases.cfg3_camera(mnv, pose, W, H) for pose in range(N_POSES)]
+        workload = f"cfg3: depth-10 SH9 anisotropic 4x2-brick terrain N3Tree ({tree.capacity:,} chunks), 1920x1080, 16 oblique poses per step"
     tree.move_to_device()
-    cams = [cases.cfg2_camera(mnv, pose, W, H, FX) for pose in range(N_POSES)]
     opt = mnv.RenderOptions.cli_defaults()
     setup_s = time.time() - t_setup
 
@@ -166,7 +174,7 @@ def main():
     value = rays_per_step * args.steps / elapsed / 1e6
 
     # ---- roofline of the dominant kernel (the march): algorithmic bytes per launch / launch time
-    counters = load_counters()
+    counters = load_counters() if args.workload == "cfg2" else None
     cpu_baseline = None
     parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -203,7 +211,7 @@ def main():
         avg_ms = kern_ms / launches
         achieved = per_launch / (avg_ms * 1e-3) / 1e9
         traffic = None
-        if os.path.exists(TRAFFIC_JSON) and world == 1 and args.kernel == "accel":
+        if os.path.exists(TRAFFIC_JSON) and world == 1 and args.kernel == "accel" and args.workload == "cfg2":
             tj = json.load(open(TRAFFIC_JSON))
             if tj.get("frames_per_launch") == frames_per_launch:
                 traffic = tj["hbm_bytes_per_launch"]   # PMC counters cannot be read from inside this process
@@ -228,7 +236,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "cfg2: depth-10 SH9 shell N3Tree (1,499,569 chunks), 1920x1080, 16-pose orbit per step",
+            "config": {"workload": workload,
                        "rays_per_step": rays_per_step, "kernel": args.kernel, "launches_per_step": 1 if not args.per_frame and args.kernel == "accel" else N_POSES,
                        "partition": "none" if world == 1 else f"interleaved {MACRO_W}x{MACRO_H} macro tiles, {args.gather} RCCL gather to rank 0"},
             "roofline": roofline,

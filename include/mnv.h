@@ -274,7 +274,23 @@ typedef struct mnv_synth_shell_params {
     uint64_t seed;
 } mnv_synth_shell_params;
 
+/* "Merged Mega-NeRF" stand-in (BASELINE configs[2]): anisotropic volume with a
+ * terrain-like occupied layer x = h(y, z), cut into bricks_y x bricks_z sub-modules with independent seeds. */
+typedef struct mnv_synth_terrain_params {
+    int32_t depth;
+    int32_t basis_dim;
+    int32_t bricks_y, bricks_z;  /* 4 x 2 */
+    int32_t noise_cells;         /* lattice cells of the value noise per unit length */
+    float base, amplitude;       /* height range in unit-cube x: [base, base + amplitude] */
+    float thickness;             /* half thickness of the occupied layer, unit-cube units */
+    float sigma_lo, sigma_hi;
+    float offset[3];
+    float scale[3];              /* invradius3, e.g. (0.5, 0.125, 0.125) for a 1 : 4 : 4 world extent */
+    uint64_t seed;
+} mnv_synth_terrain_params;
+
 int mnv_synth_random_tree(const mnv_synth_random_params *p, mnv_n3tree **out);
+int mnv_synth_terrain_tree(const mnv_synth_terrain_params *p, mnv_n3tree **out);
 int mnv_synth_shell_tree(const mnv_synth_shell_params *p, mnv_n3tree **out);
 
 #ifdef __cplusplus

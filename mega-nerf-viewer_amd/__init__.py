@@ -134,6 +134,13 @@ class SynthRandomParams(C.Structure):
     ]
 
 
+class SynthTerrainParams(C.Structure):
+    _fields_ = [("depth", C.c_int32), ("basis_dim", C.c_int32), ("bricks_y", C.c_int32), ("bricks_z", C.c_int32),
+                ("noise_cells", C.c_int32), ("base", C.c_float), ("amplitude", C.c_float), ("thickness", C.c_float),
+                ("sigma_lo", C.c_float), ("sigma_hi", C.c_float), ("offset", C.c_float * 3), ("scale", C.c_float * 3),
+                ("seed", C.c_uint64)]
+
+
 class SynthShellParams(C.Structure):
     _fields_ = [
         ("depth", C.c_int32),
@@ -188,6 +195,7 @@ _SIGNATURES = {
     "mnv_data_format_to_string": (C.c_int, [C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]),
     "mnv_synth_random_tree": (C.c_int, [C.POINTER(SynthRandomParams), C.POINTER(C.c_void_p)]),
     "mnv_synth_shell_tree": (C.c_int, [C.POINTER(SynthShellParams), C.POINTER(C.c_void_p)]),
+    "mnv_synth_terrain_tree": (C.c_int, [C.POINTER(SynthTerrainParams), C.POINTER(C.c_void_p)]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -332,6 +340,16 @@ class N3Tree:
         p = SynthShellParams(depth, basis_dim, radius, half_thickness, sigma_lo, sigma_hi, _f3(offset), _f3(scale), seed)
         h = C.c_void_p()
         _check(lib().mnv_synth_shell_tree(C.byref(p), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def synth_terrain(cls, depth=10, basis_dim=9, bricks_y=4, bricks_z=2, noise_cells=6, base=0.25, amplitude=0.35,
+                      thickness=1.5 / 1024, sigma_lo=50.0, sigma_hi=400.0, offset=(0.5, 0.5, 0.5), scale=(0.5, 0.125, 0.125),
+                      seed=0) -> "N3Tree":
+        p = SynthTerrainParams(depth, basis_dim, bricks_y, bricks_z, noise_cells, base, amplitude, thickness, sigma_lo, sigma_hi,
+                               _f3(offset), _f3(scale), seed)
+        h = C.c_void_p()
+        _check(lib().mnv_synth_terrain_tree(C.byref(p), C.byref(h)))
         return cls(h.value)
 
     def host_view(self) -> TreeView:

@@ -12,6 +12,7 @@
 namespace viewer::synth {
 void random_tree(const mnv_synth_random_params &p, N3Tree &out);
 void shell_tree(const mnv_synth_shell_params &p, N3Tree &out);
+void terrain_tree(const mnv_synth_terrain_params &p, N3Tree &out);
 }  // namespace viewer::synth
 
 struct mnv_n3tree {
@@ -155,6 +156,21 @@ int mnv_synth_random_tree(const mnv_synth_random_params *p, mnv_n3tree **out) {
         auto *t = new mnv_n3tree();
         try {
             viewer::synth::random_tree(*p, t->tree);
+        } catch (...) {
+            delete t;
+            throw;
+        }
+        *out = t;
+        return MNV_OK;
+    });
+}
+
+int mnv_synth_terrain_tree(const mnv_synth_terrain_params *p, mnv_n3tree **out) {
+    if (!p || !out) return mnv::set_error(MNV_E_INVALID, "null argument");
+    return guarded([&] {
+        auto *t = new mnv_n3tree();
+        try {
+            viewer::synth::terrain_tree(*p, t->tree);
         } catch (...) {
             delete t;
             throw;

@@ -214,4 +214,81 @@ void shell_tree(const mnv_synth_shell_params &p, N3Tree &out) {
     tm.lap("assign");
 }
 
+// "Merged Mega-NeRF" stand-in: an anisotropic volume (tree-x is height) holding a
+// terrain-like occupied layer x = h(y, z).  The y-z plane is cut into bricks_y x bricks_z "sub-modules",
+// each with its own noise seed, so the surface is discontinuous at brick borders like independently
+// trained sub-modules.  h is bilinear value noise on a hashed lattice: float mul/add only.
+void terrain_tree(const mnv_synth_terrain_params &p, N3Tree &out) {
+    if (p.depth < 1 || p.depth > 14) throw std::runtime_error("synth: depth out of range");
+    if (p.basis_dim < 1) throw std::runtime_error("synth: terrain tree needs an SH basis");
+    Timer tm;
+    const int data_dim = 3 * p.basis_dim + 1;
+    const int by = p.bricks_y > 0 ? p.bricks_y : 1, bz = p.bricks_z > 0 ? p.bricks_z : 1;
+    const double cells = p.noise_cells > 0 ? p.noise_cells : 8;
+    auto lattice = [&](int brick, int iy, int iz) {
+        return (double)uniform01(hash3(p.seed ^ 0x7e44a1full, (uint64_t)brick, ((uint64_t)(uint32_t)iy << 32) | (uint32_t)iz));
+    };
+    // height in [base, base + amplitude] at unit-cube (y, z)
+    auto height = [&](double y, double z) {
+        int jy = (int)(y * by), jz = (int)(z * bz);
+        jy = jy >= by ? by - 1 : jy;
+        jz = jz >= bz ? bz - 1 : jz;
+        const int brick = jy * bz + jz;
+        const double u = y * cells, v = z * cells;
+        const int iy = (int)u, iz = (int)v;
+        const double fu = u - iy, fv = v - iz;
+        const double a = lattice(brick, iy, iz), b = lattice(brick, iy + 1, iz), c = lattice(brick, iy, iz + 1), d = lattice(brick, iy + 1, iz + 1);
+        const double n = (a * (1 - fu) + b * fu) * (1 - fv) + (c * (1 - fu) + d * fu) * fv;
+        return (double)p.base + (double)p.amplitude * n;
+    };
+    // a cell overlaps the layer if its x range meets [hmin - thick - slack, hmax + thick + slack], with h sampled on
+    // a 3x3 grid of the cell's y-z footprint and a Lipschitz slack for what lies between the samples
+    const double lip = (double)p.amplitude * cells * 2.0;
+    auto overlaps = [&](uint32_t ix, uint32_t iy, uint32_t iz, int depth) {
+        const double s = std::ldexp(1.0, -depth);
+        const double x0 = ix * s, y0 = iy * s, z0 = iz * s;
+        double hmin = 1e30, hmax = -1e30;
+        for (int a = 0; a <= 2; ++a)
+            for (int b = 0; b <= 2; ++b) {
+                const double yy = y0 + 0.5 * a * s, zz = z0 + 0.5 * b * s;
+                const double h = height(yy < 1.0 ? yy : 0.999999, zz < 1.0 ? zz : 0.999999);
+                hmin = h < hmin ? h : hmin;
+                hmax = h > hmax ? h : hmax;
+            }
+        const double slack = lip * s * 0.5;
+        return x0 <= hmax + p.thickness + slack && x0 + s >= hmin - p.thickness - slack;
+    };
+    Builder b;
+    b.add_chunk(-1, 0, 0, 0, 1);
+    std::vector<uint8_t> dense;
+    for (size_t c = 0; c < b.parent.size(); ++c) {
+        const int lvl = b.level[c];
+        dense.resize((c + 1) * 8, 0);
+        for (int j = 0; j < 8; ++j) {
+            const uint64_t vox = (uint64_t)c * 8 + j;
+            const uint32_t x = b.cx[c] * 2 + ((j >> 2) & 1), y = b.cy[c] * 2 + ((j >> 1) & 1), z = b.cz[c] * 2 + (j & 1);
+            if (!overlaps(x, y, z, lvl)) continue;
+            if (lvl < p.depth) {
+                const size_t n = b.add_chunk((int32_t)vox, x, y, z, lvl + 1);
+                b.child[vox] = (int32_t)(n - c);
+            } else {
+                dense[vox] = 1;
+            }
+        }
+    }
+    tm.lap("structure");
+    const size_t nvox = b.child.size();
+    dense.resize(nvox, 0);
+    std::vector<uint16_t> data(nvox * data_dim, 0);
+    parallel_for(nvox, [&](size_t vox) {
+        if (!dense[vox]) return;
+        uint16_t *row = data.data() + vox * data_dim;
+        const float sigma = p.sigma_lo + uniform01(hash3(p.seed, vox, 2)) * (p.sigma_hi - p.sigma_lo);
+        row[data_dim - 1] = float_to_half(sigma);
+        fill_row(row, MNV_FORMAT_SH, p.basis_dim, 1.0f, p.seed, vox);
+    });
+    tm.lap("fill");
+    finish(out, b, MNV_FORMAT_SH, p.basis_dim, p.offset, p.scale, data, data_dim);
+}
+
 }  // namespace viewer::synth

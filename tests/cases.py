@@ -13,6 +13,8 @@ def make_tree(mnv, spec):
         return mnv.N3Tree.synth_random(**args)
     if kind == "shell":
         return mnv.N3Tree.synth_shell(**args)
+    if kind == "terrain":
+        return mnv.N3Tree.synth_terrain(**args)
     raise ValueError(kind)
 
 
@@ -75,10 +77,30 @@ CASES = {
     "shell_d7_sh9": dict(tree=dict(kind="shell", depth=7, basis_dim=9, radius=0.35, half_thickness=1.5 / 128, seed=0),
                          camera=dict(width=320, height=180, fx=266.0, orbit=dict(radius=2.6, azimuth=22.5, elevation=20.0)),
                          options=dict(base="cli")),
+    "terrain_d7_aniso": dict(tree=dict(kind="terrain", depth=7, basis_dim=9, bricks_y=4, bricks_z=2, noise_cells=6, base=0.25, amplitude=0.35,
+                                       thickness=1.5 / 128, scale=(0.5, 0.125, 0.125), seed=0),
+                             camera=dict(width=256, height=144, fx=190.0, center=(2.2, 4.76, 2.75), back=(0.4, 0.79, 0.46), up=(1.0, 0.0, 0.0)),
+                             options=dict(base="cli")),
     "thresholds": dict(tree=dict(kind="random", depth=5, basis_dim=4, refine_prob=0.6, empty_prob=0.3, sigma_max=80.0, seed=10),
                        camera=dict(width=128, height=96, fx=400.0),
                        options=dict(step_size=1e-3, sigma_thresh=5.0, stop_thresh=0.1, background_brightness=0.5)),
 }
+
+# BASELINE.json configs[2] stand-in: anisotropic multi-brick terrain ("merged Mega-NeRF octree"), oblique aerial camera
+CFG3_TREE = dict(kind="terrain", depth=10, basis_dim=9, bricks_y=4, bricks_z=2, noise_cells=6, base=0.25, amplitude=0.35,
+                 thickness=1.5 / 1024, scale=(0.5, 0.125, 0.125), seed=0)
+CFG3_SMALL = dict(CFG3_TREE, depth=7, thickness=1.5 / 128)
+
+
+def cfg3_camera(mnv, pose=0, width=1920, height=1080, fx=1400.0):
+    """Oblique aerial pose: world x is height (extent [-1, 1]), y and z span [-4, 4]."""
+    import numpy as _np
+    az = _np.deg2rad(22.5 * pose)
+    center = _np.float32([2.2, 5.5 * _np.cos(az), 5.5 * _np.sin(az)])
+    target = _np.float32([-0.2, 0.0, 0.0])
+    back = (center - target) / _np.linalg.norm(center - target)
+    return mnv.Camera(width, height, fx).set_pose(center, back.astype(_np.float32), (1.0, 0.0, 0.0))
+
 
 # BASELINE.json configs[1]: depth-10 SH9 shell, 1920x1080, fx 1600, orbit radius 2.6, elevation 20
 CFG2_TREE = dict(kind="shell", depth=10, basis_dim=9, radius=0.35, half_thickness=1.5 / 1024, sigma_lo=50.0, sigma_hi=400.0, seed=0)

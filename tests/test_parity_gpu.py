@@ -255,3 +255,17 @@ def test_cfg2_batched_launch_equals_per_frame_launches(mnv, torch_gpu, cfg2):
         assert np.array_equal(cases.bits(np.nan_to_num(a)), cases.bits(np.nan_to_num(s))), i
     with pytest.raises(mnv.MnvError):
         mnv.render_voxels_accel_batch(cfg2.accel, [cams[0], cases.cfg2_camera(mnv, 0)], opt, rgba=batch)  # mixed sizes
+
+
+def test_cfg3_merged_octree_standin_full_size(mnv, orc, torch_gpu):
+    """BASELINE.json configs[2] stand-in at full size: anisotropic (invradius3 = 0.5, 0.125, 0.125) 4x2-brick
+    terrain tree, 2.7 M chunks, oblique aerial camera, 1920x1080 -- tuned kernel == oracle bit for bit."""
+    tree = cases.make_tree(mnv, cases.CFG3_TREE)
+    assert tree.capacity > 2_000_000
+    cam = cases.cfg3_camera(mnv, pose=2)
+    opt = mnv.RenderOptions.cli_defaults()
+    ref = orc.render(orc.tree_from_view(tree.host_view()), cam.c, opt)
+    assert ref["counters"].rays_hit > 0.4 * ref["counters"].rays
+    tree.move_to_device()
+    got, _ = _render_gpu(mnv, torch_gpu, tree, cam, opt, "accel")
+    assert np.array_equal(cases.bits(got), cases.bits(ref["rgba"]))
