@@ -62,6 +62,8 @@ def main():
     ap.add_argument("--cpu-poses", type=int, default=4, help="poses rendered by the CPU baseline (bounded sample)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", choices=["accel", "ref_layout"], default="accel")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="process-group backend for N > 1; gloo (host-staged gather, all ranks may share one GPU) is the single-GPU rehearsal of the multi-GPU path")
     ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2",
                     help="cfg2 = BASELINE.json's headline config (default); cfg3 = merged-Mega-NeRF stand-in (anisotropic terrain, 2.7 M chunks)")
     ap.add_argument("--per-frame", action="store_true", help="one launch per pose instead of one batched launch per step")
@@ -74,10 +76,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()  # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import __graft_entry__ as g
     g.build_if_missing()
@@ -128,7 +135,7 @@ def main():
         assert n_local == mnv.partition_local_tiles((0, 0, W, H), rank, world, MACRO_W, MACRO_H)
         dt = torch.float32 if args.gather == "f32" else torch.uint8
         # one launch + one gather per step; the gather of step k overlaps the launch of step k + 1
-        tg = TileGatherer(part, rank, dev, dtype=dt, depth=RING, frames=N_POSES)
+        tg = TileGatherer(part, rank, dev, dtype=dt, depth=RING, frames=N_POSES, stage_on_host=args.backend == "gloo")
         frames = tg._frames if rank == 0 else None
         counter = [0]
 
@@ -150,6 +157,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def all_max(x):
+        t_ = torch.tensor([x], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+        return float(t_.item())
+
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -166,9 +178,7 @@ def main():
     kern_ms, launches = mnv.take_timing()
     mnv.set_timing(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = all_max(elapsed)
 
     rays_per_step = N_POSES * W * H
     value = rays_per_step * args.steps / elapsed / 1e6
@@ -202,6 +212,19 @@ def main():
         parity = {"max_abs_drgba_vs_oracle": max_diff, "pixels_not_bit_identical": n_bad, "frames_checked": n_cpu}
         if counters is None:
             counters = {"poses": fresh, "partial": True}
+    if rank == 0 and world > 1 and not args.no_cpu_baseline and args.gather == "f32":
+        # the assembled frames of the last step against the oracle (not timed): validates partition + gather + un-permute
+        import mnv_oracle as orc
+        ot = orc.tree_from_view(tree.host_view())
+        last = frames[(counter[0] - 1) % RING]
+        max_diff, n_bad, n_chk = 0.0, 0, 2
+        for i in range(n_chk):
+            r = orc.render(ot, cams[i].c, opt)
+            gpu = last[i].cpu().numpy()
+            max_diff = max(max_diff, float(np.abs(gpu - r["rgba"]).max()))
+            n_bad += int((gpu.view(np.uint32) != r["rgba"].view(np.uint32)).any(axis=-1).sum())
+        parity = {"max_abs_drgba_vs_oracle": max_diff, "pixels_not_bit_identical": n_bad, "frames_checked": n_chk,
+                  "what": "frames assembled on rank 0 after the gather"}
     roofline = None
     if counters is not None and launches > 0:
         poses = counters["poses"]

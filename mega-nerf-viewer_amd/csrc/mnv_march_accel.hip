@@ -563,8 +563,14 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     // per-launch slot: zeroed queue heads for every frame + the camera blocks, staged in pinned host
     // memory and uploaded with one asynchronous copy on the launch stream
     K.n_frames = (uint32_t)n_frames;
-    K.frame_stride_px = part.world <= 1 ? (uint32_t)P.tw * (uint32_t)P.th
-                                        : (uint32_t)partition_local_tiles({P.x0, P.y0, P.tw, P.th}, part) * K.macro_w * K.macro_h;
+    // frames of a batch are j_max = ceil(macro tiles / world) local tiles apart on EVERY rank, so that the
+    // per-rank buffers have one shape (what the gather needs) even when the tile count is ragged
+    if (part.world <= 1) {
+        K.frame_stride_px = (uint32_t)P.tw * (uint32_t)P.th;
+    } else {
+        const uint32_t n_macro = K.macros_x * (uint32_t)((P.th + part.tile_h - 1) / part.tile_h);
+        K.frame_stride_px = ((n_macro + (uint32_t)part.world - 1) / (uint32_t)part.world) * K.macro_w * K.macro_h;
+    }
     mnv_accel *mut = const_cast<mnv_accel *>(accel);
     const uint32_t slot = mut->slot_counter.fetch_add(1) % kSlots;
     uint8_t *ds = accel->slots_dev + (size_t)slot * kSlotBytes;

@@ -71,9 +71,12 @@ class TileGatherer:
     ``frame(slot)``.  With depth >= 2 the gather of frame k overlaps the render of frame k+1."""
 
     def __init__(self, part: TilePartition, rank: int, device, dtype=torch.float32, channels: int = 4, depth: int = 3, group=None,
-                 frames: int = 0):
-        """`frames` > 0: every slot holds a batch of that many frames (one launch + one gather per batch)."""
+                 frames: int = 0, stage_on_host: bool = False):
+        """`frames` > 0: every slot holds a batch of that many frames (one launch + one gather per batch).
+        `stage_on_host`: gather through host copies (for process groups without device collectives, e.g. gloo
+        in the single-GPU rehearsal of the N > 1 path); the default hands device buffers to RCCL."""
         self.part, self.rank, self.group, self.depth = part, rank, group, depth
+        self.stage_on_host = stage_on_host
         lead = (frames,) if frames > 0 else ()
         shape = lead + (part.j_max, part.tile_h, part.tile_w, channels)
         self._local = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(depth)]
@@ -89,6 +92,11 @@ class TileGatherer:
         return self._frames[slot]
 
     def submit(self, slot: int) -> None:
+        if self.stage_on_host:
+            src = self._local[slot].cpu()  # synchronises with the render on the current stream
+            host = [torch.empty_like(src) for _ in range(self.part.world)] if self.rank == 0 else None
+            self._pending[slot] = (dist.gather(src, host, dst=0, group=self.group, async_op=True), host, src)
+            return
         glist = [self._gathered[slot][r] for r in range(self.part.world)] if self.rank == 0 else None
         self._pending[slot] = dist.gather(self._local[slot], glist, dst=0, group=self.group, async_op=True)
 
@@ -96,7 +104,13 @@ class TileGatherer:
         w = self._pending[slot]
         if w is None:
             return
-        w.wait()
+        if self.stage_on_host:
+            w[0].wait()
+            if self.rank == 0:
+                for r, h in enumerate(w[1]):
+                    self._gathered[slot][r].copy_(h)
+        else:
+            w.wait()
         self._pending[slot] = None
         if self.rank == 0:
             self.part.unpermute(self._gathered[slot], out=self._frames[slot])

@@ -240,17 +240,21 @@ def test_cfg2_batched_launch_equals_per_frame_launches(mnv, torch_gpu, cfg2):
         one, one8 = _render_gpu(mnv, torch, cfg2, cam, opt, "accel", want_u8=True)
         assert np.array_equal(cases.bits(b[i]), cases.bits(one)), i
         assert np.array_equal(b8[i], one8), i
-    # partition: rank 1 of 3, ragged macro tiles
-    tw, th, world, rank = 200, 136, 3, 1
+    # partition: rank 2 of 3 owns one macro tile fewer than ranks 0/1 (20 tiles): frames are still
+    # j_max = ceil(20 / 3) = 7 local tiles apart
+    tw, th, world, rank = 200, 136, 3, 2
     n_local = mnv.partition_local_tiles((0, 0, W, H), rank, world, tw, th)
-    pb = torch.full((len(cams), n_local, th, tw, 4), float("nan"), dtype=torch.float32, device="cuda")
+    j_max = -(-((-(-W // tw)) * (-(-H // th))) // world)
+    assert n_local == j_max - 1
+    pb = torch.full((len(cams), j_max, th, tw, 4), float("nan"), dtype=torch.float32, device="cuda")
     mnv.render_voxels_accel_batch(cfg2.accel, cams, opt, part=(rank, world, tw, th), rgba=pb)
     torch.cuda.synchronize()
     for i, cam in enumerate(cams):
         single = torch.full((n_local, th, tw, 4), float("nan"), dtype=torch.float32, device="cuda")
         mnv.render_voxels_accel_part(cfg2.accel, cam, opt, rank, world, tw, th, rgba=single)
         torch.cuda.synchronize()
-        a, s = pb[i].cpu().numpy(), single.cpu().numpy()
+        a, s = pb[i, :n_local].cpu().numpy(), single.cpu().numpy()
+        assert np.isnan(pb[i, n_local:].cpu().numpy()).all()
         assert np.array_equal(np.isnan(a), np.isnan(s))
         assert np.array_equal(cases.bits(np.nan_to_num(a)), cases.bits(np.nan_to_num(s))), i
     with pytest.raises(mnv.MnvError):
