@@ -162,6 +162,10 @@ def main():
         dist.all_reduce(t_, op=dist.ReduceOp.MAX)
         return float(t_.item())
 
+    if world > 1:
+        # create the RCCL point-to-point channels outside the timed region even with --warmup 0
+        tg.submit(0)
+        tg.finish(0)
     for _ in range(args.warmup):
         step()
     if world > 1:
