@@ -221,6 +221,41 @@ int mnv_render_nerf_results(const mnv_tree_view *tree, const mnv_camera *cam, co
                             mnv_rect tile, const float *sample_values, int32_t value_stride, const float *z_vals,
                             const int64_t *offsets, float *rgba_out, uint8_t *rgba8_out, void *hip_stream);
 
+/* --------------------------------------------- refinement kernels (BASELINE config 5) */
+
+/* Mutable device view of the tree topology for the refinement kernels (the arrays a TreeSpec exposes
+ * non-const, include/data_spec.hpp:26-28). */
+typedef struct mnv_tree_edit {
+    int32_t *child;   /* [max_capacity][8] */
+    int32_t *parent;  /* [max_capacity] */
+    float offset[3];
+    float scale[3];
+    int32_t N;        /* 2 */
+    int32_t capacity; /* chunks in use BEFORE the call */
+} mnv_tree_edit;
+
+/*
+ * viewer::add_children_and_generate_samples (include/cuda/renderer_kernel.hpp:54-63,
+ * src/cuda/renderer_kernel.cu:170-198,487-510): appends num_parents chunks at [capacity, capacity +
+ * num_parents), links them under parent_nodes[i] = (chunk, child), copies the visit mark, and turns the
+ * caller's uniform [0,1) numbers in samples[num_parents*8][samples_per_corner][samples_dim] into
+ * world-space sample points inside each new voxel (+ view dir / embedding columns, + cluster ids).
+ */
+int mnv_add_children_and_generate_samples(const mnv_tree_edit *tree, const mnv_render_options *opt,
+                                          const int32_t *parent_nodes, int32_t num_parents, float *samples,
+                                          int32_t samples_dim, int16_t *cluster_indices, int32_t *visited,
+                                          const mnv_cluster_grid *grid, void *hip_stream);
+/* viewer::generate_samples (renderer_kernel.hpp:65-73, renderer_kernel.cu:200-213,512-534): the same
+ * sample generation for existing voxels nodes[i] = (chunk, child). */
+int mnv_generate_samples(const mnv_tree_edit *tree, const mnv_render_options *opt, const int32_t *nodes,
+                         int32_t num_items, float *samples, int32_t samples_dim, int16_t *cluster_indices,
+                         const mnv_cluster_grid *grid, void *hip_stream);
+/* viewer::adjust_parents_and_children (renderer_kernel.hpp:75-79, renderer_kernel.cu:63-86,536-549):
+ * fixes relative child offsets and parent ids of chunks [first_shift_index, capacity) before compaction;
+ * to_delete is a bool (1 byte) array, index_shifts an int32 array, both [capacity]. */
+int mnv_adjust_parents_and_children(const mnv_tree_edit *tree, int32_t first_shift_index, const uint8_t *to_delete,
+                                    const int32_t *index_shifts, void *hip_stream);
+
 /* Average device time (ms) of the last `mnv_render_*` launches since the
  * previous call, measured with HIP events on the launch stream when
  * mnv_set_timing(1) is active; used by bench.py for roofline.achieved. */

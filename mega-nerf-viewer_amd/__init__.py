@@ -119,6 +119,11 @@ class ClusterGrid(C.Structure):
     _fields_ = [("grid_dim", C.c_int32 * 2), ("min_position", C.c_float * 3), ("range", C.c_float * 3)]
 
 
+class TreeEdit(C.Structure):
+    _fields_ = [("child", C.c_void_p), ("parent", C.c_void_p), ("offset", C.c_float * 3), ("scale", C.c_float * 3),
+                ("N", C.c_int32), ("capacity", C.c_int32)]
+
+
 class SynthRandomParams(C.Structure):
     _fields_ = [
         ("depth", C.c_int32),
@@ -181,6 +186,11 @@ _SIGNATURES = {
                                               C.c_void_p, C.POINTER(ClusterGrid), C.c_void_p]),
     "mnv_render_nerf_results": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
                                           C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mnv_add_children_and_generate_samples": (C.c_int, [C.POINTER(TreeEdit), C.POINTER(RenderOptions), C.c_void_p, C.c_int32, C.c_void_p,
+                                                        C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(ClusterGrid), C.c_void_p]),
+    "mnv_generate_samples": (C.c_int, [C.POINTER(TreeEdit), C.POINTER(RenderOptions), C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                       C.c_void_p, C.POINTER(ClusterGrid), C.c_void_p]),
+    "mnv_adjust_parents_and_children": (C.c_int, [C.POINTER(TreeEdit), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_set_timing": (None, [C.c_int]),
     "mnv_take_timing": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "mnv_n3tree_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -454,6 +464,30 @@ def render_nerf_results(tree_view: TreeView, cam: Camera, opt: RenderOptions, sa
     _check(lib().mnv_render_nerf_results(C.byref(tree_view), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(sample_values),
                                          int(sample_values.shape[-1]), _ptr(z_vals), _ptr(offsets), _ptr(rgba), _ptr(rgba8),
                                          C.c_void_p(stream)))
+
+
+def tree_edit(child, parent, offset, scale, capacity: int) -> TreeEdit:
+    e = TreeEdit()
+    e.child, e.parent = _ptr(child), _ptr(parent)
+    e.offset, e.scale = _f3(offset), _f3(scale)
+    e.N, e.capacity = 2, capacity
+    return e
+
+
+def add_children_and_generate_samples(edit: TreeEdit, opt: RenderOptions, parent_nodes, samples, cluster_indices, visited,
+                                      grid: ClusterGrid, stream: int = 0) -> None:
+    _check(lib().mnv_add_children_and_generate_samples(C.byref(edit), C.byref(opt), _ptr(parent_nodes), int(parent_nodes.shape[0]),
+                                                       _ptr(samples), int(samples.shape[-1]), _ptr(cluster_indices), _ptr(visited),
+                                                       C.byref(grid), C.c_void_p(stream)))
+
+
+def generate_samples(edit: TreeEdit, opt: RenderOptions, nodes, samples, cluster_indices, grid: ClusterGrid, stream: int = 0) -> None:
+    _check(lib().mnv_generate_samples(C.byref(edit), C.byref(opt), _ptr(nodes), int(nodes.shape[0]), _ptr(samples),
+                                      int(samples.shape[-1]), _ptr(cluster_indices), C.byref(grid), C.c_void_p(stream)))
+
+
+def adjust_parents_and_children(edit: TreeEdit, first_shift_index: int, to_delete, index_shifts, stream: int = 0) -> None:
+    _check(lib().mnv_adjust_parents_and_children(C.byref(edit), first_shift_index, _ptr(to_delete), _ptr(index_shifts), C.c_void_p(stream)))
 
 
 MAX_BATCH = 64

@@ -218,6 +218,135 @@ __global__ __launch_bounds__(256) void composite_nerf_kernel(const CompositePara
     composite_and_write(P, p, o0, o1, o2, 1.0f);  // out[3] = 1 (renderer_kernel.cu:316): no background shows through
 }
 
+// ---- refinement kernels (renderer_kernel.cu:63-213) ---------------------------------------------
+
+struct RefineParams {
+    int32_t *child;
+    int32_t *parent;
+    float offset[3], scale[3];
+    int32_t capacity;
+    int32_t samples_per_corner, samples_dim, need_viewdir, appearance_embedding;
+    float *samples;
+    int16_t *cluster_indices;
+    int32_t grid_dim[2];
+    float min_position[3], range[3];
+};
+
+// generate_samples_inner, renderer_kernel.cu:88-168.  `top_parent` is the parent entry of
+// `abs_chunk` when that chunk is being created by this very launch (the reference reads it back from
+// tree.parent while another thread of the launch writes it); -1 otherwise.
+__device__ __forceinline__ void generate_samples_inner(const RefineParams &R, int64_t idx, int32_t abs_chunk, int32_t child_idx,
+                                                       int32_t top_parent) {
+    int32_t cur = abs_chunk * 8 + child_idx;
+    int depth = 0;
+    float corners[3] = {0.f, 0.f, 0.f};
+    bool first = true;
+    for (;;) {
+        const int32_t cz = cur % 2;
+        cur /= 2;
+        const int32_t cy = cur % 2;
+        cur /= 2;
+        const int32_t cx = cur % 2;
+        cur /= 2;
+        corners[0] = (corners[0] + (float)cx) / 2.f;
+        corners[1] = (corners[1] + (float)cy) / 2.f;
+        corners[2] = (corners[2] + (float)cz) / 2.f;
+        if (cur == 0) break;
+        cur = (first && top_parent >= 0) ? top_parent : R.parent[cur];
+        first = false;
+        depth += 1;
+    }
+    const float length_local = __uint_as_float((uint32_t)(127 - depth - 1) << 23);  // pow(N, -depth - 1)
+    const int spc = R.samples_per_corner, dim = R.samples_dim;
+    float *row0 = R.samples + idx * spc * dim;
+    for (int i = 0; i < 3; ++i) {
+        corners[i] -= R.offset[i];
+        corners[i] /= R.scale[i];
+        const float mul = length_local / R.scale[i];
+        for (int j = 0; j < spc; ++j) {
+            float v = row0[j * dim + i];
+            v *= mul;
+            v += corners[i];
+            row0[j * dim + i] = v;
+        }
+    }
+    if (R.need_viewdir) {
+        for (int j = 0; j < spc; ++j) {
+            row0[j * dim + 3] = 1.f;
+            row0[j * dim + 4] = 0.f;
+            row0[j * dim + 5] = 0.f;
+            if (R.appearance_embedding != -1) row0[j * dim + 6] = (float)R.appearance_embedding;
+        }
+    } else if (R.appearance_embedding != -1) {
+        for (int j = 0; j < spc; ++j) row0[j * dim + 3] = (float)R.appearance_embedding;
+    }
+    for (int j = 0; j < spc; ++j) {
+        const int g1 = (int)fmaxf(fminf((row0[j * dim + 1] - R.min_position[1]) / R.range[1] * (float)R.grid_dim[0], (float)R.grid_dim[0] - 1.0f), 0.0f);
+        const int g2 = (int)fmaxf(fminf((row0[j * dim + 2] - R.min_position[2]) / R.range[2] * (float)R.grid_dim[1], (float)R.grid_dim[1] - 1.0f), 0.0f);
+        R.cluster_indices[idx * spc + j] = (int16_t)(g1 * R.grid_dim[1] + g2);
+    }
+}
+
+__global__ void add_children_kernel(const RefineParams R, const int32_t *parent_nodes, int32_t *visited, int32_t num_parents) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (int64_t)num_parents * 8) return;
+    const int32_t rel = (int32_t)(tid / 8), child_idx = (int32_t)(tid % 8);
+    const int32_t abs_chunk = R.capacity + rel;
+    const int32_t pc = parent_nodes[rel * 2], pj = parent_nodes[rel * 2 + 1];
+    if (child_idx == 0) {
+        R.child[(int64_t)pc * 8 + pj] = abs_chunk - pc;
+        R.parent[abs_chunk] = pc * 8 + pj;
+        visited[abs_chunk] = visited[pc];
+    }
+    R.child[(int64_t)abs_chunk * 8 + child_idx] = 0;
+    generate_samples_inner(R, tid, abs_chunk, child_idx, pc * 8 + pj);
+}
+
+__global__ void generate_samples_kernel(const RefineParams R, const int32_t *nodes, int32_t num_items) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= num_items) return;
+    generate_samples_inner(R, tid, nodes[tid * 2], nodes[tid * 2 + 1], -1);
+}
+
+__global__ void adjust_parents_kernel(int32_t *child, int32_t *parent, int32_t capacity, int32_t first_shift_index,
+                                      const uint8_t *to_delete, const int32_t *index_shifts) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= capacity - first_shift_index) return;
+    const int32_t chunk = (int32_t)tid + first_shift_index;
+    const int32_t par = parent[chunk];
+    const int32_t pc = par / 8, pj = par % 8;
+    if (to_delete[chunk]) {
+        child[(int64_t)pc * 8 + pj] = 0;
+    } else {
+        const int32_t parent_shift = index_shifts[pc], child_shift = index_shifts[chunk];
+        child[(int64_t)pc * 8 + pj] += (parent_shift - child_shift);
+        parent[chunk] = par - index_shifts[pc] * 8;
+    }
+}
+
+static int fill_refine(RefineParams &R, const mnv_tree_edit *t, const mnv_render_options *opt, float *samples, int32_t samples_dim,
+                       int16_t *cluster_indices, const mnv_cluster_grid *grid) {
+    if (!t || !opt || !samples || !cluster_indices || !grid || !t->child || !t->parent) return set_error(MNV_E_INVALID, "null argument");
+    if (t->N != 2) return set_error(MNV_E_UNSUPPORTED, "only N == 2 octrees are supported");
+    const int need = 3 + (opt->need_viewdir ? 3 : 0) + (opt->appearance_embedding != -1 ? 1 : 0);
+    if (samples_dim < need) return set_error(MNV_E_INVALID, "samples_dim too small for the requested columns");
+    R.child = t->child;
+    R.parent = t->parent;
+    std::memcpy(R.offset, t->offset, sizeof(R.offset));
+    std::memcpy(R.scale, t->scale, sizeof(R.scale));
+    R.capacity = t->capacity;
+    R.samples_per_corner = opt->samples_per_corner;
+    R.samples_dim = samples_dim;
+    R.need_viewdir = opt->need_viewdir ? 1 : 0;
+    R.appearance_embedding = opt->appearance_embedding;
+    R.samples = samples;
+    R.cluster_indices = cluster_indices;
+    std::memcpy(R.grid_dim, grid->grid_dim, sizeof(R.grid_dim));
+    std::memcpy(R.min_position, grid->min_position, sizeof(R.min_position));
+    std::memcpy(R.range, grid->range, sizeof(R.range));
+    return MNV_OK;
+}
+
 }  // namespace mnv
 
 using namespace mnv;
@@ -298,6 +427,44 @@ int mnv_render_nerf_results(const mnv_tree_view *tree, const mnv_camera *cam, co
     else MNV_LAUNCH(0);
 #undef MNV_LAUNCH
     return check_hip(hipGetLastError(), "composite_nerf_kernel");
+}
+
+int mnv_add_children_and_generate_samples(const mnv_tree_edit *tree, const mnv_render_options *opt, const int32_t *parent_nodes,
+                                          int32_t num_parents, float *samples, int32_t samples_dim, int16_t *cluster_indices,
+                                          int32_t *visited, const mnv_cluster_grid *grid, void *hip_stream) {
+    RefineParams R;
+    std::memset(&R, 0, sizeof(R));
+    const int rc = fill_refine(R, tree, opt, samples, samples_dim, cluster_indices, grid);
+    if (rc) return rc;
+    if (!parent_nodes || !visited) return set_error(MNV_E_INVALID, "null argument");
+    if (num_parents <= 0) return MNV_OK;
+    const int64_t n = (int64_t)num_parents * 8;
+    hipLaunchKernelGGL(add_children_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, R, parent_nodes, visited, num_parents);
+    return check_hip(hipGetLastError(), "add_children_kernel");
+}
+
+int mnv_generate_samples(const mnv_tree_edit *tree, const mnv_render_options *opt, const int32_t *nodes, int32_t num_items,
+                         float *samples, int32_t samples_dim, int16_t *cluster_indices, const mnv_cluster_grid *grid, void *hip_stream) {
+    RefineParams R;
+    std::memset(&R, 0, sizeof(R));
+    const int rc = fill_refine(R, tree, opt, samples, samples_dim, cluster_indices, grid);
+    if (rc) return rc;
+    if (!nodes) return set_error(MNV_E_INVALID, "null argument");
+    if (num_items <= 0) return MNV_OK;
+    hipLaunchKernelGGL(generate_samples_kernel, dim3((unsigned)((num_items + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, R, nodes, num_items);
+    return check_hip(hipGetLastError(), "generate_samples_kernel");
+}
+
+int mnv_adjust_parents_and_children(const mnv_tree_edit *tree, int32_t first_shift_index, const uint8_t *to_delete,
+                                    const int32_t *index_shifts, void *hip_stream) {
+    if (!tree || !tree->child || !tree->parent || !to_delete || !index_shifts) return set_error(MNV_E_INVALID, "null argument");
+    if (tree->N != 2) return set_error(MNV_E_UNSUPPORTED, "only N == 2 octrees are supported");
+    if (first_shift_index < 1) return set_error(MNV_E_INVALID, "first_shift_index must be >= 1 (the root has no parent)");
+    const int64_t n = (int64_t)tree->capacity - first_shift_index;
+    if (n <= 0) return MNV_OK;
+    hipLaunchKernelGGL(adjust_parents_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, tree->child, tree->parent,
+                       tree->capacity, first_shift_index, to_delete, index_shifts);
+    return check_hip(hipGetLastError(), "adjust_parents_kernel");
 }
 
 }  // extern "C"

@@ -767,3 +767,102 @@ int orc_render_nerf_results(const orc_tree *tree, const orc_camera *cam, const o
     }
     return 0;
 }
+
+/* ------------------------------------------------------------ refinement kernels (config 5) */
+
+/* generate_samples_inner, renderer_kernel.cu:88-168 (N == 2) */
+static void gen_samples_inner(const int32_t *parent, const float offset[3], const float scale[3], const orc_options *opt,
+                              float *samples, int32_t dim, int16_t *clusters, const orc_cluster_grid *grid, int64_t idx,
+                              int32_t abs_chunk, int32_t child_idx) {
+    int32_t curr[4];
+    curr[0] = abs_chunk * 8 + child_idx;
+    uint8_t depth = 0;
+    float corners[3] = {0, 0, 0};
+    for (;;) {
+        for (int i = 3; i > 0; --i) {
+            curr[i] = curr[0] % 2;
+            curr[0] /= 2;
+        }
+        for (int i = 0; i < 3; ++i) {
+            corners[i] += (float)curr[i + 1];
+            corners[i] /= 2.f;
+        }
+        if (curr[0] == 0) break;
+        curr[0] = parent[curr[0]];
+        depth += 1;
+    }
+    float length_local = 1.f;
+    for (int i = 0; i < depth + 1; ++i) length_local /= 2.f; /* pow(N, -depth - 1) */
+    const int spc = opt->samples_per_corner;
+    float *row0 = samples + idx * spc * dim;
+    for (int i = 0; i < 3; ++i) {
+        corners[i] -= offset[i];
+        corners[i] /= scale[i];
+        for (int j = 0; j < spc; j++) {
+            row0[j * dim + i] *= (length_local / scale[i]);
+            row0[j * dim + i] += corners[i];
+        }
+    }
+    if (opt->need_viewdir) {
+        for (int j = 0; j < spc; j++) {
+            row0[j * dim + 3] = 1;
+            row0[j * dim + 4] = 0;
+            row0[j * dim + 5] = 0;
+            if (opt->appearance_embedding != -1) row0[j * dim + 6] = (float)opt->appearance_embedding;
+        }
+    } else if (opt->appearance_embedding != -1) {
+        for (int j = 0; j < spc; j++) row0[j * dim + 3] = (float)opt->appearance_embedding;
+    }
+    for (int j = 0; j < spc; j++) {
+        const int g1 = (int)fmaxf(fminf((row0[j * dim + 1] - grid->min_position[1]) / grid->range[1] * (float)grid->grid_dim[0],
+                                        (float)grid->grid_dim[0] - 1.0f), 0.0f);
+        const int g2 = (int)fmaxf(fminf((row0[j * dim + 2] - grid->min_position[2]) / grid->range[2] * (float)grid->grid_dim[1],
+                                        (float)grid->grid_dim[1] - 1.0f), 0.0f);
+        clusters[idx * spc + j] = (int16_t)(g1 * grid->grid_dim[1] + g2);
+    }
+}
+
+int orc_add_children_and_generate_samples(int32_t *child, int32_t *parent, const float offset[3], const float scale[3],
+                                          int32_t capacity, const orc_options *opt, const int32_t *parent_nodes,
+                                          int32_t num_parents, float *samples, int32_t samples_dim,
+                                          int16_t *cluster_indices, int32_t *visited, const orc_cluster_grid *grid) {
+    if (!child || !parent || !opt || !parent_nodes || !samples || !cluster_indices || !visited || !grid) return -1;
+    /* renderer_kernel.cu:170-198, one "thread" per (new chunk, child); linking first, as thread child_idx == 0 does */
+    for (int32_t rel = 0; rel < num_parents; ++rel) {
+        const int32_t abs_chunk = capacity + rel, pc = parent_nodes[rel * 2], pj = parent_nodes[rel * 2 + 1];
+        child[(int64_t)pc * 8 + pj] = abs_chunk - pc;
+        parent[abs_chunk] = pc * 8 + pj;
+        visited[abs_chunk] = visited[pc];
+    }
+    for (int64_t tid = 0; tid < (int64_t)num_parents * 8; ++tid) {
+        const int32_t abs_chunk = capacity + (int32_t)(tid / 8), child_idx = (int32_t)(tid % 8);
+        child[(int64_t)abs_chunk * 8 + child_idx] = 0;
+        gen_samples_inner(parent, offset, scale, opt, samples, samples_dim, cluster_indices, grid, tid, abs_chunk, child_idx);
+    }
+    return 0;
+}
+
+int orc_generate_samples(const int32_t *parent, const float offset[3], const float scale[3], const orc_options *opt,
+                         const int32_t *nodes, int32_t num_items, float *samples, int32_t samples_dim,
+                         int16_t *cluster_indices, const orc_cluster_grid *grid) {
+    if (!parent || !opt || !nodes || !samples || !cluster_indices || !grid) return -1;
+    for (int64_t tid = 0; tid < num_items; ++tid) /* renderer_kernel.cu:200-213 */
+        gen_samples_inner(parent, offset, scale, opt, samples, samples_dim, cluster_indices, grid, tid, nodes[tid * 2], nodes[tid * 2 + 1]);
+    return 0;
+}
+
+int orc_adjust_parents_and_children(int32_t *child, int32_t *parent, int32_t capacity, int32_t first_shift_index,
+                                    const uint8_t *to_delete, const int32_t *index_shifts) {
+    if (!child || !parent || !to_delete || !index_shifts || first_shift_index < 1) return -1;
+    for (int32_t chunk = first_shift_index; chunk < capacity; ++chunk) { /* renderer_kernel.cu:63-86 */
+        const int32_t pc = parent[chunk] / 8, pj = parent[chunk] % 8;
+        if (to_delete[chunk]) {
+            child[(int64_t)pc * 8 + pj] = 0;
+        } else {
+            const int32_t parent_shift = index_shifts[pc], child_shift = index_shifts[chunk];
+            child[(int64_t)pc * 8 + pj] += (parent_shift - child_shift);
+            parent[chunk] -= (index_shifts[pc] * 8);
+        }
+    }
+    return 0;
+}

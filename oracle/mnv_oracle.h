@@ -161,6 +161,22 @@ int orc_render_nerf_results(const orc_tree *tree, const orc_camera *cam, const o
                             const float *sample_values, int32_t value_stride, const float *z_vals,
                             const int64_t *offsets, float *rgba, uint8_t *rgba8, int n_threads);
 
+/*
+ * Refinement kernels (src/cuda/renderer_kernel.cu:63-213), serial restatements.  NOTE: these three live
+ * in renderer_kernel.cu, which cannot be built here (CUDA surface objects), so unlike the march and the
+ * guided-sampling pair they are NOT pinned against a reference build: parity unpinned.
+ * child/parent are edited in place; samples holds the caller's uniform [0,1) numbers on entry.
+ */
+int orc_add_children_and_generate_samples(int32_t *child, int32_t *parent, const float offset[3], const float scale[3],
+                                          int32_t capacity, const orc_options *opt, const int32_t *parent_nodes,
+                                          int32_t num_parents, float *samples, int32_t samples_dim,
+                                          int16_t *cluster_indices, int32_t *visited, const orc_cluster_grid *grid);
+int orc_generate_samples(const int32_t *parent, const float offset[3], const float scale[3], const orc_options *opt,
+                         const int32_t *nodes, int32_t num_items, float *samples, int32_t samples_dim,
+                         int16_t *cluster_indices, const orc_cluster_grid *grid);
+int orc_adjust_parents_and_children(int32_t *child, int32_t *parent, int32_t capacity, int32_t first_shift_index,
+                                    const uint8_t *to_delete, const int32_t *index_shifts);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus
