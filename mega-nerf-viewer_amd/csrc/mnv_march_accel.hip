@@ -151,6 +151,7 @@ struct AccelLaunch {
     uint32_t frame_stride_px;  // pixels between consecutive frames in the output buffers
     uint32_t *queue;           // [n_frames][kNumQueues] heads, 64 B apart
     uint32_t tiles_x, n_tiles;
+    uint32_t tile_wlog;                   // log2 of the ray-tile width (tile = 2^wlog x 2^(6-wlog) pixels, 8x8 by default)
     uint32_t band_begin[kNumQueues + 1];  // tile ranges per queue
     int32_t lds_level;                    // levels staged in LDS (<= A.grid_level)
     int32_t refill_min;                   // refill a wavefront once this many lanes are idle
@@ -168,8 +169,8 @@ __device__ __forceinline__ bool ray_pixel(const AccelLaunch &K, uint32_t id, int
     const uint32_t tile = id >> 6, w = id & 63u;
     if (K.part_world <= 1) {
         const uint32_t tx = tile % K.tiles_x, ty = tile / K.tiles_x;
-        bx = (int)(tx * 8 + (w & 7u));
-        by = (int)(ty * 8 + (w >> 3));
+        bx = (int)((tx << K.tile_wlog) + (w & ((1u << K.tile_wlog) - 1u)));
+        by = (int)((ty << (6 - K.tile_wlog)) + (w >> K.tile_wlog));
         pix = (uint32_t)by * (uint32_t)K.P.tw + (uint32_t)bx;
     } else {
         const uint32_t j = tile / K.micro_per_macro, u = tile % K.micro_per_macro;
@@ -214,13 +215,17 @@ struct __attribute__((packed, aligned(4))) ChanWords {
 // reference's iterated x*2 - floor(x*2) bit for bit (all three operations are exact in binary32).
 template <int BASIS, int BLOCK, bool STATS>
 #ifndef MNV_MIN_WAVES
-#define MNV_MIN_WAVES 6  // register budget for 6 waves per SIMD (A/B in DESIGN.md: 1 -> 0.647 ms, 6 -> 0.615 ms, 8 -> 0.615 ms with scratch spills)
+#define MNV_MIN_WAVES 8  // register budget for 8 waves per SIMD: the few spills land in the ray set-up (A/B in DESIGN.md)
 #endif
 __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const AccelLaunch K) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     uint64_t *s_exp = reinterpret_cast<uint64_t *>(s_mem);  // 32 x 8 B
     uint32_t *s_map = s_mem + 64;                            // BLOCK words: dense-sample rank -> lane, per wavefront
-    uint32_t *s_grid = s_mem + 64 + BLOCK;                   // (2^lds_level)^3 words
+    constexpr int NB = BASIS > 0 ? BASIS : 1;
+    // per-lane ray constants that only the dense-sample / finish code needs live in LDS, not in VGPRs:
+    // [k][thread] for k < NB: SH basis; then delta_scale and the output pixel index
+    float *s_ray = reinterpret_cast<float *>(s_mem + 64 + BLOCK);
+    uint32_t *s_grid = s_mem + 64 + BLOCK + (NB + 2) * BLOCK;  // (2^lds_level)^3 words
     constexpr int CHAN_BYTES = chan_bytes_for(BASIS);
     constexpr int ROW_BYTES = row_bytes_pow2(BASIS);
     const FrameParams &P = K.P;
@@ -256,12 +261,12 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
     const int L2 = A.grid2_level;                                       // 0: no second grid
     const int sh2 = Lq - L2;
     const int shg = Lq - A.grid_level;
-    constexpr int NB = BASIS > 0 ? BASIS : 1;
+    float *my_ray = s_ray + threadIdx.x;             // [k * BLOCK]
+    float *wave_ray = s_ray + (threadIdx.x & ~63);  // [k * BLOCK + lane]
 
     // per-lane ray state
-    RaySetup<NB> r;
     float t = 0.f, T = 1.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
-    uint32_t pix = 0;
+    float dir0 = 0.f, dir1 = 0.f, dir2 = 0.f, inv0 = 0.f, inv1 = 0.f, inv2 = 0.f, tmax = 0.f;
     bool alive = false;
 
     // ray queues: home queue first, then steal round robin; frames of a batch are walked in order,
@@ -322,8 +327,10 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                 if (rank < grab && id < end) {
                     int bx, by;
                     stat(2, true);
+                    uint32_t pix;
                     if (ray_pixel(K, id, bx, by, pix)) {
                         pix += pix_base;
+                        RaySetup<NB> r;
                         setup_ray<(BASIS > 0 ? BASIS : 0)>(P, *Cp, P.x0 + bx, P.y0 + by, r);
                         if constexpr (BASIS == 0)
                             r.basis[0] = (0 < P.basis_min || 0 > P.basis_max) ? 0.f : (float)0.28209479177387814;
@@ -332,6 +339,13 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                             alive = true;
                             t = r.tmin;
                             T = 1.f;
+                            tmax = r.tmax;
+                            dir0 = r.dir[0]; dir1 = r.dir[1]; dir2 = r.dir[2];
+                            inv0 = r.invdir[0]; inv1 = r.invdir[1]; inv2 = r.invdir[2];
+#pragma unroll
+                            for (int k = 0; k < NB; ++k) my_ray[k * BLOCK] = r.basis[k];
+                            my_ray[NB * BLOCK] = r.delta_scale;
+                            my_ray[(NB + 1) * BLOCK] = __uint_as_float(pix);
                         } else {
                             composite_and_write(P, (int64_t)pix, 0.f, 0.f, 0.f, P.render_depth ? 1.f : 0.f);
                         }
@@ -349,22 +363,22 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
         float delta_t = 0.f, weight = 0.f, att = 1.f;
         uint32_t vox = 0;
         if (alive) {
-            if (!(t < r.tmax)) {
+            if (!(t < tmax)) {
                 // loop exit, rt_core.cuh:325-330
                 float a = 1.f - T;
                 if (P.render_depth) {
                     o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
                     a = 1.f;
                 }
-                composite_and_write(P, (int64_t)pix, o0, o1, o2, a);
+                composite_and_write(P, (int64_t)__float_as_uint(my_ray[(NB + 1) * BLOCK]), o0, o1, o2, a);
                 alive = false;
             } else {
                 stat(4, true);
                 float pos[3];
                 uint32_t q[3];
-                pos[0] = cen0 + t * r.dir[0];
-                pos[1] = cen1 + t * r.dir[1];
-                pos[2] = cen2 + t * r.dir[2];
+                pos[0] = cen0 + t * dir0;
+                pos[1] = cen1 + t * dir1;
+                pos[2] = cen2 + t * dir2;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     pos[i] = fmaxf(fminf(pos[i], 1.f - 1e-6f), 0.f);
@@ -396,11 +410,12 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                 const float inv_cube = __uint_as_float((uint32_t)(127 - depth) << 23);  // 2^-depth
                 // _dda_unit on the in-leaf coordinates, rt_core.cuh:88-100
                 float tu = 1e4f;
+                const float invd[3] = {inv0, inv1, inv2};
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     const float x = __builtin_amdgcn_fractf(pos[i] * sc);
-                    const float t1 = -x * r.invdir[i];
-                    const float t2 = t1 + r.invdir[i];
+                    const float t1 = -x * invd[i];
+                    const float t2 = t1 + invd[i];
                     tu = fminf(tu, fmaxf(t1, t2));
                 }
                 delta_t = tu * inv_cube + P.step_size;
@@ -410,7 +425,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                     dense = true;
                     if (src == 0) vox = A.grid_vox[((((q[0] >> shg) << A.grid_level) + (q[1] >> shg)) << A.grid_level) + (q[2] >> shg)];
                     else if (src == 1) vox = A.grid2_vox[vox];
-                    att = exact_expf(-delta_t * r.delta_scale * sigma, s_exp);
+                    att = exact_expf(-delta_t * my_ray[NB * BLOCK] * sigma, s_exp);
                     weight = T * (1.f - att);
                 }
             }
@@ -441,7 +456,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                     const uint32_t vx = lane_read(vox, owner);
                     float b[NB];
 #pragma unroll
-                    for (int k = 0; k < NB; ++k) b[k] = lane_read(r.basis[k], owner);
+                    for (int k = 0; k < NB; ++k) b[k] = wave_ray[k * BLOCK + owner];  // the owner's SH basis, from LDS
                     float v = 0.f;
                     if (task) {
                         constexpr int NW = CHAN_BYTES / 4;
@@ -481,7 +496,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                     o0 *= sc;
                     o1 *= sc;
                     o2 *= sc;
-                    composite_and_write(P, (int64_t)pix, o0, o1, o2, 1.f);
+                    composite_and_write(P, (int64_t)__float_as_uint(my_ray[(NB + 1) * BLOCK]), o0, o1, o2, 1.f);
                     alive = false;
                 }
             }
@@ -533,9 +548,12 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     K.A = accel->view;
     K.part_rank = part.rank;
     K.part_world = part.world;
+    static const int env_wlog = getenv("MNV_TILE_WLOG") ? atoi(getenv("MNV_TILE_WLOG")) : 3;
+    K.tile_wlog = (env_wlog >= 0 && env_wlog <= 6) ? (uint32_t)env_wlog : 3u;
     if (part.world <= 1) {
-        K.tiles_x = (uint32_t)((P.tw + 7) / 8);
-        const uint32_t tiles_y = (uint32_t)((P.th + 7) / 8);
+        const uint32_t tile_w = 1u << K.tile_wlog, tile_h = 64u >> K.tile_wlog;
+        K.tiles_x = (uint32_t)((P.tw + tile_w - 1) / tile_w);
+        const uint32_t tiles_y = (uint32_t)((P.th + tile_h - 1) / tile_h);
         K.n_tiles = K.tiles_x * tiles_y;
         // contiguous bands of tile rows per queue
         for (int q = 0; q <= kNumQueues; ++q) K.band_begin[q] = (uint32_t)(((uint64_t)tiles_y * q) / kNumQueues) * K.tiles_x;
@@ -590,18 +608,19 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     if (e != hipSuccess) return (int)e;
 
     const int env_level = getenv("MNV_LDS_LEVEL") ? atoi(getenv("MNV_LDS_LEVEL")) : -1;
-    int lds_level = accel->view.grid_level < 4 ? accel->view.grid_level : 4;
+    int lds_level = accel->view.grid_level < 3 ? accel->view.grid_level : 3;  // 2 KB; level 4 (16 KB) measured equal and costs occupancy
     if (env_level >= 1 && env_level <= accel->view.grid_level) lds_level = env_level;
     K.lds_level = lds_level;
-    const size_t lds_bytes = 256 + 256 * 4 + ((size_t)4 << (3 * lds_level));
+    const int nb_lds = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim > 0) ? accel->view.basis_dim : 1;
+    const size_t lds_bytes = 256 + 256 * 4 + (size_t)(nb_lds + 2) * 256 * 4 + ((size_t)4 << (3 * lds_level));
     const int env_bpc = getenv("MNV_BLOCKS_PER_CU") ? atoi(getenv("MNV_BLOCKS_PER_CU")) : 0;
     static const int env_refill = getenv("MNV_REFILL_MIN") ? atoi(getenv("MNV_REFILL_MIN")) : 0;
     static const int env_ablate = getenv("MNV_ABLATE") ? atoi(getenv("MNV_ABLATE")) : 0;
     K.ablate = env_ablate;
     static const bool env_stats = getenv("MNV_STATS") != nullptr;
     K.stats = env_stats ? accel->stats : nullptr;
-    K.refill_min = env_refill > 0 ? env_refill : 56;  // sweep in DESIGN.md: 16 -> 0.606 ms, 32 -> 0.535, 48 -> 0.507, 56 -> 0.504, 64 -> 0.506
-    int blocks_per_cu = lds_level >= 5 ? 1 : 6;
+    K.refill_min = env_refill > 0 ? env_refill : 64;  // sweep in DESIGN.md: 16 -> 0.606 ms, 32 -> 0.535, 48 -> 0.507, 56 -> 0.504, 64 -> 0.506
+    int blocks_per_cu = lds_level >= 5 ? 1 : (lds_level == 4 ? 6 : 8);
     if (env_bpc > 0) blocks_per_cu = env_bpc;
     int n_blocks = accel->num_cus * blocks_per_cu;
     const uint64_t n_waves_needed = (uint64_t)K.n_tiles * (uint64_t)n_frames;  // one initial 8x8 tile per wave
