@@ -22,7 +22,7 @@ def _port():
     return p
 
 
-@pytest.mark.parametrize("world,gather", [(2, "f32"), (3, "f32")])
+@pytest.mark.parametrize("world,gather", [(2, "f32"), (3, "u8")])
 def test_bench_multirank_rehearsal(torch_gpu, world, gather):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
