@@ -498,6 +498,8 @@ def render_voxels_accel_batch(accel: int, cams, opt: RenderOptions, tile=None, p
     """Several frames (`cams`: list of Camera, same image size) in one launch; frame f is written at
     rgba[f].  `part` = (rank, world, tile_w, tile_h) selects the interleaved macro-tile partition."""
     n = len(cams)
+    if n < 1 or n > MAX_BATCH:
+        raise MnvError(MNV_E_INVALID, f"need 1 .. {MAX_BATCH} cameras, got {n}")
     arr = (CameraStruct * n)(*[c.c for c in cams])
     if tile is None:
         tile = (0, 0, cams[0].width, cams[0].height)

@@ -273,3 +273,67 @@ def test_cfg3_merged_octree_standin_full_size(mnv, orc, torch_gpu):
     tree.move_to_device()
     got, _ = _render_gpu(mnv, torch_gpu, tree, cam, opt, "accel")
     assert np.array_equal(cases.bits(got), cases.bits(ref["rgba"]))
+
+
+_STRESS = {
+    # axis-aligned camera: direction components that are exactly 0 -> invdir = 1 / 1e-9
+    "axis_aligned": dict(camera=dict(width=96, height=96, fx=300.0, center=(0.0, 0.0, 4.0), back=(0.0, 0.0, 1.0), up=(0.0, 1.0, 0.0)), options=dict()),
+    # negative sigma threshold: every leaf, including sigma == 0 ones, is shaded
+    "all_leaves_dense": dict(camera=dict(width=96, height=72, fx=250.0), options=dict(sigma_thresh=-1.0)),
+    # never stop early / stop at the first sample
+    "no_early_stop": dict(camera=dict(width=96, height=72, fx=250.0), options=dict(stop_thresh=0.0)),
+    "stop_immediately": dict(camera=dict(width=96, height=72, fx=250.0), options=dict(stop_thresh=1.0)),
+    # a small and a huge epsilon step (a step_size below the float spacing of t, e.g. 0 or 1e-7 at t ~ 4,
+    # stalls the march on a cell face forever -- in the reference as well -- and is not a valid input)
+    "small_step": dict(camera=dict(width=64, height=48, fx=200.0), options=dict(step_size=1e-5)),
+    "huge_step": dict(camera=dict(width=96, height=72, fx=250.0), options=dict(step_size=0.25)),
+    # degenerate / inverted bounding boxes and a slab thinner than a voxel
+    "empty_bbox": dict(camera=dict(width=64, height=48, fx=200.0), options=dict(render_bbox=(0.6, 0.6, 0.6, 0.4, 0.4, 0.4))),
+    "thin_slab": dict(camera=dict(width=96, height=72, fx=250.0), options=dict(render_bbox=(0.0, 0.0, 0.4999, 1.0, 1.0, 0.5001))),
+    # wide field of view from inside a voxel corner, off-centre principal point, non-square pixels
+    "inside_wide": dict(camera=dict(width=120, height=80, fx=40.0, fy=25.0, cx=10.0, cy=70.0, center=(0.01, 0.02, -0.03), back=(0.3, -0.5, 0.81)),
+                        options=dict(background_brightness=0.3)),
+    # basis window that removes every basis function, and one beyond the basis count
+    "no_basis": dict(camera=dict(width=96, height=72, fx=250.0), options=dict(basis_minmax=(5, 2))),
+    "basis_window_high": dict(camera=dict(width=96, height=72, fx=250.0), options=dict(basis_minmax=(3, 40))),
+    # large rotation of the view directions
+    "rot_pi": dict(camera=dict(width=96, height=72, fx=250.0), options=dict(rot_dirs=(0.0, 3.14159274, 0.0))),
+}
+
+
+@pytest.mark.parametrize("name", list(_STRESS))
+def test_stress_options_bit_exact(mnv, orc, torch_gpu, name):
+    """Corner cases of camera and RenderOptions on an SH9 tree: both kernels == oracle, bit for bit."""
+    spec = _STRESS[name]
+    tree = cases.make_tree(mnv, dict(kind="random", depth=6, basis_dim=9, refine_prob=0.55, empty_prob=0.5, sigma_max=50.0, coef_sd=1.2, seed=21))
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, dict(spec["options"], base="cli"))
+    ref = orc.render(orc.tree_from_view(tree.host_view()), cam.c, opt, want_rgba8=True)
+    assert np.isfinite(ref["rgba"]).all()
+    tree.move_to_device()
+    for which in ("ref_layout", "accel"):
+        got, got8 = _render_gpu(mnv, torch_gpu, tree, cam, opt, which, want_u8=True)
+        assert np.array_equal(cases.bits(got), cases.bits(ref["rgba"])), (name, which, float(np.abs(got - ref["rgba"]).max()))
+        assert np.array_equal(got8, ref["rgba8"]), (name, which)
+
+
+def test_batch_limits(mnv, torch_gpu):
+    torch = torch_gpu
+    tree = cases.make_tree(mnv, cases.CASES["sh4_d6"]["tree"])
+    tree.move_to_device()
+    opt = mnv.RenderOptions.cli_defaults()
+    cams = [mnv.orbit_camera(64, 40, 90.0, 3.0, 5.0 * i, 15.0) for i in range(mnv.MAX_BATCH)]
+    out = torch.full((mnv.MAX_BATCH, 40, 64, 4), float("nan"), dtype=torch.float32, device="cuda")
+    mnv.render_voxels_accel_batch(tree.accel, cams, opt, rgba=out)  # the maximum batch
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    assert np.isfinite(o).all()
+    for i in (0, 31, 63):
+        one = torch.empty((40, 64, 4), dtype=torch.float32, device="cuda")
+        mnv.render_voxels_accel(tree.accel, cams[i], opt, rgba=one)
+        torch.cuda.synchronize()
+        assert np.array_equal(cases.bits(o[i]), cases.bits(one.cpu().numpy()))
+    with pytest.raises(mnv.MnvError):
+        mnv.render_voxels_accel_batch(tree.accel, cams + cams[:1], opt, rgba=out)  # 65 cameras
+    with pytest.raises(mnv.MnvError):
+        mnv.render_voxels_accel_batch(tree.accel, [], opt, rgba=out)
