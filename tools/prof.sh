@@ -19,5 +19,7 @@ pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc tcp TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_TCP_STATE_READ_sum
 pmc grbm GRBM_GUI_ACTIVE GRBM_COUNT
+pmc rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
+pmc wrreq TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 python3 tools/prof_summary.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"
