@@ -18,6 +18,16 @@ __global__ void gather_rows(const uint8_t *rows, const uint32_t *idx, uint32_t n
     if (a == 0x12345678u) sink[0] = a;
 }
 
+// the same gather with non-temporal loads: does the L2 then fetch 64-B sectors instead of 128-B lines?
+__global__ void gather_rows_nt(const uint8_t *rows, const uint32_t *idx, uint32_t n, uint32_t *sink) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s = t / 4, c = t % 4;
+    if (s >= n) return;
+    const uint4 *p = reinterpret_cast<const uint4 *>(rows + (uint64_t)idx[s] * 64 + c * 16);
+    uint32_t a = __builtin_nontemporal_load(&p->x) ^ __builtin_nontemporal_load(&p->y) ^ __builtin_nontemporal_load(&p->z) ^ __builtin_nontemporal_load(&p->w);
+    if (a == 0x12345678u) sink[0] = a;
+}
+
 // reads 16 B of half `half` (0/1) of the 128-B line that holds row idx[s]
 __global__ void touch_half(const uint8_t *rows, const uint32_t *idx, uint32_t n, uint32_t half, uint32_t *sink) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -50,6 +60,8 @@ int main() {
     hipLaunchKernelGGL(gather_rows, dim3((n * 3 + 255) / 256), dim3(256), 0, 0, rows, idx, n, sink);
     hipDeviceSynchronize();
     hipLaunchKernelGGL(stream_read, dim3(2048), dim3(256), 0, 0, (const uint4 *)rows, (uint64_t)(1ull << 30) / 16, sink);  // 1 GiB coalesced
+    hipDeviceSynchronize();
+    hipLaunchKernelGGL(gather_rows_nt, dim3((n * 4 + 255) / 256), dim3(256), 0, 0, rows, idx, n, sink);
     hipDeviceSynchronize();
     // does a miss on one 64-B half fill the whole 128-B line?  touch half 0 of 8192 lines, then half 1
     hipLaunchKernelGGL(touch_half, dim3(32), dim3(256), 0, 0, rows, idx, 8192u, 0u, sink);
