@@ -161,7 +161,7 @@ struct AccelLaunch {
     uint32_t macros_x;                    // macro tiles per row of the rectangle
     uint32_t micro_x, micro_per_macro;    // 8x8 micro tiles per macro-tile row / per macro tile
     unsigned long long *stats;            // STATS builds only: 16 counters
-    int32_t ablate;                       // diagnostics only (breaks results): 1 no colour, 2 no dense samples
+    int32_t ablate;                       // diagnostics only (breaks results): 1 no colour, 2 no dense samples, 4 cached rows
 };
 
 // ray id -> pixel of the rectangle (bx, by) and index of the pixel in the output buffer
@@ -453,7 +453,8 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                     const bool task = my_s < 21 && smp < n_dense;
                     const int owner = task ? (int)map[smp] : lane;
                     const float w = lane_read(weight, owner);
-                    const uint32_t vx = lane_read(vox, owner);
+                    uint32_t vx = lane_read(vox, owner);
+                    if (K.ablate & 4) vx &= 0xffffu;  // diagnostics: rows served from cache (wrong colours)
                     float b[NB];
 #pragma unroll
                     for (int k = 0; k < NB; ++k) b[k] = wave_ray[k * BLOCK + owner];  // the owner's SH basis, from LDS
