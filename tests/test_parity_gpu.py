@@ -337,3 +337,18 @@ def test_batch_limits(mnv, torch_gpu):
         mnv.render_voxels_accel_batch(tree.accel, cams + cams[:1], opt, rgba=out)  # 65 cameras
     with pytest.raises(mnv.MnvError):
         mnv.render_voxels_accel_batch(tree.accel, [], opt, rgba=out)
+
+
+@pytest.mark.parametrize("depth,refine,basis", [(1, 0.0, 9), (2, 0.9, 4), (3, 0.8, 1), (12, 0.33, 9), (14, 0.3, 4)])
+def test_tree_depth_extremes_bit_exact(mnv, orc, torch_gpu, depth, refine, basis):
+    """Trees shallower than the lookup grids (root chunk only, depth 2-3) and much deeper than them
+    (depth 12 / 14: the level-2 grid is capped by its memory budget, several node loads follow)."""
+    tree = cases.make_tree(mnv, dict(kind="random", depth=depth, basis_dim=basis, refine_prob=refine, empty_prob=0.4, sigma_max=60.0, seed=100 + depth))
+    cam = mnv.Camera(160, 120, 420.0).set_pose((-2.6, 1.3, 1.9), (-0.75, 0.37, 0.55))
+    opt = mnv.RenderOptions.cli_defaults()
+    ref = orc.render(orc.tree_from_view(tree.host_view()), cam.c, opt)
+    assert ref["counters"].hits > 0
+    tree.move_to_device()
+    for which in ("ref_layout", "accel"):
+        got, _ = _render_gpu(mnv, torch_gpu, tree, cam, opt, which)
+        assert np.array_equal(cases.bits(got), cases.bits(ref["rgba"])), (depth, which)
