@@ -352,3 +352,19 @@ def test_tree_depth_extremes_bit_exact(mnv, orc, torch_gpu, depth, refine, basis
     for which in ("ref_layout", "accel"):
         got, _ = _render_gpu(mnv, torch_gpu, tree, cam, opt, which)
         assert np.array_equal(cases.bits(got), cases.bits(ref["rgba"])), (depth, which)
+
+
+@pytest.mark.parametrize("step", [1e-4, 1.5e-3, 3e-3, 5e-2])
+def test_extreme_opacity_exercises_expf_tails(mnv, orc, torch_gpu, step):
+    """sigma up to the binary16 maximum: the opacity exponent -dt * scale * sigma sweeps through the
+    denormal (-87 .. -104) and underflow (< -104) branches of expf on the device, bit for bit."""
+    tree = cases.make_tree(mnv, dict(kind="random", depth=5, basis_dim=4, refine_prob=0.6, empty_prob=0.3, sigma_max=65000.0, coef_sd=30.0, seed=77))
+    cam = mnv.Camera(128, 96, 300.0)
+    opt = mnv.RenderOptions.cli_defaults()
+    opt.step_size, opt.stop_thresh = step, 0.0  # never stop early: T itself goes denormal / zero
+    ref = orc.render(orc.tree_from_view(tree.host_view()), cam.c, opt)
+    assert np.isfinite(ref["rgba"]).all()
+    tree.move_to_device()
+    for which in ("ref_layout", "accel"):
+        got, _ = _render_gpu(mnv, torch_gpu, tree, cam, opt, which)
+        assert np.array_equal(cases.bits(got), cases.bits(ref["rgba"])), (step, which, float(np.abs(got - ref["rgba"]).max()))
