@@ -182,6 +182,20 @@ int mnv_render_voxels_accel_batch(const mnv_accel *accel, const mnv_camera *cams
                                   const mnv_render_options *opt, mnv_rect tile, mnv_partition part, float *rgba_out,
                                   uint8_t *rgba8_out, void *hip_stream);
 
+/*
+ * The tuned march with the refinement trackers of render_voxels_trace_ray
+ * (include/cuda/rt_core.cuh:179-180,237-252,308-321; consumed by cuda_renderer.cpp:150-175):
+ * split_track / sample_track are [tile.h][tile.w][3] float rows (priority, chunk, child) exactly
+ * as mnv_render_voxels writes them; sample_counts is the tree's live [capacity][N^3] int16 array in
+ * the reference layout (it changes between frames, so it is not part of the accel) or NULL.
+ * opt->max_depth / opt->max_sample_count bound the candidates.  The `visited` marks
+ * (track_visit) need every chunk on the descent path and stay with mnv_render_voxels.
+ * Either tracker may be NULL; with both NULL this is mnv_render_voxels_accel.
+ */
+int mnv_render_voxels_accel_track(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,
+                                  mnv_rect tile, float *rgba_out, uint8_t *rgba8_out, float *split_track,
+                                  float *sample_track, const int16_t *sample_counts, void *hip_stream);
+
 /* ------------------------------------------------ guided sampling kernels (BASELINE config 5) */
 
 /* Cluster grid over world y,z used to route samples to sub-module MLPs

@@ -181,6 +181,8 @@ _SIGNATURES = {
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_render_voxels_accel_batch": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.c_int32, C.POINTER(RenderOptions), Rect,
                                                 Partition, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mnv_render_voxels_accel_track": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_get_samples_from_voxels": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32,
                                               C.c_void_p, C.POINTER(ClusterGrid), C.c_void_p]),
@@ -429,6 +431,16 @@ def render_voxels_accel(accel: int, cam: Camera, opt: RenderOptions, tile=None, 
         tile = (0, 0, cam.width, cam.height)
     _check(lib().mnv_render_voxels_accel(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba), _ptr(rgba8),
                                          C.c_void_p(stream)))
+
+
+def render_voxels_accel_track(accel: int, cam: Camera, opt: RenderOptions, tile=None, rgba=None, rgba8=None,
+                              split_track=None, sample_track=None, sample_counts=None, stream: int = 0) -> None:
+    """The tuned march with the refinement trackers (rows as render_voxels writes them)."""
+    if tile is None:
+        tile = (0, 0, cam.width, cam.height)
+    _check(lib().mnv_render_voxels_accel_track(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba),
+                                               _ptr(rgba8), _ptr(split_track), _ptr(sample_track), _ptr(sample_counts),
+                                               C.c_void_p(stream)))
 
 
 def partition_local_tiles(tile, rank: int, world: int, tile_w: int, tile_h: int) -> int:

@@ -160,7 +160,11 @@ struct AccelLaunch {
     uint32_t macro_w, macro_h;            // macro tile size in pixels
     uint32_t macros_x;                    // macro tiles per row of the rectangle
     uint32_t micro_x, micro_per_macro;    // 8x8 micro tiles per macro-tile row / per macro tile
-    unsigned long long *stats;            // STATS builds only: 16 counters
+    unsigned long long *stats;            // MODE 1 only: 16 counters
+    // MODE 2 only: refinement trackers (rt_core.cuh:179-180,237-252,308-321), indexed like the pixels
+    float *split_track, *sample_track;
+    const int16_t *sample_counts;         // reference layout [capacity][8], may be NULL
+    int32_t max_depth, max_sample_count;
     int32_t ablate;                       // diagnostics only (breaks results): 1 no colour, 2 no dense samples, 4 cached rows
 };
 
@@ -213,7 +217,7 @@ struct __attribute__((packed, aligned(4))) ChanWords {
 // bit (Lq - d) of each coordinate is the child index at depth d, and the cell numbers of the two
 // lookup grids are plain shifts.  The in-leaf coordinates are fract(pos * 2^depth), which equals the
 // reference's iterated x*2 - floor(x*2) bit for bit (all three operations are exact in binary32).
-template <int BASIS, int BLOCK, bool STATS>
+template <int BASIS, int BLOCK, int MODE /* 0 plain, 1 statistics, 2 refinement trackers */>
 #ifndef MNV_MIN_WAVES
 #define MNV_MIN_WAVES 8  // register budget for 8 waves per SIMD: the few spills land in the ray set-up (A/B in DESIGN.md)
 #endif
@@ -268,6 +272,23 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
     float t = 0.f, T = 1.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
     float dir0 = 0.f, dir1 = 0.f, dir2 = 0.f, inv0 = 0.f, inv1 = 0.f, inv2 = 0.f, tmax = 0.f;
     bool alive = false;
+    // MODE 2: per-ray tracker state
+    float max_weight = -1.f, max_sample_weight = -1.f, sp_prio = 0.f, sa_prio = 0.f;
+    int32_t sp_vox = -1, sa_vox = -1;
+    auto write_trackers = [&](uint32_t p) {
+        if constexpr (MODE == 2) {
+            if (K.split_track) {
+                K.split_track[(int64_t)p * 3 + 0] = sp_prio;
+                K.split_track[(int64_t)p * 3 + 1] = sp_vox < 0 ? -1.f : (float)(sp_vox >> 3);
+                K.split_track[(int64_t)p * 3 + 2] = sp_vox < 0 ? -1.f : (float)(sp_vox & 7);
+            }
+            if (K.sample_track) {
+                K.sample_track[(int64_t)p * 3 + 0] = sa_prio;
+                K.sample_track[(int64_t)p * 3 + 1] = sa_vox < 0 ? -1.f : (float)(sa_vox >> 3);
+                K.sample_track[(int64_t)p * 3 + 2] = sa_vox < 0 ? -1.f : (float)(sa_vox & 7);
+            }
+        }
+    };
 
     // ray queues: home queue first, then steal round robin; frames of a batch are walked in order,
     // every wavefront at its own pace, so the tail of frame f overlaps the start of frame f + 1
@@ -279,7 +300,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
     uint32_t pix_base = 0;
 
     auto stat = [&](int slot, bool pred) {
-        if constexpr (STATS) {
+        if constexpr (MODE == 1) {
             const uint64_t m = __ballot(pred);
             if (m && lane == (int)__builtin_ctzll(m)) {
                 atomicAdd(&K.stats[slot], 1ull);
@@ -330,6 +351,12 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                     uint32_t pix;
                     if (ray_pixel(K, id, bx, by, pix)) {
                         pix += pix_base;
+                        if constexpr (MODE == 2) {
+                            max_weight = max_sample_weight = -1.f;
+                            sp_prio = (float)(K.max_depth + 1);
+                            sa_prio = (float)(K.max_sample_count + 1);
+                            sp_vox = sa_vox = -1;
+                        }
                         RaySetup<NB> r;
                         setup_ray<(BASIS > 0 ? BASIS : 0)>(P, *Cp, P.x0 + bx, P.y0 + by, r);
                         if constexpr (BASIS == 0)
@@ -348,6 +375,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                             my_ray[(NB + 1) * BLOCK] = __uint_as_float(pix);
                         } else {
                             composite_and_write(P, (int64_t)pix, 0.f, 0.f, 0.f, P.render_depth ? 1.f : 0.f);
+                            write_trackers(pix);
                         }
                     }
                 }
@@ -371,6 +399,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                     a = 1.f;
                 }
                 composite_and_write(P, (int64_t)__float_as_uint(my_ray[(NB + 1) * BLOCK]), o0, o1, o2, a);
+                write_trackers(__float_as_uint(my_ray[(NB + 1) * BLOCK]));
                 alive = false;
             } else {
                 stat(4, true);
@@ -420,13 +449,38 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                 }
                 delta_t = tu * inv_cube + P.step_size;
                 const float sigma = half_bits_to_float((uint16_t)word);
-                if (sigma > P.sigma_thresh && !(K.ablate & 2)) {
-                    // opacity of a dense sample, rt_core.cuh:233-235
-                    dense = true;
+                const bool is_dense = sigma > P.sigma_thresh && !(K.ablate & 2);
+                bool need_vox = is_dense;
+                if constexpr (MODE == 2) need_vox = is_dense || max_weight == -1.f || max_sample_weight == -1.f;
+                if (need_vox) {
+                    // voxel index of a leaf that was answered by one of the lookup grids
                     if (src == 0) vox = A.grid_vox[((((q[0] >> shg) << A.grid_level) + (q[1] >> shg)) << A.grid_level) + (q[2] >> shg)];
                     else if (src == 1) vox = A.grid2_vox[vox];
+                }
+                if (is_dense) {
+                    // opacity of a dense sample, rt_core.cuh:233-235
+                    dense = true;
                     att = exact_expf(-delta_t * my_ray[NB * BLOCK] * sigma, s_exp);
                     weight = T * (1.f - att);
+                }
+                if constexpr (MODE == 2) {
+                    // rt_core.cuh:237-252 (dense leaf: best weight so far) and :308-321 (first leaf before any dense one)
+                    if (need_vox) {
+                        const bool split_ok = depth < K.max_depth && (is_dense ? weight > max_weight : max_weight == -1.f);
+                        if (split_ok) {
+                            sp_vox = (int32_t)vox;
+                            sp_prio = (float)depth;
+                            if (is_dense) max_weight = weight;
+                        }
+                        if (K.sample_counts && (is_dense ? weight > max_sample_weight : max_sample_weight == -1.f)) {
+                            const int16_t sc = K.sample_counts[vox];
+                            if (sc < K.max_sample_count) {
+                                sa_vox = (int32_t)vox;
+                                sa_prio = (float)sc;
+                                if (is_dense) max_sample_weight = weight;
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -498,6 +552,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                     o1 *= sc;
                     o2 *= sc;
                     composite_and_write(P, (int64_t)__float_as_uint(my_ray[(NB + 1) * BLOCK]), o0, o1, o2, 1.f);
+                    write_trackers(__float_as_uint(my_ray[(NB + 1) * BLOCK]));
                     alive = false;
                 }
             }
@@ -510,10 +565,10 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
 
 static int row_bytes_for(int basis) { return row_bytes_pow2(basis); }
 
-template <int BASIS, bool ST>
+template <int BASIS, int MODE>
 static int launch_variant2(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
     constexpr int BLOCK = 256;
-    auto kern = march_accel_kernel<BASIS, BLOCK, ST>;
+    auto kern = march_accel_kernel<BASIS, BLOCK, MODE>;
     static thread_local size_t configured = 0;
     if (lds_bytes > 65536 && configured < lds_bytes) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -527,9 +582,10 @@ static int launch_variant2(const AccelLaunch &K, int n_blocks, size_t lds_bytes,
 template <int BASIS>
 static int launch_variant(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
     if constexpr (BASIS == 9) {  // MNV_STATS=1 diagnostics build of the headline variant only
-        if (K.stats) return launch_variant2<BASIS, true>(K, n_blocks, lds_bytes, stream);
+        if (K.stats) return launch_variant2<BASIS, 1>(K, n_blocks, lds_bytes, stream);
     }
-    return launch_variant2<BASIS, false>(K, n_blocks, lds_bytes, stream);
+    if (K.split_track || K.sample_track) return launch_variant2<BASIS, 2>(K, n_blocks, lds_bytes, stream);
+    return launch_variant2<BASIS, 0>(K, n_blocks, lds_bytes, stream);
 }
 
 int32_t partition_local_tiles(mnv_rect tile, mnv_partition part) {
@@ -540,12 +596,26 @@ int32_t partition_local_tiles(mnv_rect tile, mnv_partition part) {
     return (int32_t)((total - part.rank + part.world - 1) / part.world);
 }
 
+// Refinement trackers of one launch (all device pointers; rows indexed like the pixels).
+struct AccelTrack {
+    float *split_track, *sample_track;
+    const int16_t *sample_counts;
+    int32_t max_depth, max_sample_count;
+};
+
 int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *cams, int n_frames, mnv_partition part,
-                 hipStream_t stream) {
+                 const AccelTrack *track, hipStream_t stream) {
     if (P.tw <= 0 || P.th <= 0 || n_frames <= 0) return 0;
     AccelLaunch K;
     std::memset(static_cast<void *>(&K), 0, sizeof(K));
     K.P = P;
+    if (track) {
+        K.split_track = track->split_track;
+        K.sample_track = track->sample_track;
+        K.sample_counts = track->sample_counts;
+        K.max_depth = track->max_depth;
+        K.max_sample_count = track->max_sample_count;
+    }
     K.A = accel->view;
     K.part_rank = part.rank;
     K.part_world = part.world;
@@ -608,13 +678,14 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
 
-    const int env_level = getenv("MNV_LDS_LEVEL") ? atoi(getenv("MNV_LDS_LEVEL")) : -1;
+    // diagnostics knobs; read once
+    static const int env_level = getenv("MNV_LDS_LEVEL") ? atoi(getenv("MNV_LDS_LEVEL")) : -1;
     int lds_level = accel->view.grid_level < 3 ? accel->view.grid_level : 3;  // 2 KB; level 4 (16 KB) measured equal and costs occupancy
     if (env_level >= 1 && env_level <= accel->view.grid_level) lds_level = env_level;
     K.lds_level = lds_level;
     const int nb_lds = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim > 0) ? accel->view.basis_dim : 1;
     const size_t lds_bytes = 256 + 256 * 4 + (size_t)(nb_lds + 2) * 256 * 4 + ((size_t)4 << (3 * lds_level));
-    const int env_bpc = getenv("MNV_BLOCKS_PER_CU") ? atoi(getenv("MNV_BLOCKS_PER_CU")) : 0;
+    static const int env_bpc = getenv("MNV_BLOCKS_PER_CU") ? atoi(getenv("MNV_BLOCKS_PER_CU")) : 0;
     static const int env_refill = getenv("MNV_REFILL_MIN") ? atoi(getenv("MNV_REFILL_MIN")) : 0;
     static const int env_ablate = getenv("MNV_ABLATE") ? atoi(getenv("MNV_ABLATE")) : 0;
     K.ablate = env_ablate;
@@ -791,9 +862,9 @@ int mnv_render_voxels_accel_part(const mnv_accel *accel, const mnv_camera *cam, 
     return mnv_render_voxels_accel_batch(accel, cam, 1, opt, tile, part, rgba_out, rgba8_out, hip_stream);
 }
 
-int mnv_render_voxels_accel_batch(const mnv_accel *accel, const mnv_camera *cams, int32_t n_cams,
-                                  const mnv_render_options *opt, mnv_rect tile, mnv_partition part, float *rgba_out,
-                                  uint8_t *rgba8_out, void *hip_stream) {
+static int render_accel(const mnv_accel *accel, const mnv_camera *cams, int32_t n_cams, const mnv_render_options *opt,
+                        mnv_rect tile, mnv_partition part, float *rgba_out, uint8_t *rgba8_out, const AccelTrack *track,
+                        void *hip_stream) {
     if (!accel) return set_error(MNV_E_INVALID, "accel is null");
     if (!cams || n_cams < 1 || n_cams > MNV_MAX_BATCH) return set_error(MNV_E_INVALID, "need 1 .. MNV_MAX_BATCH cameras");
     if (part.world > 1 && (part.rank < 0 || part.rank >= part.world || part.tile_w < 8 || part.tile_h < 8 ||
@@ -817,9 +888,26 @@ int mnv_render_voxels_accel_batch(const mnv_accel *accel, const mnv_camera *cams
     }
     hipStream_t stream = (hipStream_t)hip_stream;
     LaunchTimer timer(stream);
-    rc = launch_accel(accel, P, blocks, n_cams, part, stream);
+    rc = launch_accel(accel, P, blocks, n_cams, part, track, stream);
     if (rc == -1000) return set_error(MNV_E_UNSUPPORTED, "unsupported basis_dim for the accel path");
     return check_hip((hipError_t)rc, "march_accel_kernel");
+}
+
+int mnv_render_voxels_accel_batch(const mnv_accel *accel, const mnv_camera *cams, int32_t n_cams,
+                                  const mnv_render_options *opt, mnv_rect tile, mnv_partition part, float *rgba_out,
+                                  uint8_t *rgba8_out, void *hip_stream) {
+    return render_accel(accel, cams, n_cams, opt, tile, part, rgba_out, rgba8_out, nullptr, hip_stream);
+}
+
+int mnv_render_voxels_accel_track(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,
+                                  mnv_rect tile, float *rgba_out, uint8_t *rgba8_out, float *split_track,
+                                  float *sample_track, const int16_t *sample_counts, void *hip_stream) {
+    if (!opt) return set_error(MNV_E_INVALID, "options are null");
+    if (!split_track && !sample_track)
+        return mnv_render_voxels_accel(accel, cam, opt, tile, rgba_out, rgba8_out, hip_stream);
+    const mnv_partition whole = {0, 1, 0, 0};
+    const AccelTrack track = {split_track, sample_track, sample_counts, opt->max_depth, opt->max_sample_count};
+    return render_accel(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, &track, hip_stream);
 }
 
 }  // extern "C"

@@ -69,6 +69,41 @@ def test_trackers_and_visited_match_oracle(mnv, orc, torch_gpu):
     assert np.array_equal(visited.cpu().numpy(), visited_ref)
 
 
+@pytest.mark.parametrize("name,max_depth,with_counts", [("sh4_d6", 5, True), ("shell_d7_sh9", 7, True), ("rgba_d5", 3, False),
+                                                        ("terrain_d7_aniso", 6, True), ("cfg1_sh1_d4", 9, True)])
+def test_accel_trackers_match_oracle(mnv, orc, torch_gpu, name, max_depth, with_counts):
+    """The tuned kernel's tracker mode (mnv_render_voxels_accel_track) writes the rows of
+    rt_core.cuh:237-252,308-321 -- voxel indices recovered through the lookup grids."""
+    torch = torch_gpu
+    spec = cases.CASES[name]
+    tree = cases.make_tree(mnv, spec["tree"])
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    opt.max_depth = max_depth
+    opt.max_sample_count = 9
+    v = tree.host_view()
+    rng = np.random.default_rng(7)
+    sc = rng.integers(0, 14, size=(v.capacity, 8)).astype(np.int16) if with_counts else None
+    ref = orc.render(orc.tree_from_view(v, sample_counts=sc), cam.c, opt, want_trackers=True)
+    tree.move_to_device()
+    sc_dev = torch.from_numpy(sc).cuda() if with_counts else None
+    h, w = cam.height, cam.width
+    rgba = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    split = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")
+    sample = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")
+    mnv.render_voxels_accel_track(tree.accel, cam, opt, rgba=rgba, split_track=split, sample_track=sample, sample_counts=sc_dev)
+    torch.cuda.synchronize()
+    assert np.array_equal(cases.bits(rgba.cpu().numpy()), cases.bits(ref["rgba"]))
+    assert np.array_equal(split.cpu().numpy(), ref["split"])
+    assert np.array_equal(sample.cpu().numpy(), ref["sample"])
+    # a tile of the frame, split tracker only
+    tile = (w // 4, h // 4, w // 2 + 3, h // 2 + 1)
+    split_t = torch.full((tile[3], tile[2], 3), -1.0, dtype=torch.float32, device="cuda")
+    mnv.render_voxels_accel_track(tree.accel, cam, opt, tile=tile, split_track=split_t)
+    torch.cuda.synchronize()
+    assert np.array_equal(split_t.cpu().numpy(), ref["split"][tile[1]:tile[1] + tile[3], tile[0]:tile[0] + tile[2]])
+
+
 def test_empty_tree_draws_background(mnv, torch_gpu):
     torch = torch_gpu
     cam = mnv.Camera(64, 48)
