@@ -270,6 +270,59 @@ int mnv_generate_samples(const mnv_tree_edit *tree, const mnv_render_options *op
 int mnv_adjust_parents_and_children(const mnv_tree_edit *tree, int32_t first_shift_index, const uint8_t *to_delete,
                                     const int32_t *index_shifts, void *hip_stream);
 
+/* --------------------------- refinement: what the reference does with the trackers between frames
+ * (VolumeRenderer::Impl::expand_voxels / get_more_samples / prune_tree, src/renderer/cuda_renderer.cpp:205-381,
+ * there a chain of libtorch tensor ops; here device-resident, one call per step).  These calls
+ * synchronise `hip_stream` before returning because they hand counts back to the host, as the
+ * reference's `.size(0)` / `.item()` reads do. */
+
+/*
+ * expand_voxels' vote (cuda_renderer.cpp:205-227): among the rows (priority, chunk, child) of split_track
+ * with chunk >= 0, count identical rows, keep those proposed by >= 2 rays, order by (count descending,
+ * priority, chunk, child ascending) -- torch::unique_dim's lexicographic order on (-count, row) -- and write
+ * the first min(max_out, n) as int32 (chunk, child) pairs to nodes_out (device, [max_out][2]).
+ *   n_out         host: pairs written            n_candidates  host: rows that qualified ("Split candidates: N")
+ * Rows hold integer-valued floats (|priority| < 32768, 0 <= chunk < 2^31, 0 <= child < 8), which is what the
+ * march writes.  max_out = opt.split_batch_size.
+ */
+int mnv_select_split_candidates(const float *split_track, int64_t n_rows, int32_t max_out, int32_t *nodes_out,
+                                int32_t *n_out, int32_t *n_candidates, void *hip_stream);
+/* get_more_samples' selection (cuda_renderer.cpp:281-296): unique rows of sample_track with chunk >= 0 in
+ * ascending (priority, chunk, child) order, no vote threshold; first min(max_out, n) as (chunk, child). */
+int mnv_select_sample_candidates(const float *sample_track, int64_t n_rows, int32_t max_out, int32_t *nodes_out,
+                                 int32_t *n_out, int32_t *n_candidates, void *hip_stream);
+/*
+ * cuda_renderer.cpp:262-270: rows [capacity*8, (capacity + num_parents)*8) of data (device binary16,
+ * [max_capacity][8][data_dim]) become the mean over samples_per_corner of results[num_parents*8]
+ * [samples_per_corner][result_stride] (device float, result_stride >= data_dim; the reference's is
+ * data_dim + 1); sample_counts (may be NULL) of the new chunks is set to samples_per_corner.  `capacity` is
+ * the chunk count BEFORE the split; the caller then adds num_parents to it.  Mean = fp32 sum in sample order /
+ * n, rounded once to binary16 (torch's reduction order is unspecified: agreement is to 1 binary16 ulp).
+ */
+int mnv_apply_split_results(uint16_t *data, int16_t *sample_counts, int32_t capacity, int32_t num_parents,
+                            const float *results, int32_t result_stride, int32_t samples_per_corner, int32_t data_dim,
+                            void *hip_stream);
+/*
+ * cuda_renderer.cpp:307-332: running average of existing voxels nodes[i] = (chunk, child) with
+ * samples_per_corner new network outputs each: data += (sum_new - half(n_new * data)) / (count + n_new),
+ * count += n_new.  The reference expression stops at index_add_ (binary16 self, fp32 source is rejected by
+ * libtorch), so the last rounding is this build's choice: one rounding of (old + update) to binary16.
+ */
+int mnv_apply_sample_results(uint16_t *data, int16_t *sample_counts, const int32_t *nodes, int32_t num_items,
+                             const float *results, int32_t result_stride, int32_t samples_per_corner, int32_t data_dim,
+                             void *hip_stream);
+/*
+ * prune_tree (cuda_renderer.cpp:335-381): chunks of [0, tree->capacity) whose visit mark is 0 are deleted,
+ * the survivors are compacted in order (child offsets and parent ids fixed up by
+ * mnv_adjust_parents_and_children with first_shift_index 0), and all marks but the root's are cleared over
+ * [1, max_capacity).  data / tree->child / tree->parent are compacted; sample_counts too when non-NULL (the
+ * reference leaves sample_counts uncompacted -- pass NULL for that behaviour).
+ *   new_capacity  host: chunks in use after the call     num_deleted  host: 0 = "Nothing can be pruned"
+ * Returns MNV_E_INVALID when the root itself is unmarked (no track_visit frame was rendered).
+ */
+int mnv_prune_tree(const mnv_tree_edit *tree, uint16_t *data, int32_t data_dim, int16_t *sample_counts, int32_t *visited,
+                   int32_t max_capacity, int32_t *new_capacity, int32_t *num_deleted, void *hip_stream);
+
 /* Average device time (ms) of the last `mnv_render_*` launches since the
  * previous call, measured with HIP events on the launch stream when
  * mnv_set_timing(1) is active; used by bench.py for roofline.achieved. */

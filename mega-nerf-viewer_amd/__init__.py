@@ -193,6 +193,12 @@ _SIGNATURES = {
     "mnv_generate_samples": (C.c_int, [C.POINTER(TreeEdit), C.POINTER(RenderOptions), C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                        C.c_void_p, C.POINTER(ClusterGrid), C.c_void_p]),
     "mnv_adjust_parents_and_children": (C.c_int, [C.POINTER(TreeEdit), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mnv_select_split_candidates": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]),
+    "mnv_select_sample_candidates": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]),
+    "mnv_apply_split_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "mnv_apply_sample_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "mnv_prune_tree": (C.c_int, [C.POINTER(TreeEdit), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
+                                 C.POINTER(C.c_int32), C.c_void_p]),
     "mnv_set_timing": (None, [C.c_int]),
     "mnv_take_timing": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "mnv_n3tree_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -500,6 +506,40 @@ def generate_samples(edit: TreeEdit, opt: RenderOptions, nodes, samples, cluster
 
 def adjust_parents_and_children(edit: TreeEdit, first_shift_index: int, to_delete, index_shifts, stream: int = 0) -> None:
     _check(lib().mnv_adjust_parents_and_children(C.byref(edit), first_shift_index, _ptr(to_delete), _ptr(index_shifts), C.c_void_p(stream)))
+
+
+def select_split_candidates(split_track, max_out: int, nodes_out, stream: int = 0):
+    """expand_voxels' vote on a [n][3] device tracker -> (pairs written to nodes_out, qualifying candidates)."""
+    n_out, n_cand = C.c_int32(0), C.c_int32(0)
+    _check(lib().mnv_select_split_candidates(_ptr(split_track), split_track.numel() // 3, max_out, _ptr(nodes_out), C.byref(n_out),
+                                             C.byref(n_cand), C.c_void_p(stream)))
+    return n_out.value, n_cand.value
+
+
+def select_sample_candidates(sample_track, max_out: int, nodes_out, stream: int = 0):
+    n_out, n_cand = C.c_int32(0), C.c_int32(0)
+    _check(lib().mnv_select_sample_candidates(_ptr(sample_track), sample_track.numel() // 3, max_out, _ptr(nodes_out), C.byref(n_out),
+                                              C.byref(n_cand), C.c_void_p(stream)))
+    return n_out.value, n_cand.value
+
+
+def apply_split_results(data, sample_counts, capacity: int, num_parents: int, results, samples_per_corner: int, data_dim: int,
+                        stream: int = 0) -> None:
+    _check(lib().mnv_apply_split_results(_ptr(data), _ptr(sample_counts), capacity, num_parents, _ptr(results), results.shape[-1],
+                                         samples_per_corner, data_dim, C.c_void_p(stream)))
+
+
+def apply_sample_results(data, sample_counts, nodes, results, samples_per_corner: int, data_dim: int, stream: int = 0) -> None:
+    _check(lib().mnv_apply_sample_results(_ptr(data), _ptr(sample_counts), _ptr(nodes), nodes.shape[0], _ptr(results), results.shape[-1],
+                                          samples_per_corner, data_dim, C.c_void_p(stream)))
+
+
+def prune_tree(edit: TreeEdit, data, data_dim: int, sample_counts, visited, max_capacity: int, stream: int = 0):
+    """-> (new_capacity, num_deleted)."""
+    new_cap, n_del = C.c_int32(0), C.c_int32(0)
+    _check(lib().mnv_prune_tree(C.byref(edit), _ptr(data), data_dim, _ptr(sample_counts), _ptr(visited), max_capacity, C.byref(new_cap),
+                                C.byref(n_del), C.c_void_p(stream)))
+    return new_cap.value, n_del.value
 
 
 MAX_BATCH = 64

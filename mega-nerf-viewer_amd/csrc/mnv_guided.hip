@@ -313,6 +313,11 @@ __global__ void adjust_parents_kernel(int32_t *child, int32_t *parent, int32_t c
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= capacity - first_shift_index) return;
     const int32_t chunk = (int32_t)tid + first_shift_index;
+    // The root has no parent slot to fix.  The reference's host code does pass first_shift_index 0
+    // (cuda_renderer.cpp:350: argmin of a cumsum); its thread for chunk 0 then adds 0 to child[0][0]
+    // (svox stores parent 0 for the root), i.e. changes nothing -- skipped here, which also removes the
+    // unsynchronised read-modify-write on that word.
+    if (chunk == 0) return;
     const int32_t par = parent[chunk];
     const int32_t pc = par / 8, pj = par % 8;
     if (to_delete[chunk]) {
@@ -459,7 +464,7 @@ int mnv_adjust_parents_and_children(const mnv_tree_edit *tree, int32_t first_shi
                                     const int32_t *index_shifts, void *hip_stream) {
     if (!tree || !tree->child || !tree->parent || !to_delete || !index_shifts) return set_error(MNV_E_INVALID, "null argument");
     if (tree->N != 2) return set_error(MNV_E_UNSUPPORTED, "only N == 2 octrees are supported");
-    if (first_shift_index < 1) return set_error(MNV_E_INVALID, "first_shift_index must be >= 1 (the root has no parent)");
+    if (first_shift_index < 0) return set_error(MNV_E_INVALID, "first_shift_index must be >= 0");
     const int64_t n = (int64_t)tree->capacity - first_shift_index;
     if (n <= 0) return MNV_OK;
     hipLaunchKernelGGL(adjust_parents_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, tree->child, tree->parent,

@@ -1,0 +1,398 @@
+// mnv_refine.hip -- the tracker-consuming side of the refinement loop (BASELINE config 5), device-resident.
+//
+// The reference runs this as a chain of libtorch tensor ops on the host thread
+// (src/renderer/cuda_renderer.cpp:205-381: expand_voxels, get_more_samples, prune_tree); here each step is
+// one entry point working on the caller's device arrays:
+//   mnv_select_split_candidates    cuda_renderer.cpp:205-227  (unique_dim vote count, count >= 2, order)
+//   mnv_select_sample_candidates   cuda_renderer.cpp:281-296  (unique_dim, order)
+//   mnv_apply_split_results        cuda_renderer.cpp:262-272  (mean over samples -> new f16 rows)
+//   mnv_apply_sample_results       cuda_renderer.cpp:307-332  (running average)
+//   mnv_prune_tree                 cuda_renderer.cpp:335-381  (visit-mark compaction)
+// Sorting / run-length / scan primitives come from rocPRIM; the row arithmetic is written here.
+// All of it is integer or byte work except the two averages (fp32, rounded once to binary16).
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/functional.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+#include "mnv_internal.h"
+
+namespace mnv {
+
+namespace {
+
+// ---------------------------------------------------------------- grow-only device workspace, per device
+struct Workspace {
+    void *ptr = nullptr;
+    size_t cap = 0;
+};
+std::mutex g_ws_mutex;
+Workspace g_ws[16];
+
+int ws_reserve(size_t bytes, uint8_t **out) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return set_error(MNV_E_NO_DEVICE, "no current HIP device");
+    Workspace &w = g_ws[dev];
+    if (w.cap < bytes) {
+        if (w.ptr) (void)hipFree(w.ptr);
+        w.ptr = nullptr;
+        w.cap = 0;
+        const size_t want = bytes + bytes / 4;
+        int rc = check_hip(hipMalloc(&w.ptr, want), "hipMalloc(refine workspace)");
+        if (rc) return rc;
+        w.cap = want;
+    }
+    *out = static_cast<uint8_t *>(w.ptr);
+    return MNV_OK;
+}
+
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) {
+        const size_t at = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return at;
+    }
+};
+
+// ---------------------------------------------------------------- candidate selection
+
+// Tracker rows are (priority, chunk, child) as floats holding integers (rt_core.cuh:239-251,310-320);
+// lexicographic order of the rows == order of this packed key.  Rows with chunk < 0 are "no candidate".
+constexpr uint64_t kNoCandidate = 1ull << 51;
+constexpr int kKeyBits = 52;
+
+__global__ void pack_tracker_keys(const float *__restrict__ track, int64_t n_rows, uint64_t *__restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows) return;
+    const float prio = track[i * 3 + 0], chunk = track[i * 3 + 1], child = track[i * 3 + 2];
+    uint64_t key = kNoCandidate;
+    if (chunk >= 0.f) {
+        const uint64_t p = (uint64_t)((int32_t)prio + 32768) & 0xffffu;
+        key = (p << 35) | ((uint64_t)(uint32_t)(int32_t)chunk << 3) | ((uint64_t)(int32_t)child & 7u);
+    }
+    keys[i] = key;
+}
+
+// info[0] = runs that are real candidates, info[1] = those with count >= 2
+__global__ void count_candidates(const uint64_t *__restrict__ unique_keys, const uint32_t *__restrict__ counts,
+                                 const uint32_t *__restrict__ n_runs, uint32_t *__restrict__ info) {
+    const uint32_t n = *n_runs;
+    uint32_t valid = 0, voted = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if (unique_keys[i] != kNoCandidate) {
+            ++valid;
+            voted += counts[i] >= 2u;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        valid += __shfl_down(valid, off);
+        voted += __shfl_down(voted, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (valid) atomicAdd(&info[0], valid);
+        if (voted) atomicAdd(&info[1], voted);
+    }
+}
+
+__global__ void unpack_nodes(const uint64_t *__restrict__ keys, int32_t n, int32_t *__restrict__ nodes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = keys[i];
+    nodes[2 * i + 0] = (int32_t)((k >> 3) & 0xffffffffu);
+    nodes[2 * i + 1] = (int32_t)(k & 7u);
+}
+
+int select_candidates(const float *track, int64_t n_rows, int32_t max_out, bool need_votes, int32_t *nodes_out,
+                      int32_t *n_out, int32_t *n_candidates, hipStream_t stream) {
+    if (n_out) *n_out = 0;
+    if (n_candidates) *n_candidates = 0;
+    if (!track || n_rows < 0 || max_out < 0 || (max_out > 0 && !nodes_out)) return set_error(MNV_E_INVALID, "invalid tracker arguments");
+    if (n_rows == 0) return MNV_OK;
+    if (n_rows > 0x7fffffff) return set_error(MNV_E_UNSUPPORTED, "more than 2^31 - 1 tracker rows");
+    const size_t n = (size_t)n_rows;
+
+    size_t tmp_sort = 0, tmp_rle = 0, tmp_sort2 = 0;
+    uint64_t *nk = nullptr;
+    uint32_t *nc = nullptr;
+    (void)rocprim::radix_sort_keys(nullptr, tmp_sort, nk, nk, n, 0, kKeyBits, stream);
+    (void)rocprim::run_length_encode(nullptr, tmp_rle, nk, (unsigned int)n, nk, nc, nc, stream);
+    (void)rocprim::radix_sort_pairs_desc(nullptr, tmp_sort2, nc, nc, nk, nk, n, 0, 32, stream);
+    const size_t tmp_bytes = std::max(tmp_sort, std::max(tmp_rle, tmp_sort2));
+
+    Carver c;
+    const size_t o_keys = c.take(n * 8), o_sorted = c.take(n * 8), o_unique = c.take(n * 8), o_counts = c.take(n * 4);
+    const size_t o_counts2 = c.take(n * 4), o_info = c.take(64), o_tmp = c.take(tmp_bytes);
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    uint8_t *ws = nullptr;
+    int rc = ws_reserve(c.off, &ws);
+    if (rc) return rc;
+    uint64_t *keys = reinterpret_cast<uint64_t *>(ws + o_keys), *sorted = reinterpret_cast<uint64_t *>(ws + o_sorted);
+    uint64_t *unique_keys = reinterpret_cast<uint64_t *>(ws + o_unique);
+    uint32_t *counts = reinterpret_cast<uint32_t *>(ws + o_counts), *counts2 = reinterpret_cast<uint32_t *>(ws + o_counts2);
+    uint32_t *info = reinterpret_cast<uint32_t *>(ws + o_info);  // [0] valid, [1] voted, [2] runs
+    void *tmp = ws + o_tmp;
+
+    if ((rc = check_hip(hipMemsetAsync(info, 0, 64, stream), "memset"))) return rc;
+    hipLaunchKernelGGL(pack_tracker_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, track, n_rows, keys);
+    size_t t = tmp_bytes;
+    if ((rc = check_hip(rocprim::radix_sort_keys(tmp, t, keys, sorted, n, 0, kKeyBits, stream), "radix_sort_keys"))) return rc;
+    t = tmp_bytes;
+    if ((rc = check_hip(rocprim::run_length_encode(tmp, t, sorted, (unsigned int)n, unique_keys, counts, info + 2, stream), "run_length_encode")))
+        return rc;
+    hipLaunchKernelGGL(count_candidates, dim3(256), dim3(256), 0, stream, unique_keys, counts, info + 2, info);
+    uint32_t h[3] = {0, 0, 0};
+    if ((rc = check_hip(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, stream), "copy counts"))) return rc;
+    if ((rc = check_hip(hipStreamSynchronize(stream), "select_candidates"))) return rc;
+    const uint32_t n_valid = h[0], n_voted = h[1], n_runs = h[2];
+
+    const uint64_t *ordered = unique_keys;  // ascending (priority, chunk, child); "no candidate" sorts last
+    uint32_t n_sel = n_valid;
+    if (need_votes) {
+        // cuda_renderer.cpp:213-217: rows (-count, priority, chunk, child) with count >= 2, sorted ascending ==
+        // count descending, ties in key order -- a stable descending sort of the already key-ordered runs.
+        // The "no candidate" run would sort first by its count, so it is cut off before the sort.
+        n_sel = n_voted;
+        if (n_voted > 0) {
+            t = tmp_bytes;
+            if ((rc = check_hip(rocprim::radix_sort_pairs_desc(tmp, t, counts, counts2, unique_keys, sorted, (size_t)n_valid, 0, 32, stream),
+                                "radix_sort_pairs_desc")))
+                return rc;
+            ordered = sorted;
+        }
+    }
+    (void)n_runs;
+    const int32_t n_write = (int32_t)std::min<uint32_t>(n_sel, (uint32_t)max_out);
+    if (n_write > 0) hipLaunchKernelGGL(unpack_nodes, dim3((n_write + 255) / 256), dim3(256), 0, stream, ordered, n_write, nodes_out);
+    // the workspace is reused by the next call: finish before the lock is released
+    if ((rc = check_hip(hipStreamSynchronize(stream), "unpack_nodes"))) return rc;
+    if (n_out) *n_out = n_write;
+    if (n_candidates) *n_candidates = (int32_t)n_sel;
+    return MNV_OK;
+}
+
+// ---------------------------------------------------------------- data updates
+
+__device__ inline uint16_t float_to_half_bits(float f) {
+    return __half_as_ushort(__float2half_rn(f));
+}
+
+// cuda_renderer.cpp:262-266: data[capacity*8 + i][c] = mean_j results[i][j][c]
+__global__ void split_mean_kernel(uint16_t *__restrict__ data, int64_t first_row, int64_t n_rows, const float *__restrict__ results,
+                                  int32_t spc, int32_t data_dim, int32_t stride) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * data_dim) return;
+    const int64_t i = idx / data_dim;
+    const int c = (int)(idx - i * data_dim);
+    const float *src = results + i * spc * stride + c;
+    float sum = 0.f;
+    for (int j = 0; j < spc; ++j) sum += src[(int64_t)j * stride];
+    data[(first_row + i) * data_dim + c] = float_to_half_bits(sum / (float)spc);
+}
+
+__global__ void fill_i16_kernel(int16_t *__restrict__ p, int64_t n, int16_t v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// cuda_renderer.cpp:307-332: new average = old average + (sum of new - n_new * old average) / new count
+__global__ void sample_average_kernel(uint16_t *__restrict__ data, const int16_t *__restrict__ sample_counts,
+                                      const int32_t *__restrict__ nodes, int32_t n_items, const float *__restrict__ results,
+                                      int32_t spc, int32_t data_dim, int32_t stride) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)n_items * data_dim) return;
+    const int64_t i = idx / data_dim;
+    const int c = (int)(idx - i * data_dim);
+    const int64_t row = (int64_t)nodes[2 * i] * 8 + nodes[2 * i + 1];
+    const float *src = results + i * spc * stride + c;
+    float sum = 0.f;
+    for (int j = 0; j < spc; ++j) sum += src[(int64_t)j * stride];
+    const float old = half_bits_to_float(data[row * data_dim + c]);
+    // `samples_per_corner * data` is a binary16 tensor in the reference expression (:322-324)
+    const float scaled_old = half_bits_to_float(float_to_half_bits((float)spc * old));
+    const int16_t new_count = (int16_t)(sample_counts[row] + (int16_t)spc);
+    const float update = (sum - scaled_old) / (float)new_count;
+    data[row * data_dim + c] = float_to_half_bits(old + update);
+}
+
+__global__ void bump_counts_kernel(int16_t *__restrict__ sample_counts, const int32_t *__restrict__ nodes, int32_t n_items, int16_t add) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const int64_t row = (int64_t)nodes[2 * i] * 8 + nodes[2 * i + 1];
+    sample_counts[row] = (int16_t)(sample_counts[row] + add);
+}
+
+// ---------------------------------------------------------------- pruning
+
+struct UnvisitedFlag {
+    __device__ int32_t operator()(int32_t v) const { return v == 0 ? 1 : 0; }
+};
+
+__global__ void to_delete_kernel(const int32_t *__restrict__ visited, int32_t n, uint8_t *__restrict__ to_delete) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) to_delete[i] = visited[i] == 0;
+}
+
+// Gather the surviving rows of source chunks [s, e) into scratch (dense, in destination order).
+__global__ void prune_gather_kernel(const uint8_t *__restrict__ src, uint8_t *__restrict__ scratch, const uint8_t *__restrict__ to_delete,
+                                    const int32_t *__restrict__ shifts, int32_t s, int32_t e, int32_t dest_base, int32_t row_words) {
+    // one wavefront-sized group of threads per chunk row; rows are multiples of 4 bytes
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t chunk = s + (int32_t)(gid / row_words);
+    const int32_t w = (int32_t)(gid % row_words);
+    if (chunk >= e || to_delete[chunk]) return;
+    const int32_t dest = chunk - shifts[chunk] - dest_base;
+    reinterpret_cast<uint32_t *>(scratch)[(int64_t)dest * row_words + w] = reinterpret_cast<const uint32_t *>(src)[(int64_t)chunk * row_words + w];
+}
+
+}  // namespace
+
+}  // namespace mnv
+
+using namespace mnv;
+
+extern "C" {
+
+int mnv_select_split_candidates(const float *split_track, int64_t n_rows, int32_t max_out, int32_t *nodes_out,
+                                int32_t *n_out, int32_t *n_candidates, void *hip_stream) {
+    return select_candidates(split_track, n_rows, max_out, true, nodes_out, n_out, n_candidates, (hipStream_t)hip_stream);
+}
+
+int mnv_select_sample_candidates(const float *sample_track, int64_t n_rows, int32_t max_out, int32_t *nodes_out,
+                                 int32_t *n_out, int32_t *n_candidates, void *hip_stream) {
+    return select_candidates(sample_track, n_rows, max_out, false, nodes_out, n_out, n_candidates, (hipStream_t)hip_stream);
+}
+
+int mnv_apply_split_results(uint16_t *data, int16_t *sample_counts, int32_t capacity, int32_t num_parents,
+                            const float *results, int32_t result_stride, int32_t samples_per_corner, int32_t data_dim,
+                            void *hip_stream) {
+    if (!data || !results || capacity < 0 || num_parents < 0 || samples_per_corner < 1 || data_dim < 1 || result_stride < data_dim)
+        return set_error(MNV_E_INVALID, "invalid split-result arguments");
+    if (num_parents == 0) return MNV_OK;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const int64_t rows = (int64_t)num_parents * 8, elems = rows * data_dim;
+    hipLaunchKernelGGL(split_mean_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, stream, data, (int64_t)capacity * 8, rows,
+                       results, samples_per_corner, data_dim, result_stride);
+    if (sample_counts)  // cuda_renderer.cpp:268-269
+        hipLaunchKernelGGL(fill_i16_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, stream, sample_counts + (int64_t)capacity * 8,
+                           rows, (int16_t)samples_per_corner);
+    return check_hip(hipGetLastError(), "apply_split_results");
+}
+
+int mnv_apply_sample_results(uint16_t *data, int16_t *sample_counts, const int32_t *nodes, int32_t num_items,
+                             const float *results, int32_t result_stride, int32_t samples_per_corner, int32_t data_dim,
+                             void *hip_stream) {
+    if (!data || !sample_counts || !nodes || !results || num_items < 0 || samples_per_corner < 1 || data_dim < 1 ||
+        result_stride < data_dim)
+        return set_error(MNV_E_INVALID, "invalid sample-result arguments");
+    if (num_items == 0) return MNV_OK;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const int64_t elems = (int64_t)num_items * data_dim;
+    hipLaunchKernelGGL(sample_average_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, stream, data, sample_counts, nodes,
+                       num_items, results, samples_per_corner, data_dim, result_stride);
+    hipLaunchKernelGGL(bump_counts_kernel, dim3((num_items + 255) / 256), dim3(256), 0, stream, sample_counts, nodes, num_items,
+                       (int16_t)samples_per_corner);
+    return check_hip(hipGetLastError(), "apply_sample_results");
+}
+
+int mnv_prune_tree(const mnv_tree_edit *tree, uint16_t *data, int32_t data_dim, int16_t *sample_counts, int32_t *visited,
+                   int32_t max_capacity, int32_t *new_capacity, int32_t *num_deleted, void *hip_stream) {
+    if (num_deleted) *num_deleted = 0;
+    if (!tree || !tree->child || !tree->parent || !data || !visited || data_dim < 1 || tree->capacity < 1 ||
+        max_capacity < tree->capacity)
+        return set_error(MNV_E_INVALID, "invalid prune arguments");
+    if (tree->N != 2) return set_error(MNV_E_UNSUPPORTED, "only N == 2 trees are supported");
+    if ((data_dim * 8 * 2) % 4) return set_error(MNV_E_UNSUPPORTED, "chunk rows must be multiples of 4 bytes");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const int32_t cap = tree->capacity;
+    if (new_capacity) *new_capacity = cap;
+
+    constexpr int32_t kSegment = 1 << 18;  // chunks gathered per pass (the reference's PRUNE_CHUNK_SIZE role)
+    const size_t data_row = (size_t)data_dim * 8 * 2;
+    size_t tmp_scan = 0;
+    {
+        auto in = rocprim::make_transform_iterator((const int32_t *)nullptr, UnvisitedFlag());
+        (void)rocprim::inclusive_scan(nullptr, tmp_scan, in, (int32_t *)nullptr, (size_t)cap, rocprim::plus<int32_t>(), stream);
+    }
+    Carver c;
+    const size_t o_del = c.take((size_t)cap), o_shift = c.take((size_t)cap * 4), o_tmp = c.take(tmp_scan);
+    const size_t o_scratch = c.take((size_t)kSegment * data_row);
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    uint8_t *ws = nullptr;
+    int rc = ws_reserve(c.off, &ws);
+    if (rc) return rc;
+    uint8_t *to_delete = ws + o_del;
+    int32_t *shifts = reinterpret_cast<int32_t *>(ws + o_shift);
+    uint8_t *scratch = ws + o_scratch;
+
+    // to_delete = visited[:capacity] == 0; index_shifts = cumsum(to_delete)   (cuda_renderer.cpp:337,348)
+    hipLaunchKernelGGL(to_delete_kernel, dim3((cap + 255) / 256), dim3(256), 0, stream, visited, cap, to_delete);
+    {
+        auto in = rocprim::make_transform_iterator((const int32_t *)visited, UnvisitedFlag());
+        size_t t = tmp_scan;
+        if ((rc = check_hip(rocprim::inclusive_scan(ws + o_tmp, t, in, shifts, (size_t)cap, rocprim::plus<int32_t>(), stream), "inclusive_scan")))
+            return rc;
+    }
+    int32_t n_del = 0, root_visited = 0;
+    if ((rc = check_hip(hipMemcpyAsync(&n_del, shifts + (cap - 1), 4, hipMemcpyDeviceToHost, stream), "copy"))) return rc;
+    if ((rc = check_hip(hipMemcpyAsync(&root_visited, visited, 4, hipMemcpyDeviceToHost, stream), "copy"))) return rc;
+    if ((rc = check_hip(hipStreamSynchronize(stream), "prune scan"))) return rc;
+    auto clear_marks = [&]() {  // cuda_renderer.cpp:343,378: everything but the root's mark
+        return max_capacity > 1 ? check_hip(hipMemsetAsync(visited + 1, 0, (size_t)(max_capacity - 1) * 4, stream), "clear visit marks") : MNV_OK;
+    };
+    if (n_del == 0) return clear_marks();  // "Nothing can be pruned"
+    if (!root_visited)
+        return set_error(MNV_E_INVALID, "the root chunk is not marked visited: render a track_visit frame before pruning");
+
+    // argmin of a non-decreasing cumsum is its first element: the reference's first_shift_index is 0
+    // (cuda_renderer.cpp:350), which is also what the fix-up needs -- unshifted chunks can point at shifted ones
+    if ((rc = mnv_adjust_parents_and_children(tree, 0, to_delete, shifts, hip_stream))) return rc;
+
+    struct Array {
+        uint8_t *base;
+        size_t row;
+    } arrays[4] = {{reinterpret_cast<uint8_t *>(data), data_row},
+                   {reinterpret_cast<uint8_t *>(tree->child), 32},
+                   {reinterpret_cast<uint8_t *>(tree->parent), 4},
+                   {reinterpret_cast<uint8_t *>(sample_counts), 16}};
+    // dest_base of a segment = index of its first source chunk minus the deletions before it; the host needs the
+    // shift at every segment start
+    const int32_t n_seg = (cap + kSegment - 1) / kSegment;
+    std::vector<int32_t> seg_shift((size_t)n_seg + 1, 0);
+    for (int32_t k = 1; k < n_seg; ++k)
+        if ((rc = check_hip(hipMemcpyAsync(&seg_shift[k], shifts + ((int64_t)k * kSegment - 1), 4, hipMemcpyDeviceToHost, stream), "copy"))) return rc;
+    if ((rc = check_hip(hipStreamSynchronize(stream), "prune segments"))) return rc;
+    seg_shift[n_seg] = n_del;
+    for (int a = 0; a < 4; ++a) {
+        if (!arrays[a].base) continue;  // sample_counts is optional (the reference leaves it uncompacted)
+        const int32_t row_words = (int32_t)(arrays[a].row / 4);
+        for (int32_t k = 0; k < n_seg; ++k) {
+            const int32_t s = k * kSegment, e = std::min(cap, s + kSegment);
+            const int32_t survivors = (e - s) - (seg_shift[k + 1] - seg_shift[k]);
+            if (survivors == 0 || seg_shift[k + 1] == 0) continue;  // nothing to move / nothing deleted up to here
+            const int32_t dest_base = s - seg_shift[k];
+            const int64_t threads = (int64_t)(e - s) * row_words;
+            hipLaunchKernelGGL(prune_gather_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, arrays[a].base, scratch,
+                               to_delete, shifts, s, e, dest_base, row_words);
+            if ((rc = check_hip(hipMemcpyAsync(arrays[a].base + (size_t)dest_base * arrays[a].row, scratch, (size_t)survivors * arrays[a].row,
+                                               hipMemcpyDeviceToDevice, stream),
+                                "prune copy")))
+                return rc;
+        }
+    }
+    if ((rc = clear_marks())) return rc;
+    // the workspace is reused by the next call
+    if ((rc = check_hip(hipStreamSynchronize(stream), "prune_tree"))) return rc;
+    if (new_capacity) *new_capacity = cap - n_del;
+    if (num_deleted) *num_deleted = n_del;
+    return MNV_OK;
+}
+
+}  // extern "C"

@@ -853,8 +853,11 @@ int orc_generate_samples(const int32_t *parent, const float offset[3], const flo
 
 int orc_adjust_parents_and_children(int32_t *child, int32_t *parent, int32_t capacity, int32_t first_shift_index,
                                     const uint8_t *to_delete, const int32_t *index_shifts) {
-    if (!child || !parent || !to_delete || !index_shifts || first_shift_index < 1) return -1;
+    if (!child || !parent || !to_delete || !index_shifts || first_shift_index < 0) return -1;
     for (int32_t chunk = first_shift_index; chunk < capacity; ++chunk) { /* renderer_kernel.cu:63-86 */
+        /* chunk 0 (the root, parent word 0 in svox files): the reference thread adds shift[0] - shift[0] = 0 to
+         * child[0][0] -- no effect, so it is skipped (cuda_renderer.cpp:350 does call with first_shift_index 0) */
+        if (chunk == 0) continue;
         const int32_t pc = parent[chunk] / 8, pj = parent[chunk] % 8;
         if (to_delete[chunk]) {
             child[(int64_t)pc * 8 + pj] = 0;

@@ -89,3 +89,153 @@ def test_adjust_parents_and_children(mnv, orc, torch_gpu):
     tgt = (np.arange(len(c2))[:, None] + c2)[c2 != 0]
     src = np.argwhere(c2 != 0)
     assert np.array_equal(p2[tgt], src[:, 0] * 8 + src[:, 1])
+
+
+# ------------------------------------------------------------------ tracker-consuming host logic (csrc/mnv_refine.hip)
+import os  # noqa: E402
+
+import refine_oracle as ro  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+_SEL = np.load(os.path.join(GOLD, "refine_selection.npz"))
+_SEL_NAMES = sorted({k.split("/")[0] for k in _SEL.files})
+
+
+@pytest.mark.parametrize("name", _SEL_NAMES)
+def test_selection_matches_torch_goldens(mnv, torch_gpu, name):
+    """expand_voxels' vote / get_more_samples' selection (cuda_renderer.cpp:205-227,281-296) against the vectors
+    produced by the reference's libtorch expressions."""
+    torch = torch_gpu
+    track, k = _SEL[f"{name}/track"], int(_SEL[f"{name}/k"])
+    d_track = torch.from_numpy(track).cuda()
+    nodes = torch.full((k, 2), -9, dtype=torch.int32, device="cuda")
+    n_out, n_cand = mnv.select_split_candidates(d_track, k, nodes)
+    want = _SEL[f"{name}/split_nodes"]
+    assert n_cand == int(_SEL[f"{name}/split_n"]) and n_out == want.shape[0]
+    assert np.array_equal(nodes.cpu().numpy()[:n_out], want) and np.all(nodes.cpu().numpy()[n_out:] == -9)
+    nodes.fill_(-9)
+    n_out, n_cand = mnv.select_sample_candidates(d_track, k, nodes)
+    want = _SEL[f"{name}/sample_nodes"]
+    assert n_cand == int(_SEL[f"{name}/sample_n"]) and n_out == want.shape[0]
+    assert np.array_equal(nodes.cpu().numpy()[:n_out], want)
+
+
+def test_selection_full_frame_against_oracle(mnv, torch_gpu):
+    """A 1920x1080 tracker (2,073,600 rows) with heavy repetition, against the numpy restatement."""
+    torch = torch_gpu
+    rng = np.random.default_rng(11)
+    n = 1920 * 1080
+    chunk = (rng.zipf(1.3, n) % 1_400_000).astype(np.int64)
+    track = np.stack([(1 + chunk % 10).astype(np.float32), chunk.astype(np.float32), (chunk * 5 % 8).astype(np.float32)], 1)
+    track[rng.random(n) < 0.6] = (11.0, -1.0, -1.0)
+    k = 100_000
+    d_track = torch.from_numpy(track).cuda()
+    nodes = torch.empty((k, 2), dtype=torch.int32, device="cuda")
+    n_out, n_cand = mnv.select_split_candidates(d_track, k, nodes)
+    want, want_n = ro.select_split_candidates(track, k)
+    assert (n_out, n_cand) == (want.shape[0], want_n) and np.array_equal(nodes.cpu().numpy()[:n_out], want)
+    n_out, n_cand = mnv.select_sample_candidates(d_track, k, nodes)
+    want, want_n = ro.select_sample_candidates(track, k)
+    assert (n_out, n_cand) == (want.shape[0], want_n) and np.array_equal(nodes.cpu().numpy()[:n_out], want)
+    # max_out == 0 only counts
+    assert mnv.select_split_candidates(d_track, 0, None) == (0, ro.select_split_candidates(track, 0)[1])
+
+
+def test_apply_split_and_sample_results(mnv, torch_gpu):
+    torch = torch_gpu
+    z = np.load(os.path.join(GOLD, "refine_split_mean.npz"))
+    results = z["results"]
+    n_children, spc, dd = results.shape[0], 8, 28
+    cap = 5
+    rng = np.random.default_rng(3)
+    data = (rng.standard_normal((cap + n_children // 8 + 2, 8, dd))).astype(np.float16)
+    counts = rng.integers(0, 30, (data.shape[0], 8)).astype(np.int16)
+    d_data, d_counts, d_res = torch.from_numpy(data.copy()).cuda(), torch.from_numpy(counts.copy()).cuda(), torch.from_numpy(results).cuda()
+    mnv.apply_split_results(d_data, d_counts, cap, n_children // 8, d_res, spc, dd)
+    torch.cuda.synchronize()
+    ro.apply_split_results(data, counts, cap, results, spc)
+    got = d_data.cpu().numpy()
+    assert np.array_equal(got.view(np.uint16), data.view(np.uint16)) and np.array_equal(d_counts.cpu().numpy(), counts)
+    # torch.mean(out=half) golden: within one binary16 step (reduction order unspecified there)
+    g = got.reshape(-1, dd)[cap * 8: cap * 8 + n_children].view(np.uint16).astype(np.int32)
+    w = z["rows"].astype(np.int32)
+    mono = lambda u: np.where(u & 0x8000, -(u & 0x7fff), u)  # noqa: E731
+    assert np.abs(mono(g) - mono(w)).max() <= 1
+
+    # running average of existing voxels (cuda_renderer.cpp:307-332)
+    nodes = np.stack([rng.permutation(data.shape[0])[:40], rng.integers(0, 8, 40)], 1).astype(np.int32)
+    res2 = (rng.standard_normal((40, spc, dd + 1)) * 2).astype(np.float32)
+    d_nodes, d_res2 = torch.from_numpy(nodes).cuda(), torch.from_numpy(res2).cuda()
+    mnv.apply_sample_results(d_data, d_counts, d_nodes, d_res2, spc, dd)
+    torch.cuda.synchronize()
+    ro.apply_sample_results(data, counts, nodes, res2, spc)
+    assert np.array_equal(d_data.cpu().numpy().view(np.uint16), data.view(np.uint16)) and np.array_equal(d_counts.cpu().numpy(), counts)
+
+
+def test_prune_matches_torch_goldens(mnv, torch_gpu):
+    torch = torch_gpu
+    z = np.load(os.path.join(GOLD, "refine_prune.npz"))
+    cap, max_cap = int(z["capacity"]), z["visited"].shape[0]
+    pad = lambda a: np.concatenate([a, np.zeros((max_cap - cap,) + a.shape[1:], a.dtype)])  # noqa: E731
+    d = {k: torch.from_numpy(pad(z[k]) if k != "visited" else z[k].copy()).cuda() for k in ("data", "child", "parent", "visited")}
+    d["data"] = d["data"].view(torch.int16)
+    edit = mnv.tree_edit(d["child"], d["parent"], [0.5] * 3, [0.5] * 3, cap)
+    new_cap, n_del = mnv.prune_tree(edit, d["data"], z["data"].shape[2], None, d["visited"], max_cap)
+    assert new_cap == int(z["new_capacity"]) and n_del == cap - new_cap
+    assert np.array_equal(d["data"].cpu().numpy()[:new_cap].view(np.uint16), z["out_data"])
+    assert np.array_equal(d["child"].cpu().numpy()[:new_cap], z["out_child"])
+    assert np.array_equal(d["parent"].cpu().numpy()[:new_cap], z["out_parent"])
+    v = d["visited"].cpu().numpy()
+    assert v[0] == 1 and not v[1:].any()
+    # nothing to prune: marks are cleared, arrays untouched
+    d["visited"][:new_cap] = 1
+    before = d["child"].clone()
+    edit = mnv.tree_edit(d["child"], d["parent"], [0.5] * 3, [0.5] * 3, new_cap)
+    assert mnv.prune_tree(edit, d["data"], z["data"].shape[2], None, d["visited"], max_cap) == (new_cap, 0)
+    assert torch.equal(before, d["child"]) and not d["visited"].cpu().numpy()[1:].any()
+    # unmarked root is refused
+    with pytest.raises(mnv.MnvError):
+        mnv.prune_tree(edit, d["data"], z["data"].shape[2], None, d["visited"] * 0, max_cap)
+
+
+def test_prune_large_tree_keeps_the_image(mnv, orc, torch_gpu):
+    """Visit marks from a real track_visit frame on a 300k-chunk tree (several compaction segments): the HIP
+    prune equals the oracle's, and the pruned tree renders the same frame bit for bit from that camera."""
+    torch = torch_gpu
+    tree = cases.make_tree(mnv, dict(kind="shell", depth=9, basis_dim=4, radius=0.35, half_thickness=1.5 / 512, seed=3))
+    cam = mnv.orbit_camera(640, 360, 520.0, 2.6, 30.0, 20.0)
+    opt = mnv.RenderOptions.cli_defaults()
+    v = tree.host_view()
+    cap, dd = v.capacity, v.data_dim
+    assert cap > (1 << 18)
+    data, child, parent = (a.copy() for a in tree.host_arrays())
+    max_cap = cap + 100
+    tree.move_to_device(max_capacity=max_cap, need_parent=True, need_sample_counts=True)
+    dv = tree.device_view()
+    h, w = cam.height, cam.width
+    rgba = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    visited = torch.zeros(max_cap, dtype=torch.int32, device="cuda")
+    mnv.render_voxels(dv, cam, opt, rgba=rgba, visited=visited, track_visit=True)
+    torch.cuda.synchronize()
+    visited_h = visited.cpu().numpy()
+    counts = (np.arange(cap * 8) % 251).astype(np.int16).reshape(cap, 8)
+    d_counts = torch.from_numpy(np.concatenate([counts, np.zeros((100, 8), np.int16)])).cuda()
+    d_child = torch.from_numpy(np.concatenate([child, np.zeros((100, 8), np.int32)])).cuda()
+    d_parent = torch.from_numpy(np.concatenate([parent, np.zeros(100, np.int32)])).cuda()
+    d_data = torch.from_numpy(np.concatenate([data, np.zeros((100, 8, dd), np.uint16)]).view(np.int16)).cuda()
+    edit = mnv.tree_edit(d_child, d_parent, list(v.offset), list(v.scale), cap)
+    new_cap, n_del = mnv.prune_tree(edit, d_data, dd, d_counts, visited, max_cap)
+    want_cap, want_del = ro.prune_tree(orc, child, parent, data, counts, visited_h, cap, max_cap)
+    assert (new_cap, n_del) == (want_cap, want_del) and 0 < new_cap < cap
+    assert np.array_equal(d_child.cpu().numpy()[:new_cap], child[:new_cap]) and np.array_equal(d_parent.cpu().numpy()[:new_cap], parent[:new_cap])
+    assert np.array_equal(d_data.cpu().numpy()[:new_cap].view(np.uint16), data[:new_cap])
+    assert np.array_equal(d_counts.cpu().numpy()[:new_cap], counts[:new_cap])
+    # render the compacted arrays
+    pv = mnv.TreeView()
+    for f in ("offset", "scale", "N", "data_dim", "format", "basis_dim"):
+        setattr(pv, f, getattr(dv, f))
+    pv.data, pv.child, pv.parent, pv.capacity = d_data.data_ptr(), d_child.data_ptr(), d_parent.data_ptr(), new_cap
+    rgba2 = torch.empty_like(rgba)
+    mnv.render_voxels(pv, cam, opt, rgba=rgba2)
+    torch.cuda.synchronize()
+    assert torch.equal(rgba.view(torch.int32), rgba2.view(torch.int32))
