@@ -323,6 +323,46 @@ int mnv_apply_sample_results(uint16_t *data, int16_t *sample_counts, const int32
 int mnv_prune_tree(const mnv_tree_edit *tree, uint16_t *data, int32_t data_dim, int16_t *sample_counts, int32_t *visited,
                    int32_t max_capacity, int32_t *new_capacity, int32_t *num_deleted, void *hip_stream);
 
+/* ------------------------------------------------ per-sample sub-module network
+ *
+ * Stands in for VolumeRenderer::Impl::query_submodules (src/renderer/cuda_renderer.cpp:165-203): every sample
+ * row is routed to the network of its cluster and the outputs are scattered back in input order.  The
+ * reference loads its networks as TorchScript files that are not part of its repository (model_path,
+ * cuda_renderer.cpp:518-539), so PARITY IS UNPINNED for the arithmetic: this is the build's own small MLP
+ * (triangle-wave position encoding, `hidden_layers` x `hidden_width` ReLU layers with binary16 activations
+ * and fp32 accumulation on the matrix cores, linear fp32 output), checked against its own CPU restatement.
+ */
+typedef struct mnv_mlp_desc {
+    int32_t n_clusters;     /* sub-modules; cluster ids 0 .. n_clusters-1 (cuda_renderer.cpp:529-533) */
+    int32_t pos_octaves;    /* encoded position: 3 + 6 * pos_octaves features */
+    int32_t dir_octaves;    /* encoded direction: 3 + 6 * dir_octaves features when need_viewdir */
+    int32_t need_viewdir;   /* sample rows are xyz, dir[3] (opt.need_viewdir) */
+    int32_t n_embeddings;   /* > 0: rows end with an appearance-embedding index (opt.appearance_embedding != -1) */
+    int32_t embedding_dim;  /* features per embedding (1 .. 64) */
+    int32_t hidden_width;   /* 64 or 128 */
+    int32_t hidden_layers;  /* >= 1 */
+    int32_t out_dim;        /* tree data_dim + 1 (cuda_renderer.cpp:255-257), <= hidden_width */
+    float center[3];        /* position normalisation p = (xyz - center) * inv_extent */
+    float inv_extent[3];
+} mnv_mlp_desc;
+typedef struct mnv_mlp mnv_mlp;
+/* binary16 parameters per cluster, in this order, all row-major: W0[hidden][in], b0[hidden], then
+ * (hidden_layers - 1) x { W[hidden][hidden], b[hidden] }, Wout[out][hidden], bout[out],
+ * embedding[n_embeddings][embedding_dim]; in = 3 + 6 pos_octaves (+ 3 + 6 dir_octaves) (+ embedding_dim). */
+size_t mnv_mlp_param_count(const mnv_mlp_desc *desc);
+/* params: host, n_clusters * mnv_mlp_param_count() binary16 values, cluster-major. */
+int mnv_mlp_create(const mnv_mlp_desc *desc, const uint16_t *params, size_t n_halfs, void *hip_stream, mnv_mlp **out);
+void mnv_mlp_destroy(mnv_mlp *mlp);
+/*
+ * samples: device float [n][samples_stride], columns xyz[, dir][, embedding index] first (the layout
+ * mnv_get_samples_from_voxels writes after its z column and the refinement kernels write from column 0);
+ * cluster_indices: device int16 [n]; results: device float [n][result_stride], columns [0, out_dim) written.
+ * Rows whose cluster id is outside [0, n_clusters) get zeros.  Asynchronous on hip_stream; the handle holds the
+ * launch scratch, so one handle serves one stream at a time.
+ */
+int mnv_query_submodules(mnv_mlp *mlp, const int16_t *cluster_indices, const float *samples, int32_t samples_stride,
+                         int64_t n, float *results, int32_t result_stride, void *hip_stream);
+
 /* Average device time (ms) of the last `mnv_render_*` launches since the
  * previous call, measured with HIP events on the launch stream when
  * mnv_set_timing(1) is active; used by bench.py for roofline.achieved. */

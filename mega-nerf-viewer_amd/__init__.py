@@ -124,6 +124,12 @@ class TreeEdit(C.Structure):
                 ("N", C.c_int32), ("capacity", C.c_int32)]
 
 
+class MlpDesc(C.Structure):
+    _fields_ = [("n_clusters", C.c_int32), ("pos_octaves", C.c_int32), ("dir_octaves", C.c_int32), ("need_viewdir", C.c_int32),
+                ("n_embeddings", C.c_int32), ("embedding_dim", C.c_int32), ("hidden_width", C.c_int32), ("hidden_layers", C.c_int32),
+                ("out_dim", C.c_int32), ("center", C.c_float * 3), ("inv_extent", C.c_float * 3)]
+
+
 class SynthRandomParams(C.Structure):
     _fields_ = [
         ("depth", C.c_int32),
@@ -199,6 +205,10 @@ _SIGNATURES = {
     "mnv_apply_sample_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "mnv_prune_tree": (C.c_int, [C.POINTER(TreeEdit), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int32), C.c_void_p]),
+    "mnv_mlp_param_count": (C.c_size_t, [C.POINTER(MlpDesc)]),
+    "mnv_mlp_create": (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mnv_mlp_destroy": (None, [C.c_void_p]),
+    "mnv_query_submodules": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
     "mnv_set_timing": (None, [C.c_int]),
     "mnv_take_timing": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "mnv_n3tree_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -540,6 +550,40 @@ def prune_tree(edit: TreeEdit, data, data_dim: int, sample_counts, visited, max_
     _check(lib().mnv_prune_tree(C.byref(edit), _ptr(data), data_dim, _ptr(sample_counts), _ptr(visited), max_capacity, C.byref(new_cap),
                                 C.byref(n_del), C.c_void_p(stream)))
     return new_cap.value, n_del.value
+
+
+def mlp_desc(n_clusters=1, pos_octaves=4, dir_octaves=2, need_viewdir=False, n_embeddings=0, embedding_dim=0, hidden_width=64,
+             hidden_layers=2, out_dim=5, center=(0.0, 0.0, 0.0), inv_extent=(1.0, 1.0, 1.0)) -> MlpDesc:
+    d = MlpDesc(n_clusters, pos_octaves, dir_octaves, int(need_viewdir), n_embeddings, embedding_dim, hidden_width, hidden_layers, out_dim)
+    d.center, d.inv_extent = _f3(center), _f3(inv_extent)
+    return d
+
+
+class Mlp:
+    """Per-sample sub-module network (include/mnv.h: mnv_mlp_*).  `params`: numpy float16/uint16
+    [n_clusters * param_count], cluster-major, in the order documented in the header."""
+
+    def __init__(self, desc: MlpDesc, params, stream: int = 0):
+        self.desc = desc
+        p = np.ascontiguousarray(params).view(np.uint16).reshape(-1)
+        h = C.c_void_p()
+        _check(lib().mnv_mlp_create(C.byref(desc), p.ctypes.data, p.size, C.c_void_p(stream), C.byref(h)))
+        self._h = h
+
+    @staticmethod
+    def param_count(desc: MlpDesc) -> int:
+        return int(lib().mnv_mlp_param_count(C.byref(desc)))
+
+    def query(self, cluster_indices, samples, results, n=None, stream: int = 0) -> None:
+        """cluster_indices int16 [n], samples float32 [n][cols], results float32 [n][>= out_dim] (device tensors)."""
+        n = int(samples.shape[0]) if n is None else n
+        _check(lib().mnv_query_submodules(self._h, _ptr(cluster_indices), _ptr(samples), samples.stride(0), n, _ptr(results),
+                                          results.stride(0), C.c_void_p(stream)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().mnv_mlp_destroy(self._h)
+            self._h = None
 
 
 MAX_BATCH = 64

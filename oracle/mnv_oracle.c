@@ -869,3 +869,72 @@ int orc_adjust_parents_and_children(int32_t *child, int32_t *parent, int32_t cap
     }
     return 0;
 }
+
+/* ------------------------------------------------------------------ the build's own sub-module MLP (unpinned) */
+
+static float mlp_tri(float t) {
+    const float r = t - floorf(t + 0.5f);
+    return 4.f * fabsf(r) - 1.f;
+}
+
+static void mlp_encode_block(const float v[3], int octaves, float *out) {
+    for (int i = 0; i < 3; ++i) out[i] = v[i];
+    for (int k = 0; k < octaves; ++k) {
+        const float scale = (float)(1u << k);
+        for (int i = 0; i < 3; ++i) {
+            out[3 + 6 * k + i] = mlp_tri(v[i] * scale);
+            out[3 + 6 * k + 3 + i] = mlp_tri(v[i] * scale + 0.25f);
+        }
+    }
+}
+
+int orc_mlp_forward(const orc_mlp_desc *D, const uint16_t *params, const int16_t *cluster_indices, const float *samples,
+                    int32_t samples_stride, int64_t n, float *results, int32_t result_stride) {
+    if (!D || !params || !cluster_indices || !samples || !results || D->hidden_width > 256 || D->hidden_layers < 1) return -1;
+    const int n_pos = 3 + 6 * D->pos_octaves, n_dir = D->need_viewdir ? 3 + 6 * D->dir_octaves : 0;
+    const int emb_dim = D->n_embeddings > 0 ? D->embedding_dim : 0;
+    const int in_dim = n_pos + n_dir + emb_dim, W = D->hidden_width;
+    const size_t per_cluster = (size_t)W * in_dim + W + (size_t)(D->hidden_layers - 1) * ((size_t)W * W + W) + (size_t)D->out_dim * W +
+                               D->out_dim + (size_t)D->n_embeddings * emb_dim;
+    if (in_dim > 512) return -1;
+#pragma omp parallel for schedule(static)
+    for (int64_t row = 0; row < n; ++row) {
+        float *out = results + row * result_stride;
+        const int c = cluster_indices[row];
+        if (c < 0 || c >= D->n_clusters) {
+            for (int k = 0; k < D->out_dim; ++k) out[k] = 0.f;
+            continue;
+        }
+        const float *x = samples + row * samples_stride;
+        const uint16_t *P = params + (size_t)c * per_cluster;
+        float enc[512], h[256], h2[256];
+        float p[3];
+        for (int i = 0; i < 3; ++i) p[i] = (x[i] - D->center[i]) * D->inv_extent[i];
+        mlp_encode_block(p, D->pos_octaves, enc);
+        if (D->need_viewdir) mlp_encode_block(x + 3, D->dir_octaves, enc + n_pos);
+        if (emb_dim > 0) {
+            int idx = (int)x[D->need_viewdir ? 6 : 3];
+            idx = idx < 0 ? 0 : (idx >= D->n_embeddings ? D->n_embeddings - 1 : idx);
+            const uint16_t *table = P + per_cluster - (size_t)D->n_embeddings * emb_dim;
+            for (int k = 0; k < emb_dim; ++k) enc[n_pos + n_dir + k] = orc_half_to_float(table[(size_t)idx * emb_dim + k]);
+        }
+        for (int k = 0; k < in_dim; ++k) enc[k] = orc_half_to_float(orc_float_to_half(enc[k])); /* activations are binary16 */
+        const float *cur = enc;
+        int cur_dim = in_dim;
+        const uint16_t *w = P;
+        for (int layer = 0; layer <= D->hidden_layers; ++layer) {
+            const int od = layer == D->hidden_layers ? D->out_dim : W;
+            float *dst = layer == D->hidden_layers ? out : (cur == h ? h2 : h);
+            const uint16_t *bias = w + (size_t)od * cur_dim;
+            for (int o = 0; o < od; ++o) {
+                float acc = orc_half_to_float(bias[o]);
+                for (int k = 0; k < cur_dim; ++k) acc += orc_half_to_float(w[(size_t)o * cur_dim + k]) * cur[k];
+                dst[o] = layer == D->hidden_layers ? acc : orc_half_to_float(orc_float_to_half(acc > 0.f ? acc : 0.f));
+            }
+            w = bias + od;
+            cur = dst;
+            cur_dim = od;
+        }
+    }
+    return 0;
+}

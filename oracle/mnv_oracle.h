@@ -177,6 +177,21 @@ int orc_generate_samples(const int32_t *parent, const float offset[3], const flo
 int orc_adjust_parents_and_children(int32_t *child, int32_t *parent, int32_t capacity, int32_t first_shift_index,
                                     const uint8_t *to_delete, const int32_t *index_shifts);
 
+/*
+ * The build's own per-sample MLP (mega-nerf-viewer_amd/csrc/mnv_mlp.hip; stands in for query_submodules,
+ * cuda_renderer.cpp:165-203).  PARITY UNPINNED: the reference's networks are TorchScript artefacts outside its
+ * repository, so this restates the build's definition, not the reference: triangle-wave encoding (exact IEEE
+ * arithmetic), binary16 weights and activations, fp32 accumulation in ascending input order, ReLU hidden layers,
+ * linear fp32 output.  Same descriptor and parameter order as mnv_mlp_desc / mnv_mlp_create (include/mnv.h).
+ */
+typedef struct {
+    int32_t n_clusters, pos_octaves, dir_octaves, need_viewdir, n_embeddings, embedding_dim;
+    int32_t hidden_width, hidden_layers, out_dim;
+    float center[3], inv_extent[3];
+} orc_mlp_desc;
+int orc_mlp_forward(const orc_mlp_desc *desc, const uint16_t *params, const int16_t *cluster_indices, const float *samples,
+                    int32_t samples_stride, int64_t n, float *results, int32_t result_stride);
+
 int orc_num_threads(void);
 
 #ifdef __cplusplus

@@ -194,3 +194,25 @@ def adjust_parents_and_children(child, parent, capacity, first_shift_index, to_d
     rc = lib().orc_adjust_parents_and_children(C.c_void_p(child.ctypes.data), C.c_void_p(parent.ctypes.data), C.c_int32(capacity),
                                                C.c_int32(first_shift_index), C.c_void_p(to_delete.ctypes.data), C.c_void_p(index_shifts.ctypes.data))
     assert rc == 0
+
+
+class OrcMlpDesc(C.Structure):
+    _fields_ = [("n_clusters", C.c_int32), ("pos_octaves", C.c_int32), ("dir_octaves", C.c_int32), ("need_viewdir", C.c_int32),
+                ("n_embeddings", C.c_int32), ("embedding_dim", C.c_int32), ("hidden_width", C.c_int32), ("hidden_layers", C.c_int32),
+                ("out_dim", C.c_int32), ("center", C.c_float * 3), ("inv_extent", C.c_float * 3)]
+
+
+def mlp_forward(desc_struct, params, cluster_indices, samples, out_cols=None):
+    """The build's own MLP on the CPU (parity unpinned, see mnv_oracle.h).  Returns float32 [n][out_cols]."""
+    d = _copy_struct(OrcMlpDesc(), desc_struct)
+    params = np.ascontiguousarray(params).view(np.uint16).reshape(-1)
+    samples = np.ascontiguousarray(samples, np.float32)
+    cluster_indices = np.ascontiguousarray(cluster_indices, np.int16)
+    n = samples.shape[0]
+    out_cols = d.out_dim if out_cols is None else out_cols
+    out = np.zeros((n, out_cols), np.float32)
+    rc = lib().orc_mlp_forward(C.byref(d), C.c_void_p(params.ctypes.data), C.c_void_p(cluster_indices.ctypes.data),
+                               C.c_void_p(samples.ctypes.data), C.c_int32(samples.shape[1]), C.c_int64(n),
+                               C.c_void_p(out.ctypes.data), C.c_int32(out_cols))
+    assert rc == 0
+    return out

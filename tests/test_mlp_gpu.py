@@ -1,0 +1,64 @@
+"""The build's own per-sample sub-module MLP (stands in for query_submodules,
+cuda_renderer.cpp:165-203) on the matrix cores against its CPU restatement.  Parity with the reference is
+unpinned by construction (its networks are TorchScript files outside the repository); what is checked here is
+the HIP kernel against the build's own definition.  Tolerance: the encoded inputs, weights and activations are
+bit-identical binary16 values on both sides; the only difference is the order of the fp32 accumulation inside
+v_mfma_f32_16x16x32_f16 versus the sequential CPU sum, which can flip a binary16 rounding of a hidden
+activation (relative 2^-11) -- bounded below by 4e-3 * (1 + |value|) on O(1) outputs."""
+import numpy as np
+import pytest
+
+import mlp_cases
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "w64_l2_rgba": dict(n_clusters=3, pos_octaves=4, hidden_width=64, hidden_layers=2, out_dim=5, center=(0.1, -0.2, 0.3), inv_extent=(0.5, 0.6, 0.7)),
+    "w64_l1_min": dict(n_clusters=1, pos_octaves=0, hidden_width=64, hidden_layers=1, out_dim=1),
+    "w64_l3_dir_emb_sh9": dict(n_clusters=8, pos_octaves=10, dir_octaves=4, need_viewdir=True, n_embeddings=12, embedding_dim=16,
+                               hidden_width=64, hidden_layers=3, out_dim=29, inv_extent=(0.25, 0.25, 0.25)),
+    "w128_l4_dir_sh16": dict(n_clusters=5, pos_octaves=12, dir_octaves=4, need_viewdir=True, hidden_width=128, hidden_layers=4, out_dim=50),
+    "w128_l2_out128": dict(n_clusters=2, pos_octaves=2, hidden_width=128, hidden_layers=2, out_dim=128),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_mlp_matches_cpu_restatement(mnv, orc, torch_gpu, name):
+    torch = torch_gpu
+    desc = mnv.mlp_desc(**CONFIGS[name])
+    params = mlp_cases.make_params(mnv, desc, seed=3)
+    n = 5000 if desc.hidden_width == 64 else 3000
+    x, cluster = mlp_cases.make_samples(desc, n, seed=4)
+    mlp = mnv.Mlp(desc, params)
+    pad = 2  # extra leading / trailing columns: strides larger than the widths
+    d_x = torch.zeros((n, x.shape[1] + pad), dtype=torch.float32, device="cuda")
+    d_x[:, :x.shape[1]] = torch.from_numpy(x).cuda()
+    d_out = torch.full((n, desc.out_dim + pad), 7.0, dtype=torch.float32, device="cuda")
+    mlp.query(torch.from_numpy(cluster).cuda(), d_x, d_out)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    want = orc.mlp_forward(desc, params, cluster, x)
+    assert np.all(got[:, desc.out_dim:] == 7.0)  # columns beyond out_dim untouched
+    got = got[:, :desc.out_dim]
+    valid = (cluster >= 0) & (cluster < desc.n_clusters)
+    assert np.all(got[~valid] == 0.0) and np.all(want[~valid] == 0.0)
+    err = np.abs(got - want) / (1.0 + np.abs(want))
+    assert np.isfinite(got).all() and err.max() < 4e-3, f"{name}: max rel err {err.max():.3e}"
+    assert np.abs(want[valid]).mean() > 0.05  # the comparison is not vacuous
+    # a second call on the same handle (scratch reuse) with a different n gives the same rows
+    m = n // 3
+    d_out2 = torch.zeros((m, desc.out_dim), dtype=torch.float32, device="cuda")
+    mlp.query(torch.from_numpy(cluster[:m]).cuda(), d_x[:m], d_out2)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_out2.cpu().numpy(), got[:m])
+
+
+def test_mlp_rejects_bad_descriptions(mnv, torch_gpu):
+    for bad in (dict(hidden_width=96), dict(out_dim=65), dict(n_clusters=0), dict(hidden_layers=0), dict(n_embeddings=4, embedding_dim=0)):
+        desc = mnv.mlp_desc(**bad)
+        assert mnv.Mlp.param_count(desc) == 0
+        with pytest.raises(mnv.MnvError):
+            mnv.Mlp(desc, np.zeros(16, np.float16))
+    desc = mnv.mlp_desc()
+    with pytest.raises(mnv.MnvError):
+        mnv.Mlp(desc, np.zeros(mnv.Mlp.param_count(desc) + 1, np.float16))  # wrong blob size

@@ -163,3 +163,43 @@ def test_oracle_ray_miss_and_depth_mode(mnv, orc):
     opt.render_depth = True  # a miss in depth mode sets alpha = 1 (rt_core.cuh:196)
     r = orc.render(ot, cam.c, opt)
     assert np.all(r["rgba"][..., 3] == 1) and np.all(r["rgba"][..., :3] == 0)
+
+
+def test_mlp_restatement_against_numpy(mnv, orc):
+    """oracle/mnv_oracle.c:orc_mlp_forward (the build's own network, parity unpinned) against an independent
+    float64 numpy evaluation of the same definition (binary16 weights / activations)."""
+    import mlp_cases
+    desc = mnv.mlp_desc(n_clusters=3, pos_octaves=3, dir_octaves=2, need_viewdir=True, n_embeddings=5, embedding_dim=4,
+                        hidden_width=64, hidden_layers=2, out_dim=7, center=(0.1, 0.2, -0.3), inv_extent=(0.5, 0.4, 0.8))
+    params = mlp_cases.make_params(mnv, desc, seed=9)
+    x, cluster = mlp_cases.make_samples(desc, 300, seed=10)
+    got = orc.mlp_forward(desc, params, cluster, x)
+    per = mnv.Mlp.param_count(desc)
+
+    def tri(t):
+        return 4.0 * np.abs(t - np.floor(t + 0.5)) - 1.0
+
+    def block(v, octaves):
+        out = [v]
+        for k in range(octaves):
+            out += [tri(v * 2.0 ** k), tri(v * 2.0 ** k + 0.25)]
+        return np.concatenate(out)
+
+    f16 = lambda a: np.asarray(a, np.float64).astype(np.float16).astype(np.float64)  # noqa: E731
+    for row in range(x.shape[0]):
+        c = int(cluster[row])
+        if c < 0 or c >= desc.n_clusters:
+            assert np.all(got[row] == 0)
+            continue
+        P = params[c * per:(c + 1) * per].astype(np.float64)
+        p = (x[row, :3] - np.float32(list(desc.center))).astype(np.float32) * np.float32(list(desc.inv_extent))
+        enc = np.concatenate([block(p.astype(np.float64), 3), block(x[row, 3:6].astype(np.float64), 2),
+                              P[per - 20:].reshape(5, 4)[int(x[row, 6])]])
+        h, off, dims = f16(enc), 0, [(64, enc.size), (64, 64), (7, 64)]
+        for li, (o, i) in enumerate(dims):
+            w, b = P[off:off + o * i].reshape(o, i), P[off + o * i: off + o * i + o]
+            off += o * i + o
+            h = w @ h + b
+            if li < 2:
+                h = f16(np.maximum(h, 0))
+        assert np.allclose(got[row], h, rtol=2e-3, atol=2e-3)
