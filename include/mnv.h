@@ -323,6 +323,23 @@ int mnv_apply_sample_results(uint16_t *data, int16_t *sample_counts, const int32
 int mnv_prune_tree(const mnv_tree_edit *tree, uint16_t *data, int32_t data_dim, int16_t *sample_counts, int32_t *visited,
                    int32_t max_capacity, int32_t *new_capacity, int32_t *num_deleted, void *hip_stream);
 
+/* torch::rand's role in expand_voxels / get_more_samples (cuda_renderer.cpp:247-250,298-301): n uniform numbers in
+ * [0, 1) with 24 random bits each, a pure function of (seed, index) -- reproducible, unlike the reference. */
+int mnv_fill_uniform(float *out, int64_t n, uint64_t seed, void *hip_stream);
+/*
+ * The step between mnv_get_samples_from_voxels and the network (cuda_renderer.cpp:116-121,135):
+ * offsets_out[ray] = inclusive prefix sum of num_samples (device int64 [n_rays], what mnv_render_nerf_results
+ * takes), and the emitted rows of samples[n_rays][max_guided_samples][samples_dim] packed in ray order:
+ * z_vals_out[total] = column 0, rows_out[total][samples_dim - 1] = the remaining columns,
+ * clusters_out[total].  total_out (host) = offsets_out[n_rays - 1]; returns MNV_E_INVALID when it exceeds
+ * rows_capacity.  With all three outputs NULL only offsets_out and total_out are produced (to size the buffers).
+ * Synchronises hip_stream (the total sizes the network launch).
+ */
+int mnv_compact_guided_samples(const int16_t *num_samples, const float *samples, const int16_t *cluster_indices, int64_t n_rays,
+                               int32_t max_guided_samples, int32_t samples_dim, int64_t *offsets_out, float *z_vals_out,
+                               float *rows_out, int16_t *clusters_out, int64_t rows_capacity, int64_t *total_out,
+                               void *hip_stream);
+
 /* ------------------------------------------------ per-sample sub-module network
  *
  * Stands in for VolumeRenderer::Impl::query_submodules (src/renderer/cuda_renderer.cpp:165-203): every sample
@@ -389,6 +406,45 @@ int mnv_n3tree_save_npz(const mnv_n3tree *t, const char *npz_path); /* svox layo
 /* DataFormat::parse / to_string (src/data_format.cpp:5-41) */
 void mnv_data_format_parse(const char *str, int32_t *format, int32_t *basis_dim);
 int mnv_data_format_to_string(int32_t format, int32_t basis_dim, char *buf, size_t buflen);
+
+/* ------------------------------------------------ the VolumeRenderer role (batch / offscreen)
+ * viewer::VolumeRenderer (include/renderer/renderer.hpp:9-39, src/renderer/cuda_renderer.cpp) behind the C ABI,
+ * for hosts that are not C++: it owns a camera, the options and an internal stream; set() uploads the tree
+ * (move_to_device(max_tree_capacity, true, true)), render() draws one frame and -- with a model loaded and
+ * options.use_splitting / use_guided_sampling -- runs the reference's refinement loop
+ * (cuda_renderer.cpp:98-156: trackers -> expand_voxels / get_more_samples -> prune_tree). */
+typedef struct mnv_renderer mnv_renderer;
+typedef struct mnv_renderer_stats {  /* what the reference prints per frame */
+    int32_t track_visit, used_accel, full;
+    int32_t split_candidates, added;       /* expand_voxels: "Split candidates: N", "Added: N" */
+    int32_t sample_candidates, resampled;  /* get_more_samples */
+    int32_t pruned;                        /* prune_tree: reclaimed chunks, -1 = nothing to prune, 0 = did not run */
+    int64_t guided_samples;                /* rows sent to the networks by guided sampling */
+    int64_t capacity;                      /* chunks in use after the frame */
+} mnv_renderer_stats;
+int mnv_renderer_create(mnv_renderer **out);
+void mnv_renderer_destroy(mnv_renderer *r);
+/* VolumeRenderer::set (cuda_renderer.cpp:498-516); the tree must outlive the renderer or the next set() */
+int mnv_renderer_set(mnv_renderer *r, mnv_n3tree *tree, int64_t max_tree_capacity);
+/* load_model (cuda_renderer.cpp:518-539) from an .npz container: mlp_desc int32[9] (the mnv_mlp_desc integers in
+ * order), mlp_center f32[3], mlp_inv_extent f32[3], mlp_params binary16, grid_dim int[2], min_position f32[3],
+ * max_position f32[3] */
+int mnv_renderer_load_model(mnv_renderer *r, const char *npz_path);
+int mnv_renderer_set_model(mnv_renderer *r, const mnv_mlp_desc *desc, const uint16_t *params, size_t n_halfs,
+                           const mnv_cluster_grid *grid);
+int mnv_renderer_resize(mnv_renderer *r, int32_t width, int32_t height);
+/* the renderer's RenderOptions, mutable in place (VolumeRenderer::options) */
+mnv_render_options *mnv_renderer_options(mnv_renderer *r);
+/* VolumeRenderer::camera pose and focal length (fx <= 0 keeps the current one; fy <= 0 means fy = fx) */
+int mnv_renderer_set_camera(mnv_renderer *r, float fx, float fy, const float center[3], const float v_back[3],
+                            const float v_world_up[3]);
+/* seed of the sample jitter (torch::rand in the reference); accel_rebuild_after < 0 keeps the default */
+int mnv_renderer_set_seed(mnv_renderer *r, uint64_t seed, int32_t accel_rebuild_after);
+int mnv_renderer_render(mnv_renderer *r, mnv_renderer_stats *stats /* may be NULL */);
+/* wait for the frame and copy it to host buffers [height][width][4] (either may be NULL) */
+int mnv_renderer_download(mnv_renderer *r, float *rgba_host, uint8_t *rgba8_host);
+/* copy the (refined) device tree back into the mnv_n3tree's host arrays */
+int mnv_renderer_sync_tree(mnv_renderer *r);
 
 /* ------------------------------------------------ deterministic synthetic trees */
 /* Integer-hash PRNG, IEEE-only arithmetic: bit-identical on every host. */

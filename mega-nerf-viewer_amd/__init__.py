@@ -130,6 +130,15 @@ class MlpDesc(C.Structure):
                 ("out_dim", C.c_int32), ("center", C.c_float * 3), ("inv_extent", C.c_float * 3)]
 
 
+class RendererStats(C.Structure):
+    _fields_ = [("track_visit", C.c_int32), ("used_accel", C.c_int32), ("full", C.c_int32), ("split_candidates", C.c_int32),
+                ("added", C.c_int32), ("sample_candidates", C.c_int32), ("resampled", C.c_int32), ("pruned", C.c_int32),
+                ("guided_samples", C.c_int64), ("capacity", C.c_int64)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
 class SynthRandomParams(C.Structure):
     _fields_ = [
         ("depth", C.c_int32),
@@ -209,6 +218,21 @@ _SIGNATURES = {
     "mnv_mlp_create": (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mnv_mlp_destroy": (None, [C.c_void_p]),
     "mnv_query_submodules": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mnv_fill_uniform": (C.c_int, [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]),
+    "mnv_compact_guided_samples": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
+    "mnv_renderer_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "mnv_renderer_destroy": (None, [C.c_void_p]),
+    "mnv_renderer_set": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "mnv_renderer_load_model": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "mnv_renderer_set_model": (C.c_int, [C.c_void_p, C.POINTER(MlpDesc), C.c_void_p, C.c_size_t, C.POINTER(ClusterGrid)]),
+    "mnv_renderer_resize": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "mnv_renderer_options": (C.POINTER(RenderOptions), [C.c_void_p]),
+    "mnv_renderer_set_camera": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mnv_renderer_set_seed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int32]),
+    "mnv_renderer_render": (C.c_int, [C.c_void_p, C.POINTER(RendererStats)]),
+    "mnv_renderer_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mnv_renderer_sync_tree": (C.c_int, [C.c_void_p]),
     "mnv_set_timing": (None, [C.c_int]),
     "mnv_take_timing": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "mnv_n3tree_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -584,6 +608,76 @@ class Mlp:
         if getattr(self, "_h", None):
             lib().mnv_mlp_destroy(self._h)
             self._h = None
+
+
+def fill_uniform(out, seed: int, stream: int = 0) -> None:
+    _check(lib().mnv_fill_uniform(_ptr(out), out.numel(), seed & 0xFFFFFFFFFFFFFFFF, C.c_void_p(stream)))
+
+
+def compact_guided_samples(num_samples, samples, cluster_indices, offsets, z_vals=None, rows=None, clusters=None, stream: int = 0) -> int:
+    """cumsum + packing of the emitted guided samples; returns the total.  With the outputs None only `offsets` is filled."""
+    n_rays, max_g, dim = samples.shape
+    total = C.c_int64(0)
+    _check(lib().mnv_compact_guided_samples(_ptr(num_samples), _ptr(samples), _ptr(cluster_indices), n_rays, max_g, dim, _ptr(offsets),
+                                            _ptr(z_vals), _ptr(rows), _ptr(clusters), 0 if z_vals is None else z_vals.shape[0],
+                                            C.byref(total), C.c_void_p(stream)))
+    return total.value
+
+
+class Renderer:
+    """viewer::VolumeRenderer behind the C ABI (mnv_renderer_*): owns camera + options + stream, runs the
+    refinement loop when a model is set."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        _check(lib().mnv_renderer_create(C.byref(h)))
+        self._h = h
+        self._tree = None
+        self.width = self.height = 0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().mnv_renderer_destroy(self._h)
+            self._h = None
+
+    @property
+    def options(self) -> RenderOptions:
+        return lib().mnv_renderer_options(self._h).contents
+
+    def set(self, tree: "N3Tree", max_tree_capacity: int) -> None:
+        _check(lib().mnv_renderer_set(self._h, tree._h, max_tree_capacity))
+        self._tree = tree  # keep alive
+
+    def load_model(self, path: str) -> None:
+        _check(lib().mnv_renderer_load_model(self._h, os.fsencode(path)))
+
+    def set_model(self, desc: MlpDesc, params, grid: ClusterGrid) -> None:
+        p = np.ascontiguousarray(params).view(np.uint16).reshape(-1)
+        _check(lib().mnv_renderer_set_model(self._h, C.byref(desc), p.ctypes.data, p.size, C.byref(grid)))
+
+    def resize(self, width: int, height: int) -> None:
+        _check(lib().mnv_renderer_resize(self._h, width, height))
+        self.width, self.height = width, height
+
+    def set_camera(self, center, back, up=(0.0, 0.0, 1.0), fx: float = -1.0, fy: float = -1.0) -> None:
+        _check(lib().mnv_renderer_set_camera(self._h, fx, fy, _f3(center), _f3(back), _f3(up)))
+
+    def set_seed(self, seed: int, accel_rebuild_after: int = -1) -> None:
+        _check(lib().mnv_renderer_set_seed(self._h, seed, accel_rebuild_after))
+
+    def render(self) -> dict:
+        st = RendererStats()
+        _check(lib().mnv_renderer_render(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def download(self, want_rgba8=False):
+        rgba = np.empty((self.height, self.width, 4), np.float32)
+        rgba8 = np.empty((self.height, self.width, 4), np.uint8) if want_rgba8 else None
+        _check(lib().mnv_renderer_download(self._h, rgba.ctypes.data, rgba8.ctypes.data if want_rgba8 else None))
+        return (rgba, rgba8) if want_rgba8 else rgba
+
+    def sync_tree(self) -> None:
+        _check(lib().mnv_renderer_sync_tree(self._h))
 
 
 MAX_BATCH = 64

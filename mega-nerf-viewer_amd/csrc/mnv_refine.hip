@@ -252,6 +252,50 @@ __global__ void prune_gather_kernel(const uint8_t *__restrict__ src, uint8_t *__
     reinterpret_cast<uint32_t *>(scratch)[(int64_t)dest * row_words + w] = reinterpret_cast<const uint32_t *>(src)[(int64_t)chunk * row_words + w];
 }
 
+// ---------------------------------------------------------------- uniform numbers, guided-sample compaction
+
+__device__ inline uint64_t splitmix64(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+
+// out[i] = 24 random bits * 2^-24 in [0, 1); a pure function of (seed, i)
+__global__ void fill_uniform_kernel(float *__restrict__ out, int64_t n, uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t h = splitmix64(splitmix64(seed) ^ (uint64_t)i);
+    out[i] = (float)(uint32_t)(h >> 40) * 5.9604644775390625e-8f;
+}
+
+struct CountToI64 {
+    __device__ int64_t operator()(int16_t v) const { return (int64_t)v; }
+};
+
+// one wavefront per ray: rows [0, num_samples[ray]) of the ray's sample block -> position offsets[ray] - n
+__global__ void compact_samples_kernel(const int16_t *__restrict__ num_samples, const int64_t *__restrict__ offsets,
+                                       const float *__restrict__ samples, const int16_t *__restrict__ clusters, int64_t n_rays,
+                                       int32_t max_samples, int32_t dim, float *__restrict__ z_vals, float *__restrict__ rows_out,
+                                       int16_t *__restrict__ clusters_out) {
+    const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (ray >= n_rays) return;
+    const int n = num_samples[ray];
+    if (n <= 0) return;
+    const int64_t base = offsets[ray] - n;
+    const float *src = samples + ray * (int64_t)max_samples * dim;
+    const int cols = dim - 1;
+    for (int i = lane; i < n; i += 64) {
+        z_vals[base + i] = src[(int64_t)i * dim];
+        clusters_out[base + i] = clusters[ray * (int64_t)max_samples + i];
+    }
+    for (int e = lane; e < n * cols; e += 64) {
+        const int i = e / cols, c = e - i * cols;
+        rows_out[(base + i) * cols + c] = src[(int64_t)i * dim + 1 + c];
+    }
+}
+
 }  // namespace
 
 }  // namespace mnv
@@ -393,6 +437,46 @@ int mnv_prune_tree(const mnv_tree_edit *tree, uint16_t *data, int32_t data_dim, 
     if (new_capacity) *new_capacity = cap - n_del;
     if (num_deleted) *num_deleted = n_del;
     return MNV_OK;
+}
+
+int mnv_fill_uniform(float *out, int64_t n, uint64_t seed, void *hip_stream) {
+    if (n < 0 || (n > 0 && !out)) return set_error(MNV_E_INVALID, "invalid buffer");
+    if (n == 0) return MNV_OK;
+    hipLaunchKernelGGL(fill_uniform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, out, n, seed);
+    return check_hip(hipGetLastError(), "fill_uniform_kernel");
+}
+
+int mnv_compact_guided_samples(const int16_t *num_samples, const float *samples, const int16_t *cluster_indices, int64_t n_rays,
+                               int32_t max_guided_samples, int32_t samples_dim, int64_t *offsets_out, float *z_vals_out,
+                               float *rows_out, int16_t *clusters_out, int64_t rows_capacity, int64_t *total_out,
+                               void *hip_stream) {
+    if (total_out) *total_out = 0;
+    if (!num_samples || !samples || !cluster_indices || !offsets_out || n_rays < 0 || max_guided_samples < 1 || samples_dim < 2)
+        return set_error(MNV_E_INVALID, "invalid guided-sample arguments");
+    if (n_rays == 0) return MNV_OK;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    auto in = rocprim::make_transform_iterator(num_samples, CountToI64());
+    size_t tmp_bytes = 0;
+    (void)rocprim::inclusive_scan(nullptr, tmp_bytes, in, offsets_out, (size_t)n_rays, rocprim::plus<int64_t>(), stream);
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    uint8_t *ws = nullptr;
+    int rc = ws_reserve(tmp_bytes + 256, &ws);
+    if (rc) return rc;
+    // offsets = cumsum(num_samples)   (cuda_renderer.cpp:116)
+    if ((rc = check_hip(rocprim::inclusive_scan(ws, tmp_bytes, in, offsets_out, (size_t)n_rays, rocprim::plus<int64_t>(), stream), "inclusive_scan")))
+        return rc;
+    int64_t total = 0;
+    if ((rc = check_hip(hipMemcpyAsync(&total, offsets_out + (n_rays - 1), 8, hipMemcpyDeviceToHost, stream), "copy"))) return rc;
+    if ((rc = check_hip(hipStreamSynchronize(stream), "compact_guided_samples"))) return rc;
+    if (total_out) *total_out = total;
+    if (total == 0 || (!z_vals_out && !rows_out && !clusters_out)) return MNV_OK;  // offsets / total only
+    if (!z_vals_out || !rows_out || !clusters_out || total > rows_capacity)
+        return set_error(MNV_E_INVALID, "output buffers are missing or smaller than the sample total");
+    // the rows with z >= 0 in ray-major order (cuda_renderer.cpp:117-121), i.e. each ray's first num_samples rows
+    const int64_t threads = n_rays * 64;
+    hipLaunchKernelGGL(compact_samples_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, num_samples, offsets_out, samples,
+                       cluster_indices, n_rays, max_guided_samples, samples_dim, z_vals_out, rows_out, clusters_out);
+    return check_hip(hipGetLastError(), "compact_samples_kernel");
 }
 
 }  // extern "C"

@@ -8,6 +8,7 @@
 #include "camera.hpp"
 #include "n3tree.hpp"
 #include "render_options.hpp"
+#include "volume_renderer.hpp"
 
 namespace viewer::synth {
 void random_tree(const mnv_synth_random_params &p, N3Tree &out);
@@ -17,6 +18,10 @@ void terrain_tree(const mnv_synth_terrain_params &p, N3Tree &out);
 
 struct mnv_n3tree {
     viewer::N3Tree tree;
+};
+
+struct mnv_renderer {
+    viewer::VolumeRenderer rend;
 };
 
 namespace {
@@ -191,6 +196,113 @@ int mnv_synth_shell_tree(const mnv_synth_shell_params *p, mnv_n3tree **out) {
             throw;
         }
         *out = t;
+        return MNV_OK;
+    });
+}
+
+/* ---- viewer::VolumeRenderer behind the C ABI (include/renderer/renderer.hpp:9-39) */
+
+int mnv_renderer_create(mnv_renderer **out) {
+    if (!out) return mnv::set_error(MNV_E_INVALID, "null argument");
+    return guarded([&] {
+        *out = new mnv_renderer();
+        return MNV_OK;
+    });
+}
+
+void mnv_renderer_destroy(mnv_renderer *r) { delete r; }
+
+int mnv_renderer_set(mnv_renderer *r, mnv_n3tree *tree, int64_t max_tree_capacity) {
+    if (!r || !tree) return mnv::set_error(MNV_E_INVALID, "null argument");
+    if (max_tree_capacity < tree->tree.capacity) return mnv::set_error(MNV_E_INVALID, "max_tree_capacity is smaller than the tree");
+    return guarded([&] {
+        r->rend.set(tree->tree, (long)max_tree_capacity);
+        return MNV_OK;
+    });
+}
+
+int mnv_renderer_load_model(mnv_renderer *r, const char *npz_path) {
+    if (!r || !npz_path) return mnv::set_error(MNV_E_INVALID, "null argument");
+    return guarded([&] {
+        r->rend.load_model(npz_path);
+        return MNV_OK;
+    });
+}
+
+int mnv_renderer_set_model(mnv_renderer *r, const mnv_mlp_desc *desc, const uint16_t *params, size_t n_halfs, const mnv_cluster_grid *grid) {
+    if (!r || !desc || !params || !grid) return mnv::set_error(MNV_E_INVALID, "null argument");
+    return guarded([&] {
+        r->rend.set_model(*desc, params, n_halfs, *grid);
+        return MNV_OK;
+    });
+}
+
+int mnv_renderer_resize(mnv_renderer *r, int32_t width, int32_t height) {
+    if (!r || width < 1 || height < 1) return mnv::set_error(MNV_E_INVALID, "invalid size");
+    return guarded([&] {
+        r->rend.resize(width, height);
+        return MNV_OK;
+    });
+}
+
+mnv_render_options *mnv_renderer_options(mnv_renderer *r) { return r ? reinterpret_cast<mnv_render_options *>(&r->rend.options) : nullptr; }
+
+int mnv_renderer_set_camera(mnv_renderer *r, float fx, float fy, const float center[3], const float v_back[3], const float v_world_up[3]) {
+    if (!r || !center || !v_back || !v_world_up) return mnv::set_error(MNV_E_INVALID, "null argument");
+    viewer::Camera &c = r->rend.camera;
+    if (fx > 0.f) c.fx = c.default_fx = fx;
+    if (fy > 0.f) c.fy = c.default_fy = fy;
+    else if (fx > 0.f) c.fy = c.default_fy = fx;
+    c.center = {center[0], center[1], center[2]};
+    c.v_back = {v_back[0], v_back[1], v_back[2]};
+    c.v_world_up = {v_world_up[0], v_world_up[1], v_world_up[2]};
+    return MNV_OK;
+}
+
+int mnv_renderer_set_seed(mnv_renderer *r, uint64_t seed, int32_t accel_rebuild_after) {
+    if (!r) return mnv::set_error(MNV_E_INVALID, "null argument");
+    r->rend.seed = seed;
+    if (accel_rebuild_after >= 0) r->rend.accel_rebuild_after = accel_rebuild_after;
+    return MNV_OK;
+}
+
+int mnv_renderer_render(mnv_renderer *r, mnv_renderer_stats *stats) {
+    if (!r) return mnv::set_error(MNV_E_INVALID, "null argument");
+    return guarded([&] {
+        r->rend.render();
+        if (stats) {
+            const auto &s = r->rend.stats;
+            stats->track_visit = s.track_visit;
+            stats->used_accel = s.used_accel;
+            stats->full = s.full;
+            stats->split_candidates = s.split_candidates;
+            stats->added = s.added;
+            stats->sample_candidates = s.sample_candidates;
+            stats->resampled = s.resampled;
+            stats->pruned = s.pruned;
+            stats->guided_samples = s.guided_samples;
+            stats->capacity = s.capacity;
+        }
+        return MNV_OK;
+    });
+}
+
+int mnv_renderer_download(mnv_renderer *r, float *rgba, uint8_t *rgba8) {
+    if (!r) return mnv::set_error(MNV_E_INVALID, "null argument");
+    return guarded([&] {
+        std::vector<float> f;
+        std::vector<uint8_t> u;
+        r->rend.download(rgba ? &f : nullptr, rgba8 ? &u : nullptr);
+        if (rgba) std::memcpy(rgba, f.data(), f.size() * sizeof(float));
+        if (rgba8) std::memcpy(rgba8, u.data(), u.size());
+        return MNV_OK;
+    });
+}
+
+int mnv_renderer_sync_tree(mnv_renderer *r) {
+    if (!r) return mnv::set_error(MNV_E_INVALID, "null argument");
+    return guarded([&] {
+        r->rend.sync_tree();
         return MNV_OK;
     });
 }

@@ -226,6 +226,35 @@ void N3Tree::move_to_device(long max_capacity, bool need_parent, bool need_sampl
     }
 }
 
+void N3Tree::rebuild_accel(void *hip_stream) {
+    if (!on_device() || N != 2) return;
+    if (device.accel) mnv_accel_destroy(device.accel);
+    device.accel = nullptr;
+    const mnv_tree_view dv = device_view();
+    const int rc = mnv_accel_create(&dv, hip_stream, &device.accel);
+    if (rc != MNV_OK) throw std::runtime_error(std::string("mnv_accel_create: ") + mnv_last_error());
+}
+
+void N3Tree::copy_from_device(void *hip_stream) {
+    if (!on_device()) return;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    const size_t cap = (size_t)capacity;
+    data.resize(cap * N3_ * data_dim);
+    child.resize(cap * N3_);
+    hip_check(hipMemcpyAsync(data.data(), device.data, data.size() * sizeof(uint16_t), hipMemcpyDeviceToHost, stream), "download data");
+    hip_check(hipMemcpyAsync(child.data(), device.child, child.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream), "download child");
+    if (device.parent) {
+        parent.resize(cap);
+        hip_check(hipMemcpyAsync(parent.data(), device.parent, cap * sizeof(int32_t), hipMemcpyDeviceToHost, stream), "download parent");
+    }
+    if (device.sample_counts) {
+        sample_counts.resize(cap * N3_);
+        hip_check(hipMemcpyAsync(sample_counts.data(), device.sample_counts, sample_counts.size() * sizeof(int16_t), hipMemcpyDeviceToHost, stream),
+                  "download sample_counts");
+    }
+    hip_check(hipStreamSynchronize(stream), "download tree");
+}
+
 mnv_tree_view N3Tree::host_view() const {
     mnv_tree_view v;
     std::memset(&v, 0, sizeof(v));

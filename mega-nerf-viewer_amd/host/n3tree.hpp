@@ -36,6 +36,10 @@ struct N3Tree {
     // Throws std::runtime_error on HIP failure.
     void move_to_device(long max_capacity, bool need_parent, bool need_sample_counts, void *hip_stream = nullptr);
     void free_device();
+    // Rebuild the packed accel from the current device arrays (after refinement changed them).
+    void rebuild_accel(void *hip_stream = nullptr);
+    // Copy the first `capacity` chunks of the device arrays back into the host vectors (after refinement).
+    void copy_from_device(void *hip_stream = nullptr);
 
     // Spatial branching factor. Only 2 is supported on the device.
     int N = 0;

@@ -3,8 +3,11 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstring>
 #include <stdexcept>
 #include <string>
+
+#include "npz.hpp"
 
 namespace viewer {
 
@@ -17,17 +20,54 @@ void mnv_check(int rc, const char *what) {
 }
 }  // namespace
 
+// grow-only device buffer
+struct DeviceBuffer {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    ~DeviceBuffer() { release(); }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    template <typename T>
+    T *get(size_t count) {
+        const size_t need = count * sizeof(T);
+        if (need > bytes) {
+            release();
+            hip_check(hipMalloc(&ptr, need + need / 8), "hipMalloc(refinement buffer)");
+            bytes = need + need / 8;
+        }
+        return static_cast<T *>(ptr);
+    }
+};
+
 struct VolumeRenderer::Impl {
     N3Tree *tree = nullptr;
+    long max_tree_capacity = 0;
     hipStream_t stream = nullptr;
     float *rgba = nullptr;
     uint8_t *rgba8 = nullptr;
     int width = 0, height = 0;
     bool initial_resize = true;
 
+    // refinement state (cuda_renderer.cpp:441-468,571-600)
+    mnv_mlp *mlp = nullptr;
+    mnv_mlp_desc mlp_desc{};
+    mnv_cluster_grid grid{};
+    DeviceBuffer split_tracker, sample_tracker, visit_tracker, num_samples, cluster_indices, guided_samples;
+    DeviceBuffer offsets, z_vals, sample_rows, sample_clusters, nerf_results;
+    DeviceBuffer nodes, rand_sample, rand_clusters, results;
+    bool prune_happened = false, can_reuse_results = false, accel_stale = false;
+    bool marks_fresh = false, want_marks = false;  // see render(): prune only after a track_visit frame
+    int quiet_frames = 0;
+    long reuse_total = 0;
+    uint64_t frame = 0;
+
     Impl() { hip_check(hipStreamCreate(&stream), "hipStreamCreate"); }
     ~Impl() {
         free_frame();
+        if (mlp) mnv_mlp_destroy(mlp);
         if (stream) (void)hipStreamDestroy(stream);
     }
     void free_frame() {
@@ -36,7 +76,111 @@ struct VolumeRenderer::Impl {
         rgba = nullptr;
         rgba8 = nullptr;
     }
+    void fill_f32(float *p, size_t n, float v) {
+        uint32_t bits;
+        std::memcpy(&bits, &v, 4);
+        hip_check(hipMemsetD32Async((hipDeviceptr_t)p, (int)bits, n, stream), "fill");
+    }
+    mnv_tree_edit edit() const {
+        mnv_tree_edit e{};
+        e.child = tree->device.child;
+        e.parent = tree->device.parent;
+        for (int i = 0; i < 3; ++i) {
+            e.offset[i] = tree->offset[i];
+            e.scale[i] = tree->scale[i];
+        }
+        e.N = tree->N;
+        e.capacity = tree->capacity;
+        return e;
+    }
+    int sample_cols(const RenderOptions &o) const { return 3 + (o.need_viewdir ? 3 : 0) + (o.appearance_embedding != -1 ? 1 : 0); }
+
+    void tree_changed() {
+        accel_stale = true;
+        quiet_frames = 0;
+        can_reuse_results = false;
+    }
+
+    // cuda_renderer.cpp:205-272
+    void expand_voxels(RenderOptions &o, FrameStats &st, uint64_t seed);
+    // cuda_renderer.cpp:274-333
+    void get_more_samples(RenderOptions &o, FrameStats &st, uint64_t seed);
+    // cuda_renderer.cpp:335-381
+    void prune_tree(FrameStats &st);
 };
+
+void VolumeRenderer::Impl::expand_voxels(RenderOptions &o, FrameStats &st, uint64_t seed) {
+    const int64_t n_px = (int64_t)width * height;
+    int32_t n = 0, n_cand = 0;
+    int32_t *d_nodes = nodes.get<int32_t>((size_t)std::max(o.split_batch_size, 1) * 2);
+    mnv_check(mnv_select_split_candidates(split_tracker.get<float>(n_px * 3), n_px, o.split_batch_size, d_nodes, &n, &n_cand, stream),
+              "mnv_select_split_candidates");
+    st.split_candidates = n_cand;
+    if (n_cand == 0) {
+        get_more_samples(o, st, seed);
+        return;
+    }
+    if (n == 0) return;
+    if (tree->capacity + n > max_tree_capacity) {
+        st.full = true;  // "Full"
+        return;
+    }
+    const int dim = sample_cols(o), spc = o.samples_per_corner, dd = tree->data_dim;
+    const int64_t children = (int64_t)n * 8, rows = children * spc;
+    float *d_rand = rand_sample.get<float>((size_t)rows * dim);
+    int16_t *d_clusters = rand_clusters.get<int16_t>((size_t)rows);
+    float *d_results = results.get<float>((size_t)rows * (dd + 1));
+    mnv_check(mnv_fill_uniform(d_rand, rows * dim, seed, stream), "mnv_fill_uniform");
+    const mnv_tree_edit e = edit();
+    mnv_check(mnv_add_children_and_generate_samples(&e, o.c_abi(), d_nodes, n, d_rand, dim, d_clusters, visit_tracker.get<int32_t>(max_tree_capacity),
+                                                    &grid, stream),
+              "mnv_add_children_and_generate_samples");
+    mnv_check(mnv_query_submodules(mlp, d_clusters, d_rand, dim, rows, d_results, dd + 1, stream), "mnv_query_submodules");
+    mnv_check(mnv_apply_split_results(tree->device.data, tree->device.sample_counts, tree->capacity, n, d_results, dd + 1, spc, dd, stream),
+              "mnv_apply_split_results");
+    tree->capacity += n;
+    st.added = n;
+    tree_changed();
+}
+
+void VolumeRenderer::Impl::get_more_samples(RenderOptions &o, FrameStats &st, uint64_t seed) {
+    const int64_t n_px = (int64_t)width * height;
+    int32_t n = 0, n_cand = 0;
+    int32_t *d_nodes = nodes.get<int32_t>((size_t)std::max(o.split_batch_size, 1) * 2);
+    mnv_check(mnv_select_sample_candidates(sample_tracker.get<float>(n_px * 3), n_px, o.split_batch_size, d_nodes, &n, &n_cand, stream),
+              "mnv_select_sample_candidates");
+    st.sample_candidates = n_cand;
+    if (n == 0) return;
+    // The reference draws 3 columns here whatever the model needs (cuda_renderer.cpp:298-301) while its kernel
+    // writes the view-direction / embedding columns as well; the row is sized like expand_voxels' instead.
+    const int dim = sample_cols(o), spc = o.samples_per_corner, dd = tree->data_dim;
+    const int64_t rows = (int64_t)n * spc;
+    float *d_rand = rand_sample.get<float>((size_t)rows * dim);
+    int16_t *d_clusters = rand_clusters.get<int16_t>((size_t)rows);
+    float *d_results = results.get<float>((size_t)rows * (dd + 1));
+    mnv_check(mnv_fill_uniform(d_rand, rows * dim, seed ^ 0x5a5a5a5a5a5a5a5aull, stream), "mnv_fill_uniform");
+    const mnv_tree_edit e = edit();
+    mnv_check(mnv_generate_samples(&e, o.c_abi(), d_nodes, n, d_rand, dim, d_clusters, &grid, stream), "mnv_generate_samples");
+    mnv_check(mnv_query_submodules(mlp, d_clusters, d_rand, dim, rows, d_results, dd + 1, stream), "mnv_query_submodules");
+    mnv_check(mnv_apply_sample_results(tree->device.data, tree->device.sample_counts, d_nodes, n, d_results, dd + 1, spc, dd, stream),
+              "mnv_apply_sample_results");
+    st.resampled = n;
+    tree_changed();
+}
+
+void VolumeRenderer::Impl::prune_tree(FrameStats &st) {
+    const mnv_tree_edit e = edit();
+    int32_t new_cap = tree->capacity, n_del = 0;
+    // sample_counts is compacted with the other arrays; the reference forgets it (cuda_renderer.cpp:357-369)
+    mnv_check(mnv_prune_tree(&e, tree->device.data, tree->data_dim, tree->device.sample_counts, visit_tracker.get<int32_t>(max_tree_capacity),
+                             (int32_t)max_tree_capacity, &new_cap, &n_del, stream),
+              "mnv_prune_tree");
+    st.pruned = n_del > 0 ? n_del : -1;
+    if (n_del > 0) {
+        tree->capacity = new_cap;
+        tree_changed();
+    }
+}
 
 VolumeRenderer::VolumeRenderer() : impl_(std::make_unique<Impl>()) {}
 VolumeRenderer::~VolumeRenderer() {}
@@ -44,8 +188,75 @@ VolumeRenderer::~VolumeRenderer() {}
 void VolumeRenderer::set(N3Tree &tree, long max_tree_capacity) {
     tree.move_to_device(max_tree_capacity, true, true, impl_->stream);
     impl_->tree = &tree;
+    impl_->max_tree_capacity = max_tree_capacity;
+    // visit_tracker = zeros, [0] = 1 (cuda_renderer.cpp:504-506)
+    int32_t *visited = impl_->visit_tracker.get<int32_t>((size_t)max_tree_capacity);
+    hip_check(hipMemsetAsync(visited, 0, (size_t)max_tree_capacity * 4, impl_->stream), "clear visit marks");
+    const int32_t one = 1;
+    hip_check(hipMemcpyAsync(visited, &one, 4, hipMemcpyHostToDevice, impl_->stream), "mark root");
+    hip_check(hipStreamSynchronize(impl_->stream), "set");
+    impl_->prune_happened = impl_->can_reuse_results = impl_->accel_stale = impl_->marks_fresh = impl_->want_marks = false;
+    impl_->quiet_frames = 0;
     options.basis_minmax[0] = 0;
     options.basis_minmax[1] = std::max(tree.data_format.basis_dim - 1, 0);
+}
+
+void VolumeRenderer::set_model(const mnv_mlp_desc &desc, const uint16_t *params, size_t n_halfs, const mnv_cluster_grid &grid) {
+    mnv_mlp *m = nullptr;
+    mnv_check(mnv_mlp_create(&desc, params, n_halfs, impl_->stream, &m), "mnv_mlp_create");
+    if (impl_->mlp) mnv_mlp_destroy(impl_->mlp);
+    impl_->mlp = m;
+    impl_->mlp_desc = desc;
+    impl_->grid = grid;
+    // cuda_renderer.cpp:534-537
+    options.need_viewdir = desc.need_viewdir != 0;
+    if (options.appearance_embedding == -1 && desc.n_embeddings > 0) options.appearance_embedding = 0;
+    if (desc.n_embeddings <= 0) options.appearance_embedding = -1;
+    impl_->can_reuse_results = false;
+}
+
+bool VolumeRenderer::has_model() const { return impl_->mlp != nullptr; }
+
+void VolumeRenderer::load_model(const std::string &npz_path) {
+    npz::Archive a = npz::load(npz_path);
+    auto need = [&](const char *name) -> npz::Array & {
+        auto it = a.find(name);
+        if (it == a.end()) throw std::runtime_error(std::string("model container lacks '") + name + "'");
+        return it->second;
+    };
+    auto ints = [&](const char *name, size_t count, int32_t *out) {
+        npz::Array &arr = need(name);
+        if (arr.num_vals() != count || (arr.kind != 'i' && arr.kind != 'u')) throw std::runtime_error(std::string(name) + " has an unexpected shape");
+        for (size_t i = 0; i < count; ++i) out[i] = arr.word_size == 8 ? (int32_t)arr.data<int64_t>()[i] : arr.data<int32_t>()[i];
+    };
+    auto floats = [&](const char *name, size_t count, float *out) {
+        npz::Array &arr = need(name);
+        if (arr.num_vals() != count || arr.kind != 'f') throw std::runtime_error(std::string(name) + " has an unexpected shape");
+        for (size_t i = 0; i < count; ++i) out[i] = arr.word_size == 8 ? (float)arr.data<double>()[i] : arr.data<float>()[i];
+    };
+    int32_t d[9];
+    ints("mlp_desc", 9, d);
+    mnv_mlp_desc desc{};
+    desc.n_clusters = d[0];
+    desc.pos_octaves = d[1];
+    desc.dir_octaves = d[2];
+    desc.need_viewdir = d[3];
+    desc.n_embeddings = d[4];
+    desc.embedding_dim = d[5];
+    desc.hidden_width = d[6];
+    desc.hidden_layers = d[7];
+    desc.out_dim = d[8];
+    floats("mlp_center", 3, desc.center);
+    floats("mlp_inv_extent", 3, desc.inv_extent);
+    mnv_cluster_grid grid{};
+    ints("grid_dim", 2, grid.grid_dim);
+    float max_position[3];
+    floats("min_position", 3, grid.min_position);
+    floats("max_position", 3, max_position);
+    for (int i = 0; i < 3; ++i) grid.range[i] = max_position[i] - grid.min_position[i];  // cuda_renderer.cpp:527
+    npz::Array &p = need("mlp_params");
+    if (p.word_size != 2) throw std::runtime_error("mlp_params must be binary16");
+    set_model(desc, p.data<uint16_t>(), p.num_vals(), grid);
 }
 
 void VolumeRenderer::clear() { impl_->tree = nullptr; }
@@ -74,24 +285,116 @@ void VolumeRenderer::resize(int width, int height) {
 }
 
 void VolumeRenderer::render() {
-    if (!impl_->rgba) resize(camera.width, camera.height);
+    Impl &I = *impl_;
+    if (!I.rgba) resize(camera.width, camera.height);
     camera._update();
     const mnv_camera cv = camera.c_abi();
-    const mnv_rect full = {0, 0, impl_->width, impl_->height};
-    if (impl_->tree == nullptr || impl_->tree->N <= 0) {
+    const mnv_rect full = {0, 0, I.width, I.height};
+    stats = FrameStats();
+    if (I.tree == nullptr || I.tree->N <= 0) {
         mnv_tree_view empty = {};  // N == 0: background only (renderer_kernel.cu:266)
-        mnv_check(mnv_render_voxels(&empty, &cv, options.c_abi(), full, impl_->rgba, impl_->rgba8, nullptr, nullptr, nullptr, 0, impl_->stream),
-                  "mnv_render_voxels");
+        mnv_check(mnv_render_voxels(&empty, &cv, options.c_abi(), full, I.rgba, I.rgba8, nullptr, nullptr, nullptr, 0, I.stream), "mnv_render_voxels");
         return;
     }
-    if (impl_->tree->device.accel) {
-        mnv_check(mnv_render_voxels_accel(impl_->tree->device.accel, &cv, options.c_abi(), full, impl_->rgba, impl_->rgba8, impl_->stream),
-                  "mnv_render_voxels_accel");
-    } else {
-        const mnv_tree_view dv = impl_->tree->device_view();
-        mnv_check(mnv_render_voxels(&dv, &cv, options.c_abi(), full, impl_->rgba, impl_->rgba8, nullptr, nullptr, nullptr, 0, impl_->stream),
-                  "mnv_render_voxels");
+    N3Tree &tree = *I.tree;
+    const int64_t n_px = (int64_t)I.width * I.height;
+    const bool refine = I.mlp != nullptr && (options.use_splitting || options.use_guided_sampling);
+    if (refine && I.mlp_desc.out_dim != tree.data_dim + 1)
+        throw std::runtime_error("the model's out_dim must be the tree's data_dim + 1 (cuda_renderer.cpp:255-257)");
+
+    // cuda_renderer.cpp:98-107
+    const bool camera_has_changed = camera.has_changed();
+    const bool track_visit = refine && ((camera_has_changed && tree.capacity > I.max_tree_capacity * 3 / 4) || I.prune_happened || I.want_marks);
+    if (camera_has_changed) I.can_reuse_results = false;
+    stats.track_visit = track_visit;
+    float *split = nullptr, *sample = nullptr;
+    int32_t *visited = I.visit_tracker.get<int32_t>((size_t)std::max<long>(I.max_tree_capacity, 1));
+    if (refine && options.use_splitting) {
+        split = I.split_tracker.get<float>(n_px * 3);
+        sample = I.sample_tracker.get<float>(n_px * 3);
+        I.fill_f32(split, n_px * 3, -1.f);
+        I.fill_f32(sample, n_px * 3, -1.f);
     }
+    // the packed accel describes the tree as it was when it was built: after a refinement step the march reads the
+    // reference-layout arrays directly until the tree has been quiet for accel_rebuild_after frames
+    if (I.accel_stale && I.quiet_frames >= accel_rebuild_after) {
+        tree.rebuild_accel(I.stream);
+        I.accel_stale = false;
+    }
+    const mnv_tree_view dv = tree.device_view();
+
+    if (refine && options.use_guided_sampling) {
+        // cuda_renderer.cpp:109-139
+        const int samples_dim = 1 + I.sample_cols(options), max_g = options.max_guided_samples, dd = tree.data_dim;
+        int64_t *offsets = I.offsets.get<int64_t>(n_px);
+        if (!I.can_reuse_results) {
+            int16_t *num = I.num_samples.get<int16_t>(n_px);
+            int16_t *clusters = I.cluster_indices.get<int16_t>(n_px * max_g);
+            float *guided = I.guided_samples.get<float>((size_t)n_px * max_g * samples_dim);
+            hip_check(hipMemsetAsync(num, 0, n_px * 2, I.stream), "clear num_samples");
+            mnv_check(mnv_get_samples_from_voxels(&dv, &cv, options.c_abi(), full, split, sample, visited, track_visit, num, guided, samples_dim,
+                                                  clusters, &I.grid, I.stream),
+                      "mnv_get_samples_from_voxels");
+            int64_t total = 0;
+            mnv_check(mnv_compact_guided_samples(num, guided, clusters, n_px, max_g, samples_dim, offsets, nullptr, nullptr, nullptr, 0, &total, I.stream),
+                      "mnv_compact_guided_samples");
+            float *z = I.z_vals.get<float>((size_t)std::max<int64_t>(total, 1));
+            float *rows = I.sample_rows.get<float>((size_t)std::max<int64_t>(total, 1) * (samples_dim - 1));
+            int16_t *row_clusters = I.sample_clusters.get<int16_t>((size_t)std::max<int64_t>(total, 1));
+            float *values = I.nerf_results.get<float>((size_t)std::max<int64_t>(total, 1) * (dd + 1));
+            if (total > 0) {
+                mnv_check(mnv_compact_guided_samples(num, guided, clusters, n_px, max_g, samples_dim, offsets, z, rows, row_clusters, total, &total, I.stream),
+                          "mnv_compact_guided_samples");
+                mnv_check(mnv_query_submodules(I.mlp, row_clusters, rows, samples_dim - 1, total, values, dd + 1, I.stream), "mnv_query_submodules");
+            }
+            I.reuse_total = total;
+            I.can_reuse_results = true;
+        }
+        stats.guided_samples = I.reuse_total;
+        mnv_check(mnv_render_nerf_results(&dv, &cv, options.c_abi(), full, I.nerf_results.get<float>(1), tree.data_dim + 1, I.z_vals.get<float>(1), offsets,
+                                          I.rgba, I.rgba8, I.stream),
+                  "mnv_render_nerf_results");
+    } else if (tree.device.accel && !I.accel_stale && !track_visit) {
+        stats.used_accel = true;
+        if (split)
+            mnv_check(mnv_render_voxels_accel_track(tree.device.accel, &cv, options.c_abi(), full, I.rgba, I.rgba8, split, sample,
+                                                    tree.device.sample_counts, I.stream),
+                      "mnv_render_voxels_accel_track");
+        else
+            mnv_check(mnv_render_voxels_accel(tree.device.accel, &cv, options.c_abi(), full, I.rgba, I.rgba8, I.stream), "mnv_render_voxels_accel");
+    } else {
+        mnv_check(mnv_render_voxels(&dv, &cv, options.c_abi(), full, I.rgba, I.rgba8, split, sample, visited, track_visit, I.stream), "mnv_render_voxels");
+    }
+
+    if (refine) {
+        const int before = tree.capacity;
+        ++I.quiet_frames;
+        // cuda_renderer.cpp:144-155.  The capacity check runs only while splitting is on: the reference's unconditional
+        // check would prune a tree that was merely loaded with max_tree_capacity close to its size.
+        if (options.use_splitting) {
+            I.expand_voxels(options, stats, seed + 0x9e3779b97f4a7c15ull * I.frame);
+            if (track_visit) I.marks_fresh = true;
+            I.want_marks = false;
+            if (I.max_tree_capacity - tree.capacity < options.split_batch_size) {
+                // The reference prunes here with whatever marks exist (cuda_renderer.cpp:148-150); with a camera that
+                // has not moved since the tree was small that is no marks at all and the whole tree goes.  Here a
+                // prune waits for one track_visit frame since the marks were last cleared.
+                if (I.marks_fresh) {
+                    I.prune_tree(stats);
+                    I.prune_happened = true;
+                    I.marks_fresh = false;
+                } else {
+                    I.want_marks = true;
+                    I.prune_happened = false;
+                }
+            } else {
+                I.prune_happened = false;
+            }
+        }
+        (void)before;
+    }
+    ++I.frame;
+    stats.capacity = tree.capacity;
 }
 
 const char *VolumeRenderer::get_backend() { return "HIP gfx950"; }
@@ -107,6 +410,10 @@ void VolumeRenderer::download(std::vector<float> *rgba, std::vector<uint8_t> *rg
         rgba8->resize(n);
         hip_check(hipMemcpy(rgba8->data(), impl_->rgba8, n, hipMemcpyDeviceToHost), "download rgba8");
     }
+}
+
+void VolumeRenderer::sync_tree() {
+    if (impl_->tree) impl_->tree->copy_from_device(impl_->stream);
 }
 
 const float *VolumeRenderer::device_rgba() const { return impl_->rgba; }

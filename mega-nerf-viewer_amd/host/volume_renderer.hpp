@@ -4,12 +4,20 @@
 // src/renderer/cuda_renderer.cpp:68-163,383-516): it owns a Camera and RenderOptions, `set()` moves a
 // tree to the device, `resize()` sizes the frame, `render()` launches the march for the current
 // camera.  The GL framebuffers / CUDA-GL interop / blit of the reference are replaced by a linear
-// device frame (float RGBA + RGBA8) that `download()` copies to the host.  Guided sampling and
-// refinement (load_model, expand_voxels, prune_tree) are not part of this path.
+// device frame (float RGBA + RGBA8) that `download()` copies to the host.
+//
+// With a model loaded (load_model / set_model) render() also runs the reference's refinement loop
+// (cuda_renderer.cpp:98-156,205-381): options.use_guided_sampling composites per-sample network outputs
+// instead of tree colours, options.use_splitting grows the tree from the per-ray trackers
+// (expand_voxels / get_more_samples) and prunes unvisited chunks when it is nearly full (prune_tree).
+// Every step is a device-resident libmnv entry point; the host only sequences them.  The networks are the
+// build's own small MLPs (include/mnv.h, mnv_mlp_desc) -- the reference's TorchScript containers are not
+// part of its repository.
 #pragma once
 
 #include <cstdint>
 #include <memory>
+#include <string>
 #include <vector>
 
 #include "camera.hpp"
@@ -42,6 +50,31 @@ struct VolumeRenderer {
     const uint8_t *device_rgba8() const;
     // Average device time per render() since the last call, in ms (HIP events).
     double take_average_ms();
+
+    // Role of load_model (cuda_renderer.cpp:518-539): read a model container.  Here an .npz with
+    //   mlp_desc int32[9] (n_clusters, pos_octaves, dir_octaves, need_viewdir, n_embeddings, embedding_dim,
+    //   hidden_width, hidden_layers, out_dim), mlp_center f32[3], mlp_inv_extent f32[3], mlp_params f16/u16 [..],
+    //   grid_dim int32[2], min_position f32[3], max_position f32[3]
+    // Sets options.need_viewdir / appearance_embedding from the description as the reference does.
+    void load_model(const std::string &npz_path);
+    void set_model(const mnv_mlp_desc &desc, const uint16_t *params, size_t n_halfs, const mnv_cluster_grid &grid);
+    bool has_model() const;
+    // Copy the (refined) device tree back into the N3Tree's host arrays, e.g. before N3Tree::save_npz.
+    void sync_tree();
+
+    // What the last render() did (the reference prints these to stdout).
+    struct FrameStats {
+        bool track_visit = false, used_accel = false, full = false;
+        int split_candidates = 0, added = 0;        // expand_voxels
+        int sample_candidates = 0, resampled = 0;   // get_more_samples
+        int pruned = 0;                             // prune_tree (-1: ran, nothing to prune)
+        long guided_samples = 0;                    // rows sent to the networks by guided sampling
+        long capacity = 0;
+    } stats;
+    // Seed of the sample-position jitter (torch::rand in the reference); frame f uses (seed, f).
+    uint64_t seed = 0;
+    // Frames without a tree change after which the packed accel is rebuilt and used again.
+    int accel_rebuild_after = 4;
 
     // Camera instance
     Camera camera;

@@ -1,0 +1,263 @@
+"""The VolumeRenderer refinement loop (host/volume_renderer.cpp; reference src/renderer/cuda_renderer.cpp:98-156,205-381)
+driven through the mnv_renderer_* C ABI.
+
+Frame-level checks: the first refinement step is emulated with the checkers (CPU march oracle for the trackers,
+refine_oracle for the vote, the C oracle for add_children / sample generation / the MLP, refine_oracle for the mean)
+and must give the same topology exactly and the same new rows to the MLP tolerance; guided sampling is compared
+bit for bit with the reference's own tensor expressions (cumsum + boolean-mask compaction) evaluated by torch on the
+device; longer runs are checked through tree invariants and accel-vs-reference-layout equality on the grown tree."""
+import numpy as np
+import pytest
+
+import cases
+import mlp_cases
+import refine_oracle as ro
+
+pytestmark = pytest.mark.gpu
+
+M64 = (1 << 64) - 1
+
+
+def splitmix64(x):
+    x = (x + 0x9e3779b97f4a7c15) & M64
+    x = ((x ^ (x >> 30)) * 0xbf58476d1ce4e5b9) & M64
+    x = ((x ^ (x >> 27)) * 0x94d049bb133111eb) & M64
+    return x ^ (x >> 31)
+
+
+def uniform_numpy(n, seed):
+    """mnv_fill_uniform on the host (include/mnv.h)."""
+    s = splitmix64(seed & M64)
+    out = np.empty(n, np.float32)
+    for i in range(n):
+        out[i] = np.float32((splitmix64(s ^ i) >> 40) * 2.0 ** -24)
+    return out
+
+
+def make_grid(mnv):
+    g = mnv.ClusterGrid()
+    g.grid_dim[0], g.grid_dim[1] = 3, 2
+    for i, (lo, rng) in enumerate([(-1.0, 2.0), (-1.1, 2.2), (-0.9, 1.8)]):
+        g.min_position[i], g.range[i] = lo, rng
+    return g
+
+
+def setup(mnv, case, extra_capacity, need_viewdir=False, seed=5, **opt_over):
+    spec = cases.CASES[case]
+    tree = cases.make_tree(mnv, spec["tree"])
+    v = tree.host_view()
+    cam_spec = spec["camera"]
+    desc = mnv.mlp_desc(n_clusters=6, pos_octaves=4, dir_octaves=2, need_viewdir=need_viewdir, hidden_width=64, hidden_layers=2,
+                        out_dim=v.data_dim + 1)
+    params = mlp_cases.make_params(mnv, desc, seed=21)
+    r = mnv.Renderer()
+    r.resize(cam_spec["width"], cam_spec["height"])
+    r.set(tree, v.capacity + extra_capacity)
+    r.set_model(desc, params, make_grid(mnv))
+    # Camera ctor defaults (camera.cpp:29-45) when the case does not pose the camera
+    r.set_camera(cam_spec.get("center", (-3.55, 0.0, 3.55)), cam_spec.get("back", (-0.7071068, 0.0, 0.7071068)), fx=cam_spec["fx"])
+    r.set_seed(seed)
+    opt = cases.make_options(mnv, spec["options"])
+    o = r.options
+    for name in ("step_size", "sigma_thresh", "stop_thresh", "background_brightness"):
+        setattr(o, name, getattr(opt, name))
+    for k, val in opt_over.items():
+        setattr(o, k, val)
+    return r, tree, desc, params, cam_spec
+
+
+def check_tree_links(child, parent, cap):
+    """Every chunk but the root hangs under exactly the slot its parent word names."""
+    tgt = np.arange(cap)[:, None] + child[:cap]
+    nz = child[:cap] != 0
+    assert np.all((tgt[nz] > 0) & (tgt[nz] < cap))
+    rows, slots = np.nonzero(nz)
+    assert np.array_equal(parent[tgt[nz]], rows * 8 + slots)
+    assert np.array_equal(np.sort(tgt[nz]), np.arange(1, cap))  # each chunk referenced once
+
+
+def test_first_refinement_step_matches_checkers(mnv, orc, torch_gpu):
+    seed = 5
+    r, tree, desc, params, cam_spec = setup(mnv, "rgba_d5", 5000, seed=seed, use_splitting=True, max_depth=7, split_batch_size=64,
+                                            samples_per_corner=4, max_sample_count=64)
+    tree0 = cases.make_tree(mnv, cases.CASES["rgba_d5"]["tree"])  # untouched twin for the checkers (sync_tree reallocates the host arrays)
+    v = tree0.host_view()
+    cap, dd = v.capacity, v.data_dim
+    data0, child0, parent0 = (a.copy() for a in tree0.host_arrays())
+    st = r.render()
+    frame = r.download()
+    r.sync_tree()
+
+    # --- the same step with the checkers
+    cam = cases.make_camera(mnv, cam_spec)
+    opt = mnv.RenderOptions()
+    import ctypes as C
+    C.memmove(C.byref(opt), C.byref(r.options), C.sizeof(opt))
+    counts = np.full((cap, 8), 8, np.int16)
+    ref = orc.render(orc.tree_from_view(v, sample_counts=counts), cam.c, opt, want_trackers=True)
+    assert np.array_equal(cases.bits(frame), cases.bits(ref["rgba"]))
+    nodes, n_cand = ro.select_split_candidates(ref["split"].reshape(-1, 3), 64)
+    n = nodes.shape[0]
+    assert n > 0 and st["split_candidates"] == n_cand and st["added"] == n and st["capacity"] == cap + n
+    assert st["used_accel"] == 1 and st["track_visit"] == 0 and st["pruned"] == 0
+    max_cap = cap + 5000
+    child = np.zeros((max_cap, 8), np.int32)
+    child[:cap] = child0
+    parent = np.zeros(max_cap, np.int32)
+    parent[:cap] = parent0
+    visited = np.zeros(max_cap, np.int32)
+    visited[0] = 1
+    spc, dim = 4, 3
+    samples = uniform_numpy(n * 8 * spc * dim, seed).reshape(n * 8, spc, dim)
+    clusters = np.full((n * 8, spc), -1, np.int16)
+    orc.add_children_and_generate_samples(child, parent, list(v.offset), list(v.scale), cap, opt, nodes, samples, clusters, visited, make_grid(mnv))
+    results = orc.mlp_forward(desc, params, clusters.reshape(-1), samples.reshape(-1, dim), out_cols=dd + 1).reshape(n * 8, spc, dd + 1)
+    data = np.zeros((max_cap, 8, dd), np.float16)
+    data[:cap] = data0.view(np.float16)
+    big_counts = np.zeros((max_cap, 8), np.int16)
+    big_counts[:cap] = counts
+    ro.apply_split_results(data, big_counts, cap, results, spc)
+
+    got_data, got_child, got_parent = tree.host_arrays()
+    assert tree.capacity == cap + n
+    assert np.array_equal(got_child, child[:cap + n]) and np.array_equal(got_parent, parent[:cap + n])
+    check_tree_links(got_child, got_parent, cap + n)
+    assert np.array_equal(got_data[:cap], data0)  # existing rows untouched
+    new_got = got_data[cap:].view(np.float16).astype(np.float32)
+    new_want = data[cap:cap + n].astype(np.float32)
+    err = np.abs(new_got - new_want) / (1.0 + np.abs(new_want))
+    assert err.max() < 5e-3 and np.abs(new_want).mean() > 0.02
+
+
+def test_refinement_run_keeps_a_valid_tree_and_accel_is_rebuilt(mnv, torch_gpu):
+    torch = torch_gpu
+    r, tree, desc, params, cam_spec = setup(mnv, "sh4_d6", 40000, need_viewdir=True, use_splitting=True, max_depth=8, split_batch_size=512,
+                                            samples_per_corner=4, max_sample_count=24)
+    r.set_seed(9, accel_rebuild_after=2)
+    cap0 = tree.capacity
+    caps, added, resampled = [], 0, 0
+    for f in range(10):
+        a = 0.1 * f
+        r.set_camera((-2.4 * np.cos(a) - 1.1 * np.sin(a), 1.1 * np.cos(a) - 2.4 * np.sin(a), 1.6), (-0.72 * np.cos(a) - 0.33 * np.sin(a), 0.33 * np.cos(a) - 0.72 * np.sin(a), 0.48))
+        st = r.render()
+        caps.append(st["capacity"])
+        added += st["added"]
+        resampled += st["resampled"]
+        assert st["added"] <= 512 and st["pruned"] == 0
+    assert caps == sorted(caps) and caps[-1] == cap0 + added and added > 0
+    assert np.isfinite(r.download()).all()
+    r.sync_tree()
+    data, child, parent = tree.host_arrays()
+    assert child.shape[0] == caps[-1]
+    check_tree_links(child, parent, caps[-1])
+    # nothing left to split or sample: after accel_rebuild_after quiet frames the packed accel is rebuilt from the grown
+    # tree and used again
+    used = []
+    r.options.max_depth = 1
+    r.options.max_sample_count = -30000
+    for f in range(4):
+        st = r.render()
+        used.append(st["used_accel"])
+        assert st["added"] == 0 and st["resampled"] == 0
+    assert used[-1] == 1 and used[0] == 0
+    # the rebuilt accel and the reference-layout kernel agree bit for bit on the grown tree
+    cam = cases.make_camera(mnv, cam_spec)
+    opt = cases.make_options(mnv, cases.CASES["sh4_d6"]["options"])
+    opt.basis_minmax[1] = 3
+    h, w = cam.height, cam.width
+    a = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    mnv.render_voxels(tree.device_view(), cam, opt, rgba=a)
+    mnv.render_voxels_accel(tree.accel, cam, opt, rgba=b)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def test_prune_runs_inside_the_loop(mnv, torch_gpu):
+    # max_tree_capacity - capacity < split_batch_size from the start, but capacity <= 3/4 max: the camera change of the first
+    # frame does not collect visit marks, so the prune waits one track_visit frame (host/volume_renderer.cpp)
+    r, tree, desc, params, cam_spec = setup(mnv, "sh4_d6", 600, use_splitting=True, max_depth=8, split_batch_size=700, samples_per_corner=2,
+                                            max_sample_count=24)
+    cap0 = tree.capacity
+    log = [r.render() for _ in range(4)]
+    assert log[0]["track_visit"] == 0 and log[0]["pruned"] == 0 and 0 < log[0]["added"] <= 600
+    assert log[1]["track_visit"] == 1 and log[1]["pruned"] > 0 and log[1]["capacity"] < cap0
+    assert log[2]["track_visit"] == 1  # prune_happened (cuda_renderer.cpp:101-102)
+    r.sync_tree()
+    data, child, parent = tree.host_arrays()
+    assert child.shape[0] == tree.capacity == log[-1]["capacity"]
+    check_tree_links(child, parent, tree.capacity)
+    assert np.isfinite(r.download()).all()
+
+
+def test_prune_on_the_first_frame_when_the_tree_is_nearly_full(mnv, orc, torch_gpu):
+    """capacity > 3/4 max and a changed camera: the first frame marks visits (cuda_renderer.cpp:101-102) and prunes right
+    after its split step; the picture of that frame is the unpruned tree's."""
+    r, tree, desc, params, cam_spec = setup(mnv, "sh4_d6", 36, use_splitting=True, max_depth=8, split_batch_size=24, samples_per_corner=2,
+                                            max_sample_count=24)
+    tree0 = cases.make_tree(mnv, cases.CASES["sh4_d6"]["tree"])
+    cap0 = tree.capacity
+    st = r.render()
+    assert st["track_visit"] == 1 and st["used_accel"] == 0 and st["added"] == 24 and st["pruned"] > 0
+    assert st["capacity"] == cap0 + 24 - st["pruned"]
+    frame = r.download()
+    cam = cases.make_camera(mnv, cam_spec)
+    import ctypes as C
+    opt = mnv.RenderOptions()
+    C.memmove(C.byref(opt), C.byref(r.options), C.sizeof(opt))
+    ref = orc.render(orc.tree_from_view(tree0.host_view()), cam.c, opt)
+    assert np.array_equal(cases.bits(frame), cases.bits(ref["rgba"]))
+    r.sync_tree()
+    data, child, parent = tree.host_arrays()
+    check_tree_links(child, parent, tree.capacity)
+
+
+def test_guided_sampling_frame_matches_reference_tensor_ops(mnv, torch_gpu):
+    """use_guided_sampling: get_samples -> compaction -> networks -> composite.  The compaction is compared with the
+    reference's own expressions (cuda_renderer.cpp:116-121: cumsum, boolean mask on column 0) run by torch."""
+    torch = torch_gpu
+    r, tree, desc, params, cam_spec = setup(mnv, "rgba_d5", 0, use_guided_sampling=True, max_guided_samples=16)
+    st = r.render()
+    frame = r.download()
+    assert st["guided_samples"] > 0 and st["used_accel"] == 0
+
+    cam = cases.make_camera(mnv, cam_spec)
+    import ctypes as C
+    opt = mnv.RenderOptions()
+    C.memmove(C.byref(opt), C.byref(r.options), C.sizeof(opt))
+    dv = tree.device_view()
+    n_px, max_g, dim = cam.width * cam.height, 16, 4
+    num = torch.zeros(n_px, dtype=torch.int16, device="cuda")
+    guided = torch.zeros((n_px, max_g, dim), dtype=torch.float32, device="cuda")
+    guided[:, :, 0] = -1
+    clusters = torch.zeros((n_px, max_g), dtype=torch.int16, device="cuda")
+    mnv.get_samples_from_voxels(dv, cam, opt, num, guided, clusters, make_grid(mnv))
+    offsets = torch.cumsum(num, 0)
+    flat = guided.view(-1, dim)
+    mask = flat[:, 0] >= 0
+    valid, valid_clusters = flat[mask], clusters.view(-1)[mask]
+    assert valid.shape[0] == st["guided_samples"] == int(offsets[-1])
+    # the build's compaction equals the boolean-mask form
+    off2 = torch.empty(n_px, dtype=torch.int64, device="cuda")
+    total = valid.shape[0]
+    z2 = torch.empty(total, dtype=torch.float32, device="cuda")
+    rows2 = torch.empty((total, dim - 1), dtype=torch.float32, device="cuda")
+    cl2 = torch.empty(total, dtype=torch.int16, device="cuda")
+    assert mnv.compact_guided_samples(num, guided, clusters, off2, z2, rows2, cl2) == total
+    torch.cuda.synchronize()
+    assert torch.equal(off2, offsets) and torch.equal(z2, valid[:, 0]) and torch.equal(rows2, valid[:, 1:]) and torch.equal(cl2, valid_clusters)
+    # networks + composite
+    mlp = mnv.Mlp(desc, params)
+    values = torch.zeros((total, tree.host_view().data_dim + 1), dtype=torch.float32, device="cuda")
+    mlp.query(valid_clusters, valid[:, 1:], values)
+    out = torch.empty((cam.height, cam.width, 4), dtype=torch.float32, device="cuda")
+    mnv.render_nerf_results(dv, cam, opt, values, valid[:, 0].contiguous(), offsets, rgba=out)
+    torch.cuda.synchronize()
+    assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(frame))
+    # further frames with an unchanged camera (Camera::_update renormalises: a fixed point from the second call on)
+    # reuse the network outputs (can_reuse_results) and give the same picture
+    r.render()
+    f2 = r.download()
+    st3 = r.render()
+    assert st3["guided_samples"] > 0 and np.array_equal(cases.bits(r.download()), cases.bits(f2))
+    assert np.abs(f2 - frame).max() < 1e-4
