@@ -57,7 +57,10 @@ __global__ __launch_bounds__(256) void march_ref_layout_kernel(const MarchParams
             int32_t chunk = 0, cidx;
             int depth = 1;
             for (;;) {
-                if (P.track_visit) atomicCAS(&P.visited[chunk], 0, 1);
+                // rt_core.cuh:132-134 marks with atomicCAS(&visited[chunk], 0, 1); the mark only ever goes 0 -> 1, so a
+                // load and a conditional plain store leave the same array -- without every ray serialising on the
+                // root's word (measured: 974 ms -> about the unmarked frame time on the cfg2 frame)
+                if (P.track_visit && __hip_atomic_load(&P.visited[chunk], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) P.visited[chunk] = 1;
                 cidx = 0;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {

@@ -103,16 +103,49 @@ struct MlpLaunch {
 
 // ---------------------------------------------------------------- counting sort by cluster
 
-__global__ void mlp_histogram(const int16_t *__restrict__ cluster, int64_t n, int32_t n_clusters, int32_t *__restrict__ counts,
-                              float *__restrict__ results, int32_t result_stride, int32_t out_dim) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = cluster[i];
-    if (c >= 0 && c < n_clusters) {
-        atomicAdd(&counts[c], 1);
-    } else {
-        for (int k = 0; k < out_dim; ++k) results[i * result_stride + k] = 0.f;  // no sub-module: zeros
+// Rows per block of the two sort passes; each thread handles kSortItems rows.
+constexpr int kSortItems = 8;
+constexpr int kSortRows = 256 * kSortItems;
+
+// Wavefront-aggregated add of 1 to s_bins[c] for every active lane: one LDS atomic per distinct bin in the
+// wavefront instead of one per lane (neighbouring samples mostly share a cluster).  Returns the lane's rank
+// among the block's rows of its bin.
+__device__ inline int aggregated_rank(int32_t *s_bins, int c, bool valid) {
+    int rank = 0;
+    unsigned long long todo = __ballot(valid);
+    const unsigned lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int c0 = __shfl(c, leader);
+        const unsigned long long same = __ballot(valid && c == c0);
+        int base = 0;
+        if ((int)lane == leader) base = atomicAdd(&s_bins[c0], __popcll(same));
+        base = __shfl(base, leader);
+        if (valid && c == c0) rank = base + __popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
     }
+    return rank;
+}
+
+__global__ __launch_bounds__(256) void mlp_histogram(const int16_t *__restrict__ cluster, int64_t n, int32_t n_clusters,
+                                                     int32_t *__restrict__ counts, float *__restrict__ results, int32_t result_stride,
+                                                     int32_t out_dim) {
+    __shared__ int32_t s_bins[kMaxClusters];
+    for (int c = threadIdx.x; c < n_clusters; c += 256) s_bins[c] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kSortRows;
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        const int c = i < n ? cluster[i] : -1;
+        const bool valid = c >= 0 && c < n_clusters;
+        (void)aggregated_rank(s_bins, c, valid);
+        if (i < n && !valid)
+            for (int o = 0; o < out_dim; ++o) results[i * result_stride + o] = 0.f;  // no sub-module: zeros
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < n_clusters; c += 256)
+        if (s_bins[c]) atomicAdd(&counts[c], s_bins[c]);
 }
 
 // one block: exclusive scan of the counts, tile list
@@ -144,12 +177,29 @@ __global__ void mlp_plan(const int32_t *__restrict__ counts, int32_t n_clusters,
     }
 }
 
-__global__ void mlp_scatter(const int16_t *__restrict__ cluster, int64_t n, int32_t n_clusters, int32_t *__restrict__ cursor,
-                            int32_t *__restrict__ order) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int c = cluster[i];
-    if (c >= 0 && c < n_clusters) order[atomicAdd(&cursor[c], 1)] = (int32_t)i;
+__global__ __launch_bounds__(256) void mlp_scatter(const int16_t *__restrict__ cluster, int64_t n, int32_t n_clusters,
+                                                   int32_t *__restrict__ cursor, int32_t *__restrict__ order) {
+    __shared__ int32_t s_bins[kMaxClusters];
+    for (int c = threadIdx.x; c < n_clusters; c += 256) s_bins[c] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kSortRows;
+    int rank[kSortItems], bin[kSortItems];
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        const int c = i < n ? cluster[i] : -1;
+        const bool valid = c >= 0 && c < n_clusters;
+        bin[k] = valid ? c : -1;
+        rank[k] = aggregated_rank(s_bins, c, valid);
+    }
+    __syncthreads();
+    // one global reservation per bin and block; s_bins becomes the block's base position
+    for (int c = threadIdx.x; c < n_clusters; c += 256)
+        if (s_bins[c]) s_bins[c] = atomicAdd(&cursor[c], s_bins[c]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kSortItems; ++k)
+        if (bin[k] >= 0) order[s_bins[bin[k]] + rank[k]] = (int32_t)(base + k * 256 + threadIdx.x);
 }
 
 // ---------------------------------------------------------------- the network
@@ -467,7 +517,7 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
     int32_t *tiles = reinterpret_cast<int32_t *>(m->scratch + o_tiles), *order = reinterpret_cast<int32_t *>(m->scratch + o_order);
 
     if ((rc = check_hip(hipMemsetAsync(counts, 0, kMaxClusters * 4, stream), "memset"))) return rc;
-    const unsigned nb = (unsigned)((n + 255) / 256);
+    const unsigned nb = (unsigned)((n + kSortRows - 1) / kSortRows);
     hipLaunchKernelGGL(mlp_histogram, dim3(nb), dim3(256), 0, stream, cluster_indices, n, S.n_clusters, counts, results, result_stride, S.out_dim);
     hipLaunchKernelGGL(mlp_plan, dim3(1), dim3(256), 0, stream, counts, S.n_clusters, seg_start, cursor, tiles, n_tiles);
     hipLaunchKernelGGL(mlp_scatter, dim3(nb), dim3(256), 0, stream, cluster_indices, n, S.n_clusters, cursor, order);
