@@ -1,8 +1,14 @@
 // mnv_render -- offline batch renderer: the reference's `nerf-viewer` command line without the window.
 //
 // Flag names and defaults follow the reference (src/opts.cpp:17-32 common flags, main.cpp:491-505
-// viewer flags); flags that only make sense for the interactive window or for guided sampling
-// (--model_path, --grid, -x, -n, -v, -y, -z) are accepted and ignored.  Added for batch use:
+// viewer flags); --grid (wireframe overlay) is accepted and ignored.  --model_path names a model container
+// (an .npz, see VolumeRenderer::load_model) and enables the refinement flags, which the reference exposes as
+// window check boxes (main.cpp:270-300) rather than flags:
+//   --use_splitting          grow / resample / prune the tree from the per-ray trackers while rendering
+//   --use_guided_sampling    composite per-sample network outputs instead of the tree's colours
+//   --max_depth D  --max_sample_count C  --seed S
+//   --save_tree FILE.npz     write the refined tree after the last frame
+// Added for batch use:
 //   --out PREFIX     write PREFIX_%04d.ppm (RGB from the RGBA8 output) per frame
 //   --raw            also write PREFIX_%04d.f32 (float RGBA, row-major, little endian)
 //   --frames N       render N frames; with --orbit DEG the camera is rotated about --origin around
@@ -50,7 +56,7 @@ Args parse(int argc, char **argv) {
         {"s", "step_size"}, {"e", "stop_thresh"}, {"a", "sigma_thresh"}, {"c", "max_tree_capacity"}, {"x", "split_batch_size"},
         {"n", "nerf_batch_size"}, {"v", "samples_per_voxel"}, {"b", "bounds_only"}, {"y", "appearance_embedding"},
         {"z", "max_guided_samples"}, {"w", "width"}, {"h", "height"}};
-    static const char *flags[] = {"bounds_only", "raw", "help"};
+    static const char *flags[] = {"bounds_only", "raw", "help", "use_splitting", "use_guided_sampling"};
     Args a;
     for (int i = 1; i < argc; ++i) {
         std::string t = argv[i];
@@ -78,7 +84,10 @@ Args parse(int argc, char **argv) {
 void usage() {
     std::puts("usage: mnv_render npz_file [--bg 0.0] [-s step_size] [-e stop_thresh] [-a sigma_thresh] [-c max_tree_capacity]\n"
               "                  [-w width] [-h height] [--fx 1111] [--fy -1] [--cx -1] [--cy -1] [--center x,y,z] [--back x,y,z]\n"
-              "                  [--origin x,y,z] [--world_up x,y,z] [-b] [--out PREFIX] [--raw] [--frames N] [--orbit DEG] [--gpu ID]");
+              "                  [--origin x,y,z] [--world_up x,y,z] [-b] [--out PREFIX] [--raw] [--frames N] [--orbit DEG] [--gpu ID]\n"
+              "                  [--model_path MODEL.npz [--use_splitting] [--use_guided_sampling] [-x split_batch_size] [-v samples_per_voxel]\n"
+              "                   [-y appearance_embedding] [-z max_guided_samples] [--max_depth D] [--max_sample_count C] [--seed S]\n"
+              "                   [--save_tree FILE.npz]]");
 }
 
 // rotate v about unit axis k by angle (Rodrigues), double precision
@@ -132,8 +141,19 @@ int main(int argc, char **argv) {
         rend.camera.origin = {origin[0], origin[1], origin[2]};
         rend.camera.v_world_up = {up[0], up[1], up[2]};
 
-        if (tree.N > 0) rend.set(tree, std::max<long>(tree.capacity, std::min<long>(args.l("max_tree_capacity", 20000000), tree.capacity)));
+        const bool refine = args.has("model_path") && (args.has("use_splitting") || args.has("use_guided_sampling"));
+        // the reference reserves max_tree_capacity (default 20M chunks) up front; without refinement the tree cannot grow
+        const long max_capacity = refine ? std::max<long>(tree.capacity, args.l("max_tree_capacity", 20000000)) : tree.capacity;
+        if (tree.N > 0) rend.set(tree, max_capacity);
         rend.resize(width, height);
+        if (args.has("model_path")) {  // main.cpp:585-589
+            rend.load_model(args.get("model_path", ""));
+            rend.options.use_splitting = args.has("use_splitting");
+            rend.options.use_guided_sampling = args.has("use_guided_sampling");
+            rend.options.max_depth = (int)args.l("max_depth", rend.options.max_depth);
+            rend.options.max_sample_count = (int)args.l("max_sample_count", rend.options.max_sample_count);
+            rend.seed = (uint64_t)args.l("seed", 0);
+        }
 
         const long frames = args.l("frames", 1);
         const double orbit = args.f("orbit", 0.f) * M_PI / 180.0;
@@ -146,6 +166,15 @@ int main(int argc, char **argv) {
         mnv_set_timing(1);
         for (long f = 0; f < frames; ++f) {
             rend.render();
+            if (refine) {
+                const auto &st = rend.stats;
+                std::printf("frame %ld: capacity %ld", f, st.capacity);
+                if (st.split_candidates || st.added) std::printf("  split candidates %d, added %d%s", st.split_candidates, st.added, st.full ? " (full)" : "");
+                if (st.sample_candidates) std::printf("  sample candidates %d, resampled %d", st.sample_candidates, st.resampled);
+                if (st.pruned) std::printf("  pruned %d", st.pruned > 0 ? st.pruned : 0);
+                if (st.guided_samples) std::printf("  guided samples %ld", st.guided_samples);
+                std::printf("\n");
+            }
             if (!out.empty()) {
                 rend.download(args.has("raw") ? &rgba : nullptr, &rgba8);
                 char name[4096];
@@ -175,6 +204,10 @@ int main(int argc, char **argv) {
             }
         }
         rend.download(nullptr, nullptr);
+        if (args.has("save_tree") && tree.N > 0) {
+            rend.sync_tree();
+            tree.save_npz(args.get("save_tree", ""));
+        }
         const double ms = rend.take_average_ms();
         std::printf("%s: %ld frame(s) %dx%d, %.3f ms/frame on the device, %.1f Mrays/s\n", rend.get_backend(), frames, width, height, ms,
                     ms > 0 ? (double)width * height / ms / 1e3 : 0.0);

@@ -60,3 +60,52 @@ def test_mnv_render_cli_errors(tmp_path, mnv, torch_gpu):
     assert r.returncode == 0, r.stderr
     f = np.fromfile(out + "_0000.f32", dtype=np.float32).reshape(8, 16, 4)
     assert np.all(f[..., :3] == 0.5) and np.all(f[..., 3] == 0)
+
+
+def test_mnv_render_cli_refinement(mnv, torch_gpu, tmp_path):
+    """--model_path + --use_splitting: the CLI runs the same refinement loop as the mnv_renderer_* API (same seed ->
+    the same refined tree, written by --save_tree)."""
+    import mlp_cases
+    from test_renderer_refine_gpu import check_tree_links, make_grid
+    spec = cases.CASES["rgba_d5"]
+    tree = cases.make_tree(mnv, spec["tree"])
+    cap0, dd = tree.capacity, tree.host_view().data_dim
+    npz = str(tmp_path / "scene.npz")
+    tree.save_npz(npz)
+    desc = mnv.mlp_desc(n_clusters=6, pos_octaves=4, hidden_width=64, hidden_layers=2, out_dim=dd + 1)
+    params = mlp_cases.make_params(mnv, desc, seed=21)
+    g = make_grid(mnv)
+    model = str(tmp_path / "model.npz")
+    np.savez(model, mlp_desc=np.array([6, 4, 2, 0, 0, 0, 64, 2, dd + 1], np.int32), mlp_center=np.zeros(3, np.float32),
+             mlp_inv_extent=np.ones(3, np.float32), mlp_params=params, grid_dim=np.array(list(g.grid_dim), np.int64),
+             min_position=np.array(list(g.min_position), np.float32),
+             max_position=np.array([g.min_position[i] + g.range[i] for i in range(3)], np.float32))
+    refined = str(tmp_path / "refined.npz")
+    w = h = 192
+    cmd = [EXE, npz, "-w", str(w), "-h", str(h), "--fx", "900", "--bg", "1.0", "--center", "-3.55,0,3.55", "--model_path", model, "--use_splitting",
+           "-x", "64", "-v", "4", "--max_depth", "7", "--max_sample_count", "64", "--seed", "5", "-c", str(cap0 + 2000), "--frames", "3",
+           "--save_tree", refined]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "frame 0: capacity" in r.stdout and "added" in r.stdout
+    out_tree = mnv.N3Tree.open(refined)
+    data, child, parent = out_tree.host_arrays()
+    assert out_tree.capacity > cap0
+    check_tree_links(child, parent, out_tree.capacity)
+
+    rr = mnv.Renderer()
+    rr.resize(w, h)
+    tree2 = cases.make_tree(mnv, spec["tree"])
+    rr.set(tree2, cap0 + 2000)
+    rr.set_model(desc, params, g)
+    rr.set_camera((-3.55, 0.0, 3.55), (-0.7071068, 0.0, 0.7071068), fx=900.0)
+    rr.set_seed(5)
+    o = rr.options
+    o.background_brightness, o.step_size, o.stop_thresh, o.sigma_thresh = 1.0, 1e-4, 1e-2, 1e-2
+    o.use_splitting, o.split_batch_size, o.samples_per_corner, o.max_depth, o.max_sample_count = True, 64, 4, 7, 64
+    for _ in range(3):
+        st = rr.render()
+    rr.sync_tree()
+    d2, c2, p2 = tree2.host_arrays()
+    assert st["capacity"] == out_tree.capacity
+    assert np.array_equal(c2, child) and np.array_equal(p2, parent) and np.array_equal(d2, data)
