@@ -69,10 +69,14 @@ def main():
     ap.add_argument("--kernel", choices=["accel", "ref_layout"], default="accel")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend for N > 1; gloo (host-staged gather, all ranks may share one GPU) is the single-GPU rehearsal of the multi-GPU path")
-    ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2",
-                    help="cfg2 = BASELINE.json's headline config (default); cfg3 = merged-Mega-NeRF stand-in (anisotropic terrain, 2.7 M chunks)")
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4"], default="cfg2",
+                    help="cfg2 = BASELINE.json's headline config (default); cfg3 = merged-Mega-NeRF stand-in (anisotropic terrain, 2.7 M chunks); "
+                         "cfg4 = cfg3 at 3840x2160 (configs[3], meant for --gpus 8)")
     ap.add_argument("--per-frame", action="store_true", help="one launch per pose instead of one batched launch per step")
     args = ap.parse_args()
+    global W, H
+    if args.workload == "cfg4":
+        W, H = 3840, 2160
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -104,8 +108,8 @@ def main():
         workload = "cfg2: depth-10 SH9 shell N3Tree (1,499,569 chunks), 1920x1080, 16-pose orbit per step"
     else:
         tree = cases.make_tree(mnv, cases.CFG3_TREE)
-        cams = [cases.cfg3_camera(mnv, pose, W, H) for pose in range(N_POSES)]
-        workload = f"cfg3: depth-10 SH9 anisotropic 4x2-brick terrain N3Tree ({tree.capacity:,} chunks), 1920x1080, 16 oblique poses per step"
+        cams = [cases.cfg3_camera(mnv, pose, W, H, fx=1400.0 * W / 1920) for pose in range(N_POSES)]
+        workload = f"{args.workload}: depth-10 SH9 anisotropic 4x2-brick terrain N3Tree ({tree.capacity:,} chunks), {W}x{H}, 16 oblique poses per step"
     tree.move_to_device()
     opt = mnv.RenderOptions.cli_defaults()
     setup_s = time.time() - t_setup
@@ -253,7 +257,7 @@ def main():
                 traffic = tj["hbm_bytes_per_launch"]   # PMC counters cannot be read from inside this process
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "kernel": "march_accel_kernel<9,256,false>" if args.kernel == "accel" else "march_ref_layout_kernel<9>",
+                    "kernel": "march_accel_kernel<9,256,0>" if args.kernel == "accel" else "march_ref_layout_kernel<9>",
                     "frames_per_launch": frames_per_launch,
                     "avg_launch_ms": round(avg_ms, 5), "launches": launches,
                     "algorithmic_bytes_per_launch": int(per_launch)}

@@ -170,6 +170,15 @@ int mnv_render_voxels_accel_part(const mnv_accel *accel, const mnv_camera *cam, 
                                  void *hip_stream);
 
 /*
+ * The un-permute step on the gathering rank: `gathered` is what the RCCL gather of the ranks'
+ * compact buffers produces, [world][n_frames][ceil(macro tiles / world)][tile_h][tile_w] pixels (n_frames = 1 for
+ * mnv_render_voxels_accel_part), `frames` receives [n_frames][height][width] pixels.  bytes_per_pixel: 4 (RGBA8) or
+ * 16 (float RGBA).  part.rank is ignored.
+ */
+int mnv_assemble_tiles(const void *gathered, void *frames, int32_t width, int32_t height, mnv_partition part, int32_t n_frames,
+                       int32_t bytes_per_pixel, void *hip_stream);
+
+/*
  * Several frames in ONE launch: cams[0 .. n_cams) (same image size, same options, same tile /
  * partition); frame f is written at rgba_out + f * frame_elems * 4 (frame_elems = tile.w * tile.h, or
  * ceil(macro_tiles / world) * tile_w * tile_h under a partition -- the same on every rank, so that

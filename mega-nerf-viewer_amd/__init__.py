@@ -194,6 +194,7 @@ _SIGNATURES = {
     "mnv_partition_local_tiles": (C.c_int32, [Rect, Partition]),
     "mnv_render_voxels_accel_part": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, Partition,
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mnv_assemble_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, Partition, C.c_int32, C.c_int32, C.c_void_p]),
     "mnv_render_voxels_accel_batch": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.c_int32, C.POINTER(RenderOptions), Rect,
                                                 Partition, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_render_voxels_accel_track": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
@@ -481,6 +482,13 @@ def render_voxels_accel_track(accel: int, cam: Camera, opt: RenderOptions, tile=
     _check(lib().mnv_render_voxels_accel_track(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba),
                                                _ptr(rgba8), _ptr(split_track), _ptr(sample_track), _ptr(sample_counts),
                                                C.c_void_p(stream)))
+
+
+def assemble_tiles(gathered, frames, width: int, height: int, world: int, tile_w: int, tile_h: int, n_frames: int = 1, stream: int = 0) -> None:
+    """Rank 0's un-permute of the gathered tile buffers into frames (device tensors, RGBA8 or float RGBA)."""
+    bpp = gathered.element_size() * 4
+    _check(lib().mnv_assemble_tiles(_ptr(gathered), _ptr(frames), width, height, Partition(0, world, tile_w, tile_h), n_frames, bpp,
+                                    C.c_void_p(stream)))
 
 
 def partition_local_tiles(tile, rank: int, world: int, tile_w: int, tile_h: int) -> int:

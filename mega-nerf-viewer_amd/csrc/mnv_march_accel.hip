@@ -561,6 +561,23 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
     }
 }
 
+// Rank 0 after the gather: macro tile m of frame f sits at gathered[m % world][f][m / world];
+// one thread per pixel, the destination is written row-major (coalesced), the source is read in tile rows.
+template <typename PIXEL>
+__global__ void assemble_tiles_kernel(const PIXEL *__restrict__ gathered, PIXEL *__restrict__ frames, int32_t width, int32_t height,
+                                      int32_t tile_w, int32_t tile_h, int32_t macros_x, int32_t j_max, int32_t world, int32_t n_frames) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per_frame = (int64_t)width * height;
+    if (idx >= per_frame * n_frames) return;
+    const int32_t f = (int32_t)(idx / per_frame);
+    const int32_t p = (int32_t)(idx - (int64_t)f * per_frame);
+    const int32_t y = p / width, x = p - y * width;
+    const int32_t mx = x / tile_w, my = y / tile_h;
+    const int32_t m = my * macros_x + mx, r = m % world, j = m / world;
+    const int64_t src = ((((int64_t)r * n_frames + f) * j_max + j) * tile_h + (y - my * tile_h)) * tile_w + (x - mx * tile_w);
+    frames[idx] = gathered[src];
+}
+
 // ---------------------------------------------------------------------------- host side
 
 static int row_bytes_for(int basis) { return row_bytes_pow2(basis); }
@@ -849,6 +866,26 @@ void mnv_accel_destroy(mnv_accel *a) {
 size_t mnv_accel_device_bytes(const mnv_accel *a) { return a ? a->bytes : 0; }
 
 int32_t mnv_partition_local_tiles(mnv_rect tile, mnv_partition part) { return partition_local_tiles(tile, part); }
+
+int mnv_assemble_tiles(const void *gathered, void *frames, int32_t width, int32_t height, mnv_partition part, int32_t n_frames,
+                       int32_t bytes_per_pixel, void *hip_stream) {
+    if (!gathered || !frames || width < 1 || height < 1 || n_frames < 1 || part.world < 1 || part.tile_w < 8 || part.tile_h < 8 ||
+        part.tile_w % 8 || part.tile_h % 8)
+        return set_error(MNV_E_INVALID, "invalid tile-assembly arguments");
+    if (bytes_per_pixel != 4 && bytes_per_pixel != 16) return set_error(MNV_E_UNSUPPORTED, "pixels are RGBA8 (4 bytes) or float RGBA (16 bytes)");
+    const int32_t macros_x = (width + part.tile_w - 1) / part.tile_w, macros_y = (height + part.tile_h - 1) / part.tile_h;
+    const int32_t j_max = (macros_x * macros_y + part.world - 1) / part.world;
+    const int64_t n = (int64_t)width * height * n_frames;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (bytes_per_pixel == 4)
+        hipLaunchKernelGGL(assemble_tiles_kernel<uint32_t>, grid, block, 0, stream, static_cast<const uint32_t *>(gathered), static_cast<uint32_t *>(frames),
+                           width, height, part.tile_w, part.tile_h, macros_x, j_max, part.world, n_frames);
+    else
+        hipLaunchKernelGGL(assemble_tiles_kernel<uint4>, grid, block, 0, stream, static_cast<const uint4 *>(gathered), static_cast<uint4 *>(frames), width,
+                           height, part.tile_w, part.tile_h, macros_x, j_max, part.world, n_frames);
+    return check_hip(hipGetLastError(), "assemble_tiles_kernel");
+}
 
 int mnv_render_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,
                             mnv_rect tile, float *rgba_out, uint8_t *rgba8_out, void *hip_stream) {

@@ -51,6 +51,13 @@ class TilePartition:
         gathered [world, F, j_max, tile_h, tile_w, C] -> frames [F, height, width, C]."""
         c = gathered.shape[-1]
         batched = gathered.dim() == 6
+        if (gathered.is_cuda and out is not None and out.is_cuda and c == 4 and gathered.is_contiguous() and out.is_contiguous()
+                and gathered.dtype == out.dtype and gathered.dtype in (torch.uint8, torch.float32)):
+            # one pass over the pixels in libmnv (mnv_assemble_tiles) instead of index_select + permute + copy
+            from . import assemble_tiles
+            assemble_tiles(gathered, out, self.width, self.height, self.world, self.tile_w, self.tile_h,
+                           n_frames=gathered.shape[1] if batched else 1, stream=torch.cuda.current_stream(gathered.device).cuda_stream)
+            return out
         g = gathered if batched else gathered.unsqueeze(1)
         f = g.shape[1]
         t = g.permute(1, 0, 2, 3, 4, 5).reshape(f, self.world * self.j_max, self.tile_h, self.tile_w, c)

@@ -403,3 +403,20 @@ def test_extreme_opacity_exercises_expf_tails(mnv, orc, torch_gpu, step):
     for which in ("ref_layout", "accel"):
         got, _ = _render_gpu(mnv, torch_gpu, tree, cam, opt, which)
         assert np.array_equal(cases.bits(got), cases.bits(ref["rgba"])), (step, which, float(np.abs(got - ref["rgba"]).max()))
+
+
+@pytest.mark.parametrize("world,w,h,frames", [(3, 1920, 1080, 2), (8, 1000, 700, 0), (2, 136, 128, 3), (5, 3840, 2160, 1)])
+def test_assemble_tiles_kernel_equals_index_permutation(mnv, torch_gpu, world, w, h, frames):
+    """mnv_assemble_tiles (rank 0's un-permute after the gather) against the torch index_select / permute form of
+    TilePartition.unpermute, RGBA8 and float RGBA, with and without the frame dimension, ragged tile counts."""
+    torch = torch_gpu
+    from mega_nerf_viewer_amd.multigpu import TilePartition
+    part = TilePartition(w, h, world, 128, 120)
+    lead = (frames,) if frames else ()
+    for dt in (torch.uint8, torch.float32):
+        g = torch.randint(0, 255, (world,) + lead + (part.j_max, 120, 128, 4), device="cuda").to(dt)
+        want = part.unpermute(g)  # torch path (out=None)
+        out = torch.zeros(lead + (h, w, 4), dtype=dt, device="cuda")
+        got = part.unpermute(g, out=out)
+        torch.cuda.synchronize()
+        assert got is out and torch.equal(out, want)
