@@ -92,6 +92,53 @@ def main():
     new_cap, n_del = mnv.prune_tree(edit, d_data, dd, None, marks, cap)
     torch.cuda.synchronize()
     out["prune_cfg2"] = {"ms": (time.perf_counter() - t0) * 1e3, "capacity": cap, "new_capacity": new_cap, "deleted": n_del}
+    del d_child, d_parent, d_data, marks, visited, rgba, tree
+    torch.cuda.empty_cache()
+
+    # whole frames through the VolumeRenderer loop on the cfg2 tree at 1920x1080 (wall time per render(), device idle at both ends)
+    def renderer(**opts):
+        t = cases.make_tree(mnv, cases.CFG2_TREE)
+        desc = mnv.mlp_desc(n_clusters=8, pos_octaves=10, hidden_width=64, hidden_layers=2, out_dim=t.host_view().data_dim + 1)
+        r = mnv.Renderer()
+        r.resize(1920, 1080)
+        r.set(t, t.capacity + 400_000)
+        g = mnv.ClusterGrid()
+        g.grid_dim[0], g.grid_dim[1] = 4, 2
+        for i in range(3):
+            g.min_position[i], g.range[i] = -1.0, 2.0
+        r.set_model(desc, mlp_cases.make_params(mnv, desc, seed=4), g)
+        o = r.options
+        o.background_brightness, o.step_size, o.stop_thresh, o.sigma_thresh = 0.0, 1e-4, 1e-2, 1e-2
+        o.split_batch_size, o.samples_per_corner, o.max_guided_samples = 4096, 8, 128
+        for k, v_ in opts.items():
+            setattr(o, k, v_)
+        return r, t
+
+    def frames(r, n, move=True):
+        log = []
+        for f in range(n):
+            if move:
+                az = np.deg2rad(22.5 * f)
+                el = np.deg2rad(20.0)
+                c = np.array([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)])
+                r.set_camera(tuple(2.6 * c), tuple(c), fx=1600.0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st = r.render()
+            r.download()  # waits for the frame (copies 41 MB to the host: ~2 ms of the figure)
+            st["ms"] = (time.perf_counter() - t0) * 1e3
+            log.append(st)
+        return log
+
+    r, t = renderer()
+    out["renderer_plain_frames"] = [round(s["ms"], 3) for s in frames(r, 4)]
+    del r, t
+    r, t = renderer(use_splitting=True, max_depth=11, max_sample_count=64)
+    out["renderer_splitting_frames"] = [{k: (round(v, 3) if k == "ms" else v) for k, v in s.items() if k in ("ms", "added", "resampled", "used_accel", "capacity", "split_candidates")}
+                                        for s in frames(r, 6)]
+    del r, t
+    r, t = renderer(use_guided_sampling=True, max_guided_samples=32)
+    out["renderer_guided_frames"] = [{k: (round(v, 3) if k == "ms" else v) for k, v in s.items() if k in ("ms", "guided_samples")} for s in frames(r, 3)]
     print(json.dumps(out, indent=1))
 
 
