@@ -37,6 +37,7 @@ import torch.distributed as dist  # noqa: E402
 
 W, H, FX = 1920, 1080, 1600.0
 N_POSES = 16
+N_FRAMES = 16  # frames per step: N_POSES x --laps
 MACRO_W, MACRO_H = 128, 120          # 15 x 9 = 135 macro tiles; 15 is odd -> diagonal rank pattern
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8.0 TB/s spec
 COUNTERS_JSON = os.path.join(ROOT, "tests", "golden", "cfg2_counters.json")
@@ -73,10 +74,14 @@ def main():
                     help="cfg2 = BASELINE.json's headline config (default); cfg3 = merged-Mega-NeRF stand-in (anisotropic terrain, 2.7 M chunks); "
                          "cfg4 = cfg3 at 3840x2160 (configs[3], meant for --gpus 8)")
     ap.add_argument("--per-frame", action="store_true", help="one launch per pose instead of one batched launch per step")
+    ap.add_argument("--laps", type=int, default=4, help="the step walks the 16-pose orbit this many times (16 x laps frames in one launch, <= 64)")
     args = ap.parse_args()
-    global W, H
+    global W, H, N_FRAMES
     if args.workload == "cfg4":
         W, H = 3840, 2160
+    if not 1 <= args.laps <= 4:
+        raise SystemExit("--laps must be 1 .. 4 (MNV_MAX_BATCH = 64 frames per launch)")
+    N_FRAMES = N_POSES * args.laps
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -104,11 +109,11 @@ def main():
     t_setup = time.time()
     if args.workload == "cfg2":
         tree = cases.make_tree(mnv, cases.CFG2_TREE)
-        cams = [cases.cfg2_camera(mnv, pose, W, H, FX) for pose in range(N_POSES)]
-        workload = "cfg2: depth-10 SH9 shell N3Tree (1,499,569 chunks), 1920x1080, 16-pose orbit per step"
+        cams = [cases.cfg2_camera(mnv, pose % N_POSES, W, H, FX) for pose in range(N_FRAMES)]
+        workload = "cfg2: depth-10 SH9 shell N3Tree (1,499,569 chunks), 1920x1080, 16-pose orbit per step" + (f" x {args.laps} laps" if args.laps > 1 else "")
     else:
         tree = cases.make_tree(mnv, cases.CFG3_TREE)
-        cams = [cases.cfg3_camera(mnv, pose, W, H, fx=1400.0 * W / 1920) for pose in range(N_POSES)]
+        cams = [cases.cfg3_camera(mnv, pose % N_POSES, W, H, fx=1400.0 * W / 1920) for pose in range(N_FRAMES)]
         workload = f"{args.workload}: depth-10 SH9 anisotropic 4x2-brick terrain N3Tree ({tree.capacity:,} chunks), {W}x{H}, 16 oblique poses per step"
     tree.move_to_device()
     opt = mnv.RenderOptions.cli_defaults()
@@ -118,7 +123,7 @@ def main():
     RING = 2
     if world == 1:
         # one launch per step: the 16 poses as a batch (frame f at frames[slot][f])
-        frames = [torch.empty((N_POSES, H, W, 4), dtype=torch.float32, device=dev) for _ in range(RING)]
+        frames = [torch.empty((N_FRAMES, H, W, 4), dtype=torch.float32, device=dev) for _ in range(RING)]
         dv = tree.device_view() if args.kernel == "ref_layout" else None
         counter = [0]
 
@@ -128,7 +133,7 @@ def main():
             if args.kernel == "accel" and not args.per_frame:
                 mnv.render_voxels_accel_batch(tree.accel, cams, opt, rgba=frames[slot], stream=stream)
             else:
-                for i in range(N_POSES):
+                for i in range(N_FRAMES):
                     render_pose(i, frames[slot][i])
 
         def render_pose(i, out):
@@ -144,7 +149,7 @@ def main():
         assert n_local == mnv.partition_local_tiles((0, 0, W, H), rank, world, MACRO_W, MACRO_H)
         dt = torch.float32 if args.gather == "f32" else torch.uint8
         # one launch + one gather per step; the gather of step k overlaps the launch of step k + 1
-        tg = TileGatherer(part, rank, dev, dtype=dt, depth=RING, frames=N_POSES, stage_on_host=args.backend == "gloo")
+        tg = TileGatherer(part, rank, dev, dtype=dt, depth=RING, frames=N_FRAMES, stage_on_host=args.backend == "gloo")
         frames = tg._frames if rank == 0 else None
         counter = [0]
 
@@ -193,7 +198,7 @@ def main():
     if world > 1:
         elapsed = all_max(elapsed)
 
-    rays_per_step = N_POSES * W * H
+    rays_per_step = N_FRAMES * W * H
     value = rays_per_step * args.steps / elapsed / 1e6
 
     # ---- roofline of the dominant kernel (the march): algorithmic bytes per launch / launch time
@@ -246,7 +251,7 @@ def main():
     if counters is not None and launches > 0:
         poses = counters["poses"]
         mean_bytes = float(np.mean([alg_bytes(c) for c in poses.values()]))
-        frames_per_launch = 1 if (args.per_frame or args.kernel != "accel") and world == 1 else N_POSES
+        frames_per_launch = 1 if (args.per_frame or args.kernel != "accel") and world == 1 else N_FRAMES
         per_launch = mean_bytes * frames_per_launch / world   # each rank's launch covers 1/world of its frames
         avg_ms = kern_ms / launches
         achieved = per_launch / (avg_ms * 1e-3) / 1e9
@@ -277,7 +282,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": workload,
-                       "rays_per_step": rays_per_step, "kernel": args.kernel, "launches_per_step": 1 if not args.per_frame and args.kernel == "accel" else N_POSES,
+                       "rays_per_step": rays_per_step, "kernel": args.kernel, "launches_per_step": 1 if not args.per_frame and args.kernel == "accel" else N_FRAMES,
                        "partition": "none" if world == 1 else f"interleaved {MACRO_W}x{MACRO_H} macro tiles, {args.gather} RCCL gather to rank 0"},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

@@ -25,7 +25,7 @@ def _port():
 @pytest.mark.parametrize("world,gather", [(2, "f32"), (3, "u8")])
 def test_bench_multirank_rehearsal(torch_gpu, world, gather):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1", "--laps", "1",
            "--backend", "gloo", "--gather", gather]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
