@@ -50,6 +50,25 @@ def render_npz(npz_path, cam_struct, opt_struct, n_probe=4096, contract=False):
     return dict(rgba=rgba, data_probe=dp, child_probe=cp, parent_probe=pp, meta=list(meta))
 
 
+def render_track_npz(npz_path, cam_struct, opt_struct, capacity, sample_counts=None, track_visit=True):
+    """The reference's march with its trackers: dict(rgba [h,w,4], split [h,w,3], sample [h,w,3], visited [capacity])."""
+    h = lib()
+    w, ht = cam_struct.width, cam_struct.height
+    rgba = np.empty((ht, w, 4), np.float32)
+    split, sample = np.empty((ht, w, 3), np.float32), np.empty((ht, w, 3), np.float32)
+    visited = np.zeros(capacity, np.int32)
+    sc = None if sample_counts is None else np.ascontiguousarray(sample_counts, np.int16)
+    h.ref_render_track_npz.restype = C.c_int
+    wd, hh, fx, fy, cx, cy, c2w = _cam_args(cam_struct)
+    rc = h.ref_render_track_npz(os.fsencode(npz_path), C.c_int(wd), C.c_int(hh), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), c2w,
+                                C.byref(opt_struct), C.c_int(C.sizeof(opt_struct)),
+                                C.c_void_p(sc.ctypes.data) if sc is not None else C.c_void_p(0), C.c_int(int(track_visit)), C.c_void_p(rgba.ctypes.data),
+                                C.c_void_p(split.ctypes.data), C.c_void_p(sample.ctypes.data), C.c_void_p(visited.ctypes.data))
+    if rc != 0:
+        raise RuntimeError(f"ref_render_track_npz failed with {rc}")
+    return dict(rgba=rgba, split=split, sample=sample, visited=visited)
+
+
 def _cam_args(cam_struct):
     return (cam_struct.width, cam_struct.height, cam_struct.fx, cam_struct.fy, cam_struct.cx, cam_struct.cy,
             (C.c_float * 12)(*list(cam_struct.c2w)))

@@ -202,6 +202,52 @@ int ref_render_npz(const char *npz_path, int width, int height, float fx, float 
     return 0;
 }
 
+// The reference's render_voxels_trace_ray with its refinement trackers and visit marks (rt_core.cuh:132-134,179-180,237-252,
+// 308-321) returned to the host.  sample_counts_host: [capacity][8] int16 uploaded into the tree's device array, or NULL for
+// all 8 (the reference leaves the device array uninitialised, n3tree.cpp:235-241).
+int ref_render_track_npz(const char *npz_path, int width, int height, float fx, float fy, float cx, float cy, const float *c2w12,
+                         const void *opt_bytes, int opt_size, const int16_t *sample_counts_host, int track_visit, float *rgba_host,
+                         float *split_host, float *sample_host, int32_t *visited_host) {
+    using namespace viewer;
+    if (opt_size != (int)sizeof(RenderOptions)) return -2;
+    RenderOptions opt;
+    memcpy(&opt, opt_bytes, sizeof(opt));
+    try {
+        N3Tree tree;
+        tree.open(npz_path);
+        if (tree.N == 0) return -3;
+        tree.move_to_device(tree.capacity, true, true);
+        if (sample_counts_host) {
+            torch::Tensor sc = torch::from_blob((void *)sample_counts_host, {(int64_t)tree.capacity, 8}, torch::kInt16).clone();
+            tree.sample_counts.copy_(sc);
+        } else {
+            tree.sample_counts.fill_(8);
+        }
+        CamPOD cam = {width, height, fx, fy, cx, cy, {}};
+        memcpy(cam.transform, c2w12, sizeof(cam.transform));
+        const int64_t n = (int64_t)width * height;
+        auto fopt = torch::TensorOptions().device(torch::kCUDA).dtype(torch::kFloat32);
+        torch::Tensor out = torch::zeros({n, 4}, fopt);
+        torch::Tensor to_split = torch::full({n, 3}, -1.f, fopt), to_sample = torch::full({n, 3}, -1.f, fopt);  // cuda_renderer.cpp:97-98
+        torch::Tensor visited = torch::zeros({tree.capacity}, torch::TensorOptions().device(torch::kCUDA).dtype(torch::kInt32));
+        const int threads = 512;
+        const int blocks = N_BLOCKS_NEEDED(n, threads);
+        hipLaunchKernelGGL(ref_render_voxels_kernel, dim3(blocks), dim3(threads), 0, 0, viewer::internal::TreeSpec(tree), cam, opt,
+                           out.data_ptr<float>(), to_split.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
+                           to_sample.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
+                           visited.packed_accessor32<int32_t, 1, torch::RestrictPtrTraits>(), track_visit != 0);
+        if (hipDeviceSynchronize() != hipSuccess) return -4;
+        memcpy(rgba_host, out.cpu().data_ptr<float>(), n * 4 * sizeof(float));
+        memcpy(split_host, to_split.cpu().data_ptr<float>(), n * 3 * sizeof(float));
+        memcpy(sample_host, to_sample.cpu().data_ptr<float>(), n * 3 * sizeof(float));
+        memcpy(visited_host, visited.cpu().data_ptr<int32_t>(), (size_t)tree.capacity * sizeof(int32_t));
+    } catch (const std::exception &e) {
+        fprintf(stderr, "ref_render_track_npz: %s\n", e.what());
+        return -1;
+    }
+    return 0;
+}
+
 // The reference's get_samples_trace_ray on the tree in `npz_path` (full frame, offscreen).
 int ref_get_samples_npz(const char *npz_path, int width, int height, float fx, float fy, float cx, float cy, const float *c2w12,
                         const void *opt_bytes, int opt_size, const int32_t *grid_dim2, const float *min_position3,

@@ -88,3 +88,33 @@ def test_guided_nerf_results_matches_reference_device_code(mnv, orc, case):
     tree, cam, opt, values, z, offsets = guided_cases.nerf_results_setup(mnv, case)
     o = orc.render_nerf_results(orc.tree_from_view(tree.host_view()), cam.c, opt, values, z, offsets)["rgba"]
     assert np.abs(o.astype(np.float64) - g["rgba"].astype(np.float64)).max() <= TOL
+
+
+# ---- refinement trackers and visit marks of the reference's own device code (tests/golden/make_tracker_goldens.py)
+TRACKER_CASES = sorted(f[len("ref_trackers_"):-4] for f in os.listdir(GOLD) if f.startswith("ref_trackers_"))
+
+
+def tracker_setup(mnv, name):
+    z = np.load(os.path.join(GOLD, f"ref_trackers_{name}.npz"))
+    spec = cases.CASES[name]
+    tree = cases.make_tree(mnv, spec["tree"])
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    opt.max_depth, opt.max_sample_count = int(z["max_depth"]), int(z["max_sample_count"])
+    cap = tree.host_view().capacity
+    counts = (np.random.default_rng(sum(map(ord, name))).integers(0, 14, size=(cap, 8)).astype(np.int16) if int(z["with_counts"])
+              else np.full((cap, 8), 8, np.int16))
+    return z, tree, cam, opt, counts
+
+
+@pytest.mark.parametrize("name", TRACKER_CASES)
+def test_oracle_trackers_match_reference_device_code(mnv, orc, name):
+    """A14 (rt_core.cuh:132-134,179-180,237-252,308-321): the oracle's tracker rows and visit marks equal what the
+    reference's render_voxels_trace_ray produced on gfx950, element for element."""
+    z, tree, cam, opt, counts = tracker_setup(mnv, name)
+    v = tree.host_view()
+    visited = np.zeros(v.capacity, np.int32)
+    o = orc.render(orc.tree_from_view(v, sample_counts=counts), cam.c, opt, want_trackers=True, visited=visited, track_visit=True)
+    assert np.array_equal(o["split"], z["split"]) and np.array_equal(o["sample"], z["sample"])
+    assert np.array_equal(visited, z["visited"])
+    assert (z["split"][..., 1] >= 0).any()

@@ -1,6 +1,8 @@
 """GPU parity tests proper: the HIP kernels, called through the C ABI, against the CPU oracle on
 the same seeded inputs.  Bar: BIT-EXACT float RGBA (north_star tolerance is 1e-4 per channel; the
 kernels reproduce the oracle's arithmetic specification exactly, so the tests ask for equality)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -420,3 +422,26 @@ def test_assemble_tiles_kernel_equals_index_permutation(mnv, torch_gpu, world, w
         got = part.unpermute(g, out=out)
         torch.cuda.synchronize()
         assert got is out and torch.equal(out, want)
+
+
+@pytest.mark.parametrize("name", sorted(f[len("ref_trackers_"):-4] for f in os.listdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+                                        if f.startswith("ref_trackers_")))
+def test_trackers_match_reference_device_code_goldens(mnv, torch_gpu, name):
+    """Both march kernels against the tracker rows / visit marks the reference's own device code wrote on gfx950."""
+    torch = torch_gpu
+    from test_goldens import tracker_setup
+    z, tree, cam, opt, counts = tracker_setup(mnv, name)
+    tree.move_to_device()
+    dv = tree.device_view()
+    sc = torch.from_numpy(counts).cuda()
+    dv.sample_counts = sc.data_ptr()
+    h, w = cam.height, cam.width
+    new = lambda: torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")  # noqa: E731
+    split, sample, visited = new(), new(), torch.zeros(dv.capacity, dtype=torch.int32, device="cuda")
+    mnv.render_voxels(dv, cam, opt, split_track=split, sample_track=sample, visited=visited, track_visit=True)
+    split2, sample2 = new(), new()
+    mnv.render_voxels_accel_track(tree.accel, cam, opt, split_track=split2, sample_track=sample2, sample_counts=sc)
+    torch.cuda.synchronize()
+    for got, want in ((split, "split"), (sample, "sample"), (split2, "split"), (sample2, "sample")):
+        assert np.array_equal(got.cpu().numpy(), z[want])
+    assert np.array_equal(visited.cpu().numpy(), z["visited"])
