@@ -29,7 +29,8 @@
  * this path.  The oracle is pinned against outputs of the
  * reference's own device code (include/cuda/rt_core.cuh) compiled for gfx950 by
  * the recipe in oracle/Makefile.ref into oracle/_ref/ and run on an MI355X; the
- * resulting vectors are committed under tests/golden/ (see tests/golden/README.md).
+ * resulting vectors are committed under tests/golden/ (see tests/golden/README.md): frames, the refinement trackers and
+ * visit marks (ref_trackers_*.npz), the guided-sampling pair and the three refinement kernels.
  */
 #ifndef MNV_ORACLE_H
 #define MNV_ORACLE_H
@@ -163,8 +164,10 @@ int orc_render_nerf_results(const orc_tree *tree, const orc_camera *cam, const o
 
 /*
  * Refinement kernels (src/cuda/renderer_kernel.cu:63-213), serial restatements.  NOTE: these three live
- * in renderer_kernel.cu, which cannot be built here (CUDA surface objects), so unlike the march and the
- * guided-sampling pair they are NOT pinned against a reference build: parity unpinned.
+ * in renderer_kernel.cu, which as a whole cannot be built for gfx950 (surf2Dread / surf2Dwrite); oracle/Makefile.ref
+ * cuts the block with these three kernels (renderer_kernel.cu:63-213, no surface calls) out of the reference file verbatim
+ * and builds it into oracle/_ref, and tests/golden/ref_refine_kernels.npz holds what they produced on gfx950: these
+ * restatements reproduce it bit for bit (tests/test_goldens.py).
  * child/parent are edited in place; samples holds the caller's uniform [0,1) numbers on entry.
  */
 int orc_add_children_and_generate_samples(int32_t *child, int32_t *parent, const float offset[3], const float scale[3],

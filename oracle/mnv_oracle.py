@@ -170,10 +170,17 @@ def _f3(v):
     return (C.c_float * 3)(*[float(x) for x in v])
 
 
+def _raw(*arrays):
+    """The C side reads raw memory: every array must be C-contiguous."""
+    for a in arrays:
+        assert a.flags["C_CONTIGUOUS"], "pass C-contiguous arrays (np.ascontiguousarray)"
+
+
 def add_children_and_generate_samples(child, parent, offset, scale, capacity, opt_struct, parent_nodes, samples, clusters, visited, grid_struct):
     """In-place on the numpy arrays (child int32 [max_cap,8], parent int32 [max_cap], samples float32, ...)."""
     opt = _copy_struct(OrcOptions(), opt_struct)
     grid = _copy_struct(OrcClusterGrid(), grid_struct)
+    _raw(child, parent, parent_nodes, samples, clusters, visited)
     rc = lib().orc_add_children_and_generate_samples(C.c_void_p(child.ctypes.data), C.c_void_p(parent.ctypes.data), _f3(offset), _f3(scale),
                                                      C.c_int32(capacity), C.byref(opt), C.c_void_p(parent_nodes.ctypes.data),
                                                      C.c_int32(parent_nodes.shape[0]), C.c_void_p(samples.ctypes.data), C.c_int32(samples.shape[-1]),
@@ -184,6 +191,7 @@ def add_children_and_generate_samples(child, parent, offset, scale, capacity, op
 def generate_samples(parent, offset, scale, opt_struct, nodes, samples, clusters, grid_struct):
     opt = _copy_struct(OrcOptions(), opt_struct)
     grid = _copy_struct(OrcClusterGrid(), grid_struct)
+    _raw(parent, nodes, samples, clusters)
     rc = lib().orc_generate_samples(C.c_void_p(parent.ctypes.data), _f3(offset), _f3(scale), C.byref(opt), C.c_void_p(nodes.ctypes.data),
                                     C.c_int32(nodes.shape[0]), C.c_void_p(samples.ctypes.data), C.c_int32(samples.shape[-1]),
                                     C.c_void_p(clusters.ctypes.data), C.byref(grid))
@@ -191,6 +199,7 @@ def generate_samples(parent, offset, scale, opt_struct, nodes, samples, clusters
 
 
 def adjust_parents_and_children(child, parent, capacity, first_shift_index, to_delete, index_shifts):
+    _raw(child, parent, to_delete, index_shifts)
     rc = lib().orc_adjust_parents_and_children(C.c_void_p(child.ctypes.data), C.c_void_p(parent.ctypes.data), C.c_int32(capacity),
                                                C.c_int32(first_shift_index), C.c_void_p(to_delete.ctypes.data), C.c_void_p(index_shifts.ctypes.data))
     assert rc == 0

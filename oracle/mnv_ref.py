@@ -108,3 +108,56 @@ def render_nerf_results_npz(npz_path, cam_struct, opt_struct, sample_values, z_v
     if rc != 0:
         raise RuntimeError(f"ref_render_nerf_results_npz failed with {rc}")
     return rgba
+
+
+def _grid_args(grid_struct):
+    return ((C.c_int32 * 2)(*list(grid_struct.grid_dim)), (C.c_float * 3)(*list(grid_struct.min_position)), (C.c_float * 3)(*list(grid_struct.range)))
+
+
+def add_children_npz(npz_path, opt_struct, max_capacity, parent_nodes, samples, visited, grid_struct):
+    """The reference's add_children_and_generate_samples_kernel.  samples [n*8][spc][dim] uniform numbers in; returns
+    dict(samples, clusters, visited, child [max_capacity][8], parent [max_capacity])."""
+    h = lib()
+    h.ref_add_children_npz.restype = C.c_int
+    parent_nodes = np.ascontiguousarray(parent_nodes, np.int32)
+    samples = np.ascontiguousarray(samples, np.float32).copy()
+    visited = np.ascontiguousarray(visited, np.int32).copy()
+    n = parent_nodes.shape[0]
+    clusters = np.empty(samples.shape[:2], np.int16)
+    child, parent = np.empty((max_capacity, 8), np.int32), np.empty(max_capacity, np.int32)
+    gd, mp, rg = _grid_args(grid_struct)
+    rc = h.ref_add_children_npz(os.fsencode(npz_path), C.byref(opt_struct), C.c_int(C.sizeof(opt_struct)), C.c_int(max_capacity),
+                                C.c_void_p(parent_nodes.ctypes.data), C.c_int(n), C.c_void_p(samples.ctypes.data), C.c_int(samples.shape[-1]),
+                                C.c_void_p(clusters.ctypes.data), C.c_void_p(visited.ctypes.data), gd, mp, rg, C.c_void_p(child.ctypes.data),
+                                C.c_void_p(parent.ctypes.data))
+    if rc != 0:
+        raise RuntimeError(f"ref_add_children_npz failed with {rc}")
+    return dict(samples=samples, clusters=clusters, visited=visited, child=child, parent=parent)
+
+
+def generate_samples_npz(npz_path, opt_struct, nodes, samples, grid_struct):
+    h = lib()
+    h.ref_generate_samples_npz.restype = C.c_int
+    nodes = np.ascontiguousarray(nodes, np.int32)
+    samples = np.ascontiguousarray(samples, np.float32).copy()
+    clusters = np.empty(samples.shape[:2], np.int16)
+    gd, mp, rg = _grid_args(grid_struct)
+    rc = h.ref_generate_samples_npz(os.fsencode(npz_path), C.byref(opt_struct), C.c_int(C.sizeof(opt_struct)), C.c_void_p(nodes.ctypes.data),
+                                    C.c_int(nodes.shape[0]), C.c_void_p(samples.ctypes.data), C.c_int(samples.shape[-1]),
+                                    C.c_void_p(clusters.ctypes.data), gd, mp, rg)
+    if rc != 0:
+        raise RuntimeError(f"ref_generate_samples_npz failed with {rc}")
+    return dict(samples=samples, clusters=clusters)
+
+
+def adjust_parents_npz(npz_path, capacity, first_shift_index, to_delete, index_shifts):
+    h = lib()
+    h.ref_adjust_parents_npz.restype = C.c_int
+    to_delete = np.ascontiguousarray(to_delete, np.uint8)
+    index_shifts = np.ascontiguousarray(index_shifts, np.int32)
+    child, parent = np.empty((capacity, 8), np.int32), np.empty(capacity, np.int32)
+    rc = h.ref_adjust_parents_npz(os.fsencode(npz_path), C.c_int(first_shift_index), C.c_void_p(to_delete.ctypes.data),
+                                  C.c_void_p(index_shifts.ctypes.data), C.c_void_p(child.ctypes.data), C.c_void_p(parent.ctypes.data))
+    if rc != 0:
+        raise RuntimeError(f"ref_adjust_parents_npz failed with {rc}")
+    return dict(child=child, parent=parent)

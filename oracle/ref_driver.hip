@@ -14,6 +14,11 @@
 // below follows :30-38 (screen2worlddir), :40-61 (rodrigues), :272-275, :282-288 and the
 // offscreen branch of composite_and_write (:224-229), and stores the four floats the reference
 // holds just before its u8 cast.
+//
+// The three refinement kernels (adjust_parents_and_children_kernel, add_children_and_generate_samples_kernel,
+// generate_samples_kernel with generate_samples_inner; renderer_kernel.cu:63-213) sit in that same file but touch no
+// surface: oracle/Makefile.ref cuts that contiguous block out of the reference file, verbatim, into the scratch
+// directory (refine_kernels.inc) and it is included below, so these run as the reference wrote them too.
 #include <hip/hip_runtime.h>
 
 #include "cuda/common.cuh"
@@ -24,6 +29,9 @@
 
 namespace viewer {
 // cuda_assert is defined in the reference's src/cuda/common.cu (compiled alongside)
+
+using internal::TreeSpec;
+#include "refine_kernels.inc"  // the reference's own text: renderer_kernel.cu, adjust_parents_and_children_kernel .. generate_samples_kernel
 
 namespace {
 
@@ -243,6 +251,112 @@ int ref_render_track_npz(const char *npz_path, int width, int height, float fx, 
         memcpy(visited_host, visited.cpu().data_ptr<int32_t>(), (size_t)tree.capacity * sizeof(int32_t));
     } catch (const std::exception &e) {
         fprintf(stderr, "ref_render_track_npz: %s\n", e.what());
+        return -1;
+    }
+    return 0;
+}
+
+// The reference's add_children_and_generate_samples_kernel (renderer_kernel.cu:170-198, launched as :487-510) on the tree in
+// `npz_path` moved to the device with room for max_capacity chunks.  samples: in = the caller's uniform numbers, out = sample
+// rows; child_out [max_capacity][8], parent_out [max_capacity], visited in/out [max_capacity].
+int ref_add_children_npz(const char *npz_path, const void *opt_bytes, int opt_size, int max_capacity, const int32_t *parent_nodes,
+                         int num_parents, float *samples, int samples_dim, int16_t *clusters, int32_t *visited,
+                         const int32_t *grid_dim2, const float *min_position3, const float *range3, int32_t *child_out,
+                         int32_t *parent_out) {
+    using namespace viewer;
+    if (opt_size != (int)sizeof(RenderOptions)) return -2;
+    RenderOptions opt;
+    memcpy(&opt, opt_bytes, sizeof(opt));
+    try {
+        N3Tree tree;
+        tree.open(npz_path);
+        if (tree.N == 0) return -3;
+        tree.move_to_device(max_capacity, true, true);
+        auto dev = torch::kCUDA;
+        const int64_t rows = (int64_t)num_parents * 8, spc = opt.samples_per_corner;
+        torch::Tensor pn = torch::from_blob((void *)parent_nodes, {(int64_t)num_parents, 2}, torch::kInt32).clone().to(dev);
+        torch::Tensor smp = torch::from_blob((void *)samples, {rows, spc, (int64_t)samples_dim}, torch::kFloat32).clone().to(dev);
+        torch::Tensor cl = torch::full({rows, spc}, -1, torch::TensorOptions().device(dev).dtype(torch::kInt16));
+        torch::Tensor vis = torch::from_blob((void *)visited, {(int64_t)max_capacity}, torch::kInt32).clone().to(dev);
+        torch::Tensor gd = torch::from_blob((void *)grid_dim2, {2}, torch::kInt32).clone().to(dev);
+        torch::Tensor mp = torch::from_blob((void *)min_position3, {3}, torch::kFloat32).clone().to(dev);
+        torch::Tensor rg = torch::from_blob((void *)range3, {3}, torch::kFloat32).clone().to(dev);
+        const int threads = 512, blocks = N_BLOCKS_NEEDED(rows, threads);
+        hipLaunchKernelGGL(add_children_and_generate_samples_kernel, dim3(blocks), dim3(threads), 0, 0, viewer::internal::TreeSpec(tree), opt,
+                           pn.packed_accessor32<int32_t, 2, torch::RestrictPtrTraits>(), smp.packed_accessor32<float, 3, torch::RestrictPtrTraits>(),
+                           cl.packed_accessor32<short, 2, torch::RestrictPtrTraits>(), vis.packed_accessor32<int32_t, 1, torch::RestrictPtrTraits>(),
+                           gd.packed_accessor32<int32_t, 1, torch::RestrictPtrTraits>(), mp.packed_accessor32<float, 1, torch::RestrictPtrTraits>(),
+                           rg.packed_accessor32<float, 1, torch::RestrictPtrTraits>(), num_parents);
+        if (hipDeviceSynchronize() != hipSuccess) return -4;
+        memcpy(samples, smp.cpu().data_ptr(), rows * spc * samples_dim * 4);
+        memcpy(clusters, cl.cpu().data_ptr(), rows * spc * 2);
+        memcpy(visited, vis.cpu().data_ptr(), (size_t)max_capacity * 4);
+        memcpy(child_out, tree.child.cpu().contiguous().data_ptr(), (size_t)max_capacity * 8 * 4);
+        memcpy(parent_out, tree.parent.cpu().contiguous().data_ptr(), (size_t)max_capacity * 4);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "ref_add_children_npz: %s\n", e.what());
+        return -1;
+    }
+    return 0;
+}
+
+// The reference's generate_samples_kernel (renderer_kernel.cu:200-213, launched as :512-534) for existing voxels nodes[i] = (chunk, child).
+int ref_generate_samples_npz(const char *npz_path, const void *opt_bytes, int opt_size, const int32_t *nodes, int num_items, float *samples,
+                             int samples_dim, int16_t *clusters, const int32_t *grid_dim2, const float *min_position3, const float *range3) {
+    using namespace viewer;
+    if (opt_size != (int)sizeof(RenderOptions)) return -2;
+    RenderOptions opt;
+    memcpy(&opt, opt_bytes, sizeof(opt));
+    try {
+        N3Tree tree;
+        tree.open(npz_path);
+        if (tree.N == 0) return -3;
+        tree.move_to_device(tree.capacity, true, true);
+        auto dev = torch::kCUDA;
+        const int64_t rows = num_items, spc = opt.samples_per_corner;
+        torch::Tensor nd = torch::from_blob((void *)nodes, {rows, 2}, torch::kInt32).clone().to(dev);
+        torch::Tensor smp = torch::from_blob((void *)samples, {rows, spc, (int64_t)samples_dim}, torch::kFloat32).clone().to(dev);
+        torch::Tensor cl = torch::full({rows, spc}, -1, torch::TensorOptions().device(dev).dtype(torch::kInt16));
+        torch::Tensor gd = torch::from_blob((void *)grid_dim2, {2}, torch::kInt32).clone().to(dev);
+        torch::Tensor mp = torch::from_blob((void *)min_position3, {3}, torch::kFloat32).clone().to(dev);
+        torch::Tensor rg = torch::from_blob((void *)range3, {3}, torch::kFloat32).clone().to(dev);
+        const int threads = 512, blocks = N_BLOCKS_NEEDED(rows, threads);
+        hipLaunchKernelGGL(generate_samples_kernel, dim3(blocks), dim3(threads), 0, 0, viewer::internal::TreeSpec(tree), opt,
+                           nd.packed_accessor32<int32_t, 2, torch::RestrictPtrTraits>(), smp.packed_accessor32<float, 3, torch::RestrictPtrTraits>(),
+                           cl.packed_accessor32<short, 2, torch::RestrictPtrTraits>(), gd.packed_accessor32<int32_t, 1, torch::RestrictPtrTraits>(),
+                           mp.packed_accessor32<float, 1, torch::RestrictPtrTraits>(), rg.packed_accessor32<float, 1, torch::RestrictPtrTraits>(),
+                           num_items);
+        if (hipDeviceSynchronize() != hipSuccess) return -4;
+        memcpy(samples, smp.cpu().data_ptr(), rows * spc * samples_dim * 4);
+        memcpy(clusters, cl.cpu().data_ptr(), rows * spc * 2);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "ref_generate_samples_npz: %s\n", e.what());
+        return -1;
+    }
+    return 0;
+}
+
+// The reference's adjust_parents_and_children_kernel (renderer_kernel.cu:63-86, launched as :536-549).
+int ref_adjust_parents_npz(const char *npz_path, int first_shift_index, const uint8_t *to_delete, const int32_t *index_shifts,
+                           int32_t *child_out, int32_t *parent_out) {
+    using namespace viewer;
+    try {
+        N3Tree tree;
+        tree.open(npz_path);
+        if (tree.N == 0) return -3;
+        const int64_t cap = tree.capacity;
+        tree.move_to_device(cap, true, true);
+        auto dev = torch::kCUDA;
+        torch::Tensor td = torch::from_blob((void *)to_delete, {cap}, torch::kUInt8).clone().to(torch::kBool).to(dev);
+        torch::Tensor sh = torch::from_blob((void *)index_shifts, {cap}, torch::kInt32).clone().to(dev);
+        const int threads = 512, blocks = N_BLOCKS_NEEDED(cap - first_shift_index, threads);
+        hipLaunchKernelGGL(adjust_parents_and_children_kernel, dim3(blocks), dim3(threads), 0, 0, viewer::internal::TreeSpec(tree), first_shift_index,
+                           td.packed_accessor32<bool, 1, torch::RestrictPtrTraits>(), sh.packed_accessor32<int32_t, 1, torch::RestrictPtrTraits>());
+        if (hipDeviceSynchronize() != hipSuccess) return -4;
+        memcpy(child_out, tree.child.cpu().contiguous().data_ptr(), (size_t)cap * 8 * 4);
+        memcpy(parent_out, tree.parent.cpu().contiguous().data_ptr(), (size_t)cap * 4);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "ref_adjust_parents_npz: %s\n", e.what());
         return -1;
     }
     return 0;

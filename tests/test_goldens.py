@@ -118,3 +118,38 @@ def test_oracle_trackers_match_reference_device_code(mnv, orc, name):
     assert np.array_equal(o["split"], z["split"]) and np.array_equal(o["sample"], z["sample"])
     assert np.array_equal(visited, z["visited"])
     assert (z["split"][..., 1] >= 0).any()
+
+
+# ---- the reference's own refinement kernels (renderer_kernel.cu:63-213; tests/golden/make_refine_kernel_goldens.py)
+def test_oracle_refinement_kernels_match_reference_code(mnv, orc):
+    import refine_kernel_cases as rk
+    z = np.load(os.path.join(GOLD, "ref_refine_kernels.npz"))
+    g = rk.grid(mnv)
+    for variant in rk.VARIANTS:
+        tree, opt, dim, parent_nodes, visited, samples = rk.add_children_inputs(mnv, variant)
+        v = tree.host_view()
+        _, child, parent = tree.host_arrays()
+        cap = tree.capacity
+        child_big = np.zeros((cap + rk.N_NEW, 8), np.int32)
+        child_big[:cap] = child
+        parent_big = np.zeros(cap + rk.N_NEW, np.int32)
+        parent_big[:cap] = parent
+        clusters = np.full(samples.shape[:2], -1, np.int16)
+        orc.add_children_and_generate_samples(child_big, parent_big, list(v.offset), list(v.scale), cap, opt, parent_nodes, samples, clusters, visited, g)
+        pre = f"add_children/{variant}/"
+        assert np.array_equal(child_big, z[pre + "child"]) and np.array_equal(parent_big, z[pre + "parent"]) and np.array_equal(visited, z[pre + "visited"])
+        assert np.array_equal(cases.bits(samples), cases.bits(z[pre + "samples"])) and np.array_equal(clusters, z[pre + "clusters"])
+
+        tree, opt, dim, nodes, samples = rk.generate_samples_inputs(mnv, variant)
+        v = tree.host_view()
+        _, _, parent = tree.host_arrays()
+        clusters = np.full(samples.shape[:2], -1, np.int16)
+        orc.generate_samples(parent, list(v.offset), list(v.scale), opt, nodes, samples, clusters, g)
+        pre = f"generate_samples/{variant}/"
+        assert np.array_equal(cases.bits(samples), cases.bits(z[pre + "samples"])) and np.array_equal(clusters, z[pre + "clusters"])
+    tree, to_delete, shifts = rk.adjust_inputs(mnv, orc)
+    _, child, parent = (a.copy() for a in tree.host_arrays())
+    orc.adjust_parents_and_children(child, parent, tree.capacity, 1, to_delete, shifts)
+    assert np.array_equal(child, z["adjust_parents/child"])
+    keep = to_delete == 0
+    assert np.array_equal(parent[keep], z["adjust_parents/parent"][keep])
