@@ -161,3 +161,16 @@ def adjust_parents_npz(npz_path, capacity, first_shift_index, to_delete, index_s
     if rc != 0:
         raise RuntimeError(f"ref_adjust_parents_npz failed with {rc}")
     return dict(child=child, parent=parent)
+
+
+def camera_pose(width, height, fx, fy, cx, cy, center, back, up, updates=1):
+    """The reference's Camera ctor + _update (src/camera.cpp:29-82, glm): -> (c2w float32 [12], (fx, fy, cx, cy))."""
+    h = lib()
+    h.ref_camera_pose.restype = C.c_int
+    out, intr = (C.c_float * 12)(), (C.c_float * 4)()
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
+    rc = h.ref_camera_pose(C.c_int(width), C.c_int(height), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), f3(center), f3(back),
+                           f3(up), C.c_int(updates), out, intr)
+    if rc != 0:
+        raise RuntimeError(f"ref_camera_pose failed with {rc}")
+    return np.array(list(out), np.float32), tuple(float(x) for x in intr)

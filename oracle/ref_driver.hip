@@ -8,19 +8,24 @@
 // through the reference's own N3Tree loader (src/n3tree/n3tree.cpp + 3rdparty/cnpy), its
 // TreeSpec (include/data_spec.hpp:25-50) and its RenderOptions (include/render_options.hpp).
 //
-// The only restated piece is the ~30-line per-pixel wrapper of render_voxels_kernel
-// (src/cuda/renderer_kernel.cu:243-292): that kernel writes through CUDA surface objects
-// (surf2Dwrite), which gfx950 has no hardware for, so it cannot be built as is.  The wrapper
-// below follows :30-38 (screen2worlddir), :40-61 (rodrigues), :272-275, :282-288 and the
-// offscreen branch of composite_and_write (:224-229), and stores the four floats the reference
+// The only restated piece is the body of the per-pixel kernels (render_voxels_kernel, renderer_kernel.cu:243-292, and its
+// two guided-sampling siblings): they write through CUDA surface objects (surf2Dwrite), which gfx950 has no hardware for,
+// so they cannot be built as they are.  The kernels below follow :272-275, :282-288 and the offscreen branch of
+// composite_and_write (:224-229), call the reference's own screen2worlddir (:30-38) and rodrigues (:40-61) on the
+// reference's own CameraSpec / Camera (include/data_spec.hpp:9-23, src/camera.cpp), and store the four floats the reference
 // holds just before its u8 cast.
 //
-// The three refinement kernels (adjust_parents_and_children_kernel, add_children_and_generate_samples_kernel,
-// generate_samples_kernel with generate_samples_inner; renderer_kernel.cu:63-213) sit in that same file but touch no
-// surface: oracle/Makefile.ref cuts that contiguous block out of the reference file, verbatim, into the scratch
-// directory (refine_kernels.inc) and it is included below, so these run as the reference wrote them too.
+// screen2worlddir, rodrigues and the three refinement kernels (adjust_parents_and_children_kernel,
+// add_children_and_generate_samples_kernel, generate_samples_kernel with generate_samples_inner; renderer_kernel.cu:30-213)
+// sit in that same file but touch no surface: oracle/Makefile.ref cuts that contiguous block out of the reference file,
+// verbatim, into the scratch directory (refine_kernels.inc) and it is included below, so these run as the reference wrote them.
 #include <hip/hip_runtime.h>
 
+#include <glm/gtc/type_ptr.hpp>
+
+#include <memory>
+
+#include "camera.hpp"
 #include "cuda/common.cuh"
 #include "cuda/rt_core.cuh"
 #include "data_spec.hpp"
@@ -30,41 +35,23 @@
 namespace viewer {
 // cuda_assert is defined in the reference's src/cuda/common.cu (compiled alongside)
 
+using internal::CameraSpec;
 using internal::TreeSpec;
-#include "refine_kernels.inc"  // the reference's own text: renderer_kernel.cu, adjust_parents_and_children_kernel .. generate_samples_kernel
+#include "refine_kernels.inc"  // the reference's own text: renderer_kernel.cu, screen2worlddir .. generate_samples_kernel
 
 namespace {
 
-struct CamPOD {  // what CameraSpec carries (data_spec.hpp:9-23), c2w by value
-    int width, height;
-    float fx, fy, cx, cy;
-    float transform[12];
-};
-
-template <typename scalar_t>
-__device__ __inline__ void ref_screen2worlddir(int ix, int iy, const CamPOD &cam, scalar_t *out, scalar_t *cen) {
-    scalar_t xyz[3] = {(ix + 0.5f - cam.cx) / cam.fx, -(iy + 0.5f - cam.cy) / cam.fy, -1.0f};
-    _mv3(cam.transform, xyz, out);
-    _normalize(out);
-    _copy3(cam.transform + 9, cen);
+// The reference's Camera with the given intrinsics and the caller's 12-float camera-to-world matrix (column-major right | up |
+// back | center): _update(false) leaves the matrix alone and uploads it (src/camera.cpp:113-123).
+std::unique_ptr<Camera> make_camera(int width, int height, float fx, float fy, float cx, float cy, const float *c2w12) {
+    auto cam = std::make_unique<Camera>(width, height, fx, fy, cx, cy);
+    memcpy(glm::value_ptr(cam->transform), c2w12, 12 * sizeof(float));
+    cam->_update(false, true);
+    (void)hipDeviceSynchronize();
+    return cam;
 }
 
-template <typename scalar_t>
-__device__ __inline__ void ref_rodrigues(const scalar_t *__restrict__ aa, scalar_t *__restrict__ dir) {
-    scalar_t angle = _norm(aa);
-    if (angle < 1e-6) return;
-    scalar_t k[3];
-    for (int i = 0; i < 3; ++i) k[i] = aa[i] / angle;
-    scalar_t cos_angle = cos(angle), sin_angle = sin(angle);
-    scalar_t cross[3];
-    _cross3(k, dir, cross);
-    scalar_t dot = _dot3(k, dir);
-    for (int i = 0; i < 3; ++i) {
-        dir[i] = dir[i] * cos_angle + cross[i] * sin_angle + k[i] * dot * (1.0 - cos_angle);
-    }
-}
-
-__global__ void ref_render_voxels_kernel(const internal::TreeSpec tree, const CamPOD cam, const RenderOptions opt,
+__global__ void ref_render_voxels_kernel(const internal::TreeSpec tree, const CameraSpec cam, const RenderOptions opt,
                                          float *rgba,
                                          torch::PackedTensorAccessor32<float, 2, torch::RestrictPtrTraits> to_split,
                                          torch::PackedTensorAccessor32<float, 2, torch::RestrictPtrTraits> to_sample,
@@ -76,12 +63,12 @@ __global__ void ref_render_voxels_kernel(const internal::TreeSpec tree, const Ca
     bool enable_draw = tree.N > 0;
     out[0] = out[1] = out[2] = out[3] = 0.f;
     if (enable_draw) {
-        ref_screen2worlddir(x, y, cam, dir, cen);
+        screen2worlddir(x, y, cam, dir, cen);
         for (int i = 0; i < 3; ++i) cen[i] = tree.offset[i] + tree.scale[i] * cen[i];
         float t_max = 1e9f;
         float vdir[3] = {dir[0], dir[1], dir[2]};
         float aa[3] = {opt.rot_dirs[0], opt.rot_dirs[1], opt.rot_dirs[2]};
-        ref_rodrigues(aa, vdir);
+        rodrigues(aa, vdir);
         device::render_voxels_trace_ray(tree, visited, dir, vdir, cen, opt, t_max, out, &to_split[idx][1],
                                         &to_split[idx][2], &to_split[idx][0], &to_sample[idx][1],
                                         &to_sample[idx][2], &to_sample[idx][0], track_visit);
@@ -98,7 +85,7 @@ __global__ void ref_render_voxels_kernel(const internal::TreeSpec tree, const Ca
 }
 
 // restated wrapper of get_samples_from_voxels_kernel (renderer_kernel.cu:329-363), offscreen
-__global__ void ref_get_samples_kernel(internal::TreeSpec tree, const CamPOD cam, const RenderOptions opt,
+__global__ void ref_get_samples_kernel(internal::TreeSpec tree, const CameraSpec cam, const RenderOptions opt,
                                        torch::PackedTensorAccessor32<float, 2, torch::RestrictPtrTraits> to_split,
                                        torch::PackedTensorAccessor32<float, 2, torch::RestrictPtrTraits> to_sample,
                                        torch::PackedTensorAccessor32<int32_t, 1, torch::RestrictPtrTraits> visited,
@@ -111,10 +98,10 @@ __global__ void ref_get_samples_kernel(internal::TreeSpec tree, const CamPOD cam
     CUDA_GET_THREAD_ID(idx, cam.width * cam.height);
     const int x = idx % cam.width, y = idx / cam.width;
     float dir[3], cen[3];
-    ref_screen2worlddir(x, y, cam, dir, cen);
+    screen2worlddir(x, y, cam, dir, cen);
     float vdir[3] = {dir[0], dir[1], dir[2]};
     float aa[3] = {opt.rot_dirs[0], opt.rot_dirs[1], opt.rot_dirs[2]};
-    ref_rodrigues(aa, vdir);
+    rodrigues(aa, vdir);
     float t_max = 1e9f;
     device::get_samples_trace_ray(tree, visited, dir, vdir, cen, opt, t_max, &to_split[idx][1], &to_split[idx][2],
                                   &to_split[idx][0], &to_sample[idx][1], &to_sample[idx][2], &to_sample[idx][0], false,
@@ -122,7 +109,7 @@ __global__ void ref_get_samples_kernel(internal::TreeSpec tree, const CamPOD cam
 }
 
 // restated wrapper of render_nerf_results_kernel (renderer_kernel.cu:294-327), offscreen composite
-__global__ void ref_render_nerf_kernel(const internal::TreeSpec tree, const CamPOD cam, const RenderOptions opt, float *rgba,
+__global__ void ref_render_nerf_kernel(const internal::TreeSpec tree, const CameraSpec cam, const RenderOptions opt, float *rgba,
                                        const torch::PackedTensorAccessor64<float, 2, torch::RestrictPtrTraits> sample_values,
                                        const torch::PackedTensorAccessor64<float, 1, torch::RestrictPtrTraits> z_vals,
                                        const torch::PackedTensorAccessor32<int64_t, 1, torch::RestrictPtrTraits> offsets) {
@@ -131,10 +118,10 @@ __global__ void ref_render_nerf_kernel(const internal::TreeSpec tree, const CamP
     float dir[3], cen[3], out[4];
     out[0] = out[1] = out[2] = 0.f;
     out[3] = 1.0f;
-    ref_screen2worlddir(x, y, cam, dir, cen);
+    screen2worlddir(x, y, cam, dir, cen);
     float vdir[3] = {dir[0], dir[1], dir[2]};
     float aa[3] = {opt.rot_dirs[0], opt.rot_dirs[1], opt.rot_dirs[2]};
-    ref_rodrigues(aa, vdir);
+    rodrigues(aa, vdir);
     device::composite_nerf_results(tree, vdir, opt, (idx == 0 ? 0 : offsets[idx - 1]), offsets[idx], sample_values, z_vals, out);
     const float nalpha = 1.f - out[3];
     const float remain = opt.background_brightness * nalpha;
@@ -181,14 +168,8 @@ int ref_render_npz(const char *npz_path, int width, int height, float fx, float 
         }
         tree.move_to_device(tree.capacity, true, true);
         tree.sample_counts.fill_(8);  // the reference leaves this array uninitialised (n3tree.cpp:235-241)
-        CamPOD cam;
-        cam.width = width;
-        cam.height = height;
-        cam.fx = fx;
-        cam.fy = fy;
-        cam.cx = cx;
-        cam.cy = cy;
-        memcpy(cam.transform, c2w12, sizeof(cam.transform));
+        auto camera = make_camera(width, height, fx, fy, cx, cy, c2w12);
+        const CameraSpec cam(*camera);
         const int64_t n = (int64_t)width * height;
         auto fopt = torch::TensorOptions().device(torch::kCUDA).dtype(torch::kFloat32);
         torch::Tensor out = torch::zeros({n, 4}, fopt);
@@ -231,8 +212,8 @@ int ref_render_track_npz(const char *npz_path, int width, int height, float fx, 
         } else {
             tree.sample_counts.fill_(8);
         }
-        CamPOD cam = {width, height, fx, fy, cx, cy, {}};
-        memcpy(cam.transform, c2w12, sizeof(cam.transform));
+        auto camera = make_camera(width, height, fx, fy, cx, cy, c2w12);
+        const CameraSpec cam(*camera);
         const int64_t n = (int64_t)width * height;
         auto fopt = torch::TensorOptions().device(torch::kCUDA).dtype(torch::kFloat32);
         torch::Tensor out = torch::zeros({n, 4}, fopt);
@@ -362,6 +343,31 @@ int ref_adjust_parents_npz(const char *npz_path, int first_shift_index, const ui
     return 0;
 }
 
+// The reference's Camera constructor + _update pose math (src/camera.cpp:29-82, glm): pose vectors -> the 12-float
+// camera-to-world matrix and the resolved intrinsics (fx, fy, cx, cy).  updates = how many times _update() runs after the
+// vectors are set (the viewer calls it once per frame; it renormalises v_back each time).
+int ref_camera_pose(int width, int height, float fx, float fy, float cx, float cy, const float *center3, const float *back3,
+                    const float *up3, int updates, float *c2w12_out, float *intrinsics4_out) {
+    using namespace viewer;
+    try {
+        Camera cam(width, height, fx, fy, cx, cy);
+        cam.center = glm::vec3(center3[0], center3[1], center3[2]);
+        cam.v_back = glm::vec3(back3[0], back3[1], back3[2]);
+        cam.v_world_up = glm::vec3(up3[0], up3[1], up3[2]);
+        for (int i = 0; i < updates; ++i) cam._update();
+        (void)hipDeviceSynchronize();
+        memcpy(c2w12_out, glm::value_ptr(cam.transform), 12 * sizeof(float));
+        intrinsics4_out[0] = cam.fx;
+        intrinsics4_out[1] = cam.fy;
+        intrinsics4_out[2] = cam.cx;
+        intrinsics4_out[3] = cam.cy;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "ref_camera_pose: %s\n", e.what());
+        return -1;
+    }
+    return 0;
+}
+
 // The reference's get_samples_trace_ray on the tree in `npz_path` (full frame, offscreen).
 int ref_get_samples_npz(const char *npz_path, int width, int height, float fx, float fy, float cx, float cy, const float *c2w12,
                         const void *opt_bytes, int opt_size, const int32_t *grid_dim2, const float *min_position3,
@@ -377,8 +383,8 @@ int ref_get_samples_npz(const char *npz_path, int width, int height, float fx, f
         if (tree.N == 0) return -3;
         tree.move_to_device(tree.capacity, true, true);
         tree.sample_counts.fill_(8);
-        CamPOD cam = {width, height, fx, fy, cx, cy, {}};
-        memcpy(cam.transform, c2w12, sizeof(cam.transform));
+        auto camera = make_camera(width, height, fx, fy, cx, cy, c2w12);
+        const CameraSpec cam(*camera);
         const int64_t n = (int64_t)width * height;
         auto dev = torch::kCUDA;
         auto fopt = torch::TensorOptions().device(dev).dtype(torch::kFloat32);
@@ -426,8 +432,8 @@ int ref_render_nerf_results_npz(const char *npz_path, int width, int height, flo
         tree.open(npz_path);
         if (tree.N == 0) return -3;
         tree.move_to_device(tree.capacity, true, true);
-        CamPOD cam = {width, height, fx, fy, cx, cy, {}};
-        memcpy(cam.transform, c2w12, sizeof(cam.transform));
+        auto camera = make_camera(width, height, fx, fy, cx, cy, c2w12);
+        const CameraSpec cam(*camera);
         const int64_t n = (int64_t)width * height;
         auto dev = torch::kCUDA;
         torch::Tensor sv = torch::from_blob((void *)sample_values, {n_samples, (int64_t)value_stride}, torch::kFloat32).clone().to(dev);

@@ -153,3 +153,27 @@ def test_oracle_refinement_kernels_match_reference_code(mnv, orc):
     assert np.array_equal(child, z["adjust_parents/child"])
     keep = to_delete == 0
     assert np.array_equal(parent[keep], z["adjust_parents/parent"][keep])
+
+
+def test_camera_pose_matches_reference_camera(mnv, orc):
+    """T6: Camera ctor defaults + _update pose math (src/camera.cpp:29-82, glm) -- the build's host Camera and the oracle's
+    orc_camera_pose against matrices produced by the reference's own Camera class (tests/golden/make_camera_goldens.py)."""
+    import ctypes as C
+    z = np.load(os.path.join(GOLD, "ref_camera_pose.npz"))
+    for row, want1, want2, want3, intr in zip(z["inputs"], z["c2w_1"], z["c2w_2"], z["c2w_3"], z["intrinsics"]):
+        w, h, fx, fy, cx, cy = int(row[0]), int(row[1]), *[float(x) for x in row[2:6]]
+        center, back, up = tuple(np.float32(row[6:9])), tuple(np.float32(row[9:12])), tuple(np.float32(row[12:15]))
+        cam = mnv.Camera(w, h, fx, fy, cx, cy).set_pose(center, back, up)
+        got = np.float32(list(cam.c2w))
+        assert np.array_equal(got.view(np.uint32), want1.view(np.uint32))
+        assert np.array_equal(np.float32([cam.c.fx, cam.c.fy, cam.c.cx, cam.c.cy]), intr)
+        # the viewer calls _update() every frame; it renormalises v_back (a fixed point after the second call at the latest)
+        cam2 = mnv.Camera(w, h, fx, fy, cx, cy).set_pose(center, tuple(got[6:9]), up)
+        got2 = np.float32(list(cam2.c2w))
+        assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32))
+        cam3 = mnv.Camera(w, h, fx, fy, cx, cy).set_pose(center, tuple(got2[6:9]), up)
+        assert np.array_equal(np.float32(list(cam3.c2w)).view(np.uint32), want3.view(np.uint32))
+        out = (C.c_float * 12)()
+        f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
+        orc.lib().orc_camera_pose(f3(center), f3(back), f3(up), out)
+        assert np.array_equal(np.float32(list(out)).view(np.uint32), want1.view(np.uint32))
