@@ -96,9 +96,9 @@ struct MlpLaunch {
     int32_t samples_stride;
     float *results;
     int32_t result_stride;
-    const int32_t *order;    // rows sorted by cluster
-    const int32_t *tiles;    // [n][3]: cluster, first position in `order`, rows
-    const int32_t *n_tiles;
+    const int32_t *order;       // rows sorted by cluster
+    const int32_t *seg_start;   // [n_clusters + 1]: first position of each cluster in `order`
+    const int32_t *tile_start;  // [n_clusters + 1]: first 256-row tile of each cluster; [n_clusters] = number of tiles
 };
 
 // ---------------------------------------------------------------- counting sort by cluster
@@ -148,9 +148,9 @@ __global__ __launch_bounds__(256) void mlp_histogram(const int16_t *__restrict__
         if (s_bins[c]) atomicAdd(&counts[c], s_bins[c]);
 }
 
-// one block: exclusive scan of the counts, tile list
+// one block: exclusive scans of the counts -> segment starts and first tile of every cluster
 __global__ void mlp_plan(const int32_t *__restrict__ counts, int32_t n_clusters, int32_t *__restrict__ seg_start,
-                         int32_t *__restrict__ cursor, int32_t *__restrict__ tiles, int32_t *__restrict__ n_tiles) {
+                         int32_t *__restrict__ cursor, int32_t *__restrict__ tile_start) {
     __shared__ int32_t s_start[kMaxClusters + 1], s_tile[kMaxClusters + 1];
     if (threadIdx.x == 0) {
         int32_t a = 0, t = 0;
@@ -162,18 +162,12 @@ __global__ void mlp_plan(const int32_t *__restrict__ counts, int32_t n_clusters,
         }
         s_start[n_clusters] = a;
         s_tile[n_clusters] = t;
-        *n_tiles = t;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < n_clusters; c += blockDim.x) {
+    for (int c = threadIdx.x; c <= n_clusters; c += blockDim.x) {
         seg_start[c] = s_start[c];
-        cursor[c] = s_start[c];
-        const int32_t cnt = s_start[c + 1] - s_start[c];
-        for (int32_t t = s_tile[c], first = 0; t < s_tile[c + 1]; ++t, first += kRowsPerBlock) {
-            tiles[3 * t + 0] = c;
-            tiles[3 * t + 1] = s_start[c] + first;
-            tiles[3 * t + 2] = cnt - first < kRowsPerBlock ? cnt - first : kRowsPerBlock;
-        }
+        tile_start[c] = s_tile[c];
+        if (c < n_clusters) cursor[c] = s_start[c];
     }
 }
 
@@ -218,8 +212,17 @@ template <int MT>  // hidden width = 16 * MT
 __global__ __launch_bounds__(256) void mlp_forward_kernel(const MlpLaunch L) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const MlpShape &S = L.S;
-    if ((int)blockIdx.x >= *L.n_tiles) return;
-    const int cluster = L.tiles[3 * blockIdx.x + 0], first = L.tiles[3 * blockIdx.x + 1], rows = L.tiles[3 * blockIdx.x + 2];
+    if ((int)blockIdx.x >= L.tile_start[S.n_clusters]) return;
+    // the cluster whose tile range holds this block: last c with tile_start[c] <= blockIdx.x (uniform: scalar loads)
+    int lo = 0, hi = S.n_clusters;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (L.tile_start[mid] <= (int)blockIdx.x) lo = mid;
+        else hi = mid;
+    }
+    const int cluster = lo;
+    const int first = L.seg_start[cluster] + ((int)blockIdx.x - L.tile_start[cluster]) * kRowsPerBlock;
+    const int rows = min(kRowsPerBlock, L.seg_start[cluster + 1] - first);
 
     // weights and biases of this cluster -> LDS
     half8 *s_frag = reinterpret_cast<half8 *>(lds);
@@ -498,8 +501,8 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
     if (n == 0) return MNV_OK;
     hipStream_t stream = (hipStream_t)hip_stream;
     const int64_t max_tiles = n / kRowsPerBlock + S.n_clusters + 1;
-    const size_t o_counts = 0, o_start = o_counts + kMaxClusters * 4, o_cursor = o_start + kMaxClusters * 4, o_ntiles = o_cursor + kMaxClusters * 4;
-    const size_t o_tiles = o_ntiles + 256, o_order = o_tiles + (((size_t)max_tiles * 12 + 255) & ~(size_t)255);
+    const size_t table = (size_t)(kMaxClusters + 64) * 4;
+    const size_t o_counts = 0, o_start = o_counts + table, o_cursor = o_start + table, o_tiles = o_cursor + table, o_order = o_tiles + table;
     const size_t need = o_order + (size_t)n * 4;
     int rc;
     if (m->scratch_bytes < need) {
@@ -513,13 +516,13 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
         m->scratch_bytes = need + need / 4;
     }
     int32_t *counts = reinterpret_cast<int32_t *>(m->scratch + o_counts), *seg_start = reinterpret_cast<int32_t *>(m->scratch + o_start);
-    int32_t *cursor = reinterpret_cast<int32_t *>(m->scratch + o_cursor), *n_tiles = reinterpret_cast<int32_t *>(m->scratch + o_ntiles);
-    int32_t *tiles = reinterpret_cast<int32_t *>(m->scratch + o_tiles), *order = reinterpret_cast<int32_t *>(m->scratch + o_order);
+    int32_t *cursor = reinterpret_cast<int32_t *>(m->scratch + o_cursor);
+    int32_t *tile_start = reinterpret_cast<int32_t *>(m->scratch + o_tiles), *order = reinterpret_cast<int32_t *>(m->scratch + o_order);
 
     if ((rc = check_hip(hipMemsetAsync(counts, 0, kMaxClusters * 4, stream), "memset"))) return rc;
     const unsigned nb = (unsigned)((n + kSortRows - 1) / kSortRows);
     hipLaunchKernelGGL(mlp_histogram, dim3(nb), dim3(256), 0, stream, cluster_indices, n, S.n_clusters, counts, results, result_stride, S.out_dim);
-    hipLaunchKernelGGL(mlp_plan, dim3(1), dim3(256), 0, stream, counts, S.n_clusters, seg_start, cursor, tiles, n_tiles);
+    hipLaunchKernelGGL(mlp_plan, dim3(1), dim3(256), 0, stream, counts, S.n_clusters, seg_start, cursor, tile_start);
     hipLaunchKernelGGL(mlp_scatter, dim3(nb), dim3(256), 0, stream, cluster_indices, n, S.n_clusters, cursor, order);
 
     MlpLaunch L;
@@ -532,8 +535,8 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
     L.results = results;
     L.result_stride = result_stride;
     L.order = order;
-    L.tiles = tiles;
-    L.n_tiles = n_tiles;
+    L.seg_start = seg_start;
+    L.tile_start = tile_start;
     const size_t lds_bytes = (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4;
     if (S.hidden_width == 64) {
         auto kern = mlp_forward_kernel<4>;

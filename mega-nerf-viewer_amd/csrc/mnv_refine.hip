@@ -273,24 +273,25 @@ struct CountToI64 {
     __device__ int64_t operator()(int16_t v) const { return (int64_t)v; }
 };
 
-// one wavefront per ray: rows [0, num_samples[ray]) of the ray's sample block -> position offsets[ray] - n
+// 16 lanes per ray (a few samples per ray is typical): rows [0, num_samples[ray]) of the ray's sample block -> position
+// offsets[ray] - n
 __global__ void compact_samples_kernel(const int16_t *__restrict__ num_samples, const int64_t *__restrict__ offsets,
                                        const float *__restrict__ samples, const int16_t *__restrict__ clusters, int64_t n_rays,
                                        int32_t max_samples, int32_t dim, float *__restrict__ z_vals, float *__restrict__ rows_out,
                                        int16_t *__restrict__ clusters_out) {
-    const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
+    const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int lane = threadIdx.x & 15;
     if (ray >= n_rays) return;
     const int n = num_samples[ray];
     if (n <= 0) return;
     const int64_t base = offsets[ray] - n;
     const float *src = samples + ray * (int64_t)max_samples * dim;
     const int cols = dim - 1;
-    for (int i = lane; i < n; i += 64) {
+    for (int i = lane; i < n; i += 16) {
         z_vals[base + i] = src[(int64_t)i * dim];
         clusters_out[base + i] = clusters[ray * (int64_t)max_samples + i];
     }
-    for (int e = lane; e < n * cols; e += 64) {
+    for (int e = lane; e < n * cols; e += 16) {
         const int i = e / cols, c = e - i * cols;
         rows_out[(base + i) * cols + c] = src[(int64_t)i * dim + 1 + c];
     }
@@ -473,7 +474,7 @@ int mnv_compact_guided_samples(const int16_t *num_samples, const float *samples,
     if (!z_vals_out || !rows_out || !clusters_out || total > rows_capacity)
         return set_error(MNV_E_INVALID, "output buffers are missing or smaller than the sample total");
     // the rows with z >= 0 in ray-major order (cuda_renderer.cpp:117-121), i.e. each ray's first num_samples rows
-    const int64_t threads = n_rays * 64;
+    const int64_t threads = n_rays * 16;
     hipLaunchKernelGGL(compact_samples_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, num_samples, offsets_out, samples,
                        cluster_indices, n_rays, max_guided_samples, samples_dim, z_vals_out, rows_out, clusters_out);
     return check_hip(hipGetLastError(), "compact_samples_kernel");

@@ -335,18 +335,24 @@ void VolumeRenderer::render() {
             mnv_check(mnv_get_samples_from_voxels(&dv, &cv, options.c_abi(), full, split, sample, visited, track_visit, num, guided, samples_dim,
                                                   clusters, &I.grid, I.stream),
                       "mnv_get_samples_from_voxels");
-            int64_t total = 0;
-            mnv_check(mnv_compact_guided_samples(num, guided, clusters, n_px, max_g, samples_dim, offsets, nullptr, nullptr, nullptr, 0, &total, I.stream),
-                      "mnv_compact_guided_samples");
-            float *z = I.z_vals.get<float>((size_t)std::max<int64_t>(total, 1));
-            float *rows = I.sample_rows.get<float>((size_t)std::max<int64_t>(total, 1) * (samples_dim - 1));
-            int16_t *row_clusters = I.sample_clusters.get<int16_t>((size_t)std::max<int64_t>(total, 1));
-            float *values = I.nerf_results.get<float>((size_t)std::max<int64_t>(total, 1) * (dd + 1));
-            if (total > 0) {
-                mnv_check(mnv_compact_guided_samples(num, guided, clusters, n_px, max_g, samples_dim, offsets, z, rows, row_clusters, total, &total, I.stream),
-                          "mnv_compact_guided_samples");
-                mnv_check(mnv_query_submodules(I.mlp, row_clusters, rows, samples_dim - 1, total, values, dd + 1, I.stream), "mnv_query_submodules");
+            // one call in the steady state: the packed buffers keep the size of the previous frames and grow when a frame
+            // emits more (the call then reports the total it needs)
+            int64_t total = 0, cap_rows = (int64_t)(I.z_vals.bytes / sizeof(float));
+            float *z = nullptr, *rows = nullptr, *values = nullptr;
+            int16_t *row_clusters = nullptr;
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                z = I.z_vals.get<float>((size_t)std::max<int64_t>(cap_rows, 1));
+                rows = I.sample_rows.get<float>((size_t)std::max<int64_t>(cap_rows, 1) * (samples_dim - 1));
+                row_clusters = I.sample_clusters.get<int16_t>((size_t)std::max<int64_t>(cap_rows, 1));
+                const int rc = mnv_compact_guided_samples(num, guided, clusters, n_px, max_g, samples_dim, offsets, z, rows, row_clusters, cap_rows, &total,
+                                                          I.stream);
+                if (rc == MNV_OK) break;
+                if (total <= cap_rows || attempt == 1) mnv_check(rc, "mnv_compact_guided_samples");
+                cap_rows = total + total / 8;
             }
+            values = I.nerf_results.get<float>((size_t)std::max<int64_t>(total, 1) * (dd + 1));
+            if (total > 0)
+                mnv_check(mnv_query_submodules(I.mlp, row_clusters, rows, samples_dim - 1, total, values, dd + 1, I.stream), "mnv_query_submodules");
             I.reuse_total = total;
             I.can_reuse_results = true;
         }
