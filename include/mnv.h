@@ -146,6 +146,19 @@ int mnv_render_voxels(const mnv_tree_view *tree, const mnv_camera *cam, const mn
  */
 typedef struct mnv_accel mnv_accel;
 int mnv_accel_create(const mnv_tree_view *device_tree, void *hip_stream, mnv_accel **out);
+/* The same with room for max_capacity chunks, so that mnv_accel_refresh can follow a tree that grows by refinement. */
+int mnv_accel_create_reserved(const mnv_tree_view *device_tree, int64_t max_capacity, void *hip_stream, mnv_accel **out);
+/*
+ * Bring the accel up to date after a refinement step on the same device arrays, without rebuilding it:
+ *   tree           the view with its NEW capacity; chunks [old_capacity, tree->capacity) were appended under existing
+ *                  leaves (mnv_add_children_and_generate_samples + mnv_apply_split_results); needs tree->parent then
+ *   changed_nodes  device int32 [n_changed][2] (chunk, child) of existing leaves whose data row was rewritten
+ *                  (mnv_apply_sample_results), or NULL
+ * Node words, colour rows and chunk depths of the affected voxels are patched, and of the lookup grids exactly the cells
+ * those voxels cover.  After mnv_prune_tree, which renumbers chunks, destroy and create instead.  Synchronises hip_stream.
+ */
+int mnv_accel_refresh(mnv_accel *accel, const mnv_tree_view *tree, int32_t old_capacity, const int32_t *changed_nodes,
+                      int32_t n_changed, void *hip_stream);
 void mnv_accel_destroy(mnv_accel *accel);
 size_t mnv_accel_device_bytes(const mnv_accel *accel);
 int mnv_render_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,

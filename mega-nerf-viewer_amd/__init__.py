@@ -187,6 +187,8 @@ _SIGNATURES = {
     "mnv_render_voxels": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mnv_accel_create": (C.c_int, [C.POINTER(TreeView), C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mnv_accel_create_reserved": (C.c_int, [C.POINTER(TreeView), C.c_int64, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mnv_accel_refresh": (C.c_int, [C.c_void_p, C.POINTER(TreeView), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
     "mnv_accel_destroy": (None, [C.c_void_p]),
     "mnv_accel_device_bytes": (C.c_size_t, [C.c_void_p]),
     "mnv_render_voxels_accel": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
@@ -464,6 +466,24 @@ def render_voxels(tree_view: TreeView, cam: Camera, opt: RenderOptions, tile=Non
         tile = (0, 0, cam.width, cam.height)
     _check(lib().mnv_render_voxels(C.byref(tree_view), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba), _ptr(rgba8),
                                    _ptr(split_track), _ptr(sample_track), _ptr(visited), int(track_visit), C.c_void_p(stream)))
+
+
+def accel_create(tree_view: TreeView, max_capacity: int = 0, stream: int = 0) -> int:
+    """Packed accel of a device tree view with room for max_capacity chunks (0: the tree's capacity); free with accel_destroy."""
+    h = C.c_void_p()
+    _check(lib().mnv_accel_create_reserved(C.byref(tree_view), max(max_capacity, tree_view.capacity), C.c_void_p(stream), C.byref(h)))
+    return h.value
+
+
+def accel_destroy(accel: int) -> None:
+    lib().mnv_accel_destroy(C.c_void_p(accel))
+
+
+def accel_refresh(accel: int, tree_view: TreeView, old_capacity: int, changed_nodes=None, stream: int = 0) -> None:
+    """Patch the accel after chunks [old_capacity, tree_view.capacity) were appended and / or the rows of changed_nodes
+    (device int32 [n][2]) were rewritten."""
+    n = 0 if changed_nodes is None else int(changed_nodes.shape[0])
+    _check(lib().mnv_accel_refresh(C.c_void_p(accel), C.byref(tree_view), old_capacity, _ptr(changed_nodes), n, C.c_void_p(stream)))
 
 
 def render_voxels_accel(accel: int, cam: Camera, opt: RenderOptions, tile=None, rgba=None, rgba8=None, stream: int = 0) -> None:

@@ -63,6 +63,9 @@ struct mnv_accel {
     uint32_t *grid_vox = nullptr;
     uint32_t *grid2 = nullptr;
     uint32_t *grid2_vox = nullptr;
+    int32_t *depth = nullptr;             // [reserved] depth of the voxels of each chunk (root chunk: 1); kept for mnv_accel_refresh
+    int32_t *flags = nullptr;             // [4] device scratch of refresh: changed, deepest depth, grids dirty
+    int64_t reserved = 0;                 // chunks the nodes / rows / depth arrays have room for
     unsigned long long *stats = nullptr;  // MNV_STATS=1 diagnostics
     // per-launch slots: [n_frames][kNumQueues] ray-queue heads (64 B apart) + [n_frames] camera blocks,
     // written on the launch stream by stage_launch_kernel; kSlots launches may be in flight

@@ -128,6 +128,108 @@ __global__ void accel_build_grid2(const uint32_t *nodes, uint32_t *grid2, uint32
     grid2_vox[o] = vox;
 }
 
+// ---- incremental update after a refinement step (mnv_accel_refresh)
+
+// depth of appended chunks from their parent words (parent[c] = parent_chunk * 8 + slot); repeated until nothing changes
+// because a new chunk may hang under another new chunk.  flags[0] = changed, flags[1] = deepest depth seen.
+__global__ void accel_refresh_depth(const int32_t *parent, int32_t *depth, int32_t first, int32_t capacity, int32_t *flags) {
+    const int32_t c = first + (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (c >= capacity || depth[c] != 0) return;
+    const int32_t pc = parent[c] >> 3;
+    if (pc < 0 || pc >= capacity) return;
+    const int32_t dp = depth[pc];
+    if (dp == 0) return;
+    depth[c] = dp + 1;
+    flags[0] = 1;
+    atomicMax(&flags[1], dp + 1);
+}
+
+// node words of the appended chunks' voxels and the link word of the voxel each of them hangs under;
+// flags[2] = 1 when that voxel was shallow enough to be held by a lookup grid
+__global__ void accel_refresh_nodes(const int32_t *child, const int32_t *parent, const uint16_t *data, const int32_t *depth, uint32_t *nodes,
+                                    int32_t first, int32_t capacity, int32_t data_dim, int32_t grid_depth, int32_t *flags) {
+    const int64_t v = (int64_t)first * 8 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= (int64_t)capacity * 8) return;
+    const int32_t c = (int32_t)(v >> 3);
+    const int32_t skip = child[v];
+    if (skip != 0) {
+        nodes[v] = (uint32_t)(c + skip);
+    } else {
+        nodes[v] = kLeafBit | (((uint32_t)depth[c] & 0x7fu) << 16) | (uint32_t)data[v * data_dim + data_dim - 1];
+    }
+    if ((v & 7) == 0) {
+        const int32_t pv = parent[c];
+        nodes[pv] = (uint32_t)c;
+        if (depth[pv >> 3] <= grid_depth) flags[2] = 1;
+    }
+}
+
+// existing leaves whose data row was rewritten (mnv_apply_sample_results): sigma in the node word, colour row
+__global__ void accel_refresh_changed(const int32_t *changed_nodes, int32_t n, const int32_t *child, const uint16_t *data, const int32_t *depth,
+                                      uint32_t *nodes, uint16_t *rows, int32_t data_dim, int32_t per_chan, int32_t chan_halfs,
+                                      int32_t row_halfs, int32_t grid_depth, int32_t *flags) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t c = changed_nodes[2 * i];
+    const int64_t v = (int64_t)c * 8 + changed_nodes[2 * i + 1];
+    if (child[v] != 0) return;
+    nodes[v] = kLeafBit | (((uint32_t)depth[c] & 0x7fu) << 16) | (uint32_t)data[v * data_dim + data_dim - 1];
+    for (int ch = 0; ch < 3; ++ch)
+        for (int32_t k = 0; k < chan_halfs; ++k) rows[v * row_halfs + ch * chan_halfs + k] = k < per_chan ? data[v * data_dim + ch * per_chan + k] : (uint16_t)0;
+    if (depth[c] <= grid_depth) flags[2] = 1;
+}
+
+// Rewrite the level-L2 lookup cells covered by voxels that stopped being (or changed as) leaves.  Block (b, s): voxel b of the
+// list -- vox_list[b], or the parent voxel of chunk first_chunk + b when vox_list is NULL -- slice s of its cells.  The voxel's
+// integer coordinates come from the walk up the parent words.
+__global__ void accel_patch_grid2(const int32_t *vox_pairs, int32_t first_chunk, const int32_t *parent, const int32_t *depth,
+                                  const uint32_t *nodes, uint32_t *grid2, uint32_t *grid2_vox, int32_t L2) {
+    __shared__ uint32_t s_box[4];  // x, y, z at the voxel's own level; its depth (0: nothing to do)
+    if (threadIdx.x == 0) {
+        int64_t pv = vox_pairs ? (int64_t)vox_pairs[2 * blockIdx.x] * 8 + vox_pairs[2 * blockIdx.x + 1] : (int64_t)parent[first_chunk + blockIdx.x];
+        int32_t cur = (int32_t)(pv >> 3);
+        const int32_t d = depth[cur];
+        uint32_t x = 0, y = 0, z = 0;
+        if (d >= 1 && d <= L2) {
+            uint32_t slot = (uint32_t)(pv & 7);
+            for (int k = 0; k < d; ++k) {
+                x |= ((slot >> 2) & 1u) << k;
+                y |= ((slot >> 1) & 1u) << k;
+                z |= (slot & 1u) << k;
+                if (cur == 0) break;
+                const int32_t p = parent[cur];
+                slot = (uint32_t)(p & 7);
+                cur = p >> 3;
+            }
+        }
+        s_box[0] = x;
+        s_box[1] = y;
+        s_box[2] = z;
+        s_box[3] = (d >= 1 && d <= L2) ? (uint32_t)d : 0u;
+    }
+    __syncthreads();
+    const int d = (int)s_box[3];
+    if (d == 0) return;
+    const int sh = L2 - d;  // the voxel covers (2^sh)^3 cells
+    const uint32_t bx = s_box[0] << sh, by = s_box[1] << sh, bz = s_box[2] << sh;
+    const uint64_t total = (uint64_t)1 << (3 * sh);
+    for (uint64_t i = (uint64_t)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.y * blockDim.x) {
+        const uint32_t ix = bx + (uint32_t)(i >> (2 * sh)), iy = by + (uint32_t)((i >> sh) & ((1u << sh) - 1u)), iz = bz + (uint32_t)(i & ((1u << sh) - 1u));
+        uint32_t chunk = 0, word = 0, vox = 0;
+        for (int32_t l = 1; l <= L2; ++l) {
+            const int32_t s2 = L2 - l;
+            const uint32_t cidx = (((ix >> s2) & 1u) << 2) | (((iy >> s2) & 1u) << 1) | ((iz >> s2) & 1u);
+            vox = chunk * 8u + cidx;
+            word = nodes[vox];
+            if (word & kLeafBit) break;
+            chunk = word;
+        }
+        const uint32_t o = grid2_index(ix, iy, iz, L2);
+        grid2[o] = word;
+        grid2_vox[o] = vox;
+    }
+}
+
 // Per-launch parameters that live in device memory: zeroes the ray-queue heads of every frame and
 // stores the camera blocks (handed over by value, so no host staging buffer or copy engine is involved).
 constexpr int kStageCams = 32;
@@ -735,7 +837,12 @@ using namespace mnv;
 extern "C" {
 
 int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) {
+    return mnv_accel_create_reserved(t, t ? t->capacity : 0, hip_stream, out);
+}
+
+int mnv_accel_create_reserved(const mnv_tree_view *t, int64_t max_capacity, void *hip_stream, mnv_accel **out) {
     if (!t || !out) return set_error(MNV_E_INVALID, "null argument");
+    if (max_capacity < t->capacity) return set_error(MNV_E_INVALID, "max_capacity is smaller than the tree");
     if (t->N != 2) return set_error(MNV_E_UNSUPPORTED, "accel needs N == 2");
     if (!t->data || !t->child || t->capacity < 1 || t->data_dim < 1) return set_error(MNV_E_INVALID, "invalid device tree view");
     const int b = (t->format == MNV_FORMAT_SH && t->basis_dim >= 0) ? t->basis_dim : -1;
@@ -748,8 +855,6 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
     int rc = MNV_OK;
     int32_t *depth = nullptr, *changed = nullptr;
     auto fail = [&](int code) {
-        if (depth) (void)hipFree(depth);
-        if (changed) (void)hipFree(changed);
         mnv_accel_destroy(a);
         return code;
     };
@@ -760,17 +865,20 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
 
     const int64_t cap = t->capacity, nvox = cap * 8;
     const int row_bytes = row_bytes_for(b);
-    if ((rc = check_hip(hipMalloc((void **)&a->nodes, nvox * 4), "hipMalloc(nodes)"))) return fail(rc);
-    if ((rc = check_hip(hipMalloc((void **)&a->rows, nvox * row_bytes), "hipMalloc(rows)"))) return fail(rc);
-    if ((rc = check_hip(hipMalloc((void **)&depth, cap * 4), "hipMalloc(depth)"))) return fail(rc);
-    if ((rc = check_hip(hipMalloc((void **)&changed, 4), "hipMalloc(flag)"))) return fail(rc);
+    a->reserved = max_capacity;
+    if ((rc = check_hip(hipMalloc((void **)&a->nodes, max_capacity * 8 * 4), "hipMalloc(nodes)"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&a->rows, max_capacity * 8 * row_bytes), "hipMalloc(rows)"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&a->depth, max_capacity * 4), "hipMalloc(depth)"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&a->flags, 16), "hipMalloc(flag)"))) return fail(rc);
+    depth = a->depth;
+    changed = a->flags;
     if ((rc = check_hip(hipMalloc((void **)&a->slots_dev, (size_t)kSlots * kSlotBytes), "hipMalloc(slots)"))) return fail(rc);
 
     if ((rc = check_hip(hipMalloc((void **)&a->stats, 16 * sizeof(unsigned long long)), "hipMalloc(stats)"))) return fail(rc);
     if ((rc = check_hip(hipMemsetAsync(a->stats, 0, 16 * sizeof(unsigned long long), stream), "memset stats"))) return fail(rc);
 
     // chunk depths: root chunk holds depth-1 voxels
-    if ((rc = check_hip(hipMemsetAsync(depth, 0, cap * 4, stream), "memset depth"))) return fail(rc);
+    if ((rc = check_hip(hipMemsetAsync(depth, 0, max_capacity * 4, stream), "memset depth"))) return fail(rc);
     const int32_t one = 1;
     if ((rc = check_hip(hipMemcpyAsync(depth, &one, 4, hipMemcpyHostToDevice, stream), "seed depth"))) return fail(rc);
     const unsigned nb = (unsigned)((nvox + 255) / 256);
@@ -813,9 +921,6 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
     }
     if ((rc = check_hip(hipGetLastError(), "accel build launch"))) return fail(rc);
     if ((rc = check_hip(hipStreamSynchronize(stream), "accel build"))) return fail(rc);
-    (void)hipFree(depth);
-    (void)hipFree(changed);
-    depth = changed = nullptr;
 
     a->view.nodes = a->nodes;
     a->view.rows = a->rows;
@@ -840,6 +945,69 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
     return MNV_OK;
 }
 
+int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity, const int32_t *changed_nodes, int32_t n_changed,
+                      void *hip_stream) {
+    if (!a || !t) return set_error(MNV_E_INVALID, "null argument");
+    if (old_capacity != a->view.capacity) return set_error(MNV_E_INVALID, "old_capacity is not the capacity the accel was last built or refreshed for");
+    if (t->capacity < old_capacity || t->capacity > a->reserved)
+        return set_error(MNV_E_INVALID, "the tree shrank or outgrew the reserved capacity (rebuild with mnv_accel_create_reserved)");
+    if (t->data_dim != a->view.data_dim || t->format != a->view.format || t->basis_dim != a->view.basis_dim || !t->data || !t->child)
+        return set_error(MNV_E_INVALID, "tree view does not match the accel");
+    if (t->capacity > old_capacity && !t->parent) return set_error(MNV_E_INVALID, "appended chunks need the parent array");
+    if (n_changed < 0 || (n_changed > 0 && !changed_nodes)) return set_error(MNV_E_INVALID, "invalid changed_nodes");
+    if (t->capacity == old_capacity && n_changed == 0) return MNV_OK;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    int rc;
+    const int b = (t->format == MNV_FORMAT_SH && t->basis_dim >= 0) ? t->basis_dim : -1;
+    const int per_chan = b > 0 ? b : 1, chan_halfs = b > 0 ? chan_bytes_for(b) / 2 : 1, row_halfs = a->view.row_bytes / 2;
+    const int grid_depth = a->view.grid_level;  // leaves this shallow sit in the small (LDS-staged) lookup grid
+    int32_t h[4] = {0, a->view.max_depth, 0, 0};
+    if ((rc = check_hip(hipMemcpyAsync(a->flags, h, sizeof(h), hipMemcpyHostToDevice, stream), "refresh flags"))) return rc;
+    const int32_t n_new = t->capacity - old_capacity;
+    if (n_new > 0) {
+        for (int pass = 0; pass < 32; ++pass) {
+            hipLaunchKernelGGL(accel_refresh_depth, dim3((n_new + 255) / 256), dim3(256), 0, stream, t->parent, a->depth, old_capacity, t->capacity, a->flags);
+            int32_t changed = 0;
+            if ((rc = check_hip(hipMemcpyAsync(&changed, a->flags, 4, hipMemcpyDeviceToHost, stream), "read flag"))) return rc;
+            if ((rc = check_hip(hipMemsetAsync(a->flags, 0, 4, stream), "clear flag"))) return rc;
+            if ((rc = check_hip(hipStreamSynchronize(stream), "accel_refresh_depth"))) return rc;
+            if (!changed) break;
+        }
+        const int64_t nv = (int64_t)n_new * 8;
+        hipLaunchKernelGGL(accel_refresh_nodes, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, t->child, t->parent, t->data, a->depth, a->nodes,
+                           old_capacity, t->capacity, t->data_dim, grid_depth, a->flags);
+        hipLaunchKernelGGL(accel_pack_rows, dim3((unsigned)((nv * 3 + 255) / 256)), dim3(256), 0, stream, t->data + (int64_t)old_capacity * 8 * t->data_dim,
+                           reinterpret_cast<uint16_t *>(a->rows) + (int64_t)old_capacity * 8 * row_halfs, nv, t->data_dim, per_chan, chan_halfs, row_halfs);
+    }
+    if (n_changed > 0)
+        hipLaunchKernelGGL(accel_refresh_changed, dim3((n_changed + 255) / 256), dim3(256), 0, stream, changed_nodes, n_changed, t->child, t->data, a->depth,
+                           a->nodes, reinterpret_cast<uint16_t *>(a->rows), t->data_dim, per_chan, chan_halfs, row_halfs, grid_depth, a->flags);
+    if ((rc = check_hip(hipMemcpyAsync(h, a->flags, sizeof(h), hipMemcpyDeviceToHost, stream), "read flags"))) return rc;
+    if ((rc = check_hip(hipStreamSynchronize(stream), "accel refresh"))) return rc;
+    if (h[1] > 23) return set_error(MNV_E_UNSUPPORTED, "accel supports trees up to depth 23; use mnv_render_voxels");
+    if (h[2]) {  // an affected voxel is held by the small lookup grid: 32^3 cells at most, rebuilt whole
+        const int64_t gcells = (int64_t)1 << (3 * a->view.grid_level);
+        hipLaunchKernelGGL(accel_build_grid, dim3((unsigned)((gcells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid, a->grid_vox, a->view.grid_level);
+    }
+    if (a->view.grid2_level > 0) {
+        // the level-L2 grid: only the cells the affected voxels cover (voxels deeper than L2 cover none)
+        if (n_new > 0)
+            hipLaunchKernelGGL(accel_patch_grid2, dim3((unsigned)n_new, 32), dim3(256), 0, stream, (const int32_t *)nullptr, old_capacity, t->parent, a->depth,
+                               a->nodes, a->grid2, a->grid2_vox, a->view.grid2_level);
+        if (n_changed > 0 && t->parent)
+            hipLaunchKernelGGL(accel_patch_grid2, dim3((unsigned)n_changed, 32), dim3(256), 0, stream, changed_nodes, 0, t->parent, a->depth, a->nodes, a->grid2,
+                               a->grid2_vox, a->view.grid2_level);
+        else if (n_changed > 0) {
+            const int64_t g2cells = (int64_t)1 << (3 * a->view.grid2_level);
+            hipLaunchKernelGGL(accel_build_grid2, dim3((unsigned)((g2cells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid2, a->grid2_vox,
+                               a->view.grid2_level);
+        }
+    }
+    a->view.max_depth = std::max(a->view.max_depth, h[1]);
+    a->view.capacity = t->capacity;
+    return check_hip(hipGetLastError(), "accel refresh launch");
+}
+
 void mnv_accel_destroy(mnv_accel *a) {
     if (!a) return;
     if (a->stats && getenv("MNV_STATS")) {
@@ -852,6 +1020,8 @@ void mnv_accel_destroy(mnv_accel *a) {
         }
     }
     if (a->stats) (void)hipFree(a->stats);
+    if (a->depth) (void)hipFree(a->depth);
+    if (a->flags) (void)hipFree(a->flags);
     if (a->nodes) (void)hipFree(a->nodes);
     if (a->rows) (void)hipFree(a->rows);
     if (a->grid) (void)hipFree(a->grid);

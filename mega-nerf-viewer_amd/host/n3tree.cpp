@@ -1,5 +1,7 @@
 #include "n3tree.hpp"
 
+#include <algorithm>
+
 #include <hip/hip_runtime_api.h>
 
 #include <cassert>
@@ -221,7 +223,7 @@ void N3Tree::move_to_device(long max_capacity, bool need_parent, bool need_sampl
     hip_check(hipStreamSynchronize(stream), "upload");
     const mnv_tree_view dv = device_view();
     if (N == 2) {
-        const int rc = mnv_accel_create(&dv, hip_stream, &device.accel);
+        const int rc = mnv_accel_create_reserved(&dv, std::max<long>(max_capacity, capacity), hip_stream, &device.accel);
         if (rc != MNV_OK) throw std::runtime_error(std::string("mnv_accel_create: ") + mnv_last_error());
     }
 }
@@ -231,8 +233,15 @@ void N3Tree::rebuild_accel(void *hip_stream) {
     if (device.accel) mnv_accel_destroy(device.accel);
     device.accel = nullptr;
     const mnv_tree_view dv = device_view();
-    const int rc = mnv_accel_create(&dv, hip_stream, &device.accel);
+    const int rc = mnv_accel_create_reserved(&dv, std::max<long>(device.max_capacity, capacity), hip_stream, &device.accel);
     if (rc != MNV_OK) throw std::runtime_error(std::string("mnv_accel_create: ") + mnv_last_error());
+}
+
+void N3Tree::refresh_accel(int old_capacity, const int32_t *changed_nodes, int n_changed, void *hip_stream) {
+    if (!device.accel) return;
+    const mnv_tree_view dv = device_view();
+    const int rc = mnv_accel_refresh(device.accel, &dv, old_capacity, changed_nodes, n_changed, hip_stream);
+    if (rc != MNV_OK) throw std::runtime_error(std::string("mnv_accel_refresh: ") + mnv_last_error());
 }
 
 void N3Tree::copy_from_device(void *hip_stream) {

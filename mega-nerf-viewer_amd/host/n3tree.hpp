@@ -36,8 +36,11 @@ struct N3Tree {
     // Throws std::runtime_error on HIP failure.
     void move_to_device(long max_capacity, bool need_parent, bool need_sample_counts, void *hip_stream = nullptr);
     void free_device();
-    // Rebuild the packed accel from the current device arrays (after refinement changed them).
+    // Rebuild the packed accel from the current device arrays (after pruning renumbered the chunks).
     void rebuild_accel(void *hip_stream = nullptr);
+    // Patch the accel after chunks [old_capacity, capacity) were appended and / or the rows of `changed_nodes`
+    // (device (chunk, child) pairs) were rewritten (mnv_accel_refresh).
+    void refresh_accel(int old_capacity, const int32_t *changed_nodes, int n_changed, void *hip_stream = nullptr);
     // Copy the first `capacity` chunks of the device arrays back into the host vectors (after refinement).
     void copy_from_device(void *hip_stream = nullptr);
 

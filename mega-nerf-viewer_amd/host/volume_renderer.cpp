@@ -138,9 +138,11 @@ void VolumeRenderer::Impl::expand_voxels(RenderOptions &o, FrameStats &st, uint6
     mnv_check(mnv_query_submodules(mlp, d_clusters, d_rand, dim, rows, d_results, dd + 1, stream), "mnv_query_submodules");
     mnv_check(mnv_apply_split_results(tree->device.data, tree->device.sample_counts, tree->capacity, n, d_results, dd + 1, spc, dd, stream),
               "mnv_apply_split_results");
+    const int old_capacity = tree->capacity;
     tree->capacity += n;
     st.added = n;
-    tree_changed();
+    can_reuse_results = false;
+    if (!accel_stale) tree->refresh_accel(old_capacity, nullptr, 0, stream);  // the packed layout follows the split
 }
 
 void VolumeRenderer::Impl::get_more_samples(RenderOptions &o, FrameStats &st, uint64_t seed) {
@@ -165,7 +167,8 @@ void VolumeRenderer::Impl::get_more_samples(RenderOptions &o, FrameStats &st, ui
     mnv_check(mnv_apply_sample_results(tree->device.data, tree->device.sample_counts, d_nodes, n, d_results, dd + 1, spc, dd, stream),
               "mnv_apply_sample_results");
     st.resampled = n;
-    tree_changed();
+    can_reuse_results = false;
+    if (!accel_stale) tree->refresh_accel(tree->capacity, d_nodes, n, stream);  // new sigma / colour rows of the resampled leaves
 }
 
 void VolumeRenderer::Impl::prune_tree(FrameStats &st) {
@@ -315,8 +318,9 @@ void VolumeRenderer::render() {
         I.fill_f32(split, n_px * 3, -1.f);
         I.fill_f32(sample, n_px * 3, -1.f);
     }
-    // the packed accel describes the tree as it was when it was built: after a refinement step the march reads the
-    // reference-layout arrays directly until the tree has been quiet for accel_rebuild_after frames
+    // splits and resampled leaves are patched into the packed accel as they happen (mnv_accel_refresh); a prune renumbers
+    // the chunks, after which the march reads the reference-layout arrays until the accel has been rebuilt -- once the
+    // tree has been left alone for accel_rebuild_after frames
     if (I.accel_stale && I.quiet_frames >= accel_rebuild_after) {
         tree.rebuild_accel(I.stream);
         I.accel_stale = false;

@@ -129,48 +129,115 @@ def test_first_refinement_step_matches_checkers(mnv, orc, torch_gpu):
     assert err.max() < 5e-3 and np.abs(new_want).mean() > 0.02
 
 
-def test_refinement_run_keeps_a_valid_tree_and_accel_is_rebuilt(mnv, torch_gpu):
-    torch = torch_gpu
-    r, tree, desc, params, cam_spec = setup(mnv, "sh4_d6", 40000, need_viewdir=True, use_splitting=True, max_depth=8, split_batch_size=512,
-                                            samples_per_corner=4, max_sample_count=24)
-    r.set_seed(9, accel_rebuild_after=2)
-    cap0 = tree.capacity
-    caps, added, resampled = [], 0, 0
-    for f in range(10):
-        a = 0.1 * f
-        r.set_camera((-2.4 * np.cos(a) - 1.1 * np.sin(a), 1.1 * np.cos(a) - 2.4 * np.sin(a), 1.6), (-0.72 * np.cos(a) - 0.33 * np.sin(a), 0.33 * np.cos(a) - 0.72 * np.sin(a), 0.48))
-        st = r.render()
-        caps.append(st["capacity"])
-        added += st["added"]
-        resampled += st["resampled"]
-        assert st["added"] <= 512 and st["pruned"] == 0
-    assert caps == sorted(caps) and caps[-1] == cap0 + added and added > 0
-    assert np.isfinite(r.download()).all()
-    r.sync_tree()
-    data, child, parent = tree.host_arrays()
-    assert child.shape[0] == caps[-1]
-    check_tree_links(child, parent, caps[-1])
-    # nothing left to split or sample: after accel_rebuild_after quiet frames the packed accel is rebuilt from the grown
-    # tree and used again
-    used = []
-    r.options.max_depth = 1
-    r.options.max_sample_count = -30000
-    for f in range(4):
-        st = r.render()
-        used.append(st["used_accel"])
-        assert st["added"] == 0 and st["resampled"] == 0
-    assert used[-1] == 1 and used[0] == 0
-    # the rebuilt accel and the reference-layout kernel agree bit for bit on the grown tree
+def _accel_equals_reference_layout(mnv, torch, tree, cam_spec, case):
+    """The packed accel the renderer keeps and the reference-layout kernel agree bit for bit on the tree as it is now."""
     cam = cases.make_camera(mnv, cam_spec)
-    opt = cases.make_options(mnv, cases.CASES["sh4_d6"]["options"])
-    opt.basis_minmax[1] = 3
+    opt = cases.make_options(mnv, cases.CASES[case]["options"])
+    opt.basis_minmax[1] = max(tree.host_view().basis_dim - 1, 0)
     h, w = cam.height, cam.width
     a = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
     b = torch.empty_like(a)
     mnv.render_voxels(tree.device_view(), cam, opt, rgba=a)
     mnv.render_voxels_accel(tree.accel, cam, opt, rgba=b)
     torch.cuda.synchronize()
-    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    return torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def test_refinement_run_keeps_a_valid_tree_and_the_accel_follows(mnv, torch_gpu):
+    torch = torch_gpu
+    r, tree, desc, params, cam_spec = setup(mnv, "sh4_d6", 40000, need_viewdir=True, use_splitting=True, max_depth=8, split_batch_size=512,
+                                            samples_per_corner=4, max_sample_count=24)
+    r.set_seed(9)
+    cap0 = tree.capacity
+    caps, added = [], 0
+    for f in range(10):
+        a = 0.1 * f
+        r.set_camera((-2.4 * np.cos(a) - 1.1 * np.sin(a), 1.1 * np.cos(a) - 2.4 * np.sin(a), 1.6), (-0.72 * np.cos(a) - 0.33 * np.sin(a), 0.33 * np.cos(a) - 0.72 * np.sin(a), 0.48))
+        st = r.render()
+        caps.append(st["capacity"])
+        added += st["added"]
+        # every split is patched into the packed accel (mnv_accel_refresh): the tuned kernel stays in use
+        assert st["added"] <= 512 and st["pruned"] == 0 and st["used_accel"] == 1 and st["track_visit"] == 0
+    assert caps == sorted(caps) and caps[-1] == cap0 + added and added > 1000
+    assert np.isfinite(r.download()).all()
+    r.sync_tree()
+    data, child, parent = tree.host_arrays()
+    assert child.shape[0] == caps[-1]
+    check_tree_links(child, parent, caps[-1])
+    assert _accel_equals_reference_layout(mnv, torch, tree, cam_spec, "sh4_d6")
+    # no split candidates left -> get_more_samples rewrites rows of existing leaves; the accel follows those too
+    r.options.max_depth = 1
+    resampled = 0
+    for f in range(3):
+        st = r.render()
+        resampled += st["resampled"]
+        assert st["added"] == 0 and st["used_accel"] == 1
+    assert resampled > 0
+    assert _accel_equals_reference_layout(mnv, torch, tree, cam_spec, "sh4_d6")
+
+
+def test_accel_refresh_entry_point(mnv, orc, torch_gpu):
+    """mnv_accel_create_reserved + mnv_accel_refresh on their own: split shallow and deep leaves (grid rebuild and plain patch),
+    rewrite rows, and compare with an accel built from scratch and with the reference-layout kernel."""
+    torch = torch_gpu
+    import refine_kernel_cases as rk
+    spec = cases.CASES["sh4_d6"]
+    tree = cases.make_tree(mnv, spec["tree"])
+    v = tree.host_view()
+    cap, dd = v.capacity, v.data_dim
+    data, child, parent = tree.host_arrays()
+    depth = np.zeros(cap, np.int32)
+    depth[0] = 1
+    for c in range(1, cap):
+        depth[c] = depth[parent[c] >> 3] + 1
+    leaves = np.argwhere(child == 0)
+    rng = np.random.default_rng(3)
+    for pick, label in ((leaves[depth[leaves[:, 0]] >= 5], "deep"), (leaves[depth[leaves[:, 0]] <= 2], "shallow")):
+        n_new = min(24, len(pick))
+        nodes = np.ascontiguousarray(pick[rng.choice(len(pick), n_new, replace=False)], dtype=np.int32)
+        max_cap = cap + n_new
+        big = lambda a: np.concatenate([a, np.zeros((n_new,) + a.shape[1:], a.dtype)])  # noqa: E731
+        d = dict(data=torch.from_numpy(big(data).view(np.int16)).cuda(), child=torch.from_numpy(big(child)).cuda(), parent=torch.from_numpy(big(parent)).cuda())
+        tv = mnv.TreeView()
+        for f in ("offset", "scale", "N", "data_dim", "format", "basis_dim"):
+            setattr(tv, f, getattr(v, f))
+        tv.data, tv.child, tv.parent, tv.capacity = d["data"].data_ptr(), d["child"].data_ptr(), d["parent"].data_ptr(), cap
+        accel = mnv.accel_create(tv, max_cap)
+        # grow: link the children, give them rows
+        opt = mnv.RenderOptions.cli_defaults()
+        opt.samples_per_corner = 2
+        samples = torch.rand((n_new * 8, 2, 3), device="cuda")
+        clusters = torch.zeros((n_new * 8, 2), dtype=torch.int16, device="cuda")
+        visited = torch.zeros(max_cap, dtype=torch.int32, device="cuda")
+        edit = mnv.tree_edit(d["child"], d["parent"], list(v.offset), list(v.scale), cap)
+        mnv.add_children_and_generate_samples(edit, opt, torch.from_numpy(nodes).cuda(), samples, clusters, visited, rk.grid(mnv))
+        new_rows = torch.from_numpy((rng.standard_normal((n_new * 8, dd)) * 0.7).astype(np.float16).view(np.int16)).cuda()
+        new_rows.view(torch.float16)[:, dd - 1] = torch.from_numpy(rng.uniform(0, 40, n_new * 8).astype(np.float16)).cuda()
+        d["data"][cap:] = new_rows.view(n_new, 8, dd)
+        tv.capacity = max_cap
+        mnv.accel_refresh(accel, tv, cap)
+        # rewrite rows of some existing leaves as well
+        changed = np.ascontiguousarray(leaves[rng.choice(len(leaves), 30, replace=False)], dtype=np.int32)
+        rows = torch.from_numpy((rng.standard_normal((30, dd)) * 0.7).astype(np.float16).view(np.int16)).cuda()
+        rows.view(torch.float16)[:, dd - 1] = 25.0
+        d["data"].view(-1, dd)[torch.from_numpy(changed[:, 0].astype(np.int64) * 8 + changed[:, 1]).cuda()] = rows
+        mnv.accel_refresh(accel, tv, max_cap, torch.from_numpy(changed).cuda())
+        fresh = mnv.accel_create(tv)
+        cam = cases.make_camera(mnv, spec["camera"])
+        ropt = cases.make_options(mnv, spec["options"])
+        ropt.basis_minmax[1] = 3
+        imgs = [torch.empty((cam.height, cam.width, 4), dtype=torch.float32, device="cuda") for _ in range(3)]
+        mnv.render_voxels_accel(accel, cam, ropt, rgba=imgs[0])
+        mnv.render_voxels_accel(fresh, cam, ropt, rgba=imgs[1])
+        mnv.render_voxels(tv, cam, ropt, rgba=imgs[2])
+        torch.cuda.synchronize()
+        assert torch.equal(imgs[0].view(torch.int32), imgs[2].view(torch.int32)), label
+        assert torch.equal(imgs[1].view(torch.int32), imgs[2].view(torch.int32)), label
+        # refresh refuses what it cannot follow
+        with pytest.raises(mnv.MnvError):
+            mnv.accel_refresh(accel, tv, cap)  # stale old_capacity
+        mnv.accel_destroy(accel)
+        mnv.accel_destroy(fresh)
 
 
 def test_prune_runs_inside_the_loop(mnv, torch_gpu):
@@ -188,6 +255,11 @@ def test_prune_runs_inside_the_loop(mnv, torch_gpu):
     assert child.shape[0] == tree.capacity == log[-1]["capacity"]
     check_tree_links(child, parent, tree.capacity)
     assert np.isfinite(r.download()).all()
+    # the prune invalidated the packed accel; it is rebuilt accel_rebuild_after frames later and in use again
+    r.options.max_depth, r.options.max_sample_count = 1, -30000
+    used = [r.render()["used_accel"] for _ in range(8)]
+    assert used[-1] == 1
+    assert _accel_equals_reference_layout(mnv, torch_gpu, tree, cam_spec, "sh4_d6")
 
 
 def test_prune_on_the_first_frame_when_the_tree_is_nearly_full(mnv, orc, torch_gpu):

@@ -101,7 +101,7 @@ def main():
         desc = mnv.mlp_desc(n_clusters=8, pos_octaves=10, hidden_width=64, hidden_layers=2, out_dim=t.host_view().data_dim + 1)
         r = mnv.Renderer()
         r.resize(1920, 1080)
-        r.set(t, t.capacity + 400_000)
+        r.set(t, 4 * t.capacity)  # room to grow: no visit tracking, no prune (the reference reserves 20 M chunks)
         g = mnv.ClusterGrid()
         g.grid_dim[0], g.grid_dim[1] = 4, 2
         for i in range(3):
