@@ -244,6 +244,13 @@ int mnv_get_samples_from_voxels(const mnv_tree_view *tree, const mnv_camera *cam
                                 int track_visit, int16_t *num_samples, float *samples, int32_t samples_dim,
                                 int16_t *cluster_indices, const mnv_cluster_grid *grid, void *hip_stream);
 
+/* The same march on the packed accel (no visit marks: they need every chunk on the descent, see
+ * mnv_render_voxels_accel_track); sample_counts is the tree's live [capacity][8] array or NULL.  Bit-identical rows. */
+int mnv_get_samples_from_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                                      float *split_track, float *sample_track, const int16_t *sample_counts, int16_t *num_samples,
+                                      float *samples, int32_t samples_dim, int16_t *cluster_indices, const mnv_cluster_grid *grid,
+                                      void *hip_stream);
+
 /*
  * viewer::render_nerf_results (include/cuda/renderer_kernel.hpp:12-21,
  * src/cuda/renderer_kernel.cu:294-327,365-394; rt_core.cuh:334-416), offscreen: composites

@@ -204,6 +204,8 @@ _SIGNATURES = {
     "mnv_get_samples_from_voxels": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32,
                                               C.c_void_p, C.POINTER(ClusterGrid), C.c_void_p]),
+    "mnv_get_samples_from_voxels_accel": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(ClusterGrid), C.c_void_p]),
     "mnv_render_nerf_results": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
                                           C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_add_children_and_generate_samples": (C.c_int, [C.POINTER(TreeEdit), C.POINTER(RenderOptions), C.c_void_p, C.c_int32, C.c_void_p,
@@ -534,6 +536,16 @@ def get_samples_from_voxels(tree_view: TreeView, cam: Camera, opt: RenderOptions
     _check(lib().mnv_get_samples_from_voxels(C.byref(tree_view), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(split_track),
                                              _ptr(sample_track), _ptr(visited), int(track_visit), _ptr(num_samples), _ptr(samples),
                                              int(samples.shape[-1]), _ptr(cluster_indices), C.byref(grid), C.c_void_p(stream)))
+
+
+def get_samples_from_voxels_accel(accel: int, cam: Camera, opt: RenderOptions, num_samples, samples, cluster_indices, grid: ClusterGrid,
+                                  split_track=None, sample_track=None, sample_counts=None, tile=None, stream: int = 0) -> None:
+    """get_samples_from_voxels on the packed accel (no visit marks)."""
+    if tile is None:
+        tile = (0, 0, cam.width, cam.height)
+    _check(lib().mnv_get_samples_from_voxels_accel(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(split_track),
+                                                   _ptr(sample_track), _ptr(sample_counts), _ptr(num_samples), _ptr(samples),
+                                                   int(samples.shape[-1]), _ptr(cluster_indices), C.byref(grid), C.c_void_p(stream)))
 
 
 def render_nerf_results(tree_view: TreeView, cam: Camera, opt: RenderOptions, sample_values, z_vals, offsets, rgba=None,

@@ -160,6 +160,31 @@ __device__ __forceinline__ void sh_basis(const float vdir[3], float *out) {
     }
 }
 
+// World-space unit ray direction and the (rodrigues-rotated) view direction of pixel (ix, iy): what the sample-emitting march
+// multiplies z with and writes into the view-direction columns (renderer_kernel.cu:348-351 -> :30-38, :40-61).
+__device__ __forceinline__ void world_ray_dirs(const FrameParams &P, const CamBlock &C, int ix, int iy, float true_dir[3], float vdir[3]) {
+    const float *m = C.c2w;
+    const float xyz0 = (ix + 0.5f - C.cx) / C.fx, xyz1 = -(iy + 0.5f - C.cy) / C.fy, xyz2 = -1.0f;
+    true_dir[0] = m[0] * xyz0 + m[3] * xyz1 + m[6] * xyz2;
+    true_dir[1] = m[1] * xyz0 + m[4] * xyz1 + m[7] * xyz2;
+    true_dir[2] = m[2] * xyz0 + m[5] * xyz1 + m[8] * xyz2;
+    const float inv = 1.f / sqrtf(true_dir[0] * true_dir[0] + true_dir[1] * true_dir[1] + true_dir[2] * true_dir[2]);
+    for (int i = 0; i < 3; ++i) {
+        true_dir[i] *= inv;
+        vdir[i] = true_dir[i];
+    }
+    if (P.rot_enabled) {
+        const float *k = P.rot_k;
+        float cross[3];
+        cross[0] = k[1] * vdir[2] - k[2] * vdir[1];
+        cross[1] = k[2] * vdir[0] - k[0] * vdir[2];
+        cross[2] = k[0] * vdir[1] - k[1] * vdir[0];
+        const float dot = k[0] * vdir[0] + k[1] * vdir[1] + k[2] * vdir[2];
+        for (int i = 0; i < 3; ++i)
+            vdir[i] = (float)((double)(vdir[i] * P.rot_cos + cross[i] * P.rot_sin) + (double)(k[i] * dot) * (1.0 - (double)P.rot_cos));
+    }
+}
+
 // Per-ray constants produced by ray generation + march set-up.
 template <int NB>
 struct RaySetup {

@@ -41,27 +41,7 @@ __global__ __launch_bounds__(256) void get_samples_kernel(const SampleParams S) 
     // world-space ray for the emitted sample positions: true_dir / true_cen / vdir (renderer_kernel.cu:348-351)
     const float *m = P.cam.c2w;
     float true_dir[3], vdir[3];
-    {
-        const float xyz0 = (P.x0 + bx + 0.5f - P.cam.cx) / P.cam.fx, xyz1 = -(P.y0 + by + 0.5f - P.cam.cy) / P.cam.fy, xyz2 = -1.0f;
-        true_dir[0] = m[0] * xyz0 + m[3] * xyz1 + m[6] * xyz2;
-        true_dir[1] = m[1] * xyz0 + m[4] * xyz1 + m[7] * xyz2;
-        true_dir[2] = m[2] * xyz0 + m[5] * xyz1 + m[8] * xyz2;
-        const float inv = 1.f / sqrtf(true_dir[0] * true_dir[0] + true_dir[1] * true_dir[1] + true_dir[2] * true_dir[2]);
-        for (int i = 0; i < 3; ++i) {
-            true_dir[i] *= inv;
-            vdir[i] = true_dir[i];
-        }
-        if (P.rot_enabled) {
-            const float *k = P.rot_k;
-            float cross[3];
-            cross[0] = k[1] * vdir[2] - k[2] * vdir[1];
-            cross[1] = k[2] * vdir[0] - k[0] * vdir[2];
-            cross[2] = k[0] * vdir[1] - k[1] * vdir[0];
-            const float dot = k[0] * vdir[0] + k[1] * vdir[1] + k[2] * vdir[2];
-            for (int i = 0; i < 3; ++i)
-                vdir[i] = (float)((double)(vdir[i] * P.rot_cos + cross[i] * P.rot_sin) + (double)(k[i] * dot) * (1.0 - (double)P.rot_cos));
-        }
-    }
+    world_ray_dirs(P, P.cam, P.x0 + bx, P.y0 + by, true_dir, vdir);
 
     float sp_prio = (float)(P.max_depth + 1), sp_chunk = -1.f, sp_child = -1.f;
     float sa_prio = (float)(P.max_sample_count + 1), sa_chunk = -1.f, sa_child = -1.f;

@@ -268,6 +268,14 @@ struct AccelLaunch {
     const int16_t *sample_counts;         // reference layout [capacity][8], may be NULL
     int32_t max_depth, max_sample_count;
     int32_t ablate;                       // diagnostics only (breaks results): 1 no colour, 2 no dense samples, 4 cached rows
+    // MODE 3 only: the sample-emitting march of guided sampling (rt_core.cuh:418-576) -- no colour, rows of
+    // (z, world xyz[, view dir][, embedding]) per dense step and the trackers of MODE 2
+    int32_t max_guided_samples, samples_dim, need_viewdir, appearance_embedding;
+    int16_t *num_samples;
+    float *samples;
+    int16_t *cluster_indices;
+    int32_t grid_dim[2];
+    float min_position[3], range[3];
 };
 
 // ray id -> pixel of the rectangle (bx, by) and index of the pixel in the output buffer
@@ -319,7 +327,7 @@ struct __attribute__((packed, aligned(4))) ChanWords {
 // bit (Lq - d) of each coordinate is the child index at depth d, and the cell numbers of the two
 // lookup grids are plain shifts.  The in-leaf coordinates are fract(pos * 2^depth), which equals the
 // reference's iterated x*2 - floor(x*2) bit for bit (all three operations are exact in binary32).
-template <int BASIS, int BLOCK, int MODE /* 0 plain, 1 statistics, 2 refinement trackers */>
+template <int BASIS, int BLOCK, int MODE /* 0 plain, 1 statistics, 2 refinement trackers, 3 trackers + emitted samples instead of colour */>
 #ifndef MNV_MIN_WAVES
 #define MNV_MIN_WAVES 8  // register budget for 8 waves per SIMD: the few spills land in the ray set-up (A/B in DESIGN.md)
 #endif
@@ -377,8 +385,11 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
     // MODE 2: per-ray tracker state
     float max_weight = -1.f, max_sample_weight = -1.f, sp_prio = 0.f, sa_prio = 0.f;
     int32_t sp_vox = -1, sa_vox = -1;
+    int32_t ns = 0;  // MODE 3: samples emitted by this ray so far
+    static_assert(MODE != 3 || NB >= 6, "MODE 3 keeps the world-space ray in the LDS slots of the SH basis");
     auto write_trackers = [&](uint32_t p) {
-        if constexpr (MODE == 2) {
+        if constexpr (MODE == 3) K.num_samples[p] = (int16_t)ns;
+        if constexpr (MODE >= 2) {
             if (K.split_track) {
                 K.split_track[(int64_t)p * 3 + 0] = sp_prio;
                 K.split_track[(int64_t)p * 3 + 1] = sp_vox < 0 ? -1.f : (float)(sp_vox >> 3);
@@ -453,12 +464,13 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                     uint32_t pix;
                     if (ray_pixel(K, id, bx, by, pix)) {
                         pix += pix_base;
-                        if constexpr (MODE == 2) {
+                        if constexpr (MODE >= 2) {
                             max_weight = max_sample_weight = -1.f;
                             sp_prio = (float)(K.max_depth + 1);
                             sa_prio = (float)(K.max_sample_count + 1);
                             sp_vox = sa_vox = -1;
                         }
+                        if constexpr (MODE == 3) ns = K.num_samples[pix];
                         RaySetup<NB> r;
                         setup_ray<(BASIS > 0 ? BASIS : 0)>(P, *Cp, P.x0 + bx, P.y0 + by, r);
                         if constexpr (BASIS == 0)
@@ -471,12 +483,22 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                             tmax = r.tmax;
                             dir0 = r.dir[0]; dir1 = r.dir[1]; dir2 = r.dir[2];
                             inv0 = r.invdir[0]; inv1 = r.invdir[1]; inv2 = r.invdir[2];
+                            if constexpr (MODE == 3) {
+                                float true_dir[3], vdir[3];
+                                world_ray_dirs(P, *Cp, P.x0 + bx, P.y0 + by, true_dir, vdir);
 #pragma unroll
-                            for (int k = 0; k < NB; ++k) my_ray[k * BLOCK] = r.basis[k];
+                                for (int k = 0; k < 3; ++k) {
+                                    my_ray[k * BLOCK] = true_dir[k];
+                                    my_ray[(3 + k) * BLOCK] = vdir[k];
+                                }
+                            } else {
+#pragma unroll
+                                for (int k = 0; k < NB; ++k) my_ray[k * BLOCK] = r.basis[k];
+                            }
                             my_ray[NB * BLOCK] = r.delta_scale;
                             my_ray[(NB + 1) * BLOCK] = __uint_as_float(pix);
                         } else {
-                            composite_and_write(P, (int64_t)pix, 0.f, 0.f, 0.f, P.render_depth ? 1.f : 0.f);
+                            if constexpr (MODE != 3) composite_and_write(P, (int64_t)pix, 0.f, 0.f, 0.f, P.render_depth ? 1.f : 0.f);
                             write_trackers(pix);
                         }
                     }
@@ -500,7 +522,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                     o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
                     a = 1.f;
                 }
-                composite_and_write(P, (int64_t)__float_as_uint(my_ray[(NB + 1) * BLOCK]), o0, o1, o2, a);
+                if constexpr (MODE != 3) composite_and_write(P, (int64_t)__float_as_uint(my_ray[(NB + 1) * BLOCK]), o0, o1, o2, a);
                 write_trackers(__float_as_uint(my_ray[(NB + 1) * BLOCK]));
                 alive = false;
             } else {
@@ -553,7 +575,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                 const float sigma = half_bits_to_float((uint16_t)word);
                 const bool is_dense = sigma > P.sigma_thresh && !(K.ablate & 2);
                 bool need_vox = is_dense;
-                if constexpr (MODE == 2) need_vox = is_dense || max_weight == -1.f || max_sample_weight == -1.f;
+                if constexpr (MODE >= 2) need_vox = is_dense || max_weight == -1.f || max_sample_weight == -1.f;
                 if (need_vox) {
                     // voxel index of a leaf that was answered by one of the lookup grids
                     if (src == 0) vox = A.grid_vox[((((q[0] >> shg) << A.grid_level) + (q[1] >> shg)) << A.grid_level) + (q[2] >> shg)];
@@ -565,7 +587,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                     att = exact_expf(-delta_t * my_ray[NB * BLOCK] * sigma, s_exp);
                     weight = T * (1.f - att);
                 }
-                if constexpr (MODE == 2) {
+                if constexpr (MODE >= 2) {
                     // rt_core.cuh:237-252 (dense leaf: best weight so far) and :308-321 (first leaf before any dense one)
                     if (need_vox) {
                         const bool split_ok = depth < K.max_depth && (is_dense ? weight > max_weight : max_weight == -1.f);
@@ -584,13 +606,42 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                         }
                     }
                 }
+                if constexpr (MODE == 3) {
+                    // rt_core.cuh:508-549: one row per dense step while there is room
+                    if (is_dense && ns < K.max_guided_samples) {
+                        const uint32_t p = __float_as_uint(my_ray[(NB + 1) * BLOCK]);
+                        float *row = K.samples + ((int64_t)p * K.max_guided_samples + ns) * K.samples_dim;
+                        const float tz0 = t * dir0 / P.scale[0], tz1 = t * dir1 / P.scale[1], tz2 = t * dir2 / P.scale[2];
+                        const float z = sqrtf(tz0 * tz0 + tz1 * tz1 + tz2 * tz2);
+                        const float *m = Cp->c2w;
+                        const float wx = m[9] + my_ray[0 * BLOCK] * z, wy = m[10] + my_ray[1 * BLOCK] * z, wz = m[11] + my_ray[2 * BLOCK] * z;
+                        row[0] = z;
+                        row[1] = wx;
+                        row[2] = wy;
+                        row[3] = wz;
+                        if (K.need_viewdir) {
+                            row[4] = my_ray[3 * BLOCK];
+                            row[5] = my_ray[4 * BLOCK];
+                            row[6] = my_ray[5 * BLOCK];
+                            if (K.appearance_embedding != -1) row[7] = (float)K.appearance_embedding;
+                        } else if (K.appearance_embedding != -1) {
+                            row[4] = (float)K.appearance_embedding;
+                        }
+                        const int g1 = (int)fmaxf(fminf((wy - K.min_position[1]) / K.range[1] * (float)K.grid_dim[0], (float)K.grid_dim[0] - 1.0f), 0.0f);
+                        const int g2 = (int)fmaxf(fminf((wz - K.min_position[2]) / K.range[2] * (float)K.grid_dim[1], (float)K.grid_dim[1] - 1.0f), 0.0f);
+                        K.cluster_indices[(int64_t)p * K.max_guided_samples + ns] = (int16_t)(g1 * K.grid_dim[1] + g2);
+                        ns += 1;
+                    }
+                }
             }
         }
         // ---- colour of the dense samples of this iteration (rt_core.cuh:254-291)
         const uint64_t dense_mask = __ballot(dense);
         if (dense_mask != 0) {
             stat(8, dense);
-            if (P.render_depth) {
+            if constexpr (MODE == 3) {
+                // no colour: the networks supply it (render_nerf_results)
+            } else if (P.render_depth) {
                 if (dense) o0 += weight * t;
             } else if (K.ablate & 1) {
             } else if constexpr (BASIS >= 1) {
@@ -653,7 +704,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                     o0 *= sc;
                     o1 *= sc;
                     o2 *= sc;
-                    composite_and_write(P, (int64_t)__float_as_uint(my_ray[(NB + 1) * BLOCK]), o0, o1, o2, 1.f);
+                    if constexpr (MODE != 3) composite_and_write(P, (int64_t)__float_as_uint(my_ray[(NB + 1) * BLOCK]), o0, o1, o2, 1.f);
                     write_trackers(__float_as_uint(my_ray[(NB + 1) * BLOCK]));
                     alive = false;
                 }
@@ -703,6 +754,9 @@ static int launch_variant(const AccelLaunch &K, int n_blocks, size_t lds_bytes, 
     if constexpr (BASIS == 9) {  // MNV_STATS=1 diagnostics build of the headline variant only
         if (K.stats) return launch_variant2<BASIS, 1>(K, n_blocks, lds_bytes, stream);
     }
+    if constexpr (BASIS == 9) {  // the sample-emitting march reads no colour rows: one instantiation serves every row format
+        if (K.samples) return launch_variant2<BASIS, 3>(K, n_blocks, lds_bytes, stream);
+    }
     if (K.split_track || K.sample_track) return launch_variant2<BASIS, 2>(K, n_blocks, lds_bytes, stream);
     return launch_variant2<BASIS, 0>(K, n_blocks, lds_bytes, stream);
 }
@@ -720,6 +774,12 @@ struct AccelTrack {
     float *split_track, *sample_track;
     const int16_t *sample_counts;
     int32_t max_depth, max_sample_count;
+    // sample emission (MODE 3) when samples != NULL
+    int16_t *num_samples;
+    float *samples;
+    int16_t *cluster_indices;
+    int32_t max_guided_samples, samples_dim, need_viewdir, appearance_embedding;
+    const mnv_cluster_grid *grid;
 };
 
 int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *cams, int n_frames, mnv_partition part,
@@ -734,6 +794,20 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
         K.sample_counts = track->sample_counts;
         K.max_depth = track->max_depth;
         K.max_sample_count = track->max_sample_count;
+        if (track->samples) {
+            K.num_samples = track->num_samples;
+            K.samples = track->samples;
+            K.cluster_indices = track->cluster_indices;
+            K.max_guided_samples = track->max_guided_samples;
+            K.samples_dim = track->samples_dim;
+            K.need_viewdir = track->need_viewdir;
+            K.appearance_embedding = track->appearance_embedding;
+            for (int i = 0; i < 2; ++i) K.grid_dim[i] = track->grid->grid_dim[i];
+            for (int i = 0; i < 3; ++i) {
+                K.min_position[i] = track->grid->min_position[i];
+                K.range[i] = track->grid->range[i];
+            }
+        }
     }
     K.A = accel->view;
     K.part_rank = part.rank;
@@ -802,7 +876,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     int lds_level = accel->view.grid_level < 3 ? accel->view.grid_level : 3;  // 2 KB; level 4 (16 KB) measured equal and costs occupancy
     if (env_level >= 1 && env_level <= accel->view.grid_level) lds_level = env_level;
     K.lds_level = lds_level;
-    const int nb_lds = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim > 0) ? accel->view.basis_dim : 1;
+    const int nb_lds = K.samples ? 9 : (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim > 0) ? accel->view.basis_dim : 1;
     const size_t lds_bytes = 256 + 256 * 4 + (size_t)(nb_lds + 2) * 256 * 4 + ((size_t)4 << (3 * lds_level));
     static const int env_bpc = getenv("MNV_BLOCKS_PER_CU") ? atoi(getenv("MNV_BLOCKS_PER_CU")) : 0;
     static const int env_refill = getenv("MNV_REFILL_MIN") ? atoi(getenv("MNV_REFILL_MIN")) : 0;
@@ -818,6 +892,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     if ((uint64_t)n_blocks * 4u > n_waves_needed) n_blocks = (int)((n_waves_needed + 3) / 4);
     if (n_blocks < 1) n_blocks = 1;
 
+    if (K.samples) return launch_variant<9>(K, n_blocks, lds_bytes, stream);  // MODE 3 reads no colour rows
     const int b = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim >= 0) ? accel->view.basis_dim : -1;
     switch (b) {
         case -1: return launch_variant<-1>(K, n_blocks, lds_bytes, stream);
@@ -1113,8 +1188,39 @@ int mnv_render_voxels_accel_track(const mnv_accel *accel, const mnv_camera *cam,
     if (!split_track && !sample_track)
         return mnv_render_voxels_accel(accel, cam, opt, tile, rgba_out, rgba8_out, hip_stream);
     const mnv_partition whole = {0, 1, 0, 0};
-    const AccelTrack track = {split_track, sample_track, sample_counts, opt->max_depth, opt->max_sample_count};
+    AccelTrack track = {};
+    track.split_track = split_track;
+    track.sample_track = sample_track;
+    track.sample_counts = sample_counts;
+    track.max_depth = opt->max_depth;
+    track.max_sample_count = opt->max_sample_count;
     return render_accel(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, &track, hip_stream);
+}
+
+int mnv_get_samples_from_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                                      float *split_track, float *sample_track, const int16_t *sample_counts, int16_t *num_samples,
+                                      float *samples, int32_t samples_dim, int16_t *cluster_indices, const mnv_cluster_grid *grid,
+                                      void *hip_stream) {
+    if (!opt || !num_samples || !samples || !cluster_indices || !grid) return set_error(MNV_E_INVALID, "null argument");
+    const int need = 4 + (opt->need_viewdir ? 3 : 0) + (opt->appearance_embedding != -1 ? 1 : 0);
+    if (samples_dim != need) return set_error(MNV_E_INVALID, "samples_dim must be 4 + 3 * need_viewdir + (appearance_embedding != -1)");
+    if (opt->max_guided_samples < 1) return set_error(MNV_E_INVALID, "max_guided_samples must be positive");
+    AccelTrack track = {};
+    track.split_track = split_track;
+    track.sample_track = sample_track;
+    track.sample_counts = sample_counts;
+    track.max_depth = opt->max_depth;
+    track.max_sample_count = opt->max_sample_count;
+    track.num_samples = num_samples;
+    track.samples = samples;
+    track.cluster_indices = cluster_indices;
+    track.max_guided_samples = opt->max_guided_samples;
+    track.samples_dim = samples_dim;
+    track.need_viewdir = opt->need_viewdir ? 1 : 0;
+    track.appearance_embedding = opt->appearance_embedding;
+    track.grid = grid;
+    const mnv_partition whole = {0, 1, 0, 0};
+    return render_accel(accel, cam, 1, opt, tile, whole, nullptr, nullptr, &track, hip_stream);
 }
 
 }  // extern "C"

@@ -32,7 +32,9 @@ namespace mnv {
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int kRowsPerBlock = 256;  // 4 wavefronts x 64 rows
+constexpr int kRowsPerPass = 256;   // 4 wavefronts x 64 rows
+constexpr int kPasses = 8;          // passes of one workgroup over rows of the same cluster: the weights are staged once per 2048 rows
+constexpr int kRowsPerBlock = kRowsPerPass * kPasses;
 constexpr int kNT = 4;              // 16-row MFMA column tiles per wavefront
 constexpr int kMaxClusters = 1024;
 
@@ -237,6 +239,9 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(const MlpLaunch L) {
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, col = lane & 15;
+    const int block_first = first, block_rows = rows;
+    for (int pass_first = 0; pass_first < block_rows; pass_first += kRowsPerPass) {
+    const int first = block_first + pass_first, rows = min(kRowsPerPass, block_rows - pass_first);
     // the rows of this lane: one per column tile
     int32_t src_row[kNT];
     float p[kNT][3], d[kNT][3];
@@ -337,6 +342,7 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(const MlpLaunch L) {
                 if (f < S.out_dim) out[f] = acc[mt][nt][r];
             }
         }
+    }
     }
 }
 

@@ -336,9 +336,16 @@ void VolumeRenderer::render() {
             int16_t *clusters = I.cluster_indices.get<int16_t>(n_px * max_g);
             float *guided = I.guided_samples.get<float>((size_t)n_px * max_g * samples_dim);
             hip_check(hipMemsetAsync(num, 0, n_px * 2, I.stream), "clear num_samples");
-            mnv_check(mnv_get_samples_from_voxels(&dv, &cv, options.c_abi(), full, split, sample, visited, track_visit, num, guided, samples_dim,
-                                                  clusters, &I.grid, I.stream),
-                      "mnv_get_samples_from_voxels");
+            if (tree.device.accel && !I.accel_stale && !track_visit) {
+                stats.used_accel = true;
+                mnv_check(mnv_get_samples_from_voxels_accel(tree.device.accel, &cv, options.c_abi(), full, split, sample, tree.device.sample_counts, num,
+                                                            guided, samples_dim, clusters, &I.grid, I.stream),
+                          "mnv_get_samples_from_voxels_accel");
+            } else {
+                mnv_check(mnv_get_samples_from_voxels(&dv, &cv, options.c_abi(), full, split, sample, visited, track_visit, num, guided, samples_dim,
+                                                      clusters, &I.grid, I.stream),
+                          "mnv_get_samples_from_voxels");
+            }
             // one call in the steady state: the packed buffers keep the size of the previous frames and grow when a frame
             // emits more (the call then reports the total it needs)
             int64_t total = 0, cap_rows = (int64_t)(I.z_vals.bytes / sizeof(float));

@@ -101,3 +101,40 @@ def test_guided_pair_round_trip_reproduces_voxel_render_structure(mnv, orc, torc
     for ray in np.flatnonzero(ref["num_samples"] > 1)[:200]:
         k = ref["num_samples"][ray]
         assert np.all(np.diff(z[ray, :k]) > 0)  # samples are emitted front to back
+
+
+@pytest.mark.parametrize("case,need_viewdir,embedding", [("sh4_d6", False, -1), ("sh4_d6", True, 7), ("rgba_d5", True, -1), ("terrain_d7_aniso", False, 3),
+                                                         ("sh25_d4", True, 2)])
+def test_get_samples_on_the_packed_accel_matches_oracle(mnv, orc, torch_gpu, case, need_viewdir, embedding):
+    """mnv_get_samples_from_voxels_accel (the tuned kernel's sample-emitting mode) against the oracle, every row format."""
+    torch = torch_gpu
+    spec = cases.CASES[case]
+    tree = cases.make_tree(mnv, spec["tree"])
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    opt.need_viewdir, opt.appearance_embedding, opt.max_guided_samples = need_viewdir, embedding, 6
+    opt.max_depth, opt.max_sample_count = 5, 9
+    opt.rot_dirs[0], opt.rot_dirs[1] = 0.2, -0.1
+    dim = 4 + (3 if need_viewdir else 0) + (1 if embedding != -1 else 0)
+    v = tree.host_view()
+    sc = np.random.default_rng(4).integers(0, 14, size=(v.capacity, 8)).astype(np.int16)
+    ref = orc.get_samples(orc.tree_from_view(v, sample_counts=sc), cam.c, opt, _grid(mnv), dim)
+    tree.move_to_device()
+    sc_dev = torch.from_numpy(sc).cuda()
+    n = cam.width * cam.height
+    num = torch.zeros(n, dtype=torch.int16, device="cuda")
+    samples = torch.full((n, 6, dim), -1.0, dtype=torch.float32, device="cuda")
+    clusters = torch.full((n, 6), -1, dtype=torch.int16, device="cuda")
+    split = torch.full((n, 3), -1.0, dtype=torch.float32, device="cuda")
+    sample = torch.full((n, 3), -1.0, dtype=torch.float32, device="cuda")
+    mnv.get_samples_from_voxels_accel(tree.accel, cam, opt, num, samples, clusters, _grid(mnv), split_track=split, sample_track=sample,
+                                      sample_counts=sc_dev)
+    torch.cuda.synchronize()
+    assert np.array_equal(num.cpu().numpy(), ref["num_samples"]) and ref["num_samples"].max() >= 3
+    k = np.arange(6)[None, :] < ref["num_samples"][:, None]  # emitted rows; the rest keep the caller's fill on both sides
+    got_s, got_c = samples.cpu().numpy(), clusters.cpu().numpy()
+    assert np.array_equal(cases.bits(got_s[k]), cases.bits(ref["samples"][k])) and np.all(got_s[~k] == -1.0)
+    assert np.array_equal(got_c[k], ref["cluster_indices"][k])
+    assert np.array_equal(split.cpu().numpy(), ref["split"]) and np.array_equal(sample.cpu().numpy(), ref["sample"])
+    with pytest.raises(mnv.MnvError):
+        mnv.get_samples_from_voxels_accel(tree.accel, cam, opt, num, samples[..., :dim - 1].contiguous(), clusters, _grid(mnv))

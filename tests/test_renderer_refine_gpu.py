@@ -284,14 +284,17 @@ def test_prune_on_the_first_frame_when_the_tree_is_nearly_full(mnv, orc, torch_g
     check_tree_links(child, parent, tree.capacity)
 
 
-def test_guided_sampling_frame_matches_reference_tensor_ops(mnv, torch_gpu):
+@pytest.mark.parametrize("extra,accel_path", [(0, 0), (4000, 1)])
+def test_guided_sampling_frame_matches_reference_tensor_ops(mnv, torch_gpu, extra, accel_path):
     """use_guided_sampling: get_samples -> compaction -> networks -> composite.  The compaction is compared with the
     reference's own expressions (cuda_renderer.cpp:116-121: cumsum, boolean mask on column 0) run by torch."""
     torch = torch_gpu
-    r, tree, desc, params, cam_spec = setup(mnv, "rgba_d5", 0, use_guided_sampling=True, max_guided_samples=16)
+    # extra = 0: capacity > 3/4 max, the first frame tracks visits and samples on the reference layout; with room to grow the
+    # samples come from the packed accel (mnv_get_samples_from_voxels_accel) -- the same rows either way
+    r, tree, desc, params, cam_spec = setup(mnv, "rgba_d5", extra, use_guided_sampling=True, max_guided_samples=16)
     st = r.render()
     frame = r.download()
-    assert st["guided_samples"] > 0 and st["used_accel"] == 0
+    assert st["guided_samples"] > 0 and st["used_accel"] == accel_path
 
     cam = cases.make_camera(mnv, cam_spec)
     import ctypes as C
