@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--gather", choices=["f32", "u8"], default="u8",
                     help="pixel format rendered and gathered to rank 0 when N > 1: u8 = the reference's own output format "
                          "(RGBA8, renderer_kernel.cu:237; 8.3 MB per frame), f32 = the float RGBA the parity tests compare (33.2 MB per frame)")
-    ap.add_argument("--cpu-poses", type=int, default=4, help="poses rendered by the CPU baseline (bounded sample)")
+    ap.add_argument("--cpu-poses", type=int, default=16, help="poses rendered by the CPU baseline and compared bit for bit with the GPU frames (default: the whole 16-pose orbit, about 5 s on 128 host cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel", choices=["accel", "ref_layout"], default="accel")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
