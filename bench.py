@@ -74,6 +74,8 @@ def main():
                     help="cfg2 = BASELINE.json's headline config (default); cfg3 = merged-Mega-NeRF stand-in (anisotropic terrain, 2.7 M chunks); "
                          "cfg4 = cfg3 at 3840x2160 (configs[3], meant for --gpus 8)")
     ap.add_argument("--per-frame", action="store_true", help="one launch per pose instead of one batched launch per step")
+    ap.add_argument("--fast-colour", action="store_true",
+                    help="mnv_set_colour_math(1): hardware exp2 / rcp in the colour sigmoid (alpha and control flow stay exact; colours move ~1e-7)")
     ap.add_argument("--laps", type=int, default=4, help="the step walks the 16-pose orbit this many times (16 x laps frames in one launch, <= 64)")
     args = ap.parse_args()
     global W, H, N_FRAMES
@@ -106,6 +108,7 @@ def main():
     import cases
 
     dev = torch.device("cuda", local_rank)
+    mnv.set_colour_math(args.fast_colour)
     t_setup = time.time()
     if args.workload == "cfg2":
         tree = cases.make_tree(mnv, cases.CFG2_TREE)
@@ -209,7 +212,7 @@ def main():
         import mnv_oracle as orc
         ot = orc.tree_from_view(tree.host_view())
         n_cpu = max(1, min(args.cpu_poses, N_POSES))
-        t_cpu, max_diff, n_bad = 0.0, 0.0, 0
+        t_cpu, max_diff, n_bad, n_alpha = 0.0, 0.0, 0, 0
         fresh = {}
         for i in range(n_cpu):
             tc = time.perf_counter()
@@ -225,9 +228,11 @@ def main():
             d = np.abs(gpu - r["rgba"])
             max_diff = max(max_diff, float(d.max()))
             n_bad += int((gpu.view(np.uint32) != r["rgba"].view(np.uint32)).any(axis=-1).sum())
+            n_alpha += int((gpu[..., 3].view(np.uint32) != r["rgba"][..., 3].view(np.uint32)).sum())
         cpu_baseline = {"value": round(n_cpu * W * H / t_cpu / 1e6, 4), "unit": "Mrays/s", "cores": orc.lib().orc_num_threads(),
                         "kind": "port", "sample": f"poses 0..{n_cpu - 1} of the 16-pose orbit, full 1920x1080 frames, OpenMP over rows"}
-        parity = {"max_abs_drgba_vs_oracle": max_diff, "pixels_not_bit_identical": n_bad, "frames_checked": n_cpu}
+        parity = {"max_abs_drgba_vs_oracle": max_diff, "pixels_not_bit_identical": n_bad, "frames_checked": n_cpu,
+                  "alpha_not_bit_identical": n_alpha, "colour_math": "fast" if args.fast_colour else "exact"}
         if counters is None:
             counters = {"poses": fresh, "partial": True}
     if rank == 0 and world > 1 and not args.no_cpu_baseline:

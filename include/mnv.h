@@ -183,6 +183,16 @@ int mnv_render_voxels_accel_part(const mnv_accel *accel, const mnv_camera *cam, 
                                  void *hip_stream);
 
 /*
+ * Colour arithmetic of the tuned SH march (process-wide, default 0).  0: every value is computed exactly as the arithmetic
+ * specification says and frames are bit-identical to the oracle.  1: the colour sigmoid
+ * weight / (1 + exp(-dot)) uses the hardware exp2 and reciprocal (about 1 ulp each).  Opacity, transmittance, step sizes and
+ * every branch stay exact -- SURVEY.md section 7: colour-only arithmetic is continuous and feeds no control flow -- so alpha and
+ * the step sequence are unchanged and colours move by ~1e-7 (bound asserted in the tests: 2e-6; contract 1e-4).
+ * Trackers, sample emission, depth mode and RGBA-format trees are unaffected.
+ */
+void mnv_set_colour_math(int fast);
+
+/*
  * The un-permute step on the gathering rank: `gathered` is what the RCCL gather of the ranks'
  * compact buffers produces, [world][n_frames][ceil(macro tiles / world)][tile_h][tile_w] pixels (n_frames = 1 for
  * mnv_render_voxels_accel_part), `frames` receives [n_frames][height][width] pixels.  bytes_per_pixel: 4 (RGBA8) or

@@ -196,6 +196,7 @@ _SIGNATURES = {
     "mnv_partition_local_tiles": (C.c_int32, [Rect, Partition]),
     "mnv_render_voxels_accel_part": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, Partition,
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mnv_set_colour_math": (None, [C.c_int]),
     "mnv_assemble_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, Partition, C.c_int32, C.c_int32, C.c_void_p]),
     "mnv_render_voxels_accel_batch": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.c_int32, C.POINTER(RenderOptions), Rect,
                                                 Partition, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -504,6 +505,11 @@ def render_voxels_accel_track(accel: int, cam: Camera, opt: RenderOptions, tile=
     _check(lib().mnv_render_voxels_accel_track(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba),
                                                _ptr(rgba8), _ptr(split_track), _ptr(sample_track), _ptr(sample_counts),
                                                C.c_void_p(stream)))
+
+
+def set_colour_math(fast: bool) -> None:
+    """False (default): bit-identical to the oracle.  True: hardware exp2 / rcp in the colour sigmoid (colours move ~1e-7)."""
+    lib().mnv_set_colour_math(int(bool(fast)))
 
 
 def assemble_tiles(gathered, frames, width: int, height: int, world: int, tile_w: int, tile_h: int, n_frames: int = 1, stream: int = 0) -> None:

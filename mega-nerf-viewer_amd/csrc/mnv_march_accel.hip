@@ -327,7 +327,7 @@ struct __attribute__((packed, aligned(4))) ChanWords {
 // bit (Lq - d) of each coordinate is the child index at depth d, and the cell numbers of the two
 // lookup grids are plain shifts.  The in-leaf coordinates are fract(pos * 2^depth), which equals the
 // reference's iterated x*2 - floor(x*2) bit for bit (all three operations are exact in binary32).
-template <int BASIS, int BLOCK, int MODE /* 0 plain, 1 statistics, 2 refinement trackers, 3 trackers + emitted samples instead of colour */>
+template <int BASIS, int BLOCK, int MODE /* 0 plain, 1 statistics, 2 refinement trackers, 3 trackers + emitted samples instead of colour, 4 plain with fast colour math */>
 #ifndef MNV_MIN_WAVES
 #define MNV_MIN_WAVES 8  // register budget for 8 waves per SIMD: the few spills land in the ray set-up (A/B in DESIGN.md)
 #endif
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
     static_assert(MODE != 3 || NB >= 6, "MODE 3 keeps the world-space ray in the LDS slots of the SH basis");
     auto write_trackers = [&](uint32_t p) {
         if constexpr (MODE == 3) K.num_samples[p] = (int16_t)ns;
-        if constexpr (MODE >= 2) {
+        if constexpr (MODE == 2 || MODE == 3) {
             if (K.split_track) {
                 K.split_track[(int64_t)p * 3 + 0] = sp_prio;
                 K.split_track[(int64_t)p * 3 + 1] = sp_vox < 0 ? -1.f : (float)(sp_vox >> 3);
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                     uint32_t pix;
                     if (ray_pixel(K, id, bx, by, pix)) {
                         pix += pix_base;
-                        if constexpr (MODE >= 2) {
+                        if constexpr (MODE == 2 || MODE == 3) {
                             max_weight = max_sample_weight = -1.f;
                             sp_prio = (float)(K.max_depth + 1);
                             sa_prio = (float)(K.max_sample_count + 1);
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                 const float sigma = half_bits_to_float((uint16_t)word);
                 const bool is_dense = sigma > P.sigma_thresh && !(K.ablate & 2);
                 bool need_vox = is_dense;
-                if constexpr (MODE >= 2) need_vox = is_dense || max_weight == -1.f || max_sample_weight == -1.f;
+                if constexpr (MODE == 2 || MODE == 3) need_vox = is_dense || max_weight == -1.f || max_sample_weight == -1.f;
                 if (need_vox) {
                     // voxel index of a leaf that was answered by one of the lookup grids
                     if (src == 0) vox = A.grid_vox[((((q[0] >> shg) << A.grid_level) + (q[1] >> shg)) << A.grid_level) + (q[2] >> shg)];
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                     att = exact_expf(-delta_t * my_ray[NB * BLOCK] * sigma, s_exp);
                     weight = T * (1.f - att);
                 }
-                if constexpr (MODE >= 2) {
+                if constexpr (MODE == 2 || MODE == 3) {
                     // rt_core.cuh:237-252 (dense leaf: best weight so far) and :308-321 (first leaf before any dense one)
                     if (need_vox) {
                         const bool split_ok = depth < K.max_depth && (is_dense ? weight > max_weight : max_weight == -1.f);
@@ -674,7 +674,14 @@ __global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const
                             return half_bits_to_float((uint16_t)((k & 1) ? (wd >> 16) : (wd & 0xffffu)));
                         };
                         const float tmp = sh_channel<BASIS>(b, coef, 0);
-                        v = w / (1.f + exact_expf(-tmp, s_exp));
+                        if constexpr (MODE == 4) {
+                            // colour-only arithmetic: it feeds no branch (opacity, transmittance and the step sequence stay exact),
+                            // so hardware exp2 / rcp (about 1 ulp each) move a colour by ~1e-7 and nothing else
+                            const float e = __builtin_amdgcn_exp2f(tmp * -1.44269504088896341f);
+                            v = w * __builtin_amdgcn_rcpf(1.f + e);
+                        } else {
+                            v = w / (1.f + exact_expf(-tmp, s_exp));
+                        }
                     }
                     const int rl = rank - base;
                     const bool mine = dense && rl >= 0 && rl < 21;
@@ -735,6 +742,9 @@ __global__ void assemble_tiles_kernel(const PIXEL *__restrict__ gathered, PIXEL 
 
 static int row_bytes_for(int basis) { return row_bytes_pow2(basis); }
 
+// mnv_set_colour_math: 0 = exact (bit-identical to the oracle, default), 1 = hardware exp2 / rcp in the colour sigmoid
+static std::atomic<int> g_fast_colour{0};
+
 template <int BASIS, int MODE>
 static int launch_variant2(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
     constexpr int BLOCK = 256;
@@ -758,6 +768,9 @@ static int launch_variant(const AccelLaunch &K, int n_blocks, size_t lds_bytes, 
         if (K.samples) return launch_variant2<BASIS, 3>(K, n_blocks, lds_bytes, stream);
     }
     if (K.split_track || K.sample_track) return launch_variant2<BASIS, 2>(K, n_blocks, lds_bytes, stream);
+    if constexpr (BASIS >= 1) {
+        if (g_fast_colour.load(std::memory_order_relaxed)) return launch_variant2<BASIS, 4>(K, n_blocks, lds_bytes, stream);
+    }
     return launch_variant2<BASIS, 0>(K, n_blocks, lds_bytes, stream);
 }
 
@@ -1111,6 +1124,8 @@ void mnv_accel_destroy(mnv_accel *a) {
 size_t mnv_accel_device_bytes(const mnv_accel *a) { return a ? a->bytes : 0; }
 
 int32_t mnv_partition_local_tiles(mnv_rect tile, mnv_partition part) { return partition_local_tiles(tile, part); }
+
+void mnv_set_colour_math(int fast) { g_fast_colour.store(fast ? 1 : 0, std::memory_order_relaxed); }
 
 int mnv_assemble_tiles(const void *gathered, void *frames, int32_t width, int32_t height, mnv_partition part, int32_t n_frames,
                        int32_t bytes_per_pixel, void *hip_stream) {

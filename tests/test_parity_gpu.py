@@ -445,3 +445,33 @@ def test_trackers_match_reference_device_code_goldens(mnv, torch_gpu, name):
     for got, want in ((split, "split"), (sample, "sample"), (split2, "split"), (sample2, "sample")):
         assert np.array_equal(got.cpu().numpy(), z[want])
     assert np.array_equal(visited.cpu().numpy(), z["visited"])
+
+
+@pytest.mark.parametrize("name", ["sh4_d6", "sh9_d7_aniso", "shell_d7_sh9", "sh25_d4", "thresholds", "rgba_d5"])
+def test_fast_colour_math_keeps_alpha_and_control_flow_exact(mnv, orc, torch_gpu, name):
+    """mnv_set_colour_math(1): hardware exp2 / rcp in the colour sigmoid only.  Alpha (hence every opacity, transmittance and
+    early-stop decision) stays bit-identical to the oracle; colours stay within 2e-6 (contract: 1e-4)."""
+    torch = torch_gpu
+    spec = cases.CASES[name]
+    tree = cases.make_tree(mnv, spec["tree"])
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    ref = orc.render(orc.tree_from_view(tree.host_view()), cam.c, opt)["rgba"]
+    tree.move_to_device()
+    out = torch.empty((cam.height, cam.width, 4), dtype=torch.float32, device="cuda")
+    mnv.set_colour_math(True)
+    try:
+        mnv.render_voxels_accel(tree.accel, cam, opt, rgba=out)
+        torch.cuda.synchronize()
+    finally:
+        mnv.set_colour_math(False)
+    got = out.cpu().numpy()
+    assert np.array_equal(cases.bits(got[..., 3]), cases.bits(ref[..., 3]))
+    assert np.abs(got[..., :3] - ref[..., :3]).max() <= 2e-6
+    if name != "rgba_d5":  # RGBA rows have no sigmoid: nothing changes there
+        assert not np.array_equal(cases.bits(got), cases.bits(ref))
+    else:
+        assert np.array_equal(cases.bits(got), cases.bits(ref))
+    mnv.render_voxels_accel(tree.accel, cam, opt, rgba=out)  # back in exact mode: bit-identical again
+    torch.cuda.synchronize()
+    assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref))
