@@ -36,6 +36,7 @@ void apply_zip64_extra(const uint8_t *extra, size_t len, uint64_t &usize, uint64
     size_t i = 0;
     while (i + 4 <= len) {
         const uint16_t id = rd16(extra + i), sz = rd16(extra + i + 2);
+        if (i + 4 + (size_t)sz > len) return;  // record runs past the block: ignore it
         if (id == 0x0001) {
             const uint8_t *q = extra + i + 4;
             size_t left = sz;
@@ -102,10 +103,18 @@ Array parse_npy(const uint8_t *buf, size_t len) {
         if (i >= shape.size() || shape[i] == ')') break;
         char *end = nullptr;
         a.shape.push_back((size_t)std::strtoull(shape.c_str() + i, &end, 10));
+        if (end == shape.c_str() + i) throw std::runtime_error("npy: malformed shape " + shape);
         i = (size_t)(end - shape.c_str());
     }
-    const size_t nbytes = a.num_vals() * a.word_size;
-    if (hoff + hlen + nbytes > len) throw std::runtime_error("npy: truncated payload");
+    // element count and byte size with overflow checks: a header must not describe more than the payload holds
+    const size_t payload = len - hoff - hlen;
+    size_t nbytes = a.word_size;
+    if (a.word_size == 0) throw std::runtime_error("npy: unsupported descr " + descr);
+    for (size_t dim : a.shape) {
+        if (dim != 0 && nbytes > payload / dim) throw std::runtime_error("npy: truncated payload");
+        nbytes *= dim;
+    }
+    if (nbytes > payload) throw std::runtime_error("npy: truncated payload");
     a.bytes.assign(buf + hoff + hlen, buf + hoff + hlen + nbytes);
     return a;
 }
@@ -138,6 +147,7 @@ Archive load(const std::string &path) {
         cd_size = rd64(rec + 40);
         cd_off = rd64(rec + 48);
     }
+    if (cd_off > fsize || cd_size > fsize - cd_off) throw std::runtime_error("npz: central directory lies outside the file");
     std::vector<uint8_t> cd(cd_size);
     f.read_at(cd_off, cd.data(), cd_size);
 
@@ -149,14 +159,20 @@ Archive load(const std::string &path) {
         uint64_t csize = rd32(cd.data() + p + 20), usize = rd32(cd.data() + p + 24);
         const uint16_t nlen = rd16(cd.data() + p + 28), xlen = rd16(cd.data() + p + 30), clen = rd16(cd.data() + p + 32);
         uint64_t lho = rd32(cd.data() + p + 42);
+        if (p + 46 + (size_t)nlen + xlen + clen > cd.size()) throw std::runtime_error("npz: bad central directory");
         std::string name(reinterpret_cast<const char *>(cd.data() + p + 46), nlen);
         apply_zip64_extra(cd.data() + p + 46 + nlen, xlen, usize, csize, lho);
         p += 46 + (size_t)nlen + xlen + clen;
 
         uint8_t lh[30];
+        if (lho > fsize || fsize - lho < sizeof(lh)) throw std::runtime_error("npz: local header lies outside the file for " + name);
         f.read_at(lho, lh, sizeof(lh));
         if (rd32(lh) != 0x04034b50u) throw std::runtime_error("npz: bad local header for " + name);
         const uint64_t data_off = lho + 30 + rd16(lh + 26) + rd16(lh + 28);
+        // sizes come from the file: a member cannot be longer than the file, and deflate expands by at most 1032:1
+        if (data_off > fsize || csize > fsize - data_off) throw std::runtime_error("npz: member data lies outside the file for " + name);
+        if ((method == 0 && usize != csize) || (method == 8 && usize / 1032 > csize + 1))
+            throw std::runtime_error("npz: implausible member size for " + name);
 
         std::vector<uint8_t> raw(usize);
         if (method == 0) {
