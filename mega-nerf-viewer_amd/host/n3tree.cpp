@@ -79,6 +79,13 @@ void N3Tree::open(const std::string &path) {
     const size_t cap = ch.shape[0];
     if (ch.num_vals() != cap * (size_t)N3_) throw std::runtime_error("child has unexpected shape");
     child.assign(ch.data<int32_t>(), ch.data<int32_t>() + cap * N3_);
+    // the device kernels follow these links without bounds checks (as the reference's do): refuse a file whose child
+    // offsets leave the tree instead of faulting on the GPU later
+    for (size_t v = 0; v < child.size(); ++v) {
+        if (child[v] == 0) continue;
+        const int64_t target = (int64_t)(v / N3_) + child[v];
+        if (target <= 0 || target >= (int64_t)cap) throw std::runtime_error("child offset points outside the tree");
+    }
 
     const npz::Array &pd = need(z, "parent_depth");
     if (pd.word_size != 4 || pd.shape.size() != 2 || pd.shape[1] != 2) throw std::runtime_error("parent_depth must be int32 [cap,2]");
