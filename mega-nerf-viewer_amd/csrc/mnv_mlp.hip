@@ -242,27 +242,32 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(const MlpLaunch L) {
     const int block_first = first, block_rows = rows;
     for (int pass_first = 0; pass_first < block_rows; pass_first += kRowsPerPass) {
     const int first = block_first + pass_first, rows = min(kRowsPerPass, block_rows - pass_first);
-    // the rows of this lane: one per column tile
+    // Two roles per lane.  Encoding: lane L owns sample L of the wavefront (one row load, features evaluated with a
+    // wave-uniform feature index, so the index arithmetic is scalar).  Matrix operand / output: lane (g, col) serves the
+    // samples col + 16 nt.  The encoded half pairs cross over through a 4 KB per-wavefront LDS tile per K tile.
     int32_t src_row[kNT];
-    float p[kNT][3], d[kNT][3];
-    const uint16_t *emb[kNT];
 #pragma unroll
     for (int nt = 0; nt < kNT; ++nt) {
         const int local = wave * 64 + nt * 16 + col;
         src_row[nt] = local < rows ? L.order[first + local] : -1;
-        const float *x = L.samples + (int64_t)(src_row[nt] < 0 ? L.order[first] : src_row[nt]) * L.samples_stride;
+    }
+    float p[3], d[3];
+    const uint16_t *emb = nullptr;
+    {
+        const int local = wave * 64 + lane;
+        const float *x = L.samples + (int64_t)L.order[first + (local < rows ? local : 0)] * L.samples_stride;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            p[nt][i] = (x[i] - S.center[i]) * S.inv_extent[i];
-            d[nt][i] = S.need_viewdir ? x[3 + i] : 0.f;
+            p[i] = (x[i] - S.center[i]) * S.inv_extent[i];
+            d[i] = S.need_viewdir ? x[3 + i] : 0.f;
         }
-        emb[nt] = nullptr;
         if (S.n_embeddings > 0) {
             int idx = (int)x[S.need_viewdir ? 6 : 3];
             idx = idx < 0 ? 0 : (idx >= S.n_embeddings ? S.n_embeddings - 1 : idx);
-            emb[nt] = L.embeddings + ((size_t)cluster * S.n_embeddings + idx) * S.embedding_dim;
+            emb = L.embeddings + ((size_t)cluster * S.n_embeddings + idx) * S.embedding_dim;
         }
     }
+    uint32_t *s_enc = reinterpret_cast<uint32_t *>(lds + (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4) + wave * (16 * 64);
 
     f32x4 acc[MT][kNT];
     const half8 *w = s_frag;
@@ -281,18 +286,37 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(const MlpLaunch L) {
     load_bias(MT);
     const int emb_base = S.n_pos + S.n_dir;
     for (int kk = 0; kk < S.nkk0; ++kk) {
+        // encode features [32 kk, 32 kk + 32) of this lane's sample: pair (f, f + 1) -> dword ((g * 4 + e / 2) * 64 + lane) of the tile,
+        // where (g, e) is the K slot of feature f in the MFMA operand (slot_feature)
+        for (int f2 = 0; f2 < 16; ++f2) {
+            const int r = 2 * f2, f = 32 * kk + r;  // wave-uniform
+            float v0, v1;
+            if (f >= emb_base && f < S.in_dim) v0 = half_bits_to_float(emb[f - emb_base]);
+            else v0 = encode_feature(S, f, p, d);
+            if (f + 1 >= emb_base && f + 1 < S.in_dim) v1 = half_bits_to_float(emb[f + 1 - emb_base]);
+            else v1 = encode_feature(S, f + 1, p, d);
+            const int fg = (r & 15) >> 2, fe = (r >> 4) * 4 + (r & 3);
+            union {
+                _Float16 h[2];
+                uint32_t u;
+            } pk;
+            pk.h[0] = (_Float16)v0;
+            pk.h[1] = (_Float16)v1;
+            s_enc[(fg * 4 + (fe >> 1)) * 64 + lane] = pk.u;
+        }
+        __builtin_amdgcn_wave_barrier();  // LDS executes a wavefront's accesses in order; this only pins the compiler's order
         half8 bf[kNT];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int f = slot_feature(kk, g, e);
+        for (int nt = 0; nt < kNT; ++nt) {
+            union {
+                uint32_t u[4];
+                half8 h;
+            } rd;
 #pragma unroll
-            for (int nt = 0; nt < kNT; ++nt) {
-                float v;
-                if (f >= emb_base && f < S.in_dim) v = half_bits_to_float(emb[nt][f - emb_base]);
-                else v = encode_feature(S, f, p[nt], d[nt]);
-                bf[nt][e] = (_Float16)v;
-            }
+            for (int q = 0; q < 4; ++q) rd.u[q] = s_enc[(g * 4 + q) * 64 + nt * 16 + col];
+            bf[nt] = rd.h;
         }
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const half8 a = w[(mt * S.nkk0 + kk) * 64 + lane];
@@ -433,8 +457,8 @@ int mnv_mlp_create(const mnv_mlp_desc *desc, const uint16_t *params, size_t n_ha
     if (rc) return rc;
     const size_t per_cluster = param_count(S);
     if (n_halfs != per_cluster * S.n_clusters) return set_error(MNV_E_INVALID, "parameter blob has the wrong size (see mnv_mlp_param_count)");
-    const size_t lds_bytes = (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4;
-    if (lds_bytes > 150 * 1024) return set_error(MNV_E_UNSUPPORTED, "network does not fit the 160 KB LDS of a CU");
+    const size_t lds_bytes = (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4 + 4 * 16 * 64 * 4;
+    if (lds_bytes > 160 * 1024) return set_error(MNV_E_UNSUPPORTED, "network does not fit the 160 KB LDS of a CU (weights of all layers + 16 KB of encode tiles)");
     int dev = 0;
     hipDeviceProp_t prop;
     if ((rc = check_hip(hipGetDevice(&dev), "hipGetDevice"))) return rc;
@@ -543,7 +567,7 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
     L.order = order;
     L.seg_start = seg_start;
     L.tile_start = tile_start;
-    const size_t lds_bytes = (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4;
+    const size_t lds_bytes = (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4 + 4 * 16 * 64 * 4;  // + the encode tiles of the 4 wavefronts
     if (S.hidden_width == 64) {
         auto kern = mlp_forward_kernel<4>;
         if ((rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "lds attr"))) return rc;

@@ -17,7 +17,8 @@ CONFIGS = {
     "w64_l1_min": dict(n_clusters=1, pos_octaves=0, hidden_width=64, hidden_layers=1, out_dim=1),
     "w64_l3_dir_emb_sh9": dict(n_clusters=8, pos_octaves=10, dir_octaves=4, need_viewdir=True, n_embeddings=12, embedding_dim=16,
                                hidden_width=64, hidden_layers=3, out_dim=29, inv_extent=(0.25, 0.25, 0.25)),
-    "w128_l4_dir_sh16": dict(n_clusters=5, pos_octaves=12, dir_octaves=4, need_viewdir=True, hidden_width=128, hidden_layers=4, out_dim=50),
+    "w128_l3_dir_sh16": dict(n_clusters=5, pos_octaves=12, dir_octaves=4, need_viewdir=True, hidden_width=128, hidden_layers=3, out_dim=50),
+    "w128_l4_dir_sh9": dict(n_clusters=3, pos_octaves=10, dir_octaves=4, need_viewdir=True, hidden_width=128, hidden_layers=4, out_dim=29),
     "w128_l2_out128": dict(n_clusters=2, pos_octaves=2, hidden_width=128, hidden_layers=2, out_dim=128),
 }
 
@@ -54,6 +55,7 @@ def test_mlp_matches_cpu_restatement(mnv, orc, torch_gpu, name):
 
 
 def test_mlp_rejects_bad_descriptions(mnv, torch_gpu):
+    big = dict(pos_octaves=12, dir_octaves=4, need_viewdir=True, hidden_width=128, hidden_layers=5, out_dim=50)  # 194 KB of weights
     for bad in (dict(hidden_width=96), dict(out_dim=65), dict(n_clusters=0), dict(hidden_layers=0), dict(n_embeddings=4, embedding_dim=0)):
         desc = mnv.mlp_desc(**bad)
         assert mnv.Mlp.param_count(desc) == 0
@@ -62,3 +64,6 @@ def test_mlp_rejects_bad_descriptions(mnv, torch_gpu):
     desc = mnv.mlp_desc()
     with pytest.raises(mnv.MnvError):
         mnv.Mlp(desc, np.zeros(mnv.Mlp.param_count(desc) + 1, np.float16))  # wrong blob size
+    desc = mnv.mlp_desc(**big)
+    with pytest.raises(mnv.MnvError, match="LDS"):
+        mnv.Mlp(desc, np.zeros(mnv.Mlp.param_count(desc), np.float16))  # does not fit the CU's LDS
