@@ -328,10 +328,13 @@ struct __attribute__((packed, aligned(4))) ChanWords {
 // lookup grids are plain shifts.  The in-leaf coordinates are fract(pos * 2^depth), which equals the
 // reference's iterated x*2 - floor(x*2) bit for bit (all three operations are exact in binary32).
 template <int BASIS, int BLOCK, int MODE /* 0 plain, 1 statistics, 2 refinement trackers, 3 trackers + emitted samples instead of colour, 4 plain with fast colour math */>
+#ifndef MNV_TRACK_WAVES
+#define MNV_TRACK_WAVES 6  // tracker / sample modes carry six more live values per ray
+#endif
 #ifndef MNV_MIN_WAVES
 #define MNV_MIN_WAVES 8  // register budget for 8 waves per SIMD: the few spills land in the ray set-up (A/B in DESIGN.md)
 #endif
-__global__ __launch_bounds__(BLOCK, MNV_MIN_WAVES) void march_accel_kernel(const AccelLaunch K) {
+__global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES : MNV_MIN_WAVES) void march_accel_kernel(const AccelLaunch K) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     uint64_t *s_exp = reinterpret_cast<uint64_t *>(s_mem);  // 32 x 8 B
     uint32_t *s_map = s_mem + 64;                            // BLOCK words: dense-sample rank -> lane, per wavefront
@@ -899,6 +902,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     K.stats = env_stats ? accel->stats : nullptr;
     K.refill_min = env_refill > 0 ? env_refill : 64;  // sweep in DESIGN.md: 16 -> 0.606 ms, 32 -> 0.535, 48 -> 0.507, 56 -> 0.504, 64 -> 0.506
     int blocks_per_cu = lds_level >= 5 ? 1 : (lds_level == 4 ? 6 : 8);
+    if ((K.split_track || K.sample_track || K.samples) && blocks_per_cu > MNV_TRACK_WAVES) blocks_per_cu = MNV_TRACK_WAVES;
     if (env_bpc > 0) blocks_per_cu = env_bpc;
     int n_blocks = accel->num_cus * blocks_per_cu;
     const uint64_t n_waves_needed = (uint64_t)K.n_tiles * (uint64_t)n_frames;  // one initial 8x8 tile per wave
