@@ -327,7 +327,7 @@ struct __attribute__((packed, aligned(4))) ChanWords {
 // bit (Lq - d) of each coordinate is the child index at depth d, and the cell numbers of the two
 // lookup grids are plain shifts.  The in-leaf coordinates are fract(pos * 2^depth), which equals the
 // reference's iterated x*2 - floor(x*2) bit for bit (all three operations are exact in binary32).
-template <int BASIS, int BLOCK, int MODE /* 0 plain, 1 statistics, 2 refinement trackers, 3 trackers + emitted samples instead of colour, 4 plain with fast colour math */>
+template <int BASIS, int BLOCK, int MODE /* 0 plain, 1 statistics, 2 refinement trackers, 3 trackers + emitted samples instead of colour, 4 plain with fast colour math, 5 depth image (render_depth) */>
 #ifndef MNV_TRACK_WAVES
 #define MNV_TRACK_WAVES 6  // tracker / sample modes carry six more live values per ray
 #endif
@@ -339,6 +339,18 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
     uint64_t *s_exp = reinterpret_cast<uint64_t *>(s_mem);  // 32 x 8 B
     uint32_t *s_map = s_mem + 64;                            // BLOCK words: dense-sample rank -> lane, per wavefront
     constexpr int NB = BASIS > 0 ? BASIS : 1;
+    // Uniform switches cost scalar registers in the hot loop (the kernel runs at the 80-SGPR limit of 8 workgroups per CU, and
+    // what does not fit is parked in VGPR lanes and read back with VALU instructions): the colour kernels (MODE 0 / 4) carry
+    // neither the depth-image switch nor the diagnostics word.
+    auto depth_mode = [&]() -> bool {
+        if constexpr (MODE == 0 || MODE == 4) return false;
+        else if constexpr (MODE == 5) return true;
+        else return K.P.render_depth != 0;
+    };
+    auto ablate = [&](int bit) -> bool {
+        if constexpr (MODE == 1) return (K.ablate & bit) != 0;
+        else return false;
+    };
     // per-lane ray constants that only the dense-sample / finish code needs live in LDS, not in VGPRs:
     // [k][thread] for k < NB: SH basis; then delta_scale and the output pixel index
     float *s_ray = reinterpret_cast<float *>(s_mem + 64 + BLOCK);
@@ -501,7 +513,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                             my_ray[NB * BLOCK] = r.delta_scale;
                             my_ray[(NB + 1) * BLOCK] = __uint_as_float(pix);
                         } else {
-                            if constexpr (MODE != 3) composite_and_write(P, (int64_t)pix, 0.f, 0.f, 0.f, P.render_depth ? 1.f : 0.f);
+                            if constexpr (MODE != 3) composite_and_write(P, (int64_t)pix, 0.f, 0.f, 0.f, depth_mode() ? 1.f : 0.f);
                             write_trackers(pix);
                         }
                     }
@@ -521,7 +533,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
             if (!(t < tmax)) {
                 // loop exit, rt_core.cuh:325-330
                 float a = 1.f - T;
-                if (P.render_depth) {
+                if (depth_mode()) {
                     o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
                     a = 1.f;
                 }
@@ -576,7 +588,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                 }
                 delta_t = tu * inv_cube + P.step_size;
                 const float sigma = half_bits_to_float((uint16_t)word);
-                const bool is_dense = sigma > P.sigma_thresh && !(K.ablate & 2);
+                const bool is_dense = sigma > P.sigma_thresh && !ablate(2);
                 bool need_vox = is_dense;
                 if constexpr (MODE == 2 || MODE == 3) need_vox = is_dense || max_weight == -1.f || max_sample_weight == -1.f;
                 if (need_vox) {
@@ -644,9 +656,9 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
             stat(8, dense);
             if constexpr (MODE == 3) {
                 // no colour: the networks supply it (render_nerf_results)
-            } else if (P.render_depth) {
+            } else if (depth_mode()) {
                 if (dense) o0 += weight * t;
-            } else if (K.ablate & 1) {
+            } else if (ablate(1)) {
             } else if constexpr (BASIS >= 1) {
                 // SH: the wavefront evaluates the samples cooperatively, one lane per (sample, channel):
                 // 21 samples x 3 channels per pass.  Each task lane pulls the sample's weight, voxel and
@@ -664,7 +676,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                     const int owner = task ? (int)map[smp] : lane;
                     const float w = lane_read(weight, owner);
                     uint32_t vx = lane_read(vox, owner);
-                    if (K.ablate & 4) vx &= 0xffffu;  // diagnostics: rows served from cache (wrong colours)
+                    if (ablate(4)) vx &= 0xffffu;  // diagnostics: rows served from cache (wrong colours)
                     float b[NB];
 #pragma unroll
                     for (int k = 0; k < NB; ++k) b[k] = wave_ray[k * BLOCK + owner];  // the owner's SH basis, from LDS
@@ -709,7 +721,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
             if (dense) {
                 T *= att;  // rt_core.cuh:293-307
                 if (T < P.stop_thresh) {
-                    if (P.render_depth) o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
+                    if (depth_mode()) o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
                     const float sc = 1.f / (1.f - T);
                     o0 *= sc;
                     o1 *= sc;
@@ -764,13 +776,16 @@ static int launch_variant2(const AccelLaunch &K, int n_blocks, size_t lds_bytes,
 
 template <int BASIS>
 static int launch_variant(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
-    if constexpr (BASIS == 9) {  // MNV_STATS=1 diagnostics build of the headline variant only
+    if constexpr (BASIS == 9) {  // MNV_STATS=1 / MNV_ABLATE diagnostics build of the headline variant only
         if (K.stats) return launch_variant2<BASIS, 1>(K, n_blocks, lds_bytes, stream);
     }
     if constexpr (BASIS == 9) {  // the sample-emitting march reads no colour rows: one instantiation serves every row format
         if (K.samples) return launch_variant2<BASIS, 3>(K, n_blocks, lds_bytes, stream);
     }
     if (K.split_track || K.sample_track) return launch_variant2<BASIS, 2>(K, n_blocks, lds_bytes, stream);
+    if constexpr (BASIS == 9) {  // the depth image reads no colour rows either
+        if (K.P.render_depth) return launch_variant2<BASIS, 5>(K, n_blocks, lds_bytes, stream);
+    }
     if constexpr (BASIS >= 1) {
         if (g_fast_colour.load(std::memory_order_relaxed)) return launch_variant2<BASIS, 4>(K, n_blocks, lds_bytes, stream);
     }
@@ -892,14 +907,16 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     int lds_level = accel->view.grid_level < 3 ? accel->view.grid_level : 3;  // 2 KB; level 4 (16 KB) measured equal and costs occupancy
     if (env_level >= 1 && env_level <= accel->view.grid_level) lds_level = env_level;
     K.lds_level = lds_level;
-    const int nb_lds = K.samples ? 9 : (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim > 0) ? accel->view.basis_dim : 1;
+    // sample emission and the depth image read no colour rows: one instantiation (BASIS 9) serves every row format
+    const bool colourless = K.samples != nullptr || (P.render_depth && !K.split_track && !K.sample_track);
+    const int nb_lds = colourless ? 9 : (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim > 0) ? accel->view.basis_dim : 1;
     const size_t lds_bytes = 256 + 256 * 4 + (size_t)(nb_lds + 2) * 256 * 4 + ((size_t)4 << (3 * lds_level));
     static const int env_bpc = getenv("MNV_BLOCKS_PER_CU") ? atoi(getenv("MNV_BLOCKS_PER_CU")) : 0;
     static const int env_refill = getenv("MNV_REFILL_MIN") ? atoi(getenv("MNV_REFILL_MIN")) : 0;
     static const int env_ablate = getenv("MNV_ABLATE") ? atoi(getenv("MNV_ABLATE")) : 0;
     K.ablate = env_ablate;
     static const bool env_stats = getenv("MNV_STATS") != nullptr;
-    K.stats = env_stats ? accel->stats : nullptr;
+    K.stats = (env_stats || env_ablate) ? accel->stats : nullptr;  // both run on the diagnostics instantiation
     K.refill_min = env_refill > 0 ? env_refill : 64;  // sweep in DESIGN.md: 16 -> 0.606 ms, 32 -> 0.535, 48 -> 0.507, 56 -> 0.504, 64 -> 0.506
     int blocks_per_cu = lds_level >= 5 ? 1 : (lds_level == 4 ? 6 : 8);
     if ((K.split_track || K.sample_track || K.samples) && blocks_per_cu > MNV_TRACK_WAVES) blocks_per_cu = MNV_TRACK_WAVES;
@@ -909,7 +926,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     if ((uint64_t)n_blocks * 4u > n_waves_needed) n_blocks = (int)((n_waves_needed + 3) / 4);
     if (n_blocks < 1) n_blocks = 1;
 
-    if (K.samples) return launch_variant<9>(K, n_blocks, lds_bytes, stream);  // MODE 3 reads no colour rows
+    if (colourless) return launch_variant<9>(K, n_blocks, lds_bytes, stream);
     const int b = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim >= 0) ? accel->view.basis_dim : -1;
     switch (b) {
         case -1: return launch_variant<-1>(K, n_blocks, lds_bytes, stream);
