@@ -651,9 +651,12 @@ class Mlp:
                                           results.stride(0), C.c_void_p(stream)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().mnv_mlp_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().mnv_mlp_destroy(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown: module globals may be gone
+            pass
 
 
 def fill_uniform(out, seed: int, stream: int = 0) -> None:
@@ -682,9 +685,12 @@ class Renderer:
         self.width = self.height = 0
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().mnv_renderer_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().mnv_renderer_destroy(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown: module globals may be gone
+            pass
 
     @property
     def options(self) -> RenderOptions:
