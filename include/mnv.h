@@ -159,6 +159,9 @@ int mnv_accel_create_reserved(const mnv_tree_view *device_tree, int64_t max_capa
  */
 int mnv_accel_refresh(mnv_accel *accel, const mnv_tree_view *tree, int32_t old_capacity, const int32_t *changed_nodes,
                       int32_t n_changed, void *hip_stream);
+/* Rebuild every derived array from the tree in place (e.g. after mnv_prune_tree renumbered the chunks): the reserved arrays are
+ * reused, nothing is reallocated unless the lookup-grid levels change.  Synchronises hip_stream. */
+int mnv_accel_rebuild(mnv_accel *accel, const mnv_tree_view *tree, void *hip_stream);
 void mnv_accel_destroy(mnv_accel *accel);
 size_t mnv_accel_device_bytes(const mnv_accel *accel);
 int mnv_render_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,

@@ -189,6 +189,7 @@ _SIGNATURES = {
     "mnv_accel_create": (C.c_int, [C.POINTER(TreeView), C.c_void_p, C.POINTER(C.c_void_p)]),
     "mnv_accel_create_reserved": (C.c_int, [C.POINTER(TreeView), C.c_int64, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mnv_accel_refresh": (C.c_int, [C.c_void_p, C.POINTER(TreeView), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "mnv_accel_rebuild": (C.c_int, [C.c_void_p, C.POINTER(TreeView), C.c_void_p]),
     "mnv_accel_destroy": (None, [C.c_void_p]),
     "mnv_accel_device_bytes": (C.c_size_t, [C.c_void_p]),
     "mnv_render_voxels_accel": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
@@ -476,6 +477,11 @@ def accel_create(tree_view: TreeView, max_capacity: int = 0, stream: int = 0) ->
     h = C.c_void_p()
     _check(lib().mnv_accel_create_reserved(C.byref(tree_view), max(max_capacity, tree_view.capacity), C.c_void_p(stream), C.byref(h)))
     return h.value
+
+
+def accel_rebuild(accel: int, tree_view: TreeView, stream: int = 0) -> None:
+    """Rebuild the accel in place from the tree (after a prune renumbered the chunks)."""
+    _check(lib().mnv_accel_rebuild(C.c_void_p(accel), C.byref(tree_view), C.c_void_p(stream)))
 
 
 def accel_destroy(accel: int) -> None:

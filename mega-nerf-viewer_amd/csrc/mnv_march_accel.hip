@@ -949,43 +949,15 @@ int mnv_accel_create(const mnv_tree_view *t, void *hip_stream, mnv_accel **out) 
     return mnv_accel_create_reserved(t, t ? t->capacity : 0, hip_stream, out);
 }
 
-int mnv_accel_create_reserved(const mnv_tree_view *t, int64_t max_capacity, void *hip_stream, mnv_accel **out) {
-    if (!t || !out) return set_error(MNV_E_INVALID, "null argument");
-    if (max_capacity < t->capacity) return set_error(MNV_E_INVALID, "max_capacity is smaller than the tree");
-    if (t->N != 2) return set_error(MNV_E_UNSUPPORTED, "accel needs N == 2");
-    if (!t->data || !t->child || t->capacity < 1 || t->data_dim < 1) return set_error(MNV_E_INVALID, "invalid device tree view");
-    const int b = (t->format == MNV_FORMAT_SH && t->basis_dim >= 0) ? t->basis_dim : -1;
-    if (!(b == -1 || b == 1 || b == 4 || b == 9 || b == 16 || b == 25))
-        return set_error(MNV_E_UNSUPPORTED, "accel supports RGBA and SH1/4/9/16/25 rows; use mnv_render_voxels for others");
-    if (b >= 0 && t->data_dim != 3 * b + 1) return set_error(MNV_E_UNSUPPORTED, "accel needs data_dim == 3 * basis_dim + 1");
-    if (b < 0 && t->data_dim != 4) return set_error(MNV_E_UNSUPPORTED, "accel needs data_dim == 4 for RGBA rows");
-    hipStream_t stream = (hipStream_t)hip_stream;
-    mnv_accel *a = new mnv_accel();
+// (Re)build every derived array of `a` from the tree: chunk depths, node words, colour rows, lookup grids.  The big arrays
+// (nodes, rows, depth) are sized for a->reserved chunks and kept; the grids are reallocated only when their level changes.
+static int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
     int rc = MNV_OK;
-    int32_t *depth = nullptr, *changed = nullptr;
-    auto fail = [&](int code) {
-        mnv_accel_destroy(a);
-        return code;
-    };
-    if ((rc = check_hip(hipGetDevice(&a->device), "hipGetDevice"))) return fail(rc);
-    hipDeviceProp_t prop;
-    if ((rc = check_hip(hipGetDeviceProperties(&prop, a->device), "hipGetDeviceProperties"))) return fail(rc);
-    a->num_cus = prop.multiProcessorCount;
-
-    const int64_t cap = t->capacity, nvox = cap * 8;
+    const int b = (t->format == MNV_FORMAT_SH && t->basis_dim >= 0) ? t->basis_dim : -1;
+    const int64_t cap = t->capacity, nvox = cap * 8, max_capacity = a->reserved;
     const int row_bytes = row_bytes_for(b);
-    a->reserved = max_capacity;
-    if ((rc = check_hip(hipMalloc((void **)&a->nodes, max_capacity * 8 * 4), "hipMalloc(nodes)"))) return fail(rc);
-    if ((rc = check_hip(hipMalloc((void **)&a->rows, max_capacity * 8 * row_bytes), "hipMalloc(rows)"))) return fail(rc);
-    if ((rc = check_hip(hipMalloc((void **)&a->depth, max_capacity * 4), "hipMalloc(depth)"))) return fail(rc);
-    if ((rc = check_hip(hipMalloc((void **)&a->flags, 16), "hipMalloc(flag)"))) return fail(rc);
-    depth = a->depth;
-    changed = a->flags;
-    if ((rc = check_hip(hipMalloc((void **)&a->slots_dev, (size_t)kSlots * kSlotBytes), "hipMalloc(slots)"))) return fail(rc);
-
-    if ((rc = check_hip(hipMalloc((void **)&a->stats, 16 * sizeof(unsigned long long)), "hipMalloc(stats)"))) return fail(rc);
-    if ((rc = check_hip(hipMemsetAsync(a->stats, 0, 16 * sizeof(unsigned long long), stream), "memset stats"))) return fail(rc);
-
+    int32_t *depth = a->depth, *changed = a->flags;
+    auto fail = [&](int code) { return code; };
     // chunk depths: root chunk holds depth-1 voxels
     if ((rc = check_hip(hipMemsetAsync(depth, 0, max_capacity * 4, stream), "memset depth"))) return fail(rc);
     const int32_t one = 1;
@@ -1008,8 +980,13 @@ int mnv_accel_create_reserved(const mnv_tree_view *t, int64_t max_capacity, void
                        row_bytes / 2);
     int L = max_depth < kMaxGridLevel ? max_depth : kMaxGridLevel;
     const int64_t gcells = (int64_t)1 << (3 * L);
-    if ((rc = check_hip(hipMalloc((void **)&a->grid, gcells * 4), "hipMalloc(grid)"))) return fail(rc);
-    if ((rc = check_hip(hipMalloc((void **)&a->grid_vox, gcells * 4), "hipMalloc(grid_vox)"))) return fail(rc);
+    if (!a->grid || a->view.grid_level != L) {
+        if (a->grid) (void)hipFree(a->grid);
+        if (a->grid_vox) (void)hipFree(a->grid_vox);
+        a->grid = a->grid_vox = nullptr;
+        if ((rc = check_hip(hipMalloc((void **)&a->grid, gcells * 4), "hipMalloc(grid)"))) return fail(rc);
+        if ((rc = check_hip(hipMalloc((void **)&a->grid_vox, gcells * 4), "hipMalloc(grid_vox)"))) return fail(rc);
+    }
     hipLaunchKernelGGL(accel_build_grid, dim3((unsigned)((gcells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid, a->grid_vox, L);
     // second lookup grid at level L2 <= min(max_depth - 1, 9): 8^L2 words per array (64 MiB at level 8,
     // 512 MiB at level 9).  Pick the deepest level whose two arrays stay below max(128 MiB, 2 x the packed
@@ -1022,10 +999,17 @@ int mnv_accel_create_reserved(const mnv_tree_view *t, int64_t max_capacity, void
     if (env_l2 >= 0 && env_l2 <= kMaxGrid2Level && env_l2 < max_depth) L2 = env_l2;
     if (L2 <= L || L2 < 2) L2 = 0;
     int64_t g2cells = 0;
+    if (a->grid2 && a->view.grid2_level != L2) {
+        (void)hipFree(a->grid2);
+        (void)hipFree(a->grid2_vox);
+        a->grid2 = a->grid2_vox = nullptr;
+    }
     if (L2 > 0) {
         g2cells = (int64_t)1 << (3 * L2);
-        if ((rc = check_hip(hipMalloc((void **)&a->grid2, g2cells * 4), "hipMalloc(grid2)"))) return fail(rc);
-        if ((rc = check_hip(hipMalloc((void **)&a->grid2_vox, g2cells * 4), "hipMalloc(grid2_vox)"))) return fail(rc);
+        if (!a->grid2) {
+            if ((rc = check_hip(hipMalloc((void **)&a->grid2, g2cells * 4), "hipMalloc(grid2)"))) return fail(rc);
+            if ((rc = check_hip(hipMalloc((void **)&a->grid2_vox, g2cells * 4), "hipMalloc(grid2_vox)"))) return fail(rc);
+        }
         hipLaunchKernelGGL(accel_build_grid2, dim3((unsigned)((g2cells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid2, a->grid2_vox, L2);
     }
     if ((rc = check_hip(hipGetLastError(), "accel build launch"))) return fail(rc);
@@ -1050,8 +1034,54 @@ int mnv_accel_create_reserved(const mnv_tree_view *t, int64_t max_capacity, void
     a->view.format = t->format;
     a->view.capacity = t->capacity;
     a->bytes = (size_t)(nvox * 4 + nvox * row_bytes + gcells * 8 + g2cells * 8);
+    return MNV_OK;
+}
+
+int mnv_accel_create_reserved(const mnv_tree_view *t, int64_t max_capacity, void *hip_stream, mnv_accel **out) {
+    if (!t || !out) return set_error(MNV_E_INVALID, "null argument");
+    if (max_capacity < t->capacity) return set_error(MNV_E_INVALID, "max_capacity is smaller than the tree");
+    if (t->N != 2) return set_error(MNV_E_UNSUPPORTED, "accel needs N == 2");
+    if (!t->data || !t->child || t->capacity < 1 || t->data_dim < 1) return set_error(MNV_E_INVALID, "invalid device tree view");
+    const int b = (t->format == MNV_FORMAT_SH && t->basis_dim >= 0) ? t->basis_dim : -1;
+    if (!(b == -1 || b == 1 || b == 4 || b == 9 || b == 16 || b == 25))
+        return set_error(MNV_E_UNSUPPORTED, "accel supports RGBA and SH1/4/9/16/25 rows; use mnv_render_voxels for others");
+    if (b >= 0 && t->data_dim != 3 * b + 1) return set_error(MNV_E_UNSUPPORTED, "accel needs data_dim == 3 * basis_dim + 1");
+    if (b < 0 && t->data_dim != 4) return set_error(MNV_E_UNSUPPORTED, "accel needs data_dim == 4 for RGBA rows");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    mnv_accel *a = new mnv_accel();
+    int rc = MNV_OK;
+    auto fail = [&](int code) {
+        mnv_accel_destroy(a);
+        return code;
+    };
+    if ((rc = check_hip(hipGetDevice(&a->device), "hipGetDevice"))) return fail(rc);
+    hipDeviceProp_t prop;
+    if ((rc = check_hip(hipGetDeviceProperties(&prop, a->device), "hipGetDeviceProperties"))) return fail(rc);
+    a->num_cus = prop.multiProcessorCount;
+
+    const int row_bytes = row_bytes_for(b);
+    a->reserved = max_capacity;
+    if ((rc = check_hip(hipMalloc((void **)&a->nodes, max_capacity * 8 * 4), "hipMalloc(nodes)"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&a->rows, max_capacity * 8 * row_bytes), "hipMalloc(rows)"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&a->depth, max_capacity * 4), "hipMalloc(depth)"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&a->flags, 16), "hipMalloc(flag)"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&a->slots_dev, (size_t)kSlots * kSlotBytes), "hipMalloc(slots)"))) return fail(rc);
+
+    if ((rc = check_hip(hipMalloc((void **)&a->stats, 16 * sizeof(unsigned long long)), "hipMalloc(stats)"))) return fail(rc);
+    if ((rc = check_hip(hipMemsetAsync(a->stats, 0, 16 * sizeof(unsigned long long), stream), "memset stats"))) return fail(rc);
+
+    if ((rc = accel_build(a, t, stream))) return fail(rc);
     *out = a;
     return MNV_OK;
+}
+
+int mnv_accel_rebuild(mnv_accel *a, const mnv_tree_view *t, void *hip_stream) {
+    if (!a || !t) return set_error(MNV_E_INVALID, "null argument");
+    if (!t->data || !t->child || t->capacity < 1 || t->capacity > a->reserved)
+        return set_error(MNV_E_INVALID, "invalid tree view, or the tree outgrew the reserved capacity");
+    if (t->data_dim != a->view.data_dim || t->format != a->view.format || t->basis_dim != a->view.basis_dim)
+        return set_error(MNV_E_INVALID, "tree view does not match the accel");
+    return accel_build(a, t, (hipStream_t)hip_stream);
 }
 
 int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity, const int32_t *changed_nodes, int32_t n_changed,

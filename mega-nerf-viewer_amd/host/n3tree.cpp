@@ -237,9 +237,10 @@ void N3Tree::move_to_device(long max_capacity, bool need_parent, bool need_sampl
 
 void N3Tree::rebuild_accel(void *hip_stream) {
     if (!on_device() || N != 2) return;
+    const mnv_tree_view dv = device_view();
+    if (device.accel && mnv_accel_rebuild(device.accel, &dv, hip_stream) == MNV_OK) return;  // in place: the reserved arrays are reused
     if (device.accel) mnv_accel_destroy(device.accel);
     device.accel = nullptr;
-    const mnv_tree_view dv = device_view();
     const int rc = mnv_accel_create_reserved(&dv, std::max<long>(device.max_capacity, capacity), hip_stream, &device.accel);
     if (rc != MNV_OK) throw std::runtime_error(std::string("mnv_accel_create: ") + mnv_last_error());
 }

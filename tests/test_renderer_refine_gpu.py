@@ -236,6 +236,11 @@ def test_accel_refresh_entry_point(mnv, orc, torch_gpu):
         # refresh refuses what it cannot follow
         with pytest.raises(mnv.MnvError):
             mnv.accel_refresh(accel, tv, cap)  # stale old_capacity
+        # an in-place rebuild (what follows a prune) gives the same accel again
+        mnv.accel_rebuild(accel, tv)
+        mnv.render_voxels_accel(accel, cam, ropt, rgba=imgs[0])
+        torch.cuda.synchronize()
+        assert torch.equal(imgs[0].view(torch.int32), imgs[2].view(torch.int32)), label
         mnv.accel_destroy(accel)
         mnv.accel_destroy(fresh)
 
