@@ -1,0 +1,87 @@
+// mnv_reference_binding.hpp -- the binding a maintainer of cmusatyalab/mega-nerf-viewer would add to call libmnv.so
+// from the reference's own host data model (libtorch tensors, glm camera).  It is compiled only INSIDE a build of the
+// reference tree (it includes the reference's headers); this repository builds it in oracle/Makefile.ref against
+// /root/reference and runs it on the GPU (tests/test_parity_gpu.py::test_reference_binding_is_a_drop_in), which is the
+// proof that the C ABI of include/mnv.h is a drop-in for
+//     viewer::render_voxels(N3Tree&, const Camera&, const RenderOptions&, ...)      include/cuda/renderer_kernel.hpp:23-34
+// Nothing of the reference is copied here: the functions below only read public members of its structs.
+#pragma once
+
+#include <glm/gtc/type_ptr.hpp>
+
+#include <cstring>
+#include <stdexcept>
+
+#include "camera.hpp"           // reference include/camera.hpp
+#include "n3tree/n3tree.hpp"    // reference include/n3tree/n3tree.hpp
+#include "render_options.hpp"   // reference include/render_options.hpp
+
+#include "mnv.h"
+
+namespace viewer {
+
+// was: the implicit conversion N3Tree& -> internal::TreeSpec (include/data_spec.hpp:38-49)
+inline mnv_tree_view mnv_view(N3Tree &t) {
+    mnv_tree_view v{};
+    v.data = reinterpret_cast<const uint16_t *>(t.data.data_ptr<at::Half>());
+    v.child = t.child.data_ptr<int32_t>();
+    v.parent = (t.parent.defined() && t.parent.is_cuda()) ? t.parent.data_ptr<int32_t>() : nullptr;
+    v.sample_counts = (t.sample_counts.defined() && t.sample_counts.is_cuda()) ? t.sample_counts.data_ptr<int16_t>() : nullptr;
+    const torch::Tensor off = t.offset.cpu(), sc = t.scale.cpu();  // 3 floats each; a real integration caches these next to the tree
+    for (int i = 0; i < 3; ++i) {
+        v.offset[i] = off[i].item<float>();
+        v.scale[i] = sc[i].item<float>();
+    }
+    v.N = t.N;
+    v.data_dim = t.data_dim;
+    v.capacity = t.capacity;
+    v.format = t.data_format.format == DataFormat::SH ? MNV_FORMAT_SH : MNV_FORMAT_RGBA;
+    v.basis_dim = t.data_format.basis_dim;
+    return v;
+}
+
+// was: internal::CameraSpec(const Camera&) (include/data_spec.hpp:16-22) + the device copy of the matrix (src/camera.cpp:113-123)
+inline mnv_camera mnv_view(const Camera &c) {
+    mnv_camera m{};
+    m.width = c.width;
+    m.height = c.height;
+    m.fx = c.fx;
+    m.fy = c.fy;
+    m.cx = c.cx;
+    m.cy = c.cy;
+    std::memcpy(m.c2w, glm::value_ptr(c.transform), sizeof(m.c2w));  // column-major right | up | back | center
+    return m;
+}
+
+static_assert(sizeof(RenderOptions) == sizeof(mnv_render_options), "RenderOptions and mnv_render_options are the same POD");
+
+// Replacement body of viewer::render_voxels (src/cuda/renderer_kernel.cu:396-437) for a build without GL interop: the two
+// cudaArray_t targets become a linear float RGBA image (and / or RGBA8) in device memory.
+inline void render_voxels(N3Tree &tree, const Camera &cam, const RenderOptions &opt, float *rgba_linear, uint8_t *rgba8_linear,
+                          void *stream, float *to_split, float *to_sample, int32_t *visited, bool track_visit) {
+    const mnv_tree_view tv = mnv_view(tree);
+    const mnv_camera cv = mnv_view(cam);
+    const mnv_rect full{0, 0, cam.width, cam.height};
+    const int rc = mnv_render_voxels(&tv, &cv, reinterpret_cast<const mnv_render_options *>(&opt), full, rgba_linear, rgba8_linear, to_split,
+                                     to_sample, visited, track_visit ? 1 : 0, stream);
+    if (rc != MNV_OK) throw std::runtime_error(mnv_last_error());  // instead of cuda_assert's exit()
+}
+
+// The tuned path: build once where the reference calls tree->move_to_device (cuda_renderer.cpp:498-505) ...
+inline mnv_accel *make_accel(N3Tree &tree, long max_tree_capacity, void *stream) {
+    const mnv_tree_view tv = mnv_view(tree);
+    mnv_accel *accel = nullptr;
+    if (mnv_accel_create_reserved(&tv, max_tree_capacity, stream, &accel) != MNV_OK) throw std::runtime_error(mnv_last_error());
+    return accel;
+}
+
+// ... and render with it (no refinement active)
+inline void render_voxels(const mnv_accel *accel, const Camera &cam, const RenderOptions &opt, float *rgba_linear, uint8_t *rgba8_linear,
+                          void *stream) {
+    const mnv_camera cv = mnv_view(cam);
+    const mnv_rect full{0, 0, cam.width, cam.height};
+    if (mnv_render_voxels_accel(accel, &cv, reinterpret_cast<const mnv_render_options *>(&opt), full, rgba_linear, rgba8_linear, stream) != MNV_OK)
+        throw std::runtime_error(mnv_last_error());
+}
+
+}  // namespace viewer

@@ -174,3 +174,24 @@ def camera_pose(width, height, fx, fy, cx, cy, center, back, up, updates=1):
     if rc != 0:
         raise RuntimeError(f"ref_camera_pose failed with {rc}")
     return np.array(list(out), np.float32), tuple(float(x) for x in intr)
+
+
+def dropin_render_npz(npz_path, cam_spec, opt_struct, capacity, path=0, want_trackers=False):
+    """The reference's loader / N3Tree / Camera feeding libmnv.so through include/mnv_reference_binding.hpp.
+    cam_spec: dict(width, height, fx, fy, cx, cy, center, back, up).  path 0 = mnv_render_voxels, 1 = packed accel."""
+    h = lib()
+    h.ref_dropin_render_npz.restype = C.c_int
+    w, ht = cam_spec["width"], cam_spec["height"]
+    rgba, rgba8 = np.empty((ht, w, 4), np.float32), np.empty((ht, w, 4), np.uint8)
+    split = np.empty((ht, w, 3), np.float32) if want_trackers else None
+    sample = np.empty((ht, w, 3), np.float32) if want_trackers else None
+    visited = np.zeros(capacity, np.int32) if want_trackers else None
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
+    ptr = lambda a: C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)  # noqa: E731
+    rc = h.ref_dropin_render_npz(os.fsencode(npz_path), C.c_int(w), C.c_int(ht), C.c_float(cam_spec["fx"]), C.c_float(cam_spec.get("fy", -1.0)),
+                                 C.c_float(cam_spec.get("cx", -1.0)), C.c_float(cam_spec.get("cy", -1.0)), f3(cam_spec["center"]), f3(cam_spec["back"]),
+                                 f3(cam_spec.get("up", (0.0, 0.0, 1.0))), C.byref(opt_struct), C.c_int(C.sizeof(opt_struct)), C.c_int(path), ptr(rgba),
+                                 ptr(rgba8), ptr(split), ptr(sample), ptr(visited))
+    if rc != 0:
+        raise RuntimeError(f"ref_dropin_render_npz failed with {rc}")
+    return dict(rgba=rgba, rgba8=rgba8, split=split, sample=sample, visited=visited)

@@ -32,6 +32,8 @@
 #include "n3tree/n3tree.hpp"
 #include "render_options.hpp"
 
+#include "mnv_reference_binding.hpp"  // include/ of this repository: the reference-side binding to libmnv.so
+
 namespace viewer {
 // cuda_assert is defined in the reference's src/cuda/common.cu (compiled alongside)
 
@@ -363,6 +365,55 @@ int ref_camera_pose(int width, int height, float fx, float fy, float cx, float c
         intrinsics4_out[3] = cam.cy;
     } catch (const std::exception &e) {
         fprintf(stderr, "ref_camera_pose: %s\n", e.what());
+        return -1;
+    }
+    return 0;
+}
+
+// Drop-in demonstration: the reference's own loader, N3Tree (libtorch tensors on the device) and Camera (glm) feed libmnv.so
+// through include/mnv_reference_binding.hpp -- what a ROCm build of the viewer would do per frame.  path: 0 = mnv_render_voxels on
+// the reference's arrays (with trackers / visit marks), 1 = the packed accel.  Trackers / visited may be NULL.
+int ref_dropin_render_npz(const char *npz_path, int width, int height, float fx, float fy, float cx, float cy, const float *center3,
+                          const float *back3, const float *up3, const void *opt_bytes, int opt_size, int path, float *rgba_host,
+                          uint8_t *rgba8_host, float *split_host, float *sample_host, int32_t *visited_host) {
+    using namespace viewer;
+    if (opt_size != (int)sizeof(RenderOptions)) return -2;
+    RenderOptions opt;
+    memcpy(&opt, opt_bytes, sizeof(opt));
+    try {
+        N3Tree tree;
+        tree.open(npz_path);
+        if (tree.N == 0) return -3;
+        tree.move_to_device(tree.capacity, true, true);
+        tree.sample_counts.fill_(8);
+        Camera cam(width, height, fx, fy, cx, cy);  // the reference's camera: pose vectors -> _update() (glm)
+        cam.center = glm::vec3(center3[0], center3[1], center3[2]);
+        cam.v_back = glm::vec3(back3[0], back3[1], back3[2]);
+        cam.v_world_up = glm::vec3(up3[0], up3[1], up3[2]);
+        cam._update();
+        const int64_t n = (int64_t)width * height;
+        auto fopt = torch::TensorOptions().device(torch::kCUDA).dtype(torch::kFloat32);
+        torch::Tensor out = torch::zeros({n, 4}, fopt), out8 = torch::zeros({n, 4}, torch::TensorOptions().device(torch::kCUDA).dtype(torch::kUInt8));
+        torch::Tensor to_split = torch::full({n, 3}, -1.f, fopt), to_sample = torch::full({n, 3}, -1.f, fopt);
+        torch::Tensor visited = torch::zeros({tree.capacity}, torch::TensorOptions().device(torch::kCUDA).dtype(torch::kInt32));
+        if (hipDeviceSynchronize() != hipSuccess) return -4;
+        if (path == 0) {
+            render_voxels(tree, cam, opt, out.data_ptr<float>(), out8.data_ptr<uint8_t>(), nullptr, to_split.data_ptr<float>(),
+                          to_sample.data_ptr<float>(), visited.data_ptr<int32_t>(), visited_host != nullptr);
+        } else {
+            mnv_accel *accel = make_accel(tree, tree.capacity, nullptr);
+            render_voxels(accel, cam, opt, out.data_ptr<float>(), out8.data_ptr<uint8_t>(), nullptr);
+            if (hipDeviceSynchronize() != hipSuccess) return -4;
+            mnv_accel_destroy(accel);
+        }
+        if (hipDeviceSynchronize() != hipSuccess) return -4;
+        memcpy(rgba_host, out.cpu().data_ptr<float>(), n * 4 * sizeof(float));
+        if (rgba8_host) memcpy(rgba8_host, out8.cpu().data_ptr<uint8_t>(), n * 4);
+        if (split_host) memcpy(split_host, to_split.cpu().data_ptr<float>(), n * 3 * sizeof(float));
+        if (sample_host) memcpy(sample_host, to_sample.cpu().data_ptr<float>(), n * 3 * sizeof(float));
+        if (visited_host) memcpy(visited_host, visited.cpu().data_ptr<int32_t>(), (size_t)tree.capacity * sizeof(int32_t));
+    } catch (const std::exception &e) {
+        fprintf(stderr, "ref_dropin_render_npz: %s\n", e.what());
         return -1;
     }
     return 0;

@@ -475,3 +475,34 @@ def test_fast_colour_math_keeps_alpha_and_control_flow_exact(mnv, orc, torch_gpu
     mnv.render_voxels_accel(tree.accel, cam, opt, rgba=out)  # back in exact mode: bit-identical again
     torch.cuda.synchronize()
     assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref))
+
+
+@pytest.mark.parametrize("name", ["sh4_d6", "sh9_d7_aniso", "rgba_d5", "terrain_d7_aniso"])
+def test_reference_binding_is_a_drop_in(mnv, orc, torch_gpu, tmp_path, name):
+    """include/mnv_reference_binding.hpp compiled inside a build of the reference (oracle/Makefile.ref): the reference's OWN loader,
+    N3Tree (libtorch tensors on the device) and Camera (glm) feed libmnv.so -- mnv_render_voxels with trackers and visit marks,
+    and the packed accel.  Frames, trackers and marks equal the oracle's bit for bit: the C ABI is a drop-in for
+    viewer::render_voxels (include/cuda/renderer_kernel.hpp:23-34)."""
+    import mnv_ref
+    if not mnv_ref.available():
+        pytest.skip("oracle/_ref/libmnv_ref_gfx950.so not built (needs /root/reference at build time)")
+    spec = cases.CASES[name]
+    tree = cases.make_tree(mnv, spec["tree"])
+    cs = dict(dict(center=(-3.55, 0.0, 3.55), back=(-0.7071068, 0.0, 0.7071068)), **spec["camera"])  # Camera ctor defaults if unposed
+    cam = cases.make_camera(mnv, cs)
+    opt = cases.make_options(mnv, spec["options"])
+    opt.max_depth, opt.max_sample_count = 5, 9
+    opt.basis_minmax[0], opt.basis_minmax[1] = 0, max(tree.host_view().basis_dim - 1, 0)
+    path = str(tmp_path / "t.npz")
+    tree.save_npz(path)
+    v = tree.host_view()
+    counts = np.full((v.capacity, 8), 8, np.int16)
+    visited = np.zeros(v.capacity, np.int32)
+    want = orc.render(orc.tree_from_view(v, sample_counts=counts), cam.c, opt, want_rgba8=True, want_trackers=True, visited=visited, track_visit=True)
+    cam_spec = dict(width=cs["width"], height=cs["height"], fx=cs["fx"], center=cs["center"], back=cs["back"], up=cs.get("up", (0.0, 0.0, 1.0)))
+    got = mnv_ref.dropin_render_npz(path, cam_spec, opt, v.capacity, path=0, want_trackers=True)
+    assert np.array_equal(cases.bits(got["rgba"]), cases.bits(want["rgba"])) and np.array_equal(got["rgba8"], want["rgba8"])
+    assert np.array_equal(got["split"], want["split"]) and np.array_equal(got["sample"], want["sample"])
+    assert np.array_equal(got["visited"], visited)
+    got = mnv_ref.dropin_render_npz(path, cam_spec, opt, v.capacity, path=1)
+    assert np.array_equal(cases.bits(got["rgba"]), cases.bits(want["rgba"])) and np.array_equal(got["rgba8"], want["rgba8"])
