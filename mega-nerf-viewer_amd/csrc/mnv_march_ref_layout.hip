@@ -5,8 +5,10 @@
 // (reference src/cuda/renderer_kernel.cu:243-292 -> include/cuda/rt_core.cuh:162-332)
 // for callers that hand over reference-layout device arrays, including the
 // refinement trackers (rt_core.cuh:237-252,308-321) and visit marks (:132-134).
-// One lane per ray, 8x8-pixel tile per wavefront, 4 wavefronts per workgroup;
-// every step restarts the descent from the root exactly as the reference does.
+// One lane per ray, 8x8-pixel tile per wavefront, 4 wavefronts per workgroup.  Every step restarts the descent from the
+// root as the reference does; unless visit marks are wanted, the first three levels of that descent come from a 512-cell
+// table each workgroup derives from `child` when it starts (x*2, floorf and x - floorf(x) are exact, so entering the
+// descent at level 4 with fract(pos * 8) gives the same leaf and the same in-leaf coordinates bit for bit).
 // The tuned path (packed layout, LDS top grid, persistent waves) is
 // mnv_march_accel.hip; both produce bit-identical pixels.
 #include "mnv_device.h"
@@ -16,10 +18,38 @@
 
 namespace mnv {
 
+#ifndef MNV_REF_TOP_LEVEL
+#define MNV_REF_TOP_LEVEL 3
+#endif
+constexpr uint32_t kTopLeaf = 0x80000000u;  // top-table word: leaf at depth (word >> 28) & 7, voxel index in the low 28 bits
+
 template <int BASIS /* -1 RGBA, 0 DC-only with runtime stride, 1/4/9/16/25 */>
 __global__ __launch_bounds__(256) void march_ref_layout_kernel(const MarchParams P) {
     __shared__ uint64_t s_exp[32];
+    constexpr int TL = MNV_REF_TOP_LEVEL, TG = 1 << TL;  // table level and cells per axis
+    __shared__ uint32_t s_top[TG * TG * TG];
     load_exp_table(s_exp);
+    // level-3 cell -> the leaf of depth <= 3 that covers it, or the chunk holding its depth-4 voxels
+    const bool use_top = !P.track_visit && P.capacity < (1 << 25);
+    if (use_top) {
+        for (int i = threadIdx.x; i < TG * TG * TG; i += 256) {
+            int32_t chunk = 0;
+            uint32_t word = 0;
+            for (int l = 1; l <= TL; ++l) {
+                const int s3 = TL - l;
+                const int cidx = (((i >> (2 * TL)) >> s3) & 1) << 2 | ((((i >> TL) & (TG - 1)) >> s3) & 1) << 1 | (((i & (TG - 1)) >> s3) & 1);
+                const int32_t skip = P.child[(int64_t)chunk * 8 + cidx];
+                if (skip == 0) {
+                    word = kTopLeaf | ((uint32_t)l << 28) | (uint32_t)(chunk * 8 + cidx);
+                    break;
+                }
+                chunk += skip;
+                word = (uint32_t)chunk;
+            }
+            s_top[i] = word;
+        }
+        __syncthreads();
+    }
 
     // 16x16 pixel block per workgroup, 8x8 per wavefront
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -56,6 +86,25 @@ __global__ __launch_bounds__(256) void march_ref_layout_kernel(const MarchParams
             }
             int32_t chunk = 0, cidx;
             int depth = 1;
+            bool at_leaf = false;
+            if (use_top) {
+                const uint32_t word = s_top[((int)(pos[0] * (float)TG) * TG + (int)(pos[1] * (float)TG)) * TG + (int)(pos[2] * (float)TG)];
+                if (word & kTopLeaf) {
+                    depth = (int)((word >> 28) & 7u);
+                    chunk = (int32_t)((word & 0x0fffffffu) >> 3);
+                    cidx = (int32_t)(word & 7u);
+                    const float sc = __uint_as_float((uint32_t)(127 + depth) << 23);
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) pos[i] = __builtin_amdgcn_fractf(pos[i] * sc);
+                    at_leaf = true;
+                } else {
+                    depth = TL + 1;
+                    chunk = (int32_t)word;
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) pos[i] = __builtin_amdgcn_fractf(pos[i] * (float)TG);
+                }
+            }
+            if (!at_leaf)
             for (;;) {
                 // rt_core.cuh:132-134 marks with atomicCAS(&visited[chunk], 0, 1); the mark only ever goes 0 -> 1, so a
                 // load and a conditional plain store leave the same array -- without every ray serialising on the
