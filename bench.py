@@ -38,7 +38,8 @@ import torch.distributed as dist  # noqa: E402
 W, H, FX = 1920, 1080, 1600.0
 N_POSES = 16
 N_FRAMES = 16  # frames per step: N_POSES x --laps
-MACRO_W, MACRO_H = 128, 120          # 15 x 9 = 135 macro tiles; 15 is odd -> diagonal rank pattern
+MACRO_W, MACRO_H = 64, 24            # 30 x 45 = 1350 macro tiles: per-rank launch times within 3 % of each other at world 8
+                                     # (tools/partition_balance.py: 128x120 tiles leave the slowest rank 19 % behind)
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8.0 TB/s spec
 COUNTERS_JSON = os.path.join(ROOT, "tests", "golden", "cfg2_counters.json")
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_traffic.json")   # HBM bytes per launch from the committed PMC passes

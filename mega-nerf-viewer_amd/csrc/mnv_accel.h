@@ -67,7 +67,7 @@ struct mnv_accel {
     int32_t *flags = nullptr;             // [4] device scratch of refresh: changed, deepest depth, grids dirty
     int64_t reserved = 0;                 // chunks the nodes / rows / depth arrays have room for
     unsigned long long *stats = nullptr;  // MNV_STATS=1 diagnostics
-    // per-launch slots: [n_frames][kNumQueues] ray-queue heads (64 B apart) + [n_frames] camera blocks,
+    // per-launch slots: [kNumQueues] ray-queue heads (64 B apart; a queue spans the frames of a batch) + [n_frames] camera blocks,
     // written on the launch stream by stage_launch_kernel; kSlots launches may be in flight
     uint8_t *slots_dev = nullptr;
     std::atomic<uint32_t> slot_counter{0};

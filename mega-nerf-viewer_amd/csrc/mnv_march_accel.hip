@@ -251,7 +251,7 @@ struct AccelLaunch {
     const CamBlock *__restrict__ cams;  // [n_frames] device array (written by stage_launch_kernel)
     uint32_t n_frames;
     uint32_t frame_stride_px;  // pixels between consecutive frames in the output buffers
-    uint32_t *queue;           // [n_frames][kNumQueues] heads, 64 B apart
+    uint32_t *queue;           // [kNumQueues] heads, 64 B apart; queue q = band q of every frame, frame-major
     uint32_t tiles_x, n_tiles;
     uint32_t tile_wlog;                   // log2 of the ray-tile width (tile = 2^wlog x 2^(6-wlog) pixels, 8x8 by default)
     uint32_t band_begin[kNumQueues + 1];  // tile ranges per queue
@@ -418,11 +418,14 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
         }
     };
 
-    // ray queues: home queue first, then steal round robin; frames of a batch are walked in order,
-    // every wavefront at its own pace, so the tail of frame f overlaps the start of frame f + 1
+    // ray queues: queue q holds band q (a contiguous run of 8x8 tiles) of EVERY frame of the batch, frame-major, behind one
+    // head; a wavefront drains its home queue (workgroup b -> XCD b % 8), then steals round robin.  A batch is refilled a
+    // whole tile at a time (refill_min = 64), so a grab never straddles two frames and the camera stays wave-uniform; the
+    // tail of one frame overlaps the head of the next, and an exhausted queue is polled once per wavefront, not once per frame.
     const uint32_t home = blockIdx.x % kNumQueues;
-    uint32_t qsel = 0;   // queues of the current frame tried so far (wave-uniform)
-    uint32_t frame = 0;  // frame this wavefront draws rays from (wave-uniform)
+    uint32_t qsel = 0;     // queues tried so far (wave-uniform)
+    bool drained = false;  // every queue is empty (wave-uniform)
+    uint32_t frame = 0;    // frame of the rays this wavefront holds (wave-uniform)
     const CamBlock *__restrict__ Cp = K.cams;  // camera of `frame` (wave-uniform pointer: scalar loads)
     float cen0 = Cp->cen[0], cen1 = Cp->cen[1], cen2 = Cp->cen[2];
     uint32_t pix_base = 0;
@@ -441,35 +444,36 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
         const uint64_t idle = __ballot(!alive);
         const int n_idle = __popcll(idle);
         stat(0, true);
-        // Tile-sized refills (refill_min ~ 56 of 64 lanes) keep a wavefront's rays coherent.
-        if (frame < K.n_frames && n_idle >= K.refill_min) {
+        // Tile-sized refills keep a wavefront's rays coherent (sweep in DESIGN.md).
+        if (!drained && n_idle >= K.refill_min) {
             if (qsel >= kNumQueues) {
-                // this frame's queues are empty: finish the rays in flight, then move to the next frame
-                // (camera constants are wave-uniform, so a wavefront never mixes frames)
-                if (n_idle == 64) {
-                    frame = __builtin_amdgcn_readfirstlane(frame + 1);
-                    qsel = 0;
-                    if (frame < K.n_frames) {
-                        Cp = K.cams + frame;
-                        cen0 = Cp->cen[0];
-                        cen1 = Cp->cen[1];
-                        cen2 = Cp->cen[2];
-                        pix_base = frame * K.frame_stride_px;
-                    }
-                    continue;
-                }
+                drained = true;
             } else {
             // ---- refill idle lanes from the ray queues
             const uint32_t q = (home + qsel) % kNumQueues;
-            const uint32_t begin = K.band_begin[q] * 64u, end = K.band_begin[q + 1] * 64u;
+            const uint32_t begin = K.band_begin[q] * 64u, span = (K.band_begin[q + 1] - K.band_begin[q]) * 64u;  // rays of the band, per frame
             const uint32_t grab = (uint32_t)n_idle;
-            uint32_t base = 0;
-            if (lane == 0) base = begin + atomicAdd(&K.queue[(frame * kNumQueues + q) * 16], grab);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= end) {
+            uint32_t off = 0;
+            if (lane == 0) off = atomicAdd(&K.queue[q * 16], grab);
+            off = __builtin_amdgcn_readfirstlane(off);
+            if (span == 0 || (uint64_t)off >= (uint64_t)span * K.n_frames) {
                 ++qsel;
                 continue;
             }
+            uint32_t f = 0;
+            if (K.n_frames > 1) {
+                f = off / span;
+                off -= f * span;
+                if (f != frame) {
+                    frame = f;
+                    Cp = K.cams + f;
+                    cen0 = Cp->cen[0];
+                    cen1 = Cp->cen[1];
+                    cen2 = Cp->cen[2];
+                    pix_base = f * K.frame_stride_px;
+                }
+            }
+            const uint32_t base = begin + off, end = begin + span;
             if (!alive) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 const uint32_t id = base + rank;
@@ -522,7 +526,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
             }
         }
         if (__ballot(alive) == 0) {
-            if (frame >= K.n_frames) break;
+            if (drained) break;
             continue;
         }
         // ---- one march step (rt_core.cuh:220-323) for every live lane
@@ -887,7 +891,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     mnv_accel *mut = const_cast<mnv_accel *>(accel);
     const uint32_t slot = mut->slot_counter.fetch_add(1) % kSlots;
     uint8_t *ds = accel->slots_dev + (size_t)slot * kSlotBytes;
-    const size_t heads_bytes = (size_t)n_frames * kNumQueues * 64;
+    const size_t heads_bytes = (size_t)kNumQueues * 64;  // one head per queue; a queue spans the frames of the batch
     K.queue = reinterpret_cast<uint32_t *>(ds);
     CamBlock *dcams = reinterpret_cast<CamBlock *>(ds + heads_bytes);
     K.cams = dcams;
@@ -917,7 +921,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     K.ablate = env_ablate;
     static const bool env_stats = getenv("MNV_STATS") != nullptr;
     K.stats = (env_stats || env_ablate) ? accel->stats : nullptr;  // both run on the diagnostics instantiation
-    K.refill_min = env_refill > 0 ? env_refill : 64;  // sweep in DESIGN.md: 16 -> 0.606 ms, 32 -> 0.535, 48 -> 0.507, 56 -> 0.504, 64 -> 0.506
+    K.refill_min = (env_refill > 0 && n_frames == 1) ? env_refill : 64;  // batches refill whole tiles (a grab must not straddle frames);  // sweep in DESIGN.md: 16 -> 0.606 ms, 32 -> 0.535, 48 -> 0.507, 56 -> 0.504, 64 -> 0.506
     int blocks_per_cu = lds_level >= 5 ? 1 : (lds_level == 4 ? 6 : 8);
     if ((K.split_track || K.sample_track || K.samples) && blocks_per_cu > MNV_TRACK_WAVES) blocks_per_cu = MNV_TRACK_WAVES;
     if (env_bpc > 0) blocks_per_cu = env_bpc;

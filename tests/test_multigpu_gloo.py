@@ -107,7 +107,7 @@ def test_unpermute_with_frame_dimension(mnv):
 def test_partition_index_math_matches_c_abi(mnv):
     from mega_nerf_viewer_amd.multigpu import TilePartition
 
-    for (W, H, world, tw, th) in [(1920, 1080, 8, 128, 120), (1920, 1080, 3, 200, 136), (100, 50, 4, 8, 8), (7, 5, 2, 8, 8)]:
+    for (W, H, world, tw, th) in [(1920, 1080, 8, 64, 24), (1920, 1080, 8, 128, 120), (1920, 1080, 3, 200, 136), (100, 50, 4, 8, 8), (7, 5, 2, 8, 8)]:
         part = TilePartition(W, H, world, tw, th)
         seen = []
         for r in range(world):

@@ -208,7 +208,7 @@ def test_cfg2_interleaved_partition_reassembles_bit_exact(mnv, torch_gpu, cfg2, 
     opt = mnv.RenderOptions.cli_defaults()
     full, full8 = _render_gpu(mnv, torch, cfg2, cam, opt, "accel", want_u8=True)
     H, W = cam.height, cam.width
-    for (tw, th) in [(128, 120), (200, 136)]:
+    for (tw, th) in [(64, 24), (128, 120), (200, 136)]:
         mx, my = -(-W // tw), -(-H // th)
         out = np.full((my * th, mx * tw, 4), np.nan, np.float32)
         out8 = np.zeros((my * th, mx * tw, 4), np.uint8)
