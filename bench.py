@@ -77,6 +77,15 @@ def main():
     ap.add_argument("--per-frame", action="store_true", help="one launch per pose instead of one batched launch per step")
     ap.add_argument("--fast-colour", action="store_true",
                     help="mnv_set_colour_math(1): hardware exp2 / rcp in the colour sigmoid (alpha and control flow stay exact; colours move ~1e-7)")
+    ap.add_argument("--reserve-cus", type=int, default=-1,
+                    help="N > 1: compute units the march leaves free for the RCCL kernels of the tile gather (the march runs on a CU-masked "
+                         "stream).  Default 32 when N > 1 (one unit per shader engine and XCD; measured cost of the march: 10 %%), 0 when N = 1. "
+                         "Without it the gather cannot overlap the next step: RCCL's workgroups do not fit beside the persistent march workgroups "
+                         "(tools/cumask/probe.py)")
+    ap.add_argument("--one-march-stream", action="store_true", help="N > 1: launch every step on the same stream (default: one stream per ring slot)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="test hook: with one process, run the N > 1 code path (process group, partition with world 1, reserved stream, "
+                         "tile gather, un-permute) -- the only way to execute the RCCL calls on a one-GPU box")
     ap.add_argument("--laps", type=int, default=4, help="the step walks the 16-pose orbit this many times (16 x laps frames in one launch, <= 64)")
     args = ap.parse_args()
     global W, H, N_FRAMES
@@ -96,8 +105,10 @@ def main():
     if args.backend == "gloo":
         local_rank = local_rank % torch.cuda.device_count()  # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist   # the partition / gather code path
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -123,9 +134,22 @@ def main():
     opt = mnv.RenderOptions.cli_defaults()
     setup_s = time.time() - t_setup
 
-    stream = torch.cuda.current_stream(dev).cuda_stream
     RING = 2
-    if world == 1:
+    reserve = args.reserve_cus if args.reserve_cus >= 0 else (32 if multi else 0)
+    n_march_streams = RING if multi and not args.one_march_stream else 1
+    march_streams = None
+    if reserve > 0 or n_march_streams > 1:
+        # the march (and what follows it in stream order) runs on streams that cannot use `reserve` compute units; RCCL's own stream
+        # and the gatherer's side stream can.  Two such streams, one per ring slot: the launch of step k + 1 fills the wave slots
+        # the last wavefronts of step k leave (tools/rank_solo.py: 2.46 -> 2.33 ms per step for one rank of eight).
+        march_streams = []
+        for _ in range(n_march_streams):
+            handle, enabled = mnv.stream_create_reserved(reserve)
+            march_streams.append(torch.cuda.ExternalStream(handle, device=dev))
+        mnv.accel_set_cu_budget(tree.accel, enabled)
+        torch.cuda.set_stream(march_streams[0])
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    if not multi:
         # one launch per step: the 16 poses as a batch (frame f at frames[slot][f])
         frames = [torch.empty((N_FRAMES, H, W, 4), dtype=torch.float32, device=dev) for _ in range(RING)]
         dv = tree.device_view() if args.kernel == "ref_layout" else None
@@ -160,18 +184,20 @@ def main():
         def step():
             slot = counter[0] % RING
             counter[0] += 1
-            tg.finish(slot)  # the slot's previous gather must be done before its buffer is overwritten
-            kw = dict(rgba=tg.local(slot)) if args.gather == "f32" else dict(rgba8=tg.local(slot))
-            if n_local > 0:
-                mnv.render_voxels_accel_batch(tree.accel, cams, opt, part=(rank, world, MACRO_W, MACRO_H), stream=stream, **kw)
-            tg.submit(slot)
+            st = march_streams[slot % n_march_streams] if march_streams else torch.cuda.current_stream(dev)
+            with torch.cuda.stream(st):
+                tg.finish(slot)  # orders this stream after the slot's previous gather: its buffer is about to be overwritten
+                kw = dict(rgba=tg.local(slot)) if args.gather == "f32" else dict(rgba8=tg.local(slot))
+                if n_local > 0:
+                    mnv.render_voxels_accel_batch(tree.accel, cams, opt, part=(rank, world, MACRO_W, MACRO_H), stream=st.cuda_stream, **kw)
+                tg.submit(slot)
 
         def render_pose(i, out):
             mnv.render_voxels_accel(tree.accel, cams[i], opt, rgba=out, stream=stream)
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -180,26 +206,26 @@ def main():
         dist.all_reduce(t_, op=dist.ReduceOp.MAX)
         return float(t_.item())
 
-    if world > 1:
+    if multi:
         # create the RCCL point-to-point channels outside the timed region even with --warmup 0
         tg.submit(0)
         tg.finish(0)
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if multi:
         tg.finish_all()
     sync_all()
     mnv.set_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    if world > 1:
+    if multi:
         tg.finish_all()
     sync_all()
     elapsed = time.perf_counter() - t0
     kern_ms, launches = mnv.take_timing()
     mnv.set_timing(False)
-    if world > 1:
+    if multi:
         elapsed = all_max(elapsed)
 
     rays_per_step = N_FRAMES * W * H
@@ -209,7 +235,7 @@ def main():
     counters = load_counters() if args.workload == "cfg2" else None
     cpu_baseline = None
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         import mnv_oracle as orc
         ot = orc.tree_from_view(tree.host_view())
         n_cpu = max(1, min(args.cpu_poses, N_POSES))
@@ -224,7 +250,7 @@ def main():
             render_pose(i, scratch)
             torch.cuda.synchronize(dev)
             gpu = scratch.cpu().numpy()
-            if world == 1 and not args.per_frame and args.kernel == "accel":  # the batched launch wrote the same frame
+            if not multi and not args.per_frame and args.kernel == "accel":  # the batched launch wrote the same frame
                 assert np.array_equal(frames[(counter[0] - 1) % RING][i].cpu().numpy().view(np.uint32), gpu.view(np.uint32))
             d = np.abs(gpu - r["rgba"])
             max_diff = max(max_diff, float(d.max()))
@@ -236,7 +262,7 @@ def main():
                   "alpha_not_bit_identical": n_alpha, "colour_math": "fast" if args.fast_colour else "exact"}
         if counters is None:
             counters = {"poses": fresh, "partial": True}
-    if rank == 0 and world > 1 and not args.no_cpu_baseline:
+    if rank == 0 and multi and not args.no_cpu_baseline:
         # the assembled frames of the last step against the oracle (not timed): validates partition + gather + un-permute
         import mnv_oracle as orc
         ot = orc.tree_from_view(tree.host_view())
@@ -257,12 +283,12 @@ def main():
     if counters is not None and launches > 0:
         poses = counters["poses"]
         mean_bytes = float(np.mean([alg_bytes(c) for c in poses.values()]))
-        frames_per_launch = 1 if (args.per_frame or args.kernel != "accel") and world == 1 else N_FRAMES
+        frames_per_launch = 1 if (args.per_frame or args.kernel != "accel") and not multi else N_FRAMES
         per_launch = mean_bytes * frames_per_launch / world   # each rank's launch covers 1/world of its frames
         avg_ms = kern_ms / launches
         achieved = per_launch / (avg_ms * 1e-3) / 1e9
         traffic = None
-        if os.path.exists(TRAFFIC_JSON) and world == 1 and args.kernel == "accel" and args.workload == "cfg2":
+        if os.path.exists(TRAFFIC_JSON) and not multi and args.kernel == "accel" and args.workload == "cfg2":
             tj = json.load(open(TRAFFIC_JSON))
             if tj.get("frames_per_launch") == frames_per_launch:
                 traffic = tj["hbm_bytes_per_launch"]   # PMC counters cannot be read from inside this process
@@ -272,6 +298,8 @@ def main():
                     "frames_per_launch": frames_per_launch,
                     "avg_launch_ms": round(avg_ms, 5), "launches": launches,
                     "algorithmic_bytes_per_launch": int(per_launch)}
+        if n_march_streams > 1:
+            roofline["note"] = "consecutive launches run on two streams and overlap: each launch's event interval includes the share of the device it left to its neighbour"
 
     if rank == 0:
         line = {
@@ -289,16 +317,24 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload,
                        "rays_per_step": rays_per_step, "kernel": args.kernel, "launches_per_step": 1 if not args.per_frame and args.kernel == "accel" else N_FRAMES,
-                       "partition": "none" if world == 1 else f"interleaved {MACRO_W}x{MACRO_H} macro tiles, {args.gather} RCCL gather to rank 0"},
+                       "partition": "none" if not multi else f"interleaved {MACRO_W}x{MACRO_H} macro tiles, {args.gather} RCCL gather to rank 0",
+                       "reserved_cus": reserve, "march_streams": n_march_streams},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "parity": parity,
             "setup_s": round(setup_s, 2),
         }
-        print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL printf()s its library path into C stdio's buffer, which a pipe only sees at exit: flush it now so that the JSON line
+        # is the last line of stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stderr.flush()
+        print(json.dumps(line), flush=True)
+
 
 
 if __name__ == "__main__":

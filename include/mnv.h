@@ -164,6 +164,12 @@ int mnv_accel_refresh(mnv_accel *accel, const mnv_tree_view *tree, int32_t old_c
 int mnv_accel_rebuild(mnv_accel *accel, const mnv_tree_view *tree, void *hip_stream);
 void mnv_accel_destroy(mnv_accel *accel);
 size_t mnv_accel_device_bytes(const mnv_accel *accel);
+/* Compute units the tuned kernel may fill with its persistent workgroups (8 per unit).  Default (and num_cus <= 0): every unit
+ * of the device.  A caller that launches on a stream created with hipExtStreamCreateWithCUMask -- to leave units free for
+ * the RCCL kernels of the tile gather, which cannot become resident next to a full set of persistent workgroups -- passes
+ * the number of units its mask enables.  New; the reference has no counterpart (auto_cuda_threads, renderer_kernel.cu:14-28,
+ * sizes a non-persistent launch). */
+int mnv_accel_set_cu_budget(mnv_accel *accel, int32_t num_cus);
 int mnv_render_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,
                             mnv_rect tile, float *rgba_out, uint8_t *rgba8_out, void *hip_stream);
 
@@ -173,7 +179,8 @@ int mnv_render_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const
  * row-major; this call renders the macro tiles m with m % world == rank.  Outputs are compact
  * and local-tile-major: local tile j = m / world is stored at
  * rgba_out[j][tile_h][tile_w][4] (pixels outside `tile` are left untouched), which is the
- * contiguous buffer each rank hands to the RCCL gather.  world <= 1 is the plain call.
+ * contiguous buffer each rank hands to the RCCL gather.  world <= 1 with tile_w == 0 is the plain call; world == 1 with a
+ * tile size gives the same macro-tile-major layout from a single rank.
  */
 typedef struct mnv_partition {
     int32_t rank, world;
@@ -421,6 +428,16 @@ void mnv_mlp_destroy(mnv_mlp *mlp);
  */
 int mnv_query_submodules(mnv_mlp *mlp, const int16_t *cluster_indices, const float *samples, int32_t samples_stride,
                          int64_t n, float *results, int32_t result_stride, void *hip_stream);
+
+/* A HIP stream whose kernels run on all but `reserve_cus` compute units (hipExtStreamCreateWithCUMask; the units are taken
+ * evenly from the XCDs, and from their shader engines when reserve_cus is a multiple of 32).  The tuned kernel is persistent and
+ * fills every wave slot of the units it may use, so kernels of other streams -- the RCCL channel workgroups of the multi-GPU
+ * tile gather (about 288 VGPRs per lane: they do not fit beside more than three march workgroups) -- would otherwise wait
+ * for a whole launch to drain.  Launch the march on this stream and give the accel the matching budget
+ * (mnv_accel_set_cu_budget(accel, *enabled_cus)).  reserve_cus == 0: an ordinary non-blocking stream.  New: the reference
+ * renders on one GPU and has no gather. */
+int mnv_stream_create_reserved(int32_t reserve_cus, void **stream_out, int32_t *enabled_cus);
+int mnv_stream_destroy(void *stream);
 
 /* Average device time (ms) of the last `mnv_render_*` launches since the
  * previous call, measured with HIP events on the launch stream when

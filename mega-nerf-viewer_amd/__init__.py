@@ -192,6 +192,9 @@ _SIGNATURES = {
     "mnv_accel_rebuild": (C.c_int, [C.c_void_p, C.POINTER(TreeView), C.c_void_p]),
     "mnv_accel_destroy": (None, [C.c_void_p]),
     "mnv_accel_device_bytes": (C.c_size_t, [C.c_void_p]),
+    "mnv_accel_set_cu_budget": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mnv_stream_create_reserved": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
+    "mnv_stream_destroy": (C.c_int, [C.c_void_p]),
     "mnv_render_voxels_accel": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_partition_local_tiles": (C.c_int32, [Rect, Partition]),
@@ -754,6 +757,22 @@ def render_voxels_accel_batch(accel: int, cams, opt: RenderOptions, tile=None, p
     p = Partition(0, 1, 0, 0) if part is None else Partition(*part)
     _check(lib().mnv_render_voxels_accel_batch(C.c_void_p(accel), arr, n, C.byref(opt), Rect(*tile), p, _ptr(rgba), _ptr(rgba8),
                                                C.c_void_p(stream)))
+
+
+def accel_set_cu_budget(accel: int, num_cus: int) -> None:
+    """Compute units the tuned kernel fills (0 = all); for launches on a CU-masked stream."""
+    _check(lib().mnv_accel_set_cu_budget(accel, int(num_cus)))
+
+
+def stream_create_reserved(reserve_cus: int):
+    """(stream handle, enabled compute units): a HIP stream that leaves `reserve_cus` units free for other streams' kernels."""
+    h, n = C.c_void_p(), C.c_int32()
+    _check(lib().mnv_stream_create_reserved(int(reserve_cus), C.byref(h), C.byref(n)))
+    return h.value, n.value
+
+
+def stream_destroy(stream: int) -> None:
+    _check(lib().mnv_stream_destroy(C.c_void_p(stream)))
 
 
 def set_timing(enable: bool) -> None:

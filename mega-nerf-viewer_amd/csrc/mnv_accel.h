@@ -71,7 +71,10 @@ struct mnv_accel {
     // written on the launch stream by stage_launch_kernel; kSlots launches may be in flight
     uint8_t *slots_dev = nullptr;
     std::atomic<uint32_t> slot_counter{0};
+    hipEvent_t slot_done[mnv::kSlots] = {};  // recorded after the launch that used the slot
+    bool slot_used[mnv::kSlots] = {};
     size_t bytes = 0;
     int device = 0;
-    int num_cus = 0;
+    int num_cus = 0;     // units the persistent launch fills (mnv_accel_set_cu_budget)
+    int device_cus = 0;  // units of the device
 };

@@ -165,6 +165,34 @@ void mnv_set_timing(int enable) {
     g_timing_launches = 0;
 }
 
+int mnv_stream_create_reserved(int32_t reserve_cus, void **stream_out, int32_t *enabled_cus) {
+    if (!stream_out) return set_error(MNV_E_INVALID, "stream_out is null");
+    int dev = 0;
+    int rc = check_hip(hipGetDevice(&dev), "hipGetDevice");
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    if ((rc = check_hip(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties"))) return rc;
+    const int n = prop.multiProcessorCount;
+    if (reserve_cus < 0 || reserve_cus >= n) return set_error(MNV_E_INVALID, "reserve_cus must be in [0, compute units of the device)");
+    hipStream_t s = nullptr;
+    if (reserve_cus == 0) {
+        if ((rc = check_hip(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreateWithFlags"))) return rc;
+    } else {
+        // low (n - reserve) bits: on gfx942 / gfx950 mask bit i enables a unit of XCD i % 8 and, within the XCD, of shader
+        // engine (i / 8) % 4 (tools/cumask/map_bits.py), so a multiple of 32 removes one unit from every shader engine
+        uint32_t mask[32] = {0};
+        const int keep = n - reserve_cus;
+        if (n > 1024) return set_error(MNV_E_UNSUPPORTED, "more than 1024 compute units");
+        for (int i = 0; i < keep; ++i) mask[i >> 5] |= 1u << (i & 31);
+        if ((rc = check_hip(hipExtStreamCreateWithCUMask(&s, (uint32_t)((n + 31) / 32), mask), "hipExtStreamCreateWithCUMask"))) return rc;
+    }
+    *stream_out = (void *)s;
+    if (enabled_cus) *enabled_cus = n - reserve_cus;
+    return MNV_OK;
+}
+
+int mnv_stream_destroy(void *stream) { return check_hip(hipStreamDestroy((hipStream_t)stream), "hipStreamDestroy"); }
+
 int mnv_take_timing(double *total_ms, int32_t *launches) {
     std::lock_guard<std::mutex> lk(g_timing_mu);
     for (auto &p : g_pending) {

@@ -257,7 +257,7 @@ struct AccelLaunch {
     uint32_t band_begin[kNumQueues + 1];  // tile ranges per queue
     int32_t lds_level;                    // levels staged in LDS (<= A.grid_level)
     int32_t refill_min;                   // refill a wavefront once this many lanes are idle
-    // interleaved macro-tile partition (world <= 1: plain tile)
+    // interleaved macro-tile partition (part_world = 0: plain tile)
     int32_t part_rank, part_world;
     uint32_t macro_w, macro_h;            // macro tile size in pixels
     uint32_t macros_x;                    // macro tiles per row of the rectangle
@@ -281,7 +281,7 @@ struct AccelLaunch {
 // ray id -> pixel of the rectangle (bx, by) and index of the pixel in the output buffer
 __device__ __forceinline__ bool ray_pixel(const AccelLaunch &K, uint32_t id, int &bx, int &by, uint32_t &pix) {
     const uint32_t tile = id >> 6, w = id & 63u;
-    if (K.part_world <= 1) {
+    if (K.part_world < 1) {
         const uint32_t tx = tile % K.tiles_x, ty = tile / K.tiles_x;
         bx = (int)((tx << K.tile_wlog) + (w & ((1u << K.tile_wlog) - 1u)));
         by = (int)((ty << (6 - K.tile_wlog)) + (w >> K.tile_wlog));
@@ -796,8 +796,11 @@ static int launch_variant(const AccelLaunch &K, int n_blocks, size_t lds_bytes, 
     return launch_variant2<BASIS, 0>(K, n_blocks, lds_bytes, stream);
 }
 
+// world > 1, or a single rank that asks for the macro-tile-major layout by naming a tile size
+static bool is_partitioned(mnv_partition part) { return part.world > 1 || (part.world == 1 && part.tile_w > 0); }
+
 int32_t partition_local_tiles(mnv_rect tile, mnv_partition part) {
-    if (tile.w <= 0 || tile.h <= 0 || part.world <= 1) return part.world <= 1 ? 1 : 0;
+    if (tile.w <= 0 || tile.h <= 0 || !is_partitioned(part)) return is_partitioned(part) ? 0 : 1;
     const int64_t mx = (tile.w + part.tile_w - 1) / part.tile_w, my = (tile.h + part.tile_h - 1) / part.tile_h;
     const int64_t total = mx * my;
     if (part.rank >= total) return 0;
@@ -816,6 +819,8 @@ struct AccelTrack {
     int32_t max_guided_samples, samples_dim, need_viewdir, appearance_embedding;
     const mnv_cluster_grid *grid;
 };
+
+constexpr int kUnsupportedBasis = -1000;  // not a hipError_t
 
 int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *cams, int n_frames, mnv_partition part,
                  const AccelTrack *track, hipStream_t stream) {
@@ -846,10 +851,10 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     }
     K.A = accel->view;
     K.part_rank = part.rank;
-    K.part_world = part.world;
+    K.part_world = is_partitioned(part) ? part.world : 0;
     static const int env_wlog = getenv("MNV_TILE_WLOG") ? atoi(getenv("MNV_TILE_WLOG")) : 3;
     K.tile_wlog = (env_wlog >= 0 && env_wlog <= 6) ? (uint32_t)env_wlog : 3u;
-    if (part.world <= 1) {
+    if (!is_partitioned(part)) {
         const uint32_t tile_w = 1u << K.tile_wlog, tile_h = 64u >> K.tile_wlog;
         K.tiles_x = (uint32_t)((P.tw + tile_w - 1) / tile_w);
         const uint32_t tiles_y = (uint32_t)((P.th + tile_h - 1) / tile_h);
@@ -877,12 +882,11 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
         for (int q = 0; q <= kNumQueues; ++q)
             K.band_begin[q] = q >= env_queues ? total : (uint32_t)(((uint64_t)total * q) / env_queues);
     }
-    // per-launch slot: zeroed queue heads for every frame + the camera blocks, staged in pinned host
-    // memory and uploaded with one asynchronous copy on the launch stream
+    // per-launch slot: zeroed queue heads + the camera blocks, written by stage_launch_kernel on the launch stream
     K.n_frames = (uint32_t)n_frames;
     // frames of a batch are j_max = ceil(macro tiles / world) local tiles apart on EVERY rank, so that the
     // per-rank buffers have one shape (what the gather needs) even when the tile count is ragged
-    if (part.world <= 1) {
+    if (!is_partitioned(part)) {
         K.frame_stride_px = (uint32_t)P.tw * (uint32_t)P.th;
     } else {
         const uint32_t n_macro = K.macros_x * (uint32_t)((P.th + part.tile_h - 1) / part.tile_h);
@@ -890,6 +894,11 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     }
     mnv_accel *mut = const_cast<mnv_accel *>(accel);
     const uint32_t slot = mut->slot_counter.fetch_add(1) % kSlots;
+    // a caller that runs more than kSlots launches ahead of the device waits here for the launch that last used the slot
+    if (mut->slot_used[slot]) {
+        hipError_t es = hipEventSynchronize(mut->slot_done[slot]);
+        if (es != hipSuccess) return (int)es;
+    }
     uint8_t *ds = accel->slots_dev + (size_t)slot * kSlotBytes;
     const size_t heads_bytes = (size_t)kNumQueues * 64;  // one head per queue; a queue spans the frames of the batch
     K.queue = reinterpret_cast<uint32_t *>(ds);
@@ -930,17 +939,24 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     if ((uint64_t)n_blocks * 4u > n_waves_needed) n_blocks = (int)((n_waves_needed + 3) / 4);
     if (n_blocks < 1) n_blocks = 1;
 
-    if (colourless) return launch_variant<9>(K, n_blocks, lds_bytes, stream);
+    int rc = kUnsupportedBasis;
     const int b = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim >= 0) ? accel->view.basis_dim : -1;
-    switch (b) {
-        case -1: return launch_variant<-1>(K, n_blocks, lds_bytes, stream);
-        case 1: return launch_variant<1>(K, n_blocks, lds_bytes, stream);
-        case 4: return launch_variant<4>(K, n_blocks, lds_bytes, stream);
-        case 9: return launch_variant<9>(K, n_blocks, lds_bytes, stream);
-        case 16: return launch_variant<16>(K, n_blocks, lds_bytes, stream);
-        case 25: return launch_variant<25>(K, n_blocks, lds_bytes, stream);
-        default: return -1000;
+    if (colourless) rc = launch_variant<9>(K, n_blocks, lds_bytes, stream);
+    else
+        switch (b) {
+            case -1: rc = launch_variant<-1>(K, n_blocks, lds_bytes, stream); break;
+            case 1: rc = launch_variant<1>(K, n_blocks, lds_bytes, stream); break;
+            case 4: rc = launch_variant<4>(K, n_blocks, lds_bytes, stream); break;
+            case 9: rc = launch_variant<9>(K, n_blocks, lds_bytes, stream); break;
+            case 16: rc = launch_variant<16>(K, n_blocks, lds_bytes, stream); break;
+            case 25: rc = launch_variant<25>(K, n_blocks, lds_bytes, stream); break;
+            default: break;
+        }
+    if (rc == 0) {
+        rc = (int)hipEventRecord(mut->slot_done[slot], stream);
+        mut->slot_used[slot] = true;
     }
+    return rc;
 }
 
 }  // namespace mnv
@@ -1061,7 +1077,7 @@ int mnv_accel_create_reserved(const mnv_tree_view *t, int64_t max_capacity, void
     if ((rc = check_hip(hipGetDevice(&a->device), "hipGetDevice"))) return fail(rc);
     hipDeviceProp_t prop;
     if ((rc = check_hip(hipGetDeviceProperties(&prop, a->device), "hipGetDeviceProperties"))) return fail(rc);
-    a->num_cus = prop.multiProcessorCount;
+    a->num_cus = a->device_cus = prop.multiProcessorCount;
 
     const int row_bytes = row_bytes_for(b);
     a->reserved = max_capacity;
@@ -1070,6 +1086,8 @@ int mnv_accel_create_reserved(const mnv_tree_view *t, int64_t max_capacity, void
     if ((rc = check_hip(hipMalloc((void **)&a->depth, max_capacity * 4), "hipMalloc(depth)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&a->flags, 16), "hipMalloc(flag)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&a->slots_dev, (size_t)kSlots * kSlotBytes), "hipMalloc(slots)"))) return fail(rc);
+    for (int i = 0; i < kSlots; ++i)
+        if ((rc = check_hip(hipEventCreateWithFlags(&a->slot_done[i], hipEventDisableTiming), "hipEventCreate(slot)"))) return fail(rc);
 
     if ((rc = check_hip(hipMalloc((void **)&a->stats, 16 * sizeof(unsigned long long)), "hipMalloc(stats)"))) return fail(rc);
     if ((rc = check_hip(hipMemsetAsync(a->stats, 0, 16 * sizeof(unsigned long long), stream), "memset stats"))) return fail(rc);
@@ -1172,11 +1190,20 @@ void mnv_accel_destroy(mnv_accel *a) {
     if (a->grid2) (void)hipFree(a->grid2);
     if (a->grid2_vox) (void)hipFree(a->grid2_vox);
     if (a->slots_dev) (void)hipFree(a->slots_dev);
+    for (int i = 0; i < kSlots; ++i)
+        if (a->slot_done[i]) (void)hipEventDestroy(a->slot_done[i]);
 
     delete a;
 }
 
 size_t mnv_accel_device_bytes(const mnv_accel *a) { return a ? a->bytes : 0; }
+
+int mnv_accel_set_cu_budget(mnv_accel *a, int32_t num_cus) {
+    if (!a) return set_error(MNV_E_INVALID, "accel is null");
+    if (num_cus > a->device_cus) return set_error(MNV_E_INVALID, "the device has fewer compute units");
+    a->num_cus = num_cus <= 0 ? a->device_cus : num_cus;
+    return MNV_OK;
+}
 
 int32_t mnv_partition_local_tiles(mnv_rect tile, mnv_partition part) { return partition_local_tiles(tile, part); }
 
@@ -1219,7 +1246,7 @@ static int render_accel(const mnv_accel *accel, const mnv_camera *cams, int32_t 
                         void *hip_stream) {
     if (!accel) return set_error(MNV_E_INVALID, "accel is null");
     if (!cams || n_cams < 1 || n_cams > MNV_MAX_BATCH) return set_error(MNV_E_INVALID, "need 1 .. MNV_MAX_BATCH cameras");
-    if (part.world > 1 && (part.rank < 0 || part.rank >= part.world || part.tile_w < 8 || part.tile_h < 8 ||
+    if (is_partitioned(part) && (part.rank < 0 || part.rank >= part.world || part.tile_w < 8 || part.tile_h < 8 ||
                            part.tile_w % 8 || part.tile_h % 8))
         return set_error(MNV_E_INVALID, "partition needs 0 <= rank < world and macro tiles that are multiples of 8 pixels");
     for (int i = 1; i < n_cams; ++i)
@@ -1241,7 +1268,7 @@ static int render_accel(const mnv_accel *accel, const mnv_camera *cams, int32_t 
     hipStream_t stream = (hipStream_t)hip_stream;
     LaunchTimer timer(stream);
     rc = launch_accel(accel, P, blocks, n_cams, part, track, stream);
-    if (rc == -1000) return set_error(MNV_E_UNSUPPORTED, "unsupported basis_dim for the accel path");
+    if (rc == kUnsupportedBasis) return set_error(MNV_E_UNSUPPORTED, "unsupported basis_dim for the accel path");
     return check_hip((hipError_t)rc, "march_accel_kernel");
 }
 

@@ -73,9 +73,11 @@ class TilePartition:
 
 
 class TileGatherer:
-    """Ring of `depth` in-flight frames: render into ``local(slot)``, then ``submit(slot)`` starts the
-    asynchronous gather to rank 0; ``finish(slot)`` waits for it and (on rank 0) un-permutes into
-    ``frame(slot)``.  With depth >= 2 the gather of frame k overlaps the render of frame k+1."""
+    """Ring of `depth` in-flight steps: render into ``local(slot)`` on the current stream, then ``submit(slot)`` starts the
+    asynchronous gather to rank 0; ``finish(slot)`` orders the slot's next render after that gather and (on rank 0) un-permutes
+    into ``frame(slot)``.  Nothing here blocks the host, and nothing but the reuse of a slot's own buffer makes the render stream
+    wait: the gather's completion and the un-permute are enqueued on a side stream, so with depth >= 2 the gather and assembly of
+    step k overlap the render of step k+1 (on rank 0 too, which would otherwise pay the un-permute between two renders)."""
 
     def __init__(self, part: TilePartition, rank: int, device, dtype=torch.float32, channels: int = 4, depth: int = 3, group=None,
                  frames: int = 0, stage_on_host: bool = False):
@@ -88,6 +90,9 @@ class TileGatherer:
         shape = lead + (part.j_max, part.tile_h, part.tile_w, channels)
         self._local = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(depth)]
         self._pending = [None] * depth
+        on_gpu = torch.device(device).type == "cuda"
+        self._side = torch.cuda.Stream(device=device) if on_gpu and not stage_on_host else None
+        self._sent = [torch.cuda.Event() for _ in range(depth)] if self._side is not None else None
         if rank == 0:
             self._gathered = [torch.empty((part.world,) + shape, dtype=dtype, device=device) for _ in range(depth)]
             self._frames = [torch.empty(lead + (part.height, part.width, channels), dtype=dtype, device=device) for _ in range(depth)]
@@ -105,23 +110,42 @@ class TileGatherer:
             self._pending[slot] = (dist.gather(src, host, dst=0, group=self.group, async_op=True), host, src)
             return
         glist = [self._gathered[slot][r] for r in range(self.part.world)] if self.rank == 0 else None
-        self._pending[slot] = dist.gather(self._local[slot], glist, dst=0, group=self.group, async_op=True)
+        if self._side is None:
+            self._pending[slot] = dist.gather(self._local[slot], glist, dst=0, group=self.group, async_op=True)
+            return
+        # the collective is ordered after everything the side stream holds (the un-permute that last read this slot's gather
+        # buffer) and after the render just enqueued on the current stream
+        self._side.wait_stream(torch.cuda.current_stream(self._side.device))
+        with torch.cuda.stream(self._side):
+            self._pending[slot] = dist.gather(self._local[slot], glist, dst=0, group=self.group, async_op=True)
 
     def finish(self, slot: int) -> None:
         w = self._pending[slot]
         if w is None:
             return
+        self._pending[slot] = None
         if self.stage_on_host:
             w[0].wait()
             if self.rank == 0:
                 for r, h in enumerate(w[1]):
                     self._gathered[slot][r].copy_(h)
-        else:
+                self.part.unpermute(self._gathered[slot], out=self._frames[slot])
+            return
+        if self._side is None:
             w.wait()
-        self._pending[slot] = None
-        if self.rank == 0:
-            self.part.unpermute(self._gathered[slot], out=self._frames[slot])
+            if self.rank == 0:
+                self.part.unpermute(self._gathered[slot], out=self._frames[slot])
+            return
+        with torch.cuda.stream(self._side):
+            w.wait()                       # side stream: after the gather
+            self._sent[slot].record()      # local(slot) may be overwritten from here on
+            if self.rank == 0:
+                self.part.unpermute(self._gathered[slot], out=self._frames[slot])
+        torch.cuda.current_stream(self._side.device).wait_event(self._sent[slot])
 
     def finish_all(self) -> None:
         for s in range(self.depth):
             self.finish(s)
+        if self._side is not None:
+            # frames are read on the current stream (or the host) next
+            torch.cuda.current_stream(self._side.device).wait_stream(self._side)

@@ -34,3 +34,19 @@ def test_bench_multirank_rehearsal(torch_gpu, world, gather):
     assert d["n_gpus"] == world and d["scaling"] == "strong" and d["steps"] == 2
     assert d["parity"]["pixels_not_bit_identical"] == 0 and d["parity"]["max_abs_drgba_vs_oracle"] == 0.0
     assert d["value"] > 0 and d["roofline"]["launches"] == 2
+
+
+@pytest.mark.parametrize("gather,reserve", [("u8", 32), ("f32", 0)])
+def test_bench_rccl_path_single_rank(torch_gpu, gather, reserve):
+    """The RCCL calls of the N > 1 path executed for real (a one-GPU box allows one rank): process group on "nccl", partition with
+    world 1, march on the CU-masked stream, dist.gather on the side stream, un-permute, all_reduce, barrier.  Assembled frames are
+    compared with the oracle inside bench.py."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port()))
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "3", "--warmup", "1", "--laps", "1", "--gather", gather,
+           "--reserve-cus", str(reserve)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["reserved_cus"] == reserve and "RCCL gather" in d["config"]["partition"]
+    assert d["parity"]["pixels_not_bit_identical"] == 0 and d["parity"]["frames_checked"] == 2
+    assert d["value"] > 0 and d["roofline"]["launches"] == 3
