@@ -553,17 +553,24 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                 pos[2] = cen2 + t * dir2;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    pos[i] = fmaxf(fminf(pos[i], 1.f - 1e-6f), 0.f);
+                    pos[i] = __builtin_amdgcn_fmed3f(pos[i], 0.f, 1.f - 1e-6f);  // == max(min(x, hi), 0) for every non-NaN x
                     q[i] = (uint32_t)(pos[i] * qscale);
                 }
                 // top of the tree: LDS grid at level LL
-                uint32_t word = s_grid[((((q[0] >> sh1) << LL) + (q[1] >> sh1)) << LL) + (q[2] >> sh1)];
+                uint32_t word = s_grid[((((q[0] >> sh1) << LL) | (q[1] >> sh1)) << LL) | (q[2] >> sh1)];
                 int src = 0;  // where the leaf word came from: 0 LDS grid, 1 grid2, 2 node array
                 if (!(word & kLeafBit)) {
                     int sh = sh1;  // q >> sh is the cell at the depth `word` describes
                     if (L2 > LL) {
                         // middle of the tree: one load from the brick-ordered level-L2 grid
-                        vox = grid2_index(q[0] >> sh2, q[1] >> sh2, q[2] >> sh2, L2);
+                        // brick number from the high bits of the three cell coordinates, cell-in-brick from their two low bits
+                        const int LB = L2 - 2;
+                        uint32_t g = q[0] >> (sh2 + 2);
+                        g = (g << LB) | (q[1] >> (sh2 + 2));
+                        g = (g << LB) | (q[2] >> (sh2 + 2));
+                        g = (g << 2) | __builtin_amdgcn_ubfe(q[0], (uint32_t)sh2, 2u);
+                        g = (g << 2) | __builtin_amdgcn_ubfe(q[1], (uint32_t)sh2, 2u);
+                        vox = (g << 2) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh2, 2u);
                         word = A.grid2[vox];
                         src = 1;
                         sh = sh2;
@@ -571,8 +578,9 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                     while (!(word & kLeafBit)) {
                         stat(6, true);
                         --sh;
-                        const uint32_t cidx = (((q[0] >> sh) & 1u) << 2) | (((q[1] >> sh) & 1u) << 1) | ((q[2] >> sh) & 1u);
-                        vox = word * 8u + cidx;
+                        uint32_t v = (word << 1) | __builtin_amdgcn_ubfe(q[0], (uint32_t)sh, 1u);
+                        v = (v << 1) | __builtin_amdgcn_ubfe(q[1], (uint32_t)sh, 1u);
+                        vox = (v << 1) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh, 1u);
                         word = A.nodes[vox];
                         src = 2;
                     }
@@ -677,6 +685,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                 for (int base = 0; base < n_dense; base += 21) {
                     const int smp = base + my_s;
                     const bool task = my_s < 21 && smp < n_dense;
+                    stat(10, task);  // colour passes and their busy task lanes
                     const int owner = task ? (int)map[smp] : lane;
                     const float w = lane_read(weight, owner);
                     uint32_t vx = lane_read(vox, owner);
@@ -1174,8 +1183,8 @@ void mnv_accel_destroy(mnv_accel *a) {
     if (a->stats && getenv("MNV_STATS")) {
         unsigned long long h[16];
         if (hipMemcpy(h, a->stats, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-            const char *names[] = {"outer_iter", "refill", "march_step", "node_load", "dense"};
-            for (int i = 0; i < 5; ++i)
+            const char *names[] = {"outer_iter", "refill", "march_step", "node_load", "dense", "colour_pass"};
+            for (int i = 0; i < 6; ++i)
                 fprintf(stderr, "[mnv stats] %-13s wave-level %llu lane-level %llu (%.1f lanes)\n", names[i], h[2 * i], h[2 * i + 1],
                         h[2 * i] ? (double)h[2 * i + 1] / (double)h[2 * i] : 0.0);
         }
