@@ -506,3 +506,57 @@ def test_reference_binding_is_a_drop_in(mnv, orc, torch_gpu, tmp_path, name):
     assert np.array_equal(got["visited"], visited)
     got = mnv_ref.dropin_render_npz(path, cam_spec, opt, v.capacity, path=1)
     assert np.array_equal(cases.bits(got["rgba"]), cases.bits(want["rgba"])) and np.array_equal(got["rgba8"], want["rgba8"])
+
+
+def test_reserved_stream_renders_bit_identical_frames(mnv, torch_gpu, cfg2):
+    """mnv_stream_create_reserved + mnv_accel_set_cu_budget (the multi-GPU path's CU-masked launch stream): frames, single and batched,
+    are the frames of the ordinary stream; invalid reservations and budgets are refused; more launches than launch slots may be queued."""
+    torch = torch_gpu
+    opt = mnv.RenderOptions.cli_defaults()
+    cams = [cases.cfg2_camera(mnv, pose=p) for p in (2, 9)]
+    H, W = cams[0].height, cams[0].width
+    want = torch.empty((2, H, W, 4), dtype=torch.float32, device="cuda")
+    mnv.render_voxels_accel_batch(cfg2.accel, cams, opt, rgba=want)
+    torch.cuda.synchronize()
+    n_cus = torch.cuda.get_device_properties(0).multi_processor_count
+    for bad in (-1, n_cus):
+        with pytest.raises(mnv.MnvError):
+            mnv.stream_create_reserved(bad)
+    with pytest.raises(mnv.MnvError):
+        mnv.accel_set_cu_budget(cfg2.accel, n_cus + 1)
+    handle, enabled = mnv.stream_create_reserved(32)
+    try:
+        assert enabled == n_cus - 32
+        mnv.accel_set_cu_budget(cfg2.accel, enabled)
+        st = torch.cuda.ExternalStream(handle)
+        got = torch.full((2, H, W, 4), float("nan"), dtype=torch.float32, device="cuda")
+        one = torch.full((H, W, 4), float("nan"), dtype=torch.float32, device="cuda")
+        for _ in range(70):  # more than the 64 launch slots of the accel: the 65th launch waits for the first
+            mnv.render_voxels_accel(cfg2.accel, cams[1], opt, rgba=one, stream=handle)
+        mnv.render_voxels_accel_batch(cfg2.accel, cams, opt, rgba=got, stream=handle)
+        st.synchronize()
+        assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+        assert torch.equal(one.view(torch.int32), want[1].view(torch.int32))
+    finally:
+        mnv.accel_set_cu_budget(cfg2.accel, 0)
+        torch.cuda.synchronize()
+        mnv.stream_destroy(handle)
+
+
+def test_single_rank_partition_layout(mnv, torch_gpu, cfg2):
+    """world == 1 with a tile size: the macro-tile-major layout from one rank (what bench.py --force-dist gathers) un-permutes
+    to the plain frame."""
+    from mega_nerf_viewer_amd.multigpu import TilePartition
+    torch = torch_gpu
+    opt = mnv.RenderOptions.cli_defaults()
+    cam = cases.cfg2_camera(mnv, pose=11)
+    H, W = cam.height, cam.width
+    full, _ = _render_gpu(mnv, torch, cfg2, cam, opt, "accel")
+    part = TilePartition(W, H, 1, 64, 24)
+    assert mnv.partition_local_tiles((0, 0, W, H), 0, 1, 64, 24) == part.n_macro == 1350
+    buf = torch.full((1, part.j_max, 24, 64, 4), float("nan"), dtype=torch.float32, device="cuda")
+    mnv.render_voxels_accel_part(cfg2.accel, cam, opt, 0, 1, 64, 24, rgba=buf[0])
+    out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    part.unpermute(buf, out=out)
+    torch.cuda.synchronize()
+    assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(full))
