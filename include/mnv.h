@@ -215,9 +215,9 @@ int mnv_assemble_tiles(const void *gathered, void *frames, int32_t width, int32_
  * Several frames in ONE launch: cams[0 .. n_cams) (same image size, same options, same tile /
  * partition); frame f is written at rgba_out + f * frame_elems * 4 (frame_elems = tile.w * tile.h, or
  * ceil(macro_tiles / world) * tile_w * tile_h under a partition -- the same on every rank, so that
- * the per-rank buffers have one shape even when a rank owns one tile fewer).  Wavefronts walk the frames in order at
- * their own pace, so the tail of one frame overlaps the start of the next -- for a camera path this
- * is ~30 % faster than one launch per frame.  n_cams <= MNV_MAX_BATCH.
+ * the per-rank buffers have one shape even when a rank owns one tile fewer).  The ray queues span the frames of the
+ * batch (frame-major), so wavefronts that finish their share of one frame carry on with the next: the tail of a frame overlaps
+ * the start of the next -- for a camera path this is ~2x faster than one launch per frame.  n_cams <= MNV_MAX_BATCH.
  */
 #define MNV_MAX_BATCH 64
 int mnv_render_voxels_accel_batch(const mnv_accel *accel, const mnv_camera *cams, int32_t n_cams,
