@@ -27,6 +27,13 @@ for f in find("trace/**/*kernel_trace.csv"):
             if KEY in n and n not in seen:
                 seen.add(n)
                 print({k: row[k] for k in row if k in ("Kernel_Name", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")})
+print("== kernel trace: duration of every dispatch of the march kernel, in order (ns; the first one runs cold: page tables, caches) ==")
+for f in find("trace/**/*kernel_trace.csv"):
+    with open(f) as fh:
+        rows = [r for r in csv.DictReader(fh) if KEY in r.get("Kernel_Name", "")]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows]
+    print(durs, "mean of all but the first:", round(sum(durs[1:]) / max(1, len(durs) - 1)) if len(durs) > 1 else None)
 print("== PMC counters, per-dispatch average over the march kernel's dispatches ==")
 for d in find("pmc_*/"):
     agg = defaultdict(list)
