@@ -322,7 +322,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload,
                        "rays_per_step": rays_per_step, "kernel": args.kernel, "launches_per_step": 1 if not args.per_frame and args.kernel == "accel" else N_FRAMES,
-                       "partition": "none" if not multi else f"interleaved {MACRO_W}x{MACRO_H} macro tiles, {args.gather} RCCL gather to rank 0",
+                       "partition": "none" if not multi else f"interleaved {MACRO_W}x{MACRO_H} macro tiles, {args.gather} {'RCCL' if args.backend == 'nccl' else 'gloo (host-staged rehearsal)'} gather to rank 0",
                        "reserved_cus": reserve, "march_streams": n_march_streams},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
