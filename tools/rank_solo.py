@@ -28,15 +28,19 @@ def main():
     ap.add_argument("--macro", default="64x24")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--laps", type=int, default=4)
+    ap.add_argument("--workload", choices=["cfg2", "cfg4"], default="cfg2", help="cfg4 = the merged-octree stand-in at 3840x2160 (BASELINE.json configs[3])")
     args = ap.parse_args()
-    W, H, FX = 1920, 1080, 1600.0
+    W, H, FX = (1920, 1080, 1600.0) if args.workload == "cfg2" else (3840, 2160, 2800.0)
     nf = 16 * args.laps
     mw, mh = (int(v) for v in args.macro.split("x"))
     dev = torch.device("cuda", 0)
-    tree = cases.make_tree(mnv, cases.CFG2_TREE)
+    tree = cases.make_tree(mnv, cases.CFG2_TREE if args.workload == "cfg2" else cases.CFG3_TREE)
     tree.move_to_device()
     opt = mnv.RenderOptions.cli_defaults()
-    cams = [cases.cfg2_camera(mnv, p % 16, W, H, FX) for p in range(nf)]
+    if args.workload == "cfg2":
+        cams = [cases.cfg2_camera(mnv, p % 16, W, H, FX) for p in range(nf)]
+    else:
+        cams = [cases.cfg3_camera(mnv, p % 16, W, H, fx=FX) for p in range(nf)]
     rows = []
     for reserve in (int(v) for v in args.reserves.split(",")):
         for n_streams in (int(v) for v in args.streams.split(",")):
@@ -61,7 +65,7 @@ def main():
                 t0 = time.perf_counter()
                 run(args.steps)
                 ms = (time.perf_counter() - t0) / args.steps * 1e3
-                row = {"world": world, "rank": args.rank, "reserve": reserve, "streams": n_streams, "ms_per_step": round(ms, 4),
+                row = {"workload": args.workload, "world": world, "rank": args.rank, "reserve": reserve, "streams": n_streams, "ms_per_step": round(ms, 4),
                        "Mrays_per_s_if_all_ranks_alike": round(nf * W * H / ms / 1e3, 1)}
                 rows.append(row)
                 print(json.dumps(row), flush=True)
