@@ -263,6 +263,7 @@ struct AccelLaunch {
     uint32_t macros_x;                    // macro tiles per row of the rectangle
     uint32_t micro_x, micro_per_macro;    // 8x8 micro tiles per macro-tile row / per macro tile
     unsigned long long *stats;            // MODE 1 only: 16 counters
+    int32_t count_stats;                  // MODE 1 only: 0 = ablation run without the counters' atomics
     // MODE 2 only: refinement trackers (rt_core.cuh:179-180,237-252,308-321), indexed like the pixels
     float *split_track, *sample_track;
     const int16_t *sample_counts;         // reference layout [capacity][8], may be NULL
@@ -432,6 +433,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
 
     auto stat = [&](int slot, bool pred) {
         if constexpr (MODE == 1) {
+            if (!K.count_stats) return;
             const uint64_t m = __ballot(pred);
             if (m && lane == (int)__builtin_ctzll(m)) {
                 atomicAdd(&K.stats[slot], 1ull);
@@ -939,6 +941,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     K.ablate = env_ablate;
     static const bool env_stats = getenv("MNV_STATS") != nullptr;
     K.stats = (env_stats || env_ablate) ? accel->stats : nullptr;  // both run on the diagnostics instantiation
+    K.count_stats = env_stats ? 1 : 0;
     K.refill_min = (env_refill > 0 && n_frames == 1) ? env_refill : 64;  // batches refill whole tiles (a grab must not straddle frames);  // sweep in DESIGN.md: 16 -> 0.606 ms, 32 -> 0.535, 48 -> 0.507, 56 -> 0.504, 64 -> 0.506
     int blocks_per_cu = lds_level >= 5 ? 1 : (lds_level == 4 ? 6 : 8);
     if ((K.split_track || K.sample_track || K.samples) && blocks_per_cu > MNV_TRACK_WAVES) blocks_per_cu = MNV_TRACK_WAVES;

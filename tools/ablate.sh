@@ -1,6 +1,7 @@
+#!/bin/bash
+# Ablations of the march kernel (diagnostics instantiation, counters off): MNV_ABLATE bits 1 = no colour evaluation, 2 = no dense samples, 4 = colour rows from 64 K cached rows (wrong colours)
 run() { echo -n "$*: "; env "$@" python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['avg_launch_ms'])"; }
-run MNV_STATS=1
+run MNV_ABLATE=8
 run MNV_ABLATE=4
 run MNV_ABLATE=1
 run MNV_ABLATE=2
-run MNV_GRID2_LEVEL=8
