@@ -86,6 +86,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="test hook: with one process, run the N > 1 code path (process group, partition with world 1, reserved stream, "
                          "tile gather, un-permute) -- the only way to execute the RCCL calls on a one-GPU box")
+    ap.add_argument("--root-period", type=int, default=-1,
+                    help="N > 1: mnv_partition.root_period -- every M-th round of the tile deal leaves rank 0 out, because rank 0 also takes in "
+                         "the gather and un-permutes the frames (tools/root_emulation.py: +19 %% on its march at N = 8).  Default round(44 / N) "
+                         "(6 at N = 8: rank 0 renders 5/6 of a plain share); 0 = plain round robin")
     ap.add_argument("--laps", type=int, default=4, help="the step walks the 16-pose orbit this many times (16 x laps frames in one launch, <= 64)")
     args = ap.parse_args()
     global W, H, N_FRAMES
@@ -177,9 +181,10 @@ def main():
     else:
         from mega_nerf_viewer_amd.multigpu import TileGatherer, TilePartition
 
-        part = TilePartition(W, H, world, MACRO_W, MACRO_H)
+        root_period = args.root_period if args.root_period >= 0 else (max(2, round(44 / world)) if world > 1 else 0)
+        part = TilePartition(W, H, world, MACRO_W, MACRO_H, root_period)
         n_local = part.local_tiles(rank)
-        assert n_local == mnv.partition_local_tiles((0, 0, W, H), rank, world, MACRO_W, MACRO_H)
+        assert n_local == mnv.partition_local_tiles((0, 0, W, H), rank, world, MACRO_W, MACRO_H, part.root_period)
         dt = torch.float32 if args.gather == "f32" else torch.uint8
         # one launch + one gather per step; the gather of step k overlaps the launch of step k + 1
         tg = TileGatherer(part, rank, dev, dtype=dt, depth=RING, frames=N_FRAMES, stage_on_host=args.backend == "gloo")
@@ -194,7 +199,7 @@ def main():
                 tg.finish(slot)  # orders this stream after the slot's previous gather: its buffer is about to be overwritten
                 kw = dict(rgba=tg.local(slot)) if args.gather == "f32" else dict(rgba8=tg.local(slot))
                 if n_local > 0:
-                    mnv.render_voxels_accel_batch(tree.accel, cams, opt, part=(rank, world, MACRO_W, MACRO_H), stream=st.cuda_stream, **kw)
+                    mnv.render_voxels_accel_batch(tree.accel, cams, opt, part=part.part(rank), stream=st.cuda_stream, **kw)
                 tg.submit(slot)
 
         def render_pose(i, out):
@@ -289,7 +294,7 @@ def main():
         poses = counters["poses"]
         mean_bytes = float(np.mean([alg_bytes(c) for c in poses.values()]))
         frames_per_launch = 1 if (args.per_frame or args.kernel != "accel") and not multi else N_FRAMES
-        per_launch = mean_bytes * frames_per_launch / world   # each rank's launch covers 1/world of its frames
+        per_launch = mean_bytes * frames_per_launch / world   # each rank's launch covers about 1/world of its frames (rank 0 a little less, see --root-period)
         avg_ms = kern_ms / launches
         achieved = per_launch / (avg_ms * 1e-3) / 1e9
         traffic = None
@@ -323,7 +328,7 @@ def main():
             "config": {"workload": workload,
                        "rays_per_step": rays_per_step, "kernel": args.kernel, "launches_per_step": 1 if not args.per_frame and args.kernel == "accel" else N_FRAMES,
                        "partition": "none" if not multi else f"interleaved {MACRO_W}x{MACRO_H} macro tiles, {args.gather} {'RCCL' if args.backend == 'nccl' else 'gloo (host-staged rehearsal)'} gather to rank 0",
-                       "reserved_cus": reserve, "march_streams": n_march_streams},
+                       "reserved_cus": reserve, "march_streams": n_march_streams, "root_period": part.root_period if multi else 0},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "parity": parity,

@@ -185,6 +185,10 @@ int mnv_render_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const
 typedef struct mnv_partition {
     int32_t rank, world;
     int32_t tile_w, tile_h;
+    /* 0: macro tile m belongs to rank m % world (local index m / world).  M >= 2: tiles are still dealt in rounds of `world`, but every
+     * M-th round leaves rank 0 out -- rank 0 renders (M - 1) / M of a plain share.  For the rank that also receives the gather and
+     * un-permutes the frames (measured on one MI355X for world 8: that work stretches its march by 19 %, tools/root_emulation.py). */
+    int32_t root_period;
 } mnv_partition;
 /* number of local macro tiles of `rank` (the leading dimension of its output buffer) */
 int32_t mnv_partition_local_tiles(mnv_rect tile, mnv_partition part);
@@ -206,7 +210,7 @@ void mnv_set_colour_math(int fast);
  * The un-permute step on the gathering rank: `gathered` is what the RCCL gather of the ranks'
  * compact buffers produces, [world][n_frames][ceil(macro tiles / world)][tile_h][tile_w] pixels (n_frames = 1 for
  * mnv_render_voxels_accel_part), `frames` receives [n_frames][height][width] pixels.  bytes_per_pixel: 4 (RGBA8) or
- * 16 (float RGBA).  part.rank is ignored.
+ * 16 (float RGBA).  part.rank is ignored; part.root_period must be the one the ranks rendered with.
  */
 int mnv_assemble_tiles(const void *gathered, void *frames, int32_t width, int32_t height, mnv_partition part, int32_t n_frames,
                        int32_t bytes_per_pixel, void *hip_stream);

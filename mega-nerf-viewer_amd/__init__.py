@@ -112,7 +112,7 @@ class Rect(C.Structure):
 
 
 class Partition(C.Structure):
-    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("tile_w", C.c_int32), ("tile_h", C.c_int32)]
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("root_period", C.c_int32)]
 
 
 class ClusterGrid(C.Structure):
@@ -521,25 +521,26 @@ def set_colour_math(fast: bool) -> None:
     lib().mnv_set_colour_math(int(bool(fast)))
 
 
-def assemble_tiles(gathered, frames, width: int, height: int, world: int, tile_w: int, tile_h: int, n_frames: int = 1, stream: int = 0) -> None:
+def assemble_tiles(gathered, frames, width: int, height: int, world: int, tile_w: int, tile_h: int, n_frames: int = 1, stream: int = 0,
+                   root_period: int = 0) -> None:
     """Rank 0's un-permute of the gathered tile buffers into frames (device tensors, RGBA8 or float RGBA)."""
     bpp = gathered.element_size() * 4
-    _check(lib().mnv_assemble_tiles(_ptr(gathered), _ptr(frames), width, height, Partition(0, world, tile_w, tile_h), n_frames, bpp,
+    _check(lib().mnv_assemble_tiles(_ptr(gathered), _ptr(frames), width, height, Partition(0, world, tile_w, tile_h, root_period), n_frames, bpp,
                                     C.c_void_p(stream)))
 
 
-def partition_local_tiles(tile, rank: int, world: int, tile_w: int, tile_h: int) -> int:
-    return int(lib().mnv_partition_local_tiles(Rect(*tile), Partition(rank, world, tile_w, tile_h)))
+def partition_local_tiles(tile, rank: int, world: int, tile_w: int, tile_h: int, root_period: int = 0) -> int:
+    return int(lib().mnv_partition_local_tiles(Rect(*tile), Partition(rank, world, tile_w, tile_h, root_period)))
 
 
 def render_voxels_accel_part(accel: int, cam: Camera, opt: RenderOptions, rank: int, world: int, tile_w: int, tile_h: int,
-                             tile=None, rgba=None, rgba8=None, stream: int = 0) -> None:
-    """Render the macro tiles m % world == rank of `tile` into a compact local-tile-major buffer
-    [local_tiles][tile_h][tile_w][4] (see mnv_partition in include/mnv.h)."""
+                             tile=None, rgba=None, rgba8=None, stream: int = 0, root_period: int = 0) -> None:
+    """Render the macro tiles of `rank` (m % world == rank, or the root-relieving deal of mnv_partition.root_period) of `tile` into a
+    compact local-tile-major buffer [local_tiles][tile_h][tile_w][4] (see mnv_partition in include/mnv.h)."""
     if tile is None:
         tile = (0, 0, cam.width, cam.height)
     _check(lib().mnv_render_voxels_accel_part(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile),
-                                              Partition(rank, world, tile_w, tile_h), _ptr(rgba), _ptr(rgba8), C.c_void_p(stream)))
+                                              Partition(rank, world, tile_w, tile_h, root_period), _ptr(rgba), _ptr(rgba8), C.c_void_p(stream)))
 
 
 def get_samples_from_voxels(tree_view: TreeView, cam: Camera, opt: RenderOptions, num_samples, samples, cluster_indices,
@@ -747,7 +748,7 @@ MAX_BATCH = 64
 def render_voxels_accel_batch(accel: int, cams, opt: RenderOptions, tile=None, part=None, rgba=None, rgba8=None,
                               stream: int = 0) -> None:
     """Several frames (`cams`: list of Camera, same image size) in one launch; frame f is written at
-    rgba[f].  `part` = (rank, world, tile_w, tile_h) selects the interleaved macro-tile partition."""
+    rgba[f].  `part` = (rank, world, tile_w, tile_h[, root_period]) selects the interleaved macro-tile partition."""
     n = len(cams)
     if n < 1 or n > MAX_BATCH:
         raise MnvError(MNV_E_INVALID, f"need 1 .. {MAX_BATCH} cameras, got {n}")

@@ -38,6 +38,47 @@ constexpr int kSlots = 64;        // per-launch parameter slots in flight
 constexpr size_t kSlotBytes = (size_t)MNV_MAX_BATCH * (kNumQueues * 64 + sizeof(mnv::CamBlock));
 constexpr int kMaxGrid2Level = 9;  // 8^9 * 4 B = 512 MiB per array
 
+// Interleaved macro-tile partition (mnv_partition in include/mnv.h).  Tiles are dealt in rounds of `world`; with a root period
+// M >= 2 every M-th round leaves rank 0 out, so a period is L = world * M - 1 tiles of which rank 0 owns M - 1 and the others M.
+__host__ __device__ inline uint32_t part_tile_of(uint32_t j, int32_t rank, int32_t world, int32_t M) {  // local tile j of `rank` -> macro tile
+    if (M < 2) return (uint32_t)rank + j * (uint32_t)world;
+    const uint32_t L = (uint32_t)world * (uint32_t)M - 1u, c = rank == 0 ? (uint32_t)M - 1u : (uint32_t)M;
+    const uint32_t p = j / c, k = j - p * c;
+    return p * L + (k + 1u < (uint32_t)M ? k * (uint32_t)world + (uint32_t)rank : ((uint32_t)M - 1u) * (uint32_t)world + (uint32_t)rank - 1u);
+}
+__host__ __device__ inline void part_owner_of(uint32_t m, int32_t world, int32_t M, uint32_t &rank, uint32_t &j) {  // macro tile -> (rank, local tile)
+    if (M < 2) {
+        rank = m % (uint32_t)world;
+        j = m / (uint32_t)world;
+        return;
+    }
+    const uint32_t L = (uint32_t)world * (uint32_t)M - 1u, p = m / L, o = m - p * L, full = ((uint32_t)M - 1u) * (uint32_t)world;
+    uint32_t k;
+    if (o < full) {
+        k = o / (uint32_t)world;
+        rank = o - k * (uint32_t)world;
+    } else {
+        k = (uint32_t)M - 1u;
+        rank = o - full + 1u;
+    }
+    j = p * (rank == 0 ? (uint32_t)M - 1u : (uint32_t)M) + k;
+}
+// number of macro tiles < n_macro that `rank` owns
+inline int64_t part_local_count(int64_t n_macro, int32_t rank, int32_t world, int32_t M) {
+    if (M < 2) return rank >= n_macro ? 0 : (n_macro - rank + world - 1) / world;
+    const int64_t L = (int64_t)world * M - 1, c = rank == 0 ? M - 1 : M;
+    int64_t n = (n_macro / L) * c;
+    const int64_t rem = n_macro % L;
+    for (int64_t k = 0; k < c; ++k)
+        if ((int64_t)part_tile_of((uint32_t)k, rank, world, M) < rem) ++n;
+    return n;
+}
+inline int64_t part_j_max(int64_t n_macro, int32_t world, int32_t M) {
+    int64_t best = 0;
+    for (int32_t r = 0; r < world; ++r) best = best > part_local_count(n_macro, r, world, M) ? best : part_local_count(n_macro, r, world, M);
+    return best;
+}
+
 struct AccelView {
     const uint32_t *nodes;
     const uint8_t *rows;

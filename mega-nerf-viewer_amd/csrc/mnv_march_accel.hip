@@ -258,7 +258,7 @@ struct AccelLaunch {
     int32_t lds_level;                    // levels staged in LDS (<= A.grid_level)
     int32_t refill_min;                   // refill a wavefront once this many lanes are idle
     // interleaved macro-tile partition (part_world = 0: plain tile)
-    int32_t part_rank, part_world;
+    int32_t part_rank, part_world, part_period;  // part_period: mnv_partition.root_period
     uint32_t macro_w, macro_h;            // macro tile size in pixels
     uint32_t macros_x;                    // macro tiles per row of the rectangle
     uint32_t micro_x, micro_per_macro;    // 8x8 micro tiles per macro-tile row / per macro tile
@@ -290,7 +290,7 @@ __device__ __forceinline__ bool ray_pixel(const AccelLaunch &K, uint32_t id, int
     } else {
         const uint32_t j = tile / K.micro_per_macro, u = tile % K.micro_per_macro;
         const uint32_t mx = u % K.micro_x, my = u / K.micro_x;
-        const uint32_t m = (uint32_t)K.part_rank + j * (uint32_t)K.part_world;
+        const uint32_t m = part_tile_of(j, K.part_rank, K.part_world, K.part_period);
         const uint32_t MX = m % K.macros_x, MY = m / K.macros_x;
         const uint32_t lx = mx * 8 + (w & 7u), ly = my * 8 + (w >> 3);
         bx = (int)(MX * K.macro_w + lx);
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
 // one thread per pixel, the destination is written row-major (coalesced), the source is read in tile rows.
 template <typename PIXEL>
 __global__ void assemble_tiles_kernel(const PIXEL *__restrict__ gathered, PIXEL *__restrict__ frames, int32_t width, int32_t height,
-                                      int32_t tile_w, int32_t tile_h, int32_t macros_x, int32_t j_max, int32_t world, int32_t n_frames) {
+                                      int32_t tile_w, int32_t tile_h, int32_t macros_x, int32_t j_max, int32_t world, int32_t period, int32_t n_frames) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t per_frame = (int64_t)width * height;
     if (idx >= per_frame * n_frames) return;
@@ -763,7 +763,8 @@ __global__ void assemble_tiles_kernel(const PIXEL *__restrict__ gathered, PIXEL 
     const int32_t p = (int32_t)(idx - (int64_t)f * per_frame);
     const int32_t y = p / width, x = p - y * width;
     const int32_t mx = x / tile_w, my = y / tile_h;
-    const int32_t m = my * macros_x + mx, r = m % world, j = m / world;
+    uint32_t r, j;
+    part_owner_of((uint32_t)(my * macros_x + mx), world, period, r, j);
     const int64_t src = ((((int64_t)r * n_frames + f) * j_max + j) * tile_h + (y - my * tile_h)) * tile_w + (x - mx * tile_w);
     frames[idx] = gathered[src];
 }
@@ -809,13 +810,12 @@ static int launch_variant(const AccelLaunch &K, int n_blocks, size_t lds_bytes, 
 
 // world > 1, or a single rank that asks for the macro-tile-major layout by naming a tile size
 static bool is_partitioned(mnv_partition part) { return part.world > 1 || (part.world == 1 && part.tile_w > 0); }
+static int32_t root_period_of(mnv_partition part) { return part.world > 1 && part.root_period >= 2 ? part.root_period : 0; }
 
 int32_t partition_local_tiles(mnv_rect tile, mnv_partition part) {
     if (tile.w <= 0 || tile.h <= 0 || !is_partitioned(part)) return is_partitioned(part) ? 0 : 1;
     const int64_t mx = (tile.w + part.tile_w - 1) / part.tile_w, my = (tile.h + part.tile_h - 1) / part.tile_h;
-    const int64_t total = mx * my;
-    if (part.rank >= total) return 0;
-    return (int32_t)((total - part.rank + part.world - 1) / part.world);
+    return (int32_t)part_local_count(mx * my, part.rank, part.world, root_period_of(part));
 }
 
 // Refinement trackers of one launch (all device pointers; rows indexed like the pixels).
@@ -863,6 +863,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     K.A = accel->view;
     K.part_rank = part.rank;
     K.part_world = is_partitioned(part) ? part.world : 0;
+    K.part_period = root_period_of(part);
     static const int env_wlog = getenv("MNV_TILE_WLOG") ? atoi(getenv("MNV_TILE_WLOG")) : 3;
     K.tile_wlog = (env_wlog >= 0 && env_wlog <= 6) ? (uint32_t)env_wlog : 3u;
     if (!is_partitioned(part)) {
@@ -901,7 +902,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
         K.frame_stride_px = (uint32_t)P.tw * (uint32_t)P.th;
     } else {
         const uint32_t n_macro = K.macros_x * (uint32_t)((P.th + part.tile_h - 1) / part.tile_h);
-        K.frame_stride_px = ((n_macro + (uint32_t)part.world - 1) / (uint32_t)part.world) * K.macro_w * K.macro_h;
+        K.frame_stride_px = (uint32_t)part_j_max(n_macro, part.world, root_period_of(part)) * K.macro_w * K.macro_h;
     }
     mnv_accel *mut = const_cast<mnv_accel *>(accel);
     const uint32_t slot = mut->slot_counter.fetch_add(1) % kSlots;
@@ -1228,22 +1229,24 @@ int mnv_assemble_tiles(const void *gathered, void *frames, int32_t width, int32_
         return set_error(MNV_E_INVALID, "invalid tile-assembly arguments");
     if (bytes_per_pixel != 4 && bytes_per_pixel != 16) return set_error(MNV_E_UNSUPPORTED, "pixels are RGBA8 (4 bytes) or float RGBA (16 bytes)");
     const int32_t macros_x = (width + part.tile_w - 1) / part.tile_w, macros_y = (height + part.tile_h - 1) / part.tile_h;
-    const int32_t j_max = (macros_x * macros_y + part.world - 1) / part.world;
+    if (part.root_period < 0) return set_error(MNV_E_INVALID, "root_period must be 0 or >= 2");
+    const int32_t period = root_period_of(part);
+    const int32_t j_max = (int32_t)part_j_max((int64_t)macros_x * macros_y, part.world, period);
     const int64_t n = (int64_t)width * height * n_frames;
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     hipStream_t stream = (hipStream_t)hip_stream;
     if (bytes_per_pixel == 4)
         hipLaunchKernelGGL(assemble_tiles_kernel<uint32_t>, grid, block, 0, stream, static_cast<const uint32_t *>(gathered), static_cast<uint32_t *>(frames),
-                           width, height, part.tile_w, part.tile_h, macros_x, j_max, part.world, n_frames);
+                           width, height, part.tile_w, part.tile_h, macros_x, j_max, part.world, period, n_frames);
     else
         hipLaunchKernelGGL(assemble_tiles_kernel<uint4>, grid, block, 0, stream, static_cast<const uint4 *>(gathered), static_cast<uint4 *>(frames), width,
-                           height, part.tile_w, part.tile_h, macros_x, j_max, part.world, n_frames);
+                           height, part.tile_w, part.tile_h, macros_x, j_max, part.world, period, n_frames);
     return check_hip(hipGetLastError(), "assemble_tiles_kernel");
 }
 
 int mnv_render_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,
                             mnv_rect tile, float *rgba_out, uint8_t *rgba8_out, void *hip_stream) {
-    const mnv_partition whole = {0, 1, 0, 0};
+    const mnv_partition whole = {0, 1, 0, 0, 0};
     return mnv_render_voxels_accel_batch(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, hip_stream);
 }
 
@@ -1259,8 +1262,8 @@ static int render_accel(const mnv_accel *accel, const mnv_camera *cams, int32_t 
     if (!accel) return set_error(MNV_E_INVALID, "accel is null");
     if (!cams || n_cams < 1 || n_cams > MNV_MAX_BATCH) return set_error(MNV_E_INVALID, "need 1 .. MNV_MAX_BATCH cameras");
     if (is_partitioned(part) && (part.rank < 0 || part.rank >= part.world || part.tile_w < 8 || part.tile_h < 8 ||
-                           part.tile_w % 8 || part.tile_h % 8))
-        return set_error(MNV_E_INVALID, "partition needs 0 <= rank < world and macro tiles that are multiples of 8 pixels");
+                           part.tile_w % 8 || part.tile_h % 8 || part.root_period < 0 || part.root_period == 1))
+        return set_error(MNV_E_INVALID, "partition needs 0 <= rank < world, macro tiles that are multiples of 8 pixels and root_period 0 or >= 2");
     for (int i = 1; i < n_cams; ++i)
         if (cams[i].width != cams[0].width || cams[i].height != cams[0].height)
             return set_error(MNV_E_INVALID, "all cameras of a batch must have the same image size");
@@ -1296,7 +1299,7 @@ int mnv_render_voxels_accel_track(const mnv_accel *accel, const mnv_camera *cam,
     if (!opt) return set_error(MNV_E_INVALID, "options are null");
     if (!split_track && !sample_track)
         return mnv_render_voxels_accel(accel, cam, opt, tile, rgba_out, rgba8_out, hip_stream);
-    const mnv_partition whole = {0, 1, 0, 0};
+    const mnv_partition whole = {0, 1, 0, 0, 0};
     AccelTrack track = {};
     track.split_track = split_track;
     track.sample_track = sample_track;
@@ -1328,7 +1331,7 @@ int mnv_get_samples_from_voxels_accel(const mnv_accel *accel, const mnv_camera *
     track.need_viewdir = opt->need_viewdir ? 1 : 0;
     track.appearance_embedding = opt->appearance_embedding;
     track.grid = grid;
-    const mnv_partition whole = {0, 1, 0, 0};
+    const mnv_partition whole = {0, 1, 0, 0, 0};
     return render_accel(accel, cam, 1, opt, tile, whole, nullptr, nullptr, &track, hip_stream);
 }
 

@@ -2,7 +2,7 @@
 
 One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the
 CPU tests).  The tree is replicated, the frame is cut into interleaved macro tiles
-(rank = tile % world, see ``mnv_partition`` in include/mnv.h), each rank renders its tiles into a
+(rank = tile % world, optionally relieving rank 0; see ``mnv_partition`` in include/mnv.h), each rank renders its tiles into a
 compact local-tile-major buffer with one kernel launch, and the buffers are gathered to rank 0
 and un-permuted into the frame there.  The march itself needs no exchange: this gather is the only
 collective of the path.  The reference has no multi-GPU code; this is new.
@@ -16,21 +16,43 @@ import torch.distributed as dist
 
 
 class TilePartition:
-    """Index math of the interleaved macro-tile partition (pure host code, mirrors
-    mnv_partition_local_tiles / ray_pixel in csrc/mnv_march_accel.hip)."""
+    """Index math of the interleaved macro-tile partition (pure host code, mirrors part_tile_of / part_owner_of in
+    csrc/mnv_accel.h).  Tiles are dealt in rounds of `world`; with ``root_period`` M >= 2 every M-th round leaves rank 0 out, so
+    that the rank which also receives the gather and un-permutes the frames renders (M - 1) / M of a plain share."""
 
-    def __init__(self, width: int, height: int, world: int, tile_w: int = 128, tile_h: int = 120):
+    def __init__(self, width: int, height: int, world: int, tile_w: int = 64, tile_h: int = 24, root_period: int = 0):
         if tile_w % 8 or tile_h % 8:
             raise ValueError("macro tiles must be multiples of 8 pixels")
+        if root_period < 0 or root_period == 1:
+            raise ValueError("root_period must be 0 or >= 2")
         self.width, self.height, self.world = width, height, world
         self.tile_w, self.tile_h = tile_w, tile_h
+        self.root_period = root_period if world > 1 else 0
         self.macros_x = -(-width // tile_w)
         self.macros_y = -(-height // tile_h)
         self.n_macro = self.macros_x * self.macros_y
-        self.j_max = -(-self.n_macro // world)
+        self.j_max = max(self.local_tiles(r) for r in range(world))
+
+    def owner(self, m: int):
+        """(rank, local index) of macro tile m."""
+        M, w = self.root_period, self.world
+        if M < 2:
+            return m % w, m // w
+        L = w * M - 1
+        p, o = divmod(m, L)
+        if o < (M - 1) * w:
+            k, r = divmod(o, w)
+        else:
+            k, r = M - 1, o - (M - 1) * w + 1
+        return r, p * (M - 1 if r == 0 else M) + k
+
+    def tiles_of(self, rank: int) -> List[int]:
+        return [m for m in range(self.n_macro) if self.owner(m)[0] == rank]
 
     def local_tiles(self, rank: int) -> int:
-        return len(range(rank, self.n_macro, self.world))
+        if self.root_period < 2:
+            return len(range(rank, self.n_macro, self.world))
+        return sum(1 for m in range(self.n_macro) if self.owner(m)[0] == rank)
 
     def tile_rect(self, m: int):
         """(x0, y0, w, h) of macro tile m clipped to the frame."""
@@ -38,13 +60,17 @@ class TilePartition:
         x0, y0 = mx * self.tile_w, my * self.tile_h
         return x0, y0, min(self.tile_w, self.width - x0), min(self.tile_h, self.height - y0)
 
-    def tiles_of(self, rank: int) -> List[int]:
-        return list(range(rank, self.n_macro, self.world))
+    def part(self, rank: int):
+        """The tuple the binding's `part=` argument takes."""
+        return (rank, self.world, self.tile_w, self.tile_h, self.root_period)
 
     def source_index(self, device) -> torch.Tensor:
         """For macro tile m: row of the [world * j_max] gathered tile table that holds it."""
-        m = torch.arange(self.n_macro, device=device)
-        return (m % self.world) * self.j_max + m // self.world
+        if self.root_period < 2:
+            m = torch.arange(self.n_macro, device=device)
+            return (m % self.world) * self.j_max + m // self.world
+        rows = [r * self.j_max + j for r, j in (self.owner(m) for m in range(self.n_macro))]
+        return torch.tensor(rows, dtype=torch.int64, device=device)
 
     def unpermute(self, gathered: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """gathered [world, j_max, tile_h, tile_w, C] -> frame [height, width, C]; with a frame dimension,
@@ -56,7 +82,8 @@ class TilePartition:
             # one pass over the pixels in libmnv (mnv_assemble_tiles) instead of index_select + permute + copy
             from . import assemble_tiles
             assemble_tiles(gathered, out, self.width, self.height, self.world, self.tile_w, self.tile_h,
-                           n_frames=gathered.shape[1] if batched else 1, stream=torch.cuda.current_stream(gathered.device).cuda_stream)
+                           n_frames=gathered.shape[1] if batched else 1, stream=torch.cuda.current_stream(gathered.device).cuda_stream,
+                           root_period=self.root_period)
             return out
         g = gathered if batched else gathered.unsqueeze(1)
         f = g.shape[1]

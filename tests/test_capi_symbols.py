@@ -31,7 +31,7 @@ def test_no_torch_or_oracle_in_the_abi(mnv):
 
 def test_struct_layouts_and_defaults(mnv):
     assert C.sizeof(mnv.RenderOptions) == 104          # reference include/render_options.hpp: 104 B by value
-    assert C.sizeof(mnv.CameraStruct) == 72 and C.sizeof(mnv.Rect) == 16 and C.sizeof(mnv.Partition) == 16
+    assert C.sizeof(mnv.CameraStruct) == 72 and C.sizeof(mnv.Rect) == 16 and C.sizeof(mnv.Partition) == 20
     o = mnv.RenderOptions.defaults()                    # struct defaults, render_options.hpp:9-56
     assert (o.step_size, o.sigma_thresh, o.stop_thresh, o.background_brightness) == (C.c_float(1e-4).value, C.c_float(1e-2).value, C.c_float(1e-2).value, 1.0)
     assert list(o.render_bbox) == [0, 0, 0, 1, 1, 1] and list(o.basis_minmax) == [0, 24]

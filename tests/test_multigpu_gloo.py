@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tile_w, tile_h, n_frames, q):
+def _worker(rank, world, port, tile_w, tile_h, n_frames, root_period, q):
     try:
         for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
             if p not in sys.path:
@@ -48,8 +48,8 @@ def _worker(rank, world, port, tile_w, tile_h, n_frames, q):
             cs["center"] = (cs["center"][0] + 0.1 * k, cs["center"][1], cs["center"][2])
             cams.append(cases.make_camera(mnv, cs))
         W, H = cams[0].width, cams[0].height
-        part = TilePartition(W, H, world, tile_w, tile_h)
-        assert part.local_tiles(rank) == mnv.partition_local_tiles((0, 0, W, H), rank, world, tile_w, tile_h)
+        part = TilePartition(W, H, world, tile_w, tile_h, root_period)
+        assert part.local_tiles(rank) == mnv.partition_local_tiles((0, 0, W, H), rank, world, tile_w, tile_h, root_period)
         tg = TileGatherer(part, rank, "cpu", depth=2)
         ok = True
         for k, cam in enumerate(cams):
@@ -78,12 +78,12 @@ def _worker(rank, world, port, tile_w, tile_h, n_frames, q):
         q.put((rank, False, traceback.format_exc()))
 
 
-@pytest.mark.parametrize("world,tile", [(2, (64, 40)), (3, (48, 56))])
-def test_gather_and_unpermute_over_gloo(mnv, orc, world, tile):
+@pytest.mark.parametrize("world,tile,root_period", [(2, (64, 40), 0), (3, (48, 56), 0), (2, (16, 8), 3)])
+def test_gather_and_unpermute_over_gloo(mnv, orc, world, tile, root_period):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, tile[0], tile[1], 3, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tile[0], tile[1], 3, root_period, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in procs]
@@ -107,13 +107,18 @@ def test_unpermute_with_frame_dimension(mnv):
 def test_partition_index_math_matches_c_abi(mnv):
     from mega_nerf_viewer_amd.multigpu import TilePartition
 
-    for (W, H, world, tw, th) in [(1920, 1080, 8, 64, 24), (1920, 1080, 8, 128, 120), (1920, 1080, 3, 200, 136), (100, 50, 4, 8, 8), (7, 5, 2, 8, 8)]:
-        part = TilePartition(W, H, world, tw, th)
+    for (W, H, world, tw, th, M) in [(1920, 1080, 8, 64, 24, 0), (1920, 1080, 8, 64, 24, 6), (1920, 1080, 2, 64, 24, 22), (1920, 1080, 8, 128, 120, 0),
+                                     (1920, 1080, 3, 200, 136, 2), (100, 50, 4, 8, 8, 3), (7, 5, 2, 8, 8, 2), (1920, 1080, 1, 64, 24, 5)]:
+        part = TilePartition(W, H, world, tw, th, M)
         seen = []
         for r in range(world):
-            assert part.local_tiles(r) == mnv.partition_local_tiles((0, 0, W, H), r, world, tw, th)
-            seen += part.tiles_of(r)
+            assert part.local_tiles(r) == mnv.partition_local_tiles((0, 0, W, H), r, world, tw, th, M)
+            tiles = part.tiles_of(r)
+            assert [part.owner(m) for m in tiles] == [(r, j) for j in range(len(tiles))]   # local order = increasing macro tile number
+            seen += tiles
         assert sorted(seen) == list(range(part.n_macro))
+        if world > 1 and M >= 2 and part.n_macro >= 4 * world * M:  # rank 0 is left out of every M-th round of the deal
+            assert part.local_tiles(0) < part.local_tiles(1) and abs(part.local_tiles(0) / part.local_tiles(1) - (M - 1) / M) < 0.08
         # un-permute of a synthetic gathered table puts every macro tile where its rect says
         g = torch.zeros((world, part.j_max, th, tw, 1))
         for r in range(world):

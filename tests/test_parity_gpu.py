@@ -208,23 +208,25 @@ def test_cfg2_interleaved_partition_reassembles_bit_exact(mnv, torch_gpu, cfg2, 
     opt = mnv.RenderOptions.cli_defaults()
     full, full8 = _render_gpu(mnv, torch, cfg2, cam, opt, "accel", want_u8=True)
     H, W = cam.height, cam.width
-    for (tw, th) in [(64, 24), (128, 120), (200, 136)]:
+    from mega_nerf_viewer_amd.multigpu import TilePartition
+    for (tw, th, M) in [(64, 24, 0), (64, 24, 6), (128, 120, 0), (200, 136, 2)]:
         mx, my = -(-W // tw), -(-H // th)
+        part = TilePartition(W, H, world, tw, th, M)
         out = np.full((my * th, mx * tw, 4), np.nan, np.float32)
         out8 = np.zeros((my * th, mx * tw, 4), np.uint8)
         for rank in range(world):
-            n_local = mnv.partition_local_tiles((0, 0, W, H), rank, world, tw, th)
-            assert n_local == len(range(rank, mx * my, world))
+            n_local = mnv.partition_local_tiles((0, 0, W, H), rank, world, tw, th, M)
+            assert n_local == part.local_tiles(rank) and (M or n_local == len(range(rank, mx * my, world)))
             buf = torch.full((max(n_local, 1), th, tw, 4), float("nan"), dtype=torch.float32, device="cuda")
             buf8 = torch.zeros((max(n_local, 1), th, tw, 4), dtype=torch.uint8, device="cuda")
-            mnv.render_voxels_accel_part(cfg2.accel, cam, opt, rank, world, tw, th, rgba=buf, rgba8=buf8)
+            mnv.render_voxels_accel_part(cfg2.accel, cam, opt, rank, world, tw, th, rgba=buf, rgba8=buf8, root_period=M)
             torch.cuda.synchronize()
             b, b8 = buf.cpu().numpy(), buf8.cpu().numpy()
-            for j, m in enumerate(range(rank, mx * my, world)):
+            for j, m in enumerate(part.tiles_of(rank)):
                 MX, MY = m % mx, m // mx
                 out[MY * th:(MY + 1) * th, MX * tw:(MX + 1) * tw] = b[j]
                 out8[MY * th:(MY + 1) * th, MX * tw:(MX + 1) * tw] = b8[j]
-        assert np.array_equal(cases.bits(out[:H, :W]), cases.bits(full)), (world, tw, th)
+        assert np.array_equal(cases.bits(out[:H, :W]), cases.bits(full)), (world, tw, th, M)
         assert np.array_equal(out8[:H, :W], full8)
         if my * th > H:  # pixels outside the frame are never written
             assert np.isnan(out[H:, :]).all()
@@ -407,13 +409,14 @@ def test_extreme_opacity_exercises_expf_tails(mnv, orc, torch_gpu, step):
         assert np.array_equal(cases.bits(got), cases.bits(ref["rgba"])), (step, which, float(np.abs(got - ref["rgba"]).max()))
 
 
-@pytest.mark.parametrize("world,w,h,frames", [(3, 1920, 1080, 2), (8, 1000, 700, 0), (2, 136, 128, 3), (5, 3840, 2160, 1)])
-def test_assemble_tiles_kernel_equals_index_permutation(mnv, torch_gpu, world, w, h, frames):
+@pytest.mark.parametrize("world,w,h,frames,root_period", [(3, 1920, 1080, 2, 0), (8, 1000, 700, 0, 0), (2, 136, 128, 3, 0), (5, 3840, 2160, 1, 0),
+                                                         (8, 1920, 1080, 2, 6), (3, 1000, 700, 0, 2)])
+def test_assemble_tiles_kernel_equals_index_permutation(mnv, torch_gpu, world, w, h, frames, root_period):
     """mnv_assemble_tiles (rank 0's un-permute after the gather) against the torch index_select / permute form of
     TilePartition.unpermute, RGBA8 and float RGBA, with and without the frame dimension, ragged tile counts."""
     torch = torch_gpu
     from mega_nerf_viewer_amd.multigpu import TilePartition
-    part = TilePartition(w, h, world, 128, 120)
+    part = TilePartition(w, h, world, 128, 120, root_period)
     lead = (frames,) if frames else ()
     for dt in (torch.uint8, torch.float32):
         g = torch.randint(0, 255, (world,) + lead + (part.j_max, 120, 128, 4), device="cuda").to(dt)
