@@ -88,8 +88,8 @@ def main():
                          "tile gather, un-permute) -- the only way to execute the RCCL calls on a one-GPU box")
     ap.add_argument("--root-period", type=int, default=-1,
                     help="N > 1: mnv_partition.root_period -- every M-th round of the tile deal leaves rank 0 out, because rank 0 also takes in "
-                         "the gather and un-permutes the frames (tools/root_emulation.py: +19 %% on its march at N = 8).  Default round(44 / N) "
-                         "(6 at N = 8: rank 0 renders 5/6 of a plain share); 0 = plain round robin")
+                         "the gather and un-permutes the frames (tools/root_emulation.py: +13 %% on its march at N = 8).  Default round(64 / N) "
+                         "(8 at N = 8: rank 0 renders 7/8 of a plain share); 0 = plain round robin")
     ap.add_argument("--laps", type=int, default=4, help="the step walks the 16-pose orbit this many times (16 x laps frames in one launch, <= 64)")
     args = ap.parse_args()
     global W, H, N_FRAMES
@@ -181,7 +181,7 @@ def main():
     else:
         from mega_nerf_viewer_amd.multigpu import TileGatherer, TilePartition
 
-        root_period = args.root_period if args.root_period >= 0 else (max(2, round(44 / world)) if world > 1 else 0)
+        root_period = args.root_period if args.root_period >= 0 else (max(2, round(64 / world)) if world > 1 else 0)
         part = TilePartition(W, H, world, MACRO_W, MACRO_H, root_period)
         n_local = part.local_tiles(rank)
         assert n_local == mnv.partition_local_tiles((0, 0, W, H), rank, world, MACRO_W, MACRO_H, part.root_period)

@@ -107,7 +107,7 @@ def test_unpermute_with_frame_dimension(mnv):
 def test_partition_index_math_matches_c_abi(mnv):
     from mega_nerf_viewer_amd.multigpu import TilePartition
 
-    for (W, H, world, tw, th, M) in [(1920, 1080, 8, 64, 24, 0), (1920, 1080, 8, 64, 24, 6), (1920, 1080, 2, 64, 24, 22), (1920, 1080, 8, 128, 120, 0),
+    for (W, H, world, tw, th, M) in [(1920, 1080, 8, 64, 24, 0), (1920, 1080, 8, 64, 24, 8), (1920, 1080, 2, 64, 24, 32), (1920, 1080, 8, 128, 120, 0),
                                      (1920, 1080, 3, 200, 136, 2), (100, 50, 4, 8, 8, 3), (7, 5, 2, 8, 8, 2), (1920, 1080, 1, 64, 24, 5)]:
         part = TilePartition(W, H, world, tw, th, M)
         seen = []
