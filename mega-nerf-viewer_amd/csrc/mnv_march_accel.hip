@@ -753,6 +753,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
 
 // Rank 0 after the gather: macro tile m of frame f sits at gathered[m % world][f][m / world];
 // one thread per pixel, the destination is written row-major (coalesced), the source is read in tile rows.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // 16 bytes: one float RGBA pixel or four RGBA8 pixels
 template <typename PIXEL>
 __global__ void assemble_tiles_kernel(const PIXEL *__restrict__ gathered, PIXEL *__restrict__ frames, int32_t width, int32_t height,
                                       int32_t tile_w, int32_t tile_h, int32_t macros_x, int32_t j_max, int32_t world, int32_t period, int32_t n_frames) {
@@ -766,7 +767,8 @@ __global__ void assemble_tiles_kernel(const PIXEL *__restrict__ gathered, PIXEL 
     uint32_t r, j;
     part_owner_of((uint32_t)(my * macros_x + mx), world, period, r, j);
     const int64_t src = ((((int64_t)r * n_frames + f) * j_max + j) * tile_h + (y - my * tile_h)) * tile_w + (x - mx * tile_w);
-    frames[idx] = gathered[src];
+    // streamed once: keep these lines from displacing the march's lookup structures in L2
+    __builtin_nontemporal_store(__builtin_nontemporal_load(&gathered[src]), &frames[idx]);
 }
 
 // ---------------------------------------------------------------------------- host side
@@ -1239,8 +1241,8 @@ int mnv_assemble_tiles(const void *gathered, void *frames, int32_t width, int32_
         // holds in units of four pixels: 16 bytes per thread instead of 4 (rank 0 runs this beside its march on the few compute
         // units the march leaves free)
         const int64_t n4 = (int64_t)(width / 4) * height * n_frames;
-        hipLaunchKernelGGL(assemble_tiles_kernel<uint4>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, static_cast<const uint4 *>(gathered),
-                           static_cast<uint4 *>(frames), width / 4, height, part.tile_w / 4, part.tile_h, macros_x, j_max, part.world, period, n_frames);
+        hipLaunchKernelGGL(assemble_tiles_kernel<u32x4>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, static_cast<const u32x4 *>(gathered),
+                           static_cast<u32x4 *>(frames), width / 4, height, part.tile_w / 4, part.tile_h, macros_x, j_max, part.world, period, n_frames);
         return check_hip(hipGetLastError(), "assemble_tiles_kernel");
     }
     const int64_t n = (int64_t)width * height * n_frames;
@@ -1249,7 +1251,7 @@ int mnv_assemble_tiles(const void *gathered, void *frames, int32_t width, int32_
         hipLaunchKernelGGL(assemble_tiles_kernel<uint32_t>, grid, block, 0, stream, static_cast<const uint32_t *>(gathered), static_cast<uint32_t *>(frames),
                            width, height, part.tile_w, part.tile_h, macros_x, j_max, part.world, period, n_frames);
     else
-        hipLaunchKernelGGL(assemble_tiles_kernel<uint4>, grid, block, 0, stream, static_cast<const uint4 *>(gathered), static_cast<uint4 *>(frames), width,
+        hipLaunchKernelGGL(assemble_tiles_kernel<u32x4>, grid, block, 0, stream, static_cast<const u32x4 *>(gathered), static_cast<u32x4 *>(frames), width,
                            height, part.tile_w, part.tile_h, macros_x, j_max, part.world, period, n_frames);
     return check_hip(hipGetLastError(), "assemble_tiles_kernel");
 }
