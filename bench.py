@@ -42,7 +42,7 @@ MACRO_W, MACRO_H = 64, 24            # 30 x 45 = 1350 macro tiles: per-rank laun
                                      # (tools/partition_balance.py: 128x120 tiles leave the slowest rank 19 % behind)
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8.0 TB/s spec
 COUNTERS_JSON = os.path.join(ROOT, "tests", "golden", "cfg2_counters.json")
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_traffic.json")   # HBM bytes per launch from the committed PMC passes
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")   # HBM bytes per launch from the committed PMC passes
 
 
 def load_counters():
@@ -53,9 +53,51 @@ def load_counters():
         return json.load(f)
 
 
+def kernel_source_sha():
+    """Identity of the kernel sources a profile belongs to (tools/make_traffic_json.py stores it with the PMC numbers)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mega-nerf-viewer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def alg_bytes(c, basis_dim=9):
     # SURVEY.md 8(d): sum_rays [16 + sum_steps (4 d_s + 2 + hit_s * 6 * basis_dim)]
     return 16 * c["rays"] + 4 * c["levels"] + 2 * c["steps"] + 6 * basis_dim * c["hits"]
+
+
+def self_launch(n, backend):
+    """One process per GPU via torch.distributed.run, started from a parent that never initialises HIP."""
+    import socket
+    import subprocess
+
+    if backend == "nccl" and torch.cuda.device_count() < n:
+        print(f"bench.py: --gpus {n} over RCCL needs {n} GPUs, this node shows {torch.cuda.device_count()} "
+              f"(--backend gloo rehearses the {n}-rank path on fewer GPUs)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    for ln in r.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if r.returncode == 0 and lines:
+        d = json.loads(lines[-1])
+        if d.get("n_gpus") != n:
+            print(f"bench.py: asked for {n} ranks, the line reports {d.get('n_gpus')}", file=sys.stderr)
+            return 3
+        print(lines[-1], flush=True)
+        return 0
+    return r.returncode or 4
 
 
 def main():
@@ -75,6 +117,8 @@ def main():
                     help="cfg2 = BASELINE.json's headline config (default); cfg3 = merged-Mega-NeRF stand-in (anisotropic terrain, 2.7 M chunks); "
                          "cfg4 = cfg3 at 3840x2160 (configs[3], meant for --gpus 8)")
     ap.add_argument("--per-frame", action="store_true", help="one launch per pose instead of one batched launch per step")
+    ap.add_argument("--frame-streams", type=int, default=3,
+                    help="--per-frame: launches rotate over this many HIP streams (frames in flight; 1 = the frames of a step run back to back on one stream)")
     ap.add_argument("--fast-colour", action="store_true",
                     help="mnv_set_colour_math(1): hardware exp2 / rcp in the colour sigmoid (alpha and control flow stay exact; colours move ~1e-7)")
     ap.add_argument("--reserve-cus", type=int, default=-1,
@@ -99,11 +143,15 @@ def main():
         raise SystemExit("--laps must be 1 .. 4 (MNV_MAX_BATCH = 64 frames per launch)")
     N_FRAMES = N_POSES * args.laps
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves as FRESH child processes (this process has not
+        # touched the GPU: torch.cuda.device_count() does not initialise it on this image), relay rank 0's JSON line, exit with their code
+        sys.exit(self_launch(args.gpus, args.backend))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a {world}-rank run as a {args.gpus}-GPU number")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     if args.backend == "gloo":
@@ -118,6 +166,7 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    rccl_ranks = dist.get_world_size() if multi and args.backend == "nccl" else None
     import __graft_entry__ as g
     g.build_if_missing()
     import mega_nerf_viewer_amd as mnv
@@ -164,6 +213,11 @@ def main():
         dv = tree.device_view() if args.kernel == "ref_layout" else None
         counter = [0]
 
+        # --per-frame: the reference's call pattern (one render_voxels call per frame, cuda_renderer.cpp:141-142), with
+        # --frame-streams frames in flight: frame i goes to stream i % K, so the tail of one launch (a few wavefronts finishing
+        # the longest rays) overlaps the next launches instead of idling the device
+        pf_streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.frame_streams))] if args.per_frame and args.frame_streams > 1 else None
+
         def step():
             slot = counter[0] % RING
             counter[0] += 1
@@ -171,13 +225,14 @@ def main():
                 mnv.render_voxels_accel_batch(tree.accel, cams, opt, rgba=frames[slot], stream=stream)
             else:
                 for i in range(N_FRAMES):
-                    render_pose(i, frames[slot][i])
+                    render_pose(i, frames[slot][i], pf_streams[i % len(pf_streams)].cuda_stream if pf_streams else stream)
 
-        def render_pose(i, out):
+        def render_pose(i, out, st=None):
+            st = stream if st is None else st
             if args.kernel == "accel":
-                mnv.render_voxels_accel(tree.accel, cams[i], opt, rgba=out, stream=stream)
+                mnv.render_voxels_accel(tree.accel, cams[i], opt, rgba=out, stream=st)
             else:
-                mnv.render_voxels(dv, cams[i], opt, rgba=out, stream=stream)
+                mnv.render_voxels(dv, cams[i], opt, rgba=out, stream=st)
     else:
         from mega_nerf_viewer_amd.multigpu import TileGatherer, TilePartition
 
@@ -187,7 +242,14 @@ def main():
         assert n_local == mnv.partition_local_tiles((0, 0, W, H), rank, world, MACRO_W, MACRO_H, part.root_period)
         dt = torch.float32 if args.gather == "f32" else torch.uint8
         # one launch + one gather per step; the gather of step k overlaps the launch of step k + 1
-        tg = TileGatherer(part, rank, dev, dtype=dt, depth=RING, frames=N_FRAMES, stage_on_host=args.backend == "gloo")
+        comm = None
+        if args.backend == "nccl":
+            # the data path's collective is libmnv's own RCCL gather (mnv_gather_tiles, C ABI); torch.distributed only carries the
+            # 128-byte id to the other ranks and the barrier / max-over-ranks of the timing
+            box = [mnv.comm_get_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = mnv.Comm(box[0], world, rank)
+        tg = TileGatherer(part, rank, dev, dtype=dt, depth=RING, frames=N_FRAMES, stage_on_host=args.backend == "gloo", comm=comm)
         frames = tg._frames if rank == 0 else None
         counter = [0]
 
@@ -241,8 +303,33 @@ def main():
     rays_per_step = N_FRAMES * W * H
     value = rays_per_step * args.steps / elapsed / 1e6
 
+    # secondary number: the reference's call pattern -- ONE launch per frame -- with --frame-streams frames in flight
+    # (what VolumeRenderer::render does); not the headline, reported beside it
+    per_frame = None
+    if not multi and args.kernel == "accel" and not args.per_frame and args.frame_streams >= 1:
+        k = args.frame_streams
+        sts = [torch.cuda.Stream(device=dev) for _ in range(k)]
+        pf_out = frames[0]
+
+        def pf_step():
+            for i in range(N_FRAMES):
+                mnv.render_voxels_accel(tree.accel, cams[i], opt, rgba=pf_out[i], stream=sts[i % k].cuda_stream)
+
+        pf_step()
+        torch.cuda.synchronize(dev)
+        pf_steps = max(1, min(args.steps, 5))
+        t1 = time.perf_counter()
+        for _ in range(pf_steps):
+            pf_step()
+        torch.cuda.synchronize(dev)
+        pf_el = time.perf_counter() - t1
+        per_frame = {"value": round(rays_per_step * pf_steps / pf_el / 1e6, 2), "unit": "Mrays/s", "ms_per_frame": round(pf_el / pf_steps / N_FRAMES * 1e3, 5),
+                     "launches": pf_steps * N_FRAMES, "frames_in_flight": k,
+                     "what": "one mnv_render_voxels_accel call per 1920x1080 frame (the reference's call pattern, cuda_renderer.cpp:141-142), launches rotating over HIP streams"}
+
     # ---- roofline of the dominant kernel (the march): algorithmic bytes per launch / launch time
     counters = load_counters() if args.workload == "cfg2" else None
+    counters_checked = 0
     cpu_baseline = None
     parity = None
     if rank == 0 and not multi and not args.no_cpu_baseline:
@@ -272,13 +359,22 @@ def main():
                   "alpha_not_bit_identical": n_alpha, "colour_math": "fast" if args.fast_colour else "exact"}
         if counters is None:
             counters = {"poses": fresh, "partial": True}
+        else:
+            # the committed counters (the roofline's numerator) must be the ones this tree and these cameras produce today
+            stale = [k for k, v in fresh.items() if any(counters["poses"].get(k, {}).get(n) != x for n, x in v.items())]
+            if stale:
+                raise SystemExit(f"bench.py: tests/golden/cfg2_counters.json disagrees with the oracle's counters for poses {stale}: "
+                                 f"e.g. committed {counters['poses'].get(stale[0])} vs fresh {fresh[stale[0]]}")
+            counters_checked = len(fresh)
     if rank == 0 and multi and not args.no_cpu_baseline:
         # the assembled frames of the last step against the oracle (not timed): validates partition + gather + un-permute
         import mnv_oracle as orc
         ot = orc.tree_from_view(tree.host_view())
         last = frames[(counter[0] - 1) % RING]
-        max_diff, n_bad, n_chk = 0.0, 0, 2
-        for i in range(n_chk):
+        max_diff, n_bad = 0.0, 0
+        chk = sorted({0, 1, N_FRAMES // 2, N_FRAMES - 1})   # first, second, a middle and the last frame of the batch (frame stride, ragged rounds)
+        n_chk = len(chk)
+        for i in chk:
             r = orc.render(ot, cams[i].c, opt, want_rgba8=True)
             gpu = last[i].cpu().numpy()
             if args.gather == "f32":
@@ -288,7 +384,7 @@ def main():
                 max_diff = max(max_diff, float(np.abs(gpu.astype(np.int32) - r["rgba8"].astype(np.int32)).max()) / 255.0)
                 n_bad += int((gpu != r["rgba8"]).any(axis=-1).sum())
         parity = {"max_abs_drgba_vs_oracle": max_diff, "pixels_not_bit_identical": n_bad, "frames_checked": n_chk,
-                  "what": "frames assembled on rank 0 after the gather"}
+                  "frames": chk, "what": "frames assembled on rank 0 after the gather"}
     roofline = None
     if counters is not None and launches > 0:
         poses = counters["poses"]
@@ -297,13 +393,18 @@ def main():
         per_launch = mean_bytes * frames_per_launch / world   # each rank's launch covers about 1/world of its frames (rank 0 a little less, see --root-period)
         avg_ms = kern_ms / launches
         achieved = per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         if os.path.exists(TRAFFIC_JSON) and not multi and args.kernel == "accel" and args.workload == "cfg2":
             tj = json.load(open(TRAFFIC_JSON))
-            if tj.get("frames_per_launch") == frames_per_launch:
-                traffic = tj["hbm_bytes_per_launch"]   # PMC counters cannot be read from inside this process
+            # PMC counters cannot be read from inside this process: `traffic` is what the committed rocprofv3 --pmc passes measured
+            # for THIS kernel source (sha over csrc/) and launch shape; any other source or shape reports null
+            if tj.get("frames_per_launch") == frames_per_launch and tj.get("kernel_source_sha") == kernel_source_sha():
+                traffic = tj["hbm_bytes_per_launch"]
+                traffic_source = os.path.relpath(TRAFFIC_JSON, ROOT)
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                    "frac_real_hbm": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None,
+                    "counters_rechecked_poses": counters_checked,
                     "kernel": "march_accel_kernel<9,256,0>" if args.kernel == "accel" else "march_ref_layout_kernel<9>",
                     "frames_per_launch": frames_per_launch,
                     "avg_launch_ms": round(avg_ms, 5), "launches": launches,
@@ -317,6 +418,7 @@ def main():
             "value": round(value, 2),
             "unit": "Mrays/s",
             "n_gpus": world,
+            "rccl_ranks": rccl_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -330,6 +432,7 @@ def main():
                        "partition": "none" if not multi else f"interleaved {MACRO_W}x{MACRO_H} macro tiles, {args.gather} {'RCCL' if args.backend == 'nccl' else 'gloo (host-staged rehearsal)'} gather to rank 0",
                        "reserved_cus": reserve, "march_streams": n_march_streams, "root_period": part.root_period if multi else 0},
             "roofline": roofline,
+            "per_frame": per_frame,
             "cpu_baseline": cpu_baseline,
             "parity": parity,
             "setup_s": round(setup_s, 2),

@@ -41,6 +41,8 @@ extern "C" {
 #define MNV_E_UNSUPPORTED (-2) /* e.g. N != 2, basis_dim not in {-1,0,1,4,9,16,25} */
 #define MNV_E_NO_DEVICE (-3)   /* no HIP device / extension unusable */
 #define MNV_E_IO (-4)          /* file / npz errors */
+#define MNV_E_NO_RCCL (-5)     /* mnv_comm_*: librccl.so.1 cannot be loaded */
+#define MNV_E_RCCL (-6)        /* mnv_comm_*: an RCCL call failed (text in mnv_last_error) */
 
 #define MNV_FORMAT_RGBA 0 /* reference include/data_format.hpp:8-12 */
 #define MNV_FORMAT_SH 1
@@ -214,6 +216,30 @@ void mnv_set_colour_math(int fast);
  */
 int mnv_assemble_tiles(const void *gathered, void *frames, int32_t width, int32_t height, mnv_partition part, int32_t n_frames,
                        int32_t bytes_per_pixel, void *hip_stream);
+
+/*
+ * The gather that precedes it: the only collective of the path, RCCL over xGMI, one process per GPU (the
+ * reference renders on one device, src/renderer/cuda_renderer.cpp:68-163, so there is no reference interface to cite).
+ * RCCL (librccl.so.1) is bound at the first mnv_comm_* call; MNV_E_NO_RCCL when it cannot be loaded.
+ *
+ *   mnv_comm_get_unique_id   one rank (the root) draws the 128-byte id; the host program hands it to the other ranks
+ *                            (pipe, shared memory, torch.distributed store -- the library does not care)
+ *   mnv_comm_init_rank       collective over the `world` ranks; binds the communicator to the calling thread's current device
+ *   mnv_gather_tiles         asynchronous on `hip_stream`: rank r's `local` (bytes_per_rank bytes, device) lands at
+ *                            gathered + r * bytes_per_rank on the root (`gathered` is ignored elsewhere): grouped ncclRecv on the
+ *                            root, one ncclSend on every other rank, a device copy for the root's own share (a send / receive
+ *                            to itself when world == 1, so that a one-GPU box runs the RCCL path for real)
+ * A communicator is used from one host thread at a time; calls on it are ordered like RCCL calls (same order on every rank).
+ */
+#define MNV_COMM_ID_BYTES 128
+typedef struct mnv_comm mnv_comm;
+int mnv_comm_get_unique_id(void *id_out /* MNV_COMM_ID_BYTES */);
+int mnv_comm_init_rank(const void *id, int32_t world, int32_t rank, mnv_comm **out);
+int32_t mnv_comm_rank(const mnv_comm *comm);
+int32_t mnv_comm_world(const mnv_comm *comm);
+int32_t mnv_comm_rccl_version(void); /* ncclGetVersion of the library that was bound, 0 if none */
+int mnv_gather_tiles(mnv_comm *comm, const void *local, void *gathered, size_t bytes_per_rank, int32_t root, void *hip_stream);
+void mnv_comm_destroy(mnv_comm *comm);
 
 /*
  * Several frames in ONE launch: cams[0 .. n_cams) (same image size, same options, same tile /

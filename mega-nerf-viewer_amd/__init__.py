@@ -202,6 +202,13 @@ _SIGNATURES = {
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_set_colour_math": (None, [C.c_int]),
     "mnv_assemble_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, Partition, C.c_int32, C.c_int32, C.c_void_p]),
+    "mnv_comm_get_unique_id": (C.c_int, [C.c_void_p]),
+    "mnv_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "mnv_comm_rank": (C.c_int32, [C.c_void_p]),
+    "mnv_comm_world": (C.c_int32, [C.c_void_p]),
+    "mnv_comm_rccl_version": (C.c_int32, []),
+    "mnv_gather_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "mnv_comm_destroy": (None, [C.c_void_p]),
     "mnv_render_voxels_accel_batch": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.c_int32, C.POINTER(RenderOptions), Rect,
                                                 Partition, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_render_voxels_accel_track": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
@@ -774,6 +781,53 @@ def stream_create_reserved(reserve_cus: int):
 
 def stream_destroy(stream: int) -> None:
     _check(lib().mnv_stream_destroy(C.c_void_p(stream)))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_get_unique_id() -> bytes:
+    """The 128-byte RCCL id one rank draws and hands to the others (any side channel)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _check(lib().mnv_comm_get_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """RCCL communicator of the tile gather (mnv_comm_*): one process per GPU, bound to the current device."""
+
+    def __init__(self, unique_id: bytes, world: int, rank: int):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise MnvError(MNV_E_INVALID, "unique id must be 128 bytes")
+        h = C.c_void_p()
+        _check(lib().mnv_comm_init_rank(C.create_string_buffer(unique_id, COMM_ID_BYTES), int(world), int(rank), C.byref(h)))
+        self.handle, self.world, self.rank = h.value, int(world), int(rank)
+
+    def gather_tiles(self, local, gathered, root: int = 0, stream: int = 0) -> None:
+        """local: contiguous device tensor; gathered (root only): contiguous device tensor [world, *local.shape]."""
+        nbytes = local.numel() * local.element_size()
+        if not local.is_contiguous() or not local.is_cuda:
+            raise MnvError(MNV_E_INVALID, "local must be a contiguous device tensor")
+        if self.rank == root:
+            if gathered is None or not gathered.is_contiguous() or not gathered.is_cuda or gathered.numel() * gathered.element_size() != nbytes * self.world:
+                raise MnvError(MNV_E_INVALID, "gathered must be a contiguous device tensor of world x local bytes")
+        _check(lib().mnv_gather_tiles(C.c_void_p(self.handle), _ptr(local), _ptr(gathered) if gathered is not None else None, nbytes, int(root),
+                                      C.c_void_p(stream)))
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            lib().mnv_comm_destroy(C.c_void_p(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def rccl_version() -> int:
+    return int(lib().mnv_comm_rccl_version())
 
 
 def set_timing(enable: bool) -> None:

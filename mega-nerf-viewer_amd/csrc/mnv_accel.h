@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <mutex>
 
 #include "../../include/mnv.h"
 #include "mnv_device.h"
@@ -108,9 +109,12 @@ struct mnv_accel {
     int32_t *flags = nullptr;             // [4] device scratch of refresh: changed, deepest depth, grids dirty
     int64_t reserved = 0;                 // chunks the nodes / rows / depth arrays have room for
     unsigned long long *stats = nullptr;  // MNV_STATS=1 diagnostics
+    unsigned long long *timeline = nullptr;  // MNV_TIMELINE=<file> diagnostics: tile / wavefront time stamps of the last launch
+    size_t timeline_bytes = 0, timeline_tiles = 0, timeline_waves = 0, timeline_tiles_per_frame = 0;
     // per-launch slots: [kNumQueues] ray-queue heads (64 B apart; a queue spans the frames of a batch) + [n_frames] camera blocks,
     // written on the launch stream by stage_launch_kernel; kSlots launches may be in flight
     uint8_t *slots_dev = nullptr;
+    std::mutex launch_mutex;              // guards the three slot fields below (launch_accel)
     std::atomic<uint32_t> slot_counter{0};
     hipEvent_t slot_done[mnv::kSlots] = {};  // recorded after the launch that used the slot
     bool slot_used[mnv::kSlots] = {};

@@ -25,6 +25,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "mnv_accel.h"
 #include "mnv_internal.h"
@@ -264,6 +266,8 @@ struct AccelLaunch {
     uint32_t micro_x, micro_per_macro;    // 8x8 micro tiles per macro-tile row / per macro tile
     unsigned long long *stats;            // MODE 1 only: 16 counters
     int32_t count_stats;                  // MODE 1 only: 0 = ablation run without the counters' atomics
+    unsigned long long *timeline;         // MODE 1 only (MNV_TIMELINE): per tile {t_grab, t_done, wave, iterations}, then per wave {t_entry, t_exit} (100 MHz ticks)
+    uint32_t timeline_tiles;              // tile records (n_tiles * n_frames)
     // MODE 2 only: refinement trackers (rt_core.cuh:179-180,237-252,308-321), indexed like the pixels
     float *split_track, *sample_track;
     const int16_t *sample_counts;         // reference layout [capacity][8], may be NULL
@@ -431,6 +435,20 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
     float cen0 = Cp->cen[0], cen1 = Cp->cen[1], cen2 = Cp->cen[2];
     uint32_t pix_base = 0;
 
+    // MODE 1 + MNV_TIMELINE: when each tile was grabbed and finished and by which wavefront (tools/timeline.py)
+    uint32_t tl_rec = ~0u, tl_iters = 0;
+    auto tl_close = [&](unsigned long long now) {
+        if constexpr (MODE == 1) {
+            if (K.timeline && tl_rec != ~0u && lane == 0) {
+                K.timeline[(size_t)tl_rec * 4 + 1] = now;
+                K.timeline[(size_t)tl_rec * 4 + 3] = tl_iters;
+            }
+        }
+    };
+    if constexpr (MODE == 1) {
+        if (K.timeline && lane == 0) K.timeline[(size_t)K.timeline_tiles * 4 + (size_t)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 2] = wall_clock64();
+    }
+
     auto stat = [&](int slot, bool pred) {
         if constexpr (MODE == 1) {
             if (!K.count_stats) return;
@@ -446,6 +464,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
         const uint64_t idle = __ballot(!alive);
         const int n_idle = __popcll(idle);
         stat(0, true);
+        if constexpr (MODE == 1) ++tl_iters;
         // Tile-sized refills keep a wavefront's rays coherent (sweep in DESIGN.md).
         if (!drained && n_idle >= K.refill_min) {
             if (qsel >= kNumQueues) {
@@ -476,6 +495,18 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                 }
             }
             const uint32_t base = begin + off, end = begin + span;
+            if constexpr (MODE == 1) {
+                if (K.timeline) {
+                    const unsigned long long now = wall_clock64();
+                    tl_close(now);
+                    tl_rec = f * K.n_tiles + (base >> 6);
+                    tl_iters = 0;
+                    if (lane == 0) {
+                        K.timeline[(size_t)tl_rec * 4 + 0] = now;
+                        K.timeline[(size_t)tl_rec * 4 + 2] = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+                    }
+                }
+            }
             if (!alive) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
                 const uint32_t id = base + rank;
@@ -528,6 +559,12 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
             }
         }
         if (__ballot(alive) == 0) {
+            if constexpr (MODE == 1) {
+                if (K.timeline && tl_rec != ~0u) {  // the tile is done; what follows is queue polling
+                    tl_close(wall_clock64());
+                    tl_rec = ~0u;
+                }
+            }
             if (drained) break;
             continue;
         }
@@ -749,6 +786,9 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
         }
         t += delta_t;  // 0 for lanes that did not step
     }
+    if constexpr (MODE == 1) {
+        if (K.timeline && lane == 0) K.timeline[(size_t)K.timeline_tiles * 4 + (size_t)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 2 + 1] = wall_clock64();
+    }
 }
 
 // Rank 0 after the gather: macro tile m of frame f sits at gathered[m % world][f][m / world];
@@ -782,11 +822,9 @@ template <int BASIS, int MODE>
 static int launch_variant2(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
     constexpr int BLOCK = 256;
     auto kern = march_accel_kernel<BASIS, BLOCK, MODE>;
-    static thread_local size_t configured = 0;
-    if (lds_bytes > 65536 && configured < lds_bytes) {
+    if (lds_bytes > 65536) {  // diagnostics only (MNV_LDS_LEVEL=5); the attribute is per device, so set it on every such launch
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
-        configured = lds_bytes;
     }
     hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(BLOCK), lds_bytes, stream, K);
     return (int)hipGetLastError();
@@ -906,7 +944,10 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
         const uint32_t n_macro = K.macros_x * (uint32_t)((P.th + part.tile_h - 1) / part.tile_h);
         K.frame_stride_px = (uint32_t)part_j_max(n_macro, part.world, root_period_of(part)) * K.macro_w * K.macro_h;
     }
+    // The per-launch slot bookkeeping is the handle's only mutable state on this path; launches from several host threads
+    // (or one thread feeding several streams) serialise here from the slot's acquisition to the record of its event.
     mnv_accel *mut = const_cast<mnv_accel *>(accel);
+    std::lock_guard<std::mutex> launch_lock(mut->launch_mutex);
     const uint32_t slot = mut->slot_counter.fetch_add(1) % kSlots;
     // a caller that runs more than kSlots launches ahead of the device waits here for the launch that last used the slot
     if (mut->slot_used[slot]) {
@@ -943,7 +984,8 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     static const int env_ablate = getenv("MNV_ABLATE") ? atoi(getenv("MNV_ABLATE")) : 0;
     K.ablate = env_ablate;
     static const bool env_stats = getenv("MNV_STATS") != nullptr;
-    K.stats = (env_stats || env_ablate) ? accel->stats : nullptr;  // both run on the diagnostics instantiation
+    static const char *env_timeline = getenv("MNV_TIMELINE");
+    K.stats = (env_stats || env_ablate || env_timeline) ? accel->stats : nullptr;  // all three run on the diagnostics instantiation
     K.count_stats = env_stats ? 1 : 0;
     K.refill_min = (env_refill > 0 && n_frames == 1) ? env_refill : 64;  // batches refill whole tiles (a grab must not straddle frames);  // sweep in DESIGN.md: 16 -> 0.606 ms, 32 -> 0.535, 48 -> 0.507, 56 -> 0.504, 64 -> 0.506
     int blocks_per_cu = lds_level >= 5 ? 1 : (lds_level == 4 ? 6 : 8);
@@ -954,6 +996,23 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     if ((uint64_t)n_blocks * 4u > n_waves_needed) n_blocks = (int)((n_waves_needed + 3) / 4);
     if (n_blocks < 1) n_blocks = 1;
 
+    if (env_timeline && K.stats) {
+        // diagnostics: (re)allocate the record buffer of this launch; mnv_accel_destroy writes the last launch's records to the file
+        const size_t tiles = (size_t)K.n_tiles * (size_t)n_frames, waves = (size_t)n_blocks * 4;
+        const size_t bytes = (tiles * 4 + waves * 2) * 8;
+        if (mut->timeline_bytes < bytes) {
+            if (mut->timeline) (void)hipFree(mut->timeline);
+            mut->timeline = nullptr;
+            if (hipMalloc((void **)&mut->timeline, bytes) != hipSuccess) return (int)hipErrorOutOfMemory;
+            mut->timeline_bytes = bytes;
+        }
+        (void)hipMemsetAsync(mut->timeline, 0, bytes, stream);
+        mut->timeline_tiles = tiles;
+        mut->timeline_waves = waves;
+        mut->timeline_tiles_per_frame = K.n_tiles;
+        K.timeline = mut->timeline;
+        K.timeline_tiles = (uint32_t)tiles;
+    }
     int rc = kUnsupportedBasis;
     const int b = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim >= 0) ? accel->view.basis_dim : -1;
     if (colourless) rc = launch_variant<9>(K, n_blocks, lds_bytes, stream);
@@ -1195,6 +1254,20 @@ void mnv_accel_destroy(mnv_accel *a) {
                         h[2 * i] ? (double)h[2 * i + 1] / (double)h[2 * i] : 0.0);
         }
     }
+    if (a->timeline && getenv("MNV_TIMELINE")) {
+        const size_t words = a->timeline_tiles * 4 + a->timeline_waves * 2;
+        std::vector<unsigned long long> h(words + 3);
+        h[0] = a->timeline_tiles;
+        h[1] = a->timeline_waves;
+        h[2] = a->timeline_tiles_per_frame;
+        if (hipMemcpy(h.data() + 3, a->timeline, words * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *f = fopen(getenv("MNV_TIMELINE"), "wb")) {
+                fwrite(h.data(), 8, h.size(), f);
+                fclose(f);
+            }
+        }
+    }
+    if (a->timeline) (void)hipFree(a->timeline);
     if (a->stats) (void)hipFree(a->stats);
     if (a->depth) (void)hipFree(a->depth);
     if (a->flags) (void)hipFree(a->flags);

@@ -100,25 +100,31 @@ class TilePartition:
 
 
 class TileGatherer:
-    """Ring of `depth` in-flight steps: render into ``local(slot)`` on the current stream, then ``submit(slot)`` starts the
-    asynchronous gather to rank 0; ``finish(slot)`` orders the slot's next render after that gather and (on rank 0) un-permutes
-    into ``frame(slot)``.  Nothing here blocks the host, and nothing but the reuse of a slot's own buffer makes the render stream
-    wait: the gather's completion and the un-permute are enqueued on a side stream, so with depth >= 2 the gather and assembly of
-    step k overlap the render of step k+1 (on rank 0 too, which would otherwise pay the un-permute between two renders)."""
+    """Ring of `depth` in-flight steps: render into ``local(slot)`` on the current stream, then ``submit(slot)`` enqueues the
+    gather to rank 0 and (on rank 0) the un-permute into ``frame(slot)`` on the SLOT'S OWN side stream; ``finish(slot)`` orders the
+    slot's next render (current stream) after that gather.  Nothing here blocks the host, and nothing but the reuse of a slot's own
+    buffer makes a render stream wait: with depth >= 2 the gather and assembly of step k overlap the render of step k+1 (on rank 0
+    too, which would otherwise pay the un-permute between two renders).  One side stream per slot: with a shared one, the wait for
+    march k+1 that precedes gather k+1 would also delay the completion record of gather k, and with it march k+2.
+
+    The gather itself is ``comm.gather_tiles`` (libmnv's RCCL path, mnv_gather_tiles) when an ``mnv.Comm`` is given, otherwise
+    ``torch.distributed.gather`` on `group` (gloo in the CPU tests and the one-GPU rehearsal)."""
 
     def __init__(self, part: TilePartition, rank: int, device, dtype=torch.float32, channels: int = 4, depth: int = 3, group=None,
-                 frames: int = 0, stage_on_host: bool = False):
+                 frames: int = 0, stage_on_host: bool = False, comm=None):
         """`frames` > 0: every slot holds a batch of that many frames (one launch + one gather per batch).
         `stage_on_host`: gather through host copies (for process groups without device collectives, e.g. gloo
         in the single-GPU rehearsal of the N > 1 path); the default hands device buffers to RCCL."""
-        self.part, self.rank, self.group, self.depth = part, rank, group, depth
+        self.part, self.rank, self.group, self.depth, self.comm = part, rank, group, depth, comm
         self.stage_on_host = stage_on_host
         lead = (frames,) if frames > 0 else ()
         shape = lead + (part.j_max, part.tile_h, part.tile_w, channels)
         self._local = [torch.zeros(shape, dtype=dtype, device=device) for _ in range(depth)]
         self._pending = [None] * depth
         on_gpu = torch.device(device).type == "cuda"
-        self._side = torch.cuda.Stream(device=device) if on_gpu and not stage_on_host else None
+        if comm is not None and (not on_gpu or stage_on_host):
+            raise ValueError("the RCCL communicator gathers device buffers")
+        self._side = [torch.cuda.Stream(device=device) for _ in range(depth)] if on_gpu and not stage_on_host else None
         self._sent = [torch.cuda.Event() for _ in range(depth)] if self._side is not None else None
         if rank == 0:
             self._gathered = [torch.empty((part.world,) + shape, dtype=dtype, device=device) for _ in range(depth)]
@@ -140,11 +146,19 @@ class TileGatherer:
         if self._side is None:
             self._pending[slot] = dist.gather(self._local[slot], glist, dst=0, group=self.group, async_op=True)
             return
-        # the collective is ordered after everything the side stream holds (the un-permute that last read this slot's gather
-        # buffer) and after the render just enqueued on the current stream
-        self._side.wait_stream(torch.cuda.current_stream(self._side.device))
-        with torch.cuda.stream(self._side):
-            self._pending[slot] = dist.gather(self._local[slot], glist, dst=0, group=self.group, async_op=True)
+        side = self._side[slot]
+        # the slot's side stream already holds the un-permute that last read this slot's gather table; the collective is ordered
+        # after it and after the render just enqueued on the current stream
+        side.wait_stream(torch.cuda.current_stream(side.device))
+        with torch.cuda.stream(side):
+            if self.comm is not None:
+                self.comm.gather_tiles(self._local[slot], self._gathered[slot] if self.rank == 0 else None, root=0, stream=side.cuda_stream)
+            else:
+                dist.gather(self._local[slot], glist, dst=0, group=self.group, async_op=True).wait()  # stream-level wait on `side`
+            self._sent[slot].record()      # local(slot) may be overwritten from here on
+            if self.rank == 0:
+                self.part.unpermute(self._gathered[slot], out=self._frames[slot])
+        self._pending[slot] = True
 
     def finish(self, slot: int) -> None:
         w = self._pending[slot]
@@ -163,16 +177,12 @@ class TileGatherer:
             if self.rank == 0:
                 self.part.unpermute(self._gathered[slot], out=self._frames[slot])
             return
-        with torch.cuda.stream(self._side):
-            w.wait()                       # side stream: after the gather
-            self._sent[slot].record()      # local(slot) may be overwritten from here on
-            if self.rank == 0:
-                self.part.unpermute(self._gathered[slot], out=self._frames[slot])
-        torch.cuda.current_stream(self._side.device).wait_event(self._sent[slot])
+        torch.cuda.current_stream(self._side[slot].device).wait_event(self._sent[slot])
 
     def finish_all(self) -> None:
         for s in range(self.depth):
             self.finish(s)
         if self._side is not None:
             # frames are read on the current stream (or the host) next
-            torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+            for side in self._side:
+                torch.cuda.current_stream(side.device).wait_stream(side)

@@ -36,6 +36,33 @@ def test_bench_multirank_rehearsal(torch_gpu, world, gather):
     assert d["value"] > 0 and d["roofline"]["launches"] == 2
 
 
+def test_bench_starts_its_own_ranks(torch_gpu):
+    """`python bench.py --gpus 2` WITHOUT a launcher: bench.py starts the two ranks itself (fresh child processes, the parent never
+    touches the GPU) and relays rank 0's line; a line that reports another rank count is an error, not a one-GPU number."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--laps", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["parity"]["pixels_not_bit_identical"] == 0 and d["parity"]["frames_checked"] >= 3
+
+
+def test_bench_refuses_a_rank_count_it_cannot_have(torch_gpu):
+    """Over RCCL every rank needs its own GPU: on a one-GPU box `--gpus 2` must fail, not print a one-GPU line."""
+    if torch_gpu.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    env["WORLD_SIZE"], env["RANK"], env["LOCAL_RANK"] = "1", "0", "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "refusing" in r.stderr
+
+
 @pytest.mark.parametrize("gather,reserve", [("u8", 32), ("f32", 0)])
 def test_bench_rccl_path_single_rank(torch_gpu, gather, reserve):
     """The RCCL calls of the N > 1 path executed for real (a one-GPU box allows one rank): process group on "nccl", partition with
@@ -47,6 +74,6 @@ def test_bench_rccl_path_single_rank(torch_gpu, gather, reserve):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["n_gpus"] == 1 and d["config"]["reserved_cus"] == reserve and "RCCL gather" in d["config"]["partition"]
-    assert d["parity"]["pixels_not_bit_identical"] == 0 and d["parity"]["frames_checked"] == 2
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["config"]["reserved_cus"] == reserve and "RCCL gather" in d["config"]["partition"]
+    assert d["parity"]["pixels_not_bit_identical"] == 0 and d["parity"]["frames_checked"] >= 3
     assert d["value"] > 0 and d["roofline"]["launches"] == 3
