@@ -309,7 +309,7 @@ def main():
     if not multi and args.kernel == "accel" and not args.per_frame and args.frame_streams >= 1:
         k = args.frame_streams
         sts = [torch.cuda.Stream(device=dev) for _ in range(k)]
-        pf_out = frames[0]
+        pf_out = torch.empty_like(frames[0])   # own buffer: the batched frames of the last timed step stay intact for the parity check
 
         def pf_step():
             for i in range(N_FRAMES):

@@ -106,6 +106,8 @@ typedef struct mnv_rect {
 int mnv_version(void);
 /* Thread-local description of the last non-zero status returned on this thread. */
 const char *mnv_last_error(void);
+/* first 16 hex digits of the SHA-256 over the library's sources (csrc/, host/, include/ in the Makefile's order) at build time */
+const char *mnv_source_sha(void);
 /* Number of visible HIP devices (0 when there is none; never fails). */
 int mnv_device_count(void);
 /* struct defaults of include/render_options.hpp:9-56 */
@@ -532,6 +534,16 @@ int mnv_renderer_set_seed(mnv_renderer *r, uint64_t seed, int32_t accel_rebuild_
 int mnv_renderer_render(mnv_renderer *r, mnv_renderer_stats *stats /* may be NULL */);
 /* wait for the frame and copy it to host buffers [height][width][4] (either may be NULL) */
 int mnv_renderer_download(mnv_renderer *r, float *rgba_host, uint8_t *rgba8_host);
+/*
+ * Frames in flight (VolumeRenderer::frames_in_flight, default 3).  The reference issues one render_voxels call per frame on
+ * one stream (src/renderer/cuda_renderer.cpp:141-142); here plain frames (no refinement, packed accel current) rotate over
+ * `count` slots, each with its own HIP stream and frame buffers, so the tail of one launch overlaps the next launches.
+ * mnv_renderer_render returns at once; mnv_renderer_last_slot names the slot it rendered into and
+ * mnv_renderer_download_slot waits for that slot's frame only.  count = 1 restores the one-stream behaviour.
+ */
+int mnv_renderer_set_frames_in_flight(mnv_renderer *r, int32_t count);
+int32_t mnv_renderer_last_slot(const mnv_renderer *r);
+int mnv_renderer_download_slot(mnv_renderer *r, int32_t slot, float *rgba_host, uint8_t *rgba8_host);
 /* copy the (refined) device tree back into the mnv_n3tree's host arrays */
 int mnv_renderer_sync_tree(mnv_renderer *r);
 

@@ -179,6 +179,7 @@ class SynthShellParams(C.Structure):
 _SIGNATURES = {
     "mnv_version": (C.c_int, []),
     "mnv_last_error": (C.c_char_p, []),
+    "mnv_source_sha": (C.c_char_p, []),
     "mnv_device_count": (C.c_int, []),
     "mnv_default_render_options": (None, [C.POINTER(RenderOptions)]),
     "mnv_cli_render_options": (None, [C.POINTER(RenderOptions)]),
@@ -250,6 +251,9 @@ _SIGNATURES = {
     "mnv_renderer_render": (C.c_int, [C.c_void_p, C.POINTER(RendererStats)]),
     "mnv_renderer_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_renderer_sync_tree": (C.c_int, [C.c_void_p]),
+    "mnv_renderer_set_frames_in_flight": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mnv_renderer_last_slot": (C.c_int32, [C.c_void_p]),
+    "mnv_renderer_download_slot": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mnv_set_timing": (None, [C.c_int]),
     "mnv_take_timing": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "mnv_n3tree_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
@@ -290,6 +294,28 @@ def lib() -> C.CDLL:
             fn.argtypes = args
         _lib = h
     return _lib
+
+
+def built_source_sha() -> str:
+    """Hash of the sources the loaded libmnv.so was built from (mnv_source_sha)."""
+    return lib().mnv_source_sha().decode()
+
+
+def shipped_source_sha() -> str:
+    """The same hash over the sources in this tree (the Makefile's SRC_SHA: sorted relative names, contents concatenated)."""
+    import glob
+    import hashlib
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    names = []
+    for pat in ("csrc/*.hip", "csrc/*.h", "host/*.cpp", "host/*.hpp", "../include/*.h", "csrc/mnv_comm.cpp"):
+        names += [os.path.relpath(f, here) for f in glob.glob(os.path.join(here, pat))]
+    names = sorted(set(names))
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(here, n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def _check(rc: int) -> None:
@@ -747,6 +773,18 @@ class Renderer:
 
     def sync_tree(self) -> None:
         _check(lib().mnv_renderer_sync_tree(self._h))
+
+    def set_frames_in_flight(self, count: int) -> None:
+        _check(lib().mnv_renderer_set_frames_in_flight(self._h, int(count)))
+
+    def last_slot(self) -> int:
+        return int(lib().mnv_renderer_last_slot(self._h))
+
+    def download_slot(self, slot: int, want_rgba8=False):
+        rgba = np.empty((self.height, self.width, 4), np.float32)
+        rgba8 = np.empty((self.height, self.width, 4), np.uint8) if want_rgba8 else None
+        _check(lib().mnv_renderer_download_slot(self._h, int(slot), rgba.ctypes.data, rgba8.ctypes.data if want_rgba8 else None))
+        return (rgba, rgba8) if want_rgba8 else rgba
 
 
 MAX_BATCH = 64

@@ -299,6 +299,29 @@ int mnv_renderer_download(mnv_renderer *r, float *rgba, uint8_t *rgba8) {
     });
 }
 
+int mnv_renderer_set_frames_in_flight(mnv_renderer *r, int32_t count) {
+    if (!r || count < 1 || count > 16) return mnv::set_error(MNV_E_INVALID, "frames in flight: 1 .. 16");
+    return guarded([&] {
+        r->rend.sync_tree_streams();
+        r->rend.frames_in_flight = count;
+        return MNV_OK;
+    });
+}
+
+int32_t mnv_renderer_last_slot(const mnv_renderer *r) { return r ? r->rend.last_slot() : -1; }
+
+int mnv_renderer_download_slot(mnv_renderer *r, int32_t slot, float *rgba, uint8_t *rgba8) {
+    if (!r) return mnv::set_error(MNV_E_INVALID, "null argument");
+    return guarded([&] {
+        std::vector<float> f;
+        std::vector<uint8_t> u;
+        r->rend.download_slot(slot, rgba ? &f : nullptr, rgba8 ? &u : nullptr);
+        if (rgba) std::memcpy(rgba, f.data(), f.size() * sizeof(float));
+        if (rgba8) std::memcpy(rgba8, u.data(), u.size());
+        return MNV_OK;
+    });
+}
+
 int mnv_renderer_sync_tree(mnv_renderer *r) {
     if (!r) return mnv::set_error(MNV_E_INVALID, "null argument");
     return guarded([&] {

@@ -14,7 +14,24 @@
 //   --frames N       render N frames; with --orbit DEG the camera is rotated about --origin around
 //                    --world_up by DEG degrees per frame (default 0: N identical frames, for timing)
 //   --gpu ID         HIP device
+//   --gpus N         one process per GPU (forked before any HIP call), devices --gpu .. --gpu + N - 1: the tree is replicated, every
+//                    frame is cut into interleaved 64x24 macro tiles (mnv_partition), each rank renders its tiles of up to 64
+//                    frames with one launch, the compact buffers are gathered to rank 0 over RCCL (mnv_gather_tiles) and
+//                    un-permuted there (mnv_assemble_tiles); rank 0 writes the frames.  --gpus 1 runs the same path with one
+//                    rank.  --reserve_cus R (default 32 when N > 1) keeps R compute units free for the RCCL kernels.
+//                    Not combined with --model_path (refinement mutates the tree).
+//   --in_flight K    plain frames in flight (default 3; VolumeRenderer::frames_in_flight): frame k is downloaded and written
+//                    after frames k+1 .. k+K-1 have been issued
 #include <hip/hip_runtime_api.h>
+
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <csignal>
+#include <deque>
 
 #include <cmath>
 #include <cstdio>
@@ -85,6 +102,7 @@ void usage() {
     std::puts("usage: mnv_render npz_file [--bg 0.0] [-s step_size] [-e stop_thresh] [-a sigma_thresh] [-c max_tree_capacity]\n"
               "                  [-w width] [-h height] [--fx 1111] [--fy -1] [--cx -1] [--cy -1] [--center x,y,z] [--back x,y,z]\n"
               "                  [--origin x,y,z] [--world_up x,y,z] [-b] [--out PREFIX] [--raw] [--frames N] [--orbit DEG] [--gpu ID]\n"
+              "                  [--in_flight K] [--gpus N [--reserve_cus R] [--root_period M]]\n"
               "                  [--model_path MODEL.npz [--use_splitting] [--use_guided_sampling] [-x split_batch_size] [-v samples_per_voxel]\n"
               "                   [-y appearance_embedding] [-z max_guided_samples] [--max_depth D] [--max_sample_count C] [--seed S]\n"
               "                   [--save_tree FILE.npz]]");
@@ -102,6 +120,266 @@ void rotate(float v[3], const float k[3], double ang) {
 
 }  // namespace
 
+
+namespace {
+
+void hip_ok(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+void mnv_ok(int rc, const char *what) {
+    if (rc != MNV_OK) throw std::runtime_error(std::string(what) + ": " + mnv_last_error());
+}
+
+// the options / camera part of the command line (render_options_from_args src/opts.cpp:49-67, camera flags main.cpp:550-582)
+void configure(const Args &args, viewer::VolumeRenderer &rend, int width, int height) {
+    rend.options.background_brightness = args.f("bg", 0.0f);
+    rend.options.step_size = args.f("step_size", 1e-4f);
+    rend.options.stop_thresh = args.f("stop_thresh", 1e-2f);
+    rend.options.sigma_thresh = args.f("sigma_thresh", 1e-2f);
+    rend.options.split_batch_size = (int)args.l("split_batch_size", 4096);
+    rend.options.nerf_batch_size = (int)args.l("nerf_batch_size", 4096);
+    rend.options.samples_per_corner = (int)args.l("samples_per_voxel", 8);
+    rend.options.appearance_embedding = (int)args.l("appearance_embedding", -1);
+    rend.options.max_guided_samples = (int)args.l("max_guided_samples", 128);
+    rend.camera = viewer::Camera(width, height, args.f("fx", 1111.f), args.f("fy", -1.f), args.f("cx", -1.f), args.f("cy", -1.f));
+    const std::vector<float> center = args.vec("center", {-3.5f, 0.f, 3.5f}), back = args.vec("back", {-0.7071068f, 0.f, 0.7071068f}),
+                             origin = args.vec("origin", {0.f, 0.f, 0.f}), up = args.vec("world_up", {0.f, 0.f, 1.f});
+    if (center.size() != 3 || back.size() != 3 || origin.size() != 3 || up.size() != 3) throw std::runtime_error("vector flags need 3 components");
+    rend.camera.center = {center[0], center[1], center[2]};
+    rend.camera.v_back = {back[0], back[1], back[2]};
+    rend.camera.origin = {origin[0], origin[1], origin[2]};
+    rend.camera.v_world_up = {up[0], up[1], up[2]};
+}
+
+// --orbit: rotate the camera about `origin` around world_up by `ang`
+void orbit_step(viewer::Camera &cam, double ang) {
+    float axis[3] = {cam.v_world_up.x, cam.v_world_up.y, cam.v_world_up.z};
+    const float an = std::sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
+    for (float &v : axis) v /= an;
+    float c[3] = {cam.center.x - cam.origin.x, cam.center.y - cam.origin.y, cam.center.z - cam.origin.z};
+    float b[3] = {cam.v_back.x, cam.v_back.y, cam.v_back.z};
+    rotate(c, axis, ang);
+    rotate(b, axis, ang);
+    cam.center = {c[0] + cam.origin.x, c[1] + cam.origin.y, c[2] + cam.origin.z};
+    cam.v_back = {b[0], b[1], b[2]};
+}
+
+void write_frame(const std::string &out, long f, int width, int height, const uint8_t *rgba8, const float *rgba) {
+    char name[4096];
+    std::snprintf(name, sizeof(name), "%s_%04ld.ppm", out.c_str(), f);
+    if (std::FILE *fp = std::fopen(name, "wb")) {
+        std::fprintf(fp, "P6\n%d %d\n255\n", width, height);
+        for (size_t p = 0; p < (size_t)width * height; ++p) std::fwrite(&rgba8[p * 4], 1, 3, fp);
+        std::fclose(fp);
+    } else {
+        throw std::runtime_error(std::string("cannot write ") + name);
+    }
+    if (rgba) {
+        std::snprintf(name, sizeof(name), "%s_%04ld.f32", out.c_str(), f);
+        std::FILE *fp = std::fopen(name, "wb");
+        if (!fp) throw std::runtime_error(std::string("cannot write ") + name);
+        std::fwrite(rgba, sizeof(float), (size_t)width * height * 4, fp);
+        std::fclose(fp);
+    }
+}
+
+// ---- multi-GPU mode: one process per GPU --------------------------------------------------------------------------------
+
+struct Rendezvous {  // anonymous shared mapping created before the fork
+    std::atomic<int> id_ready;
+    std::atomic<int> failed;
+    char id[MNV_COMM_ID_BYTES];
+};
+
+constexpr int kMacroW = 64, kMacroH = 24;  // per-rank launch times within 3 % of each other at world 8
+
+int run_rank(const Args &args, int rank, int world, Rendezvous *rv) {
+    if (hipSetDevice((int)args.l("gpu", 0) + rank) != hipSuccess) throw std::runtime_error("rank " + std::to_string(rank) + ": no usable HIP device");
+    viewer::N3Tree tree(args.file);
+    if (tree.N <= 0) throw std::runtime_error("--gpus needs a tree (N > 0)");
+    const int width = (int)args.l("width", 800), height = (int)args.l("height", 800);
+    viewer::VolumeRenderer rend;
+    configure(args, rend, width, height);
+    rend.set(tree, tree.capacity);  // every rank holds the whole tree: the march needs no exchange
+    rend.resize(width, height);
+    if (!tree.device.accel) throw std::runtime_error("--gpus needs the packed accel (N == 2, RGBA or SH1/4/9/16/25 rows)");
+
+    // communicator: rank 0 draws the id, the others read it from the shared page
+    if (rank == 0) {
+        mnv_ok(mnv_comm_get_unique_id(rv->id), "mnv_comm_get_unique_id");
+        rv->id_ready.store(1, std::memory_order_release);
+    } else {
+        while (!rv->id_ready.load(std::memory_order_acquire)) {
+            if (rv->failed.load()) throw std::runtime_error("another rank failed before the rendezvous");
+            usleep(1000);
+        }
+    }
+    mnv_comm *comm = nullptr;
+    mnv_ok(mnv_comm_init_rank(rv->id, world, rank, &comm), "mnv_comm_init_rank");
+
+    const long frames = args.l("frames", 1);
+    const double orbit = args.f("orbit", 0.f) * M_PI / 180.0;
+    const std::string out = args.get("out", "");
+    const bool raw = args.has("raw");
+    std::vector<mnv_camera> cams;  // the whole camera path, as the single-GPU loop would walk it
+    for (long f = 0; f < frames; ++f) {
+        rend.camera._update();
+        cams.push_back(rend.camera.c_abi());
+        if (orbit != 0.0) orbit_step(rend.camera, orbit);
+    }
+
+    const mnv_rect full = {0, 0, width, height};
+    const int32_t root_period = world > 1 ? (int32_t)std::max<long>(2, args.l("root_period", std::lround(64.0 / world))) : 0;
+    const mnv_partition part = {rank, world, kMacroW, kMacroH, root_period};
+    int32_t j_max = 0;
+    for (int r = 0; r < world; ++r) {
+        const mnv_partition pr = {r, world, kMacroW, kMacroH, root_period};
+        j_max = std::max(j_max, mnv_partition_local_tiles(full, pr));
+    }
+    const int batch = (int)std::min<long>(MNV_MAX_BATCH, std::max<long>(frames, 1));
+    const size_t tile_px = (size_t)j_max * kMacroW * kMacroH, local_px = tile_px * batch, frame_px = (size_t)width * height;
+
+    // the march runs on a stream that leaves `reserve` compute units to the RCCL kernels of the gather
+    const int reserve = (int)args.l("reserve_cus", world > 1 ? 32 : 0);
+    void *march_stream = nullptr;
+    int32_t enabled = 0;
+    mnv_ok(mnv_stream_create_reserved(reserve, &march_stream, &enabled), "mnv_stream_create_reserved");
+    mnv_ok(mnv_accel_set_cu_budget(tree.device.accel, enabled), "mnv_accel_set_cu_budget");
+    hipStream_t side = nullptr;
+    hip_ok(hipStreamCreateWithFlags(&side, hipStreamNonBlocking), "hipStreamCreate");
+
+    constexpr int RING = 2;
+    struct Slot {
+        uint8_t *local8 = nullptr, *gathered8 = nullptr, *frames8 = nullptr;
+        float *local = nullptr, *gathered = nullptr, *framesf = nullptr;
+        hipEvent_t rendered = nullptr, sent = nullptr, assembled = nullptr;
+        long first = -1;
+        int count = 0;
+    } slots[RING];
+    for (Slot &s : slots) {
+        hip_ok(hipMalloc((void **)&s.local8, local_px * 4), "hipMalloc(local tiles)");
+        if (raw) hip_ok(hipMalloc((void **)&s.local, local_px * 16), "hipMalloc(local tiles f32)");
+        if (rank == 0) {
+            hip_ok(hipMalloc((void **)&s.gathered8, local_px * 4 * world), "hipMalloc(gather table)");
+            hip_ok(hipMalloc((void **)&s.frames8, frame_px * 4 * batch), "hipMalloc(frames)");
+            if (raw) {
+                hip_ok(hipMalloc((void **)&s.gathered, local_px * 16 * world), "hipMalloc(gather table f32)");
+                hip_ok(hipMalloc((void **)&s.framesf, frame_px * 16 * batch), "hipMalloc(frames f32)");
+            }
+        }
+        hip_ok(hipEventCreateWithFlags(&s.rendered, hipEventDisableTiming), "hipEventCreate");
+        hip_ok(hipEventCreateWithFlags(&s.sent, hipEventDisableTiming), "hipEventCreate");
+        hip_ok(hipEventCreateWithFlags(&s.assembled, hipEventDisableTiming), "hipEventCreate");
+    }
+    std::vector<uint8_t> host8;
+    std::vector<float> hostf;
+    auto flush = [&](Slot &s) {  // rank 0: wait for the slot's assembled frames and write them
+        if (s.first < 0) return;
+        hip_ok(hipEventSynchronize(s.assembled), "assemble");
+        if (rank == 0 && !out.empty()) {
+            host8.resize(frame_px * 4 * s.count);
+            hip_ok(hipMemcpy(host8.data(), s.frames8, host8.size(), hipMemcpyDeviceToHost), "download frames");
+            if (raw) {
+                hostf.resize(frame_px * 4 * s.count);
+                hip_ok(hipMemcpy(hostf.data(), s.framesf, hostf.size() * 4, hipMemcpyDeviceToHost), "download frames f32");
+            }
+            for (int i = 0; i < s.count; ++i)
+                write_frame(out, s.first + i, width, height, host8.data() + frame_px * 4 * i, raw ? hostf.data() + frame_px * 4 * i : nullptr);
+        }
+        s.first = -1;
+    };
+
+    const auto wall0 = std::chrono::steady_clock::now();
+    int b = 0;
+    for (long f0 = 0; f0 < frames; f0 += batch, ++b) {
+        Slot &s = slots[b % RING];
+        flush(s);  // frames of the batch that used this slot two batches ago
+        const int n = (int)std::min<long>(batch, frames - f0);
+        s.first = f0;
+        s.count = n;
+        // one launch per rank and batch; the buffer is reused only after the gather that last read it
+        hip_ok(hipStreamWaitEvent((hipStream_t)march_stream, s.sent, 0), "wait(sent)");
+        mnv_ok(mnv_render_voxels_accel_batch(tree.device.accel, cams.data() + f0, n, rend.options.c_abi(), full, part, s.local, s.local8, march_stream),
+               "mnv_render_voxels_accel_batch");
+        hip_ok(hipEventRecord(s.rendered, (hipStream_t)march_stream), "record(rendered)");
+        // gather + un-permute on the side stream, overlapping the next batch's march
+        hip_ok(hipStreamWaitEvent(side, s.rendered, 0), "wait(rendered)");
+        mnv_ok(mnv_gather_tiles(comm, s.local8, s.gathered8, tile_px * 4 * n, 0, side), "mnv_gather_tiles");
+        if (raw) mnv_ok(mnv_gather_tiles(comm, s.local, s.gathered, tile_px * 16 * n, 0, side), "mnv_gather_tiles(f32)");
+        hip_ok(hipEventRecord(s.sent, side), "record(sent)");
+        if (rank == 0) {
+            mnv_ok(mnv_assemble_tiles(s.gathered8, s.frames8, width, height, part, n, 4, side), "mnv_assemble_tiles");
+            if (raw) mnv_ok(mnv_assemble_tiles(s.gathered, s.framesf, width, height, part, n, 16, side), "mnv_assemble_tiles(f32)");
+        }
+        hip_ok(hipEventRecord(s.assembled, side), "record(assembled)");
+    }
+    for (int k = 0; k < RING; ++k) flush(slots[(b + k) % RING]);
+    hip_ok(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    if (rank == 0)
+        std::printf("%s x %d (RCCL %d): %ld frame(s) %dx%d, interleaved %dx%d macro tiles, %.3f ms/frame wall%s, %.1f Mrays/s\n", rend.get_backend(), world,
+                    (int)mnv_comm_rccl_version(), frames, width, height, kMacroW, kMacroH, wall_ms / std::max<long>(frames, 1),
+                    out.empty() ? "" : " incl. download + file output", wall_ms > 0 ? (double)width * height * frames / wall_ms / 1e3 : 0.0);
+    for (Slot &s : slots) {
+        for (void *p : {(void *)s.local8, (void *)s.gathered8, (void *)s.frames8, (void *)s.local, (void *)s.gathered, (void *)s.framesf})
+            if (p) (void)hipFree(p);
+        (void)hipEventDestroy(s.rendered);
+        (void)hipEventDestroy(s.sent);
+        (void)hipEventDestroy(s.assembled);
+    }
+    (void)hipStreamDestroy(side);
+    mnv_comm_destroy(comm);
+    (void)mnv_stream_destroy(march_stream);
+    return 0;
+}
+
+// Fork one child per rank BEFORE anything in this process touches HIP, wait for them, and take a failing rank's peers down
+// with it (they would otherwise wait in RCCL forever).
+int run_distributed(const Args &args, int world) {
+    if (world < 1 || world > 64) throw std::runtime_error("--gpus must be 1 .. 64");
+    if (args.has("model_path")) throw std::runtime_error("--gpus renders a read-only tree; refinement (--model_path) runs on one GPU");
+    void *page = mmap(nullptr, sizeof(Rendezvous), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if (page == MAP_FAILED) throw std::runtime_error("mmap failed");
+    Rendezvous *rv = new (page) Rendezvous();
+    rv->id_ready.store(0);
+    rv->failed.store(0);
+    std::vector<pid_t> kids;
+    for (int r = 0; r < world; ++r) {
+        std::fflush(nullptr);
+        const pid_t pid = fork();
+        if (pid < 0) throw std::runtime_error("fork failed");
+        if (pid == 0) {
+            int rc = 1;
+            try {
+                rc = run_rank(args, r, world, rv);
+            } catch (const std::exception &e) {
+                std::fprintf(stderr, "mnv_render[rank %d]: %s\n", r, e.what());
+                rv->failed.store(1);
+            }
+            std::fflush(nullptr);
+            _exit(rc);
+        }
+        kids.push_back(pid);
+    }
+    int worst = 0, left = world;
+    while (left > 0) {
+        int status = 0;
+        const pid_t pid = wait(&status);
+        if (pid < 0) break;
+        --left;
+        const int rc = WIFEXITED(status) ? WEXITSTATUS(status) : 128 + (WIFSIGNALED(status) ? WTERMSIG(status) : 0);
+        if (rc != 0 && worst == 0) {
+            worst = rc;
+            for (pid_t k : kids)
+                if (k != pid) (void)kill(k, SIGTERM);  // exactly the processes started above
+        }
+    }
+    munmap(page, sizeof(Rendezvous));
+    return worst;
+}
+
+}  // namespace
+
 int main(int argc, char **argv) {
     try {
         const Args args = parse(argc, argv);
@@ -109,6 +387,7 @@ int main(int argc, char **argv) {
             usage();
             return args.has("help") ? 0 : 2;
         }
+        if (args.has("gpus")) return run_distributed(args, (int)args.l("gpus", 1));  // before any HIP call in this process
         if (hipSetDevice((int)args.l("gpu", 0)) != hipSuccess) throw std::runtime_error("no usable HIP device");
 
         viewer::N3Tree tree(args.file);  // main.cpp:528
@@ -121,26 +400,7 @@ int main(int argc, char **argv) {
         }
         const int width = (int)args.l("width", 800), height = (int)args.l("height", 800);  // main.cpp:491-492
         viewer::VolumeRenderer rend;
-        // render_options_from_args, src/opts.cpp:49-67
-        rend.options.background_brightness = args.f("bg", 0.0f);
-        rend.options.step_size = args.f("step_size", 1e-4f);
-        rend.options.stop_thresh = args.f("stop_thresh", 1e-2f);
-        rend.options.sigma_thresh = args.f("sigma_thresh", 1e-2f);
-        rend.options.split_batch_size = (int)args.l("split_batch_size", 4096);
-        rend.options.nerf_batch_size = (int)args.l("nerf_batch_size", 4096);
-        rend.options.samples_per_corner = (int)args.l("samples_per_voxel", 8);
-        rend.options.appearance_embedding = (int)args.l("appearance_embedding", -1);
-        rend.options.max_guided_samples = (int)args.l("max_guided_samples", 128);
-        // camera from flags, main.cpp:550-582
-        rend.camera = viewer::Camera(width, height, args.f("fx", 1111.f), args.f("fy", -1.f), args.f("cx", -1.f), args.f("cy", -1.f));
-        const std::vector<float> center = args.vec("center", {-3.5f, 0.f, 3.5f}), back = args.vec("back", {-0.7071068f, 0.f, 0.7071068f}),
-                                 origin = args.vec("origin", {0.f, 0.f, 0.f}), up = args.vec("world_up", {0.f, 0.f, 1.f});
-        if (center.size() != 3 || back.size() != 3 || origin.size() != 3 || up.size() != 3) throw std::runtime_error("vector flags need 3 components");
-        rend.camera.center = {center[0], center[1], center[2]};
-        rend.camera.v_back = {back[0], back[1], back[2]};
-        rend.camera.origin = {origin[0], origin[1], origin[2]};
-        rend.camera.v_world_up = {up[0], up[1], up[2]};
-
+        configure(args, rend, width, height);
         const bool refine = args.has("model_path") && (args.has("use_splitting") || args.has("use_guided_sampling"));
         // the reference reserves max_tree_capacity (default 20M chunks) up front; without refinement the tree cannot grow
         const long max_capacity = refine ? std::max<long>(tree.capacity, args.l("max_tree_capacity", 20000000)) : tree.capacity;
@@ -158,13 +418,22 @@ int main(int argc, char **argv) {
         const long frames = args.l("frames", 1);
         const double orbit = args.f("orbit", 0.f) * M_PI / 180.0;
         const std::string out = args.get("out", "");
-        float axis[3] = {up[0], up[1], up[2]};
-        const float an = std::sqrt(axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2]);
-        for (float &v : axis) v /= an;
         std::vector<float> rgba;
         std::vector<uint8_t> rgba8;
         mnv_set_timing(1);
+        rend.frames_in_flight = (int)std::max<long>(1, args.l("in_flight", rend.frames_in_flight));
+        const size_t depth = refine ? 1 : (size_t)rend.frames_in_flight;
+        std::deque<std::pair<long, int>> pending;  // (frame, slot) rendered but not yet written
+        auto write_oldest = [&]() {
+            const long f = pending.front().first;
+            const int slot = pending.front().second;
+            pending.pop_front();
+            rend.download_slot(slot, args.has("raw") ? &rgba : nullptr, &rgba8);
+            write_frame(out, f, width, height, rgba8.data(), args.has("raw") ? rgba.data() : nullptr);
+        };
+        const auto wall0 = std::chrono::steady_clock::now();
         for (long f = 0; f < frames; ++f) {
+            while (pending.size() >= depth) write_oldest();  // the slot frame f is about to take must have been written
             rend.render();
             if (refine) {
                 const auto &st = rend.stats;
@@ -175,42 +444,20 @@ int main(int argc, char **argv) {
                 if (st.guided_samples) std::printf("  guided samples %ld", st.guided_samples);
                 std::printf("\n");
             }
-            if (!out.empty()) {
-                rend.download(args.has("raw") ? &rgba : nullptr, &rgba8);
-                char name[4096];
-                std::snprintf(name, sizeof(name), "%s_%04ld.ppm", out.c_str(), f);
-                if (std::FILE *fp = std::fopen(name, "wb")) {
-                    std::fprintf(fp, "P6\n%d %d\n255\n", width, height);
-                    for (size_t p = 0; p < (size_t)width * height; ++p) std::fwrite(&rgba8[p * 4], 1, 3, fp);
-                    std::fclose(fp);
-                } else {
-                    throw std::runtime_error(std::string("cannot write ") + name);
-                }
-                if (args.has("raw")) {
-                    std::snprintf(name, sizeof(name), "%s_%04ld.f32", out.c_str(), f);
-                    std::FILE *fp = std::fopen(name, "wb");
-                    if (!fp) throw std::runtime_error(std::string("cannot write ") + name);
-                    std::fwrite(rgba.data(), sizeof(float), rgba.size(), fp);
-                    std::fclose(fp);
-                }
-            }
-            if (orbit != 0.0) {  // rotate the camera about `origin` around world_up
-                float c[3] = {rend.camera.center.x - origin[0], rend.camera.center.y - origin[1], rend.camera.center.z - origin[2]};
-                float b[3] = {rend.camera.v_back.x, rend.camera.v_back.y, rend.camera.v_back.z};
-                rotate(c, axis, orbit);
-                rotate(b, axis, orbit);
-                rend.camera.center = {c[0] + origin[0], c[1] + origin[1], c[2] + origin[2]};
-                rend.camera.v_back = {b[0], b[1], b[2]};
-            }
+            if (!out.empty()) pending.emplace_back(f, rend.last_slot());
+            if (orbit != 0.0) orbit_step(rend.camera, orbit);
         }
-        rend.download(nullptr, nullptr);
+        while (!pending.empty()) write_oldest();
+        rend.sync_tree_streams();
+        const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
         if (args.has("save_tree") && tree.N > 0) {
             rend.sync_tree();
             tree.save_npz(args.get("save_tree", ""));
         }
         const double ms = rend.take_average_ms();
-        std::printf("%s: %ld frame(s) %dx%d, %.3f ms/frame on the device, %.1f Mrays/s\n", rend.get_backend(), frames, width, height, ms,
-                    ms > 0 ? (double)width * height / ms / 1e3 : 0.0);
+        std::printf("%s: %ld frame(s) %dx%d, %.3f ms per launch on the device, %.3f ms/frame wall (%d in flight%s), %.1f Mrays/s\n", rend.get_backend(), frames,
+                    width, height, ms, wall_ms / frames, refine ? 1 : rend.frames_in_flight, out.empty() ? "" : ", incl. download + file output",
+                    wall_ms > 0 ? (double)width * height * frames / wall_ms / 1e3 : 0.0);
         return 0;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "mnv_render: %s\n", e.what());

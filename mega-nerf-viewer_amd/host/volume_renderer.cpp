@@ -6,6 +6,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "npz.hpp"
 
@@ -45,8 +46,20 @@ struct DeviceBuffer {
 struct VolumeRenderer::Impl {
     N3Tree *tree = nullptr;
     long max_tree_capacity = 0;
-    hipStream_t stream = nullptr;
-    float *rgba = nullptr;
+    // Frames in flight.  The reference calls render_voxels once per frame on one stream (cuda_renderer.cpp:141-142); a single
+    // 1080p launch of the march ends in a tail of a few wavefronts finishing the longest rays (a third of the wave slots idle
+    // on average), so plain frames rotate over `slots` -- each with its own stream and frame buffers -- and the tail of frame k
+    // overlaps frames k+1, k+2.  Frames that refine the tree run one at a time on slot 0 (they mutate what the next one reads).
+    struct Slot {
+        hipStream_t stream = nullptr;
+        float *rgba = nullptr;
+        uint8_t *rgba8 = nullptr;
+    };
+    std::vector<Slot> slots;
+    int cur = 0;            // slot of the most recent render()
+    bool overlapped = false;  // plain frames may still be running on slots other than 0
+    hipStream_t stream = nullptr;  // = slots[0].stream: refinement, tree upload, accel rebuild
+    float *rgba = nullptr;         // = slots[cur]
     uint8_t *rgba8 = nullptr;
     int width = 0, height = 0;
     bool initial_resize = true;
@@ -64,17 +77,52 @@ struct VolumeRenderer::Impl {
     long reuse_total = 0;
     uint64_t frame = 0;
 
-    Impl() { hip_check(hipStreamCreate(&stream), "hipStreamCreate"); }
+    Impl() {
+        slots.resize(1);
+        hip_check(hipStreamCreate(&slots[0].stream), "hipStreamCreate");
+        stream = slots[0].stream;
+    }
     ~Impl() {
         free_frame();
         if (mlp) mnv_mlp_destroy(mlp);
-        if (stream) (void)hipStreamDestroy(stream);
+        for (Slot &s : slots)
+            if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    void sync_all() {
+        for (Slot &s : slots) hip_check(hipStreamSynchronize(s.stream), "hipStreamSynchronize");
+        overlapped = false;
     }
     void free_frame() {
-        if (rgba) (void)hipFree(rgba);
-        if (rgba8) (void)hipFree(rgba8);
+        for (Slot &s : slots) {
+            if (s.stream) (void)hipStreamSynchronize(s.stream);
+            if (s.rgba) (void)hipFree(s.rgba);
+            if (s.rgba8) (void)hipFree(s.rgba8);
+            s.rgba = nullptr;
+            s.rgba8 = nullptr;
+        }
         rgba = nullptr;
         rgba8 = nullptr;
+    }
+    // make `n` slots exist, each with a stream and frame buffers of the current size
+    void ensure_slots(int n) {
+        if (n < 1) n = 1;
+        while ((int)slots.size() < n) {
+            Slot s;
+            hip_check(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate");
+            slots.push_back(s);
+        }
+        for (int i = 0; i < n; ++i) {
+            Slot &s = slots[i];
+            if (!s.rgba && width > 0 && height > 0) {
+                hip_check(hipMalloc((void **)&s.rgba, (size_t)width * height * 4 * sizeof(float)), "hipMalloc(frame)");
+                hip_check(hipMalloc((void **)&s.rgba8, (size_t)width * height * 4), "hipMalloc(frame8)");
+            }
+        }
+    }
+    void use_slot(int i) {
+        cur = i;
+        rgba = slots[i].rgba;
+        rgba8 = slots[i].rgba8;
     }
     void fill_f32(float *p, size_t n, float v) {
         uint32_t bits;
@@ -189,6 +237,7 @@ VolumeRenderer::VolumeRenderer() : impl_(std::make_unique<Impl>()) {}
 VolumeRenderer::~VolumeRenderer() {}
 
 void VolumeRenderer::set(N3Tree &tree, long max_tree_capacity) {
+    impl_->sync_all();
     tree.move_to_device(max_tree_capacity, true, true, impl_->stream);
     impl_->tree = &tree;
     impl_->max_tree_capacity = max_tree_capacity;
@@ -283,17 +332,34 @@ void VolumeRenderer::resize(int width, int height) {
     impl_->free_frame();
     impl_->width = width;
     impl_->height = height;
-    hip_check(hipMalloc((void **)&impl_->rgba, (size_t)width * height * 4 * sizeof(float)), "hipMalloc(frame)");
-    hip_check(hipMalloc((void **)&impl_->rgba8, (size_t)width * height * 4), "hipMalloc(frame8)");
+    impl_->ensure_slots(1);
+    impl_->use_slot(0);
 }
 
 void VolumeRenderer::render() {
     Impl &I = *impl_;
-    if (!I.rgba) resize(camera.width, camera.height);
+    if (!I.slots[0].rgba) resize(camera.width, camera.height);
     camera._update();
     const mnv_camera cv = camera.c_abi();
     const mnv_rect full = {0, 0, I.width, I.height};
     stats = FrameStats();
+    {
+        // a plain frame of a tree with a current accel takes the next slot; everything else runs alone on slot 0
+        const bool refine_now = I.mlp != nullptr && (options.use_splitting || options.use_guided_sampling);
+        const bool plain = !refine_now && I.tree != nullptr && I.tree->N > 0 && I.tree->device.accel && !I.accel_stale;
+        if (plain && frames_in_flight > 1) {
+            I.ensure_slots(frames_in_flight);
+            I.use_slot((I.cur + 1) % frames_in_flight);
+            I.overlapped = true;
+            mnv_check(mnv_render_voxels_accel(I.tree->device.accel, &cv, options.c_abi(), full, I.rgba, I.rgba8, I.slots[I.cur].stream), "mnv_render_voxels_accel");
+            stats.used_accel = true;
+            stats.capacity = I.tree->capacity;
+            ++I.frame;
+            return;
+        }
+        if (I.overlapped) I.sync_all();
+        I.use_slot(0);
+    }
     if (I.tree == nullptr || I.tree->N <= 0) {
         mnv_tree_view empty = {};  // N == 0: background only (renderer_kernel.cu:266)
         mnv_check(mnv_render_voxels(&empty, &cv, options.c_abi(), full, I.rgba, I.rgba8, nullptr, nullptr, nullptr, 0, I.stream), "mnv_render_voxels");
@@ -417,19 +483,29 @@ void VolumeRenderer::render() {
 const char *VolumeRenderer::get_backend() { return "HIP gfx950"; }
 
 void VolumeRenderer::download(std::vector<float> *rgba, std::vector<uint8_t> *rgba8) {
+    download_slot(impl_->cur, rgba, rgba8);
+}
+
+int VolumeRenderer::last_slot() const { return impl_->cur; }
+
+void VolumeRenderer::download_slot(int slot, std::vector<float> *rgba, std::vector<uint8_t> *rgba8) {
+    if (slot < 0 || slot >= (int)impl_->slots.size() || !impl_->slots[slot].rgba) throw std::runtime_error("download_slot: no such frame slot");
     const size_t n = (size_t)impl_->width * impl_->height * 4;
-    hip_check(hipStreamSynchronize(impl_->stream), "render");
+    hip_check(hipStreamSynchronize(impl_->slots[slot].stream), "render");
     if (rgba) {
         rgba->resize(n);
-        hip_check(hipMemcpy(rgba->data(), impl_->rgba, n * sizeof(float), hipMemcpyDeviceToHost), "download rgba");
+        hip_check(hipMemcpy(rgba->data(), impl_->slots[slot].rgba, n * sizeof(float), hipMemcpyDeviceToHost), "download rgba");
     }
     if (rgba8) {
         rgba8->resize(n);
-        hip_check(hipMemcpy(rgba8->data(), impl_->rgba8, n, hipMemcpyDeviceToHost), "download rgba8");
+        hip_check(hipMemcpy(rgba8->data(), impl_->slots[slot].rgba8, n, hipMemcpyDeviceToHost), "download rgba8");
     }
 }
 
+void VolumeRenderer::sync_tree_streams() { impl_->sync_all(); }
+
 void VolumeRenderer::sync_tree() {
+    impl_->sync_all();
     if (impl_->tree) impl_->tree->copy_from_device(impl_->stream);
 }
 

@@ -45,6 +45,15 @@ struct VolumeRenderer {
 
     // Wait for the last render() and copy the frame to the host ([height][width][4]).
     void download(std::vector<float> *rgba, std::vector<uint8_t> *rgba8);
+    // Frames in flight: plain frames (no refinement, accel current) rotate over this many slots, each with its own HIP stream
+    // and frame buffers, so that the tail of one launch overlaps the next launches (1 = the reference's one-stream behaviour).
+    // render() returns at once; last_slot() names the slot it used and download_slot() waits for that slot's frame only --
+    // a caller that wants overlap downloads frame k after it has issued frames k+1 .. k+frames_in_flight-1.
+    int frames_in_flight = 3;
+    int last_slot() const;
+    void download_slot(int slot, std::vector<float> *rgba, std::vector<uint8_t> *rgba8);
+    // Wait for every frame in flight.
+    void sync_tree_streams();
     // Device pointers of the current frame (valid until the next resize()).
     const float *device_rgba() const;
     const uint8_t *device_rgba8() const;

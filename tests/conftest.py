@@ -13,6 +13,24 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_report_header(config):
+    """Say which binaries the run uses: a missing live reference build or a stale libmnv.so is a reported condition, not a
+    silent skip (tests that need oracle/_ref still skip individually; the committed goldens hold the pin without it)."""
+    try:
+        import __graft_entry__ as g
+
+        st = g.build_state()
+        return [f"mnv build state: libmnv.so: {st['libmnv']}; oracle: {st['oracle']}",
+                f"mnv live reference build: {st['live_reference_build']}"]
+    except Exception as e:  # the header must never break collection
+        return [f"mnv build state: unavailable ({e})"]
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    ref = os.path.join(ROOT, "oracle", "_ref", "libmnv_ref_gfx950.so")
+    terminalreporter.write_line(f"mnv live reference build: {'present' if os.path.exists(ref) else 'ABSENT (tests against oracle/_ref were skipped; goldens from it are committed)'}")
+
+
 @pytest.fixture(scope="session")
 def mnv():
     """The product binding; builds libmnv.so / the oracle on first use if they are missing."""

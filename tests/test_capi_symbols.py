@@ -51,3 +51,16 @@ def test_device_entry_points_fail_loudly_without_a_gpu(mnv):
     with pytest.raises(mnv.MnvError) as e:
         t.move_to_device()
     assert e.value.code == mnv.MNV_E_NO_DEVICE
+
+
+def test_comm_entry_points_validate_without_a_gpu(mnv):
+    """mnv_comm_* / mnv_gather_tiles reject bad arguments before they touch RCCL or a device."""
+    lib = mnv.lib()
+    assert lib.mnv_gather_tiles(None, None, None, 16, 0, None) == mnv.MNV_E_INVALID
+    assert lib.mnv_comm_get_unique_id(None) == mnv.MNV_E_INVALID
+    h = C.c_void_p()
+    assert lib.mnv_comm_init_rank(None, 2, 0, C.byref(h)) == mnv.MNV_E_INVALID
+    buf = C.create_string_buffer(128)
+    assert lib.mnv_comm_init_rank(buf, 2, 2, C.byref(h)) == mnv.MNV_E_INVALID      # rank outside the world
+    assert lib.mnv_comm_rank(None) == -1 and lib.mnv_comm_world(None) == 0
+    lib.mnv_comm_destroy(None)

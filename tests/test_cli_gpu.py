@@ -47,6 +47,41 @@ def test_mnv_render_cli_matches_oracle(mnv, orc, torch_gpu, tmp_path):
     assert np.array_equal(rgb, ref["rgba8"][..., :3])
 
 
+def test_mnv_render_multi_gpu_mode_with_one_rank(mnv, orc, torch_gpu, tmp_path):
+    """`mnv_render --gpus 1`: the multi-GPU mode of the C++ host (one forked process per GPU, interleaved macro-tile partition,
+    one batched launch per rank and 64 frames, RCCL gather through mnv_gather_tiles, un-permute on rank 0) run with the one rank a
+    one-GPU box allows.  70 orbit frames = two batches through the ring; every file equals the single-GPU path's, byte for byte,
+    and frame 0 equals the oracle."""
+    tree = cases.make_tree(mnv, cases.CASES["sh9_d7_aniso"]["tree"])
+    npz = str(tmp_path / "scene.npz")
+    tree.save_npz(npz)
+    w, h, frames = 200, 144, 70
+    center, back = (-3.0, 2.0, 5.0), (-0.45, 0.3, 0.75)
+    common = [EXE, npz, "-w", str(w), "-h", str(h), "--fx", "450", "--bg", "0.25", "--center", ",".join(map(str, center)),
+              "--back", ",".join(map(str, back)), "--raw", "--frames", str(frames), "--orbit", "3.5"]
+    one, dist = str(tmp_path / "one"), str(tmp_path / "dist")
+    r1 = subprocess.run(common + ["--out", one], capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr + r1.stdout
+    r2 = subprocess.run(common + ["--out", dist, "--gpus", "1"], capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr + r2.stdout
+    assert "x 1 (RCCL" in r2.stdout and "macro tiles" in r2.stdout
+    for f in range(frames):
+        for ext in ("f32", "ppm"):
+            a = open(f"{one}_{f:04d}.{ext}", "rb").read()
+            b = open(f"{dist}_{f:04d}.{ext}", "rb").read()
+            assert a == b, (f, ext)
+    cam = mnv.Camera(w, h, 450.0).set_pose(center, back)
+    opt = mnv.RenderOptions.cli_defaults()
+    opt.background_brightness = 0.25
+    opt.basis_minmax[0], opt.basis_minmax[1] = 0, 8
+    ref = orc.render(orc.tree_from_view(tree.host_view()), cam.c, opt)
+    got = np.fromfile(dist + "_0000.f32", dtype=np.float32).reshape(h, w, 4)
+    assert np.array_equal(cases.bits(got), cases.bits(ref["rgba"]))
+    # a rank that fails takes the run down with a non-zero status instead of hanging its peers
+    r3 = subprocess.run([EXE, str(tmp_path / "missing.npz"), "--gpus", "1"], capture_output=True, text=True, timeout=120)
+    assert r3.returncode != 0 and "rank 0" in r3.stderr
+
+
 def test_mnv_render_cli_errors(tmp_path, mnv, torch_gpu):
     r = subprocess.run([EXE], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stdout

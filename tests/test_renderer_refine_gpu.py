@@ -341,3 +341,46 @@ def test_guided_sampling_frame_matches_reference_tensor_ops(mnv, torch_gpu, extr
     st3 = r.render()
     assert st3["guided_samples"] > 0 and np.array_equal(cases.bits(r.download()), cases.bits(f2))
     assert np.abs(f2 - frame).max() < 1e-4
+
+
+def test_plain_frames_in_flight_match_the_oracle(mnv, orc, torch_gpu):
+    """VolumeRenderer::frames_in_flight: plain frames rotate over slots with their own streams and buffers
+    (mnv_renderer_set_frames_in_flight / _last_slot / _download_slot).  Seven poses through three slots, each downloaded
+    only after the following frames were issued; every frame equals the oracle's bit for bit, and a renderer with one
+    frame in flight gives the same frames."""
+    spec = cases.CASES["sh9_d7_aniso"]
+    tree = cases.make_tree(mnv, spec["tree"])
+    ot = orc.tree_from_view(tree.host_view())
+    w, h, fx = 320, 200, 420.0
+    poses = [((-3.0 + 0.4 * i, 2.0 - 0.3 * i, 4.0 + 0.2 * i), (-0.5 + 0.05 * i, 0.3, 0.75)) for i in range(7)]
+
+    def run(in_flight):
+        r = mnv.Renderer()
+        r.resize(w, h)
+        r.set(tree, tree.capacity)
+        r.set_frames_in_flight(in_flight)
+        opt = r.options
+        opt.background_brightness = 0.25
+        got, pending = {}, []
+        for i, (center, back) in enumerate(poses):
+            if len(pending) >= in_flight:
+                j, slot = pending.pop(0)
+                got[j] = r.download_slot(slot, want_rgba8=True)
+            r.set_camera(center, back, fx=fx)
+            st = r.render()
+            assert st["used_accel"]
+            pending.append((i, r.last_slot()))
+        slots_used = {s for _, s in pending}
+        for j, slot in pending:
+            got[j] = r.download_slot(slot, want_rgba8=True)
+        return got, slots_used, mnv.RenderOptions.from_buffer_copy(opt)   # the struct lives inside the renderer
+
+    got3, slots3, opt = run(3)
+    got1, slots1, _ = run(1)
+    assert slots3 == {0, 1, 2} and slots1 == {0}
+    for i, (center, back) in enumerate(poses):
+        cam = mnv.Camera(w, h, fx).set_pose(center, back)
+        ref = orc.render(ot, cam.c, opt, want_rgba8=True)
+        assert np.array_equal(got3[i][0].view(np.uint32), ref["rgba"].view(np.uint32)), i
+        assert np.array_equal(got3[i][1], ref["rgba8"]), i
+        assert np.array_equal(got1[i][0].view(np.uint32), got3[i][0].view(np.uint32)), i
