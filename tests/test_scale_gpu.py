@@ -1,0 +1,154 @@
+"""BASELINE.json configs[3] and configs[4] at their stated sizes on ONE MI355X (the driver-run suite has no 8-GPU box):
+
+* cfg4 -- the merged-octree stand-in at 3840x2160: the tuned kernel equals the oracle on the full 8.3 M-pixel frame, and the
+  eight ranks of the multi-GPU run (interleaved 64x24 macro tiles, root-relieving deal, batched launch per rank, gather table,
+  mnv_assemble_tiles) are executed one after the other on this GPU and reassemble the same frames byte for byte;
+* cfg5 -- dynamic refinement and guided sampling on the 1.5 M-chunk depth-10 SH9 tree at 1920x1080 through VolumeRenderer
+  (mnv_renderer_*): the tree stays a valid tree, the packed accel follows it (tuned kernel == reference-layout kernel on the
+  grown tree), and the guided-sampling frame equals the reference's tensor-op formulation evaluated by torch.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+import mlp_cases
+from test_renderer_refine_gpu import check_tree_links, make_grid
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cfg4_merged_octree_4k_full_frame_and_world8_reassembly(mnv, orc, torch_gpu):
+    torch = torch_gpu
+    from mega_nerf_viewer_amd.multigpu import TilePartition
+
+    W, H, world, tw, th, period = 3840, 2160, 8, 64, 24, 8
+    tree = cases.make_tree(mnv, cases.CFG3_TREE)
+    assert tree.capacity > 2_000_000
+    ot = orc.tree_from_view(tree.host_view())
+    tree.move_to_device()
+    opt = mnv.RenderOptions.cli_defaults()
+    cams = [cases.cfg3_camera(mnv, pose, W, H, fx=2800.0) for pose in (5, 11)]
+    refs = [orc.render(ot, c.c, opt, want_rgba8=True) for c in cams]
+    assert refs[0]["counters"].rays == W * H and refs[0]["counters"].rays_hit > 0.4 * W * H
+
+    # the whole 4K frame on the tuned kernel: float and RGBA8 equal the oracle's
+    out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    out8 = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+    mnv.render_voxels_accel(tree.accel, cams[0], opt, rgba=out, rgba8=out8)
+    torch.cuda.synchronize()
+    assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(refs[0]["rgba"]))
+    assert np.array_equal(out8.cpu().numpy(), refs[0]["rgba8"])
+
+    # the eight ranks' launches, one after the other: two frames per launch into each rank's compact buffer, the buffers placed
+    # in the table the RCCL gather fills, un-permuted by the root's kernel
+    part = TilePartition(W, H, world, tw, th, period)
+    n_macro = part.n_macro
+    counts = [mnv.partition_local_tiles((0, 0, W, H), r, world, tw, th, period) for r in range(world)]
+    assert sum(counts) == n_macro and counts[0] < counts[1] and max(counts) == part.j_max       # rank 0 renders less (root relief)
+    table = torch.zeros((world, len(cams), part.j_max, th, tw, 4), dtype=torch.uint8, device="cuda")
+    for r in range(world):
+        mnv.render_voxels_accel_batch(tree.accel, cams, opt, part=part.part(r), rgba8=table[r])
+    frames = torch.zeros((len(cams), H, W, 4), dtype=torch.uint8, device="cuda")
+    mnv.assemble_tiles(table, frames, W, H, world, tw, th, n_frames=len(cams), root_period=period)
+    torch.cuda.synchronize()
+    got = frames.cpu().numpy()
+    for f in range(len(cams)):
+        assert np.array_equal(got[f], refs[f]["rgba8"]), f
+    # size-independent properties of the full frame
+    a = refs[0]["rgba"][..., 3]
+    assert a.min() >= 0.0 and a.max() <= 1.0 and np.isfinite(refs[0]["rgba"]).all()
+
+
+def _renderer_on_cfg2(mnv, extra_capacity, w=1920, h=1080, **opt_over):
+    tree = cases.make_tree(mnv, cases.CFG2_TREE)
+    v = tree.host_view()
+    desc = mnv.mlp_desc(n_clusters=6, pos_octaves=4, dir_octaves=2, need_viewdir=False, hidden_width=64, hidden_layers=2, out_dim=v.data_dim + 1)
+    params = mlp_cases.make_params(mnv, desc, seed=21)
+    r = mnv.Renderer()
+    r.resize(w, h)
+    r.set(tree, v.capacity + extra_capacity)
+    r.set_model(desc, params, make_grid(mnv))
+    r.set_seed(7)
+    for k, val in opt_over.items():
+        setattr(r.options, k, val)
+    return r, tree, desc, params
+
+
+def _pose(mnv, r, pose, w=1920, h=1080):
+    cam = cases.cfg2_camera(mnv, pose, w, h, 1600.0)
+    m = cam.c2w
+    r.set_camera(tuple(m[9:12]), tuple(m[6:9]), fx=1600.0)
+    return cam
+
+
+def test_cfg5_splitting_at_scale_keeps_a_valid_tree_and_the_accel_follows(mnv, torch_gpu):
+    torch = torch_gpu
+    # room to grow and capacity <= 3/4 max: camera changes do not trigger visit tracking, every frame runs on the tuned kernel
+    r, tree, desc, params = _renderer_on_cfg2(mnv, 1_000_000, use_splitting=True, max_depth=12, split_batch_size=4096, samples_per_corner=8)
+    cap0 = tree.capacity
+    assert cap0 == 1_499_569
+    caps, added = [], 0
+    for f in range(6):
+        _pose(mnv, r, f % 3)
+        st = r.render()
+        caps.append(st["capacity"])
+        added += st["added"]
+        assert st["used_accel"] == 1 and st["track_visit"] == 0 and st["pruned"] == 0
+        assert st["split_candidates"] > 0 and 0 < st["added"] <= 4096
+    assert caps == sorted(caps) and caps[-1] == cap0 + added and added >= 6 * 2048
+    frame = r.download()
+    assert np.isfinite(frame).all() and frame[..., 3].min() >= 0.0 and frame[..., 3].max() <= 1.0
+    r.sync_tree()
+    data, child, parent = tree.host_arrays()
+    assert child.shape[0] == caps[-1]
+    check_tree_links(child, parent, caps[-1])
+    # the packed accel was patched six times (mnv_accel_refresh): it still describes the tree the reference-layout kernel reads
+    cam = cases.cfg2_camera(mnv, 1)
+    opt = mnv.RenderOptions()
+    C.memmove(C.byref(opt), C.byref(r.options), C.sizeof(opt))
+    a = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    mnv.render_voxels(tree.device_view(), cam, opt, rgba=a)
+    mnv.render_voxels_accel(tree.accel, cam, opt, rgba=b)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def test_cfg5_guided_sampling_frame_at_scale_matches_tensor_ops(mnv, torch_gpu):
+    """use_guided_sampling on the 1.5 M-chunk tree at 1920x1080 (about 9 M samples through the networks per frame): the frame
+    VolumeRenderer produces equals sample march -> cumsum / boolean-mask compaction (cuda_renderer.cpp:116-121, by torch) ->
+    networks -> CSR composite, bit for bit."""
+    torch = torch_gpu
+    max_g, dim = 64, 4
+    r, tree, desc, params = _renderer_on_cfg2(mnv, 1_000_000, use_guided_sampling=True, max_guided_samples=max_g)
+    cam = _pose(mnv, r, 2)
+    st = r.render()
+    frame = r.download()
+    assert st["guided_samples"] > 5_000_000 and st["used_accel"] == 1
+    opt = mnv.RenderOptions()
+    C.memmove(C.byref(opt), C.byref(r.options), C.sizeof(opt))
+    dv = tree.device_view()
+    # the renderer's camera went through Camera::_update(); rebuild the same block the way its first render() did
+    cam = mnv.Camera(1920, 1080, 1600.0).set_pose(tuple(cam.c2w[9:12]), tuple(cam.c2w[6:9]))
+    n_px = 1920 * 1080
+    num = torch.zeros(n_px, dtype=torch.int16, device="cuda")
+    guided = torch.zeros((n_px, max_g, dim), dtype=torch.float32, device="cuda")
+    guided[:, :, 0] = -1
+    clusters = torch.zeros((n_px, max_g), dtype=torch.int16, device="cuda")
+    mnv.get_samples_from_voxels(dv, cam, opt, num, guided, clusters, make_grid(mnv))
+    offsets = torch.cumsum(num, 0)
+    flat = guided.view(-1, dim)
+    mask = flat[:, 0] >= 0
+    valid, valid_clusters = flat[mask], clusters.view(-1)[mask]
+    total = valid.shape[0]
+    assert total == st["guided_samples"] == int(offsets[-1])
+    values = torch.zeros((total, tree.host_view().data_dim + 1), dtype=torch.float32, device="cuda")
+    mnv.Mlp(desc, params).query(valid_clusters, valid[:, 1:].contiguous(), values)
+    out = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda")
+    mnv.render_nerf_results(dv, cam, opt, values, valid[:, 0].contiguous(), offsets, rgba=out)
+    torch.cuda.synchronize()
+    assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(frame))
+    a = frame[..., 3]
+    assert np.isfinite(frame).all() and a.min() >= 0.0 and a.max() <= 1.0 + 1e-6
