@@ -22,7 +22,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmnv.so")
+LIB_PATH = os.environ.get("MNV_LIB_PATH") or os.path.join(_HERE, "libmnv.so")   # MNV_LIB_PATH: A/B builds of the library (tools/build_variant.sh)
 
 MNV_OK = 0
 MNV_E_INVALID = -1

@@ -339,7 +339,15 @@ template <int BASIS, int BLOCK, int MODE /* 0 plain, 1 statistics, 2 refinement 
 #ifndef MNV_MIN_WAVES
 #define MNV_MIN_WAVES 8  // register budget for 8 waves per SIMD: the few spills land in the ray set-up (A/B in DESIGN.md)
 #endif
-__global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES : MNV_MIN_WAVES) void march_accel_kernel(const AccelLaunch K) {
+// A/B knobs (tools/build_variant.sh): explicit register budgets on top of the launch bounds
+#if defined(MNV_NUM_VGPR) && defined(MNV_NUM_SGPR)
+#define MNV_EXTRA_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(MNV_NUM_VGPR), amdgpu_num_sgpr(MNV_NUM_SGPR)))
+#elif defined(MNV_NUM_VGPR)
+#define MNV_EXTRA_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(MNV_NUM_VGPR)))
+#else
+#define MNV_EXTRA_KERNEL_ATTR
+#endif
+__global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES : MNV_MIN_WAVES) MNV_EXTRA_KERNEL_ATTR void march_accel_kernel(const AccelLaunch K) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     uint64_t *s_exp = reinterpret_cast<uint64_t *>(s_mem);  // 32 x 8 B
     uint32_t *s_map = s_mem + 64;                            // BLOCK words: dense-sample rank -> lane, per wavefront

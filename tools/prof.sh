@@ -6,7 +6,7 @@ TAG=${1:-prof}; shift || true
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
-ARGS="--steps 4 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 4 --warmup 1 --no-cpu-baseline --frame-streams 0 $*"   # --frame-streams 0: no secondary per-frame launches of the same kernel name in the profile
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/trace.log" 2>&1
 pmc() { # name counters...
   local name=$1; shift

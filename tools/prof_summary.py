@@ -18,15 +18,17 @@ for f in find("trace/**/*kernel_stats.csv"):
     with open(f) as fh:
         for row in csv.DictReader(fh):
             print({k: row[k] for k in row if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
-print("== kernel trace: register / LDS usage of the march kernel ==")
-for f in find("trace/**/*kernel_trace.csv"):
-    with open(f) as fh:
-        seen = set()
-        for row in csv.DictReader(fh):
-            n = row.get("Kernel_Name", "")
-            if KEY in n and n not in seen:
-                seen.add(n)
-                print({k: row[k] for k in row if k in ("Kernel_Name", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size", "Workgroup_Size", "Grid_Size")})
+print("== register / LDS / scratch usage of the march kernels: code-object metadata of libmnv.so (tools/kernel_resources.py; rocprofv3's VGPR_Count / LDS_Block_Size columns are wrong for these kernels on this stack) ==")
+try:
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import kernel_resources
+
+    for k in kernel_resources.kernels():
+        if any(t in k["kernel"] for t in ("march_accel_kernel<9, 256, 0>", "march_accel_kernel<9, 256, 2>", "march_accel_kernel<9, 256, 3>", "march_ref_layout_kernel<9>")):
+            print(k)
+    print("dynamic LDS of march_accel_kernel<9,256,*>: 256 + 1024 + (9 + 2) * 1024 + 2048 = 14592 bytes per workgroup (launch_accel)")
+except Exception as e:  # noqa: BLE001
+    print("unavailable:", e)
 print("== kernel trace: duration of every dispatch of the march kernel, in order (ns; the first one runs cold: page tables, caches) ==")
 for f in find("trace/**/*kernel_trace.csv"):
     with open(f) as fh:
