@@ -461,6 +461,22 @@ void mnv_mlp_destroy(mnv_mlp *mlp);
 int mnv_query_submodules(mnv_mlp *mlp, const int16_t *cluster_indices, const float *samples, int32_t samples_stride,
                          int64_t n, float *results, int32_t result_stride, void *hip_stream);
 
+/*
+ * The guided-sampling frame as ONE kernel (BASELINE.json configs[4]): what the reference does with get_samples_from_voxels,
+ * a cumsum / boolean-mask compaction, query_submodules and render_nerf_results (src/renderer/cuda_renderer.cpp:107-139) --
+ * and this library's own four entry points above do the same way -- happens inside the march: every lane marches its ray on
+ * the packed accel, the wavefront evaluates the sub-module network for one pending sample per lane on the matrix cores
+ * (weights of the batch's cluster as the MFMA A operand), and each lane composites its samples in ray order.  No sample
+ * buffer exists.  The frame is bit-identical to mnv_get_samples_from_voxels_accel -> mnv_compact_guided_samples ->
+ * mnv_query_submodules -> mnv_render_nerf_results (same march, same MFMA sequence, same composite arithmetic).
+ * Restrictions (MNV_E_UNSUPPORTED otherwise; use the four-step path): 64-wide networks, RGBA / SH1/4/9/16 trees, no
+ * render_depth, no refinement trackers or visit marks in the same frame.
+ *   sample_counter  optional device counter: += network evaluations (= what the four-step path reports as guided samples)
+ */
+int mnv_render_guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, const mnv_mlp *mlp,
+                            const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, unsigned long long *sample_counter,
+                            void *hip_stream);
+
 /* A HIP stream whose kernels run on all but `reserve_cus` compute units (hipExtStreamCreateWithCUMask; the units are taken
  * evenly from the XCDs, and from their shader engines when reserve_cus is a multiple of 32).  The tuned kernel is persistent and
  * fills every wave slot of the units it may use, so kernels of other streams -- the RCCL channel workgroups of the multi-GPU
@@ -512,6 +528,8 @@ typedef struct mnv_renderer_stats {  /* what the reference prints per frame */
     int32_t pruned;                        /* prune_tree: reclaimed chunks, -1 = nothing to prune, 0 = did not run */
     int64_t guided_samples;                /* rows sent to the networks by guided sampling */
     int64_t capacity;                      /* chunks in use after the frame */
+    int32_t fused;                         /* the guided-sampling frame ran as one kernel (mnv_render_guided_fused) */
+    int32_t reserved;
 } mnv_renderer_stats;
 int mnv_renderer_create(mnv_renderer **out);
 void mnv_renderer_destroy(mnv_renderer *r);
@@ -542,6 +560,9 @@ int mnv_renderer_download(mnv_renderer *r, float *rgba_host, uint8_t *rgba8_host
  * mnv_renderer_download_slot waits for that slot's frame only.  count = 1 restores the one-stream behaviour.
  */
 int mnv_renderer_set_frames_in_flight(mnv_renderer *r, int32_t count);
+/* VolumeRenderer::use_fused_guided (default on): guided-sampling frames that need nothing but the picture run as one kernel;
+ * off = always the four steps of cuda_renderer.cpp:107-139 (sample march, compaction, networks, composite) */
+int mnv_renderer_set_fused_guided(mnv_renderer *r, int enable);
 int32_t mnv_renderer_last_slot(const mnv_renderer *r);
 int mnv_renderer_download_slot(mnv_renderer *r, int32_t slot, float *rgba_host, uint8_t *rgba8_host);
 /* copy the (refined) device tree back into the mnv_n3tree's host arrays */

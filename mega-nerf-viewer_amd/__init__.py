@@ -133,7 +133,7 @@ class MlpDesc(C.Structure):
 class RendererStats(C.Structure):
     _fields_ = [("track_visit", C.c_int32), ("used_accel", C.c_int32), ("full", C.c_int32), ("split_candidates", C.c_int32),
                 ("added", C.c_int32), ("sample_candidates", C.c_int32), ("resampled", C.c_int32), ("pruned", C.c_int32),
-                ("guided_samples", C.c_int64), ("capacity", C.c_int64)]
+                ("guided_samples", C.c_int64), ("capacity", C.c_int64), ("fused", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -219,6 +219,8 @@ _SIGNATURES = {
                                               C.c_void_p, C.POINTER(ClusterGrid), C.c_void_p]),
     "mnv_get_samples_from_voxels_accel": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(ClusterGrid), C.c_void_p]),
+    "mnv_render_guided_fused": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.c_void_p, C.POINTER(ClusterGrid),
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_render_nerf_results": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
                                           C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_add_children_and_generate_samples": (C.c_int, [C.POINTER(TreeEdit), C.POINTER(RenderOptions), C.c_void_p, C.c_int32, C.c_void_p,
@@ -253,6 +255,7 @@ _SIGNATURES = {
     "mnv_renderer_sync_tree": (C.c_int, [C.c_void_p]),
     "mnv_renderer_set_frames_in_flight": (C.c_int, [C.c_void_p, C.c_int32]),
     "mnv_renderer_last_slot": (C.c_int32, [C.c_void_p]),
+    "mnv_renderer_set_fused_guided": (C.c_int, [C.c_void_p, C.c_int]),
     "mnv_renderer_download_slot": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mnv_set_timing": (None, [C.c_int]),
     "mnv_take_timing": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
@@ -607,6 +610,16 @@ def render_nerf_results(tree_view: TreeView, cam: Camera, opt: RenderOptions, sa
                                          C.c_void_p(stream)))
 
 
+def render_guided_fused(accel: int, cam: Camera, opt: RenderOptions, mlp: "Mlp", grid: ClusterGrid, tile=None, rgba=None, rgba8=None,
+                        sample_counter=None, stream: int = 0) -> None:
+    """The guided-sampling frame as one kernel (mnv_render_guided_fused).  `sample_counter`: optional device int64 tensor [1],
+    incremented by the number of network evaluations."""
+    if tile is None:
+        tile = (0, 0, cam.width, cam.height)
+    _check(lib().mnv_render_guided_fused(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), mlp._h, C.byref(grid), _ptr(rgba), _ptr(rgba8),
+                                         _ptr(sample_counter), C.c_void_p(stream)))
+
+
 def tree_edit(child, parent, offset, scale, capacity: int) -> TreeEdit:
     e = TreeEdit()
     e.child, e.parent = _ptr(child), _ptr(parent)
@@ -776,6 +789,9 @@ class Renderer:
 
     def set_frames_in_flight(self, count: int) -> None:
         _check(lib().mnv_renderer_set_frames_in_flight(self._h, int(count)))
+
+    def set_fused_guided(self, enable: bool) -> None:
+        _check(lib().mnv_renderer_set_fused_guided(self._h, int(enable)))
 
     def last_slot(self) -> int:
         return int(lib().mnv_renderer_last_slot(self._h))

@@ -1,0 +1,508 @@
+// mnv_guided_fused.h -- the guided-sampling frame as ONE kernel (BASELINE.json configs[4]: "per-sample tiny-MLP fused into
+// the HIP march kernel").  Included by mnv_march_accel.hip (it shares AccelLaunch, the ray queues and the launch slots).
+//
+// What the reference does with four steps and three global buffers per frame (src/renderer/cuda_renderer.cpp:107-139):
+//     get_samples_from_voxels   rt_core.cuh:418-576     every dense march step emits (z, world xyz[, dir][, embedding])
+//     cumsum + boolean masks    cuda_renderer.cpp:116-121  compaction of the [rays][max_guided_samples] buffer
+//     query_submodules          cuda_renderer.cpp:165-203  per-cluster network over the compacted samples
+//     render_nerf_results       rt_core.cuh:334-416     CSR composite of the network outputs along every ray
+// happens here inside one persistent wavefront per 8x8-pixel tile, and no sample ever reaches global memory:
+//   * every lane marches its ray on the packed accel (same traversal and arithmetic as march_accel_kernel).  The composite of
+//     sample i needs z_{i+1} (rt_core.cuh:358-362), so a lane holds its newest sample back in registers and releases the
+//     previous one -- now complete with its delta z, or flagged as the ray's last -- into a per-wavefront pool in LDS (a ring
+//     of 128 entries: world position, delta z, owner lane, cluster, and the pool slot of the owner's next sample);
+//   * when the pool holds 64 samples (or nothing more can arrive), the wavefront runs the network on the matrix cores for the
+//     pool's first 64 entries (the leading run that shares a cluster): lane j encodes entry j into column j of the MFMA B
+//     operand through a 4 KB LDS tile; the weight fragments of that cluster are the A operand, read from global memory
+//     (L2-resident, 16 KB for the 64x2 network) one layer ahead of their use -- the identical v_mfma_f32_16x16x32_f16 sequence
+//     as mlp_forward_kernel, so the outputs equal mnv_query_submodules' bit for bit;
+//   * the outputs cross to LDS ([feature][column]); lane j turns column j into the sample's transmittance factor and the three
+//     colour denominators (render_nerf_results' arithmetic, SH basis of the OWNING ray read from LDS), and every owner then
+//     walks the chain of its samples in this pass in ray order and accumulates weight / denominator: frames equal the
+//     four-kernel path's bit for bit (tests/test_guided_fused_gpu.py), which remains the checker and the path for frames that
+//     also track refinement.
+// Lanes never wait for the network: a ray with many samples does not hold back its tile's passes (one sample per lane and pass
+// -- the first version -- filled 23 of 64 columns on average: passes per tile = samples of its longest ray).
+#pragma once
+
+#include "mnv_mlp.h"
+
+#pragma clang fp contract(off)
+
+namespace mnv {
+
+struct FusedGuided {
+    MlpShape S;
+    const uint16_t *frags;       // [n_clusters][frag_halfs]
+    const float *biases;         // [n_clusters][bias_floats]
+    const uint16_t *embeddings;  // [n_clusters][n_embeddings][embedding_dim]
+    int32_t grid_dim[2];
+    float min_position[3], range[3];
+    int32_t max_guided_samples, appearance_embedding;
+    int32_t batch_min;           // run the network once this many samples wait in a wavefront's pool (1 .. 64)
+    unsigned long long *sample_counter;  // += samples evaluated (one atomic per wavefront)
+    int32_t diag;                        // MNV_FUSED_DIAG: sample_counter[1] += network passes, [2] += march iterations
+};
+
+// LDS of one 256-thread workgroup: exp table (256 B) | top-of-tree grid ((2^lds_level)^3 words) | per-ray constants
+// [NB + 3][256] floats (SH basis, view direction) | per wavefront: network tile of 16 * mt_out features x 64 columns (the first
+// 4 KB double as the encode tile), sample pool 6 x 128 words, per-column results 4 x 64 floats
+constexpr int kPool = 128;  // ring capacity: a pass is due at 64 entries and one march step adds at most 64
+__host__ __device__ inline size_t fused_wave_words(int mt_out) { return (size_t)(mt_out * 16 > 16 ? mt_out * 16 : 16) * 64 + 6 * kPool + 4 * 64; }
+__host__ __device__ inline size_t fused_lds_bytes(int nb, int lds_level, int mt_out) {
+    return 256 + ((size_t)4 << (3 * lds_level)) + (size_t)(nb + 3) * 256 * 4 + 4 * fused_wave_words(mt_out) * 4;
+}
+
+#ifndef MNV_FUSED_WAVES
+#define MNV_FUSED_WAVES 2  // workgroups per CU = wavefronts per SIMD: 256 VGPRs, no spills (3: 168 VGPRs and ~80 spilled values; A/B in DESIGN.md)
+#endif
+template <int BASIS, int NKK0 /* 32-feature K tiles of the encoded input: 1 or 2 */>
+__global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(const AccelLaunch K, const FusedGuided F) {
+    constexpr int BLOCK = 256, MT = 4;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
+    uint64_t *s_exp = reinterpret_cast<uint64_t *>(s_mem);
+    constexpr int NB = BASIS > 0 ? BASIS : 1;
+    const FrameParams &P = K.P;
+    const AccelView &A = K.A;
+    const MlpShape &S = F.S;
+    const int LL = K.lds_level;
+    const int cells = 1 << (3 * LL);
+    uint32_t *s_grid = s_mem + 64;
+    float *s_ray = reinterpret_cast<float *>(s_grid + cells);  // [k][thread]: k < NB basis, then vdir[3]
+    const int tile_words = (S.mt_out * 16 > 16 ? S.mt_out * 16 : 16) * 64;
+    uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_ray + (NB + 3) * BLOCK) + (threadIdx.x >> 6) * fused_wave_words(S.mt_out);  // this wavefront's LDS
+    float *s_out = reinterpret_cast<float *>(s_tile);
+    float *s_px = s_out + tile_words, *s_py = s_px + kPool, *s_pz = s_py + kPool, *s_pd = s_pz + kPool;  // pool: world xyz, delta z
+    uint32_t *s_pm = reinterpret_cast<uint32_t *>(s_pd + kPool), *s_pn = s_pm + kPool;  // owner | last << 6 | cluster << 8; owner's next slot
+    float *s_ra = reinterpret_cast<float *>(s_pn + kPool), *s_r0 = s_ra + 64, *s_r1 = s_r0 + 64, *s_r2 = s_r1 + 64;  // per-column results
+    constexpr uint32_t kNone = 0xffffffffu;
+
+    if (threadIdx.x < 32) s_exp[threadIdx.x] = kExp2fTab[threadIdx.x];
+    for (int i = threadIdx.x; i < cells; i += BLOCK) {
+        const int G = 1 << LL;
+        const int iz = i & (G - 1), iy = (i >> LL) & (G - 1), ix = i >> (2 * LL);
+        uint32_t chunk = 0, word = 0;
+        for (int l = 1; l <= LL; ++l) {
+            const int s = LL - l;
+            const int cidx = (((ix >> s) & 1) << 2) | (((iy >> s) & 1) << 1) | ((iz >> s) & 1);
+            word = A.nodes[(int64_t)chunk * 8 + cidx];
+            if (word & kLeafBit) break;
+            chunk = word;
+        }
+        s_grid[i] = word;
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
+    const int Lq = A.max_depth;
+    const float qscale = __uint_as_float((uint32_t)(127 + Lq) << 23);
+    const int sh1 = Lq - LL, L2 = A.grid2_level, sh2 = Lq - L2;
+    float *my_ray = s_ray + threadIdx.x;
+
+    // per-lane ray state
+    bool has_ray = false, done = true, held = false;
+    float t = 0.f, T = 1.f, tmax = 0.f, dir0 = 0.f, dir1 = 0.f, dir2 = 0.f, inv0 = 0.f, inv1 = 0.f, inv2 = 0.f, delta_scale = 0.f;
+    float td0 = 0.f, td1 = 0.f, td2 = 0.f;  // world-space unit direction (sample positions)
+    uint32_t pix = 0;
+    int ns = 0;                              // samples emitted by the ray
+    float hz = 0.f, hx = 0.f, hy = 0.f, hw = 0.f;  // the held-back (newest) sample: z, world xyz
+    int hcl = -1;                            // its cluster
+    uint32_t first_pending = kNone, prev_slot = kNone;  // pool slots (monotonic numbers): oldest sample not yet composited, last one pushed
+    float ti = 1.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;  // composite state (render_nerf_results)
+    int n_eval = 0, n_batches = 0, n_steps = 0, n_cut = 0, n_drain = 0;
+    uint32_t head = 0, tail = 0;             // pool bounds (wave-uniform, monotonic; slot = number & (kPool - 1))
+
+    const uint32_t home = blockIdx.x % kNumQueues;
+    uint32_t qsel = 0;
+    bool drained = false;
+    const CamBlock *__restrict__ Cp = K.cams;
+    const float cen0 = Cp->cen[0], cen1 = Cp->cen[1], cen2 = Cp->cen[2];
+    const int wave_base = threadIdx.x & ~63;
+
+    for (;;) {
+        // ---- a new 8x8 tile once every lane has written its pixel
+        if (__ballot(has_ray) == 0) {
+            if (drained) break;
+            if (qsel >= kNumQueues) {
+                drained = true;
+                continue;
+            }
+            const uint32_t q = (home + qsel) % kNumQueues;
+            const uint32_t begin = K.band_begin[q] * 64u, span = (K.band_begin[q + 1] - K.band_begin[q]) * 64u;
+            uint32_t off = 0;
+            if (lane == 0) off = atomicAdd(&K.queue[q * 16], 64u);
+            off = __builtin_amdgcn_readfirstlane(off);
+            if (off >= span) {
+                ++qsel;
+                continue;
+            }
+            const uint32_t id = begin + off + (uint32_t)lane;
+            int bx, by;
+            uint32_t p;
+            if (ray_pixel(K, id, bx, by, p)) {
+                pix = p;
+                has_ray = true;
+                done = true;
+                held = false;
+                ns = 0;
+                first_pending = prev_slot = kNone;
+                ti = 1.f;
+                o0 = o1 = o2 = 0.f;
+                RaySetup<NB> r;
+                setup_ray<(BASIS > 0 ? BASIS : 0)>(P, *Cp, P.x0 + bx, P.y0 + by, r);
+                if constexpr (BASIS == 0) r.basis[0] = (0 < P.basis_min || 0 > P.basis_max) ? 0.f : (float)0.28209479177387814;
+                float true_dir[3], vdir[3];
+                world_ray_dirs(P, *Cp, P.x0 + bx, P.y0 + by, true_dir, vdir);
+                td0 = true_dir[0];
+                td1 = true_dir[1];
+                td2 = true_dir[2];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) my_ray[k * BLOCK] = r.basis[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) my_ray[(NB + k) * BLOCK] = vdir[k];
+                if (r.in_bbox) {
+                    done = false;
+                    t = r.tmin;
+                    T = 1.f;
+                    tmax = r.tmax;
+                    dir0 = r.dir[0]; dir1 = r.dir[1]; dir2 = r.dir[2];
+                    inv0 = r.invdir[0]; inv1 = r.invdir[1]; inv2 = r.invdir[2];
+                    delta_scale = r.delta_scale;
+                }
+            }
+            continue;
+        }
+
+        // ---- one march step (rt_core.cuh:452-560) for the lanes whose ray is still under way
+        bool fresh = false;                      // this step emitted a sample
+        float sz = 0.f, sx = 0.f, sy = 0.f, sw = 0.f;
+        int scl = -1;
+        if (__ballot(has_ray && !done) != 0) ++n_steps;
+        if (has_ray && !done) {
+            if (!(t < tmax)) {
+                done = true;
+            } else {
+                float pos[3];
+                uint32_t q[3];
+                pos[0] = cen0 + t * dir0;
+                pos[1] = cen1 + t * dir1;
+                pos[2] = cen2 + t * dir2;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    pos[i] = __builtin_amdgcn_fmed3f(pos[i], 0.f, 1.f - 1e-6f);
+                    q[i] = (uint32_t)(pos[i] * qscale);
+                }
+                uint32_t word = s_grid[((((q[0] >> sh1) << LL) | (q[1] >> sh1)) << LL) | (q[2] >> sh1)];
+                if (!(word & kLeafBit)) {
+                    int sh = sh1;
+                    if (L2 > LL) {
+                        const int LB = L2 - 2;
+                        uint32_t gi = q[0] >> (sh2 + 2);
+                        gi = (gi << LB) | (q[1] >> (sh2 + 2));
+                        gi = (gi << LB) | (q[2] >> (sh2 + 2));
+                        gi = (gi << 2) | __builtin_amdgcn_ubfe(q[0], (uint32_t)sh2, 2u);
+                        gi = (gi << 2) | __builtin_amdgcn_ubfe(q[1], (uint32_t)sh2, 2u);
+                        gi = (gi << 2) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh2, 2u);
+                        word = A.grid2[gi];
+                        sh = sh2;
+                    }
+                    while (!(word & kLeafBit)) {
+                        --sh;
+                        uint32_t v = (word << 1) | __builtin_amdgcn_ubfe(q[0], (uint32_t)sh, 1u);
+                        v = (v << 1) | __builtin_amdgcn_ubfe(q[1], (uint32_t)sh, 1u);
+                        v = (v << 1) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh, 1u);
+                        word = A.nodes[v];
+                    }
+                }
+                const int depth = (int)((word >> 16) & 0x7fu);
+                const float sc = __uint_as_float((uint32_t)(127 + depth) << 23);
+                const float inv_cube = __uint_as_float((uint32_t)(127 - depth) << 23);
+                float tu = 1e4f;
+                const float invd[3] = {inv0, inv1, inv2};
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const float x = __builtin_amdgcn_fractf(pos[i] * sc);
+                    const float t1 = -x * invd[i];
+                    const float t2 = t1 + invd[i];
+                    tu = fminf(tu, fmaxf(t1, t2));
+                }
+                const float delta_t = tu * inv_cube + P.step_size;
+                const float sigma = half_bits_to_float((uint16_t)word);
+                if (sigma > P.sigma_thresh) {
+                    const float att = exact_expf(-delta_t * delta_scale * sigma, s_exp);
+                    // rt_core.cuh:508-549: one sample per dense step while there is room
+                    if (ns < F.max_guided_samples) {
+                        const float tz0 = t * dir0 / P.scale[0], tz1 = t * dir1 / P.scale[1], tz2 = t * dir2 / P.scale[2];
+                        sz = sqrtf(tz0 * tz0 + tz1 * tz1 + tz2 * tz2);
+                        const float *m = Cp->c2w;
+                        sx = m[9] + td0 * sz;
+                        sy = m[10] + td1 * sz;
+                        sw = m[11] + td2 * sz;
+                        const int g1 = (int)fmaxf(fminf((sy - F.min_position[1]) / F.range[1] * (float)F.grid_dim[0], (float)F.grid_dim[0] - 1.0f), 0.0f);
+                        const int g2 = (int)fmaxf(fminf((sw - F.min_position[2]) / F.range[2] * (float)F.grid_dim[1], (float)F.grid_dim[1] - 1.0f), 0.0f);
+                        scl = (int)(int16_t)(g1 * F.grid_dim[1] + g2);
+                        fresh = true;
+                        ++ns;
+                    }
+                    T *= att;
+                    if (T < P.stop_thresh) done = true;
+                }
+                t += delta_t;
+                // a ray that has emitted its quota contributes nothing more: its remaining steps are skipped
+                if (ns >= F.max_guided_samples) done = true;
+            }
+        }
+
+        // ---- release complete samples into the pool: the held one once its successor exists (delta z known), or as the ray's
+        //      last sample one step after the ray ended
+        {
+            bool push = false, last = false;
+            float pz_ = 0.f, px_ = 0.f, py_ = 0.f, pw_ = 0.f, pdz = 0.f;
+            int pcl = -1;
+            if (fresh) {
+                if (held) {
+                    push = true;
+                    pz_ = hz; px_ = hx; py_ = hy; pw_ = hw; pcl = hcl;
+                    pdz = sz - hz;  // delta_i = z[i + 1] - z[i], rt_core.cuh:359
+                }
+                hz = sz; hx = sx; hy = sy; hw = sw; hcl = scl;
+                held = true;
+            } else if (has_ray && done && held) {
+                push = true;
+                last = true;
+                pz_ = hz; px_ = hx; py_ = hy; pw_ = hw; pcl = hcl;
+                held = false;
+            }
+            (void)pz_;
+            const uint64_t pm = __ballot(push);
+            if (pm != 0) {
+                if (push) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                    const uint32_t slot = tail + rank, e = slot & (kPool - 1);
+                    s_px[e] = px_;
+                    s_py[e] = py_;
+                    s_pz[e] = pw_;
+                    s_pd[e] = pdz;
+                    s_pm[e] = (uint32_t)lane | (last ? 64u : 0u) | ((uint32_t)(pcl & 0xffff) << 8);
+                    s_pn[e] = kNone;
+                    if (prev_slot != kNone && (int32_t)(prev_slot - head) >= 0) s_pn[prev_slot & (kPool - 1)] = slot;  // still in the pool: chain it
+                    if (first_pending == kNone) first_pending = slot;
+                    prev_slot = slot;
+                }
+                tail += (uint32_t)__popcll(pm);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+
+        // ---- the network for the head of the pool: when 64 samples wait, or when nothing more can arrive
+        //      (a pass may take fewer than 64 entries -- a cluster boundary -- so passes repeat until fewer than batch_min <= 64 wait:
+        //      the next march step then adds at most 64 and the ring of 128 cannot overflow)
+        const bool more_to_come = __ballot(has_ray && (!done || held)) != 0;
+        while (tail - head >= (uint32_t)F.batch_min || (tail != head && !more_to_come)) {
+            const uint32_t size = tail - head;
+            if (size < (uint32_t)F.batch_min) ++n_drain;
+            const int n = size < 64u ? (int)size : 64;
+            const uint32_t e = (head + (uint32_t)lane) & (kPool - 1);
+            const bool col_on = lane < n;
+            const uint32_t meta = col_on ? s_pm[e] : 0u;
+            const int owner = (int)(meta & 63u), my_cl = (int)(int16_t)(meta >> 8);
+            // The window's samples may belong to several sub-modules (a ray that crosses the front and the back of a surface changes
+            // cluster on the way, and its neighbours do so a few steps apart): the network runs once per distinct cluster of the
+            // window, every run fills the columns of its own cluster, and the pool stays first-in first-out.
+            uint64_t todo = __ballot(col_on);
+            while (todo != 0) {
+            const int c_star = __builtin_amdgcn_readfirstlane(__shfl(my_cl, (int)__builtin_ctzll(todo)));
+            const bool col_sel = col_on && my_cl == c_star;
+            const uint64_t sel = __ballot(col_sel);
+            todo &= ~sel;
+            ++n_batches;
+            if (todo != 0) ++n_cut;
+            const bool valid_cluster = c_star >= 0 && c_star < S.n_clusters;
+            if (valid_cluster) {
+                float p[3], d[3];
+                p[0] = ((col_on ? s_px[e] : 0.f) - S.center[0]) * S.inv_extent[0];
+                p[1] = ((col_on ? s_py[e] : 0.f) - S.center[1]) * S.inv_extent[1];
+                p[2] = ((col_on ? s_pz[e] : 0.f) - S.center[2]) * S.inv_extent[2];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) d[i] = S.need_viewdir ? s_ray[(NB + i) * BLOCK + wave_base + owner] : 0.f;
+                const uint16_t *emb = nullptr;
+                if (S.n_embeddings > 0) {
+                    int idx = (int)(float)F.appearance_embedding;
+                    idx = idx < 0 ? 0 : (idx >= S.n_embeddings ? S.n_embeddings - 1 : idx);
+                    emb = F.embeddings + ((size_t)c_star * S.n_embeddings + idx) * S.embedding_dim;
+                }
+                const half8 *w = reinterpret_cast<const half8 *>(F.frags + (size_t)c_star * S.frag_halfs);
+                const float *b = F.biases + (size_t)c_star * S.bias_floats;
+                // The weight fragments come from global memory (L2): with two or three wavefronts per SIMD nothing hides a
+                // load issued right before its MFMA, so the fragments of a layer are requested one layer ahead -- layer 0's
+                // before the encode, layer l + 1's before layer l's MFMAs -- and wait in registers (8 fragments per layer).
+                constexpr int kFr = MT * (MT / 2);  // fragments of a hidden layer; the output layer's (2 * mt_out) are read as 8 as well
+                                                    // (the arrays are padded, mnv_mlp_create), so every fetch is 8 unconditional loads
+                half8 cur[kFr], nxt[kFr];
+                f32x4 bias_cur[MT], bias_nxt[MT];
+                auto fetch = [&](half8 *dst, f32x4 *bdst, const half8 *src, const float *bsrc) {
+#pragma unroll
+                    for (int i = 0; i < kFr; ++i) dst[i] = src[i * 64 + lane];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) bdst[mt] = *reinterpret_cast<const f32x4 *>(bsrc + 16 * mt + 4 * g);
+                };
+                constexpr int n0 = MT * NKK0;  // layer 0: fragment (mt, kk) at index mt * NKK0 + kk
+                static_assert(n0 <= kFr, "layer 0 is prefetched whole");
+                fetch(cur, bias_cur, w, b);
+                f32x4 acc[MT][kNT];
+                // layer 0: every lane encodes its own sample; the half pairs cross over through the LDS tile
+                const int emb_base = S.n_pos + S.n_dir;
+#pragma unroll
+                for (int kk = 0; kk < NKK0; ++kk) {
+#pragma nounroll
+                    for (int f2 = 0; f2 < 16; ++f2) {
+                        const int r = 2 * f2, f = 32 * kk + r;
+                        float v0, v1;
+                        if (f >= emb_base && f < S.in_dim) v0 = half_bits_to_float(emb[f - emb_base]);
+                        else v0 = encode_feature(S, f, p, d);
+                        if (f + 1 >= emb_base && f + 1 < S.in_dim) v1 = half_bits_to_float(emb[f + 1 - emb_base]);
+                        else v1 = encode_feature(S, f + 1, p, d);
+                        const int fg = (r & 15) >> 2, fe = (r >> 4) * 4 + (r & 3);
+                        union {
+                            _Float16 h[2];
+                            uint32_t u;
+                        } pk;
+                        pk.h[0] = (_Float16)v0;
+                        pk.h[1] = (_Float16)v1;
+                        s_tile[(fg * 4 + (fe >> 1)) * 64 + lane] = pk.u;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    half8 bf[kNT];
+#pragma unroll
+                    for (int nt = 0; nt < kNT; ++nt) {
+                        union {
+                            uint32_t u[4];
+                            half8 h;
+                        } rd;
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) rd.u[q4] = s_tile[(g * 4 + q4) * 64 + nt * 16 + col];
+                        bf[nt] = rd.h;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (kk == 0) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < kNT; ++nt) acc[mt][nt] = bias_cur[mt];
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                        for (int nt = 0; nt < kNT; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[mt * NKK0 + kk], bf[nt], acc[mt][nt], 0, 0, 0);
+                    }
+                    if (kk == 0) fetch(nxt, bias_nxt, w + n0 * 64, b + 16 * MT);  // layer 1's fragments travel while layer 0 finishes
+                }
+                w += n0 * 64;
+                b += 16 * MT;
+                for (int layer = 1; layer <= S.hidden_layers; ++layer) {
+                    const int n_mt = layer < S.hidden_layers ? MT : S.mt_out;
+                    half8 bf[MT / 2][kNT];
+#pragma unroll
+                    for (int kk = 0; kk < MT / 2; ++kk)
+#pragma unroll
+                        for (int nt = 0; nt < kNT; ++nt) bf[kk][nt] = relu_pack(acc[2 * kk][nt], acc[2 * kk + 1][nt]);
+#pragma unroll
+                    for (int i = 0; i < kFr; ++i) cur[i] = nxt[i];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) bias_cur[mt] = bias_nxt[mt];
+                    if (layer < S.hidden_layers) fetch(nxt, bias_nxt, w + n_mt * (MT / 2) * 64, b + 16 * n_mt);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        if (mt < n_mt) {
+#pragma unroll
+                            for (int nt = 0; nt < kNT; ++nt) acc[mt][nt] = bias_cur[mt];
+#pragma unroll
+                            for (int kk = 0; kk < MT / 2; ++kk) {
+#pragma unroll
+                                for (int nt = 0; nt < kNT; ++nt)
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[mt * (MT / 2) + kk], bf[kk][nt], acc[mt][nt], 0, 0, 0);
+                            }
+                        }
+                    }
+                    w += n_mt * (MT / 2) * 64;
+                    b += 16 * n_mt;
+                }
+                // outputs to the tile: feature f of column j at s_out[f * 64 + j]
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (mt < S.mt_out) {
+#pragma unroll
+                        for (int nt = 0; nt < kNT; ++nt)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) s_out[(16 * mt + 4 * g + r) * 64 + nt * 16 + col] = acc[mt][nt][r];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            // ---- column j: transmittance factor and colour denominators of its sample (rt_core.cuh:356-392), SH basis of the owner
+            if (col_sel) {
+                auto sv = [&](int f) -> float { return valid_cluster ? s_out[f * 64 + lane] : 0.f; };  // no sub-module: zeros (mlp_histogram)
+                const bool last = (meta & 64u) != 0;
+                s_ra[lane] = last ? 0.f : exact_expf(-sv(3) * s_pd[e], s_exp);
+                if constexpr (BASIS >= 0) {
+                    float basis[NB];
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) basis[k] = s_ray[k * BLOCK + wave_base + owner];
+                    const int stride = BASIS > 0 ? BASIS : 0;
+                    s_r0[lane] = 1.f + exact_expf(-sh_channel<BASIS>(basis, sv, 0), s_exp);
+                    s_r1[lane] = 1.f + exact_expf(-sh_channel<BASIS>(basis, sv, stride), s_exp);
+                    s_r2[lane] = 1.f + exact_expf(-sh_channel<BASIS>(basis, sv, 2 * stride), s_exp);
+                } else {
+                    s_r0[lane] = sv(0);
+                    s_r1[lane] = sv(1);
+                    s_r2[lane] = sv(2);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // the next cluster's run rewrites the tile
+            }
+            // ---- every owner walks its samples of this pass in ray order
+            while (first_pending != kNone && (int32_t)(first_pending - (head + (uint32_t)n)) < 0) {
+                const int j = (int)(first_pending - head);
+                const uint32_t ee = first_pending & (kPool - 1);
+                const bool last = (s_pm[ee] & 64u) != 0;
+                const float wc = s_ra[j];
+                const float weight = last ? ti : ti * (1.0f - wc);
+                if constexpr (BASIS >= 0) {
+                    o0 += weight / s_r0[j];
+                    o1 += weight / s_r1[j];
+                    o2 += weight / s_r2[j];
+                } else {
+                    o0 += weight * s_r0[j];
+                    o1 += weight * s_r1[j];
+                    o2 += weight * s_r2[j];
+                }
+                ti *= wc;
+                first_pending = s_pn[ee];
+                ++n_eval;
+            }
+            head += (uint32_t)n;
+            __builtin_amdgcn_wave_barrier();  // tile, results and the freed pool slots are rewritten from here on
+        }
+        // ---- rays that have ended and whose samples are all composited: write the pixel (alpha 1, renderer_kernel.cu:316)
+        if (has_ray && done && !held && first_pending == kNone) {
+            composite_and_write(P, (int64_t)pix, o0, o1, o2, 1.0f);
+            has_ray = false;
+        }
+    }
+    if (F.sample_counter) {
+        // one atomic per wavefront
+        int tot = n_eval;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
+        if (lane == 0 && tot) atomicAdd(F.sample_counter, (unsigned long long)tot);
+        if (F.diag && lane == 0) {  // diagnostics: network passes and march iterations of this wavefront
+            atomicAdd(F.sample_counter + 1, (unsigned long long)n_batches);
+            atomicAdd(F.sample_counter + 2, (unsigned long long)n_steps);
+            atomicAdd(F.sample_counter + 3, (unsigned long long)n_cut);
+            atomicAdd(F.sample_counter + 4, (unsigned long long)n_drain);
+        }
+    }
+}
+
+}  // namespace mnv

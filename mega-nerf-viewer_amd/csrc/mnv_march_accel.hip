@@ -819,6 +819,12 @@ __global__ void assemble_tiles_kernel(const PIXEL *__restrict__ gathered, PIXEL 
     __builtin_nontemporal_store(__builtin_nontemporal_load(&gathered[src]), &frames[idx]);
 }
 
+}  // namespace mnv
+
+#include "mnv_guided_fused.h"  // guided_fused_kernel: march + per-sample network + composite in one kernel
+
+namespace mnv {
+
 // ---------------------------------------------------------------------------- host side
 
 static int row_bytes_for(int basis) { return row_bytes_pow2(basis); }
@@ -877,6 +883,7 @@ struct AccelTrack {
     int16_t *cluster_indices;
     int32_t max_guided_samples, samples_dim, need_viewdir, appearance_embedding;
     const mnv_cluster_grid *grid;
+    const FusedGuided *fused;  // non-NULL: guided_fused_kernel instead of the march (no trackers, one frame)
 };
 
 constexpr int kUnsupportedBasis = -1000;  // not a hipError_t
@@ -1023,7 +1030,30 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     }
     int rc = kUnsupportedBasis;
     const int b = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim >= 0) ? accel->view.basis_dim : -1;
-    if (colourless) rc = launch_variant<9>(K, n_blocks, lds_bytes, stream);
+    if (track && track->fused) {
+        // the fused guided-sampling frame: 3 workgroups per CU (LDS: network tiles), one 8x8 tile per wavefront at a time
+        const FusedGuided &F = *track->fused;
+        const int nb = b > 0 ? b : 1;
+        const size_t fl = fused_lds_bytes(nb, lds_level, F.S.mt_out);
+        int fb = accel->num_cus * MNV_FUSED_WAVES;
+        if ((uint64_t)fb * 4u > n_waves_needed) fb = (int)((n_waves_needed + 3) / 4);
+        if (fb < 1) fb = 1;
+        auto go = [&](auto kern) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(kern, dim3(fb), dim3(256), fl, stream, K, F);
+            return (int)hipGetLastError();
+        };
+        const bool two = F.S.nkk0 == 2;  // mnv_render_guided_fused admits 1 and 2
+        switch (b) {
+            case -1: rc = two ? go(guided_fused_kernel<-1, 2>) : go(guided_fused_kernel<-1, 1>); break;
+            case 1: rc = two ? go(guided_fused_kernel<1, 2>) : go(guided_fused_kernel<1, 1>); break;
+            case 4: rc = two ? go(guided_fused_kernel<4, 2>) : go(guided_fused_kernel<4, 1>); break;
+            case 9: rc = two ? go(guided_fused_kernel<9, 2>) : go(guided_fused_kernel<9, 1>); break;
+            case 16: rc = two ? go(guided_fused_kernel<16, 2>) : go(guided_fused_kernel<16, 1>); break;
+            default: break;
+        }
+    } else if (colourless) rc = launch_variant<9>(K, n_blocks, lds_bytes, stream);
     else
         switch (b) {
             case -1: rc = launch_variant<-1>(K, n_blocks, lds_bytes, stream); break;
@@ -1426,6 +1456,45 @@ int mnv_get_samples_from_voxels_accel(const mnv_accel *accel, const mnv_camera *
     track.grid = grid;
     const mnv_partition whole = {0, 1, 0, 0, 0};
     return render_accel(accel, cam, 1, opt, tile, whole, nullptr, nullptr, &track, hip_stream);
+}
+
+int mnv_render_guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, const mnv_mlp *mlp,
+                            const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, unsigned long long *sample_counter,
+                            void *hip_stream) {
+    if (!accel || !cam || !opt || !mlp || !grid) return set_error(MNV_E_INVALID, "null argument");
+    if (opt->render_depth) return set_error(MNV_E_UNSUPPORTED, "the fused guided-sampling frame has no depth mode; use the four-step path");
+    if (opt->max_guided_samples < 1) return set_error(MNV_E_INVALID, "max_guided_samples must be positive");
+    const MlpShape &S = mlp->shape;
+    if (S.hidden_width != 64 || S.nkk0 > 2)
+        return set_error(MNV_E_UNSUPPORTED, "the fused guided-sampling frame runs 64-wide networks with at most 64 encoded inputs; use the four-step path");
+    if (S.out_dim != accel->view.data_dim + 1) return set_error(MNV_E_INVALID, "the model's out_dim must be the tree's data_dim + 1 (cuda_renderer.cpp:255-257)");
+    if ((S.need_viewdir != 0) != (opt->need_viewdir != 0)) return set_error(MNV_E_INVALID, "options.need_viewdir does not match the model");
+    if (S.n_embeddings > 0 && opt->appearance_embedding == -1) return set_error(MNV_E_INVALID, "the model needs an appearance embedding");
+    const int b = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim >= 0) ? accel->view.basis_dim : -1;
+    if (!(b == -1 || b == 1 || b == 4 || b == 9 || b == 16))
+        return set_error(MNV_E_UNSUPPORTED, "the fused guided-sampling frame supports RGBA and SH1/4/9/16 trees; use the four-step path");
+    FusedGuided F;
+    std::memset(static_cast<void *>(&F), 0, sizeof(F));
+    F.S = S;
+    F.frags = mlp->frags;
+    F.biases = mlp->biases;
+    F.embeddings = mlp->embeddings;
+    for (int i = 0; i < 2; ++i) F.grid_dim[i] = grid->grid_dim[i];
+    for (int i = 0; i < 3; ++i) {
+        F.min_position[i] = grid->min_position[i];
+        F.range[i] = grid->range[i];
+    }
+    F.max_guided_samples = opt->max_guided_samples;
+    F.appearance_embedding = opt->appearance_embedding;
+    static const int env_batch = getenv("MNV_FUSED_BATCH_MIN") ? atoi(getenv("MNV_FUSED_BATCH_MIN")) : 64;
+    F.batch_min = env_batch < 1 ? 1 : (env_batch > 64 ? 64 : env_batch);
+    F.sample_counter = sample_counter;
+    static const bool env_diag = getenv("MNV_FUSED_DIAG") != nullptr;  // the counter then has three words
+    F.diag = env_diag && sample_counter ? 1 : 0;
+    AccelTrack track = {};
+    track.fused = &F;
+    const mnv_partition whole = {0, 1, 0, 0, 0};
+    return render_accel(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, &track, hip_stream);
 }
 
 }  // extern "C"

@@ -26,68 +26,9 @@
 #include <vector>
 
 #include "mnv_internal.h"
+#include "mnv_mlp.h"
 
 namespace mnv {
-
-using half8 = __attribute__((ext_vector_type(8))) _Float16;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-constexpr int kRowsPerPass = 256;   // 4 wavefronts x 64 rows
-constexpr int kPasses = 8;          // passes of one workgroup over rows of the same cluster: the weights are staged once per 2048 rows
-constexpr int kRowsPerBlock = kRowsPerPass * kPasses;
-constexpr int kNT = 4;              // 16-row MFMA column tiles per wavefront
-constexpr int kMaxClusters = 1024;
-
-struct MlpShape {
-    int32_t n_clusters, pos_octaves, dir_octaves, need_viewdir, n_embeddings, embedding_dim;
-    int32_t hidden_width, hidden_layers, out_dim;
-    int32_t in_dim, n_pos, n_dir;   // encoded widths
-    int32_t nkk0;                   // K tiles (32) of the first layer
-    int32_t mt_hidden, mt_out;      // M tiles (16) of hidden / output layers
-    int32_t frag_halfs;             // per cluster: all weight fragments
-    int32_t bias_floats;            // per cluster: all biases, padded per layer
-    float center[3], inv_extent[3];
-};
-
-}  // namespace mnv
-
-struct mnv_mlp {
-    mnv::MlpShape shape;
-    uint16_t *frags = nullptr;      // [n_clusters][frag_halfs] binary16, fragment order
-    float *biases = nullptr;        // [n_clusters][bias_floats]
-    uint16_t *embeddings = nullptr; // [n_clusters][n_embeddings][embedding_dim] binary16
-    uint8_t *scratch = nullptr;     // grow-only: order, tiles, counters
-    size_t scratch_bytes = 0;
-    int num_cus = 0;
-};
-
-namespace mnv {
-
-// input feature handled by K slot e of lane group g in K tile kk (see the header comment)
-__host__ __device__ inline int slot_feature(int kk, int g, int e) { return 32 * kk + 16 * (e >> 2) + 4 * g + (e & 3); }
-
-__host__ __device__ inline float tri_wave(float t) {
-    const float r = t - floorf(t + 0.5f);
-    return 4.f * fabsf(r) - 1.f;
-}
-
-// value of encoded feature f for one sample (before the binary16 rounding); 0 for padding features
-__host__ __device__ inline float encode_feature(const MlpShape &S, int f, const float p[3], const float d[3]) {
-    if (f < S.n_pos) {
-        if (f < 3) return p[f];
-        const int q = f - 3, k = q / 6, r = q - 6 * k, i = r % 3;
-        const float scale = (float)(1u << k);
-        return tri_wave(p[i] * scale + (r >= 3 ? 0.25f : 0.f));
-    }
-    f -= S.n_pos;
-    if (f < S.n_dir) {
-        if (f < 3) return d[f];
-        const int q = f - 3, k = q / 6, r = q - 6 * k, i = r % 3;
-        const float scale = (float)(1u << k);
-        return tri_wave(d[i] * scale + (r >= 3 ? 0.25f : 0.f));
-    }
-    return 0.f;  // embedding features are looked up by the caller
-}
 
 struct MlpLaunch {
     MlpShape S;
@@ -199,16 +140,6 @@ __global__ __launch_bounds__(256) void mlp_scatter(const int16_t *__restrict__ c
 }
 
 // ---------------------------------------------------------------- the network
-
-__device__ inline half8 relu_pack(const f32x4 &lo, const f32x4 &hi) {
-    half8 h;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        h[r] = (_Float16)fmaxf(lo[r], 0.f);
-        h[4 + r] = (_Float16)fmaxf(hi[r], 0.f);
-    }
-    return h;
-}
 
 template <int MT>  // hidden width = 16 * MT
 __global__ __launch_bounds__(256) void mlp_forward_kernel(const MlpLaunch L) {
@@ -499,8 +430,11 @@ int mnv_mlp_create(const mnv_mlp_desc *desc, const uint16_t *params, size_t n_ha
         mnv_mlp_destroy(m);
         return code;
     };
-    if ((rc = check_hip(hipMalloc((void **)&m->frags, frags.size() * 2), "hipMalloc(mlp fragments)"))) return fail(rc);
-    if ((rc = check_hip(hipMalloc((void **)&m->biases, biases.size() * 4), "hipMalloc(mlp biases)"))) return fail(rc);
+    // + 8 fragments / 64 floats of slack: the fused guided kernel fetches every layer as 8 fragments and 4 bias tiles
+    if ((rc = check_hip(hipMalloc((void **)&m->frags, frags.size() * 2 + 8 * 1024), "hipMalloc(mlp fragments)"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&m->biases, biases.size() * 4 + 256), "hipMalloc(mlp biases)"))) return fail(rc);
+    if ((rc = check_hip(hipMemsetAsync(m->frags, 0, frags.size() * 2 + 8 * 1024, stream), "clear"))) return fail(rc);
+    if ((rc = check_hip(hipMemsetAsync(m->biases, 0, biases.size() * 4 + 256, stream), "clear"))) return fail(rc);
     if ((rc = check_hip(hipMemcpyAsync(m->frags, frags.data(), frags.size() * 2, hipMemcpyHostToDevice, stream), "upload"))) return fail(rc);
     if ((rc = check_hip(hipMemcpyAsync(m->biases, biases.data(), biases.size() * 4, hipMemcpyHostToDevice, stream), "upload"))) return fail(rc);
     if (!emb.empty()) {

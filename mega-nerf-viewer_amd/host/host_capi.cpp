@@ -282,6 +282,8 @@ int mnv_renderer_render(mnv_renderer *r, mnv_renderer_stats *stats) {
             stats->pruned = s.pruned;
             stats->guided_samples = s.guided_samples;
             stats->capacity = s.capacity;
+            stats->fused = s.fused;
+            stats->reserved = 0;
         }
         return MNV_OK;
     });
@@ -306,6 +308,12 @@ int mnv_renderer_set_frames_in_flight(mnv_renderer *r, int32_t count) {
         r->rend.frames_in_flight = count;
         return MNV_OK;
     });
+}
+
+int mnv_renderer_set_fused_guided(mnv_renderer *r, int enable) {
+    if (!r) return mnv::set_error(MNV_E_INVALID, "null argument");
+    r->rend.use_fused_guided = enable != 0;
+    return MNV_OK;
 }
 
 int32_t mnv_renderer_last_slot(const mnv_renderer *r) { return r ? r->rend.last_slot() : -1; }

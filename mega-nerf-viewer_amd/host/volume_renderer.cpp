@@ -70,7 +70,8 @@ struct VolumeRenderer::Impl {
     mnv_cluster_grid grid{};
     DeviceBuffer split_tracker, sample_tracker, visit_tracker, num_samples, cluster_indices, guided_samples;
     DeviceBuffer offsets, z_vals, sample_rows, sample_clusters, nerf_results;
-    DeviceBuffer nodes, rand_sample, rand_clusters, results;
+    DeviceBuffer nodes, rand_sample, rand_clusters, results, fused_counter;
+    bool fused_inputs_ok = false;  // the model's encoded input fits the fused guided kernel (<= 64 features)
     bool prune_happened = false, can_reuse_results = false, accel_stale = false;
     bool marks_fresh = false, want_marks = false;  // see render(): prune only after a track_visit frame
     int quiet_frames = 0;
@@ -259,6 +260,10 @@ void VolumeRenderer::set_model(const mnv_mlp_desc &desc, const uint16_t *params,
     if (impl_->mlp) mnv_mlp_destroy(impl_->mlp);
     impl_->mlp = m;
     impl_->mlp_desc = desc;
+    {
+        const int in_dim = 3 + 6 * desc.pos_octaves + (desc.need_viewdir ? 3 + 6 * desc.dir_octaves : 0) + (desc.n_embeddings > 0 ? desc.embedding_dim : 0);
+        impl_->fused_inputs_ok = in_dim <= 64;
+    }
     impl_->grid = grid;
     // cuda_renderer.cpp:534-537
     options.need_viewdir = desc.need_viewdir != 0;
@@ -393,7 +398,25 @@ void VolumeRenderer::render() {
     }
     const mnv_tree_view dv = tree.device_view();
 
-    if (refine && options.use_guided_sampling) {
+    // the guided-sampling frame as ONE kernel (march + networks + composite, no sample buffer) whenever nothing else has to
+    // come out of the frame: no refinement trackers, no visit marks, a current accel, a network the fused kernel covers
+    const bool fuse = refine && options.use_guided_sampling && !options.use_splitting && use_fused_guided && tree.device.accel && !I.accel_stale &&
+                      !track_visit && !options.render_depth && I.mlp_desc.hidden_width == 64 && I.fused_inputs_ok &&
+                      (tree.data_format.format != DataFormat::SH || tree.data_format.basis_dim == 1 || tree.data_format.basis_dim == 4 ||
+                       tree.data_format.basis_dim == 9 || tree.data_format.basis_dim == 16);
+    if (fuse) {
+        unsigned long long *counter = I.fused_counter.get<unsigned long long>(1);
+        hip_check(hipMemsetAsync(counter, 0, sizeof(unsigned long long), I.stream), "clear sample counter");
+        mnv_check(mnv_render_guided_fused(tree.device.accel, &cv, options.c_abi(), full, I.mlp, &I.grid, I.rgba, I.rgba8, counter, I.stream),
+                  "mnv_render_guided_fused");
+        unsigned long long n = 0;
+        hip_check(hipMemcpyAsync(&n, counter, sizeof(n), hipMemcpyDeviceToHost, I.stream), "read sample counter");
+        hip_check(hipStreamSynchronize(I.stream), "guided frame");
+        stats.used_accel = true;
+        stats.fused = true;
+        stats.guided_samples = (long)n;
+        I.can_reuse_results = false;
+    } else if (refine && options.use_guided_sampling) {
         // cuda_renderer.cpp:109-139
         const int samples_dim = 1 + I.sample_cols(options), max_g = options.max_guided_samples, dd = tree.data_dim;
         int64_t *offsets = I.offsets.get<int64_t>(n_px);

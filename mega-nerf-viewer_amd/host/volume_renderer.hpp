@@ -74,6 +74,7 @@ struct VolumeRenderer {
     // What the last render() did (the reference prints these to stdout).
     struct FrameStats {
         bool track_visit = false, used_accel = false, full = false;
+        bool fused = false;                         // the guided-sampling frame ran as one kernel (mnv_render_guided_fused)
         int split_candidates = 0, added = 0;        // expand_voxels
         int sample_candidates = 0, resampled = 0;   // get_more_samples
         int pruned = 0;                             // prune_tree (-1: ran, nothing to prune)
@@ -82,6 +83,9 @@ struct VolumeRenderer {
     } stats;
     // Seed of the sample-position jitter (torch::rand in the reference); frame f uses (seed, f).
     uint64_t seed = 0;
+    // Guided-sampling frames run as one fused kernel when nothing but the picture is wanted from them (false: always the
+    // four-step path of the reference, cuda_renderer.cpp:107-139).
+    bool use_fused_guided = true;
     // Frames without a tree change after which the packed accel is rebuilt and used again.
     int accel_rebuild_after = 4;
 

@@ -1,0 +1,138 @@
+"""mnv_render_guided_fused (BASELINE.json configs[4]: the per-sample network fused into the march kernel) against the
+four-step path it replaces -- sample march on the accel, cumsum / mask compaction, mnv_query_submodules, CSR composite:
+same march, same MFMA sequence, same composite arithmetic, so frames are compared bit for bit.  The four-step path itself is
+pinned by tests/test_guided_gpu.py (kernels vs oracle vs the reference's device code) and tests/test_mlp_gpu.py."""
+import numpy as np
+import pytest
+
+import cases
+import mlp_cases
+from test_renderer_refine_gpu import make_grid
+
+pytestmark = pytest.mark.gpu
+
+
+def four_step_frame(mnv, torch, tree, cam, opt, mlp, grid, max_g, dim):
+    n_px = cam.width * cam.height
+    num = torch.zeros(n_px, dtype=torch.int16, device="cuda")
+    guided = torch.zeros((n_px, max_g, dim), dtype=torch.float32, device="cuda")
+    guided[:, :, 0] = -1
+    clusters = torch.zeros((n_px, max_g), dtype=torch.int16, device="cuda")
+    mnv.get_samples_from_voxels_accel(tree.accel, cam, opt, num, guided, clusters, grid)
+    offsets = torch.cumsum(num, 0)
+    flat = guided.view(-1, dim)
+    mask = flat[:, 0] >= 0
+    valid, valid_clusters = flat[mask], clusters.view(-1)[mask]
+    total = valid.shape[0]
+    values = torch.zeros((max(total, 1), tree.host_view().data_dim + 1), dtype=torch.float32, device="cuda")
+    if total:
+        mlp.query(valid_clusters, valid[:, 1:].contiguous(), values, n=total)
+    out = torch.empty((cam.height, cam.width, 4), dtype=torch.float32, device="cuda")
+    out8 = torch.empty((cam.height, cam.width, 4), dtype=torch.uint8, device="cuda")
+    mnv.render_nerf_results(tree.device_view(), cam, opt, values, valid[:, 0].contiguous(), offsets, rgba=out, rgba8=out8)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), out8.cpu().numpy(), total
+
+
+@pytest.mark.parametrize("case,need_viewdir,n_emb,max_g,n_clusters", [
+    ("rgba_d5", False, 0, 16, 6),
+    ("sh9_d7_aniso", False, 0, 128, 6),
+    ("sh4_d6", True, 0, 8, 6),
+    ("shell_d7_sh9", True, 3, 128, 6),
+    ("sh9_d7_aniso", False, 0, 3, 4),        # quota of 3 samples per ray; 4 networks for 6 grid cells: cells 4, 5 have no sub-module
+    ("sh16_d4", False, 0, 32, 6),
+])
+def test_fused_frame_equals_the_four_step_path(mnv, torch_gpu, case, need_viewdir, n_emb, max_g, n_clusters):
+    torch = torch_gpu
+    spec = cases.CASES[case]
+    tree = cases.make_tree(mnv, spec["tree"])
+    v = tree.host_view()
+    tree.move_to_device()
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    opt.basis_minmax[0], opt.basis_minmax[1] = 0, max(v.basis_dim - 1, 0)
+    opt.max_guided_samples = max_g
+    opt.need_viewdir = need_viewdir
+    opt.appearance_embedding = 1 if n_emb else -1
+    desc = mnv.mlp_desc(n_clusters=n_clusters, pos_octaves=4, dir_octaves=2, need_viewdir=need_viewdir, n_embeddings=n_emb, embedding_dim=8 if n_emb else 0,
+                        hidden_width=64, hidden_layers=2, out_dim=v.data_dim + 1)
+    mlp = mnv.Mlp(desc, mlp_cases.make_params(mnv, desc, seed=21))
+    grid = make_grid(mnv)
+    dim = 4 + (3 if need_viewdir else 0) + (1 if n_emb else 0)
+    ref, ref8, total = four_step_frame(mnv, torch, tree, cam, opt, mlp, grid, max_g, dim)
+    assert total > 0
+    out = torch.full((cam.height, cam.width, 4), float("nan"), dtype=torch.float32, device="cuda")
+    out8 = torch.zeros((cam.height, cam.width, 4), dtype=torch.uint8, device="cuda")
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+    mnv.render_guided_fused(tree.accel, cam, opt, mlp, grid, rgba=out, rgba8=out8, sample_counter=counter)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert int(counter.item()) == total
+    assert np.array_equal(cases.bits(got), cases.bits(ref)), float(np.nanmax(np.abs(got - ref)))
+    assert np.array_equal(out8.cpu().numpy(), ref8)
+
+
+def test_fused_frame_at_cfg2_size(mnv, torch_gpu):
+    """The 1.5 M-chunk depth-10 SH9 tree at 1920x1080: about 9 M network evaluations inside the march; ragged tile (a 1000x600
+    window) as well."""
+    torch = torch_gpu
+    tree = cases.make_tree(mnv, cases.CFG2_TREE)
+    v = tree.host_view()
+    tree.move_to_device()
+    opt = mnv.RenderOptions.cli_defaults()
+    opt.basis_minmax[1] = 8
+    opt.max_guided_samples = 64
+    desc = mnv.mlp_desc(n_clusters=6, pos_octaves=4, dir_octaves=2, need_viewdir=False, hidden_width=64, hidden_layers=2, out_dim=v.data_dim + 1)
+    mlp = mnv.Mlp(desc, mlp_cases.make_params(mnv, desc, seed=21))
+    grid = make_grid(mnv)
+    for (w, h) in ((1920, 1080), (1000, 600)):
+        cam = cases.cfg2_camera(mnv, 2, w, h, 1600.0 * w / 1920)
+        ref, ref8, total = four_step_frame(mnv, torch, tree, cam, opt, mlp, grid, 64, 4)
+        out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+        counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+        mnv.render_guided_fused(tree.accel, cam, opt, mlp, grid, rgba=out, sample_counter=counter)
+        torch.cuda.synchronize()
+        assert int(counter.item()) == total and (w < 1920 or total > 5_000_000)
+        assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref))
+
+
+def test_fused_frame_rejects_what_it_does_not_cover(mnv, torch_gpu):
+    torch = torch_gpu
+    spec = cases.CASES["rgba_d5"]
+    tree = cases.make_tree(mnv, spec["tree"])
+    tree.move_to_device()
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    out = torch.empty((cam.height, cam.width, 4), dtype=torch.float32, device="cuda")
+    wide = mnv.mlp_desc(n_clusters=2, pos_octaves=4, dir_octaves=2, need_viewdir=False, hidden_width=128, hidden_layers=2, out_dim=5)
+    with pytest.raises(mnv.MnvError):
+        mnv.render_guided_fused(tree.accel, cam, opt, mnv.Mlp(wide, mlp_cases.make_params(mnv, wide, seed=1)), make_grid(mnv), rgba=out)
+    ok = mnv.mlp_desc(n_clusters=2, pos_octaves=4, dir_octaves=2, need_viewdir=False, hidden_width=64, hidden_layers=2, out_dim=5)
+    m = mnv.Mlp(ok, mlp_cases.make_params(mnv, ok, seed=1))
+    opt.render_depth = True
+    with pytest.raises(mnv.MnvError):
+        mnv.render_guided_fused(tree.accel, cam, opt, m, make_grid(mnv), rgba=out)
+    opt.render_depth = False
+    bad = mnv.mlp_desc(n_clusters=2, pos_octaves=4, dir_octaves=2, need_viewdir=False, hidden_width=64, hidden_layers=2, out_dim=7)
+    with pytest.raises(mnv.MnvError):
+        mnv.render_guided_fused(tree.accel, cam, opt, mnv.Mlp(bad, mlp_cases.make_params(mnv, bad, seed=1)), make_grid(mnv), rgba=out)
+
+
+def test_volume_renderer_uses_the_fused_kernel_and_the_four_step_path_agrees(mnv, torch_gpu):
+    """VolumeRenderer::render with use_guided_sampling: the fused kernel when only the picture is wanted (stats.fused), the
+    four-step path when switched off or when the frame also feeds refinement; same frame either way."""
+    from test_renderer_refine_gpu import setup
+
+    frames = {}
+    for fused in (True, False):
+        r, tree, desc, params, cam_spec = setup(mnv, "sh9_d7_aniso", 4000, use_guided_sampling=True, max_guided_samples=24)
+        r.set_fused_guided(fused)
+        st = r.render()
+        assert st["fused"] == int(fused) and st["used_accel"] == 1 and st["guided_samples"] > 0
+        frames[fused] = (r.download(), st["guided_samples"])
+    assert frames[True][1] == frames[False][1]
+    assert np.array_equal(cases.bits(frames[True][0]), cases.bits(frames[False][0]))
+    # with splitting on, the frame must also produce the trackers: four-step path
+    r, tree, desc, params, cam_spec = setup(mnv, "sh9_d7_aniso", 4000, use_guided_sampling=True, use_splitting=True, max_guided_samples=24, max_depth=9)
+    st = r.render()
+    assert st["fused"] == 0 and st["guided_samples"] > 0

@@ -126,7 +126,7 @@ def test_cfg5_guided_sampling_frame_at_scale_matches_tensor_ops(mnv, torch_gpu):
     cam = _pose(mnv, r, 2)
     st = r.render()
     frame = r.download()
-    assert st["guided_samples"] > 5_000_000 and st["used_accel"] == 1
+    assert st["guided_samples"] > 5_000_000 and st["used_accel"] == 1 and st["fused"] == 1   # one kernel: march + networks + composite
     opt = mnv.RenderOptions()
     C.memmove(C.byref(opt), C.byref(r.options), C.sizeof(opt))
     dv = tree.device_view()
