@@ -1,0 +1,2 @@
+export TMPDIR=/tmp
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -8
