@@ -304,6 +304,21 @@ int mnv_get_samples_from_voxels_accel(const mnv_accel *accel, const mnv_camera *
                                       void *hip_stream);
 
 /*
+ * Both tracker marches on the packed accel WITH visit marks (the role of render_voxels / get_samples_from_voxels called with
+ * track_visit = true, cuda_renderer.cpp:101-102,112-114,141-142).  The reference marks every chunk of every descent
+ * (query_single_from_root, rt_core.cuh:132-134); the packed layout skips most of the descent, so the march marks the chunk of every
+ * leaf it steps through and a second small kernel closes the marks under `parent` -- the same array, element for element.
+ * `visited` NULL = the plain tracker entry points; `parent` is the tree's device parent array [capacity].
+ */
+int mnv_render_voxels_accel_visit(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, float *rgba_out,
+                                  uint8_t *rgba8_out, float *split_track, float *sample_track, const int16_t *sample_counts, int32_t *visited,
+                                  const int32_t *parent, void *hip_stream);
+int mnv_get_samples_from_voxels_accel_visit(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                                            float *split_track, float *sample_track, const int16_t *sample_counts, int32_t *visited,
+                                            const int32_t *parent, int16_t *num_samples, float *samples, int32_t samples_dim,
+                                            int16_t *cluster_indices, const mnv_cluster_grid *grid, void *hip_stream);
+
+/*
  * viewer::render_nerf_results (include/cuda/renderer_kernel.hpp:12-21,
  * src/cuda/renderer_kernel.cu:294-327,365-394; rt_core.cuh:334-416), offscreen: composites
  * per-sample network outputs along every ray.

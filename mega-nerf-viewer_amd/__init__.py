@@ -219,6 +219,11 @@ _SIGNATURES = {
                                               C.c_void_p, C.POINTER(ClusterGrid), C.c_void_p]),
     "mnv_get_samples_from_voxels_accel": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(ClusterGrid), C.c_void_p]),
+    "mnv_render_voxels_accel_visit": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mnv_get_samples_from_voxels_accel_visit": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.c_void_p, C.c_void_p,
+                                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                                          C.POINTER(ClusterGrid), C.c_void_p]),
     "mnv_render_guided_fused": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.c_void_p, C.POINTER(ClusterGrid),
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_render_nerf_results": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
@@ -550,6 +555,24 @@ def render_voxels_accel_track(accel: int, cam: Camera, opt: RenderOptions, tile=
     _check(lib().mnv_render_voxels_accel_track(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba),
                                                _ptr(rgba8), _ptr(split_track), _ptr(sample_track), _ptr(sample_counts),
                                                C.c_void_p(stream)))
+
+
+def render_voxels_accel_visit(accel: int, cam: Camera, opt: RenderOptions, visited, parent, tile=None, rgba=None, rgba8=None, split_track=None,
+                              sample_track=None, sample_counts=None, stream: int = 0) -> None:
+    """Tracker march on the packed accel that also leaves the reference's visit marks (march marks leaf chunks, closure adds ancestors)."""
+    if tile is None:
+        tile = (0, 0, cam.width, cam.height)
+    _check(lib().mnv_render_voxels_accel_visit(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba), _ptr(rgba8), _ptr(split_track),
+                                               _ptr(sample_track), _ptr(sample_counts), _ptr(visited), _ptr(parent), C.c_void_p(stream)))
+
+
+def get_samples_from_voxels_accel_visit(accel: int, cam: Camera, opt: RenderOptions, visited, parent, num_samples, samples, cluster_indices,
+                                        grid: ClusterGrid, split_track=None, sample_track=None, sample_counts=None, tile=None, stream: int = 0) -> None:
+    if tile is None:
+        tile = (0, 0, cam.width, cam.height)
+    _check(lib().mnv_get_samples_from_voxels_accel_visit(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(split_track), _ptr(sample_track),
+                                                         _ptr(sample_counts), _ptr(visited), _ptr(parent), _ptr(num_samples), _ptr(samples),
+                                                         int(samples.shape[-1]), _ptr(cluster_indices), C.byref(grid), C.c_void_p(stream)))
 
 
 def set_colour_math(fast: bool) -> None:

@@ -245,6 +245,21 @@ __global__ void stage_launch_kernel(uint32_t *heads, int32_t head_words, CamBloc
         reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(cams.c)[i];
 }
 
+// Visit marks on the packed layout: the march marks the chunk that holds each leaf it steps through; the reference marks every
+// chunk of every descent (query_single_from_root, rt_core.cuh:132-134), i.e. those chunks and all their ancestors.  One thread
+// per marked chunk walks up the parent words until it meets a chunk that is marked already.
+__global__ void close_visit_marks(int32_t *visited, const int32_t *parent, int32_t capacity) {
+    const int32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= capacity || c == 0 || visited[c] == 0) return;
+    int32_t p = parent[c] >> 3;
+    while (p >= 0 && p < capacity) {
+        if (__hip_atomic_load(&visited[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+        visited[p] = 1;
+        if (p == 0) break;
+        p = parent[p] >> 3;
+    }
+}
+
 // ------------------------------------------------------------------------ march kernel
 
 struct AccelLaunch {
@@ -272,6 +287,8 @@ struct AccelLaunch {
     float *split_track, *sample_track;
     const int16_t *sample_counts;         // reference layout [capacity][8], may be NULL
     int32_t max_depth, max_sample_count;
+    int32_t *visited;                     // MODE 2 / 3 only: visit marks [capacity]; the march marks the chunk of every leaf it steps through,
+                                          // close_visit_marks adds the ancestors (= every chunk of every descent, rt_core.cuh:132-134)
     int32_t ablate;                       // diagnostics only (breaks results): 1 no colour, 2 no dense samples, 4 cached rows
     // MODE 3 only: the sample-emitting march of guided sampling (rt_core.cuh:418-576) -- no colour, rows of
     // (z, world xyz[, view dir][, embedding]) per dense step and the trackers of MODE 2
@@ -649,11 +666,15 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                 const float sigma = half_bits_to_float((uint16_t)word);
                 const bool is_dense = sigma > P.sigma_thresh && !ablate(2);
                 bool need_vox = is_dense;
-                if constexpr (MODE == 2 || MODE == 3) need_vox = is_dense || max_weight == -1.f || max_sample_weight == -1.f;
+                if constexpr (MODE == 2 || MODE == 3) need_vox = is_dense || max_weight == -1.f || max_sample_weight == -1.f || K.visited != nullptr;
                 if (need_vox) {
                     // voxel index of a leaf that was answered by one of the lookup grids
                     if (src == 0) vox = A.grid_vox[((((q[0] >> shg) << A.grid_level) + (q[1] >> shg)) << A.grid_level) + (q[2] >> shg)];
                     else if (src == 1) vox = A.grid2_vox[vox];
+                }
+                if constexpr (MODE == 2 || MODE == 3) {
+                    // the mark only ever goes 0 -> 1: load + conditional plain store (mnv_march_ref_layout.hip does the same per level)
+                    if (K.visited && __hip_atomic_load(&K.visited[vox >> 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) K.visited[vox >> 3] = 1;
                 }
                 if (is_dense) {
                     // opacity of a dense sample, rt_core.cuh:233-235
@@ -852,7 +873,7 @@ static int launch_variant(const AccelLaunch &K, int n_blocks, size_t lds_bytes, 
     if constexpr (BASIS == 9) {  // the sample-emitting march reads no colour rows: one instantiation serves every row format
         if (K.samples) return launch_variant2<BASIS, 3>(K, n_blocks, lds_bytes, stream);
     }
-    if (K.split_track || K.sample_track) return launch_variant2<BASIS, 2>(K, n_blocks, lds_bytes, stream);
+    if (K.split_track || K.sample_track || K.visited) return launch_variant2<BASIS, 2>(K, n_blocks, lds_bytes, stream);
     if constexpr (BASIS == 9) {  // the depth image reads no colour rows either
         if (K.P.render_depth) return launch_variant2<BASIS, 5>(K, n_blocks, lds_bytes, stream);
     }
@@ -884,6 +905,8 @@ struct AccelTrack {
     int32_t max_guided_samples, samples_dim, need_viewdir, appearance_embedding;
     const mnv_cluster_grid *grid;
     const FusedGuided *fused;  // non-NULL: guided_fused_kernel instead of the march (no trackers, one frame)
+    int32_t *visited;          // visit marks (tracker / sample modes) ...
+    const int32_t *parent;     // ... closed under the parent words after the march
 };
 
 constexpr int kUnsupportedBasis = -1000;  // not a hipError_t
@@ -900,6 +923,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
         K.sample_counts = track->sample_counts;
         K.max_depth = track->max_depth;
         K.max_sample_count = track->max_sample_count;
+        K.visited = track->visited;
         if (track->samples) {
             K.num_samples = track->num_samples;
             K.samples = track->samples;
@@ -991,7 +1015,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     if (env_level >= 1 && env_level <= accel->view.grid_level) lds_level = env_level;
     K.lds_level = lds_level;
     // sample emission and the depth image read no colour rows: one instantiation (BASIS 9) serves every row format
-    const bool colourless = K.samples != nullptr || (P.render_depth && !K.split_track && !K.sample_track);
+    const bool colourless = K.samples != nullptr || (P.render_depth && !K.split_track && !K.sample_track && !K.visited);
     const int nb_lds = colourless ? 9 : (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim > 0) ? accel->view.basis_dim : 1;
     const size_t lds_bytes = 256 + 256 * 4 + (size_t)(nb_lds + 2) * 256 * 4 + ((size_t)4 << (3 * lds_level));
     static const int env_bpc = getenv("MNV_BLOCKS_PER_CU") ? atoi(getenv("MNV_BLOCKS_PER_CU")) : 0;
@@ -1004,7 +1028,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     K.count_stats = env_stats ? 1 : 0;
     K.refill_min = (env_refill > 0 && n_frames == 1) ? env_refill : 64;  // batches refill whole tiles (a grab must not straddle frames);  // sweep in DESIGN.md: 16 -> 0.606 ms, 32 -> 0.535, 48 -> 0.507, 56 -> 0.504, 64 -> 0.506
     int blocks_per_cu = lds_level >= 5 ? 1 : (lds_level == 4 ? 6 : 8);
-    if ((K.split_track || K.sample_track || K.samples) && blocks_per_cu > MNV_TRACK_WAVES) blocks_per_cu = MNV_TRACK_WAVES;
+    if ((K.split_track || K.sample_track || K.samples || K.visited) && blocks_per_cu > MNV_TRACK_WAVES) blocks_per_cu = MNV_TRACK_WAVES;
     if (env_bpc > 0) blocks_per_cu = env_bpc;
     int n_blocks = accel->num_cus * blocks_per_cu;
     const uint64_t n_waves_needed = (uint64_t)K.n_tiles * (uint64_t)n_frames;  // one initial 8x8 tile per wave
@@ -1064,6 +1088,11 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
             case 25: rc = launch_variant<25>(K, n_blocks, lds_bytes, stream); break;
             default: break;
         }
+    if (rc == 0 && K.visited && track->parent) {
+        hipLaunchKernelGGL(close_visit_marks, dim3((unsigned)((accel->view.capacity + 255) / 256)), dim3(256), 0, stream, K.visited, track->parent,
+                           accel->view.capacity);
+        rc = (int)hipGetLastError();
+    }
     if (rc == 0) {
         rc = (int)hipEventRecord(mut->slot_done[slot], stream);
         mut->slot_used[slot] = true;
@@ -1432,10 +1461,37 @@ int mnv_render_voxels_accel_track(const mnv_accel *accel, const mnv_camera *cam,
     return render_accel(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, &track, hip_stream);
 }
 
+int mnv_render_voxels_accel_visit(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, float *rgba_out,
+                                  uint8_t *rgba8_out, float *split_track, float *sample_track, const int16_t *sample_counts, int32_t *visited,
+                                  const int32_t *parent, void *hip_stream) {
+    if (!opt) return set_error(MNV_E_INVALID, "options are null");
+    if (!visited) return mnv_render_voxels_accel_track(accel, cam, opt, tile, rgba_out, rgba8_out, split_track, sample_track, sample_counts, hip_stream);
+    if (!parent) return set_error(MNV_E_INVALID, "visit marks on the packed layout need the parent array (the ancestors of the marked chunks)");
+    const mnv_partition whole = {0, 1, 0, 0, 0};
+    AccelTrack track = {};
+    track.split_track = split_track;
+    track.sample_track = sample_track;
+    track.sample_counts = sample_counts;
+    track.max_depth = opt->max_depth;
+    track.max_sample_count = opt->max_sample_count;
+    track.visited = visited;
+    track.parent = parent;
+    return render_accel(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, &track, hip_stream);
+}
+
 int mnv_get_samples_from_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
                                       float *split_track, float *sample_track, const int16_t *sample_counts, int16_t *num_samples,
                                       float *samples, int32_t samples_dim, int16_t *cluster_indices, const mnv_cluster_grid *grid,
                                       void *hip_stream) {
+    return mnv_get_samples_from_voxels_accel_visit(accel, cam, opt, tile, split_track, sample_track, sample_counts, nullptr, nullptr, num_samples,
+                                                   samples, samples_dim, cluster_indices, grid, hip_stream);
+}
+
+int mnv_get_samples_from_voxels_accel_visit(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                                            float *split_track, float *sample_track, const int16_t *sample_counts, int32_t *visited,
+                                            const int32_t *parent, int16_t *num_samples, float *samples, int32_t samples_dim,
+                                            int16_t *cluster_indices, const mnv_cluster_grid *grid, void *hip_stream) {
+    if (visited && !parent) return set_error(MNV_E_INVALID, "visit marks on the packed layout need the parent array (the ancestors of the marked chunks)");
     if (!opt || !num_samples || !samples || !cluster_indices || !grid) return set_error(MNV_E_INVALID, "null argument");
     const int need = 4 + (opt->need_viewdir ? 3 : 0) + (opt->appearance_embedding != -1 ? 1 : 0);
     if (samples_dim != need) return set_error(MNV_E_INVALID, "samples_dim must be 4 + 3 * need_viewdir + (appearance_embedding != -1)");
@@ -1454,6 +1510,8 @@ int mnv_get_samples_from_voxels_accel(const mnv_accel *accel, const mnv_camera *
     track.need_viewdir = opt->need_viewdir ? 1 : 0;
     track.appearance_embedding = opt->appearance_embedding;
     track.grid = grid;
+    track.visited = visited;
+    track.parent = parent;
     const mnv_partition whole = {0, 1, 0, 0, 0};
     return render_accel(accel, cam, 1, opt, tile, whole, nullptr, nullptr, &track, hip_stream);
 }

@@ -71,6 +71,55 @@ def test_trackers_and_visited_match_oracle(mnv, orc, torch_gpu):
     assert np.array_equal(visited.cpu().numpy(), visited_ref)
 
 
+@pytest.mark.parametrize("name", ["sh4_d6", "shell_d7_sh9", "rgba_d5", "terrain_d7_aniso", "cfg1_sh1_d4", "camera_inside", "ray_miss"])
+def test_accel_visit_marks_equal_the_reference_layout_kernels(mnv, orc, torch_gpu, name):
+    """mnv_render_voxels_accel_visit: the tuned kernel marks the chunk of every leaf it steps through and a closure pass adds the
+    ancestors -- the array the reference's per-level marking leaves (rt_core.cuh:132-134), element for element; trackers and frame
+    unchanged.  Checked against the oracle and the reference-layout kernel, also without trackers and in the sample march."""
+    torch = torch_gpu
+    spec = cases.CASES[name]
+    tree = cases.make_tree(mnv, spec["tree"])
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    opt.max_depth, opt.max_sample_count = 5, 9
+    v = tree.host_view()
+    sc = np.full((v.capacity, 8), 8, np.int16)
+    sc[::3] = 12
+    visited_ref = np.zeros(v.capacity, np.int32)
+    ref = orc.render(orc.tree_from_view(v, sample_counts=sc), cam.c, opt, want_trackers=True, visited=visited_ref, track_visit=True)
+    tree.move_to_device(need_parent=True, need_sample_counts=True)
+    dv = tree.device_view()
+    sc_dev = torch.from_numpy(sc).cuda()
+    parent = dv.parent
+    assert parent
+    h, w = cam.height, cam.width
+    rgba = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    split = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")
+    sample = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")
+    visited = torch.zeros(v.capacity, dtype=torch.int32, device="cuda")
+    mnv.render_voxels_accel_visit(tree.accel, cam, opt, visited, parent, rgba=rgba, split_track=split, sample_track=sample, sample_counts=sc_dev)
+    torch.cuda.synchronize()
+    assert np.array_equal(cases.bits(rgba.cpu().numpy()), cases.bits(ref["rgba"]))
+    assert np.array_equal(split.cpu().numpy(), ref["split"]) and np.array_equal(sample.cpu().numpy(), ref["sample"])
+    assert np.array_equal(visited.cpu().numpy(), visited_ref)
+    # marks only (no trackers asked for)
+    visited2 = torch.zeros(v.capacity, dtype=torch.int32, device="cuda")
+    mnv.render_voxels_accel_visit(tree.accel, cam, opt, visited2, parent, rgba=rgba)
+    torch.cuda.synchronize()
+    assert torch.equal(visited2, visited) and np.array_equal(cases.bits(rgba.cpu().numpy()), cases.bits(ref["rgba"]))
+    # the sample-emitting march leaves the same marks (same steps)
+    from test_renderer_refine_gpu import make_grid
+    opt.max_guided_samples = 8
+    n_px = h * w
+    num = torch.zeros(n_px, dtype=torch.int16, device="cuda")
+    guided = torch.zeros((n_px, 8, 4), dtype=torch.float32, device="cuda")
+    clusters = torch.zeros((n_px, 8), dtype=torch.int16, device="cuda")
+    visited3 = torch.zeros(v.capacity, dtype=torch.int32, device="cuda")
+    mnv.get_samples_from_voxels_accel_visit(tree.accel, cam, opt, visited3, parent, num, guided, clusters, make_grid(mnv))
+    torch.cuda.synchronize()
+    assert torch.equal(visited3, visited)
+
+
 @pytest.mark.parametrize("name,max_depth,with_counts", [("sh4_d6", 5, True), ("shell_d7_sh9", 7, True), ("rgba_d5", 3, False),
                                                         ("terrain_d7_aniso", 6, True), ("cfg1_sh1_d4", 9, True)])
 def test_accel_trackers_match_oracle(mnv, orc, torch_gpu, name, max_depth, with_counts):

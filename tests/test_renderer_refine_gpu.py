@@ -255,15 +255,17 @@ def test_prune_runs_inside_the_loop(mnv, torch_gpu):
     assert log[0]["track_visit"] == 0 and log[0]["pruned"] == 0 and 0 < log[0]["added"] <= 600
     assert log[1]["track_visit"] == 1 and log[1]["pruned"] > 0 and log[1]["capacity"] < cap0
     assert log[2]["track_visit"] == 1  # prune_happened (cuda_renderer.cpp:101-102)
+    # visit-mark frames run on the packed accel too (leaf chunks marked by the march, ancestors by the closure pass), and the prune
+    # rebuilds the accel in place: no frame of the loop falls back to the reference-layout kernel
+    assert [st["used_accel"] for st in log] == [1, 1, 1, 1]
     r.sync_tree()
     data, child, parent = tree.host_arrays()
     assert child.shape[0] == tree.capacity == log[-1]["capacity"]
     check_tree_links(child, parent, tree.capacity)
     assert np.isfinite(r.download()).all()
-    # the prune invalidated the packed accel; it is rebuilt accel_rebuild_after frames later and in use again
     r.options.max_depth, r.options.max_sample_count = 1, -30000
     used = [r.render()["used_accel"] for _ in range(8)]
-    assert used[-1] == 1
+    assert used == [1] * 8
     assert _accel_equals_reference_layout(mnv, torch_gpu, tree, cam_spec, "sh4_d6")
 
 
@@ -275,7 +277,7 @@ def test_prune_on_the_first_frame_when_the_tree_is_nearly_full(mnv, orc, torch_g
     tree0 = cases.make_tree(mnv, cases.CASES["sh4_d6"]["tree"])
     cap0 = tree.capacity
     st = r.render()
-    assert st["track_visit"] == 1 and st["used_accel"] == 0 and st["added"] == 24 and st["pruned"] > 0
+    assert st["track_visit"] == 1 and st["used_accel"] == 1 and st["added"] == 24 and st["pruned"] > 0
     assert st["capacity"] == cap0 + 24 - st["pruned"]
     frame = r.download()
     cam = cases.make_camera(mnv, cam_spec)
@@ -289,13 +291,13 @@ def test_prune_on_the_first_frame_when_the_tree_is_nearly_full(mnv, orc, torch_g
     check_tree_links(child, parent, tree.capacity)
 
 
-@pytest.mark.parametrize("extra,accel_path", [(0, 0), (4000, 1)])
+@pytest.mark.parametrize("extra,accel_path", [(0, 1), (4000, 1)])
 def test_guided_sampling_frame_matches_reference_tensor_ops(mnv, torch_gpu, extra, accel_path):
     """use_guided_sampling: get_samples -> compaction -> networks -> composite.  The compaction is compared with the
     reference's own expressions (cuda_renderer.cpp:116-121: cumsum, boolean mask on column 0) run by torch."""
     torch = torch_gpu
-    # extra = 0: capacity > 3/4 max, the first frame tracks visits and samples on the reference layout; with room to grow the
-    # samples come from the packed accel (mnv_get_samples_from_voxels_accel) -- the same rows either way
+    # extra = 0: capacity > 3/4 max, the first frame also tracks visits (four-step path, sample march on the accel with visit marks);
+    # with room to grow it is the fused kernel -- the same picture either way
     r, tree, desc, params, cam_spec = setup(mnv, "rgba_d5", extra, use_guided_sampling=True, max_guided_samples=16)
     st = r.render()
     frame = r.download()
