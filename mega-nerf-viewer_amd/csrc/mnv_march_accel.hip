@@ -448,6 +448,37 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
         }
     };
 
+    // A finished ray only records HOW it ended (fin: 1 loop exit, 2 early stop, 3 missed the bounding box); its lane idles until the
+    // wavefront refills anyway, so the end-of-ray arithmetic and the pixel / tracker stores run once per tile for all its lanes
+    // instead of once per iteration in which some ray ends (one or two lanes at a time: ~6 % of the kernel's VALU issue).
+    int fin = 0;
+    auto flush_finished = [&]() {
+        if (fin != 0) {
+            float a;
+            if (fin == 3) {
+                o0 = o1 = o2 = 0.f;
+                a = depth_mode() ? 1.f : 0.f;
+            } else if (fin == 1) {  // rt_core.cuh:325-330
+                a = 1.f - T;
+                if (depth_mode()) {
+                    o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
+                    a = 1.f;
+                }
+            } else {  // rt_core.cuh:295-307
+                if (depth_mode()) o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
+                const float sc = 1.f / (1.f - T);
+                o0 *= sc;
+                o1 *= sc;
+                o2 *= sc;
+                a = 1.f;
+            }
+            const uint32_t p = __float_as_uint(my_ray[(NB + 1) * BLOCK]);
+            if constexpr (MODE != 3) composite_and_write(P, (int64_t)p, o0, o1, o2, a);
+            write_trackers(p);
+            fin = 0;
+        }
+    };
+
     // ray queues: queue q holds band q (a contiguous run of 8x8 tiles) of EVERY frame of the batch, frame-major, behind one
     // head; a wavefront drains its home queue (workgroup b -> XCD b % 8), then steals round robin.  A batch is refilled a
     // whole tile at a time (refill_min = 64), so a grab never straddles two frames and the camera stays wave-uniform; the
@@ -492,6 +523,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
         if constexpr (MODE == 1) ++tl_iters;
         // Tile-sized refills keep a wavefront's rays coherent (sweep in DESIGN.md).
         if (!drained && n_idle >= K.refill_min) {
+            flush_finished();  // the idle lanes' pixels, before they take new rays
             if (qsel >= kNumQueues) {
                 drained = true;
             } else {
@@ -575,8 +607,8 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                             my_ray[NB * BLOCK] = r.delta_scale;
                             my_ray[(NB + 1) * BLOCK] = __uint_as_float(pix);
                         } else {
-                            if constexpr (MODE != 3) composite_and_write(P, (int64_t)pix, 0.f, 0.f, 0.f, depth_mode() ? 1.f : 0.f);
-                            write_trackers(pix);
+                            my_ray[(NB + 1) * BLOCK] = __uint_as_float(pix);
+                            fin = 3;  // the ray misses the bounding box: background pixel, written with the tile's others
                         }
                     }
                 }
@@ -590,7 +622,10 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                     tl_rec = ~0u;
                 }
             }
-            if (drained) break;
+            if (drained) {
+                flush_finished();
+                break;
+            }
             continue;
         }
         // ---- one march step (rt_core.cuh:220-323) for every live lane
@@ -599,14 +634,8 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
         uint32_t vox = 0;
         if (alive) {
             if (!(t < tmax)) {
-                // loop exit, rt_core.cuh:325-330
-                float a = 1.f - T;
-                if (depth_mode()) {
-                    o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
-                    a = 1.f;
-                }
-                if constexpr (MODE != 3) composite_and_write(P, (int64_t)__float_as_uint(my_ray[(NB + 1) * BLOCK]), o0, o1, o2, a);
-                write_trackers(__float_as_uint(my_ray[(NB + 1) * BLOCK]));
+                // loop exit, rt_core.cuh:325-330: the pixel is finished in flush_finished()
+                fin = 1;
                 alive = false;
             } else {
                 stat(4, true);
@@ -802,13 +831,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
             if (dense) {
                 T *= att;  // rt_core.cuh:293-307
                 if (T < P.stop_thresh) {
-                    if (depth_mode()) o0 = o1 = o2 = fminf(o0 * 0.3f, 1.0f);
-                    const float sc = 1.f / (1.f - T);
-                    o0 *= sc;
-                    o1 *= sc;
-                    o2 *= sc;
-                    if constexpr (MODE != 3) composite_and_write(P, (int64_t)__float_as_uint(my_ray[(NB + 1) * BLOCK]), o0, o1, o2, 1.f);
-                    write_trackers(__float_as_uint(my_ray[(NB + 1) * BLOCK]));
+                    fin = 2;  // early stop: renormalised and written in flush_finished()
                     alive = false;
                 }
             }
