@@ -80,6 +80,13 @@ def test_mnv_render_multi_gpu_mode_with_one_rank(mnv, orc, torch_gpu, tmp_path):
     # a rank that fails takes the run down with a non-zero status instead of hanging its peers
     r3 = subprocess.run([EXE, str(tmp_path / "missing.npz"), "--gpus", "1"], capture_output=True, text=True, timeout=120)
     assert r3.returncode != 0 and "rank 0" in r3.stderr
+    if torch_gpu.cuda.device_count() == 1:
+        # two ranks need two GPUs: rank 1 finds no device (or RCCL refuses the duplicate), rank 0 is taken down with it
+        r4 = subprocess.run(common + ["--gpus", "2"], capture_output=True, text=True, timeout=180)
+        assert r4.returncode != 0 and "rank" in r4.stderr
+    # refinement mutates the tree: not combined with --gpus
+    r5 = subprocess.run(common + ["--gpus", "1", "--model_path", npz], capture_output=True, text=True, timeout=120)
+    assert r5.returncode != 0 and "refinement" in r5.stderr
 
 
 def test_mnv_render_cli_errors(tmp_path, mnv, torch_gpu):
