@@ -793,7 +793,25 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                     float v = 0.f;
                     if (task) {
                         constexpr int NW = CHAN_BYTES / 4;
-                        const ChanWords<NW> cw = *reinterpret_cast<const ChanWords<NW> *>(A.rows + (int64_t)vx * ROW_BYTES + my_c * CHAN_BYTES);
+                        ChanWords<NW> cw;
+#if defined(MNV_ROW_POLICY)
+                        if constexpr (NW == 5) {
+                            // A/B (tools/build_variant.sh -DMNV_ROW_POLICY=1|2|3): cache-policy bits on the row loads -- sc0, sc1 or both
+                            const uint8_t *ra = A.rows + (int64_t)vx * ROW_BYTES + my_c * CHAN_BYTES;
+                            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                            u4 q4;
+                            uint32_t q1;
+#if MNV_ROW_POLICY == 1
+                            asm volatile("global_load_dwordx4 %0, %2, off sc0\n\tglobal_load_dword %1, %2, off offset:16 sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(q4), "=&v"(q1) : "v"(ra) : "memory");
+#elif MNV_ROW_POLICY == 2
+                            asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dword %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q4), "=&v"(q1) : "v"(ra) : "memory");
+#else
+                            asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dword %1, %2, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q4), "=&v"(q1) : "v"(ra) : "memory");
+#endif
+                            cw.w[0] = q4.x; cw.w[1] = q4.y; cw.w[2] = q4.z; cw.w[3] = q4.w; cw.w[4] = q1;
+                        } else
+#endif
+                        cw = *reinterpret_cast<const ChanWords<NW> *>(A.rows + (int64_t)vx * ROW_BYTES + my_c * CHAN_BYTES);
                         auto coef = [&](int k) -> float {
                             const uint32_t wd = cw.w[k >> 1];
                             return half_bits_to_float((uint16_t)((k & 1) ? (wd >> 16) : (wd & 0xffffu)));
