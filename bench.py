@@ -409,8 +409,11 @@ def main():
                     "frames_per_launch": frames_per_launch,
                     "avg_launch_ms": round(avg_ms, 5), "launches": launches,
                     "algorithmic_bytes_per_launch": int(per_launch)}
-        if n_march_streams > 1:
-            roofline["note"] = "consecutive launches run on two streams and overlap: each launch's event interval includes the share of the device it left to its neighbour"
+        if multi:
+            roofline["approximate"] = True
+            roofline["note"] = ("rank 0's launches only; algorithmic bytes = the frame's bytes / world (rank 0 owns a little less, see root_period)"
+                                + ("; consecutive launches run on two streams and overlap: each launch's event interval includes the share of the "
+                                   "device it left to its neighbour" if n_march_streams > 1 else ""))
 
     if rank == 0:
         line = {

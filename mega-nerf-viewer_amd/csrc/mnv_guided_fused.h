@@ -48,9 +48,10 @@ struct FusedGuided {
 // [NB + 3][256] floats (SH basis, view direction) | per wavefront: network tile of 16 * mt_out features x 64 columns (the first
 // 4 KB double as the encode tile), sample pool 6 x 128 words, per-column results 4 x 64 floats
 constexpr int kPool = 128;  // ring capacity: a pass is due at 64 entries and one march step adds at most 64
-__host__ __device__ inline size_t fused_wave_words(int mt_out) { return (size_t)(mt_out * 16 > 16 ? mt_out * 16 : 16) * 64 + 6 * kPool + 4 * 64; }
-__host__ __device__ inline size_t fused_lds_bytes(int nb, int lds_level, int mt_out) {
-    return 256 + ((size_t)4 << (3 * lds_level)) + (size_t)(nb + 3) * 256 * 4 + 4 * fused_wave_words(mt_out) * 4;
+__host__ __device__ inline int fused_tile_words(int mt_out, int nkk0) { return (mt_out > nkk0 ? mt_out : nkk0) * 16 * 64; }  // outputs, or one 4 KB encode tile per K tile
+__host__ __device__ inline size_t fused_wave_words(int mt_out, int nkk0) { return (size_t)fused_tile_words(mt_out, nkk0) + 6 * kPool + 4 * 64; }
+__host__ __device__ inline size_t fused_lds_bytes(int nb, int lds_level, int mt_out, int nkk0) {
+    return 256 + ((size_t)4 << (3 * lds_level)) + (size_t)(nb + 3) * 256 * 4 + 4 * fused_wave_words(mt_out, nkk0) * 4;
 }
 
 #ifndef MNV_FUSED_WAVES
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
     const int cells = 1 << (3 * LL);
     uint32_t *s_grid = s_mem + 64;
     float *s_ray = reinterpret_cast<float *>(s_grid + cells);  // [k][thread]: k < NB basis, then vdir[3]
-    const int tile_words = (S.mt_out * 16 > 16 ? S.mt_out * 16 : 16) * 64;
-    uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_ray + (NB + 3) * BLOCK) + (threadIdx.x >> 6) * fused_wave_words(S.mt_out);  // this wavefront's LDS
+    const int tile_words = fused_tile_words(S.mt_out, NKK0);
+    uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_ray + (NB + 3) * BLOCK) + (threadIdx.x >> 6) * fused_wave_words(S.mt_out, NKK0);  // this wavefront's LDS
     float *s_out = reinterpret_cast<float *>(s_tile);
     float *s_px = s_out + tile_words, *s_py = s_px + kPool, *s_pz = s_py + kPool, *s_pd = s_pz + kPool;  // pool: world xyz, delta z
     uint32_t *s_pm = reinterpret_cast<uint32_t *>(s_pd + kPool), *s_pn = s_pm + kPool;  // owner | last << 6 | cluster << 8; owner's next slot
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
     uint32_t first_pending = kNone, prev_slot = kNone;  // pool slots (monotonic numbers): oldest sample not yet composited, last one pushed
     float ti = 1.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;  // composite state (render_nerf_results)
     int n_eval = 0, n_batches = 0, n_steps = 0, n_cut = 0, n_drain = 0;
+    unsigned long long t_net = 0, t_enc = 0, t_hid = 0, t_eval = 0, t_apply = 0, t_all = F.diag ? wall_clock64() : 0;  // diagnostics: 100 MHz ticks
     uint32_t head = 0, tail = 0;             // pool bounds (wave-uniform, monotonic; slot = number & (kPool - 1))
 
     const uint32_t home = blockIdx.x % kNumQueues;
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
         //      the next march step then adds at most 64 and the ring of 128 cannot overflow)
         const bool more_to_come = __ballot(has_ray && (!done || held)) != 0;
         while (tail - head >= (uint32_t)F.batch_min || (tail != head && !more_to_come)) {
+            const unsigned long long t_w0 = F.diag ? wall_clock64() : 0;
             const uint32_t size = tail - head;
             if (size < (uint32_t)F.batch_min) ++n_drain;
             const int n = size < 64u ? (int)size : 64;
@@ -333,13 +336,14 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                 }
                 const half8 *w = reinterpret_cast<const half8 *>(F.frags + (size_t)c_star * S.frag_halfs);
                 const float *b = F.biases + (size_t)c_star * S.bias_floats;
-                // The weight fragments come from global memory (L2): with two or three wavefronts per SIMD nothing hides a
-                // load issued right before its MFMA, so the fragments of a layer are requested one layer ahead -- layer 0's
-                // before the encode, layer l + 1's before layer l's MFMAs -- and wait in registers (8 fragments per layer).
+                // The weight fragments come from global memory (L2, 16 KB for the 64x2 network): a layer's 8 fragments are requested
+                // before the work that precedes its MFMAs (layer 0: the encode; later layers: the ReLU + float -> half conversion of
+                // the previous accumulators) and wait in 32 registers.  (Requesting one layer further ahead cost 48 more live
+                // registers: the allocator then spilled ray state that the encode loop reloads in every iteration.)
                 constexpr int kFr = MT * (MT / 2);  // fragments of a hidden layer; the output layer's (2 * mt_out) are read as 8 as well
                                                     // (the arrays are padded, mnv_mlp_create), so every fetch is 8 unconditional loads
-                half8 cur[kFr], nxt[kFr];
-                f32x4 bias_cur[MT], bias_nxt[MT];
+                half8 cur[kFr];
+                f32x4 bias_cur[MT];
                 auto fetch = [&](half8 *dst, f32x4 *bdst, const half8 *src, const float *bsrc) {
 #pragma unroll
                     for (int i = 0; i < kFr; ++i) dst[i] = src[i * 64 + lane];
@@ -349,29 +353,40 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                 constexpr int n0 = MT * NKK0;  // layer 0: fragment (mt, kk) at index mt * NKK0 + kk
                 static_assert(n0 <= kFr, "layer 0 is prefetched whole");
                 fetch(cur, bias_cur, w, b);
+                const unsigned long long t_e0 = F.diag ? wall_clock64() : 0;
                 f32x4 acc[MT][kNT];
-                // layer 0: every lane encodes its own sample; the half pairs cross over through the LDS tile
-                const int emb_base = S.n_pos + S.n_dir;
+                // layer 0.  Every lane encodes its own column: feature f goes, as a half, to the slot of the MFMA B operand that
+                // slot_feature() assigns it (K tile f >> 5, lane group and element from f & 31), one 4 KB tile per K tile.  Straight-line
+                // per octave -- the generic encode_feature() loop of mlp_forward_kernel re-reads the network shape from the kernel
+                // arguments in every iteration, which this kernel's scalar-register pressure turned into 12 k cycles per run.
+                {
+                    _Float16 *tile_h = reinterpret_cast<_Float16 *>(s_tile);
+                    auto put = [&](int f, float v) {  // f is wave-uniform
+                        const int r = f & 31;
+                        const int dw = ((((r & 15) >> 2) * 4 + (((r >> 4) * 4 + (r & 3)) >> 1)) * 64) + (f >> 5) * 1024;
+                        tile_h[(dw + lane) * 2 + (r & 1)] = (_Float16)v;  // element e = (r >> 4) * 4 + (r & 3): its low bit is r & 1
+                    };
+                    auto octaves = [&](int base, int n_oct, const float x[3]) {
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) put(base + i, x[i]);
+                        for (int k = 0; k < n_oct; ++k) {
+                            const float scale = __uint_as_float((uint32_t)(127 + k) << 23);
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                put(base + 3 + 6 * k + i, tri_wave(x[i] * scale + 0.f));
+                                put(base + 3 + 6 * k + 3 + i, tri_wave(x[i] * scale + 0.25f));
+                            }
+                        }
+                    };
+                    octaves(0, S.pos_octaves, p);
+                    if (S.need_viewdir) octaves(S.n_pos, S.dir_octaves, d);
+                    const int emb_base = S.n_pos + S.n_dir;
+                    for (int j = 0; j < S.embedding_dim; ++j) put(emb_base + j, half_bits_to_float(emb[j]));
+                    for (int f = S.in_dim; f < 32 * NKK0; ++f) put(f, 0.f);  // padding features: finite (their weights are zero)
+                    __builtin_amdgcn_wave_barrier();
+                }
 #pragma unroll
                 for (int kk = 0; kk < NKK0; ++kk) {
-#pragma nounroll
-                    for (int f2 = 0; f2 < 16; ++f2) {
-                        const int r = 2 * f2, f = 32 * kk + r;
-                        float v0, v1;
-                        if (f >= emb_base && f < S.in_dim) v0 = half_bits_to_float(emb[f - emb_base]);
-                        else v0 = encode_feature(S, f, p, d);
-                        if (f + 1 >= emb_base && f + 1 < S.in_dim) v1 = half_bits_to_float(emb[f + 1 - emb_base]);
-                        else v1 = encode_feature(S, f + 1, p, d);
-                        const int fg = (r & 15) >> 2, fe = (r >> 4) * 4 + (r & 3);
-                        union {
-                            _Float16 h[2];
-                            uint32_t u;
-                        } pk;
-                        pk.h[0] = (_Float16)v0;
-                        pk.h[1] = (_Float16)v1;
-                        s_tile[(fg * 4 + (fe >> 1)) * 64 + lane] = pk.u;
-                    }
-                    __builtin_amdgcn_wave_barrier();
                     half8 bf[kNT];
 #pragma unroll
                     for (int nt = 0; nt < kNT; ++nt) {
@@ -380,7 +395,7 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                             half8 h;
                         } rd;
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) rd.u[q4] = s_tile[(g * 4 + q4) * 64 + nt * 16 + col];
+                        for (int q4 = 0; q4 < 4; ++q4) rd.u[q4] = s_tile[kk * 1024 + (g * 4 + q4) * 64 + nt * 16 + col];
                         bf[nt] = rd.h;
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -396,22 +411,19 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                         for (int nt = 0; nt < kNT; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[mt * NKK0 + kk], bf[nt], acc[mt][nt], 0, 0, 0);
                     }
-                    if (kk == 0) fetch(nxt, bias_nxt, w + n0 * 64, b + 16 * MT);  // layer 1's fragments travel while layer 0 finishes
                 }
+                if (F.diag) t_enc += wall_clock64() - t_e0;
+                const unsigned long long t_h0 = F.diag ? wall_clock64() : 0;
                 w += n0 * 64;
                 b += 16 * MT;
                 for (int layer = 1; layer <= S.hidden_layers; ++layer) {
                     const int n_mt = layer < S.hidden_layers ? MT : S.mt_out;
+                    fetch(cur, bias_cur, w, b);  // this layer's fragments travel while the activations are converted
                     half8 bf[MT / 2][kNT];
 #pragma unroll
                     for (int kk = 0; kk < MT / 2; ++kk)
 #pragma unroll
                         for (int nt = 0; nt < kNT; ++nt) bf[kk][nt] = relu_pack(acc[2 * kk][nt], acc[2 * kk + 1][nt]);
-#pragma unroll
-                    for (int i = 0; i < kFr; ++i) cur[i] = nxt[i];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) bias_cur[mt] = bias_nxt[mt];
-                    if (layer < S.hidden_layers) fetch(nxt, bias_nxt, w + n_mt * (MT / 2) * 64, b + 16 * n_mt);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         if (mt < n_mt) {
@@ -428,6 +440,7 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                     w += n_mt * (MT / 2) * 64;
                     b += 16 * n_mt;
                 }
+                if (F.diag) t_hid += wall_clock64() - t_h0;
                 // outputs to the tile: feature f of column j at s_out[f * 64 + j]
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -440,6 +453,7 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+            const unsigned long long t_c0 = F.diag ? wall_clock64() : 0;
             // ---- column j: transmittance factor and colour denominators of its sample (rt_core.cuh:356-392), SH basis of the owner
             if (col_sel) {
                 auto sv = [&](int f) -> float { return valid_cluster ? s_out[f * 64 + lane] : 0.f; };  // no sub-module: zeros (mlp_histogram)
@@ -460,7 +474,9 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                 }
             }
             __builtin_amdgcn_wave_barrier();  // the next cluster's run rewrites the tile
+            if (F.diag) t_eval += wall_clock64() - t_c0;
             }
+            const unsigned long long t_a0 = F.diag ? wall_clock64() : 0;
             // ---- every owner walks its samples of this pass in ray order
             while (first_pending != kNone && (int32_t)(first_pending - (head + (uint32_t)n)) < 0) {
                 const int j = (int)(first_pending - head);
@@ -483,6 +499,8 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
             }
             head += (uint32_t)n;
             __builtin_amdgcn_wave_barrier();  // tile, results and the freed pool slots are rewritten from here on
+            if (F.diag) t_apply += wall_clock64() - t_a0;
+            if (F.diag) t_net += wall_clock64() - t_w0;
         }
         // ---- rays that have ended and whose samples are all composited: write the pixel (alpha 1, renderer_kernel.cu:316)
         if (has_ray && done && !held && first_pending == kNone) {
@@ -501,6 +519,12 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
             atomicAdd(F.sample_counter + 2, (unsigned long long)n_steps);
             atomicAdd(F.sample_counter + 3, (unsigned long long)n_cut);
             atomicAdd(F.sample_counter + 4, (unsigned long long)n_drain);
+            atomicAdd(F.sample_counter + 5, t_net);
+            atomicAdd(F.sample_counter + 6, wall_clock64() - t_all);
+            atomicAdd(F.sample_counter + 7, t_enc);
+            atomicAdd(F.sample_counter + 8, t_hid);
+            atomicAdd(F.sample_counter + 9, t_eval);
+            atomicAdd(F.sample_counter + 10, t_apply);
         }
     }
 }

@@ -1099,7 +1099,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
         // the fused guided-sampling frame: 3 workgroups per CU (LDS: network tiles), one 8x8 tile per wavefront at a time
         const FusedGuided &F = *track->fused;
         const int nb = b > 0 ? b : 1;
-        const size_t fl = fused_lds_bytes(nb, lds_level, F.S.mt_out);
+        const size_t fl = fused_lds_bytes(nb, lds_level, F.S.mt_out, F.S.nkk0);
         int fb = accel->num_cus * MNV_FUSED_WAVES;
         if ((uint64_t)fb * 4u > n_waves_needed) fb = (int)((n_waves_needed + 3) / 4);
         if (fb < 1) fb = 1;

@@ -44,7 +44,7 @@ rcl = torch.empty(cap, dtype=torch.int16, device="cuda")
 values = torch.empty((cap, dd + 1), dtype=torch.float32, device="cuda")
 out_a = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
 out_b = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
-counter = torch.zeros(8, dtype=torch.int64, device="cuda")
+counter = torch.zeros(16, dtype=torch.int64, device="cuda")
 
 
 def four_step(cam):
@@ -87,6 +87,9 @@ res["fused_samples"] = int(counter[0].item())
 if os.environ.get("MNV_FUSED_DIAG"):
     res["passes"], res["march_iters"] = int(counter[1].item()), int(counter[2].item())
     res["passes_cut_by_cluster"], res["drain_passes"] = int(counter[3].item()), int(counter[4].item())
+    res["wave_us_network"], res["wave_us_total"], res["wave_us_layer0"] = [round(int(counter[i].item()) / 100.0 / 2048, 1) for i in (5, 6, 7)]
+    res["wave_us_hidden_layers"], res["wave_us_column_eval"], res["wave_us_apply"] = [round(int(counter[i].item()) / 100.0 / 2048, 1) for i in (8, 9, 10)]
+    res["us_per_run"] = round(int(counter[5].item()) / 100.0 / max(1, res["passes"]), 2)
     res["lanes_per_pass"] = round(res["fused_samples"] / max(1, res["passes"]), 2)
 res["bit_identical"] = bool(torch.equal(out_a.view(torch.int32), out_b.view(torch.int32)))
 print(json.dumps(res))
