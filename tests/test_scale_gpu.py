@@ -152,3 +152,26 @@ def test_cfg5_guided_sampling_frame_at_scale_matches_tensor_ops(mnv, torch_gpu):
     assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(frame))
     a = frame[..., 3]
     assert np.isfinite(frame).all() and a.min() >= 0.0 and a.max() <= 1.0 + 1e-6
+
+
+def test_depth11_tree_in_the_size_class_of_the_references_budget(mnv, orc, torch_gpu):
+    """The reference reserves 20 M chunks by default (`-c`, src/opts.cpp:17-32).  The depth-11 version of the merged-octree
+    stand-in has 12.7 M chunks (5.7 GB of voxel rows, 102 M voxels): beyond 2^24 voxels and 4 GiB of row bytes, where 32-bit index
+    arithmetic and float-encoded tracker rows (rt_core.cuh:237-252, inexact from 2^24) start to matter.  Both kernels == oracle."""
+    torch = torch_gpu
+    spec = dict(cases.CFG3_TREE, depth=11)
+    tree = cases.make_tree(mnv, spec)
+    assert tree.capacity > 12_000_000
+    cam = cases.cfg3_camera(mnv, 5, 960, 540, 700.0)
+    opt = mnv.RenderOptions.cli_defaults()
+    opt.basis_minmax[1] = 8
+    ref = orc.render(orc.tree_from_view(tree.host_view()), cam.c, opt)["rgba"]
+    assert (ref[..., 3] > 0).sum() > 100_000
+    tree.move_to_device()
+    a = torch.empty((540, 960, 4), dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    mnv.render_voxels_accel(tree.accel, cam, opt, rgba=a)
+    mnv.render_voxels(tree.device_view(), cam, opt, rgba=b)
+    torch.cuda.synchronize()
+    assert np.array_equal(cases.bits(a.cpu().numpy()), cases.bits(ref))
+    assert np.array_equal(cases.bits(b.cpu().numpy()), cases.bits(ref))
