@@ -491,6 +491,14 @@ int mnv_query_submodules(mnv_mlp *mlp, const int16_t *cluster_indices, const flo
 int mnv_render_guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, const mnv_mlp *mlp,
                             const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, unsigned long long *sample_counter,
                             void *hip_stream);
+/* The same frame when refinement is on as well (BASELINE.json configs[4] has both switches on: cuda_renderer.cpp:107-156): the fused
+ * kernel also writes the refinement trackers (rows pre-filled with -1 by the caller, as cuda_renderer.cpp:97-98) and, with `visited` +
+ * `parent`, the visit marks -- what get_samples_from_voxels produces besides the samples (rt_core.cuh:475-507,561-574).  A ray that
+ * has emitted max_guided_samples samples keeps marching here (its trackers follow the remaining steps); the picture is the same. */
+int mnv_render_guided_fused_track(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, const mnv_mlp *mlp,
+                                  const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, float *split_track, float *sample_track,
+                                  const int16_t *sample_counts, int32_t *visited, const int32_t *parent, unsigned long long *sample_counter,
+                                  void *hip_stream);
 
 /* A HIP stream whose kernels run on all but `reserve_cus` compute units (hipExtStreamCreateWithCUMask; the units are taken
  * evenly from the XCDs, and from their shader engines when reserve_cus is a multiple of 32).  The tuned kernel is persistent and

@@ -226,6 +226,8 @@ _SIGNATURES = {
                                                           C.POINTER(ClusterGrid), C.c_void_p]),
     "mnv_render_guided_fused": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.c_void_p, C.POINTER(ClusterGrid),
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mnv_render_guided_fused_track": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.c_void_p, C.POINTER(ClusterGrid),
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_render_nerf_results": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
                                           C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_add_children_and_generate_samples": (C.c_int, [C.POINTER(TreeEdit), C.POINTER(RenderOptions), C.c_void_p, C.c_int32, C.c_void_p,
@@ -634,13 +636,15 @@ def render_nerf_results(tree_view: TreeView, cam: Camera, opt: RenderOptions, sa
 
 
 def render_guided_fused(accel: int, cam: Camera, opt: RenderOptions, mlp: "Mlp", grid: ClusterGrid, tile=None, rgba=None, rgba8=None,
-                        sample_counter=None, stream: int = 0) -> None:
-    """The guided-sampling frame as one kernel (mnv_render_guided_fused).  `sample_counter`: optional device int64 tensor [1],
-    incremented by the number of network evaluations."""
+                        sample_counter=None, split_track=None, sample_track=None, sample_counts=None, visited=None, parent=None,
+                        stream: int = 0) -> None:
+    """The guided-sampling frame as one kernel (mnv_render_guided_fused[_track]).  `sample_counter`: optional device int64 tensor,
+    incremented by the number of network evaluations; trackers / visit marks as in render_voxels_accel_visit."""
     if tile is None:
         tile = (0, 0, cam.width, cam.height)
-    _check(lib().mnv_render_guided_fused(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), mlp._h, C.byref(grid), _ptr(rgba), _ptr(rgba8),
-                                         _ptr(sample_counter), C.c_void_p(stream)))
+    _check(lib().mnv_render_guided_fused_track(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), mlp._h, C.byref(grid), _ptr(rgba),
+                                               _ptr(rgba8), _ptr(split_track), _ptr(sample_track), _ptr(sample_counts), _ptr(visited), _ptr(parent),
+                                               _ptr(sample_counter), C.c_void_p(stream)))
 
 
 def tree_edit(child, parent, offset, scale, capacity: int) -> TreeEdit:

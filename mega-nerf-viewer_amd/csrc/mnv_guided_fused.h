@@ -57,7 +57,7 @@ __host__ __device__ inline size_t fused_lds_bytes(int nb, int lds_level, int mt_
 #ifndef MNV_FUSED_WAVES
 #define MNV_FUSED_WAVES 2  // workgroups per CU = wavefronts per SIMD: 256 VGPRs, no spills (3: 168 VGPRs and ~80 spilled values; A/B in DESIGN.md)
 #endif
-template <int BASIS, int NKK0 /* 32-feature K tiles of the encoded input: 1 or 2 */>
+template <int BASIS, int NKK0 /* 32-feature K tiles of the encoded input: 1 or 2 */, bool TRACK /* refinement trackers + visit marks as well (rt_core.cuh:475-507,561-574) */>
 __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(const AccelLaunch K, const FusedGuided F) {
     constexpr int BLOCK = 256, MT = 4;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
@@ -110,6 +110,9 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
     int hcl = -1;                            // its cluster
     uint32_t first_pending = kNone, prev_slot = kNone;  // pool slots (monotonic numbers): oldest sample not yet composited, last one pushed
     float ti = 1.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;  // composite state (render_nerf_results)
+    // TRACK: per-ray tracker state, as in march_accel_kernel MODE 2 / 3
+    float max_weight = -1.f, max_sample_weight = -1.f, sp_prio = 0.f, sa_prio = 0.f;
+    int32_t sp_vox = -1, sa_vox = -1;
     int n_eval = 0, n_batches = 0, n_steps = 0, n_cut = 0, n_drain = 0;
     unsigned long long t_net = 0, t_enc = 0, t_hid = 0, t_eval = 0, t_apply = 0, t_all = F.diag ? wall_clock64() : 0;  // diagnostics: 100 MHz ticks
     uint32_t head = 0, tail = 0;             // pool bounds (wave-uniform, monotonic; slot = number & (kPool - 1))
@@ -150,6 +153,12 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                 first_pending = prev_slot = kNone;
                 ti = 1.f;
                 o0 = o1 = o2 = 0.f;
+                if constexpr (TRACK) {
+                    max_weight = max_sample_weight = -1.f;
+                    sp_prio = (float)(K.max_depth + 1);
+                    sa_prio = (float)(K.max_sample_count + 1);
+                    sp_vox = sa_vox = -1;
+                }
                 RaySetup<NB> r;
                 setup_ray<(BASIS > 0 ? BASIS : 0)>(P, *Cp, P.x0 + bx, P.y0 + by, r);
                 if constexpr (BASIS == 0) r.basis[0] = (0 < P.basis_min || 0 > P.basis_max) ? 0.f : (float)0.28209479177387814;
@@ -195,6 +204,8 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                     q[i] = (uint32_t)(pos[i] * qscale);
                 }
                 uint32_t word = s_grid[((((q[0] >> sh1) << LL) | (q[1] >> sh1)) << LL) | (q[2] >> sh1)];
+                int src = 0;       // TRACK: where the leaf word came from (0 LDS grid, 1 grid2, 2 node array) ...
+                uint32_t vox = 0;  // ... and the leaf's voxel index (grid cell number until it is looked up)
                 if (!(word & kLeafBit)) {
                     int sh = sh1;
                     if (L2 > LL) {
@@ -207,6 +218,8 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                         gi = (gi << 2) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh2, 2u);
                         word = A.grid2[gi];
                         sh = sh2;
+                        src = 1;
+                        vox = gi;
                     }
                     while (!(word & kLeafBit)) {
                         --sh;
@@ -214,6 +227,8 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                         v = (v << 1) | __builtin_amdgcn_ubfe(q[1], (uint32_t)sh, 1u);
                         v = (v << 1) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh, 1u);
                         word = A.nodes[v];
+                        src = 2;
+                        vox = v;
                     }
                 }
                 const int depth = (int)((word >> 16) & 0x7fu);
@@ -230,8 +245,50 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                 }
                 const float delta_t = tu * inv_cube + P.step_size;
                 const float sigma = half_bits_to_float((uint16_t)word);
-                if (sigma > P.sigma_thresh) {
+                const bool is_dense = sigma > P.sigma_thresh;
+                bool need_vox = false;
+                if constexpr (TRACK) {
+                    need_vox = is_dense || max_weight == -1.f || max_sample_weight == -1.f || K.visited != nullptr;
+                    if (need_vox) {
+                        const int shg = Lq - A.grid_level;
+                        if (src == 0) vox = A.grid_vox[((((q[0] >> shg) << A.grid_level) + (q[1] >> shg)) << A.grid_level) + (q[2] >> shg)];
+                        else if (src == 1) vox = A.grid2_vox[vox];
+                        if (K.visited && __hip_atomic_load(&K.visited[vox >> 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) K.visited[vox >> 3] = 1;
+                    }
+                }
+                if constexpr (TRACK) {
+                    if (need_vox && !is_dense) {  // first leaf before any dense one, rt_core.cuh:561-574
+                        if (depth < K.max_depth && max_weight == -1.f) {
+                            sp_vox = (int32_t)vox;
+                            sp_prio = (float)depth;
+                        }
+                        if (K.sample_counts && max_sample_weight == -1.f) {
+                            const int16_t scn = K.sample_counts[vox];
+                            if (scn < K.max_sample_count) {
+                                sa_vox = (int32_t)vox;
+                                sa_prio = (float)scn;
+                            }
+                        }
+                    }
+                }
+                if (is_dense) {
                     const float att = exact_expf(-delta_t * delta_scale * sigma, s_exp);
+                    if constexpr (TRACK) {  // best dense leaf so far, rt_core.cuh:475-507
+                        const float weight = T * (1.f - att);
+                        if (depth < K.max_depth && weight > max_weight) {
+                            sp_vox = (int32_t)vox;
+                            sp_prio = (float)depth;
+                            max_weight = weight;
+                        }
+                        if (K.sample_counts && weight > max_sample_weight) {
+                            const int16_t scn = K.sample_counts[vox];
+                            if (scn < K.max_sample_count) {
+                                sa_vox = (int32_t)vox;
+                                sa_prio = (float)scn;
+                                max_sample_weight = weight;
+                            }
+                        }
+                    }
                     // rt_core.cuh:508-549: one sample per dense step while there is room
                     if (ns < F.max_guided_samples) {
                         const float tz0 = t * dir0 / P.scale[0], tz1 = t * dir1 / P.scale[1], tz2 = t * dir2 / P.scale[2];
@@ -250,8 +307,11 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                     if (T < P.stop_thresh) done = true;
                 }
                 t += delta_t;
-                // a ray that has emitted its quota contributes nothing more: its remaining steps are skipped
-                if (ns >= F.max_guided_samples) done = true;
+                // a ray that has emitted its quota contributes nothing more to the picture: its remaining steps are skipped
+                // (the trackers and visit marks do follow the remaining steps)
+                if constexpr (!TRACK) {
+                    if (ns >= F.max_guided_samples) done = true;
+                }
             }
         }
 
@@ -505,6 +565,18 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
         // ---- rays that have ended and whose samples are all composited: write the pixel (alpha 1, renderer_kernel.cu:316)
         if (has_ray && done && !held && first_pending == kNone) {
             composite_and_write(P, (int64_t)pix, o0, o1, o2, 1.0f);
+            if constexpr (TRACK) {
+                if (K.split_track) {
+                    K.split_track[(int64_t)pix * 3 + 0] = sp_prio;
+                    K.split_track[(int64_t)pix * 3 + 1] = sp_vox < 0 ? -1.f : (float)(sp_vox >> 3);
+                    K.split_track[(int64_t)pix * 3 + 2] = sp_vox < 0 ? -1.f : (float)(sp_vox & 7);
+                }
+                if (K.sample_track) {
+                    K.sample_track[(int64_t)pix * 3 + 0] = sa_prio;
+                    K.sample_track[(int64_t)pix * 3 + 1] = sa_vox < 0 ? -1.f : (float)(sa_vox >> 3);
+                    K.sample_track[(int64_t)pix * 3 + 2] = sa_vox < 0 ? -1.f : (float)(sa_vox & 7);
+                }
+            }
             has_ray = false;
         }
     }

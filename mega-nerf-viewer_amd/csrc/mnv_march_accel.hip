@@ -1110,14 +1110,21 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
             return (int)hipGetLastError();
         };
         const bool two = F.S.nkk0 == 2;  // mnv_render_guided_fused admits 1 and 2
+        const bool trk = K.split_track || K.sample_track || K.visited;
+#define MNV_FUSED_CASE(B)                                                                                       \
+    case B:                                                                                                     \
+        rc = trk ? (two ? go(guided_fused_kernel<B, 2, true>) : go(guided_fused_kernel<B, 1, true>))            \
+                 : (two ? go(guided_fused_kernel<B, 2, false>) : go(guided_fused_kernel<B, 1, false>));         \
+        break;
         switch (b) {
-            case -1: rc = two ? go(guided_fused_kernel<-1, 2>) : go(guided_fused_kernel<-1, 1>); break;
-            case 1: rc = two ? go(guided_fused_kernel<1, 2>) : go(guided_fused_kernel<1, 1>); break;
-            case 4: rc = two ? go(guided_fused_kernel<4, 2>) : go(guided_fused_kernel<4, 1>); break;
-            case 9: rc = two ? go(guided_fused_kernel<9, 2>) : go(guided_fused_kernel<9, 1>); break;
-            case 16: rc = two ? go(guided_fused_kernel<16, 2>) : go(guided_fused_kernel<16, 1>); break;
+            MNV_FUSED_CASE(-1)
+            MNV_FUSED_CASE(1)
+            MNV_FUSED_CASE(4)
+            MNV_FUSED_CASE(9)
+            MNV_FUSED_CASE(16)
             default: break;
         }
+#undef MNV_FUSED_CASE
     } else if (colourless) rc = launch_variant<9>(K, n_blocks, lds_bytes, stream);
     else
         switch (b) {
@@ -1560,7 +1567,16 @@ int mnv_get_samples_from_voxels_accel_visit(const mnv_accel *accel, const mnv_ca
 int mnv_render_guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, const mnv_mlp *mlp,
                             const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, unsigned long long *sample_counter,
                             void *hip_stream) {
+    return mnv_render_guided_fused_track(accel, cam, opt, tile, mlp, grid, rgba_out, rgba8_out, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                         sample_counter, hip_stream);
+}
+
+int mnv_render_guided_fused_track(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, const mnv_mlp *mlp,
+                                  const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, float *split_track, float *sample_track,
+                                  const int16_t *sample_counts, int32_t *visited, const int32_t *parent, unsigned long long *sample_counter,
+                                  void *hip_stream) {
     if (!accel || !cam || !opt || !mlp || !grid) return set_error(MNV_E_INVALID, "null argument");
+    if (visited && !parent) return set_error(MNV_E_INVALID, "visit marks on the packed layout need the parent array (the ancestors of the marked chunks)");
     if (opt->render_depth) return set_error(MNV_E_UNSUPPORTED, "the fused guided-sampling frame has no depth mode; use the four-step path");
     if (opt->max_guided_samples < 1) return set_error(MNV_E_INVALID, "max_guided_samples must be positive");
     const MlpShape &S = mlp->shape;
@@ -1592,6 +1608,13 @@ int mnv_render_guided_fused(const mnv_accel *accel, const mnv_camera *cam, const
     F.diag = env_diag && sample_counter ? 1 : 0;
     AccelTrack track = {};
     track.fused = &F;
+    track.split_track = split_track;
+    track.sample_track = sample_track;
+    track.sample_counts = sample_counts;
+    track.max_depth = opt->max_depth;
+    track.max_sample_count = opt->max_sample_count;
+    track.visited = visited;
+    track.parent = parent;
     const mnv_partition whole = {0, 1, 0, 0, 0};
     return render_accel(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, &track, hip_stream);
 }

@@ -406,17 +406,20 @@ void VolumeRenderer::render() {
     }
     const mnv_tree_view dv = tree.device_view();
 
-    // the guided-sampling frame as ONE kernel (march + networks + composite, no sample buffer) whenever nothing else has to
-    // come out of the frame: no refinement trackers, no visit marks, a current accel, a network the fused kernel covers
-    const bool fuse = refine && options.use_guided_sampling && !options.use_splitting && use_fused_guided && tree.device.accel && !I.accel_stale &&
-                      !track_visit && !options.render_depth && I.mlp_desc.hidden_width == 64 && I.fused_inputs_ok &&
+    // the guided-sampling frame as ONE kernel (march + networks + composite [+ trackers + visit marks], no sample buffer) whenever
+    // the accel is current and the network is one the fused kernel covers
+    const bool fuse = refine && options.use_guided_sampling && use_fused_guided && tree.device.accel && !I.accel_stale &&
+                      (!track_visit || tree.device.parent) && !options.render_depth && I.mlp_desc.hidden_width == 64 && I.fused_inputs_ok &&
                       (tree.data_format.format != DataFormat::SH || tree.data_format.basis_dim == 1 || tree.data_format.basis_dim == 4 ||
                        tree.data_format.basis_dim == 9 || tree.data_format.basis_dim == 16);
     if (fuse) {
         unsigned long long *counter = I.fused_counter.get<unsigned long long>(1);
         hip_check(hipMemsetAsync(counter, 0, sizeof(unsigned long long), I.stream), "clear sample counter");
-        mnv_check(mnv_render_guided_fused(tree.device.accel, &cv, options.c_abi(), full, I.mlp, &I.grid, I.rgba, I.rgba8, counter, I.stream),
-                  "mnv_render_guided_fused");
+        // with refinement on as well (configs[4]) the same kernel also writes the trackers and the visit marks
+        mnv_check(mnv_render_guided_fused_track(tree.device.accel, &cv, options.c_abi(), full, I.mlp, &I.grid, I.rgba, I.rgba8, split, sample,
+                                                split ? tree.device.sample_counts : nullptr, track_visit ? visited : nullptr, tree.device.parent, counter,
+                                                I.stream),
+                  "mnv_render_guided_fused_track");
         unsigned long long n = 0;
         hip_check(hipMemcpyAsync(&n, counter, sizeof(n), hipMemcpyDeviceToHost, I.stream), "read sample counter");
         hip_check(hipStreamSynchronize(I.stream), "guided frame");

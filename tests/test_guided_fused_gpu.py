@@ -132,7 +132,62 @@ def test_volume_renderer_uses_the_fused_kernel_and_the_four_step_path_agrees(mnv
         frames[fused] = (r.download(), st["guided_samples"])
     assert frames[True][1] == frames[False][1]
     assert np.array_equal(cases.bits(frames[True][0]), cases.bits(frames[False][0]))
-    # with splitting on, the frame must also produce the trackers: four-step path
-    r, tree, desc, params, cam_spec = setup(mnv, "sh9_d7_aniso", 4000, use_guided_sampling=True, use_splitting=True, max_guided_samples=24, max_depth=9)
-    st = r.render()
-    assert st["fused"] == 0 and st["guided_samples"] > 0
+    # with splitting on as well (configs[4]) the fused kernel also writes the trackers: the split step that follows finds candidates
+    logs = {}
+    for fused in (True, False):
+        r, tree, desc, params, cam_spec = setup(mnv, "sh9_d7_aniso", 4000, use_guided_sampling=True, use_splitting=True, max_guided_samples=24, max_depth=9)
+        r.set_fused_guided(fused)
+        st = r.render()
+        assert st["fused"] == int(fused) and st["guided_samples"] > 0 and st["split_candidates"] > 0 and st["added"] > 0
+        logs[fused] = (st["split_candidates"], st["added"], st["capacity"], r.download())
+    assert logs[True][:3] == logs[False][:3] and np.array_equal(cases.bits(logs[True][3]), cases.bits(logs[False][3]))
+
+
+@pytest.mark.parametrize("case,max_g", [("sh4_d6", 16), ("sh9_d7_aniso", 4), ("rgba_d5", 128), ("shell_d7_sh9", 32)])
+def test_fused_frame_with_trackers_and_visit_marks(mnv, torch_gpu, case, max_g):
+    """BASELINE.json configs[4] has refinement AND guided sampling on: mnv_render_guided_fused_track writes, besides the picture,
+    the tracker rows and visit marks that get_samples_from_voxels produces (rt_core.cuh:475-507,561-574,132-134) -- equal, element
+    for element, to the sample march on the accel (itself pinned to the oracle and the reference's device code); the picture equals
+    the four-step path's.  max_g = 4: rays keep marching after their quota, for the trackers' sake."""
+    torch = torch_gpu
+    spec = cases.CASES[case]
+    tree = cases.make_tree(mnv, spec["tree"])
+    v = tree.host_view()
+    tree.move_to_device(need_parent=True, need_sample_counts=True)
+    dv = tree.device_view()
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    opt.basis_minmax[0], opt.basis_minmax[1] = 0, max(v.basis_dim - 1, 0)
+    opt.max_guided_samples, opt.max_depth, opt.max_sample_count = max_g, 5, 9
+    sc = np.full((v.capacity, 8), 8, np.int16)
+    sc[::3] = 12
+    sc_dev = torch.from_numpy(sc).cuda()
+    desc = mnv.mlp_desc(n_clusters=6, pos_octaves=4, dir_octaves=2, need_viewdir=False, hidden_width=64, hidden_layers=2, out_dim=v.data_dim + 1)
+    mlp = mnv.Mlp(desc, mlp_cases.make_params(mnv, desc, seed=21))
+    grid = make_grid(mnv)
+    h, w = cam.height, cam.width
+    n_px = h * w
+    # the four-step path's first step with trackers and marks
+    num = torch.zeros(n_px, dtype=torch.int16, device="cuda")
+    guided = torch.zeros((n_px, max_g, 4), dtype=torch.float32, device="cuda")
+    clusters = torch.zeros((n_px, max_g), dtype=torch.int16, device="cuda")
+    split0 = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")
+    sample0 = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")
+    visited0 = torch.zeros(v.capacity, dtype=torch.int32, device="cuda")
+    mnv.get_samples_from_voxels_accel_visit(tree.accel, cam, opt, visited0, dv.parent, num, guided, clusters, grid, split_track=split0,
+                                            sample_track=sample0, sample_counts=sc_dev)
+    ref, ref8, total = four_step_frame(mnv, torch, tree, cam, opt, mlp, grid, max_g, 4)
+    # one kernel
+    out = torch.full((h, w, 4), float("nan"), dtype=torch.float32, device="cuda")
+    split = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")
+    sample = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")
+    visited = torch.zeros(v.capacity, dtype=torch.int32, device="cuda")
+    counter = torch.zeros(16, dtype=torch.int64, device="cuda")
+    mnv.render_guided_fused(tree.accel, cam, opt, mlp, grid, rgba=out, sample_counter=counter, split_track=split, sample_track=sample,
+                            sample_counts=sc_dev, visited=visited, parent=dv.parent)
+    torch.cuda.synchronize()
+    assert int(counter[0].item()) == total
+    assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref))
+    assert torch.equal(split, split0) and torch.equal(sample, sample0)
+    assert torch.equal(visited, visited0) and int(visited.sum()) > 1
+    assert (split[..., 1] >= 0).any()
