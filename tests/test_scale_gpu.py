@@ -175,3 +175,35 @@ def test_depth11_tree_in_the_size_class_of_the_references_budget(mnv, orc, torch
     torch.cuda.synchronize()
     assert np.array_equal(cases.bits(a.cpu().numpy()), cases.bits(ref))
     assert np.array_equal(cases.bits(b.cpu().numpy()), cases.bits(ref))
+
+
+def test_cfg5_refinement_and_guided_sampling_together_at_scale(mnv, torch_gpu):
+    """BASELINE.json configs[4] as stated -- dynamic refinement AND guided sampling on -- on the 1.5 M-chunk tree at 1920x1080: every
+    frame is ONE fused kernel (march + networks + composite + trackers) followed by the split step; the tree stays valid and the
+    packed accel follows it."""
+    torch = torch_gpu
+    r, tree, desc, params = _renderer_on_cfg2(mnv, 1_000_000, use_splitting=True, use_guided_sampling=True, max_depth=12, split_batch_size=4096,
+                                              samples_per_corner=8, max_guided_samples=32)
+    cap0 = tree.capacity
+    added = 0
+    for f in range(4):
+        _pose(mnv, r, f)
+        st = r.render()
+        added += st["added"]
+        assert st["fused"] == 1 and st["used_accel"] == 1 and st["guided_samples"] > 5_000_000
+        assert st["split_candidates"] > 0 and 0 < st["added"] <= 4096 and st["pruned"] == 0
+    frame = r.download()
+    assert np.isfinite(frame).all()
+    r.sync_tree()
+    data, child, parent = tree.host_arrays()
+    assert child.shape[0] == cap0 + added
+    check_tree_links(child, parent, cap0 + added)
+    cam = cases.cfg2_camera(mnv, 2)
+    opt = mnv.RenderOptions()
+    C.memmove(C.byref(opt), C.byref(r.options), C.sizeof(opt))
+    a = torch.empty((1080, 1920, 4), dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    mnv.render_voxels(tree.device_view(), cam, opt, rgba=a)
+    mnv.render_voxels_accel(tree.accel, cam, opt, rgba=b)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
