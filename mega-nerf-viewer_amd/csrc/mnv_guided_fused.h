@@ -44,19 +44,28 @@ struct FusedGuided {
     int32_t diag;                        // MNV_FUSED_DIAG: sample_counter[1] += network passes, [2] += march iterations
 };
 
+// Columns per network run: W = 16 * MNV_FUSED_NT samples; 64 / W lanes share a column in the per-column phases (encode, evaluation).
+// NT = 4: 64 accumulator + 32 activation registers -> 254 VGPRs, 2 wavefronts per SIMD.  NT = 2: half of that -> 3 wavefronts per
+// SIMD (168 VGPRs), which is what the march part of the kernel wants; the weights are then fetched twice per 64 samples (from L2).
+#ifndef MNV_FUSED_NT
+#define MNV_FUSED_NT 4
+#endif
+#ifndef MNV_FUSED_WAVES
+#define MNV_FUSED_WAVES (MNV_FUSED_NT >= 4 ? 2 : (MNV_FUSED_NT == 2 ? 3 : 4))  // workgroups per CU = wavefronts per SIMD
+#endif
+constexpr int kFNT = MNV_FUSED_NT, kFW = 16 * kFNT, kFParts = 64 / kFW;  // column tiles, columns and lanes per column of a run
+
+constexpr int kFRayRows = 3 + 3 + 5;  // per-ray LDS rows besides the SH basis: view direction, world-space unit direction, held-back sample
 // LDS of one 256-thread workgroup: exp table (256 B) | top-of-tree grid ((2^lds_level)^3 words) | per-ray constants
 // [NB + 3][256] floats (SH basis, view direction) | per wavefront: network tile of 16 * mt_out features x 64 columns (the first
 // 4 KB double as the encode tile), sample pool 6 x 128 words, per-column results 4 x 64 floats
 constexpr int kPool = 128;  // ring capacity: a pass is due at 64 entries and one march step adds at most 64
-__host__ __device__ inline int fused_tile_words(int mt_out, int nkk0) { return (mt_out > nkk0 ? mt_out : nkk0) * 16 * 64; }  // outputs, or one 4 KB encode tile per K tile
-__host__ __device__ inline size_t fused_wave_words(int mt_out, int nkk0) { return (size_t)fused_tile_words(mt_out, nkk0) + 6 * kPool + 4 * 64; }
+__host__ __device__ inline int fused_tile_words(int mt_out, int nkk0) { return (mt_out > nkk0 ? mt_out : nkk0) * 16 * kFW; }  // outputs, or one encode tile per K tile
+__host__ __device__ inline size_t fused_wave_words(int mt_out, int nkk0) { return (size_t)fused_tile_words(mt_out, nkk0) + 6 * kPool + 4 * kFW; }
 __host__ __device__ inline size_t fused_lds_bytes(int nb, int lds_level, int mt_out, int nkk0) {
-    return 256 + ((size_t)4 << (3 * lds_level)) + (size_t)(nb + 3) * 256 * 4 + 4 * fused_wave_words(mt_out, nkk0) * 4;
+    return 256 + ((size_t)4 << (3 * lds_level)) + (size_t)(nb + kFRayRows) * 256 * 4 + 4 * fused_wave_words(mt_out, nkk0) * 4;
 }
 
-#ifndef MNV_FUSED_WAVES
-#define MNV_FUSED_WAVES 2  // workgroups per CU = wavefronts per SIMD: 256 VGPRs, no spills (3: 168 VGPRs and ~80 spilled values; A/B in DESIGN.md)
-#endif
 template <int BASIS, int NKK0 /* 32-feature K tiles of the encoded input: 1 or 2 */, bool TRACK /* refinement trackers + visit marks as well (rt_core.cuh:475-507,561-574) */>
 __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(const AccelLaunch K, const FusedGuided F) {
     constexpr int BLOCK = 256, MT = 4;
@@ -69,13 +78,13 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
     const int LL = K.lds_level;
     const int cells = 1 << (3 * LL);
     uint32_t *s_grid = s_mem + 64;
-    float *s_ray = reinterpret_cast<float *>(s_grid + cells);  // [k][thread]: k < NB basis, then vdir[3]
+    float *s_ray = reinterpret_cast<float *>(s_grid + cells);  // [k][thread]: k < NB basis, then vdir[3], true_dir[3], held sample[5]
     const int tile_words = fused_tile_words(S.mt_out, NKK0);
-    uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_ray + (NB + 3) * BLOCK) + (threadIdx.x >> 6) * fused_wave_words(S.mt_out, NKK0);  // this wavefront's LDS
+    uint32_t *s_tile = reinterpret_cast<uint32_t *>(s_ray + (NB + kFRayRows) * BLOCK) + (threadIdx.x >> 6) * fused_wave_words(S.mt_out, NKK0);  // this wavefront's LDS
     float *s_out = reinterpret_cast<float *>(s_tile);
     float *s_px = s_out + tile_words, *s_py = s_px + kPool, *s_pz = s_py + kPool, *s_pd = s_pz + kPool;  // pool: world xyz, delta z
     uint32_t *s_pm = reinterpret_cast<uint32_t *>(s_pd + kPool), *s_pn = s_pm + kPool;  // owner | last << 6 | cluster << 8; owner's next slot
-    float *s_ra = reinterpret_cast<float *>(s_pn + kPool), *s_r0 = s_ra + 64, *s_r1 = s_r0 + 64, *s_r2 = s_r1 + 64;  // per-column results
+    float *s_ra = reinterpret_cast<float *>(s_pn + kPool), *s_r0 = s_ra + kFW, *s_r1 = s_r0 + kFW, *s_r2 = s_r1 + kFW;  // per-column results
     constexpr uint32_t kNone = 0xffffffffu;
 
     if (threadIdx.x < 32) s_exp[threadIdx.x] = kExp2fTab[threadIdx.x];
@@ -103,11 +112,10 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
     // per-lane ray state
     bool has_ray = false, done = true, held = false;
     float t = 0.f, T = 1.f, tmax = 0.f, dir0 = 0.f, dir1 = 0.f, dir2 = 0.f, inv0 = 0.f, inv1 = 0.f, inv2 = 0.f, delta_scale = 0.f;
-    float td0 = 0.f, td1 = 0.f, td2 = 0.f;  // world-space unit direction (sample positions)
     uint32_t pix = 0;
     int ns = 0;                              // samples emitted by the ray
-    float hz = 0.f, hx = 0.f, hy = 0.f, hw = 0.f;  // the held-back (newest) sample: z, world xyz
-    int hcl = -1;                            // its cluster
+    // world-space unit direction and the held-back (newest) sample (z, world xyz, cluster) live in LDS rows NB + 3 .. NB + 10 of the ray
+    float *my_td = my_ray + (NB + 3) * BLOCK, *my_held = my_ray + (NB + 6) * BLOCK;
     uint32_t first_pending = kNone, prev_slot = kNone;  // pool slots (monotonic numbers): oldest sample not yet composited, last one pushed
     float ti = 1.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;  // composite state (render_nerf_results)
     // TRACK: per-ray tracker state, as in march_accel_kernel MODE 2 / 3
@@ -164,9 +172,8 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                 if constexpr (BASIS == 0) r.basis[0] = (0 < P.basis_min || 0 > P.basis_max) ? 0.f : (float)0.28209479177387814;
                 float true_dir[3], vdir[3];
                 world_ray_dirs(P, *Cp, P.x0 + bx, P.y0 + by, true_dir, vdir);
-                td0 = true_dir[0];
-                td1 = true_dir[1];
-                td2 = true_dir[2];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) my_td[k * BLOCK] = true_dir[k];
 #pragma unroll
                 for (int k = 0; k < NB; ++k) my_ray[k * BLOCK] = r.basis[k];
 #pragma unroll
@@ -294,9 +301,9 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                         const float tz0 = t * dir0 / P.scale[0], tz1 = t * dir1 / P.scale[1], tz2 = t * dir2 / P.scale[2];
                         sz = sqrtf(tz0 * tz0 + tz1 * tz1 + tz2 * tz2);
                         const float *m = Cp->c2w;
-                        sx = m[9] + td0 * sz;
-                        sy = m[10] + td1 * sz;
-                        sw = m[11] + td2 * sz;
+                        sx = m[9] + my_td[0] * sz;
+                        sy = m[10] + my_td[BLOCK] * sz;
+                        sw = m[11] + my_td[2 * BLOCK] * sz;
                         const int g1 = (int)fmaxf(fminf((sy - F.min_position[1]) / F.range[1] * (float)F.grid_dim[0], (float)F.grid_dim[0] - 1.0f), 0.0f);
                         const int g2 = (int)fmaxf(fminf((sw - F.min_position[2]) / F.range[2] * (float)F.grid_dim[1], (float)F.grid_dim[1] - 1.0f), 0.0f);
                         scl = (int)(int16_t)(g1 * F.grid_dim[1] + g2);
@@ -324,15 +331,15 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
             if (fresh) {
                 if (held) {
                     push = true;
-                    pz_ = hz; px_ = hx; py_ = hy; pw_ = hw; pcl = hcl;
-                    pdz = sz - hz;  // delta_i = z[i + 1] - z[i], rt_core.cuh:359
+                    pz_ = my_held[0]; px_ = my_held[BLOCK]; py_ = my_held[2 * BLOCK]; pw_ = my_held[3 * BLOCK]; pcl = __float_as_int(my_held[4 * BLOCK]);
+                    pdz = sz - pz_;  // delta_i = z[i + 1] - z[i], rt_core.cuh:359
                 }
-                hz = sz; hx = sx; hy = sy; hw = sw; hcl = scl;
+                my_held[0] = sz; my_held[BLOCK] = sx; my_held[2 * BLOCK] = sy; my_held[3 * BLOCK] = sw; my_held[4 * BLOCK] = __int_as_float(scl);
                 held = true;
             } else if (has_ray && done && held) {
                 push = true;
                 last = true;
-                pz_ = hz; px_ = hx; py_ = hy; pw_ = hw; pcl = hcl;
+                pz_ = my_held[0]; px_ = my_held[BLOCK]; py_ = my_held[2 * BLOCK]; pw_ = my_held[3 * BLOCK]; pcl = __float_as_int(my_held[4 * BLOCK]);
                 held = false;
             }
             (void)pz_;
@@ -364,19 +371,20 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
             const unsigned long long t_w0 = F.diag ? wall_clock64() : 0;
             const uint32_t size = tail - head;
             if (size < (uint32_t)F.batch_min) ++n_drain;
-            const int n = size < 64u ? (int)size : 64;
-            const uint32_t e = (head + (uint32_t)lane) & (kPool - 1);
-            const bool col_on = lane < n;
+            const int n = size < (uint32_t)kFW ? (int)size : kFW;
+            const int cj = lane & (kFW - 1), part = lane / kFW;  // this lane's column and which share of the per-column work it does
+            const uint32_t e = (head + (uint32_t)cj) & (kPool - 1);
+            const bool col_on = cj < n;
             const uint32_t meta = col_on ? s_pm[e] : 0u;
             const int owner = (int)(meta & 63u), my_cl = (int)(int16_t)(meta >> 8);
             // The window's samples may belong to several sub-modules (a ray that crosses the front and the back of a surface changes
             // cluster on the way, and its neighbours do so a few steps apart): the network runs once per distinct cluster of the
             // window, every run fills the columns of its own cluster, and the pool stays first-in first-out.
-            uint64_t todo = __ballot(col_on);
+            uint64_t todo = __ballot(col_on && part == 0);  // one bit per column (lanes 0 .. W-1)
             while (todo != 0) {
             const int c_star = __builtin_amdgcn_readfirstlane(__shfl(my_cl, (int)__builtin_ctzll(todo)));
             const bool col_sel = col_on && my_cl == c_star;
-            const uint64_t sel = __ballot(col_sel);
+            const uint64_t sel = __ballot(col_sel && part == 0);
             todo &= ~sel;
             ++n_batches;
             if (todo != 0) ++n_cut;
@@ -403,33 +411,35 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                 constexpr int kFr = MT * (MT / 2);  // fragments of a hidden layer; the output layer's (2 * mt_out) are read as 8 as well
                                                     // (the arrays are padded, mnv_mlp_create), so every fetch is 8 unconditional loads
                 half8 cur[kFr];
-                f32x4 bias_cur[MT];
-                auto fetch = [&](half8 *dst, f32x4 *bdst, const half8 *src, const float *bsrc) {
+                auto fetch = [&](half8 *dst, const half8 *src, int count) {  // count is a compile-time constant at every call
 #pragma unroll
-                    for (int i = 0; i < kFr; ++i) dst[i] = src[i * 64 + lane];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) bdst[mt] = *reinterpret_cast<const f32x4 *>(bsrc + 16 * mt + 4 * g);
+                    for (int i = 0; i < kFr; ++i)
+                        if (i < count) dst[i] = src[i * 64 + lane];
                 };
+                auto bias_of = [&](const float *bsrc, int mt) -> f32x4 { return *reinterpret_cast<const f32x4 *>(bsrc + 16 * mt + 4 * g); };
                 constexpr int n0 = MT * NKK0;  // layer 0: fragment (mt, kk) at index mt * NKK0 + kk
                 static_assert(n0 <= kFr, "layer 0 is prefetched whole");
-                fetch(cur, bias_cur, w, b);
+                fetch(cur, w, n0);
                 const unsigned long long t_e0 = F.diag ? wall_clock64() : 0;
-                f32x4 acc[MT][kNT];
+                f32x4 acc[MT][kFNT];
                 // layer 0.  Every lane encodes its own column: feature f goes, as a half, to the slot of the MFMA B operand that
                 // slot_feature() assigns it (K tile f >> 5, lane group and element from f & 31), one 4 KB tile per K tile.  Straight-line
                 // per octave -- the generic encode_feature() loop of mlp_forward_kernel re-reads the network shape from the kernel
                 // arguments in every iteration, which this kernel's scalar-register pressure turned into 12 k cycles per run.
                 {
                     _Float16 *tile_h = reinterpret_cast<_Float16 *>(s_tile);
-                    auto put = [&](int f, float v) {  // f is wave-uniform
+                    auto put = [&](int f, float v) {  // f is uniform within a lane share
                         const int r = f & 31;
-                        const int dw = ((((r & 15) >> 2) * 4 + (((r >> 4) * 4 + (r & 3)) >> 1)) * 64) + (f >> 5) * 1024;
-                        tile_h[(dw + lane) * 2 + (r & 1)] = (_Float16)v;  // element e = (r >> 4) * 4 + (r & 3): its low bit is r & 1
+                        const int dw = ((((r & 15) >> 2) * 4 + (((r >> 4) * 4 + (r & 3)) >> 1)) * kFW) + (f >> 5) * (16 * kFW);
+                        tile_h[(dw + cj) * 2 + (r & 1)] = (_Float16)v;  // element e = (r >> 4) * 4 + (r & 3): its low bit is r & 1
                     };
+                    // the 64 / W lanes of a column share its features: octave k belongs to lane share k % parts, the rest to share 0
                     auto octaves = [&](int base, int n_oct, const float x[3]) {
+                        if (part == 0) {
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) put(base + i, x[i]);
-                        for (int k = 0; k < n_oct; ++k) {
+                            for (int i = 0; i < 3; ++i) put(base + i, x[i]);
+                        }
+                        for (int k = part; k < n_oct; k += kFParts) {
                             const float scale = __uint_as_float((uint32_t)(127 + k) << 23);
 #pragma unroll
                             for (int i = 0; i < 3; ++i) {
@@ -441,34 +451,38 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                     octaves(0, S.pos_octaves, p);
                     if (S.need_viewdir) octaves(S.n_pos, S.dir_octaves, d);
                     const int emb_base = S.n_pos + S.n_dir;
-                    for (int j = 0; j < S.embedding_dim; ++j) put(emb_base + j, half_bits_to_float(emb[j]));
-                    for (int f = S.in_dim; f < 32 * NKK0; ++f) put(f, 0.f);  // padding features: finite (their weights are zero)
+                    if (part == 0) {
+                        for (int j = 0; j < S.embedding_dim; ++j) put(emb_base + j, half_bits_to_float(emb[j]));
+                        for (int f = S.in_dim; f < 32 * NKK0; ++f) put(f, 0.f);  // padding features: finite (their weights are zero)
+                    }
                     __builtin_amdgcn_wave_barrier();
                 }
 #pragma unroll
                 for (int kk = 0; kk < NKK0; ++kk) {
-                    half8 bf[kNT];
+                    half8 bf[kFNT];
 #pragma unroll
-                    for (int nt = 0; nt < kNT; ++nt) {
+                    for (int nt = 0; nt < kFNT; ++nt) {
                         union {
                             uint32_t u[4];
                             half8 h;
                         } rd;
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) rd.u[q4] = s_tile[kk * 1024 + (g * 4 + q4) * 64 + nt * 16 + col];
+                        for (int q4 = 0; q4 < 4; ++q4) rd.u[q4] = s_tile[kk * (16 * kFW) + (g * 4 + q4) * kFW + nt * 16 + col];
                         bf[nt] = rd.h;
                     }
                     __builtin_amdgcn_wave_barrier();
                     if (kk == 0) {
 #pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const f32x4 bv = bias_of(b, mt);
 #pragma unroll
-                            for (int nt = 0; nt < kNT; ++nt) acc[mt][nt] = bias_cur[mt];
+                            for (int nt = 0; nt < kFNT; ++nt) acc[mt][nt] = bv;
+                        }
                     }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-                        for (int nt = 0; nt < kNT; ++nt)
+                        for (int nt = 0; nt < kFNT; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[mt * NKK0 + kk], bf[nt], acc[mt][nt], 0, 0, 0);
                     }
                 }
@@ -478,21 +492,22 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                 b += 16 * MT;
                 for (int layer = 1; layer <= S.hidden_layers; ++layer) {
                     const int n_mt = layer < S.hidden_layers ? MT : S.mt_out;
-                    fetch(cur, bias_cur, w, b);  // this layer's fragments travel while the activations are converted
-                    half8 bf[MT / 2][kNT];
+                    fetch(cur, w, kFr);  // this layer's fragments travel while the activations are converted
+                    half8 bf[MT / 2][kFNT];
 #pragma unroll
                     for (int kk = 0; kk < MT / 2; ++kk)
 #pragma unroll
-                        for (int nt = 0; nt < kNT; ++nt) bf[kk][nt] = relu_pack(acc[2 * kk][nt], acc[2 * kk + 1][nt]);
+                        for (int nt = 0; nt < kFNT; ++nt) bf[kk][nt] = relu_pack(acc[2 * kk][nt], acc[2 * kk + 1][nt]);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         if (mt < n_mt) {
+                            const f32x4 bv = bias_of(b, mt);
 #pragma unroll
-                            for (int nt = 0; nt < kNT; ++nt) acc[mt][nt] = bias_cur[mt];
+                            for (int nt = 0; nt < kFNT; ++nt) acc[mt][nt] = bv;
 #pragma unroll
                             for (int kk = 0; kk < MT / 2; ++kk) {
 #pragma unroll
-                                for (int nt = 0; nt < kNT; ++nt)
+                                for (int nt = 0; nt < kFNT; ++nt)
                                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(cur[mt * (MT / 2) + kk], bf[kk][nt], acc[mt][nt], 0, 0, 0);
                             }
                         }
@@ -506,9 +521,9 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                 for (int mt = 0; mt < MT; ++mt) {
                     if (mt < S.mt_out) {
 #pragma unroll
-                        for (int nt = 0; nt < kNT; ++nt)
+                        for (int nt = 0; nt < kFNT; ++nt)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) s_out[(16 * mt + 4 * g + r) * 64 + nt * 16 + col] = acc[mt][nt][r];
+                            for (int r = 0; r < 4; ++r) s_out[(16 * mt + 4 * g + r) * kFW + nt * 16 + col] = acc[mt][nt][r];
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -516,21 +531,26 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
             const unsigned long long t_c0 = F.diag ? wall_clock64() : 0;
             // ---- column j: transmittance factor and colour denominators of its sample (rt_core.cuh:356-392), SH basis of the owner
             if (col_sel) {
-                auto sv = [&](int f) -> float { return valid_cluster ? s_out[f * 64 + lane] : 0.f; };  // no sub-module: zeros (mlp_histogram)
-                const bool last = (meta & 64u) != 0;
-                s_ra[lane] = last ? 0.f : exact_expf(-sv(3) * s_pd[e], s_exp);
+                auto sv = [&](int f) -> float { return valid_cluster ? s_out[f * kFW + cj] : 0.f; };  // no sub-module: zeros (mlp_histogram)
+                // the four quantities of a column are dealt to its 64 / W lanes: quantity q belongs to lane share q % parts
+                if (0 % kFParts == part) {
+                    const bool last = (meta & 64u) != 0;
+                    s_ra[cj] = last ? 0.f : exact_expf(-sv(3) * s_pd[e], s_exp);
+                }
                 if constexpr (BASIS >= 0) {
                     float basis[NB];
 #pragma unroll
                     for (int k = 0; k < NB; ++k) basis[k] = s_ray[k * BLOCK + wave_base + owner];
                     const int stride = BASIS > 0 ? BASIS : 0;
-                    s_r0[lane] = 1.f + exact_expf(-sh_channel<BASIS>(basis, sv, 0), s_exp);
-                    s_r1[lane] = 1.f + exact_expf(-sh_channel<BASIS>(basis, sv, stride), s_exp);
-                    s_r2[lane] = 1.f + exact_expf(-sh_channel<BASIS>(basis, sv, 2 * stride), s_exp);
+                    if (1 % kFParts == part) s_r0[cj] = 1.f + exact_expf(-sh_channel<BASIS>(basis, sv, 0), s_exp);
+                    if (2 % kFParts == part) s_r1[cj] = 1.f + exact_expf(-sh_channel<BASIS>(basis, sv, stride), s_exp);
+                    if (3 % kFParts == part) s_r2[cj] = 1.f + exact_expf(-sh_channel<BASIS>(basis, sv, 2 * stride), s_exp);
                 } else {
-                    s_r0[lane] = sv(0);
-                    s_r1[lane] = sv(1);
-                    s_r2[lane] = sv(2);
+                    if (part == 0) {
+                        s_r0[cj] = sv(0);
+                        s_r1[cj] = sv(1);
+                        s_r2[cj] = sv(2);
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();  // the next cluster's run rewrites the tile

@@ -1601,8 +1601,8 @@ int mnv_render_guided_fused_track(const mnv_accel *accel, const mnv_camera *cam,
     }
     F.max_guided_samples = opt->max_guided_samples;
     F.appearance_embedding = opt->appearance_embedding;
-    static const int env_batch = getenv("MNV_FUSED_BATCH_MIN") ? atoi(getenv("MNV_FUSED_BATCH_MIN")) : 64;
-    F.batch_min = env_batch < 1 ? 1 : (env_batch > 64 ? 64 : env_batch);
+    static const int env_batch = getenv("MNV_FUSED_BATCH_MIN") ? atoi(getenv("MNV_FUSED_BATCH_MIN")) : kFW;
+    F.batch_min = env_batch < 1 ? 1 : (env_batch > kFW ? kFW : env_batch);
     F.sample_counter = sample_counter;
     static const bool env_diag = getenv("MNV_FUSED_DIAG") != nullptr;  // the counter then has three words
     F.diag = env_diag && sample_counter ? 1 : 0;
