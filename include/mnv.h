@@ -418,6 +418,11 @@ int mnv_apply_sample_results(uint16_t *data, int16_t *sample_counts, const int32
  */
 int mnv_prune_tree(const mnv_tree_edit *tree, uint16_t *data, int32_t data_dim, int16_t *sample_counts, int32_t *visited,
                    int32_t max_capacity, int32_t *new_capacity, int32_t *num_deleted, void *hip_stream);
+/* The same, and the packed accel of the tree follows in place (NULL: plain mnv_prune_tree): surviving chunks are renumbered in the node
+ * words and both lookup grids, voxels whose sub-tree went become leaves, the colour rows are compacted -- about 0.9 ms of traffic for
+ * the 1.5 M-chunk tree instead of the 2.9 ms of mnv_accel_rebuild.  The accel must describe the tree as it is before the call. */
+int mnv_prune_tree_accel(const mnv_tree_edit *tree, uint16_t *data, int32_t data_dim, int16_t *sample_counts, int32_t *visited,
+                         int32_t max_capacity, mnv_accel *accel, int32_t *new_capacity, int32_t *num_deleted, void *hip_stream);
 
 /* torch::rand's role in expand_voxels / get_more_samples (cuda_renderer.cpp:247-250,298-301): n uniform numbers in
  * [0, 1) with 24 random bits each, a pure function of (seed, index) -- reproducible, unlike the reference. */

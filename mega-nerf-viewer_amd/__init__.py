@@ -241,6 +241,8 @@ _SIGNATURES = {
     "mnv_apply_sample_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "mnv_prune_tree": (C.c_int, [C.POINTER(TreeEdit), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int32), C.c_void_p]),
+    "mnv_prune_tree_accel": (C.c_int, [C.POINTER(TreeEdit), C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_int32),
+                                       C.POINTER(C.c_int32), C.c_void_p]),
     "mnv_mlp_param_count": (C.c_size_t, [C.POINTER(MlpDesc)]),
     "mnv_mlp_create": (C.c_int, [C.POINTER(MlpDesc), C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mnv_mlp_destroy": (None, [C.c_void_p]),
@@ -697,11 +699,11 @@ def apply_sample_results(data, sample_counts, nodes, results, samples_per_corner
                                           samples_per_corner, data_dim, C.c_void_p(stream)))
 
 
-def prune_tree(edit: TreeEdit, data, data_dim: int, sample_counts, visited, max_capacity: int, stream: int = 0):
-    """-> (new_capacity, num_deleted)."""
+def prune_tree(edit: TreeEdit, data, data_dim: int, sample_counts, visited, max_capacity: int, stream: int = 0, accel: int = 0):
+    """-> (new_capacity, num_deleted).  `accel`: the tree's packed accel follows the prune in place (mnv_prune_tree_accel)."""
     new_cap, n_del = C.c_int32(0), C.c_int32(0)
-    _check(lib().mnv_prune_tree(C.byref(edit), _ptr(data), data_dim, _ptr(sample_counts), _ptr(visited), max_capacity, C.byref(new_cap),
-                                C.byref(n_del), C.c_void_p(stream)))
+    _check(lib().mnv_prune_tree_accel(C.byref(edit), _ptr(data), data_dim, _ptr(sample_counts), _ptr(visited), max_capacity,
+                                      C.c_void_p(accel) if accel else None, C.byref(new_cap), C.byref(n_del), C.c_void_p(stream)))
     return new_cap.value, n_del.value
 
 

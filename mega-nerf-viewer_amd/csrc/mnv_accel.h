@@ -105,6 +105,9 @@ struct mnv_accel {
     uint32_t *grid_vox = nullptr;
     uint32_t *grid2 = nullptr;
     uint32_t *grid2_vox = nullptr;
+    uint32_t *nodes_spare = nullptr;      // second set of nodes / rows / depth, allocated by the first prune (accel_apply_prune writes the
+    uint8_t *rows_spare = nullptr;        // survivors out of place, then the sets swap)
+    int32_t *depth_spare = nullptr;
     int32_t *depth = nullptr;             // [reserved] depth of the voxels of each chunk (root chunk: 1); kept for mnv_accel_refresh
     int32_t *flags = nullptr;             // [4] device scratch of refresh: changed, deepest depth, grids dirty
     int64_t reserved = 0;                 // chunks the nodes / rows / depth arrays have room for

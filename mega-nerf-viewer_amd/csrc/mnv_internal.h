@@ -22,6 +22,9 @@ void fill_camera(CamBlock &C, const mnv_camera *cam);
 int fill_tree_params(MarchParams &P, const mnv_tree_view *t);
 int launch_ref_layout(const MarchParams &P, hipStream_t stream);
 int launch_background(const FrameParams &P, hipStream_t stream);
+// the packed layout follows a prune; called by mnv_prune_tree_accel with the OLD numbering (before fix-up and compaction)
+int accel_apply_prune(mnv_accel *a, const int32_t *parent, const uint16_t *data, int32_t data_dim, const uint8_t *to_delete, const int32_t *shifts,
+                      int32_t old_capacity, int32_t n_deleted, hipStream_t stream);
 
 // event-based timing of the render launches (mnv_set_timing / mnv_take_timing)
 struct LaunchTimer {

@@ -232,6 +232,72 @@ __global__ void accel_patch_grid2(const int32_t *vox_pairs, int32_t first_chunk,
     }
 }
 
+// ---- the packed layout follows a prune (mnv_prune_tree_accel): chunk c survives as c - shifts[c] unless to_delete[c]; a voxel whose
+// child chunk is deleted becomes a leaf (the marks are closed under ancestors, so a deleted chunk's whole sub-tree goes with it).
+// All three kernels read the OLD numbering: they run before the tree arrays are fixed up and compacted.
+
+__device__ __forceinline__ uint32_t pruned_leaf_word(const int32_t *depth, const uint16_t *data, int32_t data_dim, int32_t chunk, int32_t slot) {
+    return kLeafBit | (((uint32_t)depth[chunk] & 0x7fu) << 16) | (uint32_t)data[((int64_t)chunk * 8 + slot) * data_dim + data_dim - 1];
+}
+
+__global__ void accel_prune_nodes(const uint32_t *nodes, const int32_t *depth, const uint16_t *data, int32_t data_dim, const uint8_t *to_delete,
+                                  const int32_t *shifts, int32_t capacity, uint32_t *nodes_out, int32_t *depth_out) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= (int64_t)capacity * 8) return;
+    const int32_t c = (int32_t)(v >> 3);
+    if (to_delete[c]) return;
+    uint32_t word = nodes[v];
+    if (!(word & kLeafBit)) {
+        const int32_t cc = (int32_t)word;
+        word = to_delete[cc] ? pruned_leaf_word(depth, data, data_dim, c, (int32_t)(v & 7)) : (uint32_t)(cc - shifts[cc]);
+    }
+    const int32_t nc = c - shifts[c];
+    nodes_out[(int64_t)nc * 8 + (v & 7)] = word;
+    if ((v & 7) == 0) depth_out[nc] = depth[c];
+}
+
+__global__ void accel_prune_rows(const uint4 *rows, const uint8_t *to_delete, const int32_t *shifts, int32_t capacity, int32_t quads_per_chunk,
+                                 uint4 *rows_out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)capacity * quads_per_chunk) return;
+    const int32_t c = (int32_t)(i / quads_per_chunk);
+    if (to_delete[c]) return;
+    rows_out[(int64_t)(c - shifts[c]) * quads_per_chunk + (i - (int64_t)c * quads_per_chunk)] = rows[i];
+}
+
+__global__ void accel_prune_grid(uint32_t *grid, uint32_t *grid_vox, int64_t cells, const int32_t *parent, const int32_t *depth, const uint16_t *data,
+                                 int32_t data_dim, const uint8_t *to_delete, const int32_t *shifts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    uint32_t word = grid[i];
+    int32_t c, slot = 0;
+    if (word & kLeafBit) {
+        const uint32_t vox = grid_vox[i];
+        c = (int32_t)(vox >> 3);
+        slot = (int32_t)(vox & 7u);
+        if (!to_delete[c]) {
+            grid_vox[i] = (uint32_t)(c - shifts[c]) * 8u + (uint32_t)slot;
+            return;
+        }
+    } else {
+        c = (int32_t)word;  // the chunk of the cell's children
+        if (!to_delete[c]) {
+            grid[i] = (uint32_t)(c - shifts[c]);
+            return;
+        }
+    }
+    // the covering voxel sits in (or points into) a deleted sub-tree: the leaf is now the voxel under which the first deleted chunk hung
+    int32_t pc;
+    do {
+        const int32_t pv = parent[c];
+        pc = pv >> 3;
+        slot = pv & 7;
+        c = pc;
+    } while (to_delete[pc]);
+    grid[i] = pruned_leaf_word(depth, data, data_dim, pc, slot);
+    grid_vox[i] = (uint32_t)(pc - shifts[pc]) * 8u + (uint32_t)slot;
+}
+
 // Per-launch parameters that live in device memory: zeroes the ray-queue heads of every frame and
 // stores the camera blocks (handed over by value, so no host staging buffer or copy engine is involved).
 constexpr int kStageCams = 32;
@@ -928,6 +994,45 @@ static int launch_variant(const AccelLaunch &K, int n_blocks, size_t lds_bytes, 
 static bool is_partitioned(mnv_partition part) { return part.world > 1 || (part.world == 1 && part.tile_w > 0); }
 static int32_t root_period_of(mnv_partition part) { return part.world > 1 && part.root_period >= 2 ? part.root_period : 0; }
 
+// Called by mnv_prune_tree_accel between its scan and its fix-up / compaction (old numbering everywhere).
+int accel_apply_prune(mnv_accel *a, const int32_t *parent, const uint16_t *data, int32_t data_dim, const uint8_t *to_delete, const int32_t *shifts,
+                      int32_t old_capacity, int32_t n_deleted, hipStream_t stream) {
+    if (!a || old_capacity != a->view.capacity) return set_error(MNV_E_INVALID, "the accel does not describe the tree that is being pruned");
+    int rc;
+    const int64_t reserved = a->reserved;
+    const int row_bytes = a->view.row_bytes;
+    if (!a->nodes_spare) {  // second set of the per-voxel arrays: the survivors are written out of place, then the sets swap
+        if ((rc = check_hip(hipMalloc((void **)&a->nodes_spare, reserved * 8 * 4), "hipMalloc(nodes spare)"))) return rc;
+        if ((rc = check_hip(hipMalloc((void **)&a->rows_spare, reserved * 8 * row_bytes), "hipMalloc(rows spare)"))) return rc;
+        if ((rc = check_hip(hipMalloc((void **)&a->depth_spare, reserved * 4), "hipMalloc(depth spare)"))) return rc;
+    }
+    if ((rc = check_hip(hipMemsetAsync(a->depth_spare, 0, reserved * 4, stream), "memset depth"))) return rc;
+    const int64_t nvox = (int64_t)old_capacity * 8;
+    hipLaunchKernelGGL(accel_prune_nodes, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, stream, a->nodes, a->depth, data, data_dim, to_delete, shifts,
+                       old_capacity, a->nodes_spare, a->depth_spare);
+    const int32_t quads = 8 * row_bytes / 16;
+    if (8 * row_bytes % 16) return set_error(MNV_E_UNSUPPORTED, "row size");
+    const int64_t nq = (int64_t)old_capacity * quads;
+    hipLaunchKernelGGL(accel_prune_rows, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const uint4 *>(a->rows), to_delete, shifts,
+                       old_capacity, quads, reinterpret_cast<uint4 *>(a->rows_spare));
+    const int64_t gcells = (int64_t)1 << (3 * a->view.grid_level);
+    hipLaunchKernelGGL(accel_prune_grid, dim3((unsigned)((gcells + 255) / 256)), dim3(256), 0, stream, a->grid, a->grid_vox, gcells, parent, a->depth, data,
+                       data_dim, to_delete, shifts);
+    if (a->view.grid2_level > 0) {
+        const int64_t g2 = (int64_t)1 << (3 * a->view.grid2_level);
+        hipLaunchKernelGGL(accel_prune_grid, dim3((unsigned)((g2 + 255) / 256)), dim3(256), 0, stream, a->grid2, a->grid2_vox, g2, parent, a->depth, data,
+                           data_dim, to_delete, shifts);
+    }
+    if ((rc = check_hip(hipGetLastError(), "accel prune launch"))) return rc;
+    std::swap(a->nodes, a->nodes_spare);
+    std::swap(a->rows, a->rows_spare);
+    std::swap(a->depth, a->depth_spare);
+    a->view.nodes = a->nodes;
+    a->view.rows = a->rows;
+    a->view.capacity = old_capacity - n_deleted;  // max_depth stays an upper bound (the march only needs pos * 2^max_depth < 2^24)
+    return MNV_OK;
+}
+
 int32_t partition_local_tiles(mnv_rect tile, mnv_partition part) {
     if (tile.w <= 0 || tile.h <= 0 || !is_partitioned(part)) return is_partitioned(part) ? 0 : 1;
     const int64_t mx = (tile.w + part.tile_w - 1) / part.tile_w, my = (tile.h + part.tile_h - 1) / part.tile_h;
@@ -1383,6 +1488,9 @@ void mnv_accel_destroy(mnv_accel *a) {
         }
     }
     if (a->timeline) (void)hipFree(a->timeline);
+    if (a->nodes_spare) (void)hipFree(a->nodes_spare);
+    if (a->rows_spare) (void)hipFree(a->rows_spare);
+    if (a->depth_spare) (void)hipFree(a->depth_spare);
     if (a->stats) (void)hipFree(a->stats);
     if (a->depth) (void)hipFree(a->depth);
     if (a->flags) (void)hipFree(a->flags);

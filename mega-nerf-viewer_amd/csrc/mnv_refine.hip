@@ -349,6 +349,11 @@ int mnv_apply_sample_results(uint16_t *data, int16_t *sample_counts, const int32
 
 int mnv_prune_tree(const mnv_tree_edit *tree, uint16_t *data, int32_t data_dim, int16_t *sample_counts, int32_t *visited,
                    int32_t max_capacity, int32_t *new_capacity, int32_t *num_deleted, void *hip_stream) {
+    return mnv_prune_tree_accel(tree, data, data_dim, sample_counts, visited, max_capacity, nullptr, new_capacity, num_deleted, hip_stream);
+}
+
+int mnv_prune_tree_accel(const mnv_tree_edit *tree, uint16_t *data, int32_t data_dim, int16_t *sample_counts, int32_t *visited,
+                         int32_t max_capacity, mnv_accel *accel, int32_t *new_capacity, int32_t *num_deleted, void *hip_stream) {
     if (num_deleted) *num_deleted = 0;
     if (!tree || !tree->child || !tree->parent || !data || !visited || data_dim < 1 || tree->capacity < 1 ||
         max_capacity < tree->capacity)
@@ -395,6 +400,9 @@ int mnv_prune_tree(const mnv_tree_edit *tree, uint16_t *data, int32_t data_dim, 
     if (n_del == 0) return clear_marks();  // "Nothing can be pruned"
     if (!root_visited)
         return set_error(MNV_E_INVALID, "the root chunk is not marked visited: render a track_visit frame before pruning");
+
+    // the packed layout follows first: its kernels read the old numbering of parent / data, which the next two steps rewrite
+    if (accel && (rc = accel_apply_prune(accel, tree->parent, data, data_dim, to_delete, shifts, cap, n_del, stream))) return rc;
 
     // argmin of a non-decreasing cumsum is its first element: the reference's first_shift_index is 0
     // (cuda_renderer.cpp:350), which is also what the fix-up needs -- unshifted chunks can point at shifted ones

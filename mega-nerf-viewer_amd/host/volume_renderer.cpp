@@ -71,7 +71,7 @@ struct VolumeRenderer::Impl {
     DeviceBuffer split_tracker, sample_tracker, visit_tracker, num_samples, cluster_indices, guided_samples;
     DeviceBuffer offsets, z_vals, sample_rows, sample_clusters, nerf_results;
     DeviceBuffer nodes, rand_sample, rand_clusters, results, fused_counter;
-    bool rebuild_after_prune = true;
+    bool patch_after_prune = true;
     bool fused_inputs_ok = false;  // the model's encoded input fits the fused guided kernel (<= 64 features)
     bool prune_happened = false, can_reuse_results = false, accel_stale = false;
     bool marks_fresh = false, want_marks = false;  // see render(): prune only after a track_visit frame
@@ -225,17 +225,19 @@ void VolumeRenderer::Impl::prune_tree(FrameStats &st) {
     const mnv_tree_edit e = edit();
     int32_t new_cap = tree->capacity, n_del = 0;
     // sample_counts is compacted with the other arrays; the reference forgets it (cuda_renderer.cpp:357-369)
-    mnv_check(mnv_prune_tree(&e, tree->device.data, tree->data_dim, tree->device.sample_counts, visit_tracker.get<int32_t>(max_tree_capacity),
-                             (int32_t)max_tree_capacity, &new_cap, &n_del, stream),
-              "mnv_prune_tree");
+    // A prune renumbers the chunks; the packed accel follows in place (mnv_prune_tree_accel: renumbered node words and lookup grids,
+    // compacted colour rows), so that the next frame -- a visit-mark frame, cuda_renderer.cpp:101-102 -- runs on the tuned kernel as well.
+    mnv_accel *follow = (tree->device.accel && !accel_stale && patch_after_prune) ? tree->device.accel : nullptr;
+    mnv_check(mnv_prune_tree_accel(&e, tree->device.data, tree->data_dim, tree->device.sample_counts, visit_tracker.get<int32_t>(max_tree_capacity),
+                                   (int32_t)max_tree_capacity, follow, &new_cap, &n_del, stream),
+              "mnv_prune_tree_accel");
     st.pruned = n_del > 0 ? n_del : -1;
     if (n_del > 0) {
         tree->capacity = new_cap;
         tree_changed();
-        // A prune renumbers the chunks: the packed layout is rebuilt in place right away (2.9 ms for the 1.5 M-chunk tree; prunes
-        // happen when the tree is nearly full, not per frame), so that the next frame -- a visit-mark frame, cuda_renderer.cpp:101-102 --
-        // runs on the tuned kernel as well.
-        if (tree->device.accel && rebuild_after_prune) {
+        if (follow) {
+            accel_stale = false;
+        } else if (tree->device.accel) {  // no patch (switched off, or the accel was stale already): rebuild in place, 2.9 ms on the 1.5 M-chunk tree
             tree->rebuild_accel(stream);
             accel_stale = false;
         }

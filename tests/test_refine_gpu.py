@@ -289,3 +289,66 @@ def test_refinement_kernels_match_reference_code_goldens(mnv, orc, torch_gpu):
     assert np.array_equal(dchild.cpu().numpy(), z["adjust_parents/child"])
     keep = to_delete == 0
     assert np.array_equal(dparent.cpu().numpy()[keep], z["adjust_parents/parent"][keep])
+
+
+@pytest.mark.parametrize("tree_spec,cam_args", [
+    (dict(kind="shell", depth=9, basis_dim=4, radius=0.35, half_thickness=1.5 / 512, seed=3), (640, 360, 520.0, 2.6, 30.0, 20.0)),
+    (dict(kind="random", depth=6, basis_dim=9, refine_prob=0.55, empty_prob=0.6, sigma_max=40.0, coef_sd=1.0, seed=11), (320, 240, 260.0, 2.4, 200.0, 35.0)),
+])
+def test_accel_follows_a_prune_in_place(mnv, orc, torch_gpu, tree_spec, cam_args):
+    """mnv_prune_tree_accel: the packed accel is patched while the tree is pruned (chunks renumbered in node words and lookup grids,
+    sub-trees that went replaced by their parent leaf, colour rows compacted).  Afterwards the patched accel, a freshly built accel of
+    the pruned tree and the reference-layout kernel give the same frames, tracker rows (voxel numbers!) and visit marks -- from the
+    pruning camera and from others that look at the pruned parts."""
+    torch = torch_gpu
+    tree = cases.make_tree(mnv, tree_spec)
+    v = tree.host_view()
+    cap, dd = v.capacity, v.data_dim
+    max_cap = cap + 64
+    tree.move_to_device(max_capacity=max_cap, need_parent=True, need_sample_counts=True)
+    dv = tree.device_view()
+    cam = mnv.orbit_camera(*cam_args)
+    opt = mnv.RenderOptions.cli_defaults()
+    opt.basis_minmax[1] = max(v.basis_dim - 1, 0)
+    opt.max_depth, opt.max_sample_count = 7, 9
+    h, w = cam.height, cam.width
+    visited = torch.zeros(max_cap, dtype=torch.int32, device="cuda")
+    before = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    mnv.render_voxels_accel_visit(tree.accel, cam, opt, visited, dv.parent, rgba=before)   # the marks of this view
+    torch.cuda.synchronize()
+    edit = mnv.TreeEdit()
+    edit.child, edit.parent, edit.N, edit.capacity = dv.child, dv.parent, 2, cap
+    for i in range(3):
+        edit.offset[i], edit.scale[i] = v.offset[i], v.scale[i]
+    new_cap, n_del = mnv.prune_tree(edit, dv.data, dd, dv.sample_counts, visited, max_cap, accel=tree.accel)
+    assert 0 < new_cap < cap and n_del == cap - new_cap
+    pv = mnv.TreeView()
+    for f in ("data", "child", "parent", "sample_counts", "offset", "scale", "N", "data_dim", "format", "basis_dim"):
+        setattr(pv, f, getattr(dv, f))
+    pv.capacity = new_cap
+    fresh = mnv.accel_create(pv, max_capacity=max_cap)
+    try:
+        sc = torch.full((max_cap, 8), 8, dtype=torch.int16, device="cuda")
+        sc[::3] = 12
+        for pose, other in enumerate([cam, mnv.orbit_camera(cam_args[0], cam_args[1], cam_args[2], cam_args[3], cam_args[4] + 140.0, -cam_args[5])]):
+            outs = []
+            for which in ("patched", "fresh", "ref"):
+                rgba = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+                split = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")
+                sample = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")
+                marks = torch.zeros(max_cap, dtype=torch.int32, device="cuda")
+                if which == "ref":
+                    pv.sample_counts = sc.data_ptr()
+                    mnv.render_voxels(pv, other, opt, rgba=rgba, split_track=split, sample_track=sample, visited=marks, track_visit=True)
+                else:
+                    mnv.render_voxels_accel_visit(tree.accel if which == "patched" else fresh, other, opt, marks, pv.parent, rgba=rgba,
+                                                  split_track=split, sample_track=sample, sample_counts=sc)
+                torch.cuda.synchronize()
+                outs.append((rgba, split, sample, marks))
+            for k in range(4):
+                assert torch.equal(outs[0][k].view(torch.int32), outs[2][k].view(torch.int32)), (pose, k, "patched vs reference layout")
+                assert torch.equal(outs[1][k].view(torch.int32), outs[2][k].view(torch.int32)), (pose, k, "fresh vs reference layout")
+            if pose == 0:
+                assert torch.equal(outs[0][0].view(torch.int32), before.view(torch.int32))   # the pruning view is unchanged by the prune
+    finally:
+        mnv.accel_destroy(fresh)
