@@ -416,10 +416,22 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                     for (int i = 0; i < kFr; ++i)
                         if (i < count) dst[i] = src[i * 64 + lane];
                 };
-                auto bias_of = [&](const float *bsrc, int mt) -> f32x4 { return *reinterpret_cast<const f32x4 *>(bsrc + 16 * mt + 4 * g); };
+                // the layer's bias tiles travel with its fragments (16 registers) when the register budget allows: 64-column runs
+                f32x4 bias_pre[kFNT >= 4 ? MT : 1];
+                auto fetch_bias = [&](const float *bsrc) {
+                    if constexpr (kFNT >= 4) {
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) bias_pre[mt] = *reinterpret_cast<const f32x4 *>(bsrc + 16 * mt + 4 * g);
+                    }
+                };
+                auto bias_of = [&](const float *bsrc, int mt) -> f32x4 {
+                    if constexpr (kFNT >= 4) return bias_pre[mt];
+                    else return *reinterpret_cast<const f32x4 *>(bsrc + 16 * mt + 4 * g);
+                };
                 constexpr int n0 = MT * NKK0;  // layer 0: fragment (mt, kk) at index mt * NKK0 + kk
                 static_assert(n0 <= kFr, "layer 0 is prefetched whole");
                 fetch(cur, w, n0);
+                fetch_bias(b);
                 const unsigned long long t_e0 = F.diag ? wall_clock64() : 0;
                 f32x4 acc[MT][kFNT];
                 // layer 0.  Every lane encodes its own column: feature f goes, as a half, to the slot of the MFMA B operand that
@@ -493,6 +505,7 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                 for (int layer = 1; layer <= S.hidden_layers; ++layer) {
                     const int n_mt = layer < S.hidden_layers ? MT : S.mt_out;
                     fetch(cur, w, kFr);  // this layer's fragments travel while the activations are converted
+                    fetch_bias(b);
                     half8 bf[MT / 2][kFNT];
 #pragma unroll
                     for (int kk = 0; kk < MT / 2; ++kk)
