@@ -543,10 +543,36 @@ def accel_refresh(accel: int, tree_view: TreeView, old_capacity: int, changed_no
     _check(lib().mnv_accel_refresh(C.c_void_p(accel), C.byref(tree_view), old_capacity, _ptr(changed_nodes), n, C.c_void_p(stream)))
 
 
+def _check_out(name: str, t, pixels: int, dtype_name: str) -> None:
+    """An output tensor must be a contiguous device tensor of the right element type with room for `pixels` RGBA pixels: the library
+    writes through the raw pointer."""
+    if t is None or isinstance(t, int):
+        return
+    import torch
+
+    want = torch.float32 if dtype_name == "f32" else torch.uint8
+    if not t.is_cuda or not t.is_contiguous() or t.dtype != want or t.numel() < pixels * 4:
+        raise MnvError(MNV_E_INVALID, f"{name} must be a contiguous {want} device tensor with at least {pixels} RGBA pixels "
+                                      f"(got {tuple(t.shape)} {t.dtype}, device {t.device})")
+
+
+def _pixels(tile, n_frames: int, part) -> int:
+    """Pixels the launch may write: frames x tile, or frames x j_max macro tiles for a partitioned launch."""
+    _, _, w, h = tile
+    if part is None or not (part[1] > 1 or (part[1] == 1 and part[2] > 0)):
+        return n_frames * w * h
+    rank, world, tw, th = part[:4]
+    period = part[4] if len(part) > 4 else 0
+    j_max = max(partition_local_tiles(tile, r, world, tw, th, period) for r in range(world))
+    return n_frames * j_max * tw * th
+
+
 def render_voxels_accel(accel: int, cam: Camera, opt: RenderOptions, tile=None, rgba=None, rgba8=None, stream: int = 0) -> None:
     """The tuned march on the packed layout (asynchronous on `stream`)."""
     if tile is None:
         tile = (0, 0, cam.width, cam.height)
+    _check_out("rgba", rgba, tile[2] * tile[3], "f32")
+    _check_out("rgba8", rgba8, tile[2] * tile[3], "u8")
     _check(lib().mnv_render_voxels_accel(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba), _ptr(rgba8),
                                          C.c_void_p(stream)))
 
@@ -602,6 +628,9 @@ def render_voxels_accel_part(accel: int, cam: Camera, opt: RenderOptions, rank: 
     compact local-tile-major buffer [local_tiles][tile_h][tile_w][4] (see mnv_partition in include/mnv.h)."""
     if tile is None:
         tile = (0, 0, cam.width, cam.height)
+    n_local = partition_local_tiles(tile, rank, world, tile_w, tile_h, root_period)
+    _check_out("rgba", rgba, n_local * tile_w * tile_h, "f32")
+    _check_out("rgba8", rgba8, n_local * tile_w * tile_h, "u8")
     _check(lib().mnv_render_voxels_accel_part(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile),
                                               Partition(rank, world, tile_w, tile_h, root_period), _ptr(rgba), _ptr(rgba8), C.c_void_p(stream)))
 
@@ -846,6 +875,9 @@ def render_voxels_accel_batch(accel: int, cams, opt: RenderOptions, tile=None, p
     if tile is None:
         tile = (0, 0, cams[0].width, cams[0].height)
     p = Partition(0, 1, 0, 0) if part is None else Partition(*part)
+    px = _pixels(tile, n, part)
+    _check_out("rgba", rgba, px, "f32")
+    _check_out("rgba8", rgba8, px, "u8")
     _check(lib().mnv_render_voxels_accel_batch(C.c_void_p(accel), arr, n, C.byref(opt), Rect(*tile), p, _ptr(rgba), _ptr(rgba8),
                                                C.c_void_p(stream)))
 

@@ -612,3 +612,31 @@ def test_single_rank_partition_layout(mnv, torch_gpu, cfg2):
     part.unpermute(buf, out=out)
     torch.cuda.synchronize()
     assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(full))
+
+
+def test_binding_rejects_output_tensors_that_are_too_small_or_of_the_wrong_kind(mnv, torch_gpu):
+    """The library writes through raw pointers; the ctypes harness checks size, element type, contiguity and device of its tensors."""
+    torch = torch_gpu
+    spec = cases.CASES["sh4_d6"]
+    tree = cases.make_tree(mnv, spec["tree"])
+    tree.move_to_device()
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    h, w = cam.height, cam.width
+    with pytest.raises(mnv.MnvError):
+        mnv.render_voxels_accel(tree.accel, cam, opt, rgba=torch.empty((h - 1, w, 4), dtype=torch.float32, device="cuda"))
+    with pytest.raises(mnv.MnvError):
+        mnv.render_voxels_accel(tree.accel, cam, opt, rgba=torch.empty((h, w, 4), dtype=torch.float16, device="cuda"))
+    with pytest.raises(mnv.MnvError):
+        mnv.render_voxels_accel(tree.accel, cam, opt, rgba=torch.empty((h, w, 4), dtype=torch.float32))          # host tensor
+    with pytest.raises(mnv.MnvError):
+        mnv.render_voxels_accel(tree.accel, cam, opt, rgba8=torch.empty((h, w, 8), dtype=torch.uint8, device="cuda")[..., :4])  # strided
+    n1 = mnv.partition_local_tiles((0, 0, w, h), 1, 3, 64, 24)
+    with pytest.raises(mnv.MnvError):
+        mnv.render_voxels_accel_part(tree.accel, cam, opt, 1, 3, 64, 24, rgba=torch.empty((n1 - 1, 24, 64, 4), dtype=torch.float32, device="cuda"))
+    j_max = max(mnv.partition_local_tiles((0, 0, w, h), r, 3, 64, 24) for r in range(3))
+    with pytest.raises(mnv.MnvError):
+        mnv.render_voxels_accel_batch(tree.accel, [cam, cam], opt, part=(1, 3, 64, 24), rgba=torch.empty((2, j_max - 1, 24, 64, 4), dtype=torch.float32, device="cuda"))
+    ok = torch.empty((2, j_max, 24, 64, 4), dtype=torch.float32, device="cuda")
+    mnv.render_voxels_accel_batch(tree.accel, [cam, cam], opt, part=(1, 3, 64, 24), rgba=ok)
+    torch.cuda.synchronize()
