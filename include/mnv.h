@@ -263,7 +263,7 @@ int mnv_render_voxels_accel_batch(const mnv_accel *accel, const mnv_camera *cams
  * as mnv_render_voxels writes them; sample_counts is the tree's live [capacity][N^3] int16 array in
  * the reference layout (it changes between frames, so it is not part of the accel) or NULL.
  * opt->max_depth / opt->max_sample_count bound the candidates.  The `visited` marks
- * (track_visit) need every chunk on the descent path and stay with mnv_render_voxels.
+ * (track_visit): mnv_render_voxels_accel_visit.
  * Either tracker may be NULL; with both NULL this is mnv_render_voxels_accel.
  */
 int mnv_render_voxels_accel_track(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,
@@ -296,8 +296,8 @@ int mnv_get_samples_from_voxels(const mnv_tree_view *tree, const mnv_camera *cam
                                 int track_visit, int16_t *num_samples, float *samples, int32_t samples_dim,
                                 int16_t *cluster_indices, const mnv_cluster_grid *grid, void *hip_stream);
 
-/* The same march on the packed accel (no visit marks: they need every chunk on the descent, see
- * mnv_render_voxels_accel_track); sample_counts is the tree's live [capacity][8] array or NULL.  Bit-identical rows. */
+/* The same march on the packed accel (visit marks: mnv_get_samples_from_voxels_accel_visit below); sample_counts is the tree's
+ * live [capacity][8] array or NULL.  Bit-identical rows. */
 int mnv_get_samples_from_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
                                       float *split_track, float *sample_track, const int16_t *sample_counts, int16_t *num_samples,
                                       float *samples, int32_t samples_dim, int16_t *cluster_indices, const mnv_cluster_grid *grid,
@@ -485,12 +485,12 @@ int mnv_query_submodules(mnv_mlp *mlp, const int16_t *cluster_indices, const flo
  * The guided-sampling frame as ONE kernel (BASELINE.json configs[4]): what the reference does with get_samples_from_voxels,
  * a cumsum / boolean-mask compaction, query_submodules and render_nerf_results (src/renderer/cuda_renderer.cpp:107-139) --
  * and this library's own four entry points above do the same way -- happens inside the march: every lane marches its ray on
- * the packed accel, the wavefront evaluates the sub-module network for one pending sample per lane on the matrix cores
- * (weights of the batch's cluster as the MFMA A operand), and each lane composites its samples in ray order.  No sample
- * buffer exists.  The frame is bit-identical to mnv_get_samples_from_voxels_accel -> mnv_compact_guided_samples ->
+ * the packed accel and releases its samples into a per-wavefront pool in LDS; the wavefront evaluates the sub-module network for
+ * 64 pooled samples at a time on the matrix cores (weights of the samples' cluster as the MFMA A operand), and the lane that owns a
+ * ray composites its samples in ray order.  No sample buffer exists in global memory.  The frame is bit-identical to mnv_get_samples_from_voxels_accel -> mnv_compact_guided_samples ->
  * mnv_query_submodules -> mnv_render_nerf_results (same march, same MFMA sequence, same composite arithmetic).
- * Restrictions (MNV_E_UNSUPPORTED otherwise; use the four-step path): 64-wide networks, RGBA / SH1/4/9/16 trees, no
- * render_depth, no refinement trackers or visit marks in the same frame.
+ * Restrictions (MNV_E_UNSUPPORTED otherwise; use the four-step path): 64-wide networks with at most 64 encoded inputs,
+ * RGBA / SH1/4/9/16 trees, no render_depth.  Refinement trackers and visit marks: mnv_render_guided_fused_track.
  *   sample_counter  optional device counter: += network evaluations (= what the four-step path reports as guided samples)
  */
 int mnv_render_guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, const mnv_mlp *mlp,
