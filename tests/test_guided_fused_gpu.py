@@ -191,3 +191,29 @@ def test_fused_frame_with_trackers_and_visit_marks(mnv, torch_gpu, case, max_g):
     assert torch.equal(split, split0) and torch.equal(sample, sample0)
     assert torch.equal(visited, visited0) and int(visited.sum()) > 1
     assert (split[..., 1] >= 0).any()
+
+
+def test_fused_frame_of_a_sub_rectangle(mnv, torch_gpu):
+    """`tile` = a window of the image (ragged 8x8 tiles at its right and bottom edges): the fused kernel writes exactly the crop of the
+    full frame, and nothing outside its [h][w] buffer."""
+    torch = torch_gpu
+    spec = cases.CASES["sh9_d7_aniso"]
+    tree = cases.make_tree(mnv, spec["tree"])
+    v = tree.host_view()
+    tree.move_to_device()
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    opt.basis_minmax[0], opt.basis_minmax[1] = 0, 8
+    opt.max_guided_samples = 16
+    desc = mnv.mlp_desc(n_clusters=6, pos_octaves=4, dir_octaves=2, hidden_width=64, hidden_layers=2, out_dim=v.data_dim + 1)
+    mlp = mnv.Mlp(desc, mlp_cases.make_params(mnv, desc, seed=21))
+    grid = make_grid(mnv)
+    full = torch.empty((cam.height, cam.width, 4), dtype=torch.float32, device="cuda")
+    mnv.render_guided_fused(tree.accel, cam, opt, mlp, grid, rgba=full)
+    x0, y0, w, h = 37, 21, 101, 67
+    guard = torch.full((h + 2, w, 4), float("nan"), dtype=torch.float32, device="cuda")
+    win = guard[1:h + 1]
+    mnv.render_guided_fused(tree.accel, cam, opt, mlp, grid, tile=(x0, y0, w, h), rgba=win)
+    torch.cuda.synchronize()
+    assert torch.equal(win.view(torch.int32), full[y0:y0 + h, x0:x0 + w].contiguous().view(torch.int32))
+    assert torch.isnan(guard[0]).all() and torch.isnan(guard[h + 1]).all()
