@@ -14,6 +14,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -51,6 +52,15 @@ Rccl &rccl() {
     static std::once_flag once;
     std::call_once(once, [] {
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // test hook: MNV_RCCL_LIBRARY names a library with the same eight entry points (tests/shim/fake_rccl.cpp lets the world > 1
+        // paths run with several ranks on one GPU, which RCCL refuses)
+        if (const char *over = getenv("MNV_RCCL_LIBRARY")) {
+            r.handle = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+            if (!r.handle) {
+                r.error = std::string("MNV_RCCL_LIBRARY: cannot load ") + over + ": " + (dlerror() ? dlerror() : "?");
+                return;
+            }
+        }
         // a copy that is already loaded wins (PyTorch ships its own librccl.so with the same soname)
         for (const char *n : names)
             if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);

@@ -194,7 +194,11 @@ struct Rendezvous {  // anonymous shared mapping created before the fork
 constexpr int kMacroW = 64, kMacroH = 24;  // per-rank launch times within 3 % of each other at world 8
 
 int run_rank(const Args &args, int rank, int world, Rendezvous *rv) {
-    if (hipSetDevice((int)args.l("gpu", 0) + rank) != hipSuccess) throw std::runtime_error("rank " + std::to_string(rank) + ": no usable HIP device");
+    // test hook: MNV_RANKS_SHARE_GPU=1 puts every rank on device --gpu (with a transport stand-in for RCCL, which refuses two ranks on
+    // one device: tests/shim/fake_rccl.cpp) so that the world > 1 paths can run on a one-GPU machine
+    const bool share = std::getenv("MNV_RANKS_SHARE_GPU") != nullptr;
+    if (hipSetDevice((int)args.l("gpu", 0) + (share ? 0 : rank)) != hipSuccess)
+        throw std::runtime_error("rank " + std::to_string(rank) + ": no usable HIP device");
     viewer::N3Tree tree(args.file);
     if (tree.N <= 0) throw std::runtime_error("--gpus needs a tree (N > 0)");
     const int width = (int)args.l("width", 800), height = (int)args.l("height", 800);

@@ -58,3 +58,17 @@ def torch_gpu():
     if not torch.cuda.is_available():
         pytest.fail("this test is marked gpu but no HIP device is visible")
     return torch
+
+
+@pytest.fixture(scope="session")
+def fake_rccl(tmp_path_factory):
+    """tests/shim/fake_rccl.cpp built into a shared library: a host-staged stand-in for the RCCL entry points libmnv.so binds, so that the
+    world > 1 paths can run with several ranks on one GPU (MNV_RCCL_LIBRARY).  Test infrastructure; RCCL's own transport is not covered."""
+    import subprocess
+
+    out = str(tmp_path_factory.mktemp("shim") / "libfake_rccl.so")
+    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "shim", "fake_rccl.cpp"),
+           "-o", out, "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out

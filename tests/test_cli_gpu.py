@@ -89,6 +89,33 @@ def test_mnv_render_multi_gpu_mode_with_one_rank(mnv, orc, torch_gpu, tmp_path):
     assert r5.returncode != 0 and "refinement" in r5.stderr
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_mnv_render_multi_gpu_mode_with_several_ranks_on_one_gpu(mnv, torch_gpu, tmp_path, fake_rccl, world):
+    """`mnv_render --gpus N` with N > 1 on a one-GPU box: the ranks share the device (MNV_RANKS_SHARE_GPU) and a host-staged stand-in
+    takes RCCL's place (MNV_RCCL_LIBRARY=tests/shim/fake_rccl.cpp; RCCL refuses two ranks on one device).  Everything of ours runs as
+    it would on N GPUs -- fork per rank, rendezvous through the shared page, communicator per rank, interleaved partition with the
+    root-relieving deal, one batched launch per rank, mnv_gather_tiles with world - 1 receives on the root and one send elsewhere, the
+    ring of two slots, un-permute, file output -- and every frame equals the single-GPU path's byte for byte."""
+    tree = cases.make_tree(mnv, cases.CASES["sh9_d7_aniso"]["tree"])
+    npz = str(tmp_path / "scene.npz")
+    tree.save_npz(npz)
+    w, h, frames = 328, 200, 70          # 70 frames: two batches through the ring; 328 x 200: ragged macro tiles on both edges
+    common = [EXE, npz, "-w", str(w), "-h", str(h), "--fx", "450", "--bg", "0.25", "--center", "-3.0,2.0,5.0", "--back", "-0.45,0.3,0.75",
+              "--raw", "--frames", str(frames), "--orbit", "3.5"]
+    one, dist = str(tmp_path / "one"), str(tmp_path / "dist")
+    r1 = subprocess.run(common + ["--out", one], capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr + r1.stdout
+    env = dict(os.environ, MNV_RCCL_LIBRARY=fake_rccl, MNV_RANKS_SHARE_GPU="1")
+    r2 = subprocess.run(common + ["--out", dist, "--gpus", str(world), "--reserve_cus", "0"], capture_output=True, text=True, timeout=900, env=env)
+    assert r2.returncode == 0, r2.stderr + r2.stdout
+    assert f"x {world} (RCCL 29999)" in r2.stdout      # the stand-in's version number: this run did not touch RCCL
+    for f in range(frames):
+        for ext in ("f32", "ppm"):
+            a = open(f"{one}_{f:04d}.{ext}", "rb").read()
+            b = open(f"{dist}_{f:04d}.{ext}", "rb").read()
+            assert a == b, (f, ext)
+
+
 def test_mnv_render_cli_errors(tmp_path, mnv, torch_gpu):
     r = subprocess.run([EXE], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stdout

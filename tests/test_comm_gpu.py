@@ -58,3 +58,77 @@ def test_partitioned_render_gather_assemble_equals_the_oracle(mnv, orc, torch_gp
                 assert np.array_equal(tg.frame(slot)[f].cpu().numpy().view(np.uint32), ref.view(np.uint32)), (slot, f)
     finally:
         comm.close()
+
+
+def _rank_main(rank, world, lib, idq, resq):
+    """One rank of the multi-process gather test (ranks share cuda:0; the transport is tests/shim/fake_rccl.cpp)."""
+    import os
+    import sys
+    import traceback
+
+    try:
+        os.environ["MNV_RCCL_LIBRARY"] = lib
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for p in (root, os.path.join(root, "tests"), os.path.join(root, "oracle")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import torch
+
+        import cases as cs
+        import mega_nerf_viewer_amd as mnv
+        from mega_nerf_viewer_amd.multigpu import TileGatherer, TilePartition
+
+        torch.cuda.set_device(0)
+        if rank == 0:
+            uid = mnv.comm_get_unique_id()
+            for _ in range(world - 1):
+                idq.put(uid)
+        else:
+            uid = idq.get(timeout=120)
+        comm = mnv.Comm(uid, world, rank)
+        assert mnv.rccl_version() == 29999
+        spec = cs.CASES["sh9_d7_aniso"]
+        tree = cs.make_tree(mnv, spec["tree"])
+        tree.move_to_device()
+        w, h = 400, 248
+        cams = [cs.make_camera(mnv, dict(spec["camera"], width=w, height=h, center=(-3.0 + 0.2 * k, 2.0, 5.0))) for k in range(3)]
+        opt = cs.make_options(mnv, spec["options"])
+        part = TilePartition(w, h, world, 64, 24, 3)
+        tg = TileGatherer(part, rank, torch.device("cuda", 0), dtype=torch.uint8, depth=2, frames=len(cams), comm=comm)
+        for slot in (0, 1, 0):
+            tg.finish(slot)
+            if part.local_tiles(rank) > 0:
+                mnv.render_voxels_accel_batch(tree.accel, cams, opt, part=part.part(rank), rgba8=tg.local(slot), stream=torch.cuda.current_stream().cuda_stream)
+            tg.submit(slot)
+        tg.finish_all()
+        torch.cuda.synchronize()
+        if rank == 0:
+            full = torch.empty((len(cams), h, w, 4), dtype=torch.uint8, device="cuda")
+            mnv.render_voxels_accel_batch(tree.accel, cams, opt, rgba8=full)
+            torch.cuda.synchronize()
+            resq.put(("ok", bool(torch.equal(tg.frame(0), full)) and bool(torch.equal(tg.frame(1), full))))
+        comm.close()
+    except Exception:  # noqa: BLE001
+        resq.put(("error", f"rank {rank}: {traceback.format_exc()}"))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_tile_gatherer_over_the_c_abi_with_several_ranks_on_one_gpu(mnv, torch_gpu, fake_rccl, world):
+    """multigpu.TileGatherer with an mnv.Comm and world > 1: every rank a process of its own on cuda:0, mnv_gather_tiles through the
+    transport stand-in, un-permute on rank 0, root-relieving deal (root_period 3): assembled frames == the single-launch frames."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    idq, resq = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_rank_main, args=(r, world, fake_rccl, idq, resq)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        kind, val = resq.get(timeout=600)
+        assert kind == "ok" and val is True, val
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()   # exactly the processes started above
+    assert all(p.exitcode == 0 for p in procs)
