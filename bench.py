@@ -54,13 +54,14 @@ def load_counters():
 
 
 def kernel_source_sha():
-    """Identity of the kernel sources a profile belongs to (tools/make_traffic_json.py stores it with the PMC numbers)."""
+    """Identity of the device code a profile belongs to -- the .hip / .h files of csrc/ (host-only .cpp files such as the RCCL binding do
+    not enter) -- stored with the PMC numbers by tools/make_traffic_json.py."""
     import hashlib
 
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mega-nerf-viewer_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h", ".cpp")):
+        if name.endswith((".hip", ".h")):
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
