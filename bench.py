@@ -244,13 +244,15 @@ def main():
         dt = torch.float32 if args.gather == "f32" else torch.uint8
         # one launch + one gather per step; the gather of step k overlaps the launch of step k + 1
         comm = None
-        if args.backend == "nccl":
+        # MNV_RCCL_LIBRARY (test hook of mnv_comm.cpp: a transport stand-in that lets several ranks share one GPU) brings the C-ABI gather
+        # into the gloo rehearsal as well, so that everything but RCCL's own transport runs as on N GPUs
+        if args.backend == "nccl" or os.environ.get("MNV_RCCL_LIBRARY"):
             # the data path's collective is libmnv's own RCCL gather (mnv_gather_tiles, C ABI); torch.distributed only carries the
             # 128-byte id to the other ranks and the barrier / max-over-ranks of the timing
             box = [mnv.comm_get_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             comm = mnv.Comm(box[0], world, rank)
-        tg = TileGatherer(part, rank, dev, dtype=dt, depth=RING, frames=N_FRAMES, stage_on_host=args.backend == "gloo", comm=comm)
+        tg = TileGatherer(part, rank, dev, dtype=dt, depth=RING, frames=N_FRAMES, stage_on_host=args.backend == "gloo" and comm is None, comm=comm)
         frames = tg._frames if rank == 0 else None
         counter = [0]
 
@@ -456,7 +458,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": workload,
                        "rays_per_step": rays_per_step, "kernel": args.kernel, "launches_per_step": 1 if not args.per_frame and args.kernel == "accel" else N_FRAMES,
-                       "partition": "none" if not multi else f"interleaved {MACRO_W}x{MACRO_H} macro tiles, {args.gather} {'RCCL' if args.backend == 'nccl' else 'gloo (host-staged rehearsal)'} gather to rank 0",
+                       "partition": "none" if not multi else f"interleaved {MACRO_W}x{MACRO_H} macro tiles, {args.gather} " + (
+                           "RCCL" if args.backend == "nccl" else ("mnv_gather_tiles over a transport stand-in (MNV_RCCL_LIBRARY)" if comm is not None
+                                                                  else "gloo (host-staged rehearsal)")) + " gather to rank 0",
                        "reserved_cus": reserve, "march_streams": n_march_streams, "root_period": part.root_period if multi else 0},
             "roofline": roofline,
             "per_frame": per_frame,

@@ -49,6 +49,21 @@ def test_bench_starts_its_own_ranks(torch_gpu):
     assert d["n_gpus"] == 2 and d["parity"]["pixels_not_bit_identical"] == 0 and d["parity"]["frames_checked"] >= 3
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_multirank_through_the_c_abi_gather(torch_gpu, fake_rccl, world):
+    """bench.py's N > 1 path with the C-ABI gather (mnv.Comm -> mnv_gather_tiles) instead of the gloo staging: CU-masked march streams,
+    one stream per ring slot, root-relieving partition, per-slot side streams, un-permute on rank 0.  The ranks share the GPU and
+    tests/shim/fake_rccl.cpp stands in for RCCL's transport (MNV_RCCL_LIBRARY); bench.py starts the ranks itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MNV_RCCL_LIBRARY"] = fake_rccl
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--steps", "3", "--warmup", "1", "--laps", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == world and "mnv_gather_tiles" in d["config"]["partition"] and d["config"]["march_streams"] == 2
+    assert d["parity"]["pixels_not_bit_identical"] == 0 and d["parity"]["frames_checked"] >= 3 and d["roofline"]["approximate"] is True
+
+
 def test_bench_refuses_a_rank_count_it_cannot_have(torch_gpu):
     """Over RCCL every rank needs its own GPU: on a one-GPU box `--gpus 2` must fail, not print a one-GPU line."""
     if torch_gpu.cuda.device_count() >= 2:
