@@ -247,7 +247,11 @@ int run_rank(const Args &args, int rank, int world, Rendezvous *rv) {
     const int reserve = (int)args.l("reserve_cus", world > 1 ? 32 : 0);
     void *march_stream = nullptr;
     int32_t enabled = 0;
-    mnv_ok(mnv_stream_create_reserved(reserve, &march_stream, &enabled), "mnv_stream_create_reserved");
+    if (mnv_stream_create_reserved(reserve, &march_stream, &enabled) != MNV_OK) {
+        // no CU masking on this system: run unmasked (the gather of a batch then waits for the next batch's march to drain)
+        std::fprintf(stderr, "mnv_render[rank %d]: %s; continuing without reserved compute units\n", rank, mnv_last_error());
+        mnv_ok(mnv_stream_create_reserved(0, &march_stream, &enabled), "mnv_stream_create_reserved");
+    }
     mnv_ok(mnv_accel_set_cu_budget(tree.device.accel, enabled), "mnv_accel_set_cu_budget");
     hipStream_t side = nullptr;
     hip_ok(hipStreamCreateWithFlags(&side, hipStreamNonBlocking), "hipStreamCreate");
