@@ -504,6 +504,11 @@ int mnv_render_guided_fused_track(const mnv_accel *accel, const mnv_camera *cam,
                                   const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, float *split_track, float *sample_track,
                                   const int16_t *sample_counts, int32_t *visited, const int32_t *parent, unsigned long long *sample_counter,
                                   void *hip_stream);
+/* The fused frame of one rank of a multi-GPU run: the macro tiles `part` assigns to the rank, written tile-major like
+ * mnv_render_voxels_accel_part (guided sampling reads the tree only, so the ranks need no exchange but the usual tile gather). */
+int mnv_render_guided_fused_part(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, mnv_partition part,
+                                 const mnv_mlp *mlp, const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out,
+                                 unsigned long long *sample_counter, void *hip_stream);
 
 /* A HIP stream whose kernels run on all but `reserve_cus` compute units (hipExtStreamCreateWithCUMask; the units are taken
  * evenly from the XCDs, and from their shader engines when reserve_cus is a multiple of 32).  The tuned kernel is persistent and

@@ -228,6 +228,8 @@ _SIGNATURES = {
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_render_guided_fused_track": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.c_void_p, C.POINTER(ClusterGrid),
                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mnv_render_guided_fused_part": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, Partition, C.c_void_p,
+                                               C.POINTER(ClusterGrid), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_render_nerf_results": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
                                           C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_add_children_and_generate_samples": (C.c_int, [C.POINTER(TreeEdit), C.POINTER(RenderOptions), C.c_void_p, C.c_int32, C.c_void_p,
@@ -676,6 +678,18 @@ def render_guided_fused(accel: int, cam: Camera, opt: RenderOptions, mlp: "Mlp",
     _check(lib().mnv_render_guided_fused_track(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), mlp._h, C.byref(grid), _ptr(rgba),
                                                _ptr(rgba8), _ptr(split_track), _ptr(sample_track), _ptr(sample_counts), _ptr(visited), _ptr(parent),
                                                _ptr(sample_counter), C.c_void_p(stream)))
+
+
+def render_guided_fused_part(accel: int, cam: Camera, opt: RenderOptions, mlp: "Mlp", grid: ClusterGrid, part, tile=None, rgba=None, rgba8=None,
+                             sample_counter=None, stream: int = 0) -> None:
+    """One rank's macro tiles of the fused guided-sampling frame (part = (rank, world, tile_w, tile_h[, root_period]))."""
+    if tile is None:
+        tile = (0, 0, cam.width, cam.height)
+    px = _pixels(tile, 1, part)
+    _check_out("rgba", rgba, px, "f32")
+    _check_out("rgba8", rgba8, px, "u8")
+    _check(lib().mnv_render_guided_fused_part(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), Partition(*part), mlp._h, C.byref(grid),
+                                              _ptr(rgba), _ptr(rgba8), _ptr(sample_counter), C.c_void_p(stream)))
 
 
 def tree_edit(child, parent, offset, scale, capacity: int) -> TreeEdit:

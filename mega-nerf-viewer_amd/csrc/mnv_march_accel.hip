@@ -1679,10 +1679,31 @@ int mnv_render_guided_fused(const mnv_accel *accel, const mnv_camera *cam, const
                                          sample_counter, hip_stream);
 }
 
+static int guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, mnv_partition part,
+                        const mnv_mlp *mlp, const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, float *split_track,
+                        float *sample_track, const int16_t *sample_counts, int32_t *visited, const int32_t *parent,
+                        unsigned long long *sample_counter, void *hip_stream);
+
 int mnv_render_guided_fused_track(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, const mnv_mlp *mlp,
                                   const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, float *split_track, float *sample_track,
                                   const int16_t *sample_counts, int32_t *visited, const int32_t *parent, unsigned long long *sample_counter,
                                   void *hip_stream) {
+    const mnv_partition whole = {0, 1, 0, 0, 0};
+    return guided_fused(accel, cam, opt, tile, whole, mlp, grid, rgba_out, rgba8_out, split_track, sample_track, sample_counts, visited, parent,
+                        sample_counter, hip_stream);
+}
+
+int mnv_render_guided_fused_part(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, mnv_partition part,
+                                 const mnv_mlp *mlp, const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out,
+                                 unsigned long long *sample_counter, void *hip_stream) {
+    return guided_fused(accel, cam, opt, tile, part, mlp, grid, rgba_out, rgba8_out, nullptr, nullptr, nullptr, nullptr, nullptr, sample_counter,
+                        hip_stream);
+}
+
+static int guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, mnv_partition part,
+                        const mnv_mlp *mlp, const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, float *split_track,
+                        float *sample_track, const int16_t *sample_counts, int32_t *visited, const int32_t *parent,
+                        unsigned long long *sample_counter, void *hip_stream) {
     if (!accel || !cam || !opt || !mlp || !grid) return set_error(MNV_E_INVALID, "null argument");
     if (visited && !parent) return set_error(MNV_E_INVALID, "visit marks on the packed layout need the parent array (the ancestors of the marked chunks)");
     if (opt->render_depth) return set_error(MNV_E_UNSUPPORTED, "the fused guided-sampling frame has no depth mode; use the four-step path");
@@ -1723,8 +1744,7 @@ int mnv_render_guided_fused_track(const mnv_accel *accel, const mnv_camera *cam,
     track.max_sample_count = opt->max_sample_count;
     track.visited = visited;
     track.parent = parent;
-    const mnv_partition whole = {0, 1, 0, 0, 0};
-    return render_accel(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, &track, hip_stream);
+    return render_accel(accel, cam, 1, opt, tile, part, rgba_out, rgba8_out, &track, hip_stream);
 }
 
 }  // extern "C"

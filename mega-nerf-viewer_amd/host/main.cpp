@@ -19,7 +19,9 @@
 //                    frames with one launch, the compact buffers are gathered to rank 0 over RCCL (mnv_gather_tiles) and
 //                    un-permuted there (mnv_assemble_tiles); rank 0 writes the frames.  --gpus 1 runs the same path with one
 //                    rank.  --reserve_cus R (default 32 when N > 1) keeps R compute units free for the RCCL kernels.
-//                    Not combined with --model_path (refinement mutates the tree).
+//                    With --model_path + --use_guided_sampling every rank runs the fused guided-sampling kernel on its tiles
+//                    (mnv_render_guided_fused_part: the networks read the tree only).  Not combined with --use_splitting
+//                    (refinement mutates the tree).
 //   --in_flight K    plain frames in flight (default 3; VolumeRenderer::frames_in_flight): frame k is downloaded and written
 //                    after frames k+1 .. k+K-1 have been issued
 #include <hip/hip_runtime_api.h>
@@ -207,6 +209,11 @@ int run_rank(const Args &args, int rank, int world, Rendezvous *rv) {
     rend.set(tree, tree.capacity);  // every rank holds the whole tree: the march needs no exchange
     rend.resize(width, height);
     if (!tree.device.accel) throw std::runtime_error("--gpus needs the packed accel (N == 2, RGBA or SH1/4/9/16/25 rows)");
+    const bool guided = args.has("model_path") && args.has("use_guided_sampling");
+    if (guided) {
+        rend.load_model(args.get("model_path", ""));  // sets need_viewdir / appearance_embedding as the single-GPU path does
+        rend.options.max_guided_samples = (int)args.l("max_guided_samples", 128);
+    }
 
     // communicator: rank 0 draws the id, the others read it from the shared page
     if (rank == 0) {
@@ -307,8 +314,17 @@ int run_rank(const Args &args, int rank, int world, Rendezvous *rv) {
         s.count = n;
         // one launch per rank and batch; the buffer is reused only after the gather that last read it
         hip_ok(hipStreamWaitEvent((hipStream_t)march_stream, s.sent, 0), "wait(sent)");
-        mnv_ok(mnv_render_voxels_accel_batch(tree.device.accel, cams.data() + f0, n, rend.options.c_abi(), full, part, s.local, s.local8, march_stream),
-               "mnv_render_voxels_accel_batch");
+        if (!guided) {
+            mnv_ok(mnv_render_voxels_accel_batch(tree.device.accel, cams.data() + f0, n, rend.options.c_abi(), full, part, s.local, s.local8, march_stream),
+                   "mnv_render_voxels_accel_batch");
+        } else {
+            // guided sampling: one fused launch (march + networks + composite) per frame, into the frame's place in the batch buffer
+            for (int i = 0; i < n; ++i)
+                mnv_ok(mnv_render_guided_fused_part(tree.device.accel, &cams[f0 + i], rend.options.c_abi(), full, part, rend.model(), &rend.cluster_grid(),
+                                                    s.local ? s.local + (size_t)i * tile_px * 4 : nullptr, s.local8 + (size_t)i * tile_px * 4, nullptr,
+                                                    march_stream),
+                       "mnv_render_guided_fused_part");
+        }
         hip_ok(hipEventRecord(s.rendered, (hipStream_t)march_stream), "record(rendered)");
         // gather + un-permute on the side stream, overlapping the next batch's march
         hip_ok(hipStreamWaitEvent(side, s.rendered, 0), "wait(rendered)");
@@ -345,7 +361,8 @@ int run_rank(const Args &args, int rank, int world, Rendezvous *rv) {
 // with it (they would otherwise wait in RCCL forever).
 int run_distributed(const Args &args, int world) {
     if (world < 1 || world > 64) throw std::runtime_error("--gpus must be 1 .. 64");
-    if (args.has("model_path")) throw std::runtime_error("--gpus renders a read-only tree; refinement (--model_path) runs on one GPU");
+    if (args.has("use_splitting")) throw std::runtime_error("--gpus renders a read-only tree; refinement (--use_splitting) mutates it and runs on one GPU");
+    if (args.has("use_guided_sampling") && !args.has("model_path")) throw std::runtime_error("--use_guided_sampling needs --model_path");
     void *page = mmap(nullptr, sizeof(Rendezvous), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
     if (page == MAP_FAILED) throw std::runtime_error("mmap failed");
     Rendezvous *rv = new (page) Rendezvous();

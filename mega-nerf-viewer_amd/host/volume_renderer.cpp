@@ -328,6 +328,9 @@ void VolumeRenderer::load_model(const std::string &npz_path) {
 
 void VolumeRenderer::clear() { impl_->tree = nullptr; }
 
+const mnv_mlp *VolumeRenderer::model() const { return impl_->mlp; }
+const mnv_cluster_grid &VolumeRenderer::cluster_grid() const { return impl_->grid; }
+
 void VolumeRenderer::resize(int width, int height) {
     if (impl_->width == width && impl_->height == height && impl_->rgba) return;
     if (!impl_->initial_resize && camera.width > 0 && camera.height > 0) {

@@ -68,6 +68,9 @@ struct VolumeRenderer {
     void load_model(const std::string &npz_path);
     void set_model(const mnv_mlp_desc &desc, const uint16_t *params, size_t n_halfs, const mnv_cluster_grid &grid);
     bool has_model() const;
+    // The loaded model as the C ABI sees it (for callers that drive libmnv entry points themselves, e.g. the multi-GPU mode of mnv_render).
+    const mnv_mlp *model() const;
+    const mnv_cluster_grid &cluster_grid() const;
     // Copy the (refined) device tree back into the N3Tree's host arrays, e.g. before N3Tree::save_npz.
     void sync_tree();
 

@@ -85,7 +85,7 @@ def test_mnv_render_multi_gpu_mode_with_one_rank(mnv, orc, torch_gpu, tmp_path):
         r4 = subprocess.run(common + ["--gpus", "2"], capture_output=True, text=True, timeout=180)
         assert r4.returncode != 0 and "rank" in r4.stderr
     # refinement mutates the tree: not combined with --gpus
-    r5 = subprocess.run(common + ["--gpus", "1", "--model_path", npz], capture_output=True, text=True, timeout=120)
+    r5 = subprocess.run(common + ["--gpus", "1", "--model_path", npz, "--use_splitting"], capture_output=True, text=True, timeout=120)
     assert r5.returncode != 0 and "refinement" in r5.stderr
 
 
@@ -114,6 +114,45 @@ def test_mnv_render_multi_gpu_mode_with_several_ranks_on_one_gpu(mnv, torch_gpu,
             a = open(f"{one}_{f:04d}.{ext}", "rb").read()
             b = open(f"{dist}_{f:04d}.{ext}", "rb").read()
             assert a == b, (f, ext)
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_mnv_render_guided_sampling_across_ranks(mnv, torch_gpu, tmp_path, fake_rccl, world):
+    """`mnv_render --gpus N --model_path M --use_guided_sampling`: every rank runs the fused guided-sampling kernel (march + networks +
+    composite) on its macro tiles (mnv_render_guided_fused_part), the tiles are gathered and un-permuted as for plain frames; the frames
+    equal the single-GPU guided frames byte for byte.  world 1 goes through RCCL itself, world 3 shares the GPU over the stand-in."""
+    import mlp_cases
+    from test_renderer_refine_gpu import make_grid
+
+    tree = cases.make_tree(mnv, cases.CASES["sh9_d7_aniso"]["tree"])
+    dd = tree.host_view().data_dim
+    npz = str(tmp_path / "scene.npz")
+    tree.save_npz(npz)
+    desc = mnv.mlp_desc(n_clusters=6, pos_octaves=4, hidden_width=64, hidden_layers=2, out_dim=dd + 1)
+    g = make_grid(mnv)
+    model = str(tmp_path / "model.npz")
+    np.savez(model, mlp_desc=np.array([6, 4, 2, 0, 0, 0, 64, 2, dd + 1], np.int32), mlp_center=np.zeros(3, np.float32),
+             mlp_inv_extent=np.ones(3, np.float32), mlp_params=mlp_cases.make_params(mnv, desc, seed=21), grid_dim=np.array(list(g.grid_dim), np.int64),
+             min_position=np.array(list(g.min_position), np.float32), max_position=np.array([g.min_position[i] + g.range[i] for i in range(3)], np.float32))
+    w, h, frames = 328, 200, 5
+    common = [EXE, npz, "-w", str(w), "-h", str(h), "--fx", "450", "--bg", "0.25", "--center", "-3.0,2.0,5.0", "--back", "-0.45,0.3,0.75", "--raw",
+              "--frames", str(frames), "--orbit", "7", "--model_path", model, "--use_guided_sampling", "-z", "24"]
+    one, dist = str(tmp_path / "one"), str(tmp_path / "dist")
+    r1 = subprocess.run(common + ["--out", one], capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0 and "guided samples" in r1.stdout, r1.stderr + r1.stdout
+    env = dict(os.environ)
+    if world > 1:
+        env.update(MNV_RCCL_LIBRARY=fake_rccl, MNV_RANKS_SHARE_GPU="1")
+    r2 = subprocess.run(common + ["--out", dist, "--gpus", str(world), "--reserve_cus", "0"], capture_output=True, text=True, timeout=900, env=env)
+    assert r2.returncode == 0, r2.stderr + r2.stdout
+    plain = str(tmp_path / "plain")
+    r3 = subprocess.run([a for a in common if a not in ("--use_guided_sampling",)] + ["--out", plain], capture_output=True, text=True, timeout=600)
+    assert r3.returncode == 0
+    for f in range(frames):
+        a = open(f"{one}_{f:04d}.f32", "rb").read()
+        assert a == open(f"{dist}_{f:04d}.f32", "rb").read(), f
+        assert open(f"{one}_{f:04d}.ppm", "rb").read() == open(f"{dist}_{f:04d}.ppm", "rb").read(), f
+        assert a != open(f"{plain}_{f:04d}.f32", "rb").read()     # the networks' colours, not the tree's
 
 
 def test_mnv_render_cli_errors(tmp_path, mnv, torch_gpu):
