@@ -72,8 +72,12 @@ def alg_bytes(c, basis_dim=9):
     return 16 * c["rays"] + 4 * c["levels"] + 2 * c["steps"] + 6 * basis_dim * c["hits"]
 
 
-def self_launch(n, backend):
-    """One process per GPU via torch.distributed.run, started from a parent that never initialises HIP."""
+def self_launch(n, backend, timeout_s):
+    """One process per GPU via torch.distributed.run, started from a parent that never initialises HIP.  The ranks run in their own
+    process group under a watchdog: a run that exceeds `timeout_s` (a wedged collective) is killed -- that group, by id -- and, like a run
+    that failed, repeated once in the conservative configuration (--gather-via torch --one-march-stream: torch.distributed's gather
+    instead of mnv_gather_tiles, one march stream); the line then says so in `launch`."""
+    import signal
     import socket
     import subprocess
 
@@ -81,24 +85,47 @@ def self_launch(n, backend):
         print(f"bench.py: --gpus {n} over RCCL needs {n} GPUs, this node shows {torch.cuda.device_count()} "
               f"(--backend gloo rehearses the {n}-rank path on fewer GPUs)", file=sys.stderr)
         return 2
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    for ln in r.stdout.splitlines():
-        if not ln.startswith("{"):
-            print(ln, file=sys.stderr)
-    if r.returncode == 0 and lines:
+
+    def attempt(extra):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True)
+        try:
+            out, _ = p.communicate(timeout=timeout_s)
+            rc = p.returncode
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)   # the launcher and its ranks: the session started above, nothing else
+            except ProcessLookupError:
+                pass
+            out, _ = p.communicate()
+            rc = -signal.SIGKILL
+            print(f"bench.py: the {n}-rank run did not finish within {timeout_s} s and was killed", file=sys.stderr)
+        lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+        for ln in out.splitlines():
+            if not ln.startswith("{"):
+                print(ln, file=sys.stderr)
+        return rc, lines
+
+    rc, lines = attempt([])
+    note = None
+    if (rc != 0 or not lines) and "--gather-via" not in sys.argv:
+        note = f"first attempt ended with code {rc}; repeated with --gather-via torch --one-march-stream"
+        print(f"bench.py: {note}", file=sys.stderr)
+        rc, lines = attempt(["--gather-via", "torch", "--one-march-stream"])
+    if rc == 0 and lines:
         d = json.loads(lines[-1])
         if d.get("n_gpus") != n:
             print(f"bench.py: asked for {n} ranks, the line reports {d.get('n_gpus')}", file=sys.stderr)
             return 3
-        print(lines[-1], flush=True)
+        if note:
+            d["launch"] = note
+        print(json.dumps(d), flush=True)
         return 0
-    return r.returncode or 4
+    return rc or 4
 
 
 def main():
@@ -135,6 +162,10 @@ def main():
                     help="N > 1: mnv_partition.root_period -- every M-th round of the tile deal leaves rank 0 out, because rank 0 also takes in "
                          "the gather and un-permutes the frames (tools/root_emulation.py: +13 %% on its march at N = 8).  Default round(64 / N) "
                          "(8 at N = 8: rank 0 renders 7/8 of a plain share); 0 = plain round robin")
+    ap.add_argument("--gather-via", choices=["abi", "torch"], default="abi",
+                    help="N > 1: abi = mnv_gather_tiles (libmnv's own RCCL gather, the product path); torch = torch.distributed's gather "
+                         "(the launcher's second attempt if the first one fails or wedges)")
+    ap.add_argument("--launch-timeout", type=float, default=420.0, help="--gpus N > 1 without a launcher: watchdog for the ranks this process starts (s)")
     ap.add_argument("--laps", type=int, default=4, help="the step walks the 16-pose orbit this many times (16 x laps frames in one launch, <= 64)")
     args = ap.parse_args()
     global W, H, N_FRAMES
@@ -147,7 +178,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves as FRESH child processes (this process has not
         # touched the GPU: torch.cuda.device_count() does not initialise it on this image), relay rank 0's JSON line, exit with their code
-        sys.exit(self_launch(args.gpus, args.backend))
+        sys.exit(self_launch(args.gpus, args.backend, args.launch_timeout))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -246,7 +277,7 @@ def main():
         comm = None
         # MNV_RCCL_LIBRARY (test hook of mnv_comm.cpp: a transport stand-in that lets several ranks share one GPU) brings the C-ABI gather
         # into the gloo rehearsal as well, so that everything but RCCL's own transport runs as on N GPUs
-        if args.backend == "nccl" or os.environ.get("MNV_RCCL_LIBRARY"):
+        if args.gather_via == "abi" and (args.backend == "nccl" or os.environ.get("MNV_RCCL_LIBRARY")):
             # the data path's collective is libmnv's own RCCL gather (mnv_gather_tiles, C ABI); torch.distributed only carries the
             # 128-byte id to the other ranks and the barrier / max-over-ranks of the timing
             box = [mnv.comm_get_unique_id() if rank == 0 else None]
@@ -459,7 +490,7 @@ def main():
             "config": {"workload": workload,
                        "rays_per_step": rays_per_step, "kernel": args.kernel, "launches_per_step": 1 if not args.per_frame and args.kernel == "accel" else N_FRAMES,
                        "partition": "none" if not multi else f"interleaved {MACRO_W}x{MACRO_H} macro tiles, {args.gather} " + (
-                           "RCCL" if args.backend == "nccl" else ("mnv_gather_tiles over a transport stand-in (MNV_RCCL_LIBRARY)" if comm is not None
+                           ("RCCL (mnv_gather_tiles)" if comm is not None else "RCCL (torch.distributed)") if args.backend == "nccl" else ("mnv_gather_tiles over a transport stand-in (MNV_RCCL_LIBRARY)" if comm is not None
                                                                   else "gloo (host-staged rehearsal)")) + " gather to rank 0",
                        "reserved_cus": reserve, "march_streams": n_march_streams, "root_period": part.root_period if multi else 0},
             "roofline": roofline,

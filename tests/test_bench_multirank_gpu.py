@@ -49,6 +49,23 @@ def test_bench_starts_its_own_ranks(torch_gpu):
     assert d["n_gpus"] == 2 and d["parity"]["pixels_not_bit_identical"] == 0 and d["parity"]["frames_checked"] >= 3
 
 
+def test_bench_launcher_repeats_a_failed_run_conservatively_and_kills_a_wedged_one(torch_gpu):
+    """The launcher inside bench.py: (i) ranks that fail (here: the C-ABI gather cannot bind its library) are started once more with
+    torch.distributed's gather, and the line says so; (ii) ranks that do not finish within --launch-timeout are killed -- their process
+    group, nothing else -- and the exit code is not 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MNV_RCCL_LIBRARY"] = "/nonexistent/librccl.so"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--laps", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and "repeated with --gather-via torch" in d["launch"] and "gloo" in d["config"]["partition"]
+    assert d["parity"]["pixels_not_bit_identical"] == 0
+    del env["MNV_RCCL_LIBRARY"]
+    r = subprocess.run(cmd + ["--launch-timeout", "2"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "was killed" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_bench_multirank_through_the_c_abi_gather(torch_gpu, fake_rccl, world):
     """bench.py's N > 1 path with the C-ABI gather (mnv.Comm -> mnv_gather_tiles) instead of the gloo staging: CU-masked march streams,
@@ -89,6 +106,6 @@ def test_bench_rccl_path_single_rank(torch_gpu, gather, reserve):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["config"]["reserved_cus"] == reserve and "RCCL gather" in d["config"]["partition"]
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["config"]["reserved_cus"] == reserve and "RCCL (mnv_gather_tiles) gather" in d["config"]["partition"]
     assert d["parity"]["pixels_not_bit_identical"] == 0 and d["parity"]["frames_checked"] >= 3
     assert d["value"] > 0 and d["roofline"]["launches"] == 3
