@@ -384,6 +384,33 @@ def main():
                        "what": "mnv_set_colour_math(1): v_exp_f32 / v_rcp_f32 in the colour sigmoid, everything that feeds a branch exact"}
         del d
 
+    # third secondary number: mnv_render_voxels itself -- the literal drop-in on the reference's own arrays (no accel, nothing kept between
+    # calls), one call per frame, on one stream and with two frames in flight; bit-identical to the frames above
+    ref_layout = None
+    if not multi and args.kernel == "accel" and not args.per_frame and args.frame_streams >= 1:
+        dv_ref = tree.device_view()
+        exact = frames[(counter[0] - 1) % RING]
+        rl_out = pf_out
+        rl = {}
+        for k_rl in (1, 2):
+            sts_rl = [torch.cuda.Stream(device=dev) for _ in range(k_rl)]
+
+            def rl_step():
+                for i in range(N_POSES):
+                    mnv.render_voxels(dv_ref, cams[i], opt, rgba=rl_out[i], stream=sts_rl[i % k_rl].cuda_stream)
+
+            rl_step()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(3):
+                rl_step()
+            torch.cuda.synchronize(dev)
+            rl[k_rl] = (time.perf_counter() - t1) / 3 / N_POSES
+        ref_layout = {"value": round(W * H / rl[2] / 1e6, 2), "unit": "Mrays/s", "frames_in_flight": 2, "ms_per_frame": round(rl[2] * 1e3, 5),
+                      "one_stream": {"value": round(W * H / rl[1] / 1e6, 2), "ms_per_frame": round(rl[1] * 1e3, 5)},
+                      "pixels_not_bit_identical": int((rl_out[:N_POSES].view(torch.int32) != exact[:N_POSES].view(torch.int32)).any(dim=-1).sum().item()),
+                      "what": "one mnv_render_voxels call per 1920x1080 frame on the reference's own arrays (renderer_kernel.hpp:23-34): per-launch level-7 lookup table + walking kernel"}
+
     # ---- roofline of the dominant kernel (the march): algorithmic bytes per launch / launch time
     counters = load_counters() if args.workload == "cfg2" else None
     counters_checked = 0
@@ -496,6 +523,7 @@ def main():
             "roofline": roofline,
             "per_frame": per_frame,
             "fast_colour": fast_colour,
+            "ref_layout": ref_layout,
             "cpu_baseline": cpu_baseline,
             "parity": parity,
             "setup_s": round(setup_s, 2),

@@ -211,6 +211,14 @@ int mnv_render_voxels_accel_part(const mnv_accel *accel, const mnv_camera *cam, 
 void mnv_set_colour_math(int fast);
 
 /*
+ * mnv_render_voxels builds, in front of every launch of at least `min_rays` rays, a dense level-7 lookup table of the tree on the
+ * caller's stream (stream-ordered scratch memory, about 10 us, 16 MB; csrc/mnv_march_ref_layout.hip) -- the caller's arrays
+ * may change between calls, so nothing is kept.  Smaller launches (tiles) derive a 512-cell table per workgroup instead.
+ * Process-wide; default 65536; 0 = always, a negative value = never.  Frames are bit-identical either way.
+ */
+void mnv_set_ref_table_min_rays(int64_t min_rays);
+
+/*
  * The un-permute step on the gathering rank: `gathered` is what the RCCL gather of the ranks'
  * compact buffers produces, [world][n_frames][ceil(macro tiles / world)][tile_h][tile_w] pixels (n_frames = 1 for
  * mnv_render_voxels_accel_part), `frames` receives [n_frames][height][width] pixels.  bytes_per_pixel: 4 (RGBA8) or

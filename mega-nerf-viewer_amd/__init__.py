@@ -202,6 +202,7 @@ _SIGNATURES = {
     "mnv_render_voxels_accel_part": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, Partition,
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_set_colour_math": (None, [C.c_int]),
+    "mnv_set_ref_table_min_rays": (None, [C.c_int64]),
     "mnv_assemble_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, Partition, C.c_int32, C.c_int32, C.c_void_p]),
     "mnv_comm_get_unique_id": (C.c_int, [C.c_void_p]),
     "mnv_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
@@ -610,6 +611,12 @@ def get_samples_from_voxels_accel_visit(accel: int, cam: Camera, opt: RenderOpti
 def set_colour_math(fast: bool) -> None:
     """False (default): bit-identical to the oracle.  True: hardware exp2 / rcp in the colour sigmoid (colours move ~1e-7)."""
     lib().mnv_set_colour_math(int(bool(fast)))
+
+
+def set_ref_table_min_rays(min_rays: int) -> None:
+    """render_voxels (reference layout): launches of at least `min_rays` rays build the per-launch level-7 lookup table first
+    (default 65536; 0 = always, negative = never); bit-identical frames either way."""
+    lib().mnv_set_ref_table_min_rays(int(min_rays))
 
 
 def assemble_tiles(gathered, frames, width: int, height: int, world: int, tile_w: int, tile_h: int, n_frames: int = 1, stream: int = 0,

@@ -15,8 +15,14 @@ def _render_gpu(mnv, torch, tree, cam, opt, which, tile=None, want_u8=False):
     w, h = (cam.width, cam.height) if tile is None else (tile[2], tile[3])
     rgba = torch.full((h, w, 4), float("nan"), dtype=torch.float32, device="cuda")
     rgba8 = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") if want_u8 else None
-    if which == "ref_layout":
-        mnv.render_voxels(tree.device_view(), cam, opt, tile=tile, rgba=rgba, rgba8=rgba8)
+    if which.startswith("ref_layout"):
+        # reference-layout kernel: "_table" forces the per-launch level-7 lookup table at every size, "_walk" forbids it
+        # (per-workgroup level-3 table only); plain = the default switch-over at 65536 rays
+        mnv.set_ref_table_min_rays({"ref_layout": 1 << 16, "ref_layout_table": 0, "ref_layout_walk": -1}[which])
+        try:
+            mnv.render_voxels(tree.device_view(), cam, opt, tile=tile, rgba=rgba, rgba8=rgba8)
+        finally:
+            mnv.set_ref_table_min_rays(1 << 16)
     else:
         mnv.render_voxels_accel(tree.accel, cam, opt, tile=tile, rgba=rgba, rgba8=rgba8)
     torch.cuda.synchronize()
@@ -24,7 +30,7 @@ def _render_gpu(mnv, torch, tree, cam, opt, which, tile=None, want_u8=False):
 
 
 @pytest.mark.parametrize("name", list(cases.CASES))
-@pytest.mark.parametrize("which", ["ref_layout", "accel"])
+@pytest.mark.parametrize("which", ["ref_layout", "ref_layout_table", "ref_layout_walk", "accel"])
 def test_case_bit_exact_vs_oracle(mnv, orc, torch_gpu, name, which):
     spec = cases.CASES[name]
     tree = cases.make_tree(mnv, spec["tree"])
@@ -37,6 +43,41 @@ def test_case_bit_exact_vs_oracle(mnv, orc, torch_gpu, name, which):
     diff = cases.bits(got) != cases.bits(ref["rgba"])
     assert not diff.any(), f"{name}/{which}: {int(diff.any(axis=-1).sum())} pixels differ, max|d|={np.abs(got - ref['rgba']).max():.3e}"
     assert np.array_equal(got8, ref["rgba8"])
+
+
+@pytest.mark.parametrize("name", ["sh4_d6", "sh9_d7_aniso", "rgba_d5"])
+def test_trackers_with_the_per_launch_table(mnv, orc, torch_gpu, name):
+    """Tracker rows of the reference-layout kernel when leaves come out of the per-launch lookup table (chunk, child and depth of a
+    leaf are decoded from the table word, its sigma is the table's copy): equal to the oracle's, and to the rows without the table."""
+    torch = torch_gpu
+    spec = cases.CASES[name]
+    tree = cases.make_tree(mnv, spec["tree"])
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    opt.max_depth = 5
+    opt.max_sample_count = 9
+    v = tree.host_view()
+    sc = np.full((v.capacity, 8), 8, np.int16)
+    sc[::3] = 12
+    ref = orc.render(orc.tree_from_view(v, sample_counts=sc), cam.c, opt, want_trackers=True)
+    tree.move_to_device(need_sample_counts=True)
+    dv = tree.device_view()
+    sc_dev = torch.from_numpy(sc).cuda()
+    dv.sample_counts = sc_dev.data_ptr()
+    h, w = cam.height, cam.width
+    for min_rays in (0, -1):
+        rgba = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+        split = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")
+        sample = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")
+        mnv.set_ref_table_min_rays(min_rays)
+        try:
+            mnv.render_voxels(dv, cam, opt, rgba=rgba, split_track=split, sample_track=sample)
+        finally:
+            mnv.set_ref_table_min_rays(1 << 16)
+        torch.cuda.synchronize()
+        assert np.array_equal(cases.bits(rgba.cpu().numpy()), cases.bits(ref["rgba"]))
+        assert np.array_equal(split.cpu().numpy().reshape(-1, 3), ref["split"].reshape(-1, 3))
+        assert np.array_equal(sample.cpu().numpy().reshape(-1, 3), ref["sample"].reshape(-1, 3))
 
 
 def test_trackers_and_visited_match_oracle(mnv, orc, torch_gpu):
@@ -215,7 +256,9 @@ def test_cfg2_full_size_accel_equals_ref_layout_and_oracle(mnv, orc, torch_gpu, 
     cam = cases.cfg2_camera(mnv, pose=3)
     opt = mnv.RenderOptions.cli_defaults()
     a, _ = _render_gpu(mnv, torch_gpu, cfg2, cam, opt, "accel")
-    b, _ = _render_gpu(mnv, torch_gpu, cfg2, cam, opt, "ref_layout")
+    b, _ = _render_gpu(mnv, torch_gpu, cfg2, cam, opt, "ref_layout")          # 2 M rays: with the per-launch level-7 table
+    assert np.array_equal(cases.bits(a), cases.bits(b))
+    b, _ = _render_gpu(mnv, torch_gpu, cfg2, cam, opt, "ref_layout_walk")     # per-workgroup level-3 table only
     assert np.array_equal(cases.bits(a), cases.bits(b))
     ref = orc.render(orc.tree_from_view(cfg2.host_view()), cam.c, opt)
     assert np.array_equal(cases.bits(a), cases.bits(ref["rgba"]))
