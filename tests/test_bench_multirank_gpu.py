@@ -66,7 +66,7 @@ def test_bench_launcher_repeats_a_failed_run_conservatively_and_kills_a_wedged_o
     assert r.returncode != 0 and "was killed" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_bench_multirank_through_the_c_abi_gather(torch_gpu, fake_rccl, world):
     """bench.py's N > 1 path with the C-ABI gather (mnv.Comm -> mnv_gather_tiles) instead of the gloo staging: CU-masked march streams,
     one stream per ring slot, root-relieving partition, per-slot side streams, un-permute on rank 0.  The ranks share the GPU and

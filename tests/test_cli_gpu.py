@@ -89,7 +89,7 @@ def test_mnv_render_multi_gpu_mode_with_one_rank(mnv, orc, torch_gpu, tmp_path):
     assert r5.returncode != 0 and "refinement" in r5.stderr
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_mnv_render_multi_gpu_mode_with_several_ranks_on_one_gpu(mnv, torch_gpu, tmp_path, fake_rccl, world):
     """`mnv_render --gpus N` with N > 1 on a one-GPU box: the ranks share the device (MNV_RANKS_SHARE_GPU) and a host-staged stand-in
     takes RCCL's place (MNV_RCCL_LIBRARY=tests/shim/fake_rccl.cpp; RCCL refuses two ranks on one device).  Everything of ours runs as
