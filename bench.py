@@ -97,11 +97,29 @@ def self_launch(n, backend, timeout_s):
             out, _ = p.communicate(timeout=timeout_s)
             rc = p.returncode
         except subprocess.TimeoutExpired:
+            # the launcher, its ranks and whatever they started: the descendants of the process started above, listed BEFORE anything dies
+            # (a rank whose launcher is gone is re-parented and can no longer be found), each ended by its own pid, then the session's group
+            victims = []
             try:
-                os.killpg(p.pid, signal.SIGKILL)   # the launcher and its ranks: the session started above, nothing else
+                import psutil
+
+                victims = psutil.Process(p.pid).children(recursive=True)
+            except Exception:
+                pass
+            for v in victims:
+                try:
+                    v.kill()
+                except Exception:
+                    pass
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
             except ProcessLookupError:
                 pass
-            out, _ = p.communicate()
+            try:
+                out, _ = p.communicate(timeout=15)
+            except subprocess.TimeoutExpired:   # something still holds the pipe: do not wait for it
+                p.stdout.close()
+                out = ""
             rc = -signal.SIGKILL
             print(f"bench.py: the {n}-rank run did not finish within {timeout_s} s and was killed", file=sys.stderr)
         lines = [ln for ln in out.splitlines() if ln.startswith("{")]

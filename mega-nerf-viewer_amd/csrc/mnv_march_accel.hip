@@ -387,13 +387,6 @@ __device__ __forceinline__ bool ray_pixel(const AccelLaunch &K, uint32_t id, int
     return bx < K.P.tw && by < K.P.th;
 }
 
-__device__ __forceinline__ float lane_read(float v, int src_lane) {
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
-}
-__device__ __forceinline__ uint32_t lane_read(uint32_t v, int src_lane) {
-    return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
-}
-
 // bytes of one colour channel block of a packed row: basis_dim halfs padded to a whole dword
 __host__ __device__ constexpr int chan_bytes_for(int basis) { return basis > 0 ? ((2 * basis + 3) / 4) * 4 : 4; }
 // bytes of a packed row: three channel blocks rounded up to a power of two (16 ... 256), so that a
@@ -433,7 +426,6 @@ template <int BASIS, int BLOCK, int MODE /* 0 plain, 1 statistics, 2 refinement 
 __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES : MNV_MIN_WAVES) MNV_EXTRA_KERNEL_ATTR void march_accel_kernel(const AccelLaunch K) {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_mem[];
     uint64_t *s_exp = reinterpret_cast<uint64_t *>(s_mem);  // 32 x 8 B
-    uint32_t *s_map = s_mem + 64;                            // BLOCK words: dense-sample rank -> lane, per wavefront
     constexpr int NB = BASIS > 0 ? BASIS : 1;
     // Uniform switches cost scalar registers in the hot loop (the kernel runs at the 80-SGPR limit of 8 workgroups per CU, and
     // what does not fit is parked in VGPR lanes and read back with VALU instructions): the colour kernels (MODE 0 / 4) carry
@@ -449,8 +441,8 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
     };
     // per-lane ray constants that only the dense-sample / finish code needs live in LDS, not in VGPRs:
     // [k][thread] for k < NB: SH basis; then delta_scale and the output pixel index
-    float *s_ray = reinterpret_cast<float *>(s_mem + 64 + BLOCK);
-    uint32_t *s_grid = s_mem + 64 + BLOCK + (NB + 2) * BLOCK;  // (2^lds_level)^3 words
+    float *s_ray = reinterpret_cast<float *>(s_mem + 64);
+    uint32_t *s_grid = s_mem + 64 + (NB + 2) * BLOCK;  // (2^lds_level)^3 words
     constexpr int CHAN_BYTES = chan_bytes_for(BASIS);
     constexpr int ROW_BYTES = row_bytes_pow2(BASIS);
     const FrameParams &P = K.P;
@@ -487,7 +479,6 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
     const int sh2 = Lq - L2;
     const int shg = Lq - A.grid_level;
     float *my_ray = s_ray + threadIdx.x;             // [k * BLOCK]
-    float *wave_ray = s_ray + (threadIdx.x & ~63);  // [k * BLOCK + lane]
 
     // per-lane ray state
     float t = 0.f, T = 1.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
@@ -835,49 +826,23 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                 if (dense) o0 += weight * t;
             } else if (ablate(1)) {
             } else if constexpr (BASIS >= 1) {
-                // SH: the wavefront evaluates the samples cooperatively, one lane per (sample, channel):
-                // 21 samples x 3 channels per pass.  Each task lane pulls the sample's weight, voxel and
-                // SH basis from the owning lane (ds_bpermute), loads its channel's coefficients, and
-                // returns weight / (1 + exp(-dot)) to the owner, which accumulates in sample order.
-                const int n_dense = __popcll(dense_mask);
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(dense_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dense_mask, 0u));
-                uint32_t *map = s_map + (threadIdx.x & ~63);
-                if (dense) map[rank] = (uint32_t)lane;
-                __builtin_amdgcn_wave_barrier();
-                const int my_s = lane / 3, my_c = lane - 3 * my_s;
-                for (int base = 0; base < n_dense; base += 21) {
-                    const int smp = base + my_s;
-                    const bool task = my_s < 21 && smp < n_dense;
-                    stat(10, task);  // colour passes and their busy task lanes
-                    const int owner = task ? (int)map[smp] : lane;
-                    const float w = lane_read(weight, owner);
-                    uint32_t vx = lane_read(vox, owner);
+                // SH: every dense lane reads its sample's row (three channel blocks of one 64-byte row: one line fill) and evaluates the
+                // three channels itself, so all rows of an iteration are requested at once.  (Until round 2 the wavefront shared the work,
+                // one lane per (sample, channel), 21 samples per pass: more lanes busy per VALU instruction, but an iteration with 22+
+                // dense lanes waited for two or three passes' row misses one after the other -- LAB_NOTEBOOK.md.)
+                if (dense) {
+                    stat(10, true);
+                    constexpr int NW = CHAN_BYTES / 4;
+                    uint32_t vx = vox;
                     if (ablate(4)) vx &= 0xffffu;  // diagnostics: rows served from cache (wrong colours)
+                    const uint8_t *row = A.rows + (int64_t)vx * ROW_BYTES;
+                    const ChanWords<NW> c0 = *reinterpret_cast<const ChanWords<NW> *>(row);
+                    const ChanWords<NW> c1 = *reinterpret_cast<const ChanWords<NW> *>(row + CHAN_BYTES);
+                    const ChanWords<NW> c2 = *reinterpret_cast<const ChanWords<NW> *>(row + 2 * CHAN_BYTES);
                     float b[NB];
 #pragma unroll
-                    for (int k = 0; k < NB; ++k) b[k] = wave_ray[k * BLOCK + owner];  // the owner's SH basis, from LDS
-                    float v = 0.f;
-                    if (task) {
-                        constexpr int NW = CHAN_BYTES / 4;
-                        ChanWords<NW> cw;
-#if defined(MNV_ROW_POLICY)
-                        if constexpr (NW == 5) {
-                            // A/B (tools/build_variant.sh -DMNV_ROW_POLICY=1|2|3): cache-policy bits on the row loads -- sc0, sc1 or both
-                            const uint8_t *ra = A.rows + (int64_t)vx * ROW_BYTES + my_c * CHAN_BYTES;
-                            typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-                            u4 q4;
-                            uint32_t q1;
-#if MNV_ROW_POLICY == 1
-                            asm volatile("global_load_dwordx4 %0, %2, off sc0\n\tglobal_load_dword %1, %2, off offset:16 sc0\n\ts_waitcnt vmcnt(0)" : "=&v"(q4), "=&v"(q1) : "v"(ra) : "memory");
-#elif MNV_ROW_POLICY == 2
-                            asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dword %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q4), "=&v"(q1) : "v"(ra) : "memory");
-#else
-                            asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dword %1, %2, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q4), "=&v"(q1) : "v"(ra) : "memory");
-#endif
-                            cw.w[0] = q4.x; cw.w[1] = q4.y; cw.w[2] = q4.z; cw.w[3] = q4.w; cw.w[4] = q1;
-                        } else
-#endif
-                        cw = *reinterpret_cast<const ChanWords<NW> *>(A.rows + (int64_t)vx * ROW_BYTES + my_c * CHAN_BYTES);
+                    for (int k = 0; k < NB; ++k) b[k] = my_ray[k * BLOCK];
+                    auto chan = [&](const ChanWords<NW> &cw) -> float {
                         auto coef = [&](int k) -> float {
                             const uint32_t wd = cw.w[k >> 1];
                             return half_bits_to_float((uint16_t)((k & 1) ? (wd >> 16) : (wd & 0xffffu)));
@@ -887,22 +852,15 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                             // colour-only arithmetic: it feeds no branch (opacity, transmittance and the step sequence stay exact),
                             // so hardware exp2 / rcp (about 1 ulp each) move a colour by ~1e-7 and nothing else
                             const float e = __builtin_amdgcn_exp2f(tmp * -1.44269504088896341f);
-                            v = w * __builtin_amdgcn_rcpf(1.f + e);
+                            return weight * __builtin_amdgcn_rcpf(1.f + e);
                         } else {
-                            v = w / (1.f + exact_expf(-tmp, s_exp));
+                            return weight / (1.f + exact_expf(-tmp, s_exp));
                         }
-                    }
-                    const int rl = rank - base;
-                    const bool mine = dense && rl >= 0 && rl < 21;
-                    const int from = mine ? 3 * rl : lane;
-                    const float v0 = lane_read(v, from), v1 = lane_read(v, mine ? from + 1 : lane), v2 = lane_read(v, mine ? from + 2 : lane);
-                    if (mine) {
-                        o0 += v0;
-                        o1 += v1;
-                        o2 += v2;
-                    }
+                    };
+                    o0 += chan(c0);
+                    o1 += chan(c1);
+                    o2 += chan(c2);
                 }
-                __builtin_amdgcn_wave_barrier();
             } else {
                 // RGBA rows (rt_core.cuh:285-290): three halfs per voxel, per-lane
                 if (dense) {
@@ -1163,7 +1121,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     // sample emission and the depth image read no colour rows: one instantiation (BASIS 9) serves every row format
     const bool colourless = K.samples != nullptr || (P.render_depth && !K.split_track && !K.sample_track && !K.visited);
     const int nb_lds = colourless ? 9 : (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim > 0) ? accel->view.basis_dim : 1;
-    const size_t lds_bytes = 256 + 256 * 4 + (size_t)(nb_lds + 2) * 256 * 4 + ((size_t)4 << (3 * lds_level));
+    const size_t lds_bytes = 256 + (size_t)(nb_lds + 2) * 256 * 4 + ((size_t)4 << (3 * lds_level));
     static const int env_bpc = getenv("MNV_BLOCKS_PER_CU") ? atoi(getenv("MNV_BLOCKS_PER_CU")) : 0;
     static const int env_refill = getenv("MNV_REFILL_MIN") ? atoi(getenv("MNV_REFILL_MIN")) : 0;
     static const int env_ablate = getenv("MNV_ABLATE") ? atoi(getenv("MNV_ABLATE")) : 0;

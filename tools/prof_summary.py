@@ -26,7 +26,7 @@ try:
     for k in kernel_resources.kernels():
         if any(t in k["kernel"] for t in ("march_accel_kernel<9, 256, 0>", "march_accel_kernel<9, 256, 2>", "march_accel_kernel<9, 256, 3>", "march_ref_layout_kernel<9>")):
             print(k)
-    print("dynamic LDS of march_accel_kernel<9,256,*>: 256 + 1024 + (9 + 2) * 1024 + 2048 = 14592 bytes per workgroup (launch_accel)")
+    print("dynamic LDS of march_accel_kernel<9,256,*>: 256 + (9 + 2) * 1024 + 2048 = 13568 bytes per workgroup (launch_accel)")
 except Exception as e:  # noqa: BLE001
     print("unavailable:", e)
 print("== kernel trace: duration of every dispatch of the march kernel, in order (ns; the first one runs cold: page tables, caches) ==")
