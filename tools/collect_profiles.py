@@ -28,7 +28,7 @@ s += "         -> %.0f L1 misses in flight per compute unit on average; TA busy 
     lat * req, 100 * avg(mem, "TA_BUSY_avr") / cyc, 100 * avg(mem, "TCP_PENDING_STALL_CYCLES_sum") / 256 / cyc)
 open(os.path.join(P, "r02_rocprofv3_summary.txt"), "w").write(s)
 shutil.copy(os.path.join(G, "r02_batch", "traffic.json"), os.path.join(P, "r02_traffic.json"))
-for t in ("per_frame", "per_frame_1stream", "cfg3", "cfg4"):
+for t in ("per_frame", "per_frame_1stream", "ref_layout", "cfg3", "cfg4"):
     shutil.copy(os.path.join(G, "r02_%s" % t, "summary.txt"), os.path.join(P, "r02_rocprofv3_summary_%s.txt" % t))
 shutil.copy(os.path.join(G, "r02_guided", "summary.txt"), os.path.join(P, "r02_rocprofv3_summary_guided_fused.txt"))
 d = json.load(open(os.path.join(G, "r02_bench_n1.json")))

@@ -5,6 +5,7 @@ python3 tools/make_traffic_json.py gpurun_out/r02_batch/summary.txt 64 > gpurun_
 bash tools/prof_mem.sh r02_mem > gpurun_out/r02_mem.txt 2>&1
 bash tools/prof_trace.sh r02_per_frame --per-frame --frame-streams 3 --steps 3 --warmup 1 > /dev/null 2>&1
 bash tools/prof_trace.sh r02_per_frame_1stream --per-frame --frame-streams 1 --steps 3 --warmup 1 > /dev/null 2>&1
+bash tools/prof_trace.sh r02_ref_layout --kernel ref_layout --per-frame --frame-streams 2 --laps 1 --steps 3 --warmup 1 > /dev/null 2>&1
 bash tools/prof_trace.sh r02_cfg3 --workload cfg3 --frame-streams 0 --steps 4 --warmup 1 > /dev/null 2>&1
 bash tools/prof_trace.sh r02_cfg4 --workload cfg4 --frame-streams 0 --steps 3 --warmup 1 > /dev/null 2>&1
 export TMPDIR=/tmp
