@@ -249,6 +249,18 @@ int32_t mnv_comm_rank(const mnv_comm *comm);
 int32_t mnv_comm_world(const mnv_comm *comm);
 int32_t mnv_comm_rccl_version(void); /* ncclGetVersion of the library that was bound, 0 if none */
 int mnv_gather_tiles(mnv_comm *comm, const void *local, void *gathered, size_t bytes_per_rank, int32_t root, void *hip_stream);
+/*
+ * Refinement on several ranks (BASELINE.json configs[4]; SURVEY.md 8(e): "run identical deterministic refinement on every rank"): every
+ * rank holds the whole tree, renders its macro tiles of the tracker frame and then needs ALL tracker rows to cast the same votes
+ * (cuda_renderer.cpp:205-227 counts candidates over the whole frame; the count does not depend on the order of the rows).
+ *   mnv_allgather            in place, asynchronous on `hip_stream`: `table` is [world][bytes_per_rank] on every rank, rank r has written
+ *                            block r; afterwards every rank holds every block (grouped ncclSend / ncclRecv between all pairs: on xGMI
+ *                            each pair has its own link)
+ *   mnv_merge_visit_marks    visited[c] = max over r of table[r][c]: the union of the ranks' visit marks (each rank marks the chunks ITS
+ *                            rays went through; a prune needs the frame's), after mnv_allgather of the per-rank mark arrays
+ */
+int mnv_allgather(mnv_comm *comm, void *table, size_t bytes_per_rank, void *hip_stream);
+int mnv_merge_visit_marks(const int32_t *table, int32_t world, int32_t capacity, int32_t *visited, void *hip_stream);
 void mnv_comm_destroy(mnv_comm *comm);
 
 /*
@@ -325,6 +337,12 @@ int mnv_get_samples_from_voxels_accel_visit(const mnv_accel *accel, const mnv_ca
                                             float *split_track, float *sample_track, const int16_t *sample_counts, int32_t *visited,
                                             const int32_t *parent, int16_t *num_samples, float *samples, int32_t samples_dim,
                                             int16_t *cluster_indices, const mnv_cluster_grid *grid, void *hip_stream);
+/* The tracker frame of one rank of a multi-GPU run: pixels AND tracker rows of the macro tiles `part` assigns to the rank, both in the
+ * compact tile-major order of mnv_render_voxels_accel_part (row p of a tracker belongs to pixel p of the rank's buffer); rows of tiles a
+ * ragged partition leaves out are not written (pre-fill with -1 as for a frame).  `visited` receives the marks of this rank's rays. */
+int mnv_render_voxels_accel_visit_part(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, mnv_partition part,
+                                       float *rgba_out, uint8_t *rgba8_out, float *split_track, float *sample_track, const int16_t *sample_counts,
+                                       int32_t *visited, const int32_t *parent, void *hip_stream);
 
 /*
  * viewer::render_nerf_results (include/cuda/renderer_kernel.hpp:12-21,
@@ -517,6 +535,12 @@ int mnv_render_guided_fused_track(const mnv_accel *accel, const mnv_camera *cam,
 int mnv_render_guided_fused_part(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, mnv_partition part,
                                  const mnv_mlp *mlp, const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out,
                                  unsigned long long *sample_counter, void *hip_stream);
+/* ... with the tracker rows and visit marks of mnv_render_guided_fused_track for the rank's tiles (compact order, as
+ * mnv_render_voxels_accel_visit_part): the frame of configs[4] -- refinement and guided sampling both on -- on one rank of several. */
+int mnv_render_guided_fused_track_part(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, mnv_partition part,
+                                       const mnv_mlp *mlp, const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, float *split_track,
+                                       float *sample_track, const int16_t *sample_counts, int32_t *visited, const int32_t *parent,
+                                       unsigned long long *sample_counter, void *hip_stream);
 
 /* A HIP stream whose kernels run on all but `reserve_cus` compute units (hipExtStreamCreateWithCUMask; the units are taken
  * evenly from the XCDs, and from their shader engines when reserve_cus is a multiple of 32).  The tuned kernel is persistent and
@@ -604,6 +628,10 @@ int mnv_renderer_set_frames_in_flight(mnv_renderer *r, int32_t count);
 /* VolumeRenderer::use_fused_guided (default on): guided-sampling frames that need nothing but the picture run as one kernel;
  * off = always the four steps of cuda_renderer.cpp:107-139 (sample march, compaction, networks, composite) */
 int mnv_renderer_set_fused_guided(mnv_renderer *r, int enable);
+/* VolumeRenderer::set_ranks: several ranks (one process per GPU, each with its own renderer over the same scene and networks) render and
+ * refine in lock step -- this rank marches its macro tiles, tracker rows and visit marks are all-gathered, the same refinement runs on
+ * every replica, rank 0's frame is the whole picture.  comm NULL = back to one rank.  The communicator stays the caller's. */
+int mnv_renderer_set_ranks(mnv_renderer *r, mnv_comm *comm, int32_t tile_w, int32_t tile_h);
 int32_t mnv_renderer_last_slot(const mnv_renderer *r);
 int mnv_renderer_download_slot(mnv_renderer *r, int32_t slot, float *rgba_host, uint8_t *rgba8_host);
 /* copy the (refined) device tree back into the mnv_n3tree's host arrays */

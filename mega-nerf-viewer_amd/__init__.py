@@ -211,6 +211,13 @@ _SIGNATURES = {
     "mnv_comm_rccl_version": (C.c_int32, []),
     "mnv_gather_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
     "mnv_comm_destroy": (None, [C.c_void_p]),
+    "mnv_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mnv_merge_visit_marks": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "mnv_render_voxels_accel_visit_part": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, Partition, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mnv_render_guided_fused_track_part": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, Partition, C.c_void_p,
+                                                     C.POINTER(ClusterGrid), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_render_voxels_accel_batch": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.c_int32, C.POINTER(RenderOptions), Rect,
                                                 Partition, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_render_voxels_accel_track": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
@@ -268,6 +275,7 @@ _SIGNATURES = {
     "mnv_renderer_set_frames_in_flight": (C.c_int, [C.c_void_p, C.c_int32]),
     "mnv_renderer_last_slot": (C.c_int32, [C.c_void_p]),
     "mnv_renderer_set_fused_guided": (C.c_int, [C.c_void_p, C.c_int]),
+    "mnv_renderer_set_ranks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "mnv_renderer_download_slot": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mnv_set_timing": (None, [C.c_int]),
     "mnv_take_timing": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
@@ -872,6 +880,11 @@ class Renderer:
     def set_fused_guided(self, enable: bool) -> None:
         _check(lib().mnv_renderer_set_fused_guided(self._h, int(enable)))
 
+    def set_ranks(self, comm, tile_w: int = 64, tile_h: int = 24) -> None:
+        """Several ranks refine one scene in lock step (VolumeRenderer::set_ranks); comm: mnv.Comm or None."""
+        self._comm = comm  # keep the communicator alive as long as the renderer uses it
+        _check(lib().mnv_renderer_set_ranks(self._h, C.c_void_p(comm.handle) if comm is not None else None, int(tile_w), int(tile_h)))
+
     def last_slot(self) -> int:
         return int(lib().mnv_renderer_last_slot(self._h))
 
@@ -950,6 +963,12 @@ class Comm:
         _check(lib().mnv_gather_tiles(C.c_void_p(self.handle), _ptr(local), _ptr(gathered) if gathered is not None else None, nbytes, int(root),
                                       C.c_void_p(stream)))
 
+    def allgather(self, table, stream: int = 0) -> None:
+        """table: contiguous device tensor [world, ...]; this rank has written table[rank]; afterwards every rank holds every block."""
+        if not table.is_contiguous() or not table.is_cuda or table.shape[0] != self.world:
+            raise MnvError(MNV_E_INVALID, "table must be a contiguous device tensor [world, ...]")
+        _check(lib().mnv_allgather(C.c_void_p(self.handle), _ptr(table), table.numel() * table.element_size() // self.world, C.c_void_p(stream)))
+
     def close(self) -> None:
         if getattr(self, "handle", None):
             lib().mnv_comm_destroy(C.c_void_p(self.handle))
@@ -960,6 +979,11 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def merge_visit_marks(table, visited, stream: int = 0) -> None:
+    """visited[c] = max over ranks of table[r][c] (int32 device tensors [world, capacity] and [capacity])."""
+    _check(lib().mnv_merge_visit_marks(_ptr(table), int(table.shape[0]), int(table.shape[1]), _ptr(visited), C.c_void_p(stream)))
 
 
 def rccl_version() -> int:

@@ -178,6 +178,23 @@ int mnv_gather_tiles(mnv_comm *c, const void *local, void *gathered, size_t byte
     return MNV_OK;
 }
 
+int mnv_allgather(mnv_comm *c, void *table, size_t bytes_per_rank, void *hip_stream) {
+    if (!c || !table) return mnv::set_error(MNV_E_INVALID, "invalid all-gather arguments");
+    if (bytes_per_rank == 0 || c->world == 1) return MNV_OK;
+    Rccl &r = rccl();
+    hipStream_t stream = (hipStream_t)hip_stream;
+    uint8_t *t = static_cast<uint8_t *>(table);
+    int rc = check_nccl(r.GroupStart(), "ncclGroupStart");
+    if (rc) return rc;
+    for (int32_t p = 0; p < c->world && !rc; ++p) {
+        if (p == c->rank) continue;
+        rc = check_nccl(r.Send(t + (size_t)c->rank * bytes_per_rank, bytes_per_rank, ncclUint8, p, c->comm, stream), "ncclSend");
+        if (!rc) rc = check_nccl(r.Recv(t + (size_t)p * bytes_per_rank, bytes_per_rank, ncclUint8, p, c->comm, stream), "ncclRecv");
+    }
+    const int rc_end = check_nccl(r.GroupEnd(), "ncclGroupEnd");
+    return rc ? rc : rc_end;
+}
+
 void mnv_comm_destroy(mnv_comm *c) {
     if (!c) return;
     if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);

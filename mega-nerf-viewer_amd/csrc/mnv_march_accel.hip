@@ -1593,6 +1593,23 @@ int mnv_render_voxels_accel_visit(const mnv_accel *accel, const mnv_camera *cam,
     return render_accel(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, &track, hip_stream);
 }
 
+int mnv_render_voxels_accel_visit_part(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, mnv_partition part,
+                                       float *rgba_out, uint8_t *rgba8_out, float *split_track, float *sample_track, const int16_t *sample_counts,
+                                       int32_t *visited, const int32_t *parent, void *hip_stream) {
+    if (!opt) return set_error(MNV_E_INVALID, "options are null");
+    if (visited && !parent) return set_error(MNV_E_INVALID, "visit marks on the packed layout need the parent array (the ancestors of the marked chunks)");
+    if (!split_track && !sample_track && !visited) return mnv_render_voxels_accel_part(accel, cam, opt, tile, part, rgba_out, rgba8_out, hip_stream);
+    AccelTrack track = {};
+    track.split_track = split_track;
+    track.sample_track = sample_track;
+    track.sample_counts = sample_counts;
+    track.max_depth = opt->max_depth;
+    track.max_sample_count = opt->max_sample_count;
+    track.visited = visited;
+    track.parent = parent;
+    return render_accel(accel, cam, 1, opt, tile, part, rgba_out, rgba8_out, &track, hip_stream);
+}
+
 int mnv_get_samples_from_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
                                       float *split_track, float *sample_track, const int16_t *sample_counts, int16_t *num_samples,
                                       float *samples, int32_t samples_dim, int16_t *cluster_indices, const mnv_cluster_grid *grid,
@@ -1656,6 +1673,14 @@ int mnv_render_guided_fused_part(const mnv_accel *accel, const mnv_camera *cam, 
                                  unsigned long long *sample_counter, void *hip_stream) {
     return guided_fused(accel, cam, opt, tile, part, mlp, grid, rgba_out, rgba8_out, nullptr, nullptr, nullptr, nullptr, nullptr, sample_counter,
                         hip_stream);
+}
+
+int mnv_render_guided_fused_track_part(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, mnv_partition part,
+                                       const mnv_mlp *mlp, const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, float *split_track,
+                                       float *sample_track, const int16_t *sample_counts, int32_t *visited, const int32_t *parent,
+                                       unsigned long long *sample_counter, void *hip_stream) {
+    return guided_fused(accel, cam, opt, tile, part, mlp, grid, rgba_out, rgba8_out, split_track, sample_track, sample_counts, visited, parent,
+                        sample_counter, hip_stream);
 }
 
 static int guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, mnv_partition part,

@@ -178,6 +178,15 @@ int select_candidates(const float *track, int64_t n_rows, int32_t max_out, bool 
     return MNV_OK;
 }
 
+// union of the ranks' visit marks (mnv_merge_visit_marks)
+__global__ void merge_marks_kernel(const int32_t *__restrict__ table, int32_t world, int32_t capacity, int32_t *__restrict__ visited) {
+    const int32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= capacity) return;
+    int32_t m = 0;
+    for (int32_t r = 0; r < world; ++r) m = max(m, table[(int64_t)r * capacity + c]);
+    visited[c] = m;
+}
+
 // ---------------------------------------------------------------- data updates
 
 __device__ inline uint16_t float_to_half_bits(float f) {
@@ -304,6 +313,13 @@ __global__ void compact_samples_kernel(const int16_t *__restrict__ num_samples, 
 using namespace mnv;
 
 extern "C" {
+
+int mnv_merge_visit_marks(const int32_t *table, int32_t world, int32_t capacity, int32_t *visited, void *hip_stream) {
+    if (!table || !visited || world < 1 || capacity < 0) return set_error(MNV_E_INVALID, "invalid visit-mark arguments");
+    if (capacity == 0) return MNV_OK;
+    hipLaunchKernelGGL(merge_marks_kernel, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, (hipStream_t)hip_stream, table, world, capacity, visited);
+    return check_hip(hipGetLastError(), "merge_marks_kernel");
+}
 
 int mnv_select_split_candidates(const float *split_track, int64_t n_rows, int32_t max_out, int32_t *nodes_out,
                                 int32_t *n_out, int32_t *n_candidates, void *hip_stream) {

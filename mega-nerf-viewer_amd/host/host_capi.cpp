@@ -316,6 +316,15 @@ int mnv_renderer_set_fused_guided(mnv_renderer *r, int enable) {
     return MNV_OK;
 }
 
+int mnv_renderer_set_ranks(mnv_renderer *r, mnv_comm *comm, int32_t tile_w, int32_t tile_h) {
+    if (!r) return mnv::set_error(MNV_E_INVALID, "null argument");
+    if (comm && (tile_w < 8 || tile_h < 8 || tile_w % 8 || tile_h % 8)) return mnv::set_error(MNV_E_INVALID, "macro tiles are multiples of 8 pixels");
+    return guarded([&] {
+        r->rend.set_ranks(comm, tile_w, tile_h);
+        return MNV_OK;
+    });
+}
+
 int32_t mnv_renderer_last_slot(const mnv_renderer *r) { return r ? r->rend.last_slot() : -1; }
 
 int mnv_renderer_download_slot(mnv_renderer *r, int32_t slot, float *rgba, uint8_t *rgba8) {

@@ -195,6 +195,90 @@ struct Rendezvous {  // anonymous shared mapping created before the fork
 
 constexpr int kMacroW = 64, kMacroH = 24;  // per-rank launch times within 3 % of each other at world 8
 
+// communicator: rank 0 draws the id, the others read it from the shared page
+mnv_comm *join_ranks(int rank, int world, Rendezvous *rv) {
+    if (rank == 0) {
+        mnv_ok(mnv_comm_get_unique_id(rv->id), "mnv_comm_get_unique_id");
+        rv->id_ready.store(1, std::memory_order_release);
+    } else {
+        while (!rv->id_ready.load(std::memory_order_acquire)) {
+            if (rv->failed.load()) throw std::runtime_error("another rank failed before the rendezvous");
+            usleep(1000);
+        }
+    }
+    mnv_comm *comm = nullptr;
+    mnv_ok(mnv_comm_init_rank(rv->id, world, rank, &comm), "mnv_comm_init_rank");
+    return comm;
+}
+
+void print_refine_stats(long f, const viewer::VolumeRenderer::FrameStats &st) {
+    std::printf("frame %ld: capacity %ld", f, st.capacity);
+    if (st.split_candidates || st.added) std::printf("  split candidates %d, added %d%s", st.split_candidates, st.added, st.full ? " (full)" : "");
+    if (st.sample_candidates) std::printf("  sample candidates %d, resampled %d", st.sample_candidates, st.resampled);
+    if (st.pruned) std::printf("  pruned %d", st.pruned > 0 ? st.pruned : 0);
+    if (st.guided_samples) std::printf("  guided samples %ld", st.guided_samples);
+    std::printf("\n");
+}
+
+// --gpus N with --use_splitting: the ranks refine ONE scene in lock step (VolumeRenderer::set_ranks) -- every rank marches its macro
+// tiles, the tracker rows are all-gathered, every rank applies the same splits / resamples / prunes to its replica of the tree, and
+// rank 0 assembles and writes the frames.  One frame at a time: a frame reads the tree the previous one left.
+int run_rank_refine(const Args &args, int rank, int world, Rendezvous *rv) {
+    const bool share = std::getenv("MNV_RANKS_SHARE_GPU") != nullptr;
+    if (hipSetDevice((int)args.l("gpu", 0) + (share ? 0 : rank)) != hipSuccess)
+        throw std::runtime_error("rank " + std::to_string(rank) + ": no usable HIP device");
+    viewer::N3Tree tree(args.file);
+    if (tree.N <= 0) throw std::runtime_error("--gpus needs a tree (N > 0)");
+    const int width = (int)args.l("width", 800), height = (int)args.l("height", 800);
+    viewer::VolumeRenderer rend;
+    configure(args, rend, width, height);
+    const long max_capacity = std::max<long>(tree.capacity, args.l("max_tree_capacity", 20000000));
+    rend.set(tree, max_capacity);
+    rend.resize(width, height);
+    rend.load_model(args.get("model_path", ""));
+    rend.options.use_splitting = args.has("use_splitting");
+    rend.options.use_guided_sampling = args.has("use_guided_sampling");
+    rend.options.max_depth = (int)args.l("max_depth", rend.options.max_depth);
+    rend.options.max_sample_count = (int)args.l("max_sample_count", rend.options.max_sample_count);
+    rend.seed = (uint64_t)args.l("seed", 0);
+    mnv_comm *comm = join_ranks(rank, world, rv);
+    rend.set_ranks(comm, kMacroW, kMacroH);
+
+    const long frames = args.l("frames", 1);
+    const double orbit = args.f("orbit", 0.f) * M_PI / 180.0;
+    const std::string out = args.get("out", "");
+    std::vector<float> rgba;
+    std::vector<uint8_t> rgba8;
+    const auto wall0 = std::chrono::steady_clock::now();
+    for (long f = 0; f < frames; ++f) {
+        rend.render();
+        if (rank == 0) {
+            print_refine_stats(f, rend.stats);
+            if (!out.empty()) {
+                rend.download(args.has("raw") ? &rgba : nullptr, &rgba8);
+                write_frame(out, f, width, height, rgba8.data(), args.has("raw") ? rgba.data() : nullptr);
+            }
+        }
+        if (orbit != 0.0) orbit_step(rend.camera, orbit);
+    }
+    rend.sync_tree_streams();
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    if (args.has("save_tree")) {  // every rank holds the same tree; rank r > 0 writes <name>.rank<r> when asked to (MNV_SAVE_EVERY_RANK: tests)
+        const std::string name = args.get("save_tree", "");
+        if (rank == 0 || std::getenv("MNV_SAVE_EVERY_RANK")) {
+            rend.sync_tree();
+            tree.save_npz(rank == 0 ? name : name + ".rank" + std::to_string(rank) + ".npz");
+        }
+    }
+    if (rank == 0)
+        std::printf("%s x %d (RCCL %d): %ld refinement frame(s) %dx%d in lock step, interleaved %dx%d macro tiles, %.3f ms/frame wall%s\n", rend.get_backend(),
+                    world, (int)mnv_comm_rccl_version(), frames, width, height, kMacroW, kMacroH, wall_ms / std::max<long>(frames, 1),
+                    out.empty() ? "" : " incl. download + file output");
+    rend.set_ranks(nullptr);
+    mnv_comm_destroy(comm);
+    return 0;
+}
+
 int run_rank(const Args &args, int rank, int world, Rendezvous *rv) {
     // test hook: MNV_RANKS_SHARE_GPU=1 puts every rank on device --gpu (with a transport stand-in for RCCL, which refuses two ranks on
     // one device: tests/shim/fake_rccl.cpp) so that the world > 1 paths can run on a one-GPU machine
@@ -215,18 +299,7 @@ int run_rank(const Args &args, int rank, int world, Rendezvous *rv) {
         rend.options.max_guided_samples = (int)args.l("max_guided_samples", 128);
     }
 
-    // communicator: rank 0 draws the id, the others read it from the shared page
-    if (rank == 0) {
-        mnv_ok(mnv_comm_get_unique_id(rv->id), "mnv_comm_get_unique_id");
-        rv->id_ready.store(1, std::memory_order_release);
-    } else {
-        while (!rv->id_ready.load(std::memory_order_acquire)) {
-            if (rv->failed.load()) throw std::runtime_error("another rank failed before the rendezvous");
-            usleep(1000);
-        }
-    }
-    mnv_comm *comm = nullptr;
-    mnv_ok(mnv_comm_init_rank(rv->id, world, rank, &comm), "mnv_comm_init_rank");
+    mnv_comm *comm = join_ranks(rank, world, rv);
 
     const long frames = args.l("frames", 1);
     const double orbit = args.f("orbit", 0.f) * M_PI / 180.0;
@@ -361,7 +434,7 @@ int run_rank(const Args &args, int rank, int world, Rendezvous *rv) {
 // with it (they would otherwise wait in RCCL forever).
 int run_distributed(const Args &args, int world) {
     if (world < 1 || world > 64) throw std::runtime_error("--gpus must be 1 .. 64");
-    if (args.has("use_splitting")) throw std::runtime_error("--gpus renders a read-only tree; refinement (--use_splitting) mutates it and runs on one GPU");
+    if (args.has("use_splitting") && !args.has("model_path")) throw std::runtime_error("--use_splitting needs --model_path");
     if (args.has("use_guided_sampling") && !args.has("model_path")) throw std::runtime_error("--use_guided_sampling needs --model_path");
     void *page = mmap(nullptr, sizeof(Rendezvous), PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
     if (page == MAP_FAILED) throw std::runtime_error("mmap failed");
@@ -376,7 +449,7 @@ int run_distributed(const Args &args, int world) {
         if (pid == 0) {
             int rc = 1;
             try {
-                rc = run_rank(args, r, world, rv);
+                rc = args.has("use_splitting") ? run_rank_refine(args, r, world, rv) : run_rank(args, r, world, rv);
             } catch (const std::exception &e) {
                 std::fprintf(stderr, "mnv_render[rank %d]: %s\n", r, e.what());
                 rv->failed.store(1);
@@ -460,15 +533,7 @@ int main(int argc, char **argv) {
         for (long f = 0; f < frames; ++f) {
             while (pending.size() >= depth) write_oldest();  // the slot frame f is about to take must have been written
             rend.render();
-            if (refine) {
-                const auto &st = rend.stats;
-                std::printf("frame %ld: capacity %ld", f, st.capacity);
-                if (st.split_candidates || st.added) std::printf("  split candidates %d, added %d%s", st.split_candidates, st.added, st.full ? " (full)" : "");
-                if (st.sample_candidates) std::printf("  sample candidates %d, resampled %d", st.sample_candidates, st.resampled);
-                if (st.pruned) std::printf("  pruned %d", st.pruned > 0 ? st.pruned : 0);
-                if (st.guided_samples) std::printf("  guided samples %ld", st.guided_samples);
-                std::printf("\n");
-            }
+            if (refine) print_refine_stats(f, rend.stats);
             if (!out.empty()) pending.emplace_back(f, rend.last_slot());
             if (orbit != 0.0) orbit_step(rend.camera, orbit);
         }

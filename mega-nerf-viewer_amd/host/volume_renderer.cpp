@@ -72,6 +72,12 @@ struct VolumeRenderer::Impl {
     DeviceBuffer offsets, z_vals, sample_rows, sample_clusters, nerf_results;
     DeviceBuffer nodes, rand_sample, rand_clusters, results, fused_counter;
     bool patch_after_prune = true;
+    // several ranks (set_ranks): this rank's share of the frame in compact tile-major order, the gather table on rank 0, the marks table
+    mnv_comm *comm = nullptr;
+    mnv_partition part = {0, 1, 0, 0, 0};
+    int64_t rank_px = 0;  // pixels per rank in the compact layout: j_max macro tiles
+    DeviceBuffer local, local8, table, table8, marks_table;
+    int64_t tracker_rows() const { return comm ? rank_px * part.world : (int64_t)width * height; }
     bool fused_inputs_ok = false;  // the model's encoded input fits the fused guided kernel (<= 64 features)
     bool prune_happened = false, can_reuse_results = false, accel_stale = false;
     bool marks_fresh = false, want_marks = false;  // see render(): prune only after a track_visit frame
@@ -157,10 +163,11 @@ struct VolumeRenderer::Impl {
     void get_more_samples(RenderOptions &o, FrameStats &st, uint64_t seed);
     // cuda_renderer.cpp:335-381
     void prune_tree(FrameStats &st);
+    void refine_after_frame(RenderOptions &o, FrameStats &st, uint64_t seed, bool track_visit);
 };
 
 void VolumeRenderer::Impl::expand_voxels(RenderOptions &o, FrameStats &st, uint64_t seed) {
-    const int64_t n_px = (int64_t)width * height;
+    const int64_t n_px = tracker_rows();
     int32_t n = 0, n_cand = 0;
     int32_t *d_nodes = nodes.get<int32_t>((size_t)std::max(o.split_batch_size, 1) * 2);
     mnv_check(mnv_select_split_candidates(split_tracker.get<float>(n_px * 3), n_px, o.split_batch_size, d_nodes, &n, &n_cand, stream),
@@ -196,7 +203,7 @@ void VolumeRenderer::Impl::expand_voxels(RenderOptions &o, FrameStats &st, uint6
 }
 
 void VolumeRenderer::Impl::get_more_samples(RenderOptions &o, FrameStats &st, uint64_t seed) {
-    const int64_t n_px = (int64_t)width * height;
+    const int64_t n_px = tracker_rows();
     int32_t n = 0, n_cand = 0;
     int32_t *d_nodes = nodes.get<int32_t>((size_t)std::max(o.split_batch_size, 1) * 2);
     mnv_check(mnv_select_sample_candidates(sample_tracker.get<float>(n_px * 3), n_px, o.split_batch_size, d_nodes, &n, &n_cand, stream),
@@ -240,6 +247,35 @@ void VolumeRenderer::Impl::prune_tree(FrameStats &st) {
         } else if (tree->device.accel) {  // no patch (switched off, or the accel was stale already): rebuild in place, 2.9 ms on the 1.5 M-chunk tree
             tree->rebuild_accel(stream);
             accel_stale = false;
+        }
+    }
+}
+
+// cuda_renderer.cpp:144-155: what follows the march of a refinement frame
+void VolumeRenderer::Impl::refine_after_frame(RenderOptions &options, FrameStats &stats, uint64_t seed, bool track_visit) {
+    Impl &I = *this;
+    N3Tree &tree = *I.tree;
+    ++I.quiet_frames;
+    // The capacity check runs only while splitting is on: the reference's unconditional
+    // check would prune a tree that was merely loaded with max_tree_capacity close to its size.
+    if (options.use_splitting) {
+        I.expand_voxels(options, stats, seed + 0x9e3779b97f4a7c15ull * I.frame);
+        if (track_visit) I.marks_fresh = true;
+        I.want_marks = false;
+        if (I.max_tree_capacity - tree.capacity < options.split_batch_size) {
+            // The reference prunes here with whatever marks exist (cuda_renderer.cpp:148-150); with a camera that
+            // has not moved since the tree was small that is no marks at all and the whole tree goes.  Here a
+            // prune waits for one track_visit frame since the marks were last cleared.
+            if (I.marks_fresh) {
+                I.prune_tree(stats);
+                I.prune_happened = true;
+                I.marks_fresh = false;
+            } else {
+                I.want_marks = true;
+                I.prune_happened = false;
+            }
+        } else {
+            I.prune_happened = false;
         }
     }
 }
@@ -331,6 +367,17 @@ void VolumeRenderer::clear() { impl_->tree = nullptr; }
 const mnv_mlp *VolumeRenderer::model() const { return impl_->mlp; }
 const mnv_cluster_grid &VolumeRenderer::cluster_grid() const { return impl_->grid; }
 
+void VolumeRenderer::set_ranks(mnv_comm *comm, int tile_w, int tile_h) {
+    Impl &I = *impl_;
+    I.sync_all();
+    I.comm = comm;
+    if (!comm) {
+        I.part = {0, 1, 0, 0, 0};
+        return;
+    }
+    I.part = {mnv_comm_rank(comm), mnv_comm_world(comm), tile_w, tile_h, 0};
+}
+
 void VolumeRenderer::resize(int width, int height) {
     if (impl_->width == width && impl_->height == height && impl_->rgba) return;
     if (!impl_->initial_resize && camera.width > 0 && camera.height > 0) {
@@ -364,7 +411,7 @@ void VolumeRenderer::render() {
     {
         // a plain frame of a tree with a current accel takes the next slot; everything else runs alone on slot 0
         const bool refine_now = I.mlp != nullptr && (options.use_splitting || options.use_guided_sampling);
-        const bool plain = !refine_now && I.tree != nullptr && I.tree->N > 0 && I.tree->device.accel && !I.accel_stale;
+        const bool plain = !I.comm && !refine_now && I.tree != nullptr && I.tree->N > 0 && I.tree->device.accel && !I.accel_stale;
         if (plain && frames_in_flight > 1) {
             I.ensure_slots(frames_in_flight);
             I.use_slot((I.cur + 1) % frames_in_flight);
@@ -377,6 +424,10 @@ void VolumeRenderer::render() {
         }
         if (I.overlapped) I.sync_all();
         I.use_slot(0);
+    }
+    if (I.comm) {
+        render_ranks();
+        return;
     }
     if (I.tree == nullptr || I.tree->N <= 0) {
         mnv_tree_view empty = {};  // N == 0: background only (renderer_kernel.cu:266)
@@ -490,33 +541,97 @@ void VolumeRenderer::render() {
         mnv_check(mnv_render_voxels(&dv, &cv, options.c_abi(), full, I.rgba, I.rgba8, split, sample, visited, track_visit, I.stream), "mnv_render_voxels");
     }
 
-    if (refine) {
-        const int before = tree.capacity;
-        ++I.quiet_frames;
-        // cuda_renderer.cpp:144-155.  The capacity check runs only while splitting is on: the reference's unconditional
-        // check would prune a tree that was merely loaded with max_tree_capacity close to its size.
-        if (options.use_splitting) {
-            I.expand_voxels(options, stats, seed + 0x9e3779b97f4a7c15ull * I.frame);
-            if (track_visit) I.marks_fresh = true;
-            I.want_marks = false;
-            if (I.max_tree_capacity - tree.capacity < options.split_batch_size) {
-                // The reference prunes here with whatever marks exist (cuda_renderer.cpp:148-150); with a camera that
-                // has not moved since the tree was small that is no marks at all and the whole tree goes.  Here a
-                // prune waits for one track_visit frame since the marks were last cleared.
-                if (I.marks_fresh) {
-                    I.prune_tree(stats);
-                    I.prune_happened = true;
-                    I.marks_fresh = false;
-                } else {
-                    I.want_marks = true;
-                    I.prune_happened = false;
-                }
-            } else {
-                I.prune_happened = false;
-            }
-        }
-        (void)before;
+    if (refine) I.refine_after_frame(options, stats, seed, track_visit);
+    ++I.frame;
+    stats.capacity = tree.capacity;
+}
+
+// render() of one rank of several (set_ranks)
+void VolumeRenderer::render_ranks() {
+    Impl &I = *impl_;
+    if (I.tree == nullptr || I.tree->N <= 0 || !I.tree->device.accel)
+        throw std::runtime_error("several ranks need a tree with the packed accel (N == 2, RGBA or SH1/4/9/16/25 rows)");
+    N3Tree &tree = *I.tree;
+    const mnv_camera cv = camera.c_abi();
+    const mnv_rect full = {0, 0, I.width, I.height};
+    const int world = I.part.world, rank = I.part.rank;
+    int32_t j_max = 0;
+    for (int r = 0; r < world; ++r) {
+        const mnv_partition pr = {r, world, I.part.tile_w, I.part.tile_h, 0};
+        j_max = std::max(j_max, mnv_partition_local_tiles(full, pr));
     }
+    I.rank_px = (int64_t)j_max * I.part.tile_w * I.part.tile_h;
+    const int64_t rows = I.rank_px * world;
+    const bool refine = I.mlp != nullptr && (options.use_splitting || options.use_guided_sampling);
+    if (refine && I.mlp_desc.out_dim != tree.data_dim + 1)
+        throw std::runtime_error("the model's out_dim must be the tree's data_dim + 1 (cuda_renderer.cpp:255-257)");
+    if (options.render_depth && refine) throw std::runtime_error("several ranks: no depth mode while refining");
+
+    // cuda_renderer.cpp:98-107 -- the same decisions on every rank: they depend on the camera and on the (replicated) tree only
+    const bool camera_has_changed = camera.has_changed();
+    const bool track_visit = refine && ((camera_has_changed && tree.capacity > I.max_tree_capacity * 3 / 4) || I.prune_happened || I.want_marks);
+    if (camera_has_changed) I.can_reuse_results = false;
+    stats.track_visit = track_visit;
+    float *local = I.local.get<float>((size_t)I.rank_px * 4);
+    uint8_t *local8 = I.local8.get<uint8_t>((size_t)I.rank_px * 4);
+    float *split = nullptr, *sample = nullptr;  // [world][rank_px][3]: block r holds rank r's rows
+    int32_t *visited = I.visit_tracker.get<int32_t>((size_t)std::max<long>(I.max_tree_capacity, 1));
+    if (refine && options.use_splitting) {
+        split = I.split_tracker.get<float>(rows * 3);
+        sample = I.sample_tracker.get<float>(rows * 3);
+        I.fill_f32(split, rows * 3, -1.f);
+        I.fill_f32(sample, rows * 3, -1.f);
+    }
+    float *my_split = split ? split + (size_t)rank * I.rank_px * 3 : nullptr, *my_sample = sample ? sample + (size_t)rank * I.rank_px * 3 : nullptr;
+    if (I.accel_stale) {  // every frame of a rank runs on the packed layout
+        tree.rebuild_accel(I.stream);
+        I.accel_stale = false;
+    }
+    if (track_visit && !tree.device.parent) throw std::runtime_error("several ranks: visit marks need the tree's parent array");
+    stats.used_accel = true;
+    if (refine && options.use_guided_sampling) {
+        const bool fits = I.mlp_desc.hidden_width == 64 && I.fused_inputs_ok &&
+                          (tree.data_format.format != DataFormat::SH || tree.data_format.basis_dim == 1 || tree.data_format.basis_dim == 4 ||
+                           tree.data_format.basis_dim == 9 || tree.data_format.basis_dim == 16);
+        if (!fits) throw std::runtime_error("several ranks: guided sampling needs a network the fused kernel covers (64 wide, at most 64 encoded inputs)");
+        unsigned long long *counter = I.fused_counter.get<unsigned long long>(1);
+        hip_check(hipMemsetAsync(counter, 0, sizeof(unsigned long long), I.stream), "clear sample counter");
+        mnv_check(mnv_render_guided_fused_track_part(tree.device.accel, &cv, options.c_abi(), full, I.part, I.mlp, &I.grid, local, local8, my_split, my_sample,
+                                                     split ? tree.device.sample_counts : nullptr, track_visit ? visited : nullptr, tree.device.parent, counter,
+                                                     I.stream),
+                  "mnv_render_guided_fused_track_part");
+        unsigned long long n = 0;
+        hip_check(hipMemcpyAsync(&n, counter, sizeof(n), hipMemcpyDeviceToHost, I.stream), "read sample counter");
+        hip_check(hipStreamSynchronize(I.stream), "guided frame");
+        stats.fused = true;
+        stats.guided_samples = (long)n;  // this rank's share
+    } else {
+        mnv_check(mnv_render_voxels_accel_visit_part(tree.device.accel, &cv, options.c_abi(), full, I.part, local, local8, my_split, my_sample,
+                                                     tree.device.sample_counts, track_visit ? visited : nullptr, tree.device.parent, I.stream),
+                  "mnv_render_voxels_accel_visit_part");
+    }
+    // the picture: tiles to rank 0, un-permuted there
+    float *table = rank == 0 ? I.table.get<float>((size_t)rows * 4) : nullptr;
+    uint8_t *table8 = rank == 0 ? I.table8.get<uint8_t>((size_t)rows * 4) : nullptr;
+    mnv_check(mnv_gather_tiles(I.comm, local, table, (size_t)I.rank_px * 16, 0, I.stream), "mnv_gather_tiles");
+    mnv_check(mnv_gather_tiles(I.comm, local8, table8, (size_t)I.rank_px * 4, 0, I.stream), "mnv_gather_tiles");
+    if (rank == 0) {
+        mnv_check(mnv_assemble_tiles(table, I.rgba, I.width, I.height, I.part, 1, 16, I.stream), "mnv_assemble_tiles");
+        mnv_check(mnv_assemble_tiles(table8, I.rgba8, I.width, I.height, I.part, 1, 4, I.stream), "mnv_assemble_tiles");
+    }
+    // the votes need every rank's tracker rows, a prune every rank's marks
+    if (split) {
+        mnv_check(mnv_allgather(I.comm, split, (size_t)I.rank_px * 12, I.stream), "mnv_allgather");
+        mnv_check(mnv_allgather(I.comm, sample, (size_t)I.rank_px * 12, I.stream), "mnv_allgather");
+    }
+    if (track_visit && world > 1) {
+        const size_t cap = (size_t)I.max_tree_capacity;
+        int32_t *marks = I.marks_table.get<int32_t>(cap * world);
+        hip_check(hipMemcpyAsync(marks + cap * rank, visited, cap * 4, hipMemcpyDeviceToDevice, I.stream), "copy marks");
+        mnv_check(mnv_allgather(I.comm, marks, cap * 4, I.stream), "mnv_allgather");
+        mnv_check(mnv_merge_visit_marks(marks, world, (int32_t)cap, visited, I.stream), "mnv_merge_visit_marks");
+    }
+    if (refine) I.refine_after_frame(options, stats, seed, track_visit);
     ++I.frame;
     stats.capacity = tree.capacity;
 }

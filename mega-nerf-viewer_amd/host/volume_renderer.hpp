@@ -74,6 +74,18 @@ struct VolumeRenderer {
     // Copy the (refined) device tree back into the N3Tree's host arrays, e.g. before N3Tree::save_npz.
     void sync_tree();
 
+    // Several ranks, one process per GPU, render and refine ONE scene in lock step (BASELINE.json configs[4] on several GPUs; SURVEY.md
+    // 8(e): "identical deterministic refinement on every rank").  Every rank holds the whole tree and the networks.  render() then
+    //   * marches only the macro tiles of this rank (pixels, tracker rows and visit marks: mnv_render_voxels_accel_visit_part /
+    //     mnv_render_guided_fused_track_part),
+    //   * all-gathers the tracker rows (mnv_allgather) -- the votes of cuda_renderer.cpp:205-227 count candidates over the whole frame and
+    //     do not depend on the order of the rows -- and, on a visit-mark frame, the marks (mnv_merge_visit_marks),
+    //   * runs the same split / resample / prune on every rank (same candidates, same jitter seed, same network): the replicas stay
+    //     identical chunk for chunk, and equal to what one GPU makes of the same camera path,
+    //   * gathers the tiles to rank 0 (mnv_gather_tiles) and un-permutes them there: rank 0's frame is the whole picture.
+    // Needs the packed accel; guided sampling needs a network the fused kernel covers.  `comm` stays the caller's.
+    void set_ranks(mnv_comm *comm, int tile_w = 64, int tile_h = 24);
+
     // What the last render() did (the reference prints these to stdout).
     struct FrameStats {
         bool track_visit = false, used_accel = false, full = false;
@@ -98,6 +110,7 @@ struct VolumeRenderer {
     RenderOptions options;
 
 private:
+    void render_ranks();
     struct Impl;
     std::unique_ptr<Impl> impl_;
 };

@@ -3,6 +3,7 @@ include/renderer/renderer.hpp:9-39 + the CLI flags of src/opts.cpp:17-32 / main.
 end to end on the GPU: .npz -> N3Tree::open -> VolumeRenderer::set/resize/render -> files,
 compared bit for bit with the oracle."""
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -84,9 +85,9 @@ def test_mnv_render_multi_gpu_mode_with_one_rank(mnv, orc, torch_gpu, tmp_path):
         # two ranks need two GPUs: rank 1 finds no device (or RCCL refuses the duplicate), rank 0 is taken down with it
         r4 = subprocess.run(common + ["--gpus", "2"], capture_output=True, text=True, timeout=180)
         assert r4.returncode != 0 and "rank" in r4.stderr
-    # refinement mutates the tree: not combined with --gpus
-    r5 = subprocess.run(common + ["--gpus", "1", "--model_path", npz, "--use_splitting"], capture_output=True, text=True, timeout=120)
-    assert r5.returncode != 0 and "refinement" in r5.stderr
+    # refinement across ranks needs the networks (test_mnv_render_refinement_across_ranks runs it)
+    r5 = subprocess.run(common + ["--gpus", "1", "--use_splitting"], capture_output=True, text=True, timeout=120)
+    assert r5.returncode != 0 and "--model_path" in r5.stderr
 
 
 @pytest.mark.parametrize("world", [2, 3, 8])
@@ -153,6 +154,57 @@ def test_mnv_render_guided_sampling_across_ranks(mnv, torch_gpu, tmp_path, fake_
         assert a == open(f"{dist}_{f:04d}.f32", "rb").read(), f
         assert open(f"{one}_{f:04d}.ppm", "rb").read() == open(f"{dist}_{f:04d}.ppm", "rb").read(), f
         assert a != open(f"{plain}_{f:04d}.f32", "rb").read()     # the networks' colours, not the tree's
+
+
+@pytest.mark.parametrize("world,guided", [(1, False), (3, False), (3, True), (8, True)])
+def test_mnv_render_refinement_across_ranks(mnv, torch_gpu, tmp_path, fake_rccl, world, guided):
+    """`mnv_render --gpus N --use_splitting [--use_guided_sampling]` (BASELINE.json configs[4] on several GPUs): the ranks refine one scene in
+    lock step -- each marches its macro tiles (pixels, tracker rows, visit marks), the tracker rows and the marks are all-gathered, every
+    rank applies the same splits / resamples / prunes to its replica.  Checked against the single-GPU run of the same camera path: every
+    frame byte for byte, the refined tree array for array, every rank's replica equal to rank 0's, and the run includes prunes (visit
+    marks merged across ranks).  world 1 goes through RCCL itself, the others share the GPU over the transport stand-in."""
+    import mlp_cases
+    from test_renderer_refine_gpu import check_tree_links, make_grid
+
+    spec = cases.CASES["sh4_d6"]
+    tree = cases.make_tree(mnv, spec["tree"])
+    cap0, dd = tree.capacity, tree.host_view().data_dim
+    npz = str(tmp_path / "scene.npz")
+    tree.save_npz(npz)
+    desc = mnv.mlp_desc(n_clusters=6, pos_octaves=4, hidden_width=64, hidden_layers=2, out_dim=dd + 1)
+    g = make_grid(mnv)
+    model = str(tmp_path / "model.npz")
+    np.savez(model, mlp_desc=np.array([6, 4, 2, 0, 0, 0, 64, 2, dd + 1], np.int32), mlp_center=np.zeros(3, np.float32),
+             mlp_inv_extent=np.ones(3, np.float32), mlp_params=mlp_cases.make_params(mnv, desc, seed=21), grid_dim=np.array(list(g.grid_dim), np.int64),
+             min_position=np.array(list(g.min_position), np.float32), max_position=np.array([g.min_position[i] + g.range[i] for i in range(3)], np.float32))
+    w, h, frames = 328, 200, 14
+    common = [EXE, npz, "-w", str(w), "-h", str(h), "--fx", "700", "--bg", "1.0", "--center", "-3.55,0,3.55", "--model_path", model, "--use_splitting",
+              "-x", "64", "-v", "4", "--max_depth", "8", "--max_sample_count", "64", "--seed", "5", "-c", str(cap0 + 330), "--frames", str(frames),
+              "--orbit", "4", "--raw"] + (["--use_guided_sampling", "-z", "24"] if guided else [])
+    one, dist = str(tmp_path / "one"), str(tmp_path / "dist")
+    r1 = subprocess.run(common + ["--out", one, "--save_tree", one + ".npz"], capture_output=True, text=True, timeout=600)
+    assert r1.returncode == 0, r1.stderr + r1.stdout
+    assert "added" in r1.stdout and "pruned" in r1.stdout, r1.stdout   # the path grows the tree until it is full, then prunes
+    env = dict(os.environ, MNV_SAVE_EVERY_RANK="1")
+    if world > 1:
+        env.update(MNV_RCCL_LIBRARY=fake_rccl, MNV_RANKS_SHARE_GPU="1")
+    r2 = subprocess.run(common + ["--out", dist, "--save_tree", dist + ".npz", "--gpus", str(world)], capture_output=True, text=True, timeout=900, env=env)
+    assert r2.returncode == 0, r2.stderr + r2.stdout
+    # the same decisions frame by frame (candidates, splits, resamples, prunes, capacities)
+    strip = lambda out: [re.sub(r"  guided samples \d+", "", ln) for ln in out.splitlines() if ln.startswith("frame ")]
+    assert strip(r1.stdout) == strip(r2.stdout)
+    for f in range(frames):
+        assert open(f"{one}_{f:04d}.f32", "rb").read() == open(f"{dist}_{f:04d}.f32", "rb").read(), f
+        assert open(f"{one}_{f:04d}.ppm", "rb").read() == open(f"{dist}_{f:04d}.ppm", "rb").read(), f
+    ta, tb = mnv.N3Tree.open(one + ".npz"), mnv.N3Tree.open(dist + ".npz")
+    assert ta.capacity == tb.capacity and ta.capacity != cap0
+    for a, b in zip(ta.host_arrays(), tb.host_arrays()):
+        assert np.array_equal(a, b)
+    check_tree_links(tb.host_arrays()[1], tb.host_arrays()[2], tb.capacity)
+    for r in range(1, world):
+        tr = mnv.N3Tree.open(f"{dist}.npz.rank{r}.npz")
+        for a, b in zip(tr.host_arrays(), tb.host_arrays()):
+            assert np.array_equal(a, b)
 
 
 def test_mnv_render_cli_errors(tmp_path, mnv, torch_gpu):

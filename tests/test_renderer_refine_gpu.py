@@ -269,6 +269,35 @@ def test_prune_runs_inside_the_loop(mnv, torch_gpu):
     assert _accel_equals_reference_layout(mnv, torch_gpu, tree, cam_spec, "sh4_d6")
 
 
+@pytest.mark.parametrize("guided", [False, True])
+def test_rank_mode_of_the_renderer_equals_the_plain_one(mnv, torch_gpu, guided):
+    """Renderer.set_ranks with a one-rank communicator (RCCL itself: this is what a one-GPU box can run of it): partitioned tracker march,
+    tile gather to the root, un-permute, all-gather of the tracker rows -- the frames, the per-frame decisions and the refined tree equal
+    the plain renderer's over a run with splits and a prune.  Several ranks: tests/test_cli_gpu.py (transport stand-in)."""
+    kw = dict(use_splitting=True, max_depth=8, split_batch_size=700, samples_per_corner=2, max_sample_count=24)
+    if guided:
+        kw.update(use_guided_sampling=True, max_guided_samples=24)
+    runs = []
+    for ranks in (False, True):
+        r, tree, desc, params, cam_spec = setup(mnv, "sh4_d6", 600, **kw)
+        if ranks:
+            r.set_ranks(mnv.Comm(mnv.comm_get_unique_id(), 1, 0), 64, 24)
+        log, frames = [], []
+        for _ in range(5):
+            st = r.render()
+            log.append({k: st[k] for k in ("track_visit", "split_candidates", "added", "sample_candidates", "resampled", "pruned", "capacity")})
+            frames.append(r.download().copy())
+        r.sync_tree()
+        runs.append((log, frames, [a.copy() for a in tree.host_arrays()]))
+        if ranks:
+            r.set_ranks(None)
+    assert runs[0][0] == runs[1][0] and any(st["pruned"] > 0 for st in runs[0][0]) and any(st["added"] > 0 for st in runs[0][0])
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    for a, b in zip(runs[0][2], runs[1][2]):
+        assert np.array_equal(a, b)
+
+
 def test_prune_on_the_first_frame_when_the_tree_is_nearly_full(mnv, orc, torch_gpu):
     """capacity > 3/4 max and a changed camera: the first frame marks visits (cuda_renderer.cpp:101-102) and prunes right
     after its split step; the picture of that frame is the unpruned tree's."""
