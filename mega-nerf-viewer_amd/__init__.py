@@ -599,10 +599,19 @@ def render_voxels_accel_track(accel: int, cam: Camera, opt: RenderOptions, tile=
 
 
 def render_voxels_accel_visit(accel: int, cam: Camera, opt: RenderOptions, visited, parent, tile=None, rgba=None, rgba8=None, split_track=None,
-                              sample_track=None, sample_counts=None, stream: int = 0) -> None:
-    """Tracker march on the packed accel that also leaves the reference's visit marks (march marks leaf chunks, closure adds ancestors)."""
+                              sample_track=None, sample_counts=None, stream: int = 0, part=None) -> None:
+    """Tracker march on the packed accel that also leaves the reference's visit marks (march marks leaf chunks, closure adds ancestors).
+    part = (rank, world, tile_w, tile_h[, root_period]): only that rank's macro tiles, pixels and tracker rows in compact tile order."""
     if tile is None:
         tile = (0, 0, cam.width, cam.height)
+    if part is not None:
+        px = _pixels(tile, 1, part)
+        _check_out("rgba", rgba, px, "f32")
+        _check_out("rgba8", rgba8, px, "u8")
+        _check(lib().mnv_render_voxels_accel_visit_part(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), Partition(*part), _ptr(rgba), _ptr(rgba8),
+                                                        _ptr(split_track), _ptr(sample_track), _ptr(sample_counts), _ptr(visited), _ptr(parent),
+                                                        C.c_void_p(stream)))
+        return
     _check(lib().mnv_render_voxels_accel_visit(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba), _ptr(rgba8), _ptr(split_track),
                                                _ptr(sample_track), _ptr(sample_counts), _ptr(visited), _ptr(parent), C.c_void_p(stream)))
 
@@ -696,13 +705,20 @@ def render_guided_fused(accel: int, cam: Camera, opt: RenderOptions, mlp: "Mlp",
 
 
 def render_guided_fused_part(accel: int, cam: Camera, opt: RenderOptions, mlp: "Mlp", grid: ClusterGrid, part, tile=None, rgba=None, rgba8=None,
-                             sample_counter=None, stream: int = 0) -> None:
-    """One rank's macro tiles of the fused guided-sampling frame (part = (rank, world, tile_w, tile_h[, root_period]))."""
+                             sample_counter=None, stream: int = 0, split_track=None, sample_track=None, sample_counts=None, visited=None,
+                             parent=None) -> None:
+    """One rank's macro tiles of the fused guided-sampling frame (part = (rank, world, tile_w, tile_h[, root_period])); with trackers /
+    visit marks: mnv_render_guided_fused_track_part (rows in the compact tile order of the pixels)."""
     if tile is None:
         tile = (0, 0, cam.width, cam.height)
     px = _pixels(tile, 1, part)
     _check_out("rgba", rgba, px, "f32")
     _check_out("rgba8", rgba8, px, "u8")
+    if split_track is not None or sample_track is not None or visited is not None:
+        _check(lib().mnv_render_guided_fused_track_part(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), Partition(*part), mlp._h, C.byref(grid),
+                                                        _ptr(rgba), _ptr(rgba8), _ptr(split_track), _ptr(sample_track), _ptr(sample_counts), _ptr(visited),
+                                                        _ptr(parent), _ptr(sample_counter), C.c_void_p(stream)))
+        return
     _check(lib().mnv_render_guided_fused_part(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), Partition(*part), mlp._h, C.byref(grid),
                                               _ptr(rgba), _ptr(rgba8), _ptr(sample_counter), C.c_void_p(stream)))
 
