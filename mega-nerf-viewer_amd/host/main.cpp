@@ -20,8 +20,9 @@
 //                    un-permuted there (mnv_assemble_tiles); rank 0 writes the frames.  --gpus 1 runs the same path with one
 //                    rank.  --reserve_cus R (default 32 when N > 1) keeps R compute units free for the RCCL kernels.
 //                    With --model_path + --use_guided_sampling every rank runs the fused guided-sampling kernel on its tiles
-//                    (mnv_render_guided_fused_part: the networks read the tree only).  Not combined with --use_splitting
-//                    (refinement mutates the tree).
+//                    (mnv_render_guided_fused_part: the networks read the tree only).  With --use_splitting the ranks refine the
+//                    scene in lock step, one frame at a time (VolumeRenderer::set_ranks: tracker rows and visit marks are
+//                    all-gathered, every rank applies the same tree edits to its replica).
 //   --in_flight K    plain frames in flight (default 3; VolumeRenderer::frames_in_flight): frame k is downloaded and written
 //                    after frames k+1 .. k+K-1 have been issued
 #include <hip/hip_runtime_api.h>
