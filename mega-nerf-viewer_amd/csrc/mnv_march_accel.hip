@@ -1537,6 +1537,9 @@ static int render_accel(const mnv_accel *accel, const mnv_camera *cams, int32_t 
     std::memset(&P, 0, sizeof(P));
     int rc = fill_params(P, &cams[0], opt, tile);
     if (rc) return rc;
+    // pixel indices of a launch are 32 bits wide (frame f starts at f * pixels per frame)
+    if ((uint64_t)(tile.w > 0 ? tile.w : 0) * (uint64_t)(tile.h > 0 ? tile.h : 0) * (uint64_t)n_cams > 0xffffffffull)
+        return set_error(MNV_E_UNSUPPORTED, "more than 2^32 pixels in one launch: render fewer frames per call");
     std::memcpy(P.offset, accel->view.offset, sizeof(P.offset));
     std::memcpy(P.scale, accel->view.scale, sizeof(P.scale));
     P.rgba = rgba_out;

@@ -241,6 +241,12 @@ def test_invalid_arguments_report_errors(mnv, torch_gpu):
     with pytest.raises(mnv.MnvError) as e:
         mnv.render_voxels(v, cam, opt, rgba=None)
     assert e.value.code == mnv.MNV_E_INVALID
+    # the tuned kernel numbers the pixels of a launch with 32 bits: a rectangle beyond that is refused, not wrapped
+    import ctypes as C
+    tree = cases.make_tree(mnv, cases.CASES["rgba_d5"]["tree"])
+    tree.move_to_device()
+    rc = mnv.lib().mnv_render_voxels_accel(C.c_void_p(tree.accel), C.byref(cam.c), C.byref(opt), mnv.Rect(0, 0, 70000, 70000), None, None, None)
+    assert rc == mnv.MNV_E_UNSUPPORTED and "2^32" in mnv.lib().mnv_last_error().decode()
 
 
 @pytest.fixture(scope="module")
