@@ -387,6 +387,13 @@ __device__ __forceinline__ bool ray_pixel(const AccelLaunch &K, uint32_t id, int
     return bx < K.P.tw && by < K.P.th;
 }
 
+__device__ __forceinline__ float lane_read(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ uint32_t lane_read(uint32_t v, int src_lane) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
+
 // bytes of one colour channel block of a packed row: basis_dim halfs padded to a whole dword
 __host__ __device__ constexpr int chan_bytes_for(int basis) { return basis > 0 ? ((2 * basis + 3) / 4) * 4 : 4; }
 // bytes of a packed row: three channel blocks rounded up to a power of two (16 ... 256), so that a
@@ -441,8 +448,10 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
     };
     // per-lane ray constants that only the dense-sample / finish code needs live in LDS, not in VGPRs:
     // [k][thread] for k < NB: SH basis; then delta_scale and the output pixel index
-    float *s_ray = reinterpret_cast<float *>(s_mem + 64);
-    uint32_t *s_grid = s_mem + 64 + (NB + 2) * BLOCK;  // (2^lds_level)^3 words
+    constexpr int MAPW = BASIS >= 16 ? BLOCK : 0;        // cooperative colour pass (SH16 / SH25 only): dense-sample rank -> lane, per wavefront
+    uint32_t *s_map = s_mem + 64;
+    float *s_ray = reinterpret_cast<float *>(s_mem + 64 + MAPW);
+    uint32_t *s_grid = s_mem + 64 + MAPW + (NB + 2) * BLOCK;  // (2^lds_level)^3 words
     constexpr int CHAN_BYTES = chan_bytes_for(BASIS);
     constexpr int ROW_BYTES = row_bytes_pow2(BASIS);
     const FrameParams &P = K.P;
@@ -479,6 +488,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
     const int sh2 = Lq - L2;
     const int shg = Lq - A.grid_level;
     float *my_ray = s_ray + threadIdx.x;             // [k * BLOCK]
+    float *wave_ray = s_ray + (threadIdx.x & ~63);  // [k * BLOCK + lane]
 
     // per-lane ray state
     float t = 0.f, T = 1.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
@@ -825,6 +835,59 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
             } else if (depth_mode()) {
                 if (dense) o0 += weight * t;
             } else if (ablate(1)) {
+            } else if constexpr (BASIS >= 16) {
+                // SH16 / SH25 (a row is 96 / 150 bytes: per-lane rows would need 24 / 39 registers and spill -- 6234 against 8687 Mrays/s for
+                // SH16, 2453 against 4062 for SH25): the wavefront evaluates the samples cooperatively, one lane per (sample, channel):
+                // 21 samples x 3 channels per pass.  Each task lane pulls the sample's weight, voxel and
+                // SH basis from the owning lane (ds_bpermute), loads its channel's coefficients, and
+                // returns weight / (1 + exp(-dot)) to the owner, which accumulates in sample order.
+                const int n_dense = __popcll(dense_mask);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(dense_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dense_mask, 0u));
+                uint32_t *map = s_map + (threadIdx.x & ~63);
+                if (dense) map[rank] = (uint32_t)lane;
+                __builtin_amdgcn_wave_barrier();
+                const int my_s = lane / 3, my_c = lane - 3 * my_s;
+                for (int base = 0; base < n_dense; base += 21) {
+                    const int smp = base + my_s;
+                    const bool task = my_s < 21 && smp < n_dense;
+                    stat(10, task);  // colour passes and their busy task lanes
+                    const int owner = task ? (int)map[smp] : lane;
+                    const float w = lane_read(weight, owner);
+                    uint32_t vx = lane_read(vox, owner);
+                    if (ablate(4)) vx &= 0xffffu;  // diagnostics: rows served from cache (wrong colours)
+                    float b[NB];
+#pragma unroll
+                    for (int k = 0; k < NB; ++k) b[k] = wave_ray[k * BLOCK + owner];  // the owner's SH basis, from LDS
+                    float v = 0.f;
+                    if (task) {
+                        constexpr int NW = CHAN_BYTES / 4;
+                        ChanWords<NW> cw;
+                        cw = *reinterpret_cast<const ChanWords<NW> *>(A.rows + (int64_t)vx * ROW_BYTES + my_c * CHAN_BYTES);
+                        auto coef = [&](int k) -> float {
+                            const uint32_t wd = cw.w[k >> 1];
+                            return half_bits_to_float((uint16_t)((k & 1) ? (wd >> 16) : (wd & 0xffffu)));
+                        };
+                        const float tmp = sh_channel<BASIS>(b, coef, 0);
+                        if constexpr (MODE == 4) {
+                            // colour-only arithmetic: it feeds no branch (opacity, transmittance and the step sequence stay exact),
+                            // so hardware exp2 / rcp (about 1 ulp each) move a colour by ~1e-7 and nothing else
+                            const float e = __builtin_amdgcn_exp2f(tmp * -1.44269504088896341f);
+                            v = w * __builtin_amdgcn_rcpf(1.f + e);
+                        } else {
+                            v = w / (1.f + exact_expf(-tmp, s_exp));
+                        }
+                    }
+                    const int rl = rank - base;
+                    const bool mine = dense && rl >= 0 && rl < 21;
+                    const int from = mine ? 3 * rl : lane;
+                    const float v0 = lane_read(v, from), v1 = lane_read(v, mine ? from + 1 : lane), v2 = lane_read(v, mine ? from + 2 : lane);
+                    if (mine) {
+                        o0 += v0;
+                        o1 += v1;
+                        o2 += v2;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             } else if constexpr (BASIS >= 1) {
                 // SH: every dense lane reads its sample's row (three channel blocks of one 64-byte row: one line fill) and evaluates the
                 // three channels itself, so all rows of an iteration are requested at once.  (Until round 2 the wavefront shared the work,
@@ -1121,7 +1184,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     // sample emission and the depth image read no colour rows: one instantiation (BASIS 9) serves every row format
     const bool colourless = K.samples != nullptr || (P.render_depth && !K.split_track && !K.sample_track && !K.visited);
     const int nb_lds = colourless ? 9 : (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim > 0) ? accel->view.basis_dim : 1;
-    const size_t lds_bytes = 256 + (size_t)(nb_lds + 2) * 256 * 4 + ((size_t)4 << (3 * lds_level));
+    const size_t lds_bytes = 256 + (nb_lds >= 16 ? 1024 : 0) + (size_t)(nb_lds + 2) * 256 * 4 + ((size_t)4 << (3 * lds_level));
     static const int env_bpc = getenv("MNV_BLOCKS_PER_CU") ? atoi(getenv("MNV_BLOCKS_PER_CU")) : 0;
     static const int env_refill = getenv("MNV_REFILL_MIN") ? atoi(getenv("MNV_REFILL_MIN")) : 0;
     static const int env_ablate = getenv("MNV_ABLATE") ? atoi(getenv("MNV_ABLATE")) : 0;
