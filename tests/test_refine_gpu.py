@@ -142,6 +142,37 @@ def test_selection_full_frame_against_oracle(mnv, torch_gpu):
     assert mnv.select_split_candidates(d_track, 0, None) == (0, ro.select_split_candidates(track, 0)[1])
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_selection_does_not_depend_on_the_order_of_the_tracker_rows(mnv, torch_gpu, seed):
+    """What refinement on several ranks rests on (VolumeRenderer::set_ranks): every rank votes on the all-gathered tracker rows, which
+    arrive rank by rank in compact tile order with -1 rows where a ragged partition left tiles out -- another order and another length
+    than the one-GPU frame.  The vote counts candidates (sort, run-length encode, stable sort by count with ties in key order), so any
+    permutation of the rows, with any number of empty rows added, selects the same nodes in the same order."""
+    torch = torch_gpu
+    rng = np.random.default_rng(100 + seed)
+    n = 200_000
+    chunk = (rng.zipf(1.25, n) % 30_000).astype(np.int64)
+    track = np.stack([(1 + chunk % 7).astype(np.float32), chunk.astype(np.float32), (chunk * 3 % 8).astype(np.float32)], 1)
+    track[rng.random(n) < 0.5] = (-1.0, -1.0, -1.0)
+    k = 5000
+    outs = []
+    for variant in range(3):
+        t = track if variant == 0 else track[rng.permutation(n)]
+        if variant == 2:
+            pad = np.full((12_345, 3), -1.0, np.float32)
+            t = np.concatenate([t[: n // 3], pad, t[n // 3:]])
+        d = torch.from_numpy(np.ascontiguousarray(t)).cuda()
+        nodes = torch.full((k, 2), -9, dtype=torch.int32, device="cuda")
+        res = [mnv.select_split_candidates(d, k, nodes), nodes.cpu().numpy().copy()]
+        nodes.fill_(-9)
+        res += [mnv.select_sample_candidates(d, k, nodes), nodes.cpu().numpy().copy()]
+        outs.append(res)
+    assert outs[0][0][0] > 100 and outs[0][2][0] > 100
+    for o in outs[1:]:
+        assert o[0] == outs[0][0] and o[2] == outs[0][2]
+        assert np.array_equal(o[1], outs[0][1]) and np.array_equal(o[3], outs[0][3])
+
+
 def test_apply_split_and_sample_results(mnv, torch_gpu):
     torch = torch_gpu
     z = np.load(os.path.join(GOLD, "refine_split_mean.npz"))
