@@ -207,3 +207,83 @@ def test_cfg5_refinement_and_guided_sampling_together_at_scale(mnv, torch_gpu):
     mnv.render_voxels_accel(tree.accel, cam, opt, rgba=b)
     torch.cuda.synchronize()
     assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
+def _cfg5_rank(rank, world, lib, idq, resq):
+    """One rank of test_cfg5_on_several_ranks_at_scale (the ranks share cuda:0; the transport is tests/shim/fake_rccl.cpp)."""
+    import hashlib
+    import os
+    import sys
+    import traceback
+
+    try:
+        if world > 1:
+            os.environ["MNV_RCCL_LIBRARY"] = lib
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for p in (root, os.path.join(root, "tests"), os.path.join(root, "oracle")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import torch
+
+        import mega_nerf_viewer_amd as mnv
+        import test_scale_gpu as me
+
+        torch.cuda.set_device(0)
+        r, tree, desc, params = me._renderer_on_cfg2(mnv, 1_000_000, use_splitting=True, use_guided_sampling=True, max_depth=12, split_batch_size=4096,
+                                                     samples_per_corner=8, max_guided_samples=32)
+        if world > 1:
+            if rank == 0:
+                uid = mnv.comm_get_unique_id()
+                for _ in range(world - 1):
+                    idq.put(uid)
+            else:
+                uid = idq.get(timeout=300)
+            r.set_ranks(mnv.Comm(uid, world, rank), 64, 24)
+        log, digest = [], hashlib.sha256()
+        for f in range(3):
+            me._pose(mnv, r, f)
+            st = r.render()
+            log.append((st["split_candidates"], st["added"], st["capacity"], st["fused"]))
+            if rank == 0:
+                digest.update(r.download().tobytes())
+        r.sync_tree()
+        for a in tree.host_arrays():
+            digest.update(np.ascontiguousarray(a).tobytes())
+        if world > 1:
+            r.set_ranks(None)
+        resq.put(("ok", rank, log, digest.hexdigest()))
+    except Exception:  # noqa: BLE001
+        resq.put(("error", rank, traceback.format_exc(), ""))
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_cfg5_on_several_ranks_at_scale(mnv, torch_gpu, fake_rccl, world):
+    """BASELINE.json configs[4] -- refinement and guided sampling both on -- at its stated size on several ranks (processes sharing this
+    GPU over the transport stand-in): 1.5 M-chunk tree, 1920x1080, three frames of 4096 splits each through Renderer.set_ranks.  Rank 0's
+    frames and refined tree hash to what one rank produces; the other ranks (their frames stay partial) take the same decisions."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+
+    def run(world):
+        idq, resq = ctx.Queue(), ctx.Queue()
+        procs = [ctx.Process(target=_cfg5_rank, args=(r, world, fake_rccl, idq, resq)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out = {}
+        try:
+            for _ in range(world):
+                kind, rank, log, dig = resq.get(timeout=900)
+                assert kind == "ok", log
+                out[rank] = (log, dig)
+        finally:
+            for p in procs:
+                p.join(timeout=120)
+                if p.is_alive():
+                    p.kill()   # exactly the processes started above
+        return out
+
+    one, many = run(1), run(world)
+    assert all(c > 0 and 0 < a <= 4096 and fused == 1 for c, a, _, fused in one[0][0])
+    assert all(many[r][0] == one[0][0] for r in range(world))
+    assert many[0][1] == one[0][1]
