@@ -172,7 +172,14 @@ void write_frame(const std::string &out, long f, int width, int height, const ui
     std::snprintf(name, sizeof(name), "%s_%04ld.ppm", out.c_str(), f);
     if (std::FILE *fp = std::fopen(name, "wb")) {
         std::fprintf(fp, "P6\n%d %d\n255\n", width, height);
-        for (size_t p = 0; p < (size_t)width * height; ++p) std::fwrite(&rgba8[p * 4], 1, 3, fp);
+        static thread_local std::vector<uint8_t> rgb;
+        rgb.resize((size_t)width * height * 3);
+        for (size_t p = 0; p < (size_t)width * height; ++p) {
+            rgb[p * 3 + 0] = rgba8[p * 4 + 0];
+            rgb[p * 3 + 1] = rgba8[p * 4 + 1];
+            rgb[p * 3 + 2] = rgba8[p * 4 + 2];
+        }
+        std::fwrite(rgb.data(), 1, rgb.size(), fp);
         std::fclose(fp);
     } else {
         throw std::runtime_error(std::string("cannot write ") + name);
