@@ -183,7 +183,7 @@ def main():
     ap.add_argument("--gather-via", choices=["abi", "torch"], default="abi",
                     help="N > 1: abi = mnv_gather_tiles (libmnv's own RCCL gather, the product path); torch = torch.distributed's gather "
                          "(the launcher's second attempt if the first one fails or wedges)")
-    ap.add_argument("--launch-timeout", type=float, default=420.0, help="--gpus N > 1 without a launcher: watchdog for the ranks this process starts (s)")
+    ap.add_argument("--launch-timeout", type=float, default=600.0, help="--gpus N > 1 without a launcher: watchdog for the ranks this process starts (s)")
     ap.add_argument("--laps", type=int, default=4, help="the step walks the 16-pose orbit this many times (16 x laps frames in one launch, <= 64)")
     args = ap.parse_args()
     global W, H, N_FRAMES
