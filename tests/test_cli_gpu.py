@@ -177,7 +177,7 @@ def test_mnv_render_refinement_across_ranks(mnv, torch_gpu, tmp_path, fake_rccl,
     np.savez(model, mlp_desc=np.array([6, 4, 2, 0, 0, 0, 64, 2, dd + 1], np.int32), mlp_center=np.zeros(3, np.float32),
              mlp_inv_extent=np.ones(3, np.float32), mlp_params=mlp_cases.make_params(mnv, desc, seed=21), grid_dim=np.array(list(g.grid_dim), np.int64),
              min_position=np.array(list(g.min_position), np.float32), max_position=np.array([g.min_position[i] + g.range[i] for i in range(3)], np.float32))
-    w, h, frames = 328, 200, 14
+    w, h, frames = 328, 200, int(os.environ.get("MNV_SOAK_FRAMES", "14"))   # MNV_SOAK_FRAMES: longer runs by hand
     common = [EXE, npz, "-w", str(w), "-h", str(h), "--fx", "700", "--bg", "1.0", "--center", "-3.55,0,3.55", "--model_path", model, "--use_splitting",
               "-x", "64", "-v", "4", "--max_depth", "8", "--max_sample_count", "64", "--seed", "5", "-c", str(cap0 + 330), "--frames", str(frames),
               "--orbit", "4", "--raw"] + (["--use_guided_sampling", "-z", "24"] if guided else [])
