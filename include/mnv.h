@@ -517,11 +517,23 @@ int mnv_query_submodules(mnv_mlp *mlp, const int16_t *cluster_indices, const flo
  * mnv_query_submodules -> mnv_render_nerf_results (same march, same MFMA sequence, same composite arithmetic).
  * Restrictions (MNV_E_UNSUPPORTED otherwise; use the four-step path): 64-wide networks with at most 64 encoded inputs,
  * RGBA / SH1/4/9/16 trees, no render_depth.  Refinement trackers and visit marks: mnv_render_guided_fused_track.
- *   sample_counter  optional device counter: += network evaluations (= what the four-step path reports as guided samples)
+ *   sample_counter  optional device counter, ONE word: += network evaluations (= what the four-step path reports as guided samples)
+ * Two kernels serve these entry points (csrc/mnv_guided_fused2.h, csrc/mnv_guided_fused.h), same frames bit for bit: when the weights
+ * of one sub-module fit a workgroup's LDS beside the sample rings (every 64-wide network of up to about 6 layers), a workgroup
+ * is three wavefronts that only march and push their samples into rings in LDS plus one wavefront that only evaluates the
+ * network -- weights resident in LDS, results handed back through the rings, the owning lanes composite; otherwise every
+ * wavefront does both jobs in turn (weights from L2).  mnv_set_fused_kernel selects one explicitly.
  */
 int mnv_render_guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, const mnv_mlp *mlp,
                             const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, unsigned long long *sample_counter,
                             void *hip_stream);
+/* Which kernel the mnv_render_guided_fused* entry points launch (process-wide): 0 = choose by the network's size (default),
+ * 1 = the one-role kernel (every wavefront marches and evaluates), 2 = producer / consumer wavefronts (MNV_E_UNSUPPORTED at the
+ * launch when the weights do not fit). */
+void mnv_set_fused_kernel(int version);
+/* Diagnostics of the fused kernels (process-wide): `words32` = NULL (default, none) or a device buffer of 32 64-bit words the
+ * kernels add run counts and per-phase times to (tools/guided_bench.py names them).  Costs a few per cent while set. */
+void mnv_set_fused_diag(unsigned long long *words32);
 /* The same frame when refinement is on as well (BASELINE.json configs[4] has both switches on: cuda_renderer.cpp:107-156): the fused
  * kernel also writes the refinement trackers (rows pre-filled with -1 by the caller, as cuda_renderer.cpp:97-98) and, with `visited` +
  * `parent`, the visit marks -- what get_samples_from_voxels produces besides the samples (rt_core.cuh:475-507,561-574).  A ray that

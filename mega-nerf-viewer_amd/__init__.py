@@ -202,6 +202,8 @@ _SIGNATURES = {
     "mnv_render_voxels_accel_part": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, Partition,
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_set_colour_math": (None, [C.c_int]),
+    "mnv_set_fused_kernel": (None, [C.c_int]),
+    "mnv_set_fused_diag": (None, [C.c_void_p]),
     "mnv_set_ref_table_min_rays": (None, [C.c_int64]),
     "mnv_assemble_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, Partition, C.c_int32, C.c_int32, C.c_void_p]),
     "mnv_comm_get_unique_id": (C.c_int, [C.c_void_p]),
@@ -628,6 +630,18 @@ def get_samples_from_voxels_accel_visit(accel: int, cam: Camera, opt: RenderOpti
 def set_colour_math(fast: bool) -> None:
     """False (default): bit-identical to the oracle.  True: hardware exp2 / rcp in the colour sigmoid (colours move ~1e-7)."""
     lib().mnv_set_colour_math(int(bool(fast)))
+
+
+def set_fused_kernel(version: int) -> None:
+    """Kernel behind render_guided_fused*: 0 = by network size (default), 1 = one-role wavefronts, 2 = producer / consumer wavefronts."""
+    lib().mnv_set_fused_kernel(int(version))
+
+
+def set_fused_diag(words32=None) -> None:
+    """Diagnostics buffer of the fused kernels: a device int64 tensor of at least 32 words, or None (default: no diagnostics)."""
+    if words32 is not None and words32.numel() < 32:
+        raise ValueError("the diagnostics buffer holds 32 words")
+    lib().mnv_set_fused_diag(_ptr(words32))
 
 
 def set_ref_table_min_rays(min_rays: int) -> None:

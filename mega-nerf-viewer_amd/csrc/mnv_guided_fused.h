@@ -40,8 +40,9 @@ struct FusedGuided {
     float min_position[3], range[3];
     int32_t max_guided_samples, appearance_embedding;
     int32_t batch_min;           // run the network once this many samples wait in a wavefront's pool (1 .. 64)
-    unsigned long long *sample_counter;  // += samples evaluated (one atomic per wavefront)
-    int32_t diag;                        // MNV_FUSED_DIAG: sample_counter[1] += network passes, [2] += march iterations
+    unsigned long long *sample_counter;  // += samples evaluated (one atomic per wavefront); ONE word
+    unsigned long long *diag;            // diagnostics (mnv_set_fused_diag, 32 words of the caller's): NULL = none
+    int32_t switch_min;                  // guided_fused2_kernel: columns a sub-module needs in a run to take over the weight copy in LDS
 };
 
 // Columns per network run: W = 16 * MNV_FUSED_NT samples; 64 / W lanes share a column in the per-column phases (encode, evaluation).
@@ -619,18 +620,18 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
         if (lane == 0 && tot) atomicAdd(F.sample_counter, (unsigned long long)tot);
-        if (F.diag && lane == 0) {  // diagnostics: network passes and march iterations of this wavefront
-            atomicAdd(F.sample_counter + 1, (unsigned long long)n_batches);
-            atomicAdd(F.sample_counter + 2, (unsigned long long)n_steps);
-            atomicAdd(F.sample_counter + 3, (unsigned long long)n_cut);
-            atomicAdd(F.sample_counter + 4, (unsigned long long)n_drain);
-            atomicAdd(F.sample_counter + 5, t_net);
-            atomicAdd(F.sample_counter + 6, wall_clock64() - t_all);
-            atomicAdd(F.sample_counter + 7, t_enc);
-            atomicAdd(F.sample_counter + 8, t_hid);
-            atomicAdd(F.sample_counter + 9, t_eval);
-            atomicAdd(F.sample_counter + 10, t_apply);
-        }
+    }
+    if (F.diag && lane == 0) {  // diagnostics buffer of mnv_set_fused_diag (32 words): network passes, march iterations, phase times
+        atomicAdd(F.diag + 1, (unsigned long long)n_batches);
+        atomicAdd(F.diag + 2, (unsigned long long)n_steps);
+        atomicAdd(F.diag + 3, (unsigned long long)n_cut);
+        atomicAdd(F.diag + 4, (unsigned long long)n_drain);
+        atomicAdd(F.diag + 5, t_net);
+        atomicAdd(F.diag + 6, wall_clock64() - t_all);
+        atomicAdd(F.diag + 7, t_enc);
+        atomicAdd(F.diag + 8, t_hid);
+        atomicAdd(F.diag + 9, t_eval);
+        atomicAdd(F.diag + 10, t_apply);
     }
 }
 

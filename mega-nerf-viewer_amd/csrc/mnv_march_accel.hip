@@ -970,7 +970,8 @@ __global__ void assemble_tiles_kernel(const PIXEL *__restrict__ gathered, PIXEL 
 
 }  // namespace mnv
 
-#include "mnv_guided_fused.h"  // guided_fused_kernel: march + per-sample network + composite in one kernel
+#include "mnv_guided_fused.h"   // guided_fused_kernel: march + per-sample network + composite in one kernel, every wavefront both roles
+#include "mnv_guided_fused2.h"  // guided_fused2_kernel: the same frame with producer (march) and consumer (network) wavefronts
 
 namespace mnv {
 
@@ -980,6 +981,9 @@ static int row_bytes_for(int basis) { return row_bytes_pow2(basis); }
 
 // mnv_set_colour_math: 0 = exact (bit-identical to the oracle, default), 1 = hardware exp2 / rcp in the colour sigmoid
 static std::atomic<int> g_fast_colour{0};
+// mnv_set_fused_kernel / mnv_set_fused_diag
+static std::atomic<int> g_fused_kernel{0};
+static std::atomic<unsigned long long *> g_fused_diag{nullptr};
 
 template <int BASIS, int MODE>
 static int launch_variant2(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
@@ -1222,9 +1226,46 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     int rc = kUnsupportedBasis;
     const int b = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim >= 0) ? accel->view.basis_dim : -1;
     if (track && track->fused) {
-        // the fused guided-sampling frame: 3 workgroups per CU (LDS: network tiles), one 8x8 tile per wavefront at a time
         const FusedGuided &F = *track->fused;
         const int nb = b > 0 ? b : 1;
+        const bool two = F.S.nkk0 == 2;  // mnv_render_guided_fused admits 1 and 2
+        const bool trk = K.split_track || K.sample_track || K.visited;
+        // producer / consumer wavefronts when one sub-module's weights fit a workgroup's LDS beside the rings (at least two workgroups per CU)
+        const size_t f2_bytes = (size_t)f2_layout(nb, lds_level, F.S).total * 4;
+        const int version = g_fused_kernel.load(std::memory_order_relaxed);
+        const bool fits2 = f2_bytes <= 80 * 1024;
+        if (version == 2 && !fits2) return set_error(MNV_E_UNSUPPORTED, "the network's weights do not fit a workgroup's LDS: use the one-role kernel");
+        if (version == 2 || (version == 0 && fits2 && kF2Default)) {
+            int per_cu = (int)((size_t)160 * 1024 / f2_bytes);
+            const int by_regs = (4 * kF2WavesPerSimd) / (kF2NP + 1);
+            if (per_cu > by_regs) per_cu = by_regs;
+            static const int env_f2 = getenv("MNV_F2_BLOCKS_PER_CU") ? atoi(getenv("MNV_F2_BLOCKS_PER_CU")) : 0;
+            if (env_f2 > 0 && env_f2 < per_cu) per_cu = env_f2;
+            int fb = accel->num_cus * per_cu;
+            if ((uint64_t)fb * kF2NP > n_waves_needed) fb = (int)((n_waves_needed + kF2NP - 1) / kF2NP);
+            if (fb < 1) fb = 1;
+            auto go2 = [&](auto kern) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)f2_bytes);
+                if (e != hipSuccess) return (int)e;
+                hipLaunchKernelGGL(kern, dim3(fb), dim3(kF2Block), f2_bytes, stream, K, F);
+                return (int)hipGetLastError();
+            };
+#define MNV_FUSED2_CASE(B)                                                                                        \
+    case B:                                                                                                       \
+        rc = trk ? (two ? go2(guided_fused2_kernel<B, 2, true>) : go2(guided_fused2_kernel<B, 1, true>))          \
+                 : (two ? go2(guided_fused2_kernel<B, 2, false>) : go2(guided_fused2_kernel<B, 1, false>));       \
+        break;
+            switch (b) {
+                MNV_FUSED2_CASE(-1)
+                MNV_FUSED2_CASE(1)
+                MNV_FUSED2_CASE(4)
+                MNV_FUSED2_CASE(9)
+                MNV_FUSED2_CASE(16)
+                default: break;
+            }
+#undef MNV_FUSED2_CASE
+        } else {
+        // the one-role kernel: 2 workgroups per CU (LDS: network tiles; 248 VGPRs), one 8x8 tile per wavefront at a time
         const size_t fl = fused_lds_bytes(nb, lds_level, F.S.mt_out, F.S.nkk0);
         int fb = accel->num_cus * MNV_FUSED_WAVES;
         if ((uint64_t)fb * 4u > n_waves_needed) fb = (int)((n_waves_needed + 3) / 4);
@@ -1235,8 +1276,6 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
             hipLaunchKernelGGL(kern, dim3(fb), dim3(256), fl, stream, K, F);
             return (int)hipGetLastError();
         };
-        const bool two = F.S.nkk0 == 2;  // mnv_render_guided_fused admits 1 and 2
-        const bool trk = K.split_track || K.sample_track || K.visited;
 #define MNV_FUSED_CASE(B)                                                                                       \
     case B:                                                                                                     \
         rc = trk ? (two ? go(guided_fused_kernel<B, 2, true>) : go(guided_fused_kernel<B, 1, true>))            \
@@ -1251,6 +1290,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
             default: break;
         }
 #undef MNV_FUSED_CASE
+        }
     } else if (colourless) rc = launch_variant<9>(K, n_blocks, lds_bytes, stream);
     else
         switch (b) {
@@ -1540,6 +1580,8 @@ int mnv_accel_set_cu_budget(mnv_accel *a, int32_t num_cus) {
 int32_t mnv_partition_local_tiles(mnv_rect tile, mnv_partition part) { return partition_local_tiles(tile, part); }
 
 void mnv_set_colour_math(int fast) { g_fast_colour.store(fast ? 1 : 0, std::memory_order_relaxed); }
+void mnv_set_fused_kernel(int version) { g_fused_kernel.store(version == 1 || version == 2 ? version : 0, std::memory_order_relaxed); }
+void mnv_set_fused_diag(unsigned long long *words32) { g_fused_diag.store(words32, std::memory_order_relaxed); }
 
 int mnv_assemble_tiles(const void *gathered, void *frames, int32_t width, int32_t height, mnv_partition part, int32_t n_frames,
                        int32_t bytes_per_pixel, void *hip_stream) {
@@ -1782,8 +1824,9 @@ static int guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv
     static const int env_batch = getenv("MNV_FUSED_BATCH_MIN") ? atoi(getenv("MNV_FUSED_BATCH_MIN")) : kFW;
     F.batch_min = env_batch < 1 ? 1 : (env_batch > kFW ? kFW : env_batch);
     F.sample_counter = sample_counter;
-    static const bool env_diag = getenv("MNV_FUSED_DIAG") != nullptr;  // the counter then has three words
-    F.diag = env_diag && sample_counter ? 1 : 0;
+    F.diag = g_fused_diag.load(std::memory_order_relaxed);
+    static const int env_switch = getenv("MNV_F2_SWITCH_MIN") ? atoi(getenv("MNV_F2_SWITCH_MIN")) : 24;
+    F.switch_min = env_switch;
     AccelTrack track = {};
     track.fused = &F;
     track.split_track = split_track;

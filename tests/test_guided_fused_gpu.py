@@ -12,6 +12,21 @@ from test_renderer_refine_gpu import make_grid
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[2, 1], ids=["producer_consumer", "one_role"])
+def fused_kernel(request, mnv, torch_gpu):
+    """Every test of this module runs with each of the two kernels behind mnv_render_guided_fused* (mnv_set_fused_kernel): wavefronts
+    specialised into march producers and a network consumer (csrc/mnv_guided_fused2.h), and every wavefront in both roles
+    (csrc/mnv_guided_fused.h).  The diagnostics buffer is on so that a spin-wait abandoned by the watchdog fails the test."""
+    diag = torch_gpu.zeros(32, dtype=torch_gpu.int64, device="cuda")
+    mnv.set_fused_kernel(request.param)
+    mnv.set_fused_diag(diag if request.param == 2 else None)
+    yield request.param
+    torch_gpu.cuda.synchronize()
+    mnv.set_fused_diag(None)
+    mnv.set_fused_kernel(0)
+    assert int(diag[15].item()) == 0, "a spin-wait of the producer / consumer kernel ran into its watchdog"
+
+
 def four_step_frame(mnv, torch, tree, cam, opt, mlp, grid, max_g, dim):
     n_px = cam.width * cam.height
     num = torch.zeros(n_px, dtype=torch.int16, device="cuda")
@@ -182,7 +197,7 @@ def test_fused_frame_with_trackers_and_visit_marks(mnv, torch_gpu, case, max_g):
     split = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")
     sample = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")
     visited = torch.zeros(v.capacity, dtype=torch.int32, device="cuda")
-    counter = torch.zeros(16, dtype=torch.int64, device="cuda")
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
     mnv.render_guided_fused(tree.accel, cam, opt, mlp, grid, rgba=out, sample_counter=counter, split_track=split, sample_track=sample,
                             sample_counts=sc_dev, visited=visited, parent=dv.parent)
     torch.cuda.synchronize()

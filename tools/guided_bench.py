@@ -44,7 +44,7 @@ rcl = torch.empty(cap, dtype=torch.int16, device="cuda")
 values = torch.empty((cap, dd + 1), dtype=torch.float32, device="cuda")
 out_a = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
 out_b = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
-counter = torch.zeros(16, dtype=torch.int64, device="cuda")
+counter = torch.zeros(1, dtype=torch.int64, device="cuda")
 
 
 def four_step(cam):
@@ -77,19 +77,47 @@ def timed(fn, cams, reps=3):
 cams = [cases.cfg2_camera(mnv, p, W, H, 1600.0) for p in range(8)]
 res = {"max_guided_samples": max_g, "pos_octaves": octaves, "batch_min": os.environ.get("MNV_FUSED_BATCH_MIN", "64")}
 res["four_step_ms"] = round(timed(four_step, cams), 4)
-res["fused_ms"] = round(timed(fused, cams), 4)
 total = four_step(cams[3])
-counter.zero_()
-fused(cams[3])
-torch.cuda.synchronize()
 res["samples"] = int(total)
-res["fused_samples"] = int(counter[0].item())
-if os.environ.get("MNV_FUSED_DIAG"):
-    res["passes"], res["march_iters"] = int(counter[1].item()), int(counter[2].item())
-    res["passes_cut_by_cluster"], res["drain_passes"] = int(counter[3].item()), int(counter[4].item())
-    res["wave_us_network"], res["wave_us_total"], res["wave_us_layer0"] = [round(int(counter[i].item()) / 100.0 / 2048, 1) for i in (5, 6, 7)]
-    res["wave_us_hidden_layers"], res["wave_us_column_eval"], res["wave_us_apply"] = [round(int(counter[i].item()) / 100.0 / 2048, 1) for i in (8, 9, 10)]
-    res["us_per_run"] = round(int(counter[5].item()) / 100.0 / max(1, res["passes"]), 2)
-    res["lanes_per_pass"] = round(res["fused_samples"] / max(1, res["passes"]), 2)
-res["bit_identical"] = bool(torch.equal(out_a.view(torch.int32), out_b.view(torch.int32)))
+diag = torch.zeros(32, dtype=torch.int64, device="cuda")
+for version, name in ((2, "producer_consumer"), (1, "one_role")):
+    mnv.set_fused_kernel(version)
+    r = {"ms": round(timed(fused, cams), 4)}
+    counter.zero_()
+    out_b.fill_(float("nan"))
+    fused(cams[3])
+    torch.cuda.synchronize()
+    r["samples"] = int(counter[0].item())
+    r["bit_identical"] = bool(torch.equal(out_a.view(torch.int32), out_b.view(torch.int32)))
+    if os.environ.get("MNV_FUSED_DIAG"):
+        diag.zero_()
+        mnv.set_fused_diag(diag)
+        r["ms_with_diag"] = round(timed(fused, cams[3:4], reps=1), 4)
+        diag.zero_()
+        fused(cams[3])
+        torch.cuda.synchronize()
+        mnv.set_fused_diag(None)
+        d = [int(x) for x in diag.tolist()]
+        if version == 1:
+            waves = 2048
+            r.update(passes=d[1], march_iters=d[2], passes_cut_by_cluster=d[3], drain_passes=d[4],
+                     wave_us_network=round(d[5] / 100.0 / waves, 1), wave_us_total=round(d[6] / 100.0 / waves, 1), wave_us_layer0=round(d[7] / 100.0 / waves, 1),
+                     wave_us_hidden_layers=round(d[8] / 100.0 / waves, 1), wave_us_column_eval=round(d[9] / 100.0 / waves, 1), wave_us_apply=round(d[10] / 100.0 / waves, 1),
+                     us_per_run=round(d[5] / 100.0 / max(1, d[1]), 2), lanes_per_pass=round(r["samples"] / max(1, d[1]), 2))
+        else:
+            names = ["-", "runs", "march_iters", "windows", "weight_reloads", "runs_from_l2", "cons_busy", "cons_total", "prod_total", "prod_ring_wait",
+                     "prod_flush_wait", "encode_l0", "layers_total", "eval", "columns", "watchdog"]
+            dd = dict(zip(names, d))
+            r.update(runs=dd["runs"], windows=dd["windows"], weight_reloads=dd["weight_reloads"], runs_from_l2=dd["runs_from_l2"], march_iters=dd["march_iters"],
+                     columns_per_run=round(dd["columns"] / max(1, dd["runs"]), 2), watchdog=dd["watchdog"],
+                     us_per_run=round(dd["cons_busy"] / 100.0 / max(1, dd["runs"]), 2),
+                     us_per_run_encode_l0=round(dd["encode_l0"] / 100.0 / max(1, dd["runs"]), 2),
+                     us_per_run_layers=round(dd["layers_total"] / 100.0 / max(1, dd["runs"]), 2),
+                     us_per_run_eval=round(dd["eval"] / 100.0 / max(1, dd["runs"]), 2),
+                     consumer_busy_frac=round(dd["cons_busy"] / max(1, dd["cons_total"]), 3),
+                     producer_ring_wait_frac=round(dd["prod_ring_wait"] / max(1, dd["prod_total"]), 3),
+                     producer_flush_wait_frac=round(dd["prod_flush_wait"] / max(1, dd["prod_total"]), 3),
+                     sum_consumer_ticks=dd["cons_total"], sum_producer_ticks=dd["prod_total"], consumers_per_simd=d[16:20], producers_per_simd=d[20:24])
+    res[name] = r
+mnv.set_fused_kernel(0)
 print(json.dumps(res))
