@@ -528,8 +528,8 @@ int mnv_render_guided_fused(const mnv_accel *accel, const mnv_camera *cam, const
                             const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, unsigned long long *sample_counter,
                             void *hip_stream);
 /* Which kernel the mnv_render_guided_fused* entry points launch (process-wide): 0 = choose by the network's size (default),
- * 1 = the one-role kernel (every wavefront marches and evaluates), 2 = producer / consumer wavefronts (MNV_E_UNSUPPORTED at the
- * launch when the weights do not fit). */
+ * 1 = the one-role kernel (every wavefront marches and evaluates), 2 = producer / consumer wavefronts wherever the rings, the
+ * rays' constants and the weights of enough sub-modules fit a workgroup's LDS (the one-role kernel otherwise). */
 void mnv_set_fused_kernel(int version);
 /* Diagnostics of the fused kernels (process-wide): `words32` = NULL (default, none) or a device buffer of 32 64-bit words the
  * kernels add run counts and per-phase times to (tools/guided_bench.py names them).  Costs a few per cent while set. */

@@ -42,7 +42,8 @@ struct FusedGuided {
     int32_t batch_min;           // run the network once this many samples wait in a wavefront's pool (1 .. 64)
     unsigned long long *sample_counter;  // += samples evaluated (one atomic per wavefront); ONE word
     unsigned long long *diag;            // diagnostics (mnv_set_fused_diag, 32 words of the caller's): NULL = none
-    int32_t switch_min;                  // guided_fused2_kernel: columns a sub-module needs in a run to take over the weight copy in LDS
+    int32_t switch_min;                  // guided_fused2_kernel: a consumer stays with its last sub-module while this many of its samples wait
+    int32_t weight_slots;                // guided_fused2_kernel: sub-modules whose weights a workgroup keeps in LDS (<= kF2NS, what fits)
 };
 
 // Columns per network run: W = 16 * MNV_FUSED_NT samples; 64 / W lanes share a column in the per-column phases (encode, evaluation).

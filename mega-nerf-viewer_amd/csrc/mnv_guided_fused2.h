@@ -7,20 +7,19 @@
 // the network no longer share one wavefront's registers and time:
 //   * a workgroup is NP PRODUCER wavefronts + one CONSUMER wavefront.  A producer marches an 8x8 tile, one ray per lane, on the packed
 //     accel exactly as guided_fused_kernel does and pushes every complete sample (world position, delta z, owner lane, cluster) into
-//     ITS ring in LDS (128 entries); it never touches the matrix cores.  The composite of a ray's samples happens in the owning lane,
-//     in ray order, whenever results have arrived: one LDS poll per march iteration;
-//   * the consumer gathers up to 64 waiting entries from the NP rings (oldest first per ring, rings that asked for a flush first),
-//     encodes them, runs the network on the matrix cores -- the identical v_mfma_f32_16x16x32_f16 sequence on the identical
-//     fragments as mlp_forward_kernel -- with the A operands read from LDS, where the weights of the workgroup's current sub-module
-//     stay between runs (a run of a minority sub-module reads its fragments from L2 instead, as guided_fused_kernel always does),
-//     turns every column into the sample's transmittance factor and colour denominators (SH basis of the owning ray from LDS) and
-//     writes those four floats over the sample's ring entry;
-//   * rings, results and the three counters per ring (pushed / flush request / evaluated) live in LDS; waves of one workgroup are
-//     co-resident by construction, so the spin-waits (s_sleep) cannot deadlock: a producer waits only when its ring holds more than
-//     64 entries (the consumer then has a full window) or after it has asked for a flush; the consumer never waits for a producer.
-// What this buys (cfg2, 1080p, 9.4 M samples): the march runs in 12 wavefronts per CU that do nothing else (was: 8 that spent 44 %
-// of their time in the network), the network's latency chain loses its three L2 round trips per run, and the register budget is
-// 128 instead of 248 (4 wavefronts per SIMD instead of 2).
+//     ITS ring in LDS (128 slots); it never touches the matrix cores.  The composite of a ray's samples happens in the owning lane,
+//     in ray order, as results arrive (a per-entry READY flag; one LDS poll per march iteration);
+//   * the consumer keeps, per lane, the state of two slots of every ring (pending? which sub-module?), picks the sub-module of the
+//     oldest waiting sample of a ring that needs service (or stays with the sub-module whose weights are in LDS while plenty of its
+//     samples wait), gathers up to 64 waiting samples OF THAT SUB-MODULE from all rings -- so a run fills its 64 columns although
+//     rays change sub-module between the front and the back of a surface -- encodes them, runs the network on the matrix cores (the
+//     identical v_mfma_f32_16x16x32_f16 sequence on the identical fragments as mlp_forward_kernel, A operands from LDS), turns every
+//     column into the sample's transmittance factor and colour denominators (SH basis of the owning ray from LDS) and writes those
+//     four floats over the sample's ring entry;
+//   * rings, results and the counters per ring (pushed / service request / evaluated) live in LDS; waves of one workgroup are
+//     co-resident by construction, so the spin-waits (s_sleep) cannot deadlock: a producer waits only after it has asked for service
+//     (its ring cannot take another step's samples, or its tile is finished), and the consumer serves such a ring's oldest sample
+//     first; the consumer never waits for a producer.
 #pragma once
 
 #include <type_traits>
@@ -31,43 +30,96 @@
 
 namespace mnv {
 
+// Shape of a workgroup: NP producer wavefronts, NC consumer wavefronts (consumer c serves the rings of producers c * NP / NC ...),
+// NS weight slots in LDS shared by the consumers.  Default: the workgroup is a whole CU's worth of wavefronts at 128 VGPRs --
+// 12 producers + 4 consumers (one per SIMD) and the weights of four sub-modules resident (the tiles a CU holds at a time are
+// neighbours on the screen: front and back of a surface, now and then a third sub-module at a boundary).
 #ifndef MNV_F2_NP
-#define MNV_F2_NP 3  // producer wavefronts per workgroup (+ 1 consumer): 4 workgroups of 256 threads per CU at 128 VGPRs
+#define MNV_F2_NP 12
 #endif
-constexpr int kF2NP = MNV_F2_NP;
-constexpr int kF2Block = 64 * (kF2NP + 1);
-constexpr int kF2Ring = 128;                       // entries per producer ring: a window is due at 64 and one march step adds at most 64
+#ifndef MNV_F2_NC
+#define MNV_F2_NC 4
+#endif
+#ifndef MNV_F2_NS
+#define MNV_F2_NS 4
+#endif
+constexpr int kF2NP = MNV_F2_NP, kF2NC = MNV_F2_NC, kF2NS = MNV_F2_NS, kF2RPC = kF2NP / kF2NC;  // RPC: rings per consumer
+constexpr int kF2Block = 64 * (kF2NP + kF2NC);
+constexpr int kF2Ring = 128;                       // slots per producer ring: one march step adds at most 64 samples
 constexpr int kF2RingWords = kF2Ring * (4 + 1 + 1);  // float4 {x, y, z, dz} -> {att, d0, d1, d2} | meta | owner's next slot
 constexpr int kF2WavesPerSimd = 4;                 // register budget: 128 VGPRs
 constexpr bool kF2Default = false;                 // mnv_set_fused_kernel(0) picks this kernel when it fits (until it is the faster one: no)
+constexpr uint32_t kF2Ready = 128u;                // meta bit: the entry holds its results
+static_assert(kF2NP % kF2NC == 0 && kF2RPC >= 1 && kF2RPC <= 4 && kF2Block <= 1024 && kF2NS >= 1 && kF2NS <= 7, "workgroup shape");
 // Watchdog of the spin-waits: a wait that lasts this many polls (s_sleep 1-2 each: tens of milliseconds; a healthy wait is a few
 // microseconds) is abandoned and the wavefront leaves -- wrong pixels and a count in the diagnostics buffer instead of a hung device.
 // No schedule of co-resident waves reaches it (header comment); it exists so that a bug cannot take the machine down.
 constexpr uint32_t kF2SpinLimit = 1u << 18;
 
 struct F2Layout {  // word offsets into the dynamic LDS block
-    int grid, ray, rings, ctrl, frags, bias, tile, total;
-    int ray_rows;
+    int grid, ray, rings, ctrl, cols, watch, wcache, frags, bias, tile, total;
+    int ray_rows, frag_words, bias_words, tile_words;
 };
-__host__ __device__ inline F2Layout f2_layout(int nb, int lds_level, const MlpShape &S) {
+__host__ __device__ inline F2Layout f2_layout(int nb, int lds_level, const MlpShape &S, int slots) {
     F2Layout L;
     L.ray_rows = nb + (S.need_viewdir ? 3 : 0);
     L.grid = 64;                                          // after the exp table
     L.ray = L.grid + (1 << (3 * lds_level));
     L.rings = (L.ray + L.ray_rows * kF2NP * 64 + 3) & ~3;  // 16-byte aligned entries
     L.ctrl = L.rings + kF2NP * kF2RingWords;
-    L.frags = L.ctrl + 16;                                // 4 words per ring, room for 4 rings
-    L.bias = L.frags + S.frag_halfs / 2;
-    L.tile = (L.bias + S.bias_floats + 3) & ~3;
+    L.cols = L.ctrl + 8 * kF2NP;                          // 8 words per ring
+    L.watch = L.cols + 64 * kF2NC;                        // column -> (ring, slot) of every consumer's current window
+    L.wcache = L.watch + (kF2RPC + 1) * 64 * kF2NC;       // per consumer and lane: what waits in the slots the lane watches (between windows the registers belong to the network)
+    L.frags = L.wcache + 32;                              // weight cache: lock, clock, per slot {cluster, state, readers, stamp}
+    L.frag_words = S.frag_halfs / 2;
+    L.bias_words = (S.bias_floats + 3) & ~3;
+    L.bias = L.frags + slots * L.frag_words;
+    L.tile = L.bias + slots * L.bias_words;
     const int enc = S.nkk0 * 16 * 64, out = 16 * S.mt_out * 32;  // encode tiles (one per K tile); outputs of 32 columns at a time
-    L.total = L.tile + (enc > out ? enc : out);
+    L.tile_words = enc > out ? enc : out;
+    L.total = L.tile + kF2NC * L.tile_words;
     return L;
 }
-static_assert(kF2NP >= 1 && kF2NP <= 4, "ctrl block holds 4 rings");
 
-struct F2Diag {  // MNV_FUSED_DIAG: sums over wavefronts, 100 MHz ticks
-    enum { kRuns = 1, kSteps, kWindows, kReloads, kGlobalRuns, kConsBusy, kConsTotal, kProdTotal, kProdRingWait, kProdFlushWait, kEnc, kLayers, kEval, kColumns, kWatchdog, kConsSimd /* 4 words: consumer wavefronts per SIMD id */, kProdSimd = kConsSimd + 4, kWords = kProdSimd + 4 };
+struct F2Diag {  // mnv_set_fused_diag: sums over wavefronts, 100 MHz ticks
+    enum { kRuns = 1, kSteps, kWindows, kReloads, kGlobalRuns, kConsBusy, kConsTotal, kProdTotal, kProdRingWait, kProdFlushWait, kEnc, kLayers, kEval, kColumns, kWatchdog,
+           kConsSimd /* 4 words: consumer wavefronts per SIMD id */, kProdSimd = kConsSimd + 4, kProdWalk = kProdSimd + 4, kProdSetup, kProdStep, kProdPush, kWords };
 };
+
+// expf as exact_expf, without branches: the special cases (|x| >= 88) are selected afterwards.  Same bits for every input.
+__device__ __forceinline__ float exact_expf_select(float x, const uint64_t *tab) {
+    constexpr double N = 32.0;
+    constexpr double InvLn2N = 0x1.71547652b82fep+0 * N;
+    constexpr double SHIFT = 0x1.8p+52;
+    constexpr double C0 = 0x1.c6af84b912394p-5 / N / N / N;
+    constexpr double C1 = 0x1.ebfce50fac4f3p-3 / N / N;
+    constexpr double C2 = 0x1.62e42ff0c52d6p-1 / N;
+    // the main path on a clamped argument (so that nothing overflows on the way), then the special cases of exact_expf in its order
+    const float xc = __builtin_amdgcn_fmed3f(x, -128.f, 128.f);
+    const double xd = (double)xc;
+    double z = InvLn2N * xd;
+    double kd = z + SHIFT;
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd -= SHIFT;
+    const double r = z - kd;
+    uint64_t t = tab[ki & 31u];
+    t += ki << 47;
+    const double s = __longlong_as_double((long long)t);
+    z = C0 * r + C1;
+    const double r2 = r * r;
+    double y = C2 * r + 1.0;
+    y = z * r2 + y;
+    y = y * s;
+    float res = (float)y;
+    const uint32_t ix = __float_as_uint(x);
+    const uint32_t abstop = (ix >> 20) & 0x7ffu;
+    const bool big = abstop >= 0x42bu;
+    res = (big && x < -0x1.9fe368p6f) ? 0.0f : res;
+    res = (big && x > 0x1.62e42ep6f) ? __uint_as_float(0x7f800000u) : res;
+    res = (big && abstop >= 0x7f8u) ? x + x : res;
+    res = ix == 0xff800000u ? 0.0f : res;
+    return res;
+}
 
 template <int BASIS, int NKK0, bool TRACK>
 __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kernel(const AccelLaunch K, const FusedGuided F) {
@@ -79,16 +131,18 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
     const AccelView &A = K.A;
     const MlpShape &S = F.S;
     const int LL = K.lds_level;
-    const F2Layout Lo = f2_layout(NB, LL, S);
+    const F2Layout Lo = f2_layout(NB, LL, S, F.weight_slots);
     uint32_t *s_grid = s_mem + Lo.grid;
     float *s_ray = reinterpret_cast<float *>(s_mem + Lo.ray);  // [row][producer thread]: SH basis, then the view direction
-    uint32_t *s_ctrl = s_mem + Lo.ctrl;                        // per ring: pushed, flush request, evaluated, producer has left
+    uint32_t *s_ctrl = s_mem + Lo.ctrl;                        // per ring (8 words): pushed, flush request, evaluated, producer has left, stall request
     constexpr uint32_t kNone = 0xffffffffu;
 
     {
         const int cells = 1 << (3 * LL);
         if (threadIdx.x < 32) s_exp[threadIdx.x] = kExp2fTab[threadIdx.x];
-        if (threadIdx.x < 16) s_ctrl[threadIdx.x] = 0u;
+        for (int i = threadIdx.x; i < 8 * kF2NP; i += kF2Block) s_ctrl[i] = 0u;
+        for (int i = threadIdx.x; i < (kF2RPC + 1) * 64 * kF2NC; i += kF2Block) s_mem[Lo.watch + i] = 0u;
+        if (threadIdx.x < 32) s_mem[Lo.wcache + threadIdx.x] = threadIdx.x >= 2 && ((threadIdx.x - 2) & 3) == 0 ? 0xffffffffu : 0u;  // slots: no cluster
         for (int i = threadIdx.x; i < cells; i += kF2Block) {
             const int G = 1 << LL;
             const int iz = i & (G - 1), iy = (i >> LL) & (G - 1), ix = i >> (2 * LL);
@@ -117,7 +171,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
         // =================================================================================== producer: march, push, composite
         float4 *r_data = reinterpret_cast<float4 *>(s_mem + Lo.rings + wave * kF2RingWords);
         uint32_t *r_meta = reinterpret_cast<uint32_t *>(r_data + kF2Ring), *r_next = r_meta + kF2Ring;
-        uint32_t *c_tail = s_ctrl + 4 * wave, *c_flush = c_tail + 1, *c_ready = c_tail + 2, *c_exit = c_tail + 3;
+        uint32_t *c_tail = s_ctrl + 8 * wave, *c_flush = c_tail + 1, *c_ready = c_tail + 2, *c_exit = c_tail + 3, *c_stall = c_tail + 4;
         float *my_ray = s_ray + wave * 64 + lane;  // [k * RB]
 
         const int Lq = A.max_depth;
@@ -136,9 +190,9 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
         float max_weight = -1.f, max_sample_weight = -1.f, sp_prio = 0.f, sa_prio = 0.f;
         int32_t sp_vox = -1, sa_vox = -1;
         int n_eval = 0, n_steps = 0;
-        unsigned long long t_ring = 0, t_flush = 0;
+        unsigned long long t_ring = 0, t_flush = 0, t_walk = 0, t_setup = 0, t_step = 0, t_push = 0;
         uint32_t spins = 0;                           // consecutive waits (watchdog)
-        uint32_t tail = 0, seen = 0, flush_sent = 0;  // wave-uniform: entries pushed; evaluated entries this wave has composited; last flush request
+        uint32_t tail = 0, seen = 0, flush_sent = 0xffffffffu, stall_sent = 0xffffffffu, head = 0;  // wave-uniform: entries pushed; evaluated entries (counter last seen); last service request; lower bound of the oldest slot in use
 
         const uint32_t home = blockIdx.x % kNumQueues;
         uint32_t qsel = 0;
@@ -147,15 +201,23 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
         const float cen0 = Cp->cen[0], cen1 = Cp->cen[1], cen2 = Cp->cen[2];
 
         for (;;) {
-            // ---- results that arrived since the last look: every owner walks its samples in ray order (rt_core.cuh:356-392)
+            // ---- results that arrived since the last look: every owner walks its samples in ray order (rt_core.cuh:356-392) as far as
+            //      they have been evaluated (entries of other sub-modules may still wait: evaluation is not first-in first-out)
+            const unsigned long long t_i0 = F.diag ? wall_clock64() : 0;
             {
                 const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_relaxed(c_ready));
                 if (r != seen) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    while (first_pending != kNone && (int32_t)(first_pending - r) < 0) {
+                    while (first_pending != kNone) {
                         const uint32_t e = first_pending & (kF2Ring - 1);
+                        // The results must be read AFTER the flag.  LDS serves a wavefront's requests in program order, so it is enough that
+                        // the compiler keeps the three reads in this order (the barrier); they travel together instead of one round trip each.
+                        const uint32_t m = __hip_atomic_load(&r_meta[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        asm volatile("" ::: "memory");
                         const float4 res = r_data[e];
-                        const bool last = (r_meta[e] & 64u) != 0;
+                        const uint32_t nx = r_next[e];
+                        if (!(m & kF2Ready)) break;
+                        const bool last = (m & 64u) != 0;
                         const float wc = res.x;
                         const float weight = last ? ti : ti * (1.0f - wc);
                         if constexpr (BASIS >= 0) {
@@ -168,7 +230,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                             o2 += weight * res.w;
                         }
                         ti *= wc;
-                        first_pending = r_next[e];
+                        first_pending = nx;
                         ++n_eval;
                     }
                     seen = r;
@@ -191,6 +253,8 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                 }
                 has_ray = false;
             }
+            const unsigned long long t_i1 = F.diag ? wall_clock64() : 0;
+            if (F.diag) t_walk += t_i1 - t_i0;
             // ---- a new 8x8 tile once every lane has written its pixel
             if (__ballot(has_ray) == 0) {
                 if (drained) break;
@@ -249,29 +313,47 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                         delta_scale = r.delta_scale;
                     }
                 }
+                if (F.diag) t_setup += wall_clock64() - t_i1;
                 continue;
             }
             // ---- nothing more can be pushed: ask for the rest of the ring to be evaluated and wait for it
             if (__ballot(has_ray && (!done || held)) == 0) {
-                if (tail != seen) {
+                if (tail != seen) {  // `seen` counts evaluated entries: all of them once it reaches `tail`
                     if (flush_sent != tail) {
                         st_release(c_flush, tail);
                         flush_sent = tail;
                     }
                     const unsigned long long t0 = F.diag ? wall_clock64() : 0;
                     __builtin_amdgcn_s_sleep(2);
-                    if (F.diag) t_flush += wall_clock64() - t0 + 1;
+                    if (F.diag) t_flush += wall_clock64() - t_i0;
+                    (void)t0;
                     if (++spins > kF2SpinLimit) break;  // watchdog: never hang the device (see kF2SpinLimit)
                 }
                 continue;  // tail == seen: every lane's chain is empty, the pixels go out at the top of the next iteration
             }
-            // ---- room for one more step's samples (at most 64)?
-            if (tail - seen > (uint32_t)(kF2Ring - 64)) {
-                const unsigned long long t0 = F.diag ? wall_clock64() : 0;
-                __builtin_amdgcn_s_sleep(1);
-                if (F.diag) t_ring += wall_clock64() - t0 + 1;
-                if (++spins > kF2SpinLimit) break;
-                continue;
+            // ---- room for one more step's samples (at most 64)?  A slot is free once its owner has composited it; rays composite in
+            //      order, so the oldest slot in use is the smallest `first_pending` of the wavefront
+            if (tail - head > (uint32_t)(kF2Ring - 64)) {
+                uint32_t age = first_pending != kNone ? tail - first_pending : 0u;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const uint32_t other = (uint32_t)__shfl_xor((int)age, o);
+                    age = other > age ? other : age;
+                }
+                head = tail - (uint32_t)__builtin_amdgcn_readfirstlane((int)age);
+                if (tail - head > (uint32_t)(kF2Ring - 64)) {
+                    // the ring cannot take another step: ask for service (the consumer then evaluates this ring's oldest entries first)
+                    if (stall_sent != tail) {
+                        st_release(c_stall, tail);
+                        stall_sent = tail;
+                    }
+                    const unsigned long long t0 = F.diag ? wall_clock64() : 0;
+                    __builtin_amdgcn_s_sleep(1);
+                    if (F.diag) t_ring += wall_clock64() - t_i0;
+                    (void)t0;
+                    if (++spins > kF2SpinLimit) break;
+                    continue;
+                }
             }
             spins = 0;
 
@@ -280,6 +362,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
             float sz = 0.f, sx = 0.f, sy = 0.f, sw = 0.f;
             int scl = -1;
             ++n_steps;
+            const unsigned long long t_i2 = F.diag ? wall_clock64() : 0;
             if (has_ray && !done) {
                 if (!(t < tmax)) {
                     done = true;
@@ -404,6 +487,8 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                 }
             }
 
+            const unsigned long long t_i3 = F.diag ? wall_clock64() : 0;
+            if (F.diag) t_step += t_i3 - t_i2;
             // ---- release complete samples into the ring: the held one once its successor exists (delta z known), or as the ray's
             //      last sample one step after the ray ended
             {
@@ -440,6 +525,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                     st_release(c_tail, tail);
                 }
             }
+            if (F.diag) t_push += wall_clock64() - t_i3;
         }
         st_release(c_exit, 1u);
         if (spins > kF2SpinLimit && F.diag && lane == 0) atomicAdd(F.diag + F2Diag::kWatchdog, 1ull);
@@ -455,290 +541,498 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
             atomicAdd(F.diag + F2Diag::kProdTotal, wall_clock64() - t_begin);
             atomicAdd(F.diag + F2Diag::kProdRingWait, t_ring);
             atomicAdd(F.diag + F2Diag::kProdFlushWait, t_flush);
+            atomicAdd(F.diag + F2Diag::kProdWalk, t_walk);
+            atomicAdd(F.diag + F2Diag::kProdSetup, t_setup);
+            atomicAdd(F.diag + F2Diag::kProdStep, t_step);
+            atomicAdd(F.diag + F2Diag::kProdPush, t_push);
         }
     } else {
         // =================================================================================== consumer: the network
         __builtin_amdgcn_s_setprio(2);
         const int g = lane >> 4, col = lane & 15;
-        half8 *s_frag = reinterpret_cast<half8 *>(s_mem + Lo.frags);
-        float *s_bias = reinterpret_cast<float *>(s_mem + Lo.bias);
-        uint32_t *s_tile = s_mem + Lo.tile;
+        const int ci = wave - kF2NP, rbase = ci * kF2RPC;  // this consumer and the first of its rings
+        uint32_t *s_cols = s_mem + Lo.cols + 64 * ci;
+        uint32_t *s_tile = s_mem + Lo.tile + ci * Lo.tile_words;
         float *s_out = reinterpret_cast<float *>(s_tile);
-        uint32_t rdy[kF2NP];
+        uint32_t *s_wc = s_mem + Lo.wcache;  // [0] lock, [1] clock, then per slot {cluster, state (1: being filled), readers, stamp}
+        uint32_t *s_rctrl = s_ctrl + 8 * rbase;
+        auto ring_data = [&](int p) { return reinterpret_cast<float4 *>(s_mem + Lo.rings + (rbase + p) * kF2RingWords); };  // p: ring of this consumer
+        auto ring_meta = [&](int p) { return s_mem + Lo.rings + (rbase + p) * kF2RingWords + 4 * kF2Ring; };
+        // this lane watches slots `lane` and `lane + 64` of every ring: is an unevaluated sample there, and of which sub-module
+        // (kept in LDS between windows -- s_watch[k * 64 + lane], k < RPC: clusters, k == RPC: waiting bits -- so that nothing of it
+        // occupies registers while the network runs)
+        uint32_t *s_watch = s_mem + Lo.watch + ci * (kF2RPC + 1) * 64 + lane;
+        uint32_t scan[kF2RPC], evald[kF2RPC], floor_[kF2RPC];  // per ring (wave-uniform): entries registered, evaluated; a lower bound of the oldest waiting slot
 #pragma unroll
-        for (int p = 0; p < kF2NP; ++p) rdy[p] = 0u;
-        int lds_cluster = -1;
+        for (int p = 0; p < kF2RPC; ++p) scan[p] = evald[p] = floor_[p] = 0u;
+        int lds_cluster = -1;  // the sub-module this consumer ran last (its weights are most likely still in a slot)
+        int held_slot = -1;    // the weight slot this consumer holds a reader's reference on
         uint32_t spins = 0;
-        unsigned long long n_runs = 0, n_windows = 0, n_reloads = 0, n_global = 0, n_cols = 0, t_busy = 0, t_enc = 0, t_lay = 0, t_eval = 0;
+        unsigned long long n_runs = 0, n_reloads = 0, n_cols = 0, t_busy = 0, t_enc = 0, t_lay = 0, t_eval = 0, t_reload = 0;
 
         for (;;) {
-            // ---- what waits in the rings
-            uint32_t pend[kF2NP];
-            bool flush[kF2NP];
-            uint32_t total = 0;
-            bool any_flush = false, all_exited = true;
+            // ---- what has arrived: register the new entries of every ring with their watcher lanes
+            uint32_t watch_cl[kF2RPC];  // clusters of the two slots this lane watches in ring p: low / high 16 bits
+            uint32_t watch_pend;        // bit 2p: slot `lane` of ring p waits, bit 2p + 1: slot `lane + 64`
 #pragma unroll
-            for (int p = 0; p < kF2NP; ++p) {
-                const uint32_t ex = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_relaxed(s_ctrl + 4 * p + 3));  // read BEFORE the tail: a producer pushes nothing after it has left
-                const uint32_t tl = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_relaxed(s_ctrl + 4 * p));
-                const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_relaxed(s_ctrl + 4 * p + 1));
-                pend[p] = tl - rdy[p];
-                flush[p] = (int32_t)(fl - rdy[p]) > 0;
-                total += pend[p];
-                any_flush |= flush[p];
-                all_exited &= ex != 0;
+            for (int p = 0; p < kF2RPC; ++p) watch_cl[p] = s_watch[p * 64];
+            watch_pend = s_watch[kF2RPC * 64];
+            uint32_t total = 0;
+            bool all_exited = true;
+            int service = -1;  // a ring whose producer waits for it (tile finished, or no room for another step)
+            bool service_stall = false;
+            {
+                uint32_t tl[kF2RPC], fl[kF2RPC], sl[kF2RPC];
+#pragma unroll
+                for (int p = 0; p < kF2RPC; ++p) {
+                    all_exited &= __builtin_amdgcn_readfirstlane((int)ld_relaxed(s_rctrl + 8 * p + 3)) != 0;  // read BEFORE the tail: a producer pushes nothing after it has left
+                    tl[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_relaxed(s_rctrl + 8 * p));
+                    fl[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_relaxed(s_rctrl + 8 * p + 1));
+                    sl[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)ld_relaxed(s_rctrl + 8 * p + 4));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+                for (int p = 0; p < kF2RPC; ++p) {
+                    const uint32_t fresh = tl[p] - scan[p];
+                    if (fresh != 0u) {
+                        const uint32_t *meta_p = ring_meta(p);
+                        if ((((uint32_t)lane - scan[p]) & (kF2Ring - 1)) < fresh) {
+                            watch_cl[p] = (watch_cl[p] & 0xffff0000u) | ((meta_p[lane] >> 8) & 0xffffu);
+                            watch_pend |= 1u << (2 * p);
+                        }
+                        if ((((uint32_t)lane + 64u - scan[p]) & (kF2Ring - 1)) < fresh) {
+                            watch_cl[p] = (watch_cl[p] & 0xffffu) | ((meta_p[lane + 64] >> 8) << 16);
+                            watch_pend |= 2u << (2 * p);
+                        }
+                        scan[p] = tl[p];
+                    }
+                    const uint32_t waiting = scan[p] - evald[p];
+                    total += waiting;
+                    // a stalled producer (no room for another step) needs its OLDEST samples; one that has finished its tile needs all of them
+                    if (waiting != 0u && sl[p] == tl[p] && (service < 0 || !service_stall)) {
+                        service = p;
+                        service_stall = true;
+                    } else if (service < 0 && waiting != 0u && fl[p] == tl[p]) {
+                        service = p;
+                    }
+                }
             }
+#pragma unroll
+            for (int p = 0; p < kF2RPC; ++p) s_watch[p * 64] = watch_cl[p];
+            s_watch[kF2RPC * 64] = watch_pend;
             if (total == 0) {
+                if (held_slot >= 0) {  // idle: let the others replace the slot
+                    if (lane == 0) __hip_atomic_fetch_sub(s_wc + 2 + 4 * held_slot + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    held_slot = -1;
+                }
                 if (all_exited) break;
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > 64u * kF2SpinLimit) break;  // watchdog (a consumer legitimately idles through a whole tile of empty space)
                 continue;
             }
-            if (total < (uint32_t)F.batch_min && !any_flush) {
+            if (total < (uint32_t)F.batch_min && service < 0) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > 64u * kF2SpinLimit) break;
                 continue;
             }
             spins = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             const unsigned long long t_w0 = F.diag ? wall_clock64() : 0;
-            // ---- the window: up to 64 entries, oldest first per ring; rings that asked for a flush come first
-            uint32_t take[kF2NP], first_col[kF2NP];
+            // ---- the window: up to 64 waiting samples of ONE sub-module, gathered from all rings of this consumer.  select(c, first, half)
+            //      lists them in s_cols (ring `first` first, and of that ring the half `half` first) without taking them yet.
+            uint32_t taken[kF2RPC];
+            uint32_t sel_bits = 0u;  // the watched slots of this lane that the window takes (same layout as watch_pend)
             int n = 0;
+            auto select = [&](int c_, int first_, uint32_t half_) __attribute__((always_inline)) {
+                // (wave-uniform by construction; said again so that the compiler keeps them in scalar registers)
+                const int c = __builtin_amdgcn_readfirstlane(c_), first = __builtin_amdgcn_readfirstlane(first_);
+                const uint32_t half = (uint32_t)__builtin_amdgcn_readfirstlane((int)half_);
+                n = 0;
+                sel_bits = 0u;
 #pragma unroll
-            for (int p = 0; p < kF2NP; ++p) take[p] = first_col[p] = 0u;
+                for (int p = 0; p < kF2RPC; ++p) taken[p] = 0u;
 #pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
+                for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-                for (int p = 0; p < kF2NP; ++p) {
-                    if (flush[p] == (pass == 0) && pend[p] != 0u && n < 64) {
-                        const uint32_t k = pend[p] < (uint32_t)(64 - n) ? pend[p] : (uint32_t)(64 - n);
-                        take[p] = k;
-                        first_col[p] = (uint32_t)n;
-                        n += (int)k;
-                    }
-                }
-            }
-            ++n_windows;
-            // column `lane` -> its ring and entry
-            int ring = 0;
-            uint32_t e = 0;
-            bool col_on = false;
+                    for (int p = 0; p < kF2RPC; ++p) {
+                        if ((p == first) == (pass == 0)) {
 #pragma unroll
-            for (int p = 0; p < kF2NP; ++p) {
-                if (take[p] != 0u && (uint32_t)lane >= first_col[p] && (uint32_t)lane < first_col[p] + take[p]) {
-                    ring = p;
-                    e = (rdy[p] + ((uint32_t)lane - first_col[p])) & (kF2Ring - 1);
-                    col_on = true;
-                }
-            }
-            float4 *e_data = reinterpret_cast<float4 *>(s_mem + Lo.rings + ring * kF2RingWords) + e;
-            const uint32_t meta = col_on ? reinterpret_cast<const uint32_t *>(s_mem + Lo.rings + ring * kF2RingWords + 4 * kF2Ring)[e] : 0u;
-            const int owner_thread = ring * 64 + (int)(meta & 63u), my_cl = (int)(int16_t)(meta >> 8);
-            const float4 smp = col_on ? *e_data : make_float4(0.f, 0.f, 0.f, 0.f);
-            // The window's samples may belong to several sub-modules (a ray that crosses the front and the back of a surface changes
-            // cluster on the way): the network runs once per distinct cluster of the window, the resident one first.
-            uint64_t todo = __ballot(col_on);
-            while (todo != 0) {
-                int c_star;
-                if (lds_cluster >= 0 && __ballot(col_on && my_cl == lds_cluster && ((todo >> lane) & 1ull)) != 0) c_star = lds_cluster;
-                else c_star = __builtin_amdgcn_readfirstlane(__shfl(my_cl, (int)__builtin_ctzll(todo)));
-                const bool col_sel = col_on && my_cl == c_star;
-                const uint64_t sel = __ballot(col_sel);
-                todo &= ~sel;
-                ++n_runs;
-                n_cols += (unsigned long long)__popcll(sel);
-                const bool valid_cluster = c_star >= 0 && c_star < S.n_clusters;
-                // ---- per column: transmittance factor and colour denominators of its sample (rt_core.cuh:356-392), SH basis of the
-                //      owner; 32 columns at a time (the output tile holds 32), two lanes per column: lane share 0 takes the opacity and
-                //      the first channel, share 1 the other two; the four floats replace the sample in its ring entry
-                auto evaluate = [&](int half, auto valid_tag) {
-                    constexpr bool kValid = decltype(valid_tag)::value;
-                    const int c32 = lane & 31, share = lane >> 5, jc = half * 32 + c32;
-                    const bool on = __shfl((int)col_sel, jc) != 0;
-                    const uint32_t meta_j = (uint32_t)__shfl((int)meta, jc);
-                    const int owner_j = __shfl(owner_thread, jc);
-                    const float dz_j = __shfl(smp.w, jc);
-                    const int ring_j = __shfl(ring, jc);
-                    const uint32_t e_j = (uint32_t)__shfl((int)e, jc);
-                    if (on) {
-                        float *dst = reinterpret_cast<float *>(reinterpret_cast<float4 *>(s_mem + Lo.rings + ring_j * kF2RingWords) + e_j);
-                        auto sv = [&](int f) -> float { return kValid ? s_out[f * 32 + c32] : 0.f; };  // no sub-module: zeros (mlp_histogram)
-                        if constexpr (BASIS >= 0) {
-                            float basis[NB];
-#pragma unroll
-                            for (int k = 0; k < NB; ++k) basis[k] = s_ray[k * RB + owner_j];
-                            const int stride = BASIS > 0 ? BASIS : 0;
-                            if (share == 0) {
-                                const bool last = (meta_j & 64u) != 0;
-                                dst[0] = last ? 0.f : exact_expf(-sv(3) * dz_j, s_exp);
-                                dst[1] = 1.f + exact_expf(-sh_channel<BASIS>(basis, sv, 0), s_exp);
-                            } else {
-                                dst[2] = 1.f + exact_expf(-sh_channel<BASIS>(basis, sv, stride), s_exp);
-                                dst[3] = 1.f + exact_expf(-sh_channel<BASIS>(basis, sv, 2 * stride), s_exp);
-                            }
-                        } else {
-                            if (share == 0) {
-                                const bool last = (meta_j & 64u) != 0;
-                                dst[0] = last ? 0.f : exact_expf(-sv(3) * dz_j, s_exp);
-                                dst[1] = sv(0);
-                            } else {
-                                dst[2] = sv(1);
-                                dst[3] = sv(2);
+                            for (int hh = 0; hh < 2; ++hh) {
+                                const uint32_t h = p == first ? (uint32_t)hh ^ half : (uint32_t)hh;  // wave-uniform
+                                const uint32_t cl16 = h ? watch_cl[p] >> 16 : watch_cl[p] & 0xffffu;
+                                const bool match = ((watch_pend >> (2 * p)) & (1u << h)) != 0u && (int)(int16_t)cl16 == c;
+                                const uint64_t msk = __ballot(match);
+                                if (msk != 0 && n < 64) {
+                                    const uint32_t k = (uint32_t)__popcll(msk), tk = k < (uint32_t)(64 - n) ? k : (uint32_t)(64 - n);
+                                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(msk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)msk, 0u));
+                                    if (match && rank < tk) {
+                                        s_cols[n + (int)rank] = ((uint32_t)p << 7) | (h << 6) | (uint32_t)lane;
+                                        sel_bits |= (1u << h) << (2 * p);
+                                    }
+                                    n = __builtin_amdgcn_readfirstlane(n + (int)tk);
+                                    taken[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(taken[p] + tk));
+                                }
                             }
                         }
                     }
-                    __builtin_amdgcn_wave_barrier();  // the next half (or the next cluster's encode) rewrites the tile
-                };
-                if (valid_cluster) {
-                    f32x4 acc[MT][4];
-                    const unsigned long long t_e0 = F.diag ? wall_clock64() : 0;
-                    // ---- whose weights: the LDS copy (refilled when a sub-module takes over a window), or L2 for a minority's run
-                    bool from_lds = c_star == lds_cluster;
-                    if (!from_lds && (lds_cluster < 0 || __popcll(sel) >= F.switch_min)) {
-                        const uint4 *src = reinterpret_cast<const uint4 *>(F.frags + (size_t)c_star * S.frag_halfs);
-                        uint4 *dst = reinterpret_cast<uint4 *>(s_frag);
-                        const int n16 = S.frag_halfs / 8;
-#pragma unroll 4
-                        for (int i = lane; i < n16; i += 64) dst[i] = src[i];
-                        const float *bsrc = F.biases + (size_t)c_star * S.bias_floats;
-                        for (int i = lane; i < S.bias_floats; i += 64) s_bias[i] = bsrc[i];
-                        __builtin_amdgcn_wave_barrier();
-                        lds_cluster = c_star;
-                        from_lds = true;
-                        ++n_reloads;
+                }
+            };
+            // Which sub-module: the one this consumer ran last (its weights are in a slot) while plenty of its samples wait and nobody
+            // needs service -- a finished tile's ring is also served with that sub-module first, as long as the ring has any;
+            // otherwise the sub-module of the OLDEST waiting sample of the ring that needs service (or of the fullest ring).
+            int c_star = -2;
+            if (!service_stall && lds_cluster >= 0) {
+                select(lds_cluster, service, 0u);
+                uint32_t of_service = 0u;
+#pragma unroll
+                for (int p = 0; p < kF2RPC; ++p)
+                    if (p == service) of_service = taken[p];
+                if (service < 0 ? n >= F.switch_min : of_service > 0u) c_star = lds_cluster;
+            }
+            if (c_star == -2) {
+                int target = service;
+                if (target < 0) {
+                    uint32_t best = 0u;
+#pragma unroll
+                    for (int p = 0; p < kF2RPC; ++p) {
+                        if (scan[p] - evald[p] > best) {
+                            best = scan[p] - evald[p];
+                            target = p;
+                        }
                     }
-                    if (!from_lds) ++n_global;
-                    // ---- encode: lane j writes column j of the B operand (one 4 KB tile per K tile), as guided_fused_kernel does
-                    {
-                        float p[3], d[3];
-                        p[0] = (smp.x - S.center[0]) * S.inv_extent[0];
-                        p[1] = (smp.y - S.center[1]) * S.inv_extent[1];
-                        p[2] = (smp.z - S.center[2]) * S.inv_extent[2];
+                }
+                uint32_t first_half = 0u;  // of the target ring: the half (0: slots 0..63, 1: 64..127) that holds its oldest waiting sample
+#pragma unroll
+                for (int p = 0; p < kF2RPC; ++p) {
+                    if (p == target) {
+                        // waiting slots of ring p as a 128-bit mask, rotated so that bit 0 is slot floor_[p]: the first set bit is the oldest
+                        const uint64_t lo = __ballot((watch_pend >> (2 * p)) & 1u), hi = __ballot((watch_pend >> (2 * p + 1)) & 1u);
+                        if ((int32_t)(scan[p] - kF2Ring - floor_[p]) > 0) floor_[p] = scan[p] - kF2Ring;  // nothing older than a ring's length can wait
+                        const uint32_t st = floor_[p] & (kF2Ring - 1);
+                        const uint64_t a = st & 64u ? hi : lo, b = st & 64u ? lo : hi;  // [a | b] starts at slot (st & 64)
+                        const uint32_t sh = st & 63u;
+                        const uint64_t r0 = sh ? (a >> sh) | (b << (64u - sh)) : a, r1 = sh ? (b >> sh) | (a << (64u - sh)) : b;
+                        const uint32_t dist = r0 ? (uint32_t)__builtin_ctzll(r0) : 64u + (uint32_t)__builtin_ctzll(r1);
+                        const uint32_t slot = (st + dist) & (kF2Ring - 1);
+                        floor_[p] += dist;
+                        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)watch_cl[p], (int)(slot & 63u));
+                        c_star = (int)(int16_t)(slot & 64u ? w >> 16 : w & 0xffffu);
+                        first_half = slot >> 6;
+                    }
+                }
+                select(c_star, target, first_half);
+            }
+            s_watch[kF2RPC * 64] = watch_pend & ~sel_bits;
+            __builtin_amdgcn_wave_barrier();
+            const bool col_on = lane < n;
+            ++n_runs;
+            n_cols += (unsigned long long)n;
+            const bool valid_cluster = c_star >= 0 && c_star < S.n_clusters;
+
+            // ---- per column: transmittance factor and colour denominators of its sample (rt_core.cuh:356-392), SH basis of the
+            //      owner; 32 columns at a time (the output tile holds 32), two lanes per column: lane share 0 takes the opacity and
+            //      the first channel, share 1 the other two; the four floats replace the sample in its ring entry
+            auto evaluate = [&](int half, auto valid_tag) __attribute__((always_inline)) {
+                constexpr bool kValid = decltype(valid_tag)::value;
+                const int c32 = lane & 31, share = lane >> 5, jc = half * 32 + c32;
+                const bool on = jc < n;
+                if (on) {
+                    const uint32_t where_j = s_cols[jc];
+                    const int ring_j = (int)(where_j >> 7);
+                    const uint32_t e_j = where_j & (kF2Ring - 1);
+                    const uint32_t meta_j = ring_meta(ring_j)[e_j];
+                    const int owner_j = (rbase + ring_j) * 64 + (int)(meta_j & 63u);
+                    float *dst = reinterpret_cast<float *>(ring_data(ring_j) + e_j);
+                    const float dz_j = dst[3];  // read by both lane shares before either writes its results ...
+                    __builtin_amdgcn_wave_barrier();  // ... (the other share of this column writes dst[3]: the read must not sink into a branch)
+                    const bool last = (meta_j & 64u) != 0;
+                    if constexpr (BASIS >= 0) {
+                        // One instruction stream for both lane shares (a branch on the share would run both bodies, each on half the
+                        // lanes): every lane evaluates two channel sums at ITS offsets and two exponentials of ITS arguments.
+                        //   share 0: X = sigma * dz (feature 3), Y = channel 0   -> {last ? 0 : exp(-X), 1 + exp(-Y)}
+                        //   share 1: X = channel 1,              Y = channel 2   -> {1 + exp(-X),        1 + exp(-Y)}
+                        float basis[NB];
+#pragma unroll
+                        for (int k = 0; k < NB; ++k) basis[k] = s_ray[k * RB + owner_j];
+                        constexpr int stride = BASIS > 0 ? BASIS : 0;
+                        const float *col_out = s_out + c32;
+                        const int offA = share ? stride : 0, offB = share ? 2 * stride : 0;
+                        auto svA = [&](int f) -> float { return kValid ? col_out[(offA + f) * 32] : 0.f; };
+                        auto svB = [&](int f) -> float { return kValid ? col_out[(offB + f) * 32] : 0.f; };
+                        const float dA = sh_channel<BASIS>(basis, svA, 0), dB = sh_channel<BASIS>(basis, svB, 0);
+                        const float sig = kValid ? col_out[3 * 32] : 0.f;
+                        const float X = share ? dA : sig * dz_j, Y = share ? dB : dA;
+                        const float eX = exact_expf_select(-X, s_exp), eY = exact_expf_select(-Y, s_exp);
+                        const float out0 = share ? 1.f + eX : (last ? 0.f : eX), out1 = 1.f + eY;
+                        *reinterpret_cast<float2 *>(dst + 2 * share) = make_float2(out0, out1);
+                    } else {
+                        auto sv = [&](int f) -> float { return kValid ? s_out[f * 32 + c32] : 0.f; };  // no sub-module: zeros (mlp_histogram)
+                        if (share == 0) {
+                            const float att = exact_expf_select(-sv(3) * dz_j, s_exp);
+                            dst[0] = last ? 0.f : att;
+                            dst[1] = sv(0);
+                        } else {
+                            dst[2] = sv(1);
+                            dst[3] = sv(2);
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();  // the next half (or the next window's encode) rewrites the tile
+            };
+
+            if (valid_cluster) {
+                const unsigned long long t_e0 = F.diag ? wall_clock64() : 0;
+                // ---- the weights of the sub-module: kF2NS slots in LDS shared by the workgroup's consumers (any number may read a slot at
+                //      a time); a sub-module that is in no slot replaces the least recently used slot nobody reads (16 KB from L2)
+                int slot = held_slot;
+                if (held_slot < 0 || c_star != lds_cluster) {
+                    if (held_slot >= 0 && lane == 0) __hip_atomic_fetch_sub(s_wc + 2 + 4 * held_slot + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    uint32_t res = 0u;  // slot | 8: fill it, | 16: somebody else is filling it
+                    if (lane == 0) {
+                        for (;;) {
+                            while (atomicCAS(&s_wc[0], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(0);
+                            int hit = -1, victim = -1;
+                            uint32_t oldest = 0xffffffffu;
+#pragma unroll
+                            for (int k = 0; k < kF2NS; ++k) {
+                                if (k >= F.weight_slots) break;
+                                const uint32_t *w4 = s_wc + 2 + 4 * k;
+                                const uint32_t wcl = __hip_atomic_load(w4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), rd = __hip_atomic_load(w4 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP),
+                                               stp = __hip_atomic_load(w4 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if ((int)wcl == c_star) hit = k;
+                                else if (rd == 0u && stp < oldest) {
+                                    oldest = stp;
+                                    victim = k;
+                                }
+                            }
+                            const uint32_t now = __hip_atomic_load(&s_wc[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u;
+                            if (hit >= 0 || victim >= 0) {
+                                const int k = hit >= 0 ? hit : victim;
+                                uint32_t *w4 = s_wc + 2 + 4 * k;
+                                __hip_atomic_store(&s_wc[1], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_store(w4 + 3, now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                __hip_atomic_fetch_add(w4 + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (hit >= 0) {
+                                    res = (uint32_t)k | (__hip_atomic_load(w4 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) ? 16u : 0u);
+                                } else {
+                                    __hip_atomic_store(w4, (uint32_t)c_star, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    __hip_atomic_store(w4 + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    res = (uint32_t)k | 8u;
+                                }
+                            }
+                            __hip_atomic_store(&s_wc[0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (hit >= 0 || victim >= 0) break;
+                            __builtin_amdgcn_s_sleep(1);  // every slot is being read and none holds this sub-module: a reader will let go
+                        }
+                    }
+                    res = (uint32_t)__builtin_amdgcn_readfirstlane((int)res);
+                    slot = (int)(res & 7u);
+                    uint32_t *w4 = s_wc + 2 + 4 * slot;
+                    if (res & 8u) {
+                        const uint4 *src = reinterpret_cast<const uint4 *>(F.frags + (size_t)c_star * S.frag_halfs);
+                        uint4 *dst = reinterpret_cast<uint4 *>(s_mem + Lo.frags + slot * Lo.frag_words);
+                        const float *bsrc = F.biases + (size_t)c_star * S.bias_floats;
+                        float *bdst = reinterpret_cast<float *>(s_mem + Lo.bias + slot * Lo.bias_words);
+                        const int nfrag = S.frag_halfs / 512;  // whole fragments: 64 lanes x 16 bytes each
+                        float bv[4];  // the biases travel with the first batch of fragments (bias_floats <= 256 here: launch_accel)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) bv[u] = lane + 64 * u < S.bias_floats ? bsrc[lane + 64 * u] : 0.f;
+                        for (int u0 = 0; u0 < nfrag; u0 += 16) {  // every guard below is wave-uniform: the batch stays in registers, its loads in flight together
+                            uint4 v[16];
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) v[u] = src[(u0 + u < nfrag ? u0 + u : nfrag - 1) * 64 + lane];  // unconditional (a clamped index): registers, not a stack array
+#pragma unroll
+                            for (int u = 0; u < 16; ++u)
+                                if (u0 + u < nfrag) dst[(u0 + u) * 64 + lane] = v[u];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (lane + 64 * u < S.bias_floats) bdst[lane + 64 * u] = bv[u];
+                        st_release(w4 + 1, 0u);  // filled
+                        ++n_reloads;
+                        if (F.diag) t_reload += wall_clock64() - t_e0;
+                    } else if (res & 16u) {
+                        while (__builtin_amdgcn_readfirstlane((int)ld_relaxed(w4 + 1)) != 0) __builtin_amdgcn_s_sleep(0);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    lds_cluster = c_star;
+                    held_slot = slot;
+                }
+                const half8 *s_frag = reinterpret_cast<const half8 *>(s_mem + Lo.frags + slot * Lo.frag_words);
+                const float *s_bias = reinterpret_cast<const float *>(s_mem + Lo.bias + slot * Lo.bias_words);
+                // ---- encode: lane j builds column j of the B operand.  A column of one K tile is 64 bytes in operand order (the 8 halfs
+                //      of lane group g at byte 16 g: features 4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3), written as four 16-byte
+                //      stores.  Position features have compile-time places (p, then per octave three phase-0 and three phase-1/4
+                //      triangle waves), guarded per octave; view direction, embedding and padding follow with half-word stores.
+                const uint32_t where = col_on ? s_cols[lane] : 0u;
+                const float4 smp = col_on ? ring_data((int)(where >> 7))[where & (kF2Ring - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
+                {
+                    float p[3];
+                    p[0] = (smp.x - S.center[0]) * S.inv_extent[0];
+                    p[1] = (smp.y - S.center[1]) * S.inv_extent[1];
+                    p[2] = (smp.z - S.center[2]) * S.inv_extent[2];
+                    // position feature f of this column (0 beyond the network's octaves): f < 3 the coordinate itself, then per octave k
+                    // three phase-0 and three phase-1/4 triangle waves; f is a compile-time constant, the octave test is wave-uniform
+                    auto feat = [&](auto f_tag) __attribute__((always_inline)) -> float {
+                        constexpr int f = decltype(f_tag)::value;
+                        if constexpr (f < 3) {
+                            return p[f];
+                        } else {
+                            constexpr int k = (f - 3) / 6, r = (f - 3) % 6, i = r % 3;
+                            const float scale = __uint_as_float((uint32_t)(127 + k) << 23);
+                            return k < S.pos_octaves ? tri_wave(p[i] * scale + (r >= 3 ? 0.25f : 0.f)) : 0.f;
+                        }
+                    };
+                    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+                    typedef float float2v __attribute__((ext_vector_type(2)));
+                    uint4 *tile_q = reinterpret_cast<uint4 *>(s_tile);
+                    auto pair = [&](auto f_tag) __attribute__((always_inline)) -> uint32_t {
+                        constexpr int f = decltype(f_tag)::value;
+                        const float2v pr = {feat(std::integral_constant<int, f>{}), feat(std::integral_constant<int, f + 1>{})};
+                        return __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, half2v));
+                    };
+                    auto group = [&](auto kk_tag, auto gg_tag) __attribute__((always_inline)) {
+                        // elements 2 q, 2 q + 1 of lane group gg: features 16 (q >> 1) + 4 gg + 2 (q & 1) + {0, 1}
+                        constexpr int kk = decltype(kk_tag)::value, gg = decltype(gg_tag)::value, f0 = 32 * kk + 4 * gg;
+                        tile_q[kk * 256 + lane * 4 + gg] = make_uint4(pair(std::integral_constant<int, f0>{}), pair(std::integral_constant<int, f0 + 2>{}),
+                                                                      pair(std::integral_constant<int, f0 + 16>{}), pair(std::integral_constant<int, f0 + 18>{}));
+                    };
+                    auto k_tile = [&](auto kk_tag) __attribute__((always_inline)) {
+                        group(kk_tag, std::integral_constant<int, 0>{});
+                        group(kk_tag, std::integral_constant<int, 1>{});
+                        group(kk_tag, std::integral_constant<int, 2>{});
+                        group(kk_tag, std::integral_constant<int, 3>{});
+                    };
+                    k_tile(std::integral_constant<int, 0>{});
+                    if constexpr (NKK0 == 2) k_tile(std::integral_constant<int, 1>{});
+                    if (S.need_viewdir || S.n_embeddings > 0) {
+                        float d[3];
+                        const int owner_thread = (rbase + (int)(where >> 7)) * 64 + (int)(ring_meta((int)(where >> 7))[where & (kF2Ring - 1)] & 63u);
 #pragma unroll
                         for (int i = 0; i < 3; ++i) d[i] = S.need_viewdir ? s_ray[(NB + i) * RB + owner_thread] : 0.f;
-                        const uint16_t *emb = nullptr;
-                        if (S.n_embeddings > 0) {
-                            int idx = (int)(float)F.appearance_embedding;
-                            idx = idx < 0 ? 0 : (idx >= S.n_embeddings ? S.n_embeddings - 1 : idx);
-                            emb = F.embeddings + ((size_t)c_star * S.n_embeddings + idx) * S.embedding_dim;
-                        }
                         _Float16 *tile_h = reinterpret_cast<_Float16 *>(s_tile);
                         auto put = [&](int f, float v) {  // f is wave-uniform
                             const int r = f & 31;
-                            const int dw = ((((r & 15) >> 2) * 4 + (((r >> 4) * 4 + (r & 3)) >> 1)) * 64) + (f >> 5) * (16 * 64);
-                            tile_h[(dw + lane) * 2 + (r & 1)] = (_Float16)v;  // element e = (r >> 4) * 4 + (r & 3): its low bit is r & 1
+                            tile_h[(f >> 5) * 2048 + lane * 32 + ((r & 15) >> 2) * 8 + (r >> 4) * 4 + (r & 3)] = (_Float16)v;
                         };
-                        auto octaves = [&](int base, int n_oct, const float x[3]) {
+                        if (S.need_viewdir) {
+                            const int base = S.n_pos;
 #pragma unroll
-                            for (int i = 0; i < 3; ++i) put(base + i, x[i]);
-                            for (int k = 0; k < n_oct; ++k) {
+                            for (int i = 0; i < 3; ++i) put(base + i, d[i]);
+                            for (int k = 0; k < S.dir_octaves; ++k) {
                                 const float scale = __uint_as_float((uint32_t)(127 + k) << 23);
 #pragma unroll
                                 for (int i = 0; i < 3; ++i) {
-                                    put(base + 3 + 6 * k + i, tri_wave(x[i] * scale + 0.f));
-                                    put(base + 3 + 6 * k + 3 + i, tri_wave(x[i] * scale + 0.25f));
+                                    put(base + 3 + 6 * k + i, tri_wave(d[i] * scale + 0.f));
+                                    put(base + 3 + 6 * k + 3 + i, tri_wave(d[i] * scale + 0.25f));
                                 }
                             }
-                        };
-                        octaves(0, S.pos_octaves, p);
-                        if (S.need_viewdir) octaves(S.n_pos, S.dir_octaves, d);
-                        const int emb_base = S.n_pos + S.n_dir;
-                        for (int j = 0; j < S.embedding_dim; ++j) put(emb_base + j, half_bits_to_float(emb[j]));
-                        for (int f = S.in_dim; f < 32 * NKK0; ++f) put(f, 0.f);  // padding features: finite (their weights are zero)
-                        __builtin_amdgcn_wave_barrier();
+                        }
+                        if (S.n_embeddings > 0) {
+                            int idx = (int)(float)F.appearance_embedding;
+                            idx = idx < 0 ? 0 : (idx >= S.n_embeddings ? S.n_embeddings - 1 : idx);
+                            const uint16_t *emb = F.embeddings + ((size_t)c_star * S.n_embeddings + idx) * S.embedding_dim;
+                            const int emb_base = S.n_pos + S.n_dir;
+                            for (int j = 0; j < S.embedding_dim; ++j) put(emb_base + j, half_bits_to_float(emb[j]));
+                        }
                     }
-                    // ---- the layers: weights = A operand, 16 samples of a column tile = B; a layer's C layout is the next layer's B layout
-                    auto network = [&](const half8 *w, const float *b) {
-                        auto bias_tile = [&](int mt) -> f32x4 { return *reinterpret_cast<const f32x4 *>(b + 16 * mt + 4 * g); };
+                    __builtin_amdgcn_wave_barrier();
+                }
+                // ---- the layers: weights = A operand (from LDS), 16 samples of a column tile = B; a layer's C layout is the next layer's B
+                //      layout.  Every layer runs over the columns in two halves (column tiles 0-1, then 2-3): the B operands of one half
+                //      are 8 to 16 registers instead of 32 and the previous layer's accumulators die half by half, so that the 64
+                //      accumulators, the operands and the fragments in flight stay inside the 128-register budget without spills
+                //      (the price: a layer's fragments are read from LDS twice).
+                f32x4 acc[MT][4];
+                const half8 *w = s_frag;
+                const float *b = s_bias;
+                auto bias_tile = [&](int mt) __attribute__((always_inline)) -> f32x4 { return *reinterpret_cast<const f32x4 *>(b + 16 * mt + 4 * g); };
+                {
+                    const uint4 *tile_q = reinterpret_cast<const uint4 *>(s_tile);
 #pragma unroll
-                        for (int kk = 0; kk < NKK0; ++kk) {
-                            half8 bf[4];
+                    for (int h = 0; h < 2; ++h) {
+                        half8 bf[NKK0][2];
 #pragma unroll
-                            for (int nt = 0; nt < 4; ++nt) {
-                                union {
-                                    uint32_t u[4];
-                                    half8 h;
-                                } rd;
+                        for (int kk = 0; kk < NKK0; ++kk)
 #pragma unroll
-                                for (int q4 = 0; q4 < 4; ++q4) rd.u[q4] = s_tile[kk * (16 * 64) + (g * 4 + q4) * 64 + nt * 16 + col];
-                                bf[nt] = rd.h;
-                            }
-                            if (kk == 0) {
-#pragma unroll
-                                for (int mt = 0; mt < MT; ++mt) {
-                                    const f32x4 bv = bias_tile(mt);
-#pragma unroll
-                                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = bv;
-                                }
-                            }
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt) {
-                                const half8 a = w[(mt * NKK0 + kk) * 64 + lane];
-#pragma unroll
-                                for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[nt], acc[mt][nt], 0, 0, 0);
-                            }
-                        }
-                        __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the outputs
-                        if (F.diag) t_enc += wall_clock64() - t_e0;
-                        w += MT * NKK0 * 64;
-                        b += 16 * MT;
-                        for (int layer = 1; layer <= S.hidden_layers; ++layer) {
-                            const int n_mt = layer < S.hidden_layers ? MT : S.mt_out;
-                            half8 bf[MT / 2][4];
-#pragma unroll
-                            for (int kk = 0; kk < MT / 2; ++kk)
-#pragma unroll
-                                for (int nt = 0; nt < 4; ++nt) bf[kk][nt] = relu_pack(acc[2 * kk][nt], acc[2 * kk + 1][nt]);
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt) {
-                                if (mt < n_mt) {
-                                    const f32x4 bv = bias_tile(mt);
-#pragma unroll
-                                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = bv;
-#pragma unroll
-                                    for (int kk = 0; kk < MT / 2; ++kk) {
-                                        const half8 a = w[(mt * (MT / 2) + kk) * 64 + lane];
-#pragma unroll
-                                        for (int nt = 0; nt < 4; ++nt)
-                                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[kk][nt], acc[mt][nt], 0, 0, 0);
-                                    }
-                                }
-                            }
-                            w += n_mt * (MT / 2) * 64;
-                            b += 16 * n_mt;
-                        }
-                    };
-                    if (from_lds) network(s_frag, s_bias);
-                    else network(reinterpret_cast<const half8 *>(F.frags + (size_t)c_star * S.frag_halfs), F.biases + (size_t)c_star * S.bias_floats);
-                    if (F.diag) t_lay += wall_clock64() - t_e0;
-                    const unsigned long long t_c0 = F.diag ? wall_clock64() : 0;
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
+                            for (int j = 0; j < 2; ++j) bf[kk][j] = __builtin_bit_cast(half8, tile_q[kk * 256 + ((2 * h + j) * 16 + col) * 4 + g]);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
-                            if (mt < S.mt_out) {
+                            const f32x4 bv = bias_tile(mt);
 #pragma unroll
-                                for (int nn = 0; nn < 2; ++nn)
+                            for (int kk = 0; kk < NKK0; ++kk) {
+                                const half8 a = w[(mt * NKK0 + kk) * 64 + lane];
 #pragma unroll
-                                    for (int r = 0; r < 4; ++r) s_out[(16 * mt + 4 * g + r) * 32 + nn * 16 + col] = acc[mt][2 * half + nn][r];
+                                for (int j = 0; j < 2; ++j)
+                                    acc[mt][2 * h + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[kk][j], kk == 0 ? bv : acc[mt][2 * h + j], 0, 0, 0);
                             }
                         }
-                        __builtin_amdgcn_wave_barrier();
-                        evaluate(half, std::true_type{});
                     }
-                    if (F.diag) t_eval += wall_clock64() - t_c0;
-                } else {
-                    evaluate(0, std::false_type{});
-                    evaluate(1, std::false_type{});
                 }
-            }
-            // ---- publish: the owners may composite these entries (and their slots come free once they have)
+                __builtin_amdgcn_wave_barrier();  // the tile is rewritten by the outputs
+                if (F.diag) t_enc += wall_clock64() - t_e0;
+                w += MT * NKK0 * 64;
+                b += 16 * MT;
+                for (int layer = 1; layer <= S.hidden_layers; ++layer) {
+                    const int n_mt = layer < S.hidden_layers ? MT : S.mt_out;
 #pragma unroll
-            for (int p = 0; p < kF2NP; ++p) {
-                if (take[p] != 0u) {
-                    rdy[p] += take[p];
-                    st_release(s_ctrl + 4 * p + 2, rdy[p]);
+                    for (int h = 0; h < 2; ++h) {
+                        half8 bf[MT / 2][2];
+#pragma unroll
+                        for (int kk = 0; kk < MT / 2; ++kk)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) bf[kk][j] = relu_pack(acc[2 * kk][2 * h + j], acc[2 * kk + 1][2 * h + j]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            if (mt < n_mt) {
+                                const half8 a0 = w[(mt * 2 + 0) * 64 + lane], a1 = w[(mt * 2 + 1) * 64 + lane];
+                                const f32x4 bv = bias_tile(mt);
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) acc[mt][2 * h + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bf[0][j], bv, 0, 0, 0);
+#pragma unroll
+                                for (int j = 0; j < 2; ++j) acc[mt][2 * h + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf[1][j], acc[mt][2 * h + j], 0, 0, 0);
+                            }
+                        }
+                    }
+                    w += n_mt * (MT / 2) * 64;
+                    b += 16 * n_mt;
+                }
+                // done reading the slot.  With a slot per consumer the reference is kept until this consumer changes sub-module or idles (one
+                // that asks for a slot holds none, so a slot nobody reads always exists); with fewer slots it is dropped after every run.
+                if (F.weight_slots < kF2NC) {
+                    if (lane == 0) __hip_atomic_fetch_sub(s_wc + 2 + 4 * slot + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    held_slot = -1;
+                }
+                if (F.diag) t_lay += wall_clock64() - t_e0;
+                const unsigned long long t_c0 = F.diag ? wall_clock64() : 0;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        if (mt < S.mt_out) {
+#pragma unroll
+                            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) s_out[(16 * mt + 4 * g + r) * 32 + nn * 16 + col] = acc[mt][2 * half + nn][r];
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    evaluate(half, std::true_type{});
+                }
+                if (F.diag) t_eval += wall_clock64() - t_c0;
+            } else {
+                evaluate(0, std::false_type{});
+                evaluate(1, std::false_type{});
+            }
+            // ---- publish: mark the entries, then the counters (the owners composite them; their slots come free once they have)
+            if (col_on) {
+                const uint32_t where = s_cols[lane];
+                __hip_atomic_fetch_or(ring_meta((int)(where >> 7)) + (where & (kF2Ring - 1)), kF2Ready, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // after the results
+            }
+#pragma unroll
+            for (int p = 0; p < kF2RPC; ++p) {
+                if (taken[p] != 0u) {
+                    evald[p] += taken[p];
+                    st_release(s_rctrl + 8 * p + 2, evald[p]);
                 }
             }
             if (F.diag) t_busy += wall_clock64() - t_w0;
@@ -747,9 +1041,9 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
             if (spins > 64u * kF2SpinLimit) atomicAdd(F.diag + F2Diag::kWatchdog, 1ull);
             atomicAdd(F.diag + F2Diag::kConsSimd + (__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3), 1ull);
             atomicAdd(F.diag + F2Diag::kRuns, n_runs);
-            atomicAdd(F.diag + F2Diag::kWindows, n_windows);
+            atomicAdd(F.diag + F2Diag::kWindows, n_runs);
             atomicAdd(F.diag + F2Diag::kReloads, n_reloads);
-            atomicAdd(F.diag + F2Diag::kGlobalRuns, n_global);
+            atomicAdd(F.diag + F2Diag::kGlobalRuns, t_reload);  // (the slot of the retired L2 path: ticks spent refilling the weights)
             atomicAdd(F.diag + F2Diag::kColumns, n_cols);
             atomicAdd(F.diag + F2Diag::kConsBusy, t_busy);
             atomicAdd(F.diag + F2Diag::kConsTotal, wall_clock64() - t_begin);

@@ -1226,18 +1226,20 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     int rc = kUnsupportedBasis;
     const int b = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim >= 0) ? accel->view.basis_dim : -1;
     if (track && track->fused) {
-        const FusedGuided &F = *track->fused;
         const int nb = b > 0 ? b : 1;
-        const bool two = F.S.nkk0 == 2;  // mnv_render_guided_fused admits 1 and 2
+        const bool two = track->fused->S.nkk0 == 2;  // mnv_render_guided_fused admits 1 and 2
         const bool trk = K.split_track || K.sample_track || K.visited;
         // producer / consumer wavefronts when one sub-module's weights fit a workgroup's LDS beside the rings (at least two workgroups per CU)
-        const size_t f2_bytes = (size_t)f2_layout(nb, lds_level, F.S).total * 4;
+        FusedGuided F = *track->fused;
+        int slots = kF2NS;  // weight slots: as many as fit beside the rings (at least one per two consumers)
+        while (slots > 1 && (size_t)f2_layout(nb, lds_level, F.S, slots).total * 4 > (size_t)160 * 1024 / (16 / (kF2NP + kF2NC))) --slots;
+        F.weight_slots = slots;
+        const size_t f2_bytes = (size_t)f2_layout(nb, lds_level, F.S, slots).total * 4;
         const int version = g_fused_kernel.load(std::memory_order_relaxed);
-        const bool fits2 = f2_bytes <= 80 * 1024;
-        if (version == 2 && !fits2) return set_error(MNV_E_UNSUPPORTED, "the network's weights do not fit a workgroup's LDS: use the one-role kernel");
-        if (version == 2 || (version == 0 && fits2 && kF2Default)) {
+        const bool fits2 = f2_bytes <= (size_t)160 * 1024 && 2 * slots >= kF2NC && F.S.bias_floats <= 256;  // (a consumer refills a sub-module's biases with four loads per lane)
+        if (fits2 && (version == 2 || (version == 0 && kF2Default))) {
             int per_cu = (int)((size_t)160 * 1024 / f2_bytes);
-            const int by_regs = (4 * kF2WavesPerSimd) / (kF2NP + 1);
+            const int by_regs = (4 * kF2WavesPerSimd) / (kF2NP + kF2NC);
             if (per_cu > by_regs) per_cu = by_regs;
             static const int env_f2 = getenv("MNV_F2_BLOCKS_PER_CU") ? atoi(getenv("MNV_F2_BLOCKS_PER_CU")) : 0;
             if (env_f2 > 0 && env_f2 < per_cu) per_cu = env_f2;
@@ -1825,7 +1827,7 @@ static int guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv
     F.batch_min = env_batch < 1 ? 1 : (env_batch > kFW ? kFW : env_batch);
     F.sample_counter = sample_counter;
     F.diag = g_fused_diag.load(std::memory_order_relaxed);
-    static const int env_switch = getenv("MNV_F2_SWITCH_MIN") ? atoi(getenv("MNV_F2_SWITCH_MIN")) : 24;
+    static const int env_switch = getenv("MNV_F2_SWITCH_MIN") ? atoi(getenv("MNV_F2_SWITCH_MIN")) : 32;
     F.switch_min = env_switch;
     AccelTrack track = {};
     track.fused = &F;

@@ -72,14 +72,27 @@ __host__ __device__ inline float encode_feature(const MlpShape &S, int f, const 
     return 0.f;  // embedding features are looked up by the caller
 }
 
+// ReLU + binary16 rounding of eight accumulators.  Rounding first and clamping the packed halves as signed 16-bit integers (a
+// half with its sign bit set -- negative or -0 -- is a negative integer) gives the bits of half(max(x, 0)) for every non-NaN x:
+// rounding is monotonic and keeps the sign.  Two instructions per pair (v_cvt_pk_f16_f32, v_pk_max_i16) instead of five
+// (fmaxf lowers to a canonicalising v_max plus the v_max itself, per value).
 __device__ inline half8 relu_pack(const f32x4 &lo, const f32x4 &hi) {
-    half8 h;
+    typedef short short2v __attribute__((ext_vector_type(2)));
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    typedef float float2v __attribute__((ext_vector_type(2)));
+    union {
+        half8 h;
+        short2v s[4];
+    } u;
+    const short2v zero = {0, 0};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        h[r] = (_Float16)fmaxf(lo[r], 0.f);
-        h[4 + r] = (_Float16)fmaxf(hi[r], 0.f);
+    for (int r = 0; r < 2; ++r) {
+        const float2v fa = {lo[2 * r], lo[2 * r + 1]}, fb = {hi[2 * r], hi[2 * r + 1]};
+        const half2v a = __builtin_convertvector(fa, half2v), b = __builtin_convertvector(fb, half2v);  // round to nearest even, as (_Float16)x
+        u.s[r] = __builtin_elementwise_max(__builtin_bit_cast(short2v, a), zero);
+        u.s[2 + r] = __builtin_elementwise_max(__builtin_bit_cast(short2v, b), zero);
     }
-    return h;
+    return u.h;
 }
 
 }  // namespace mnv

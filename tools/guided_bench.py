@@ -108,7 +108,7 @@ for version, name in ((2, "producer_consumer"), (1, "one_role")):
             names = ["-", "runs", "march_iters", "windows", "weight_reloads", "runs_from_l2", "cons_busy", "cons_total", "prod_total", "prod_ring_wait",
                      "prod_flush_wait", "encode_l0", "layers_total", "eval", "columns", "watchdog"]
             dd = dict(zip(names, d))
-            r.update(runs=dd["runs"], windows=dd["windows"], weight_reloads=dd["weight_reloads"], runs_from_l2=dd["runs_from_l2"], march_iters=dd["march_iters"],
+            r.update(runs=dd["runs"], weight_reloads=dd["weight_reloads"], us_per_reload=round(dd["runs_from_l2"] / 100.0 / max(1, dd["weight_reloads"]), 2), march_iters=dd["march_iters"],
                      columns_per_run=round(dd["columns"] / max(1, dd["runs"]), 2), watchdog=dd["watchdog"],
                      us_per_run=round(dd["cons_busy"] / 100.0 / max(1, dd["runs"]), 2),
                      us_per_run_encode_l0=round(dd["encode_l0"] / 100.0 / max(1, dd["runs"]), 2),
@@ -117,7 +117,8 @@ for version, name in ((2, "producer_consumer"), (1, "one_role")):
                      consumer_busy_frac=round(dd["cons_busy"] / max(1, dd["cons_total"]), 3),
                      producer_ring_wait_frac=round(dd["prod_ring_wait"] / max(1, dd["prod_total"]), 3),
                      producer_flush_wait_frac=round(dd["prod_flush_wait"] / max(1, dd["prod_total"]), 3),
-                     sum_consumer_ticks=dd["cons_total"], sum_producer_ticks=dd["prod_total"], consumers_per_simd=d[16:20], producers_per_simd=d[20:24])
+                     sum_consumer_ticks=dd["cons_total"], sum_producer_ticks=dd["prod_total"], consumers_per_simd=d[16:20], producers_per_simd=d[20:24],
+                     producer_frac_walk_setup_step_push=[round(d[i] / max(1, dd["prod_total"]), 3) for i in (24, 25, 26, 27)])
     res[name] = r
 mnv.set_fused_kernel(0)
 print(json.dumps(res))
