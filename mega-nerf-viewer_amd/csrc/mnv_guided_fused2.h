@@ -31,24 +31,39 @@
 namespace mnv {
 
 // Shape of a workgroup: NP producer wavefronts, NC consumer wavefronts (consumer c serves the rings of producers c * NP / NC ...),
-// NS weight slots in LDS shared by the consumers.  Default: the workgroup is a whole CU's worth of wavefronts at 128 VGPRs --
-// 12 producers + 4 consumers (one per SIMD) and the weights of four sub-modules resident (the tiles a CU holds at a time are
-// neighbours on the screen: front and back of a surface, now and then a third sub-module at a boundary).
+// NS weight slots in LDS shared by the consumers, rings of MNV_F2_RING slots.  The workgroup is a whole CU's worth of wavefronts at
+// 128 VGPRs.  Measured on cfg2 at 1080p (tools/f2_variants.sh, LAB_NOTEBOOK.md): 8 + 8 with 256-slot rings and two weight slots
+// 1.32 ms; 10 + 5 (256 slots, 2 weight slots) 1.39; 8 + 8 with 128-slot rings and four weight slots 1.45; 12 + 4 (128, 4) 1.53;
+// the one-role kernel 1.43.  Deep rings matter more than resident weights: the rays of an 8x8 tile reach a surface together, so
+// a producer emits its samples in bursts that a 128-slot ring cannot absorb.
 #ifndef MNV_F2_NP
-#define MNV_F2_NP 12
+#define MNV_F2_NP 8
 #endif
 #ifndef MNV_F2_NC
-#define MNV_F2_NC 4
+#define MNV_F2_NC 8
 #endif
 #ifndef MNV_F2_NS
-#define MNV_F2_NS 4
+#define MNV_F2_NS 2
+#endif
+#ifndef MNV_F2_COLS
+#define MNV_F2_COLS 64  // columns (samples) of a network run: 64, or 32 (half the accumulators: a smaller register budget, more wavefronts)
+#endif
+#ifndef MNV_F2_WAVES
+#define MNV_F2_WAVES 4  // wavefronts per SIMD the kernel is compiled for: 4 (128 VGPRs), 5 (96), 6 (80)
 #endif
 constexpr int kF2NP = MNV_F2_NP, kF2NC = MNV_F2_NC, kF2NS = MNV_F2_NS, kF2RPC = kF2NP / kF2NC;  // RPC: rings per consumer
+constexpr int kF2Cols = MNV_F2_COLS, kF2NT = kF2Cols / 16, kF2Halves = kF2Cols / 32;
+static_assert(kF2Cols == 64 || kF2Cols == 32, "a run is 64 or 32 columns");
 constexpr int kF2Block = 64 * (kF2NP + kF2NC);
-constexpr int kF2Ring = 128;                       // slots per producer ring: one march step adds at most 64 samples
+#ifndef MNV_F2_RING
+#define MNV_F2_RING 256
+#endif
+constexpr int kF2Ring = MNV_F2_RING;               // slots per producer ring (128 or 256): one march step adds at most 64 samples
+constexpr int kF2RingLog = kF2Ring == 256 ? 8 : 7, kF2RH = kF2Ring / 64;  // RH: slots of a ring that one consumer lane watches
+static_assert(kF2Ring == 128 || kF2Ring == 256, "ring size");
 constexpr int kF2RingWords = kF2Ring * (4 + 1 + 1);  // float4 {x, y, z, dz} -> {att, d0, d1, d2} | meta | owner's next slot
-constexpr int kF2WavesPerSimd = 4;                 // register budget: 128 VGPRs
-constexpr bool kF2Default = false;                 // mnv_set_fused_kernel(0) picks this kernel when it fits (until it is the faster one: no)
+constexpr int kF2WavesPerSimd = MNV_F2_WAVES;      // register budget: 128 / 96 / 80 VGPRs
+constexpr bool kF2Default = true;                  // mnv_set_fused_kernel(0) picks this kernel when it fits
 constexpr uint32_t kF2Ready = 128u;                // meta bit: the entry holds its results
 static_assert(kF2NP % kF2NC == 0 && kF2RPC >= 1 && kF2RPC <= 4 && kF2Block <= 1024 && kF2NS >= 1 && kF2NS <= 7, "workgroup shape");
 // Watchdog of the spin-waits: a wait that lasts this many polls (s_sleep 1-2 each: tens of milliseconds; a healthy wait is a few
@@ -69,13 +84,13 @@ __host__ __device__ inline F2Layout f2_layout(int nb, int lds_level, const MlpSh
     L.ctrl = L.rings + kF2NP * kF2RingWords;
     L.cols = L.ctrl + 8 * kF2NP;                          // 8 words per ring
     L.watch = L.cols + 64 * kF2NC;                        // column -> (ring, slot) of every consumer's current window
-    L.wcache = L.watch + (kF2RPC + 1) * 64 * kF2NC;       // per consumer and lane: what waits in the slots the lane watches (between windows the registers belong to the network)
+    L.wcache = L.watch + (kF2RPC * (kF2RH / 2) + 1) * 64 * kF2NC;       // per consumer and lane: what waits in the slots the lane watches (between windows the registers belong to the network)
     L.frags = L.wcache + 32;                              // weight cache: lock, clock, per slot {cluster, state, readers, stamp}
     L.frag_words = S.frag_halfs / 2;
     L.bias_words = (S.bias_floats + 3) & ~3;
     L.bias = L.frags + slots * L.frag_words;
     L.tile = L.bias + slots * L.bias_words;
-    const int enc = S.nkk0 * 16 * 64, out = 16 * S.mt_out * 32;  // encode tiles (one per K tile); outputs of 32 columns at a time
+    const int enc = S.nkk0 * 16 * kF2Cols, out = 16 * S.mt_out * 32;  // encode tiles (one per K tile); outputs of 32 columns at a time
     L.tile_words = enc > out ? enc : out;
     L.total = L.tile + kF2NC * L.tile_words;
     return L;
@@ -141,7 +156,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
         const int cells = 1 << (3 * LL);
         if (threadIdx.x < 32) s_exp[threadIdx.x] = kExp2fTab[threadIdx.x];
         for (int i = threadIdx.x; i < 8 * kF2NP; i += kF2Block) s_ctrl[i] = 0u;
-        for (int i = threadIdx.x; i < (kF2RPC + 1) * 64 * kF2NC; i += kF2Block) s_mem[Lo.watch + i] = 0u;
+        for (int i = threadIdx.x; i < (kF2RPC * (kF2RH / 2) + 1) * 64 * kF2NC; i += kF2Block) s_mem[Lo.watch + i] = 0u;
         if (threadIdx.x < 32) s_mem[Lo.wcache + threadIdx.x] = threadIdx.x >= 2 && ((threadIdx.x - 2) & 3) == 0 ? 0xffffffffu : 0u;  // slots: no cluster
         for (int i = threadIdx.x; i < cells; i += kF2Block) {
             const int G = 1 << LL;
@@ -558,13 +573,15 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
         uint32_t *s_rctrl = s_ctrl + 8 * rbase;
         auto ring_data = [&](int p) { return reinterpret_cast<float4 *>(s_mem + Lo.rings + (rbase + p) * kF2RingWords); };  // p: ring of this consumer
         auto ring_meta = [&](int p) { return s_mem + Lo.rings + (rbase + p) * kF2RingWords + 4 * kF2Ring; };
-        // this lane watches slots `lane` and `lane + 64` of every ring: is an unevaluated sample there, and of which sub-module
-        // (kept in LDS between windows -- s_watch[k * 64 + lane], k < RPC: clusters, k == RPC: waiting bits -- so that nothing of it
-        // occupies registers while the network runs)
-        uint32_t *s_watch = s_mem + Lo.watch + ci * (kF2RPC + 1) * 64 + lane;
-        uint32_t scan[kF2RPC], evald[kF2RPC], floor_[kF2RPC];  // per ring (wave-uniform): entries registered, evaluated; a lower bound of the oldest waiting slot
+        // this lane watches slots `lane + 64 h` (h < RH) of every ring: is an unevaluated sample there, and of which sub-module
+        // (kept in LDS between windows -- s_watch[k * 64 + lane]: first the cluster words (two 16-bit clusters each), then the waiting
+        // bits -- so that nothing of it occupies registers while the network runs)
+        constexpr int WCL = kF2RH / 2, WWORDS = kF2RPC * WCL + 1;
+        static_assert(kF2RPC * kF2RH <= 32, "waiting bits fit a word");
+        uint32_t *s_watch = s_mem + Lo.watch + ci * WWORDS * 64 + lane;
+        uint32_t scan[kF2RPC], evald[kF2RPC];  // per ring (wave-uniform): entries registered, evaluated
 #pragma unroll
-        for (int p = 0; p < kF2RPC; ++p) scan[p] = evald[p] = floor_[p] = 0u;
+        for (int p = 0; p < kF2RPC; ++p) scan[p] = evald[p] = 0u;
         int lds_cluster = -1;  // the sub-module this consumer ran last (its weights are most likely still in a slot)
         int held_slot = -1;    // the weight slot this consumer holds a reader's reference on
         uint32_t spins = 0;
@@ -572,11 +589,14 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
 
         for (;;) {
             // ---- what has arrived: register the new entries of every ring with their watcher lanes
-            uint32_t watch_cl[kF2RPC];  // clusters of the two slots this lane watches in ring p: low / high 16 bits
-            uint32_t watch_pend;        // bit 2p: slot `lane` of ring p waits, bit 2p + 1: slot `lane + 64`
+            uint32_t watch_cl[kF2RPC][WCL];  // clusters of the slots this lane watches in ring p: slot lane + 64 h in half (h & 1) of word h >> 1
+            uint32_t watch_pend;             // bit RH * p + h: slot lane + 64 h of ring p waits
 #pragma unroll
-            for (int p = 0; p < kF2RPC; ++p) watch_cl[p] = s_watch[p * 64];
-            watch_pend = s_watch[kF2RPC * 64];
+            for (int p = 0; p < kF2RPC; ++p)
+#pragma unroll
+                for (int k = 0; k < WCL; ++k) watch_cl[p][k] = s_watch[(p * WCL + k) * 64];
+            watch_pend = s_watch[kF2RPC * WCL * 64];
+            auto cl_of = [&](int p, int h) __attribute__((always_inline)) -> int { return (int)(int16_t)((h & 1) ? watch_cl[p][h >> 1] >> 16 : watch_cl[p][h >> 1] & 0xffffu); };
             uint32_t total = 0;
             bool all_exited = true;
             int service = -1;  // a ring whose producer waits for it (tile finished, or no room for another step)
@@ -596,13 +616,13 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                     const uint32_t fresh = tl[p] - scan[p];
                     if (fresh != 0u) {
                         const uint32_t *meta_p = ring_meta(p);
-                        if ((((uint32_t)lane - scan[p]) & (kF2Ring - 1)) < fresh) {
-                            watch_cl[p] = (watch_cl[p] & 0xffff0000u) | ((meta_p[lane] >> 8) & 0xffffu);
-                            watch_pend |= 1u << (2 * p);
-                        }
-                        if ((((uint32_t)lane + 64u - scan[p]) & (kF2Ring - 1)) < fresh) {
-                            watch_cl[p] = (watch_cl[p] & 0xffffu) | ((meta_p[lane + 64] >> 8) << 16);
-                            watch_pend |= 2u << (2 * p);
+#pragma unroll
+                        for (int h = 0; h < kF2RH; ++h) {
+                            if ((((uint32_t)lane + 64u * h - scan[p]) & (kF2Ring - 1)) < fresh) {
+                                const uint32_t c16 = (meta_p[lane + 64 * h] >> 8) & 0xffffu;
+                                watch_cl[p][h >> 1] = (h & 1) ? (watch_cl[p][h >> 1] & 0xffffu) | (c16 << 16) : (watch_cl[p][h >> 1] & 0xffff0000u) | c16;
+                                watch_pend |= 1u << (kF2RH * p + h);
+                            }
                         }
                         scan[p] = tl[p];
                     }
@@ -618,8 +638,10 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                 }
             }
 #pragma unroll
-            for (int p = 0; p < kF2RPC; ++p) s_watch[p * 64] = watch_cl[p];
-            s_watch[kF2RPC * 64] = watch_pend;
+            for (int p = 0; p < kF2RPC; ++p)
+#pragma unroll
+                for (int k = 0; k < WCL; ++k) s_watch[(p * WCL + k) * 64] = watch_cl[p][k];
+            s_watch[kF2RPC * WCL * 64] = watch_pend;
             if (total == 0) {
                 if (held_slot >= 0) {  // idle: let the others replace the slot
                     if (lane == 0) __hip_atomic_fetch_sub(s_wc + 2 + 4 * held_slot + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -656,17 +678,19 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                     for (int p = 0; p < kF2RPC; ++p) {
                         if ((p == first) == (pass == 0)) {
 #pragma unroll
-                            for (int hh = 0; hh < 2; ++hh) {
-                                const uint32_t h = p == first ? (uint32_t)hh ^ half : (uint32_t)hh;  // wave-uniform
-                                const uint32_t cl16 = h ? watch_cl[p] >> 16 : watch_cl[p] & 0xffffu;
-                                const bool match = ((watch_pend >> (2 * p)) & (1u << h)) != 0u && (int)(int16_t)cl16 == c;
+                            for (int hh = 0; hh < kF2RH; ++hh) {
+                                const int h = p == first ? (hh + (int)half) & (kF2RH - 1) : hh;  // wave-uniform
+                                bool match = false;  // (a compile-time h inside: the cluster words are indexed statically)
+#pragma unroll
+                                for (int hc = 0; hc < kF2RH; ++hc)
+                                    if (hc == h) match = ((watch_pend >> (kF2RH * p + hc)) & 1u) != 0u && cl_of(p, hc) == c;
                                 const uint64_t msk = __ballot(match);
-                                if (msk != 0 && n < 64) {
-                                    const uint32_t k = (uint32_t)__popcll(msk), tk = k < (uint32_t)(64 - n) ? k : (uint32_t)(64 - n);
+                                if (msk != 0 && n < kF2Cols) {
+                                    const uint32_t k = (uint32_t)__popcll(msk), tk = k < (uint32_t)(kF2Cols - n) ? k : (uint32_t)(kF2Cols - n);
                                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(msk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)msk, 0u));
                                     if (match && rank < tk) {
-                                        s_cols[n + (int)rank] = ((uint32_t)p << 7) | (h << 6) | (uint32_t)lane;
-                                        sel_bits |= (1u << h) << (2 * p);
+                                        s_cols[n + (int)rank] = ((uint32_t)p << kF2RingLog) | ((uint32_t)h << 6) | (uint32_t)lane;
+                                        sel_bits |= 1u << (kF2RH * p + h);
                                     }
                                     n = __builtin_amdgcn_readfirstlane(n + (int)tk);
                                     taken[p] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(taken[p] + tk));
@@ -680,13 +704,20 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
             // needs service -- a finished tile's ring is also served with that sub-module first, as long as the ring has any;
             // otherwise the sub-module of the OLDEST waiting sample of the ring that needs service (or of the fullest ring).
             int c_star = -2;
-            if (!service_stall && lds_cluster >= 0) {
-                select(lds_cluster, service, 0u);
-                uint32_t of_service = 0u;
+            if (!service_stall) {
+                // candidates: this consumer's last sub-module, then whatever the workgroup's weight slots hold (a run of those costs no refill)
 #pragma unroll
-                for (int p = 0; p < kF2RPC; ++p)
-                    if (p == service) of_service = taken[p];
-                if (service < 0 ? n >= F.switch_min : of_service > 0u) c_star = lds_cluster;
+                for (int k = -1; k < kF2NS; ++k) {
+                    if (c_star != -2 || k >= F.weight_slots) break;
+                    const int cand = k < 0 ? lds_cluster : __builtin_amdgcn_readfirstlane((int)ld_relaxed(s_wc + 2 + 4 * k));
+                    if (cand < 0 || (k >= 0 && cand == lds_cluster)) continue;
+                    select(cand, service, 0u);
+                    uint32_t of_service = 0u;
+#pragma unroll
+                    for (int p = 0; p < kF2RPC; ++p)
+                        if (p == service) of_service = taken[p];
+                    if (service < 0 ? n >= F.switch_min : of_service > 0u) c_star = cand;
+                }
             }
             if (c_star == -2) {
                 int target = service;
@@ -700,28 +731,36 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                         }
                     }
                 }
-                uint32_t first_half = 0u;  // of the target ring: the half (0: slots 0..63, 1: 64..127) that holds its oldest waiting sample
+                uint32_t first_half = 0u;  // of the target ring: the 64-slot part that holds its oldest waiting sample
 #pragma unroll
                 for (int p = 0; p < kF2RPC; ++p) {
                     if (p == target) {
-                        // waiting slots of ring p as a 128-bit mask, rotated so that bit 0 is slot floor_[p]: the first set bit is the oldest
-                        const uint64_t lo = __ballot((watch_pend >> (2 * p)) & 1u), hi = __ballot((watch_pend >> (2 * p + 1)) & 1u);
-                        if ((int32_t)(scan[p] - kF2Ring - floor_[p]) > 0) floor_[p] = scan[p] - kF2Ring;  // nothing older than a ring's length can wait
-                        const uint32_t st = floor_[p] & (kF2Ring - 1);
-                        const uint64_t a = st & 64u ? hi : lo, b = st & 64u ? lo : hi;  // [a | b] starts at slot (st & 64)
-                        const uint32_t sh = st & 63u;
-                        const uint64_t r0 = sh ? (a >> sh) | (b << (64u - sh)) : a, r1 = sh ? (b >> sh) | (a << (64u - sh)) : b;
-                        const uint32_t dist = r0 ? (uint32_t)__builtin_ctzll(r0) : 64u + (uint32_t)__builtin_ctzll(r1);
-                        const uint32_t slot = (st + dist) & (kF2Ring - 1);
-                        floor_[p] += dist;
-                        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)watch_cl[p], (int)(slot & 63u));
-                        c_star = (int)(int16_t)(slot & 64u ? w >> 16 : w & 0xffffu);
-                        first_half = slot >> 6;
+                        // every waiting slot of ring p lies within a ring's length below scan[p]: the oldest is the one furthest below
+                        uint32_t far = 0u, far_h = 0u;
+#pragma unroll
+                        for (int h = 0; h < kF2RH; ++h) {
+                            const uint32_t d = (watch_pend >> (kF2RH * p + h)) & 1u ? ((scan[p] - 1u - ((uint32_t)lane + 64u * h)) & (kF2Ring - 1)) + 1u : 0u;
+                            if (d > far) {
+                                far = d;
+                                far_h = (uint32_t)h;
+                            }
+                        }
+                        uint32_t top = far;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const uint32_t other = (uint32_t)__shfl_xor((int)top, o);
+                            top = other > top ? other : top;
+                        }
+                        const int who = (int)__builtin_ctzll(__ballot(far == top && far != 0u));  // the lane that watches it
+                        first_half = (uint32_t)__builtin_amdgcn_readlane((int)far_h, who);
+#pragma unroll
+                        for (int h = 0; h < kF2RH; ++h)
+                            if ((uint32_t)h == first_half) c_star = __builtin_amdgcn_readlane(cl_of(p, h), who);
                     }
                 }
                 select(c_star, target, first_half);
             }
-            s_watch[kF2RPC * 64] = watch_pend & ~sel_bits;
+            s_watch[kF2RPC * WCL * 64] = watch_pend & ~sel_bits;
             __builtin_amdgcn_wave_barrier();
             const bool col_on = lane < n;
             ++n_runs;
@@ -737,7 +776,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                 const bool on = jc < n;
                 if (on) {
                     const uint32_t where_j = s_cols[jc];
-                    const int ring_j = (int)(where_j >> 7);
+                    const int ring_j = (int)(where_j >> kF2RingLog);
                     const uint32_t e_j = where_j & (kF2Ring - 1);
                     const uint32_t meta_j = ring_meta(ring_j)[e_j];
                     const int owner_j = (rbase + ring_j) * 64 + (int)(meta_j & 63u);
@@ -789,7 +828,11 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                     uint32_t res = 0u;  // slot | 8: fill it, | 16: somebody else is filling it
                     if (lane == 0) {
                         for (;;) {
-                            while (atomicCAS(&s_wc[0], 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(0);
+                            for (;;) {  // the lock: acquire, so that nothing below is read before the lock is held
+                                uint32_t expect = 0u;
+                                if (__hip_atomic_compare_exchange_strong(&s_wc[0], &expect, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                                __builtin_amdgcn_s_sleep(0);
+                            }
                             int hit = -1, victim = -1;
                             uint32_t oldest = 0xffffffffu;
 #pragma unroll
@@ -864,7 +907,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                 //      stores.  Position features have compile-time places (p, then per octave three phase-0 and three phase-1/4
                 //      triangle waves), guarded per octave; view direction, embedding and padding follow with half-word stores.
                 const uint32_t where = col_on ? s_cols[lane] : 0u;
-                const float4 smp = col_on ? ring_data((int)(where >> 7))[where & (kF2Ring - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 smp = col_on ? ring_data((int)(where >> kF2RingLog))[where & (kF2Ring - 1)] : make_float4(0.f, 0.f, 0.f, 0.f);
                 {
                     float p[3];
                     p[0] = (smp.x - S.center[0]) * S.inv_extent[0];
@@ -893,7 +936,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                     auto group = [&](auto kk_tag, auto gg_tag) __attribute__((always_inline)) {
                         // elements 2 q, 2 q + 1 of lane group gg: features 16 (q >> 1) + 4 gg + 2 (q & 1) + {0, 1}
                         constexpr int kk = decltype(kk_tag)::value, gg = decltype(gg_tag)::value, f0 = 32 * kk + 4 * gg;
-                        tile_q[kk * 256 + lane * 4 + gg] = make_uint4(pair(std::integral_constant<int, f0>{}), pair(std::integral_constant<int, f0 + 2>{}),
+                        if (lane < kF2Cols) tile_q[kk * (4 * kF2Cols) + lane * 4 + gg] = make_uint4(pair(std::integral_constant<int, f0>{}), pair(std::integral_constant<int, f0 + 2>{}),
                                                                       pair(std::integral_constant<int, f0 + 16>{}), pair(std::integral_constant<int, f0 + 18>{}));
                     };
                     auto k_tile = [&](auto kk_tag) __attribute__((always_inline)) {
@@ -906,13 +949,13 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                     if constexpr (NKK0 == 2) k_tile(std::integral_constant<int, 1>{});
                     if (S.need_viewdir || S.n_embeddings > 0) {
                         float d[3];
-                        const int owner_thread = (rbase + (int)(where >> 7)) * 64 + (int)(ring_meta((int)(where >> 7))[where & (kF2Ring - 1)] & 63u);
+                        const int owner_thread = (rbase + (int)(where >> kF2RingLog)) * 64 + (int)(ring_meta((int)(where >> kF2RingLog))[where & (kF2Ring - 1)] & 63u);
 #pragma unroll
                         for (int i = 0; i < 3; ++i) d[i] = S.need_viewdir ? s_ray[(NB + i) * RB + owner_thread] : 0.f;
                         _Float16 *tile_h = reinterpret_cast<_Float16 *>(s_tile);
                         auto put = [&](int f, float v) {  // f is wave-uniform
                             const int r = f & 31;
-                            tile_h[(f >> 5) * 2048 + lane * 32 + ((r & 15) >> 2) * 8 + (r >> 4) * 4 + (r & 3)] = (_Float16)v;
+                            if (lane < kF2Cols) tile_h[(f >> 5) * (32 * kF2Cols) + lane * 32 + ((r & 15) >> 2) * 8 + (r >> 4) * 4 + (r & 3)] = (_Float16)v;
                         };
                         if (S.need_viewdir) {
                             const int base = S.n_pos;
@@ -942,19 +985,19 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                 //      are 8 to 16 registers instead of 32 and the previous layer's accumulators die half by half, so that the 64
                 //      accumulators, the operands and the fragments in flight stay inside the 128-register budget without spills
                 //      (the price: a layer's fragments are read from LDS twice).
-                f32x4 acc[MT][4];
+                f32x4 acc[MT][kF2NT];
                 const half8 *w = s_frag;
                 const float *b = s_bias;
                 auto bias_tile = [&](int mt) __attribute__((always_inline)) -> f32x4 { return *reinterpret_cast<const f32x4 *>(b + 16 * mt + 4 * g); };
                 {
                     const uint4 *tile_q = reinterpret_cast<const uint4 *>(s_tile);
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
+                    for (int h = 0; h < kF2Halves; ++h) {
                         half8 bf[NKK0][2];
 #pragma unroll
                         for (int kk = 0; kk < NKK0; ++kk)
 #pragma unroll
-                            for (int j = 0; j < 2; ++j) bf[kk][j] = __builtin_bit_cast(half8, tile_q[kk * 256 + ((2 * h + j) * 16 + col) * 4 + g]);
+                            for (int j = 0; j < 2; ++j) bf[kk][j] = __builtin_bit_cast(half8, tile_q[kk * (4 * kF2Cols) + ((2 * h + j) * 16 + col) * 4 + g]);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
                             const f32x4 bv = bias_tile(mt);
@@ -975,7 +1018,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                 for (int layer = 1; layer <= S.hidden_layers; ++layer) {
                     const int n_mt = layer < S.hidden_layers ? MT : S.mt_out;
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
+                    for (int h = 0; h < kF2Halves; ++h) {
                         half8 bf[MT / 2][2];
 #pragma unroll
                         for (int kk = 0; kk < MT / 2; ++kk)
@@ -1005,7 +1048,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                 if (F.diag) t_lay += wall_clock64() - t_e0;
                 const unsigned long long t_c0 = F.diag ? wall_clock64() : 0;
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
+                for (int half = 0; half < kF2Halves; ++half) {
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         if (mt < S.mt_out) {
@@ -1021,12 +1064,12 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                 if (F.diag) t_eval += wall_clock64() - t_c0;
             } else {
                 evaluate(0, std::false_type{});
-                evaluate(1, std::false_type{});
+                if constexpr (kF2Halves == 2) evaluate(1, std::false_type{});
             }
             // ---- publish: mark the entries, then the counters (the owners composite them; their slots come free once they have)
             if (col_on) {
                 const uint32_t where = s_cols[lane];
-                __hip_atomic_fetch_or(ring_meta((int)(where >> 7)) + (where & (kF2Ring - 1)), kF2Ready, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // after the results
+                __hip_atomic_fetch_or(ring_meta((int)(where >> kF2RingLog)) + (where & (kF2Ring - 1)), kF2Ready, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // after the results
             }
 #pragma unroll
             for (int p = 0; p < kF2RPC; ++p) {

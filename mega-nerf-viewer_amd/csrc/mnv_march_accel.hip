@@ -1232,11 +1232,12 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
         // producer / consumer wavefronts when one sub-module's weights fit a workgroup's LDS beside the rings (at least two workgroups per CU)
         FusedGuided F = *track->fused;
         int slots = kF2NS;  // weight slots: as many as fit beside the rings (at least one per two consumers)
-        while (slots > 1 && (size_t)f2_layout(nb, lds_level, F.S, slots).total * 4 > (size_t)160 * 1024 / (16 / (kF2NP + kF2NC))) --slots;
+        const int f2_per_cu = (4 * kF2WavesPerSimd) / (kF2NP + kF2NC);  // workgroups per CU the kernel is built for
+        while (slots > 1 && (size_t)f2_layout(nb, lds_level, F.S, slots).total * 4 > (size_t)160 * 1024 / f2_per_cu) --slots;
         F.weight_slots = slots;
         const size_t f2_bytes = (size_t)f2_layout(nb, lds_level, F.S, slots).total * 4;
         const int version = g_fused_kernel.load(std::memory_order_relaxed);
-        const bool fits2 = f2_bytes <= (size_t)160 * 1024 && 2 * slots >= kF2NC && F.S.bias_floats <= 256;  // (a consumer refills a sub-module's biases with four loads per lane)
+        const bool fits2 = f2_bytes <= (size_t)160 * 1024 / f2_per_cu && slots >= (kF2NS < 2 ? kF2NS : 2) && F.S.bias_floats <= 256;  // (a consumer refills a sub-module's biases with four loads per lane)
         if (fits2 && (version == 2 || (version == 0 && kF2Default))) {
             int per_cu = (int)((size_t)160 * 1024 / f2_bytes);
             const int by_regs = (4 * kF2WavesPerSimd) / (kF2NP + kF2NC);
