@@ -52,8 +52,10 @@ Rccl &rccl() {
     static std::once_flag once;
     std::call_once(once, [] {
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        // test hook: MNV_RCCL_LIBRARY names a library with the same eight entry points (tests/shim/fake_rccl.cpp lets the world > 1
-        // paths run with several ranks on one GPU, which RCCL refuses)
+#ifdef MNV_TEST_HOOKS
+        // Test hook, compiled only into the -DMNV_TEST_HOOKS build (testhooks/libmnv.so, what the rehearsal tests load): MNV_RCCL_LIBRARY
+        // names a library with the same eight entry points (tests/shim/fake_rccl.cpp lets the world > 1 paths run with several ranks
+        // on one GPU, which RCCL refuses).  The shipped libmnv.so binds librccl and nothing else.
         if (const char *over = getenv("MNV_RCCL_LIBRARY")) {
             r.handle = dlopen(over, RTLD_NOW | RTLD_LOCAL);
             if (!r.handle) {
@@ -61,6 +63,7 @@ Rccl &rccl() {
                 return;
             }
         }
+#endif
         // a copy that is already loaded wins (PyTorch ships its own librccl.so with the same soname)
         for (const char *n : names)
             if (!r.handle) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);

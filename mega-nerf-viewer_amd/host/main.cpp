@@ -231,8 +231,19 @@ void print_refine_stats(long f, const viewer::VolumeRenderer::FrameStats &st) {
 // --gpus N with --use_splitting: the ranks refine ONE scene in lock step (VolumeRenderer::set_ranks) -- every rank marches its macro
 // tiles, the tracker rows are all-gathered, every rank applies the same splits / resamples / prunes to its replica of the tree, and
 // rank 0 assembles and writes the frames.  One frame at a time: a frame reads the tree the previous one left.
+// Test hook, compiled only into the -DMNV_TEST_HOOKS build (testhooks/mnv_render): MNV_RANKS_SHARE_GPU=1 puts every rank on device --gpu
+// (with a transport stand-in for RCCL, which refuses two ranks on one device: tests/shim/fake_rccl.cpp) so that the world > 1 paths can
+// run on a one-GPU machine.  The shipped binary gives rank r device --gpu + r, always.
+static bool ranks_share_gpu() {
+#ifdef MNV_TEST_HOOKS
+    return std::getenv("MNV_RANKS_SHARE_GPU") != nullptr;
+#else
+    return false;
+#endif
+}
+
 int run_rank_refine(const Args &args, int rank, int world, Rendezvous *rv) {
-    const bool share = std::getenv("MNV_RANKS_SHARE_GPU") != nullptr;
+    const bool share = ranks_share_gpu();
     if (hipSetDevice((int)args.l("gpu", 0) + (share ? 0 : rank)) != hipSuccess)
         throw std::runtime_error("rank " + std::to_string(rank) + ": no usable HIP device");
     viewer::N3Tree tree(args.file);
@@ -288,9 +299,7 @@ int run_rank_refine(const Args &args, int rank, int world, Rendezvous *rv) {
 }
 
 int run_rank(const Args &args, int rank, int world, Rendezvous *rv) {
-    // test hook: MNV_RANKS_SHARE_GPU=1 puts every rank on device --gpu (with a transport stand-in for RCCL, which refuses two ranks on
-    // one device: tests/shim/fake_rccl.cpp) so that the world > 1 paths can run on a one-GPU machine
-    const bool share = std::getenv("MNV_RANKS_SHARE_GPU") != nullptr;
+    const bool share = ranks_share_gpu();
     if (hipSetDevice((int)args.l("gpu", 0) + (share ? 0 : rank)) != hipSuccess)
         throw std::runtime_error("rank " + std::to_string(rank) + ": no usable HIP device");
     viewer::N3Tree tree(args.file);
@@ -528,7 +537,6 @@ int main(int argc, char **argv) {
         std::vector<uint8_t> rgba8;
         mnv_set_timing(1);
         rend.frames_in_flight = (int)std::max<long>(1, args.l("in_flight", rend.frames_in_flight));
-        const size_t depth = refine ? 1 : (size_t)rend.frames_in_flight;
         std::deque<std::pair<long, int>> pending;  // (frame, slot) rendered but not yet written
         auto write_oldest = [&]() {
             const long f = pending.front().first;
@@ -539,7 +547,13 @@ int main(int argc, char **argv) {
         };
         const auto wall0 = std::chrono::steady_clock::now();
         for (long f = 0; f < frames; ++f) {
-            while (pending.size() >= depth) write_oldest();  // the slot frame f is about to take must have been written
+            // the slot frame f is about to take must have been written: the renderer says which one that is (frames that cannot
+            // overlap -- refinement, a tree without a packed accel -- all take slot 0, whatever --in_flight says)
+            const int next = rend.next_slot();
+            size_t keep = pending.size();
+            for (size_t i = 0; i < pending.size(); ++i)
+                if (pending[i].second == next) keep = pending.size() - 1 - i;
+            while (pending.size() > keep) write_oldest();
             rend.render();
             if (refine) print_refine_stats(f, rend.stats);
             if (!out.empty()) pending.emplace_back(f, rend.last_slot());

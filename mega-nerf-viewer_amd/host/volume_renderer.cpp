@@ -58,6 +58,7 @@ struct VolumeRenderer::Impl {
     std::vector<Slot> slots;
     int cur = 0;            // slot of the most recent render()
     bool overlapped = false;  // plain frames may still be running on slots other than 0
+    bool tree_stream_dirty = false;  // slot 0's stream may still be editing the tree / accel (a frame other than a plain one ran last)
     hipStream_t stream = nullptr;  // = slots[0].stream: refinement, tree upload, accel rebuild
     float *rgba = nullptr;         // = slots[cur]
     uint8_t *rgba8 = nullptr;
@@ -410,9 +411,14 @@ void VolumeRenderer::render() {
     stats = FrameStats();
     {
         // a plain frame of a tree with a current accel takes the next slot; everything else runs alone on slot 0
-        const bool refine_now = I.mlp != nullptr && (options.use_splitting || options.use_guided_sampling);
-        const bool plain = !I.comm && !refine_now && I.tree != nullptr && I.tree->N > 0 && I.tree->device.accel && !I.accel_stale;
-        if (plain && frames_in_flight > 1) {
+        if (overlaps_next()) {
+            // Slot streams are not ordered among each other.  Whatever slot 0's stream still holds from a frame that changed the tree
+            // or its accel (splits, resampled leaves, accel patches, a prune's renumbering: asynchronous on that stream) must be
+            // finished before a frame on another stream reads those arrays: once, on the way from such frames to plain ones.
+            if (I.tree_stream_dirty) {
+                hip_check(hipStreamSynchronize(I.stream), "hipStreamSynchronize");
+                I.tree_stream_dirty = false;
+            }
             I.ensure_slots(frames_in_flight);
             I.use_slot((I.cur + 1) % frames_in_flight);
             I.overlapped = true;
@@ -424,6 +430,7 @@ void VolumeRenderer::render() {
         }
         if (I.overlapped) I.sync_all();
         I.use_slot(0);
+        I.tree_stream_dirty = true;  // what follows runs on slot 0's stream and may edit the tree
     }
     if (I.comm) {
         render_ranks();
@@ -625,8 +632,10 @@ void VolumeRenderer::render_ranks() {
         mnv_check(mnv_allgather(I.comm, sample, (size_t)I.rank_px * 12, I.stream), "mnv_allgather");
     }
     if (track_visit && world > 1) {
-        const size_t cap = (size_t)I.max_tree_capacity;
-        int32_t *marks = I.marks_table.get<int32_t>(cap * world);
+        // the marks of the chunks that exist: the replicas agree on tree.capacity, and a chunk beyond it cannot be marked (the table is
+        // sized once for the largest tree -- reallocation would stall the frame -- but only cap words per rank travel and merge)
+        const size_t cap = (size_t)tree.capacity;
+        int32_t *marks = I.marks_table.get<int32_t>((size_t)I.max_tree_capacity * world);
         hip_check(hipMemcpyAsync(marks + cap * rank, visited, cap * 4, hipMemcpyDeviceToDevice, I.stream), "copy marks");
         mnv_check(mnv_allgather(I.comm, marks, cap * 4, I.stream), "mnv_allgather");
         mnv_check(mnv_merge_visit_marks(marks, world, (int32_t)cap, visited, I.stream), "mnv_merge_visit_marks");
@@ -643,6 +652,15 @@ void VolumeRenderer::download(std::vector<float> *rgba, std::vector<uint8_t> *rg
 }
 
 int VolumeRenderer::last_slot() const { return impl_->cur; }
+
+bool VolumeRenderer::overlaps_next() const {
+    const Impl &I = *impl_;
+    const bool refine_now = I.mlp != nullptr && (options.use_splitting || options.use_guided_sampling);
+    const bool plain = !I.comm && !refine_now && I.tree != nullptr && I.tree->N > 0 && I.tree->device.accel && !I.accel_stale;
+    return plain && frames_in_flight > 1;
+}
+
+int VolumeRenderer::next_slot() const { return overlaps_next() ? (impl_->cur + 1) % frames_in_flight : 0; }
 
 void VolumeRenderer::download_slot(int slot, std::vector<float> *rgba, std::vector<uint8_t> *rgba8) {
     if (slot < 0 || slot >= (int)impl_->slots.size() || !impl_->slots[slot].rgba) throw std::runtime_error("download_slot: no such frame slot");

@@ -51,6 +51,8 @@ struct VolumeRenderer {
     // a caller that wants overlap downloads frame k after it has issued frames k+1 .. k+frames_in_flight-1.
     int frames_in_flight = 3;
     int last_slot() const;
+    int next_slot() const;       // the slot the next render() will take (with the options, tree and camera as they are now)
+    bool overlaps_next() const;  // ... and whether that frame runs beside the previous ones (a plain frame on the packed accel)
     void download_slot(int slot, std::vector<float> *rgba, std::vector<uint8_t> *rgba8);
     // Wait for every frame in flight.
     void sync_tree_streams();

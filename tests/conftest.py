@@ -11,6 +11,11 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The live reference build (oracle/_ref: the reference's own device code for gfx950) travels with the repository.  When it is
+    # there at collection, the tests that run against it must run: a library that is present but does not load, or that vanishes
+    # on the way, FAILS them instead of skipping (tests/test_parity_gpu.py: require_live_reference).
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libmnv_ref_gfx950.so")):
+        os.environ.setdefault("MNV_REQUIRE_LIVE_REF", "1")
 
 
 def pytest_report_header(config):

@@ -10,6 +10,8 @@ import sys
 
 import pytest
 
+import hooks
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -55,6 +57,7 @@ def test_bench_launcher_repeats_a_failed_run_conservatively_and_kills_a_wedged_o
     group, nothing else -- and the exit code is not 0."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["MNV_RCCL_LIBRARY"] = "/nonexistent/librccl.so"
+    env["MNV_LIB_PATH"] = hooks.HOOKS_LIB
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--laps", "1"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -73,6 +76,7 @@ def test_bench_multirank_through_the_c_abi_gather(torch_gpu, fake_rccl, world):
     tests/shim/fake_rccl.cpp stands in for RCCL's transport (MNV_RCCL_LIBRARY); bench.py starts the ranks itself."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["MNV_RCCL_LIBRARY"] = fake_rccl
+    env["MNV_LIB_PATH"] = hooks.HOOKS_LIB
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--steps", "3", "--warmup", "1", "--laps", "1"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]

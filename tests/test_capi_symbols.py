@@ -64,3 +64,18 @@ def test_comm_entry_points_validate_without_a_gpu(mnv):
     assert lib.mnv_comm_init_rank(buf, 2, 2, C.byref(h)) == mnv.MNV_E_INVALID      # rank outside the world
     assert lib.mnv_comm_rank(None) == -1 and lib.mnv_comm_world(None) == 0
     lib.mnv_comm_destroy(None)
+
+
+def test_the_shipped_binaries_carry_no_test_hooks(mnv):
+    """MNV_RCCL_LIBRARY (a stand-in for RCCL's transport) and MNV_RANKS_SHARE_GPU (every rank on one device) exist only in the
+    -DMNV_TEST_HOOKS build under testhooks/ that the rehearsal tests load (tests/hooks.py): the shipped library cannot be pointed at
+    an arbitrary shared object through the environment."""
+    import hooks
+
+    def mentions(path, name):
+        return name.encode() in open(path, "rb").read()
+
+    exe = os.path.join(ROOT, "mega-nerf-viewer_amd", "mnv_render")
+    assert not mentions(mnv.LIB_PATH if not os.environ.get("MNV_LIB_PATH") else os.path.join(ROOT, "mega-nerf-viewer_amd", "libmnv.so"), "MNV_RCCL_LIBRARY")
+    assert not mentions(exe, "MNV_RANKS_SHARE_GPU")
+    assert mentions(hooks.HOOKS_LIB, "MNV_RCCL_LIBRARY") and mentions(hooks.HOOKS_EXE, "MNV_RANKS_SHARE_GPU")

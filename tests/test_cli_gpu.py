@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import cases
+import hooks
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -63,7 +64,7 @@ def test_mnv_render_multi_gpu_mode_with_one_rank(mnv, orc, torch_gpu, tmp_path):
     one, dist = str(tmp_path / "one"), str(tmp_path / "dist")
     r1 = subprocess.run(common + ["--out", one], capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr + r1.stdout
-    r2 = subprocess.run(common + ["--out", dist, "--gpus", "1"], capture_output=True, text=True, timeout=600)
+    r2 = subprocess.run([exe] + common[1:] + ["--out", dist, "--gpus", "1"], capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0, r2.stderr + r2.stdout
     assert "x 1 (RCCL" in r2.stdout and "macro tiles" in r2.stdout
     for f in range(frames):
@@ -107,7 +108,8 @@ def test_mnv_render_multi_gpu_mode_with_several_ranks_on_one_gpu(mnv, torch_gpu,
     r1 = subprocess.run(common + ["--out", one], capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr + r1.stdout
     env = dict(os.environ, MNV_RCCL_LIBRARY=fake_rccl, MNV_RANKS_SHARE_GPU="1")
-    r2 = subprocess.run(common + ["--out", dist, "--gpus", str(world), "--reserve_cus", "0"], capture_output=True, text=True, timeout=900, env=env)
+    exe = hooks.HOOKS_EXE  # the build that honours the two variables
+    r2 = subprocess.run([exe] + common[1:] + ["--out", dist, "--gpus", str(world), "--reserve_cus", "0"], capture_output=True, text=True, timeout=900, env=env)
     assert r2.returncode == 0, r2.stderr + r2.stdout
     assert f"x {world} (RCCL 29999)" in r2.stdout      # the stand-in's version number: this run did not touch RCCL
     for f in range(frames):
@@ -141,10 +143,11 @@ def test_mnv_render_guided_sampling_across_ranks(mnv, torch_gpu, tmp_path, fake_
     one, dist = str(tmp_path / "one"), str(tmp_path / "dist")
     r1 = subprocess.run(common + ["--out", one], capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0 and "guided samples" in r1.stdout, r1.stderr + r1.stdout
-    env = dict(os.environ)
+    env, exe = dict(os.environ), EXE
     if world > 1:
         env.update(MNV_RCCL_LIBRARY=fake_rccl, MNV_RANKS_SHARE_GPU="1")
-    r2 = subprocess.run(common + ["--out", dist, "--gpus", str(world), "--reserve_cus", "0"], capture_output=True, text=True, timeout=900, env=env)
+        exe = hooks.HOOKS_EXE  # the build that honours the two variables
+    r2 = subprocess.run([exe] + common[1:] + ["--out", dist, "--gpus", str(world), "--reserve_cus", "0"], capture_output=True, text=True, timeout=900, env=env)
     assert r2.returncode == 0, r2.stderr + r2.stdout
     plain = str(tmp_path / "plain")
     r3 = subprocess.run([a for a in common if a not in ("--use_guided_sampling",)] + ["--out", plain], capture_output=True, text=True, timeout=600)
@@ -185,10 +188,11 @@ def test_mnv_render_refinement_across_ranks(mnv, torch_gpu, tmp_path, fake_rccl,
     r1 = subprocess.run(common + ["--out", one, "--save_tree", one + ".npz"], capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr + r1.stdout
     assert "added" in r1.stdout and "pruned" in r1.stdout, r1.stdout   # the path grows the tree until it is full, then prunes
-    env = dict(os.environ, MNV_SAVE_EVERY_RANK="1")
+    env, exe = dict(os.environ, MNV_SAVE_EVERY_RANK="1"), EXE
     if world > 1:
         env.update(MNV_RCCL_LIBRARY=fake_rccl, MNV_RANKS_SHARE_GPU="1")
-    r2 = subprocess.run(common + ["--out", dist, "--save_tree", dist + ".npz", "--gpus", str(world)], capture_output=True, text=True, timeout=900, env=env)
+        exe = hooks.HOOKS_EXE  # the build that honours the two variables
+    r2 = subprocess.run([exe] + common[1:] + ["--out", dist, "--save_tree", dist + ".npz", "--gpus", str(world)], capture_output=True, text=True, timeout=900, env=env)
     assert r2.returncode == 0, r2.stderr + r2.stdout
     # the same decisions frame by frame (candidates, splits, resamples, prunes, capacities)
     strip = lambda out: [re.sub(r"  guided samples \d+", "", ln) for ln in out.splitlines() if ln.startswith("frame ")]

@@ -69,6 +69,7 @@ def _rank_main(rank, world, lib, idq, resq):
     try:
         os.environ["MNV_RCCL_LIBRARY"] = lib
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.environ["MNV_LIB_PATH"] = os.path.join(root, "mega-nerf-viewer_amd", "testhooks", "libmnv.so")  # the build that honours MNV_RCCL_LIBRARY (tests/hooks.py)
         for p in (root, os.path.join(root, "tests"), os.path.join(root, "oracle")):
             if p not in sys.path:
                 sys.path.insert(0, p)

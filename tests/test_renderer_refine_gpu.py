@@ -415,3 +415,34 @@ def test_plain_frames_in_flight_match_the_oracle(mnv, orc, torch_gpu):
         assert np.array_equal(got3[i][0].view(np.uint32), ref["rgba"].view(np.uint32)), i
         assert np.array_equal(got3[i][1], ref["rgba8"]), i
         assert np.array_equal(got1[i][0].view(np.uint32), got3[i][0].view(np.uint32)), i
+
+
+def test_plain_frames_after_refinement_wait_for_the_tree_edits(mnv, orc, torch_gpu):
+    """The frames-in-flight path launches plain frames on slot streams that nothing orders after slot 0's stream, where a
+    refinement frame leaves asynchronous work that rewrites the tree and the packed accel (splits, accel patches): the first
+    plain frames after the switches go off must see the finished tree.  Several refinement frames (4096 splits each), then three
+    plain frames through three slots: each equals the oracle's render of the refined tree bit for bit."""
+    r, tree, desc, params, cam_spec = setup(mnv, "sh9_d7_aniso", 60000, use_splitting=True, max_depth=9, split_batch_size=4096, samples_per_corner=4)
+    r.set_frames_in_flight(3)
+    added = 0
+    for _ in range(4):
+        added += r.render()["added"]
+    assert added > 0
+    r.options.use_splitting = False
+    w, h, fx = cam_spec["width"], cam_spec["height"], cam_spec["fx"]
+    poses = [(cam_spec.get("center", (-3.55, 0.0, 3.55)), cam_spec.get("back", (-0.7071068, 0.0, 0.7071068))),
+             ((-3.2, 0.4, 3.6), (-0.68, 0.1, 0.72)), ((-3.4, -0.3, 3.3), (-0.72, -0.05, 0.69))]
+    slots = []
+    for center, back in poses:
+        r.set_camera(center, back, fx=fx)
+        st = r.render()          # no synchronisation between the last refinement frame and these
+        assert st["used_accel"] and st["added"] == 0
+        slots.append(r.last_slot())
+    assert len(set(slots)) == 3
+    frames = [r.download_slot(s) for s in slots]
+    r.sync_tree()
+    ot = orc.tree_from_view(tree.host_view())
+    opt = mnv.RenderOptions.from_buffer_copy(r.options)
+    for (center, back), got in zip(poses, frames):
+        ref = orc.render(ot, mnv.Camera(w, h, fx).set_pose(center, back).c, opt)["rgba"]
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
