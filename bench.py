@@ -72,6 +72,25 @@ def alg_bytes(c, basis_dim=9):
     return 16 * c["rays"] + 4 * c["levels"] + 2 * c["steps"] + 6 * basis_dim * c["hits"]
 
 
+def gpu_count_without_hip():
+    """GPUs of this node from the KFD topology in sysfs (nodes with SIMDs), or None when that cannot be read.  The launcher below must
+    never initialise HIP (it starts the ranks as children and this pool forbids a GPU-initialised process to exec): torch.cuda.device_count()
+    may fall back to hipGetDeviceCount on builds without amdsmi, so it is not asked."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0  # no amdgpu compute driver on this machine: no GPUs
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        return n
+    except (OSError, ValueError):
+        return None
+
+
 def self_launch(n, backend, timeout_s):
     """One process per GPU via torch.distributed.run, started from a parent that never initialises HIP.  The ranks run in their own
     process group under a watchdog: a run that exceeds `timeout_s` (a wedged collective) is killed -- that group, by id -- and, like a run
@@ -81,8 +100,9 @@ def self_launch(n, backend, timeout_s):
     import socket
     import subprocess
 
-    if backend == "nccl" and torch.cuda.device_count() < n:
-        print(f"bench.py: --gpus {n} over RCCL needs {n} GPUs, this node shows {torch.cuda.device_count()} "
+    have = gpu_count_without_hip()
+    if backend == "nccl" and have is not None and have < n:
+        print(f"bench.py: --gpus {n} over RCCL needs {n} GPUs, this node shows {have} "
               f"(--backend gloo rehearses the {n}-rank path on fewer GPUs)", file=sys.stderr)
         return 2
 
@@ -146,6 +166,151 @@ def self_launch(n, backend, timeout_s):
     return rc or 4
 
 
+MFMA_PEAK_TFLOPS = 2500.0           # MI355X_MICROARCH.md: dense f16 / bf16 matrix peak (no sparsity)
+
+
+def extras_cfg3_cfg4(mnv, cases, orc, torch, dev, opt, steps):
+    """Secondary numbers of the default run: BASELINE.json configs[2] (merged-octree stand-in, 1920x1080) and configs[3] on ONE GPU
+    (the same tree at 3840x2160) -- the 7.2 M-chunk terrain of SURVEY.md 8(d), 16 oblique poses per launch.  Each with its own roofline
+    (algorithmic bytes from the oracle's counters of two poses rendered in this run) and a bit-exact check of those frames."""
+    t_setup = time.time()
+    tree = cases.make_tree(mnv, cases.CFG3_FULL)
+    ot = orc.tree_from_view(tree.host_view())
+    tree.move_to_device()
+    info = mnv.accel_info(tree.accel)
+    setup_s = time.time() - t_setup
+    out = {}
+    for name, (w, h) in (("cfg3", (1920, 1080)), ("cfg4_n1", (3840, 2160))):
+        cams = [cases.cfg3_camera(mnv, pose, w, h, fx=1400.0 * w / 1920) for pose in range(N_POSES)]
+        frames = torch.empty((N_POSES, h, w, 4), dtype=torch.float32, device=dev)
+        mnv.render_voxels_accel_batch(tree.accel, cams, opt, rgba=frames)
+        torch.cuda.synchronize(dev)
+        mnv.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            mnv.render_voxels_accel_batch(tree.accel, cams, opt, rgba=frames)
+        torch.cuda.synchronize(dev)
+        el = time.perf_counter() - t0
+        kern_ms, launches = mnv.take_timing()
+        mnv.set_timing(False)
+        chk = (0, 5)
+        byts, n_bad, max_d = [], 0, 0.0
+        for i in chk:
+            r = orc.render(ot, cams[i].c, opt)
+            byts.append(alg_bytes(r["counters"].as_dict()))
+            gpu = frames[i].cpu().numpy()
+            n_bad += int((gpu.view(np.uint32) != r["rgba"].view(np.uint32)).any(axis=-1).sum())
+            max_d = max(max_d, float(np.abs(gpu - r["rgba"]).max()))
+        per_launch = float(np.mean(byts)) * N_POSES
+        avg_ms = kern_ms / max(1, launches)
+        achieved = per_launch / (avg_ms * 1e-3) / 1e9
+        out[name] = {"value": round(N_POSES * w * h * steps / el / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
+                     "resolution": f"{w}x{h}", "frames_per_launch": N_POSES,
+                     "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                                  "traffic": None, "kernel": "march_accel_kernel<9,256,0>", "avg_launch_ms": round(avg_ms, 5), "launches": launches,
+                                  "algorithmic_bytes_per_launch": int(per_launch), "counter_poses": list(chk)},
+                     "parity": {"frames_checked": len(chk), "pixels_not_bit_identical": n_bad, "max_abs_drgba_vs_oracle": max_d}}
+        del frames
+    workload = (f"depth-11 SH9 anisotropic 4x2-brick terrain N3Tree ({tree.capacity:,} chunks, {tree.capacity * 8 * 28 * 2 / 1e9:.2f} GB of voxel rows), "
+                f"packed accel {info['device_bytes'] / 1e9:.2f} GB with a level-{info['grid2_level']} lookup grid, 16 oblique poses per launch")
+    for v in out.values():
+        v["workload"] = workload
+    out["cfg3"]["setup_s"] = round(setup_s, 2)
+    del tree
+    torch.cuda.empty_cache()
+    return out
+
+
+def extras_cfg5(mnv, cases, torch, dev, tree, frames_each=6):
+    """Secondary numbers for BASELINE.json configs[4] (dynamic refinement + guided sampling with the per-sample network fused into the march)
+    on the headline tree at 1920x1080: the guided-sampling frame as one kernel (device time per frame from HIP events, bit-exact against the
+    four-step path it replaces), and whole frames with BOTH switches on through the renderer (wall time per frame, tree edits included)."""
+    import mlp_cases
+
+    w, h = W, H
+    v = tree.host_view()
+    opt = mnv.RenderOptions.cli_defaults()
+    opt.basis_minmax[1] = 8
+    opt.max_guided_samples = 32
+    desc = mnv.mlp_desc(n_clusters=8, pos_octaves=4, hidden_width=64, hidden_layers=2, out_dim=v.data_dim + 1)
+    mlp = mnv.Mlp(desc, mlp_cases.make_params(mnv, desc, seed=4))
+    g = mnv.ClusterGrid()
+    g.grid_dim[0], g.grid_dim[1] = 4, 2
+    for i in range(3):
+        g.min_position[i], g.range[i] = -1.0, 2.0
+    cams = [cases.cfg2_camera(mnv, p, w, h, FX) for p in range(8)]
+    out = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    for c in cams[:2]:
+        mnv.render_guided_fused(tree.accel, c, opt, mlp, g, rgba=out)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
+    e0.record()
+    for _ in range(reps):
+        for c in cams:
+            mnv.render_guided_fused(tree.accel, c, opt, mlp, g, rgba=out)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    guided_ms = e0.elapsed_time(e1) / (reps * len(cams))
+    # the same frame through the four kernels the fused one replaces: sample march -> compaction -> network -> composite
+    n_px, dd = w * h, v.data_dim
+    num = torch.zeros(n_px, dtype=torch.int16, device=dev)
+    guided = torch.zeros((n_px, 32, 4), dtype=torch.float32, device=dev)
+    clusters = torch.zeros((n_px, 32), dtype=torch.int16, device=dev)
+    offsets = torch.empty(n_px, dtype=torch.int64, device=dev)
+    cap = 16_000_000
+    z = torch.empty(cap, dtype=torch.float32, device=dev)
+    rows = torch.empty((cap, 3), dtype=torch.float32, device=dev)
+    rcl = torch.empty(cap, dtype=torch.int16, device=dev)
+    values = torch.empty((cap, dd + 1), dtype=torch.float32, device=dev)
+    ref = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
+    cam = cams[3]
+    mnv.get_samples_from_voxels_accel(tree.accel, cam, opt, num, guided, clusters, g)
+    total = mnv.compact_guided_samples(num, guided, clusters, offsets, z, rows, rcl)
+    mlp.query(rcl, rows, values, n=total)
+    mnv.render_nerf_results(tree.device_view(), cam, opt, values, z, offsets, rgba=ref)
+    out.fill_(float("nan"))
+    mnv.render_guided_fused(tree.accel, cam, opt, mlp, g, rgba=out, sample_counter=counter)
+    torch.cuda.synchronize(dev)
+    n_bad = int((out.view(torch.int32) != ref.view(torch.int32)).any(dim=-1).sum().item())
+    evals = int(counter.item())
+    flops_per_eval = 2 * (32 * 64 + 64 * 64 + 64 * 32)   # the padded 32 -> 64 -> 64 -> 32 network the matrix cores run (27 inputs, 29 outputs used)
+    del num, guided, clusters, offsets, z, rows, rcl, values, ref
+    # both switches through the renderer: march + networks + composite + trackers in one kernel, vote, 4096 splits x 8 corners x 8 network samples, accel patch
+    tree2 = cases.make_tree(mnv, cases.CFG2_TREE)
+    r = mnv.Renderer()
+    r.resize(w, h)
+    r.set(tree2, tree2.capacity + 1_000_000)
+    desc6 = mnv.mlp_desc(n_clusters=6, pos_octaves=4, dir_octaves=2, hidden_width=64, hidden_layers=2, out_dim=v.data_dim + 1)
+    from test_renderer_refine_gpu import make_grid
+    r.set_model(desc6, mlp_cases.make_params(mnv, desc6, seed=21), make_grid(mnv))
+    r.set_seed(7)
+    o = r.options
+    o.use_splitting, o.use_guided_sampling, o.max_depth, o.split_batch_size, o.samples_per_corner, o.max_guided_samples = True, True, 12, 4096, 8, 32
+    ts, st = [], None
+    for f in range(frames_each + 2):
+        c = cases.cfg2_camera(mnv, f % N_POSES)
+        m = c.c2w
+        r.set_camera(tuple(m[9:12]), tuple(m[6:9]), fx=FX)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        st = r.render()
+        torch.cuda.synchronize(dev)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    both_ms = float(np.median(ts[2:]))
+    res = {"guided_ms_per_frame": round(guided_ms, 4), "guided_Mrays_per_s": round(w * h / guided_ms / 1e3, 1), "network_evals_per_frame": evals,
+           "network_evals_per_s": round(evals / (guided_ms * 1e-3), 0), "mfma_frac": round(evals * flops_per_eval / (guided_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 5),
+           "mfma_note": "network flops of the padded 32-64-64-32 tiles / whole-kernel time / 2.5 PFLOP/s: the kernel is the march AND the network",
+           "pixels_not_bit_identical_vs_four_step": n_bad,
+           "both_ms_per_frame": round(both_ms, 4), "both_network_evals_per_frame": int(st["guided_samples"]), "both_added_per_frame": int(st["added"]), "both_fused": int(st["fused"]),
+           "what": "cfg2 tree at 1920x1080: guided = mnv_render_guided_fused (one kernel per frame, 8 sub-modules, 64x2 network, quota 32), HIP events over 24 frames; "
+                   "both = VolumeRenderer::render with use_splitting + use_guided_sampling (4096 splits x 8 corners x 8 samples per frame), wall time per frame"}
+    del r, tree2
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,7 +325,7 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend for N > 1; gloo (host-staged gather, all ranks may share one GPU) is the single-GPU rehearsal of the multi-GPU path")
     ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4"], default="cfg2",
-                    help="cfg2 = BASELINE.json's headline config (default); cfg3 = merged-Mega-NeRF stand-in (anisotropic terrain, 2.7 M chunks); "
+                    help="cfg2 = BASELINE.json's headline config (default); cfg3 = merged-Mega-NeRF stand-in (anisotropic terrain, 7.2 M chunks); "
                          "cfg4 = cfg3 at 3840x2160 (configs[3], meant for --gpus 8)")
     ap.add_argument("--per-frame", action="store_true", help="one launch per pose instead of one batched launch per step")
     ap.add_argument("--frame-streams", type=int, default=3,
@@ -184,6 +349,7 @@ def main():
                     help="N > 1: abi = mnv_gather_tiles (libmnv's own RCCL gather, the product path); torch = torch.distributed's gather "
                          "(the launcher's second attempt if the first one fails or wedges)")
     ap.add_argument("--launch-timeout", type=float, default=600.0, help="--gpus N > 1 without a launcher: watchdog for the ranks this process starts (s)")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the secondary numbers for the other BASELINE configs (cfg3, cfg4_n1, cfg5)")
     ap.add_argument("--laps", type=int, default=4, help="the step walks the 16-pose orbit this many times (16 x laps frames in one launch, <= 64)")
     args = ap.parse_args()
     global W, H, N_FRAMES
@@ -195,7 +361,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves as FRESH child processes (this process has not
-        # touched the GPU: torch.cuda.device_count() does not initialise it on this image), relay rank 0's JSON line, exit with their code
+        # touched the GPU: the device count comes from sysfs, gpu_count_without_hip), relay rank 0's JSON line, exit with their code
         sys.exit(self_launch(args.gpus, args.backend, args.launch_timeout))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -230,10 +396,13 @@ def main():
         cams = [cases.cfg2_camera(mnv, pose % N_POSES, W, H, FX) for pose in range(N_FRAMES)]
         workload = "cfg2: depth-10 SH9 shell N3Tree (1,499,569 chunks), 1920x1080, 16-pose orbit per step" + (f" x {args.laps} laps" if args.laps > 1 else "")
     else:
-        tree = cases.make_tree(mnv, cases.CFG3_TREE)
+        tree = cases.make_tree(mnv, cases.CFG3_FULL)
         cams = [cases.cfg3_camera(mnv, pose % N_POSES, W, H, fx=1400.0 * W / 1920) for pose in range(N_FRAMES)]
-        workload = f"{args.workload}: depth-10 SH9 anisotropic 4x2-brick terrain N3Tree ({tree.capacity:,} chunks), {W}x{H}, 16 oblique poses per step"
+        workload = f"{args.workload}: depth-11 SH9 anisotropic 4x2-brick terrain N3Tree ({tree.capacity:,} chunks), {W}x{H}, 16 oblique poses per step"
     tree.move_to_device()
+    if args.workload != "cfg2":
+        info = mnv.accel_info(tree.accel)
+        workload += f", packed accel {info['device_bytes'] / 1e9:.2f} GB with a level-{info['grid2_level']} lookup grid"
     opt = mnv.RenderOptions.cli_defaults()
     setup_s = time.time() - t_setup
 
@@ -440,9 +609,11 @@ def main():
         n_cpu = max(1, min(args.cpu_poses, N_POSES))
         t_cpu, max_diff, n_bad, n_alpha = 0.0, 0.0, 0, 0
         fresh = {}
+        phys, hw_threads = orc.physical_cores()
+        n_thr = phys or hw_threads   # one thread per physical core (SMT siblings share the core's ports: no gain for this pointer chase)
         for i in range(n_cpu):
             tc = time.perf_counter()
-            r = orc.render(ot, cams[i].c, opt)
+            r = orc.render(ot, cams[i].c, opt, n_threads=n_thr)
             t_cpu += time.perf_counter() - tc
             fresh[str(i)] = r["counters"].as_dict()
             scratch = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
@@ -455,8 +626,10 @@ def main():
             max_diff = max(max_diff, float(d.max()))
             n_bad += int((gpu.view(np.uint32) != r["rgba"].view(np.uint32)).any(axis=-1).sum())
             n_alpha += int((gpu[..., 3].view(np.uint32) != r["rgba"][..., 3].view(np.uint32)).sum())
-        cpu_baseline = {"value": round(n_cpu * W * H / t_cpu / 1e6, 4), "unit": "Mrays/s", "cores": orc.lib().orc_num_threads(),
-                        "kind": "port", "sample": f"poses 0..{n_cpu - 1} of the 16-pose orbit, full 1920x1080 frames, OpenMP over rows"}
+        cpu_baseline = {"value": round(n_cpu * W * H / t_cpu / 1e6, 4), "unit": "Mrays/s", "cores": n_thr, "hardware_threads": hw_threads,
+                        "per_core": round(n_cpu * W * H / t_cpu / 1e6 / n_thr, 4),
+                        "kind": "port", "sample": f"poses 0..{n_cpu - 1} of the 16-pose orbit, full 1920x1080 frames; gcc -O3, OpenMP, 16x16-pixel tiles handed out one at a time, "
+                                                  "one thread per physical core"}
         parity = {"max_abs_drgba_vs_oracle": max_diff, "pixels_not_bit_identical": n_bad, "frames_checked": n_cpu,
                   "alpha_not_bit_identical": n_alpha, "colour_math": "fast" if args.fast_colour else "exact"}
         if counters is None:
@@ -517,6 +690,20 @@ def main():
                                 + ("; consecutive launches run on two streams and overlap: each launch's event interval includes the share of the "
                                    "device it left to its neighbour" if n_march_streams > 1 else ""))
 
+    cfg345 = {}
+    if rank == 0 and not multi and args.kernel == "accel" and not args.per_frame and args.workload == "cfg2" and not args.no_extras and not args.no_cpu_baseline:
+        import mnv_oracle as orc
+        try:
+            cfg345["cfg5"] = extras_cfg5(mnv, cases, torch, dev, tree)
+        except Exception as e:  # a secondary number must not cost the headline line
+            cfg345["cfg5"] = {"error": f"{type(e).__name__}: {e}"}
+        del frames
+        tree = None
+        torch.cuda.empty_cache()
+        try:
+            cfg345.update(extras_cfg3_cfg4(mnv, cases, orc, torch, dev, opt, max(1, min(args.steps, 3))))
+        except Exception as e:
+            cfg345["cfg3"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         line = {
             "metric": "Mrays/sec at 1920x1080 on depth-10 SH-9 N3Tree; max|dRGBA| vs ref",
@@ -546,6 +733,7 @@ def main():
             "parity": parity,
             "setup_s": round(setup_s, 2),
         }
+        line.update(cfg345)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

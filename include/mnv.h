@@ -58,7 +58,8 @@ typedef struct mnv_tree_view {
     const int16_t *sample_counts; /* [capacity][N^3], may be NULL, n3tree.cpp:191-193 */
     float offset[3];
     float scale[3];
-    int32_t N;         /* spatial branching factor; only 2 is supported on the device */
+    int32_t N;         /* spatial branching factor: N = 2 ONLY on the device (both kernels; MNV_E_UNSUPPORTED otherwise).  The reference's
+                          descent (rt_core.cuh:137-143) multiplies by tree.N, but its loader warns about N != 2 (n3tree.cpp:85-87) */
     int32_t data_dim;  /* halfs per voxel row; sigma is column data_dim-1 */
     int32_t format;    /* MNV_FORMAT_* */
     int32_t basis_dim; /* SH basis functions per channel, -1 if none */
@@ -168,6 +169,8 @@ int mnv_accel_refresh(mnv_accel *accel, const mnv_tree_view *tree, int32_t old_c
 int mnv_accel_rebuild(mnv_accel *accel, const mnv_tree_view *tree, void *hip_stream);
 void mnv_accel_destroy(mnv_accel *accel);
 size_t mnv_accel_device_bytes(const mnv_accel *accel);
+/* level of the brick-ordered second lookup grid (0: none): what a report names beside the bytes above */
+int32_t mnv_accel_grid2_level(const mnv_accel *accel);
 /* Compute units the tuned kernel may fill with its persistent workgroups (8 per unit).  Default (and num_cus <= 0): every unit
  * of the device.  A caller that launches on a stream created with hipExtStreamCreateWithCUMask -- to leave units free for
  * the RCCL kernels of the tile gather, which cannot become resident next to a full set of persistent workgroups -- passes

@@ -1572,6 +1572,7 @@ void mnv_accel_destroy(mnv_accel *a) {
 }
 
 size_t mnv_accel_device_bytes(const mnv_accel *a) { return a ? a->bytes : 0; }
+int32_t mnv_accel_grid2_level(const mnv_accel *a) { return a ? a->view.grid2_level : -1; }
 
 int mnv_accel_set_cu_budget(mnv_accel *a, int32_t num_cus) {
     if (!a) return set_error(MNV_E_INVALID, "accel is null");

@@ -260,21 +260,33 @@ void terrain_tree(const mnv_synth_terrain_params &p, N3Tree &out) {
     };
     Builder b;
     b.add_chunk(-1, 0, 0, 0, 1);
-    std::vector<uint8_t> dense;
-    for (size_t c = 0; c < b.parent.size(); ++c) {
-        const int lvl = b.level[c];
-        dense.resize((c + 1) * 8, 0);
-        for (int j = 0; j < 8; ++j) {
-            const uint64_t vox = (uint64_t)c * 8 + j;
-            const uint32_t x = b.cx[c] * 2 + ((j >> 2) & 1), y = b.cy[c] * 2 + ((j >> 1) & 1), z = b.cz[c] * 2 + (j & 1);
-            if (!overlaps(x, y, z, lvl)) continue;
-            if (lvl < p.depth) {
-                const size_t n = b.add_chunk((int32_t)vox, x, y, z, lvl + 1);
-                b.child[vox] = (int32_t)(n - c);
-            } else {
-                dense[vox] = 1;
+    std::vector<uint8_t> dense, hit;
+    // Chunks are numbered in breadth-first order, so a level is a contiguous range: the overlap tests of a level (nine height samples
+    // per voxel, the whole cost of a 10 M-chunk tree) run on all cores, the children are then appended in the serial order -- the
+    // tree is the one the chunk-by-chunk loop builds.
+    for (size_t lo = 0; lo < b.parent.size();) {
+        const size_t hi = b.parent.size();
+        hit.assign((hi - lo) * 8, 0);
+        parallel_for((hi - lo) * 8, [&](size_t i) {
+            const size_t c = lo + i / 8;
+            const int j = (int)(i & 7);
+            hit[i] = overlaps(b.cx[c] * 2 + ((j >> 2) & 1), b.cy[c] * 2 + ((j >> 1) & 1), b.cz[c] * 2 + (j & 1), b.level[c]) ? 1 : 0;
+        });
+        dense.resize(hi * 8, 0);
+        for (size_t c = lo; c < hi; ++c) {
+            const int lvl = b.level[c];
+            for (int j = 0; j < 8; ++j) {
+                if (!hit[(c - lo) * 8 + j]) continue;
+                const uint64_t vox = (uint64_t)c * 8 + j;
+                if (lvl < p.depth) {
+                    const size_t n = b.add_chunk((int32_t)vox, b.cx[c] * 2 + ((j >> 2) & 1), b.cy[c] * 2 + ((j >> 1) & 1), b.cz[c] * 2 + (j & 1), lvl + 1);
+                    b.child[vox] = (int32_t)(n - c);
+                } else {
+                    dense[vox] = 1;
+                }
             }
         }
+        lo = hi;
     }
     tm.lap("structure");
     const size_t nvox = b.child.size();

@@ -3,7 +3,7 @@
  * TEST INFRASTRUCTURE ONLY -- see mnv_oracle.h for scope, citations, the
  * arithmetic specification and the pinning status.
  *
- * Build: gcc -O2 -ffp-contract=off -fno-fast-math -fopenmp (oracle/Makefile).
+ * Build: gcc -O3 -ffp-contract=off -fno-fast-math -fopenmp (oracle/Makefile).
  * -ffp-contract=off is part of the specification, not an optimisation choice:
  * every control-flow-relevant value (cell classification, t < tmax, the
  * light_intensity < stop_thresh early stop) must be reproduced bit for bit.
@@ -470,10 +470,16 @@ int orc_render_voxels(const orc_tree *tree, const orc_camera *cam, const orc_opt
 #endif
     (void)n_threads;
 
-#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads) \
+    /* Work items are 16x16-pixel tiles handed out one at a time: rays differ in cost by two orders of magnitude (sky against a
+       grazing ray through the shell), and rows of a 1080p frame are only 1080 / 4 = 270 items for 128 threads.  8160 tiles keep
+       every core busy to the end; neighbouring rays share the sub-tree in a core's cache. */
+    const int32_t tiles_x = (w + 15) / 16, tiles_y = (h + 15) / 16;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) \
     reduction(+ : c_rays, c_inb, c_hit, c_steps, c_levels, c_hits, c_stop) reduction(max : c_max)
-    for (int32_t ty = 0; ty < h; ++ty) {
-        for (int32_t tx = 0; tx < w; ++tx) {
+    for (int32_t tile = 0; tile < tiles_x * tiles_y; ++tile) {
+      const int32_t ty0 = (tile / tiles_x) * 16, tx0 = (tile % tiles_x) * 16;
+      for (int32_t ty = ty0; ty < ty0 + 16 && ty < h; ++ty) {
+        for (int32_t tx = tx0; tx < tx0 + 16 && tx < w; ++tx) {
             const int ix = x0 + tx, iy = y0 + ty;
             const int64_t p = (int64_t)ty * w + tx;
             float dir[3], cen[3], out[4] = {0.f, 0.f, 0.f, 0.f};
@@ -522,6 +528,7 @@ int orc_render_voxels(const orc_tree *tree, const orc_camera *cam, const orc_opt
             c_stop += (uint64_t)st.early_stop;
             if (st.steps > c_max) c_max = st.steps;
         }
+      }
     }
     if (ctr) {
         ctr->rays += c_rays;

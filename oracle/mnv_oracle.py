@@ -104,6 +104,21 @@ def tree_from_view(view, sample_counts=None) -> OrcTree:
     return t
 
 
+def physical_cores():
+    """(physical cores, hardware threads) of this host from the sysfs topology (distinct sibling sets); (None, threads) when unreadable."""
+    import glob
+    import os
+
+    threads = os.cpu_count() or 1
+    try:
+        groups = set()
+        for f in glob.glob("/sys/devices/system/cpu/cpu[0-9]*/topology/thread_siblings_list"):
+            groups.add(open(f).read().strip())
+        return (len(groups) or None), threads
+    except OSError:
+        return None, threads
+
+
 def render(tree: OrcTree, cam_struct, opt_struct, tile=None, *, want_rgba8=False, want_trackers=False,
            want_steps=False, visited=None, track_visit=False, n_threads=0):
     """Render a tile with the oracle.  Returns dict(rgba, rgba8, split, sample, steps, counters)."""

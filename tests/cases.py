@@ -90,6 +90,9 @@ CASES = {
 CFG3_TREE = dict(kind="terrain", depth=10, basis_dim=9, bricks_y=4, bricks_z=2, noise_cells=6, base=0.25, amplitude=0.35,
                  thickness=1.5 / 1024, scale=(0.5, 0.125, 0.125), seed=0)
 CFG3_SMALL = dict(CFG3_TREE, depth=7, thickness=1.5 / 128)
+# the size SURVEY.md 8(d) states for configs[2] / [3] (5 - 10 M chunks): the same terrain one level deeper with a gentler relief --
+# 7,218,572 chunks (3.2 GB of voxel rows, 57.7 M voxels), far beyond L2 + MALL; what bench.py times as cfg3 / cfg4
+CFG3_FULL = dict(CFG3_TREE, depth=11, amplitude=0.25, noise_cells=4, thickness=1.5 / 2048)
 
 
 def cfg3_camera(mnv, pose=0, width=1920, height=1080, fx=1400.0):
