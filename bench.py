@@ -42,7 +42,15 @@ MACRO_W, MACRO_H = 64, 24            # 30 x 45 = 1350 macro tiles: per-rank laun
                                      # (tools/partition_balance.py: 128x120 tiles leave the slowest rank 19 % behind)
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: 8.0 TB/s spec
 COUNTERS_JSON = os.path.join(ROOT, "tests", "golden", "cfg2_counters.json")
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")   # HBM bytes per launch from the committed PMC passes
+def _latest_traffic_json():
+    """profiles/rNN_traffic.json of the latest round: HBM bytes per launch from the committed PMC passes (valid for one kernel source hash)."""
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))
+    return found[-1] if found else os.path.join(ROOT, "profiles", "r02_traffic.json")
+
+
+TRAFFIC_JSON = _latest_traffic_json()
 
 
 def load_counters():
@@ -311,6 +319,24 @@ def extras_cfg5(mnv, cases, torch, dev, tree, frames_each=6):
     return res
 
 
+def predicted_step(world, root_period, n_frames, workload):
+    """ms per step that the one-GPU emulation of one rank of `world` measured for this partition (profiles/r02_root_emulation.jsonl: rank 0's
+    march beside a device copy of the incoming tiles and the un-permute; 64 frames of cfg2 per step), so that the line of a real N-GPU run
+    carries the model it is to be held against.  None when no such row exists."""
+    path = os.path.join(ROOT, "profiles", "r02_root_emulation.jsonl")
+    if workload != "cfg2" or n_frames != 64 or not os.path.exists(path):
+        return None
+    rows = [json.loads(ln) for ln in open(path) if ln.strip()]
+    rows = [r for r in rows if r.get("world") == world]
+    if not rows:
+        return None
+    best = min(rows, key=lambda r: abs(r.get("root_period", 0) - root_period))
+    return {"ms_per_step": best["step_ms"], "rank0_march_only_ms": best["rank0_march_only_ms"], "other_ranks_march_ms": best["rank1_march_only_ms"],
+            "root_period_of_the_emulation": best["root_period"], "source": "profiles/r02_root_emulation.jsonl",
+            "assumes": ["RCCL's receive costs rank 0 no more than a device copy of the same bytes", "a CU-masked stream keeps the reserved units free under N processes",
+                        "the peers' sends arrive while rank 0 marches (xGMI point-to-point links are not the bound)"]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -410,6 +436,7 @@ def main():
     reserve = args.reserve_cus if args.reserve_cus >= 0 else (32 if multi else 0)
     n_march_streams = RING if multi and not args.one_march_stream else 1
     march_streams = None
+    enabled_cus = None   # compute units the march stream may use (None: an ordinary stream, all of them)
     if reserve > 0 or n_march_streams > 1:
         # the march (and what follows it in stream order) runs on streams that cannot use `reserve` compute units; RCCL's own stream
         # and the gatherer's side stream can.  Two such streams, one per ring slot: the launch of step k + 1 fills the wave slots
@@ -423,6 +450,7 @@ def main():
                 reserve = 0
                 handle, enabled = mnv.stream_create_reserved(0)
             march_streams.append(torch.cuda.ExternalStream(handle, device=dev))
+        enabled_cus = int(enabled)
         mnv.accel_set_cu_budget(tree.accel, enabled)
         torch.cuda.set_stream(march_streams[0])
     stream = torch.cuda.current_stream(dev).cuda_stream
@@ -470,7 +498,7 @@ def main():
             box = [mnv.comm_get_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             comm = mnv.Comm(box[0], world, rank)
-        tg = TileGatherer(part, rank, dev, dtype=dt, depth=RING, frames=N_FRAMES, stage_on_host=args.backend == "gloo" and comm is None, comm=comm)
+        tg = TileGatherer(part, rank, dev, dtype=dt, depth=RING, frames=N_FRAMES, stage_on_host=args.backend == "gloo" and comm is None, comm=comm, timing=True)
         frames = tg._frames if rank == 0 else None
         counter = [0]
 
@@ -518,8 +546,18 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms, launches = mnv.take_timing()
     mnv.set_timing(False)
+    per_rank = None
     if multi:
         elapsed = all_max(elapsed)
+        # what every rank saw, gathered to rank 0 for the line: an N-GPU run that is slower than the one-GPU emulation predicted says where
+        tgt = tg.take_timings()
+        mine = {"rank": rank, "march_ms": round(kern_ms / max(1, launches), 4), "march_launches": launches, "local_tiles": int(n_local),
+                "gather_ms": round(tgt["gather_ms"], 4) if "gather_ms" in tgt else None, "unpermute_ms": round(tgt["unpermute_ms"], 4) if "unpermute_ms" in tgt else None,
+                "reserved_cus": reserve, "enabled_cus": enabled_cus, "cu_mask_in_effect": bool(reserve > 0 and enabled_cus is not None and enabled_cus < torch.cuda.get_device_properties(dev).multi_processor_count),
+                "rccl_version": mnv.rccl_version() if comm is not None else None, "device": torch.cuda.get_device_name(dev), "device_index": local_rank}
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        per_rank = box
 
     rays_per_step = N_FRAMES * W * H
     value = rays_per_step * args.steps / elapsed / 1e6
@@ -734,6 +772,9 @@ def main():
             "setup_s": round(setup_s, 2),
         }
         line.update(cfg345)
+        if multi:
+            line["per_rank"] = per_rank
+            line["predicted"] = predicted_step(world, part.root_period, N_FRAMES, args.workload)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -111,7 +111,7 @@ class TileGatherer:
     ``torch.distributed.gather`` on `group` (gloo in the CPU tests and the one-GPU rehearsal)."""
 
     def __init__(self, part: TilePartition, rank: int, device, dtype=torch.float32, channels: int = 4, depth: int = 3, group=None,
-                 frames: int = 0, stage_on_host: bool = False, comm=None):
+                 frames: int = 0, stage_on_host: bool = False, comm=None, timing: bool = False):
         """`frames` > 0: every slot holds a batch of that many frames (one launch + one gather per batch).
         `stage_on_host`: gather through host copies (for process groups without device collectives, e.g. gloo
         in the single-GPU rehearsal of the N > 1 path); the default hands device buffers to RCCL."""
@@ -126,6 +126,9 @@ class TileGatherer:
             raise ValueError("the RCCL communicator gathers device buffers")
         self._side = [torch.cuda.Stream(device=device) for _ in range(depth)] if on_gpu and not stage_on_host else None
         self._sent = [torch.cuda.Event() for _ in range(depth)] if self._side is not None else None
+        # `timing`: device time of every gather and (rank 0) un-permute on the side streams, for the per-rank report of bench.py --gpus N
+        self._timing = bool(timing) and self._side is not None
+        self._t_events = []   # (gather begin, gather end, un-permute end or None)
         if rank == 0:
             self._gathered = [torch.empty((part.world,) + shape, dtype=dtype, device=device) for _ in range(depth)]
             self._frames = [torch.empty(lead + (part.height, part.width, channels), dtype=dtype, device=device) for _ in range(depth)]
@@ -151,13 +154,22 @@ class TileGatherer:
         # after it and after the render just enqueued on the current stream
         side.wait_stream(torch.cuda.current_stream(side.device))
         with torch.cuda.stream(side):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self._timing else None
+            if ev:
+                ev[0].record()
             if self.comm is not None:
                 self.comm.gather_tiles(self._local[slot], self._gathered[slot] if self.rank == 0 else None, root=0, stream=side.cuda_stream)
             else:
                 dist.gather(self._local[slot], glist, dst=0, group=self.group, async_op=True).wait()  # stream-level wait on `side`
             self._sent[slot].record()      # local(slot) may be overwritten from here on
+            if ev:
+                ev[1].record()
             if self.rank == 0:
                 self.part.unpermute(self._gathered[slot], out=self._frames[slot])
+                if ev:
+                    ev[2].record()
+            if ev:
+                self._t_events.append(ev)
         self._pending[slot] = True
 
     def finish(self, slot: int) -> None:
@@ -178,6 +190,19 @@ class TileGatherer:
                 self.part.unpermute(self._gathered[slot], out=self._frames[slot])
             return
         torch.cuda.current_stream(self._side[slot].device).wait_event(self._sent[slot])
+
+    def take_timings(self) -> dict:
+        """Average device milliseconds per step of the gather (from its enqueue on the side stream, so waiting for the peers counts) and of
+        rank 0's un-permute since the last call; empty without `timing`.  Call after the streams were synchronised."""
+        if not self._t_events:
+            return {}
+        g = [e[0].elapsed_time(e[1]) for e in self._t_events]
+        u = [e[1].elapsed_time(e[2]) for e in self._t_events] if self.rank == 0 else []
+        self._t_events = []
+        out = {"gather_ms": sum(g) / len(g), "gathers": len(g)}
+        if u:
+            out["unpermute_ms"] = sum(u) / len(u)
+        return out
 
     def finish_all(self) -> None:
         for s in range(self.depth):

@@ -113,3 +113,19 @@ def test_bench_rccl_path_single_rank(torch_gpu, gather, reserve):
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["config"]["reserved_cus"] == reserve and "RCCL (mnv_gather_tiles) gather" in d["config"]["partition"]
     assert d["parity"]["pixels_not_bit_identical"] == 0 and d["parity"]["frames_checked"] >= 3
     assert d["value"] > 0 and d["roofline"]["launches"] == 3
+    # the first-contact report: what every rank measured, next to the step the one-GPU emulation predicts for the real world size
+    (pr,) = d["per_rank"]
+    assert pr["rank"] == 0 and pr["march_ms"] > 0 and pr["gather_ms"] > 0 and pr["unpermute_ms"] > 0 and pr["rccl_version"] > 0
+    assert pr["reserved_cus"] == reserve and pr["cu_mask_in_effect"] == (reserve > 0) and (reserve == 0 or pr["enabled_cus"] < 256)
+    assert "predicted" in d      # None here: the emulation has no row for one rank
+
+
+def test_scale_preflight_with_one_rank(torch_gpu):
+    """tools/scale_preflight.py -- peer access, communicator, gathers at the bench's message sizes, all-gather between all pairs, CU-masked
+    stream under N processes -- on the one GPU of this box: every item passes over real RCCL (self send / receive)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scale_preflight.py"), "--gpus", "1", "--json"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["ok"] and d["ranks"] == 1
+    names = [it["name"] for it in d["results"][0]["items"]]
+    assert names == ["peer access", "communicator", "gather 4.1 MB", "gather 16.6 MB", "all-gather", "masked stream"]

@@ -6,6 +6,7 @@ import re
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.environ.get("ROUND", "r03")
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
 
@@ -14,8 +15,8 @@ def avg(txt, name):
     return float(m.group(1))
 
 
-s = open(os.path.join(G, "r02_batch", "summary.txt")).read()
-mem = open(os.path.join(G, "r02_mem.txt")).read()
+s = open(os.path.join(G, R + "_batch", "summary.txt")).read()
+mem = open(os.path.join(G, R + "_mem.txt")).read()
 lines = [ln for ln in mem.splitlines() if ln.startswith("pmc_")]
 lat = avg(mem, "TCP_TCC_READ_REQ_LATENCY_sum") / avg(mem, "TCP_TCC_READ_REQ_sum")
 cyc = avg(mem, "GRBM_GUI_ACTIVE") / 8
@@ -26,11 +27,11 @@ s += "derived: L1->L2 read latency = TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ
     lat, avg(mem, "TCP_TCC_READ_REQ_sum"), cyc, req)
 s += "         -> %.0f L1 misses in flight per compute unit on average; TA busy %.0f %% (average unit); TCP_PENDING_STALL %.0f %% of the cycles of an average TCP\n" % (
     lat * req, 100 * avg(mem, "TA_BUSY_avr") / cyc, 100 * avg(mem, "TCP_PENDING_STALL_CYCLES_sum") / 256 / cyc)
-open(os.path.join(P, "r02_rocprofv3_summary.txt"), "w").write(s)
-shutil.copy(os.path.join(G, "r02_batch", "traffic.json"), os.path.join(P, "r02_traffic.json"))
+open(os.path.join(P, R + "_rocprofv3_summary.txt"), "w").write(s)
+shutil.copy(os.path.join(G, R + "_batch", "traffic.json"), os.path.join(P, R + "_traffic.json"))
 for t in ("per_frame", "per_frame_1stream", "ref_layout", "cfg3", "cfg4"):
-    shutil.copy(os.path.join(G, "r02_%s" % t, "summary.txt"), os.path.join(P, "r02_rocprofv3_summary_%s.txt" % t))
-shutil.copy(os.path.join(G, "r02_guided", "summary.txt"), os.path.join(P, "r02_rocprofv3_summary_guided_fused.txt"))
-d = json.load(open(os.path.join(G, "r02_bench_n1.json")))
-json.dump(d, open(os.path.join(P, "r02_bench_n1.json"), "w"))
+    shutil.copy(os.path.join(G, "%s_%s" % (R, t), "summary.txt"), os.path.join(P, "%s_rocprofv3_summary_%s.txt" % (R, t)))
+shutil.copy(os.path.join(G, R + "_guided", "summary.txt"), os.path.join(P, R + "_rocprofv3_summary_guided_fused.txt"))
+d = json.load(open(os.path.join(G, R + "_bench_n1.json")))
+json.dump(d, open(os.path.join(P, R + "_bench_n1.json"), "w"))
 print("value", d["value"], "frac", d["roofline"]["frac"], "traffic", d["roofline"]["traffic"], "per_frame", d["per_frame"]["value"])
