@@ -132,18 +132,22 @@ __global__ void accel_build_grid2(const uint32_t *nodes, uint32_t *grid2, uint32
 
 // ---- incremental update after a refinement step (mnv_accel_refresh)
 
-// depth of appended chunks from their parent words (parent[c] = parent_chunk * 8 + slot); repeated until nothing changes
-// because a new chunk may hang under another new chunk.  flags[0] = changed, flags[1] = deepest depth seen.
+// depth of appended chunks from their parent words (parent[c] = parent_chunk * 8 + slot): a new chunk may hang under another new chunk,
+// so every thread walks up until it meets a chunk that existed before (its depth is known) and adds the hops.  One launch, no
+// iteration on the host.  flags[1] = deepest depth seen.
 __global__ void accel_refresh_depth(const int32_t *parent, int32_t *depth, int32_t first, int32_t capacity, int32_t *flags) {
     const int32_t c = first + (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (c >= capacity || depth[c] != 0) return;
-    const int32_t pc = parent[c] >> 3;
-    if (pc < 0 || pc >= capacity) return;
-    const int32_t dp = depth[pc];
-    if (dp == 0) return;
-    depth[c] = dp + 1;
-    flags[0] = 1;
-    atomicMax(&flags[1], dp + 1);
+    if (c >= capacity) return;
+    int32_t cur = c, hops = 0;
+    while (cur >= first && hops < 64) {
+        const int32_t pc = parent[cur] >> 3;
+        if (pc < 0 || pc >= capacity) return;  // not linked (yet): left at depth 0, as before
+        cur = pc;
+        ++hops;
+    }
+    const int32_t d = depth[cur] + hops;
+    depth[c] = d;
+    atomicMax(&flags[1], d);
 }
 
 // node words of the appended chunks' voxels and the link word of the voxel each of them hangs under;
@@ -163,6 +167,7 @@ __global__ void accel_refresh_nodes(const int32_t *child, const int32_t *parent,
         const int32_t pv = parent[c];
         nodes[pv] = (uint32_t)c;
         if (depth[pv >> 3] <= grid_depth) flags[2] = 1;
+        atomicMin(&flags[3], depth[pv >> 3]);  // the shallowest voxel that stopped being a leaf: how many lookup cells need a patch
     }
 }
 
@@ -179,6 +184,7 @@ __global__ void accel_refresh_changed(const int32_t *changed_nodes, int32_t n, c
     for (int ch = 0; ch < 3; ++ch)
         for (int32_t k = 0; k < chan_halfs; ++k) rows[v * row_halfs + ch * chan_halfs + k] = k < per_chan ? data[v * data_dim + ch * per_chan + k] : (uint16_t)0;
     if (depth[c] <= grid_depth) flags[2] = 1;
+    atomicMin(&flags[3], depth[c]);
 }
 
 // Rewrite the level-L2 lookup cells covered by voxels that stopped being (or changed as) leaves.  Block (b, s): voxel b of the
@@ -1480,18 +1486,11 @@ int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity
     const int b = (t->format == MNV_FORMAT_SH && t->basis_dim >= 0) ? t->basis_dim : -1;
     const int per_chan = b > 0 ? b : 1, chan_halfs = b > 0 ? chan_bytes_for(b) / 2 : 1, row_halfs = a->view.row_bytes / 2;
     const int grid_depth = a->view.grid_level;  // leaves this shallow sit in the small (LDS-staged) lookup grid
-    int32_t h[4] = {0, a->view.max_depth, 0, 0};
+    int32_t h[4] = {0, a->view.max_depth, 0, 127};  // [1] deepest depth, [2] the small lookup grid is affected, [3] shallowest affected voxel
     if ((rc = check_hip(hipMemcpyAsync(a->flags, h, sizeof(h), hipMemcpyHostToDevice, stream), "refresh flags"))) return rc;
     const int32_t n_new = t->capacity - old_capacity;
     if (n_new > 0) {
-        for (int pass = 0; pass < 32; ++pass) {
-            hipLaunchKernelGGL(accel_refresh_depth, dim3((n_new + 255) / 256), dim3(256), 0, stream, t->parent, a->depth, old_capacity, t->capacity, a->flags);
-            int32_t changed = 0;
-            if ((rc = check_hip(hipMemcpyAsync(&changed, a->flags, 4, hipMemcpyDeviceToHost, stream), "read flag"))) return rc;
-            if ((rc = check_hip(hipMemsetAsync(a->flags, 0, 4, stream), "clear flag"))) return rc;
-            if ((rc = check_hip(hipStreamSynchronize(stream), "accel_refresh_depth"))) return rc;
-            if (!changed) break;
-        }
+        hipLaunchKernelGGL(accel_refresh_depth, dim3((n_new + 255) / 256), dim3(256), 0, stream, t->parent, a->depth, old_capacity, t->capacity, a->flags);
         const int64_t nv = (int64_t)n_new * 8;
         hipLaunchKernelGGL(accel_refresh_nodes, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, t->child, t->parent, t->data, a->depth, a->nodes,
                            old_capacity, t->capacity, t->data_dim, grid_depth, a->flags);
@@ -1508,13 +1507,18 @@ int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity
         const int64_t gcells = (int64_t)1 << (3 * a->view.grid_level);
         hipLaunchKernelGGL(accel_build_grid, dim3((unsigned)((gcells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid, a->grid_vox, a->view.grid_level);
     }
-    if (a->view.grid2_level > 0) {
-        // the level-L2 grid: only the cells the affected voxels cover (voxels deeper than L2 cover none)
+    if (a->view.grid2_level > 0 && h[3] <= a->view.grid2_level) {
+        // the level-L2 grid: only the cells the affected voxels cover (voxels deeper than L2 cover none: then nothing is launched).  A
+        // voxel of depth d covers 8^(L2 - d) cells; the slices per voxel (grid.y) follow the shallowest one instead of a fixed 32
+        // (131 k mostly idle workgroups for 4096 splits: 0.19 ms per refinement frame).
+        const int sh = a->view.grid2_level - std::max(h[3], 1);
+        const uint64_t cells = (uint64_t)1 << (3 * std::min(sh, 10));
+        const unsigned gy = (unsigned)std::min<uint64_t>(32, std::max<uint64_t>(1, cells / 256));
         if (n_new > 0)
-            hipLaunchKernelGGL(accel_patch_grid2, dim3((unsigned)n_new, 32), dim3(256), 0, stream, (const int32_t *)nullptr, old_capacity, t->parent, a->depth,
+            hipLaunchKernelGGL(accel_patch_grid2, dim3((unsigned)n_new, gy), dim3(256), 0, stream, (const int32_t *)nullptr, old_capacity, t->parent, a->depth,
                                a->nodes, a->grid2, a->grid2_vox, a->view.grid2_level);
         if (n_changed > 0 && t->parent)
-            hipLaunchKernelGGL(accel_patch_grid2, dim3((unsigned)n_changed, 32), dim3(256), 0, stream, changed_nodes, 0, t->parent, a->depth, a->nodes, a->grid2,
+            hipLaunchKernelGGL(accel_patch_grid2, dim3((unsigned)n_changed, gy), dim3(256), 0, stream, changed_nodes, 0, t->parent, a->depth, a->nodes, a->grid2,
                                a->grid2_vox, a->view.grid2_level);
         else if (n_changed > 0) {
             const int64_t g2cells = (int64_t)1 << (3 * a->view.grid2_level);

@@ -164,8 +164,28 @@ struct VolumeRenderer::Impl {
     void get_more_samples(RenderOptions &o, FrameStats &st, uint64_t seed);
     // cuda_renderer.cpp:335-381
     void prune_tree(FrameStats &st);
+    // query_submodules for the samples of a refinement step.  On several ranks (set_ranks) every rank evaluates its share of the rows
+    // -- the samples are a pure function of (seed, frame), so every rank holds them all -- and the results are all-gathered: what
+    // stays replicated of the step is the vote and the tree edit, not the networks ("broadcast new rows").
+    float *query_rows(const int16_t *d_clusters, const float *d_rand, int dim, int64_t rows, int stride);
     void refine_after_frame(RenderOptions &o, FrameStats &st, uint64_t seed, bool track_visit);
 };
+
+float *VolumeRenderer::Impl::query_rows(const int16_t *d_clusters, const float *d_rand, int dim, int64_t rows, int stride) {
+    const int world = comm ? part.world : 1, rank = comm ? part.rank : 0;
+    if (world <= 1) {
+        float *d_results = results.get<float>((size_t)rows * stride);
+        mnv_check(mnv_query_submodules(mlp, d_clusters, d_rand, dim, rows, d_results, stride, stream), "mnv_query_submodules");
+        return d_results;
+    }
+    const int64_t per = (rows + world - 1) / world;  // equal blocks (the last one ragged): the all-gather's table is [world][per rows]
+    float *d_results = results.get<float>((size_t)per * world * stride);
+    const int64_t lo = std::min<int64_t>(rows, per * rank), hi = std::min<int64_t>(rows, per * (rank + 1));
+    if (hi > lo)
+        mnv_check(mnv_query_submodules(mlp, d_clusters + lo, d_rand + lo * dim, dim, hi - lo, d_results + lo * stride, stride, stream), "mnv_query_submodules");
+    mnv_check(mnv_allgather(comm, d_results, (size_t)per * stride * sizeof(float), stream), "mnv_allgather");
+    return d_results;
+}
 
 void VolumeRenderer::Impl::expand_voxels(RenderOptions &o, FrameStats &st, uint64_t seed) {
     const int64_t n_px = tracker_rows();
@@ -187,13 +207,12 @@ void VolumeRenderer::Impl::expand_voxels(RenderOptions &o, FrameStats &st, uint6
     const int64_t children = (int64_t)n * 8, rows = children * spc;
     float *d_rand = rand_sample.get<float>((size_t)rows * dim);
     int16_t *d_clusters = rand_clusters.get<int16_t>((size_t)rows);
-    float *d_results = results.get<float>((size_t)rows * (dd + 1));
     mnv_check(mnv_fill_uniform(d_rand, rows * dim, seed, stream), "mnv_fill_uniform");
     const mnv_tree_edit e = edit();
     mnv_check(mnv_add_children_and_generate_samples(&e, o.c_abi(), d_nodes, n, d_rand, dim, d_clusters, visit_tracker.get<int32_t>(max_tree_capacity),
                                                     &grid, stream),
               "mnv_add_children_and_generate_samples");
-    mnv_check(mnv_query_submodules(mlp, d_clusters, d_rand, dim, rows, d_results, dd + 1, stream), "mnv_query_submodules");
+    float *d_results = query_rows(d_clusters, d_rand, dim, rows, dd + 1);
     mnv_check(mnv_apply_split_results(tree->device.data, tree->device.sample_counts, tree->capacity, n, d_results, dd + 1, spc, dd, stream),
               "mnv_apply_split_results");
     const int old_capacity = tree->capacity;
@@ -217,11 +236,10 @@ void VolumeRenderer::Impl::get_more_samples(RenderOptions &o, FrameStats &st, ui
     const int64_t rows = (int64_t)n * spc;
     float *d_rand = rand_sample.get<float>((size_t)rows * dim);
     int16_t *d_clusters = rand_clusters.get<int16_t>((size_t)rows);
-    float *d_results = results.get<float>((size_t)rows * (dd + 1));
     mnv_check(mnv_fill_uniform(d_rand, rows * dim, seed ^ 0x5a5a5a5a5a5a5a5aull, stream), "mnv_fill_uniform");
     const mnv_tree_edit e = edit();
     mnv_check(mnv_generate_samples(&e, o.c_abi(), d_nodes, n, d_rand, dim, d_clusters, &grid, stream), "mnv_generate_samples");
-    mnv_check(mnv_query_submodules(mlp, d_clusters, d_rand, dim, rows, d_results, dd + 1, stream), "mnv_query_submodules");
+    float *d_results = query_rows(d_clusters, d_rand, dim, rows, dd + 1);
     mnv_check(mnv_apply_sample_results(tree->device.data, tree->device.sample_counts, d_nodes, n, d_results, dd + 1, spc, dd, stream),
               "mnv_apply_sample_results");
     st.resampled = n;

@@ -64,7 +64,7 @@ def test_mnv_render_multi_gpu_mode_with_one_rank(mnv, orc, torch_gpu, tmp_path):
     one, dist = str(tmp_path / "one"), str(tmp_path / "dist")
     r1 = subprocess.run(common + ["--out", one], capture_output=True, text=True, timeout=600)
     assert r1.returncode == 0, r1.stderr + r1.stdout
-    r2 = subprocess.run([exe] + common[1:] + ["--out", dist, "--gpus", "1"], capture_output=True, text=True, timeout=600)
+    r2 = subprocess.run(common + ["--out", dist, "--gpus", "1"], capture_output=True, text=True, timeout=600)   # the shipped binary over real RCCL
     assert r2.returncode == 0, r2.stderr + r2.stdout
     assert "x 1 (RCCL" in r2.stdout and "macro tiles" in r2.stdout
     for f in range(frames):
