@@ -112,6 +112,42 @@ __device__ __forceinline__ float exact_expf(float x, const uint64_t *tab) {
     return (float)y;
 }
 
+// expf as exact_expf, without branches: the main path runs on a clamped argument (nothing overflows on the way) and the special cases
+// (|x| >= 88) are selected afterwards, in exact_expf's order.  Same bits for every input; several of these in a row have no control
+// flow between them, so the compiler interleaves their binary64 chains.
+__device__ __forceinline__ float exact_expf_select(float x, const uint64_t *tab) {
+    constexpr double N = 32.0;
+    constexpr double InvLn2N = 0x1.71547652b82fep+0 * N;
+    constexpr double SHIFT = 0x1.8p+52;
+    constexpr double C0 = 0x1.c6af84b912394p-5 / N / N / N;
+    constexpr double C1 = 0x1.ebfce50fac4f3p-3 / N / N;
+    constexpr double C2 = 0x1.62e42ff0c52d6p-1 / N;
+    const float xc = __builtin_amdgcn_fmed3f(x, -128.f, 128.f);
+    const double xd = (double)xc;
+    double z = InvLn2N * xd;
+    double kd = z + SHIFT;
+    const uint64_t ki = (uint64_t)__double_as_longlong(kd);
+    kd -= SHIFT;
+    const double r = z - kd;
+    uint64_t t = tab[ki & 31u];
+    t += ki << 47;
+    const double s = __longlong_as_double((long long)t);
+    z = C0 * r + C1;
+    const double r2 = r * r;
+    double y = C2 * r + 1.0;
+    y = z * r2 + y;
+    y = y * s;
+    float res = (float)y;
+    const uint32_t ix = __float_as_uint(x);
+    const uint32_t abstop = (ix >> 20) & 0x7ffu;
+    const bool big = abstop >= 0x42bu;
+    res = (big && x < -0x1.9fe368p6f) ? 0.0f : res;
+    res = (big && x > 0x1.62e42ep6f) ? __uint_as_float(0x7f800000u) : res;
+    res = (big && abstop >= 0x7f8u) ? x + x : res;
+    res = ix == 0xff800000u ? 0.0f : res;
+    return res;
+}
+
 __device__ __forceinline__ float half_bits_to_float(uint16_t h) {
     _Float16 v;
     __builtin_memcpy(&v, &h, 2);

@@ -589,6 +589,22 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
         }
     };
 
+    // MNV_STATS=2 (diagnostics instantiation only): where the cycles of a wavefront's step go.  Every stamp waits for all outstanding
+    // memory operations first, so the phases do not overlap as they may in the product kernel: this is the DEPENDENT chain, what
+    // bounds a launch that drains.  stats[16..]: lookup (LDS grid -> grid2 -> node words), step arithmetic + opacity, row wait,
+    // colour arithmetic, the wavefront's whole time, wave-steps (tools/step_phases.py; LAB_NOTEBOOK.md round 3).
+    unsigned long long ph_lookup = 0, ph_step = 0, ph_row = 0, ph_colour = 0, ph_steps = 0, ph_mark = 0;
+    auto phase_clock = [&]() -> unsigned long long {
+        if constexpr (MODE == 1) {
+            if (K.count_stats == 2) {
+                __builtin_amdgcn_s_waitcnt(0);
+                return (unsigned long long)__builtin_readcyclecounter();
+            }
+        }
+        return 0ull;
+    };
+    const unsigned long long ph_begin = phase_clock();
+
     for (;;) {
         const uint64_t idle = __ballot(!alive);
         const int n_idle = __popcll(idle);
@@ -705,6 +721,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
         bool dense = false;
         float delta_t = 0.f, weight = 0.f, att = 1.f;
         uint32_t vox = 0;
+        ph_mark = phase_clock();
         if (alive) {
             if (!(t < tmax)) {
                 // loop exit, rt_core.cuh:325-330: the pixel is finished in flush_finished()
@@ -749,6 +766,13 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                         vox = (v << 1) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh, 1u);
                         word = A.nodes[vox];
                         src = 2;
+                    }
+                }
+                if constexpr (MODE == 1) {
+                    if (K.count_stats == 2) {
+                        const unsigned long long now = phase_clock();
+                        ph_lookup += now - ph_mark;
+                        ph_mark = now;
                     }
                 }
                 const int depth = (int)((word >> 16) & 0x7fu);
@@ -832,6 +856,14 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                 }
             }
         }
+        if constexpr (MODE == 1) {
+            if (K.count_stats == 2) {
+                const unsigned long long now = phase_clock();
+                ph_step += now - ph_mark;
+                ph_mark = now;
+                ++ph_steps;
+            }
+        }
         // ---- colour of the dense samples of this iteration (rt_core.cuh:254-291)
         const uint64_t dense_mask = __ballot(dense);
         if (dense_mask != 0) {
@@ -908,6 +940,13 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                     const ChanWords<NW> c0 = *reinterpret_cast<const ChanWords<NW> *>(row);
                     const ChanWords<NW> c1 = *reinterpret_cast<const ChanWords<NW> *>(row + CHAN_BYTES);
                     const ChanWords<NW> c2 = *reinterpret_cast<const ChanWords<NW> *>(row + 2 * CHAN_BYTES);
+                    if constexpr (MODE == 1) {
+                        if (K.count_stats == 2) {
+                            const unsigned long long now = phase_clock();   // the rows have arrived
+                            ph_row += now - ph_mark;
+                            ph_mark = now;
+                        }
+                    }
                     float b[NB];
 #pragma unroll
                     for (int k = 0; k < NB; ++k) b[k] = my_ray[k * BLOCK];
@@ -948,6 +987,19 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
             }
         }
         t += delta_t;  // 0 for lanes that did not step
+        if constexpr (MODE == 1) {
+            if (K.count_stats == 2) ph_colour += phase_clock() - ph_mark;  // (iterations without a dense lane: the ballot and the transmittance update)
+        }
+    }
+    if constexpr (MODE == 1) {
+        if (K.count_stats == 2 && lane == 0) {
+            atomicAdd(&K.stats[16], ph_lookup);
+            atomicAdd(&K.stats[17], ph_step);
+            atomicAdd(&K.stats[18], ph_row);
+            atomicAdd(&K.stats[19], ph_colour);
+            atomicAdd(&K.stats[20], phase_clock() - ph_begin);
+            atomicAdd(&K.stats[21], ph_steps);
+        }
     }
     if constexpr (MODE == 1) {
         if (K.timeline && lane == 0) K.timeline[(size_t)K.timeline_tiles * 4 + (size_t)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 2 + 1] = wall_clock64();
@@ -1202,7 +1254,8 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     static const bool env_stats = getenv("MNV_STATS") != nullptr;
     static const char *env_timeline = getenv("MNV_TIMELINE");
     K.stats = (env_stats || env_ablate || env_timeline) ? accel->stats : nullptr;  // all three run on the diagnostics instantiation
-    K.count_stats = env_stats ? 1 : 0;
+    static const int env_stats_level = getenv("MNV_STATS") ? std::max(1, atoi(getenv("MNV_STATS"))) : 0;
+    K.count_stats = env_stats ? env_stats_level : 0;
     K.refill_min = (env_refill > 0 && n_frames == 1) ? env_refill : 64;  // batches refill whole tiles (a grab must not straddle frames);  // sweep in DESIGN.md: 16 -> 0.606 ms, 32 -> 0.535, 48 -> 0.507, 56 -> 0.504, 64 -> 0.506
     int blocks_per_cu = lds_level >= 5 ? 1 : (lds_level == 4 ? 6 : 8);
     if ((K.split_track || K.sample_track || K.samples || K.visited) && blocks_per_cu > MNV_TRACK_WAVES) blocks_per_cu = MNV_TRACK_WAVES;
@@ -1453,8 +1506,8 @@ int mnv_accel_create_reserved(const mnv_tree_view *t, int64_t max_capacity, void
     for (int i = 0; i < kSlots; ++i)
         if ((rc = check_hip(hipEventCreateWithFlags(&a->slot_done[i], hipEventDisableTiming), "hipEventCreate(slot)"))) return fail(rc);
 
-    if ((rc = check_hip(hipMalloc((void **)&a->stats, 16 * sizeof(unsigned long long)), "hipMalloc(stats)"))) return fail(rc);
-    if ((rc = check_hip(hipMemsetAsync(a->stats, 0, 16 * sizeof(unsigned long long), stream), "memset stats"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&a->stats, 32 * sizeof(unsigned long long)), "hipMalloc(stats)"))) return fail(rc);
+    if ((rc = check_hip(hipMemsetAsync(a->stats, 0, 32 * sizeof(unsigned long long), stream), "memset stats"))) return fail(rc);
 
     if ((rc = accel_build(a, t, stream))) return fail(rc);
     *out = a;
@@ -1536,6 +1589,11 @@ void mnv_accel_destroy(mnv_accel *a) {
     if (a->stats && getenv("MNV_STATS")) {
         unsigned long long h[16];
         if (hipMemcpy(h, a->stats, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long ph[8] = {};
+            if (hipMemcpy(ph, a->stats + 16, sizeof(ph), hipMemcpyDeviceToHost) == hipSuccess && ph[4] > 0)
+                fprintf(stderr, "[mnv phases] share of the wavefronts' time (serialised by the stamps): lookup %.3f, step arithmetic + opacity %.3f, row wait %.3f, "
+                                "colour arithmetic %.3f, other (refill, ray set-up, flush, loop) %.3f; wave-steps %llu\n",
+                        (double)ph[0] / ph[4], (double)ph[1] / ph[4], (double)ph[2] / ph[4], (double)ph[3] / ph[4], 1.0 - (double)(ph[0] + ph[1] + ph[2] + ph[3]) / ph[4], ph[5]);
             const char *names[] = {"outer_iter", "refill", "march_step", "node_load", "dense", "colour_pass"};
             for (int i = 0; i < 6; ++i)
                 fprintf(stderr, "[mnv stats] %-13s wave-level %llu lane-level %llu (%.1f lanes)\n", names[i], h[2 * i], h[2 * i + 1],
