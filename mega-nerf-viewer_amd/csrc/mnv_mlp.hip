@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "mnv_internal.h"
@@ -141,8 +142,15 @@ __global__ __launch_bounds__(256) void mlp_scatter(const int16_t *__restrict__ c
 
 // ---------------------------------------------------------------- the network
 
-template <int MT>  // hidden width = 16 * MT
-__global__ __launch_bounds__(256) void mlp_forward_kernel(const MlpLaunch L) {
+// One workgroup = WAVES wavefronts x (16 * NT) rows per pass = 256 rows.  <4, 4, 4>: 64-wide networks, four column tiles per
+// wavefront.  <8, 2, 8>: 128-wide networks -- their weights fill most of a CU's LDS (131 KB for 4 hidden layers), so one workgroup
+// per CU is all that fits: eight wavefronts with two column tiles each share the weights (two per SIMD, 64 accumulator + 32 operand
+// registers) instead of four wavefronts that hold 128 + 64 and leave every SIMD with one wavefront and nothing to overlap its
+// LDS and matrix-pipe latencies with.
+template <int MT, int NT, int WAVES>  // hidden width = 16 * MT
+__global__ __launch_bounds__(64 * WAVES, 2) void mlp_forward_kernel(const MlpLaunch L) {
+    static_assert(WAVES * 16 * NT == kRowsPerPass, "a pass is 256 rows");
+    constexpr int COLS = 16 * NT;  // samples (MFMA columns) of one wavefront
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const MlpShape &S = L.S;
     if ((int)blockIdx.x >= L.tile_start[S.n_clusters]) return;
@@ -154,150 +162,195 @@ __global__ __launch_bounds__(256) void mlp_forward_kernel(const MlpLaunch L) {
         else hi = mid;
     }
     const int cluster = lo;
-    const int first = L.seg_start[cluster] + ((int)blockIdx.x - L.tile_start[cluster]) * kRowsPerBlock;
-    const int rows = min(kRowsPerBlock, L.seg_start[cluster + 1] - first);
+    const int block_first = L.seg_start[cluster] + ((int)blockIdx.x - L.tile_start[cluster]) * kRowsPerBlock;
+    const int block_rows = min(kRowsPerBlock, L.seg_start[cluster + 1] - block_first);
 
     // weights and biases of this cluster -> LDS
-    half8 *s_frag = reinterpret_cast<half8 *>(lds);
-    float *s_bias = reinterpret_cast<float *>(lds + (size_t)S.frag_halfs * 2);
+    const half8 *s_frag = reinterpret_cast<const half8 *>(lds);
+    const float *s_bias = reinterpret_cast<const float *>(lds + (size_t)S.frag_halfs * 2);
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(L.frags + (size_t)cluster * S.frag_halfs);
         uint4 *dst = reinterpret_cast<uint4 *>(lds);
         for (int i = threadIdx.x; i < S.frag_halfs / 8; i += blockDim.x) dst[i] = src[i];
         const float *bsrc = L.biases + (size_t)cluster * S.bias_floats;
-        for (int i = threadIdx.x; i < S.bias_floats; i += blockDim.x) s_bias[i] = bsrc[i];
+        float *bdst = reinterpret_cast<float *>(lds + (size_t)S.frag_halfs * 2);
+        for (int i = threadIdx.x; i < S.bias_floats; i += blockDim.x) bdst[i] = bsrc[i];
     }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, col = lane & 15;
-    const int block_first = first, block_rows = rows;
-    for (int pass_first = 0; pass_first < block_rows; pass_first += kRowsPerPass) {
-    const int first = block_first + pass_first, rows = min(kRowsPerPass, block_rows - pass_first);
-    // Two roles per lane.  Encoding: lane L owns sample L of the wavefront (one row load, features evaluated with a
-    // wave-uniform feature index, so the index arithmetic is scalar).  Matrix operand / output: lane (g, col) serves the
-    // samples col + 16 nt.  The encoded half pairs cross over through a 4 KB per-wavefront LDS tile per K tile.
-    int32_t src_row[kNT];
-#pragma unroll
-    for (int nt = 0; nt < kNT; ++nt) {
-        const int local = wave * 64 + nt * 16 + col;
-        src_row[nt] = local < rows ? L.order[first + local] : -1;
-    }
-    float p[3], d[3];
-    const uint16_t *emb = nullptr;
-    {
-        const int local = wave * 64 + lane;
-        const float *x = L.samples + (int64_t)L.order[first + (local < rows ? local : 0)] * L.samples_stride;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            p[i] = (x[i] - S.center[i]) * S.inv_extent[i];
-            d[i] = S.need_viewdir ? x[3 + i] : 0.f;
-        }
-        if (S.n_embeddings > 0) {
-            int idx = (int)x[S.need_viewdir ? 6 : 3];
-            idx = idx < 0 ? 0 : (idx >= S.n_embeddings ? S.n_embeddings - 1 : idx);
-            emb = L.embeddings + ((size_t)cluster * S.n_embeddings + idx) * S.embedding_dim;
-        }
-    }
-    uint32_t *s_enc = reinterpret_cast<uint32_t *>(lds + (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4) + wave * (16 * 64);
-
-    f32x4 acc[MT][kNT];
-    const half8 *w = s_frag;
-    const float *b = s_bias;
-    auto load_bias = [&](int n_mt) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-            if (mt < n_mt) {
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(b + 16 * mt + 4 * g);
-#pragma unroll
-                for (int nt = 0; nt < kNT; ++nt) acc[mt][nt] = bv;
-            }
-    };
-
-    // ---- layer 0: B fragments are computed from the raw sample on the fly
-    load_bias(MT);
+    // the wavefront's encode tile: one K tile (32 features) of its COLS samples, a sample's 64 bytes in operand order (the 8 halfs of
+    // lane group gg at byte 16 gg: features 4 gg .. 4 gg + 3 and 16 + 4 gg .. 16 + 4 gg + 3): written as four 16-byte stores by the
+    // lane that owns the sample, read as one 16-byte load per column tile by the lane that feeds the matrix pipe
+    uint4 *s_enc = reinterpret_cast<uint4 *>(lds + (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4) + wave * (COLS * 4);
     const int emb_base = S.n_pos + S.n_dir;
-    for (int kk = 0; kk < S.nkk0; ++kk) {
-        // encode features [32 kk, 32 kk + 32) of this lane's sample: pair (f, f + 1) -> dword ((g * 4 + e / 2) * 64 + lane) of the tile,
-        // where (g, e) is the K slot of feature f in the MFMA operand (slot_feature)
-        for (int f2 = 0; f2 < 16; ++f2) {
-            const int r = 2 * f2, f = 32 * kk + r;  // wave-uniform
-            float v0, v1;
-            if (f >= emb_base && f < S.in_dim) v0 = half_bits_to_float(emb[f - emb_base]);
-            else v0 = encode_feature(S, f, p, d);
-            if (f + 1 >= emb_base && f + 1 < S.in_dim) v1 = half_bits_to_float(emb[f + 1 - emb_base]);
-            else v1 = encode_feature(S, f + 1, p, d);
-            const int fg = (r & 15) >> 2, fe = (r >> 4) * 4 + (r & 3);
-            union {
-                _Float16 h[2];
-                uint32_t u;
-            } pk;
-            pk.h[0] = (_Float16)v0;
-            pk.h[1] = (_Float16)v1;
-            s_enc[(fg * 4 + (fe >> 1)) * 64 + lane] = pk.u;
-        }
-        __builtin_amdgcn_wave_barrier();  // LDS executes a wavefront's accesses in order; this only pins the compiler's order
-        half8 bf[kNT];
-#pragma unroll
-        for (int nt = 0; nt < kNT; ++nt) {
-            union {
-                uint32_t u[4];
-                half8 h;
-            } rd;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rd.u[q] = s_enc[(g * 4 + q) * 64 + nt * 16 + col];
-            bf[nt] = rd.h;
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const half8 a = w[(mt * S.nkk0 + kk) * 64 + lane];
-#pragma unroll
-            for (int nt = 0; nt < kNT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[nt], acc[mt][nt], 0, 0, 0);
-        }
-    }
-    w += MT * S.nkk0 * 64;
-    b += 16 * MT;
 
-    // ---- hidden layers 1 .. hidden_layers-1 and the output layer: B fragments are the previous accumulators
-    for (int layer = 1; layer <= S.hidden_layers; ++layer) {
-        const int n_mt = layer < S.hidden_layers ? MT : S.mt_out;
-        half8 bf[MT / 2][kNT];
+    for (int pass_first = 0; pass_first < block_rows; pass_first += kRowsPerPass) {
+        const int first = block_first + pass_first, rows = min(kRowsPerPass, block_rows - pass_first);
+        // Two roles per lane.  Encoding: lane j < COLS owns sample j of the wavefront.  Matrix operand / output: lane (g, col) serves the
+        // samples col + 16 nt.
+        int32_t src_row[NT];
 #pragma unroll
-        for (int kk = 0; kk < MT / 2; ++kk)
+        for (int nt = 0; nt < NT; ++nt) {
+            const int local = wave * COLS + nt * 16 + col;
+            src_row[nt] = local < rows ? L.order[first + local] : -1;
+        }
+        float p[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
+        const uint16_t *emb = nullptr;
+        if (lane < COLS) {
+            const int local = wave * COLS + lane;
+            const float *x = L.samples + (int64_t)L.order[first + (local < rows ? local : 0)] * L.samples_stride;
 #pragma unroll
-            for (int nt = 0; nt < kNT; ++nt) bf[kk][nt] = relu_pack(acc[2 * kk][nt], acc[2 * kk + 1][nt]);
-        load_bias(n_mt);
+            for (int i = 0; i < 3; ++i) {
+                p[i] = (x[i] - S.center[i]) * S.inv_extent[i];
+                d[i] = S.need_viewdir ? x[3 + i] : 0.f;
+            }
+            if (S.n_embeddings > 0) {
+                int idx = (int)x[S.need_viewdir ? 6 : 3];
+                idx = idx < 0 ? 0 : (idx >= S.n_embeddings ? S.n_embeddings - 1 : idx);
+                emb = L.embeddings + ((size_t)cluster * S.n_embeddings + idx) * S.embedding_dim;
+            }
+        }
+        // Encoding of K tile kk (32 features) of this lane's sample.  Position features -- the bulk -- have compile-time places in the first
+        // three K tiles (coordinate, then per octave three phase-0 and three phase-1/4 triangle waves), guarded per octave by the
+        // network's octave count (wave-uniform) and stored as four 16-byte words; whatever else the tile holds (view direction,
+        // embedding, position features past the 96th) is decoded at run time and stored half by half over the zeros.
+        typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+        typedef float float2v __attribute__((ext_vector_type(2)));
+        auto pos_feature = [&](auto f_tag) __attribute__((always_inline)) -> float {
+            constexpr int f = decltype(f_tag)::value;
+            if constexpr (f < 3) {
+                return p[f];
+            } else {
+                constexpr int k = (f - 3) / 6, r = (f - 3) % 6, i = r % 3;
+                const float scale = __uint_as_float((uint32_t)(127 + k) << 23);
+                return k < S.pos_octaves ? tri_wave(p[i] * scale + (r >= 3 ? 0.25f : 0.f)) : 0.f;
+            }
+        };
+        auto pair = [&](auto f_tag) __attribute__((always_inline)) -> uint32_t {
+            constexpr int f = decltype(f_tag)::value;
+            const float2v pr = {pos_feature(std::integral_constant<int, f>{}), pos_feature(std::integral_constant<int, f + 1>{})};
+            return __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, half2v));
+        };
+        auto fast_group = [&](auto kk_tag, auto gg_tag) __attribute__((always_inline)) {
+            constexpr int kk = decltype(kk_tag)::value, gg = decltype(gg_tag)::value, f0 = 32 * kk + 4 * gg;
+            s_enc[lane * 4 + gg] = make_uint4(pair(std::integral_constant<int, f0>{}), pair(std::integral_constant<int, f0 + 2>{}),
+                                              pair(std::integral_constant<int, f0 + 16>{}), pair(std::integral_constant<int, f0 + 18>{}));
+        };
+        auto fast_tile = [&](auto kk_tag) __attribute__((always_inline)) {
+            fast_group(kk_tag, std::integral_constant<int, 0>{});
+            fast_group(kk_tag, std::integral_constant<int, 1>{});
+            fast_group(kk_tag, std::integral_constant<int, 2>{});
+            fast_group(kk_tag, std::integral_constant<int, 3>{});
+        };
+        auto encode_tile = [&](int kk) __attribute__((always_inline)) {  // kk is wave-uniform
+            if (lane < COLS) {
+                int f_lo;  // the first feature of the tile the wide stores did not produce
+                if (kk == 0) {
+                    fast_tile(std::integral_constant<int, 0>{});
+                    f_lo = S.n_pos;
+                } else if (kk == 1) {
+                    fast_tile(std::integral_constant<int, 1>{});
+                    f_lo = S.n_pos;
+                } else if (kk == 2) {
+                    fast_tile(std::integral_constant<int, 2>{});
+                    f_lo = S.n_pos;
+                } else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (mt < n_mt) {
+                    for (int gg = 0; gg < 4; ++gg) s_enc[lane * 4 + gg] = make_uint4(0u, 0u, 0u, 0u);
+                    f_lo = 32 * kk;
+                }
+                f_lo = f_lo > 32 * kk ? f_lo : 32 * kk;
+                const int f_hi = S.in_dim < 32 * kk + 32 ? S.in_dim : 32 * kk + 32;
+                _Float16 *tile_h = reinterpret_cast<_Float16 *>(s_enc);
+                for (int f = f_lo; f < f_hi; ++f) {  // wave-uniform bounds
+                    const float v = (f >= emb_base) ? half_bits_to_float(emb[f - emb_base]) : encode_feature(S, f, p, d);
+                    const int r = f & 31;
+                    tile_h[lane * 32 + ((r & 15) >> 2) * 8 + (r >> 4) * 4 + (r & 3)] = (_Float16)v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // LDS executes a wavefront's accesses in order; this only pins the compiler's order
+        };
+
+        f32x4 acc[MT][NT];
+        const half8 *w = s_frag;
+        const float *b = s_bias;
+        auto bias_tile = [&](int mt) __attribute__((always_inline)) -> f32x4 { return *reinterpret_cast<const f32x4 *>(b + 16 * mt + 4 * g); };
+
+        // ---- layer 0: B fragments are computed from the raw sample on the fly, one K tile at a time; the bias enters as the C operand
+        //      of the first K tile's MFMAs, and the next M tile's fragment travels under the current one's MFMAs
+        for (int kk = 0; kk < S.nkk0; ++kk) {
+            encode_tile(kk);
+            half8 bf[NT];
 #pragma unroll
-                for (int kk = 0; kk < MT / 2; ++kk) {
-                    const half8 a = w[(mt * (MT / 2) + kk) * 64 + lane];
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = __builtin_bit_cast(half8, s_enc[(nt * 16 + col) * 4 + g]);
+            __builtin_amdgcn_wave_barrier();
+            half8 a = w[kk * 64 + lane];
+            if (kk == 0) {
 #pragma unroll
-                    for (int nt = 0; nt < kNT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, bf[kk][nt], acc[mt][nt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) {
+                    const half8 a_now = a;
+                    if (mt + 1 < MT) a = w[((mt + 1) * S.nkk0 + kk) * 64 + lane];
+                    const f32x4 bv = bias_tile(mt);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_now, bf[nt], bv, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const half8 a_now = a;
+                    if (mt + 1 < MT) a = w[((mt + 1) * S.nkk0 + kk) * 64 + lane];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_now, bf[nt], acc[mt][nt], 0, 0, 0);
                 }
             }
         }
-        w += n_mt * (MT / 2) * 64;
-        b += 16 * n_mt;
-    }
+        w += MT * S.nkk0 * 64;
+        b += 16 * MT;
 
-    // ---- store: lane holds features 16 mt + 4 g + r of row src_row[nt]
+        // ---- hidden layers 1 .. hidden_layers-1 and the output layer: B fragments are the previous accumulators
+        for (int layer = 1; layer <= S.hidden_layers; ++layer) {
+            const int n_mt = layer < S.hidden_layers ? MT : S.mt_out;
+            half8 bf[MT / 2][NT];
 #pragma unroll
-    for (int nt = 0; nt < kNT; ++nt) {
-        if (src_row[nt] < 0) continue;
-        float *out = L.results + (int64_t)src_row[nt] * L.result_stride;
+            for (int kk = 0; kk < MT / 2; ++kk)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            if (mt >= S.mt_out) break;
+                for (int nt = 0; nt < NT; ++nt) bf[kk][nt] = relu_pack(acc[2 * kk][nt], acc[2 * kk + 1][nt]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = 16 * mt + 4 * g + r;
-                if (f < S.out_dim) out[f] = acc[mt][nt][r];
+            for (int mt = 0; mt < MT; ++mt) {
+                if (mt < n_mt) {
+                    half8 a = w[(mt * (MT / 2)) * 64 + lane];
+#pragma unroll
+                    for (int kk = 0; kk < MT / 2; ++kk) {
+                        const half8 a_now = a;
+                        if (kk + 1 < MT / 2) a = w[(mt * (MT / 2) + kk + 1) * 64 + lane];
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            if (kk == 0) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_now, bf[0][nt], bias_tile(mt), 0, 0, 0);
+                            else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_now, bf[kk][nt], acc[mt][nt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            w += n_mt * (MT / 2) * 64;
+            b += 16 * n_mt;
+        }
+
+        // ---- store: lane holds features 16 mt + 4 g + r of row src_row[nt]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (src_row[nt] < 0) continue;
+            float *out = L.results + (int64_t)src_row[nt] * L.result_stride;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (mt >= S.mt_out) break;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * mt + 4 * g + r;
+                    if (f < S.out_dim) out[f] = acc[mt][nt][r];
+                }
             }
         }
-    }
     }
 }
 
@@ -501,15 +554,15 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
     L.order = order;
     L.seg_start = seg_start;
     L.tile_start = tile_start;
-    const size_t lds_bytes = (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4 + 4 * 16 * 64 * 4;  // + the encode tiles of the 4 wavefronts
+    const size_t lds_bytes = (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4 + 4 * 16 * 64 * 4;  // + the encode tiles: 256 samples x 64 bytes
     if (S.hidden_width == 64) {
-        auto kern = mlp_forward_kernel<4>;
+        auto kern = mlp_forward_kernel<4, 4, 4>;
         if ((rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "lds attr"))) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)max_tiles), dim3(256), lds_bytes, stream, L);
     } else {
-        auto kern = mlp_forward_kernel<8>;
+        auto kern = mlp_forward_kernel<8, 2, 8>;
         if ((rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "lds attr"))) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)max_tiles), dim3(256), lds_bytes, stream, L);
+        hipLaunchKernelGGL(kern, dim3((unsigned)max_tiles), dim3(512), lds_bytes, stream, L);
     }
     return check_hip(hipGetLastError(), "mlp_forward_kernel");
 }
