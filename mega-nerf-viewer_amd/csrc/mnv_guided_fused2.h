@@ -61,7 +61,11 @@ constexpr int kF2Block = 64 * (kF2NP + kF2NC);
 constexpr int kF2Ring = MNV_F2_RING;               // slots per producer ring (128 or 256): one march step adds at most 64 samples
 constexpr int kF2RingLog = kF2Ring == 256 ? 8 : 7, kF2RH = kF2Ring / 64;  // RH: slots of a ring that one consumer lane watches
 static_assert(kF2Ring == 128 || kF2Ring == 256, "ring size");
-constexpr int kF2RingWords = kF2Ring * (4 + 1 + 1);  // float4 {x, y, z, dz} -> {att, d0, d1, d2} | meta | owner's next slot
+#ifdef MNV_F2_LOG
+constexpr int kF2RingWords = kF2Ring * (4 + 1 + 1 + 1);  // + a debug word per entry (where in which window the consumer evaluated it)
+#else
+constexpr int kF2RingWords = kF2Ring * (4 + 1 + 1);
+#endif  // float4 {x, y, z, dz} -> {att, d0, d1, d2} | meta | owner's next slot
 constexpr int kF2WavesPerSimd = MNV_F2_WAVES;      // register budget: 128 / 96 / 80 VGPRs
 constexpr bool kF2Default = true;                  // mnv_set_fused_kernel(0) picks this kernel when it fits
 constexpr uint32_t kF2Ready = 128u;                // meta bit: the entry holds its results
@@ -170,6 +174,9 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
         float max_weight = -1.f, max_sample_weight = -1.f, sp_prio = 0.f, sa_prio = 0.f;
         int32_t sp_vox = -1, sa_vox = -1;
         int n_eval = 0, n_steps = 0;
+#ifdef MNV_F2_LOG
+        int n_comp = 0, n_pushed = 0;
+#endif
         unsigned long long t_ring = 0, t_flush = 0, t_walk = 0, t_setup = 0, t_step = 0, t_push = 0;
         uint32_t spins = 0;                           // consecutive waits (watchdog)
         uint32_t tail = 0, seen = 0, flush_sent = 0xffffffffu, stall_sent = 0xffffffffu, head = 0;  // wave-uniform: entries pushed; evaluated entries (counter last seen); last service request; lower bound of the oldest slot in use
@@ -198,6 +205,14 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                         const uint32_t nx = r_next[e];
                         if (!(m & kF2Ready)) break;
                         const bool last = (m & 64u) != 0;
+#ifdef MNV_F2_LOG
+                        if (F.diag && F.diag[31] && n_comp < 39) {
+                            float *rec = reinterpret_cast<float *>(F.diag[31]) + ((size_t)pix * 40 + n_comp) * 8;
+                            rec[0] = res.x; rec[1] = res.y; rec[2] = res.z; rec[3] = res.w;
+                            rec[4] = __uint_as_float(m); rec[5] = __uint_as_float(first_pending); rec[6] = ti; rec[7] = __uint_as_float(r_next[kF2Ring + e] & 63u);
+                        }
+                        ++n_comp;
+#endif
                         const float wc = res.x;
                         const float weight = last ? ti : ti * (1.0f - wc);
                         if constexpr (BASIS >= 0) {
@@ -219,6 +234,12 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
             // ---- rays that have ended and whose samples are all composited: write the pixel (alpha 1, renderer_kernel.cu:316)
             if (has_ray && done && !held && first_pending == kNone) {
                 composite_and_write(P, (int64_t)pix, o0, o1, o2, 1.0f);
+#ifdef MNV_F2_LOG
+                if (F.diag && F.diag[31]) {
+                    float *rec = reinterpret_cast<float *>(F.diag[31]) + ((size_t)pix * 40 + 39) * 8;
+                    rec[0] = (float)n_comp; rec[1] = o0; rec[2] = o1; rec[3] = o2; rec[4] = ti; rec[5] = (float)ns;
+                }
+#endif
                 if constexpr (TRACK) {
                     if (K.split_track) {
                         K.split_track[(int64_t)pix * 3 + 0] = sp_prio;
@@ -261,6 +282,9 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                     held = false;
                     ns = 0;
                     first_pending = prev_slot = kNone;
+#ifdef MNV_F2_LOG
+                    n_comp = n_pushed = 0;
+#endif
                     ti = 1.f;
                     o0 = o1 = o2 = 0.f;
                     if constexpr (TRACK) {
@@ -494,9 +518,15 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                     if (push) {
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
                         const uint32_t slot = tail + rank, e = slot & (kF2Ring - 1);
+#ifdef MNV_F2_CHECK_RINGS
+                        if (slot >= (uint32_t)kF2Ring && !(r_meta[e] & kF2Ready) && F.diag) atomicAdd(F.diag + 29, 1ull);  // overwrites an entry that was never evaluated
+#endif
                         r_data[e] = make_float4(px_, py_, pw_, pdz);
                         r_meta[e] = (uint32_t)lane | (last ? 64u : 0u) | ((uint32_t)(pcl & 0xffff) << 8);
                         r_next[e] = kNone;
+#ifdef MNV_F2_LOG
+                        r_next[kF2Ring + e] = pix * 64u + (uint32_t)(n_pushed++ & 63);
+#endif
                         if (first_pending == kNone) first_pending = slot;
                         else r_next[prev_slot & (kF2Ring - 1)] = slot;  // the chain's last entry is still in the ring: nobody but its owner frees it
                         prev_slot = slot;
@@ -584,6 +614,10 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
 #pragma unroll
                         for (int h = 0; h < kF2RH; ++h) {
                             if ((((uint32_t)lane + 64u * h - scan[p]) & (kF2Ring - 1)) < fresh) {
+#ifdef MNV_F2_CHECK_RINGS
+                                if (((watch_pend >> (kF2RH * p + h)) & 1u) && F.diag) atomicAdd(F.diag + 29, 1ull << 32);  // the slot's previous entry still waits
+                                if ((meta_p[lane + 64 * h] & kF2Ready) && F.diag) atomicAdd(F.diag + 29, 1ull << 40);      // a fresh entry that is already marked
+#endif
                                 const uint32_t c16 = (meta_p[lane + 64 * h] >> 8) & 0xffffu;
                                 watch_cl[p][h >> 1] = (h & 1) ? (watch_cl[p][h >> 1] & 0xffffu) | (c16 << 16) : (watch_cl[p][h >> 1] & 0xffff0000u) | c16;
                                 watch_pend |= 1u << (kF2RH * p + h);
@@ -745,10 +779,14 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                     const uint32_t e_j = where_j & (kF2Ring - 1);
                     const uint32_t meta_j = ring_meta(ring_j)[e_j];
                     const int owner_j = (rbase + ring_j) * 64 + (int)(meta_j & 63u);
+#ifdef MNV_F2_CHECK_RINGS
+                    if (share == 0 && (meta_j & kF2Ready) && F.diag) atomicAdd(F.diag + 29, 1ull << 48);  // evaluated twice
+#endif
                     float *dst = reinterpret_cast<float *>(ring_data(ring_j) + e_j);
                     const float dz_j = dst[3];  // read by both lane shares before either writes its results ...
                     __builtin_amdgcn_wave_barrier();  // ... (the other share of this column writes dst[3]: the read must not sink into a branch)
                     const bool last = (meta_j & 64u) != 0;
+
                     if constexpr (BASIS >= 0) {
                         // One instruction stream for both lane shares (a branch on the share would run both bodies, each on half the
                         // lanes): every lane evaluates two channel sums at ITS offsets and two exponentials of ITS arguments.
@@ -765,6 +803,19 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                         const float dA = sh_channel<BASIS>(basis, svA, 0), dB = sh_channel<BASIS>(basis, svB, 0);
                         const float sig = kValid ? col_out[3 * 32] : 0.f;
                         const float X = share ? dA : sig * dz_j, Y = share ? dB : dA;
+#ifdef MNV_F2_LOG
+                        if (F.diag && F.diag[30]) {
+                            const uint32_t key = ring_meta(ring_j)[2 * kF2Ring + e_j];  // pixel * 64 + sample
+                            float *rec = reinterpret_cast<float *>(F.diag[30]) + ((size_t)key * 2 + share) * 24;
+#pragma unroll
+                            for (int f = 0; f < 9; ++f) {
+                                rec[f] = svA(f);
+                                rec[9 + f] = svB(f);
+                            }
+                            rec[18] = dA; rec[19] = dB; rec[20] = X; rec[21] = __uint_as_float((uint32_t)jc | ((uint32_t)n << 8) | ((uint32_t)half << 16) | ((uint32_t)(n_runs & 0xfff) << 20));
+                            rec[22] = dz_j; rec[23] = sig;
+                        }
+#endif
                         const float eX = exact_expf_select(-X, s_exp), eY = exact_expf_select(-Y, s_exp);
                         const float out0 = share ? 1.f + eX : (last ? 0.f : eX), out1 = 1.f + eY;
                         *reinterpret_cast<float2 *>(dst + 2 * share) = make_float2(out0, out1);
@@ -867,6 +918,23 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                 }
                 const half8 *s_frag = reinterpret_cast<const half8 *>(s_mem + Lo.frags + slot * Lo.frag_words);
                 const float *s_bias = reinterpret_cast<const float *>(s_mem + Lo.bias + slot * Lo.bias_words);
+#ifdef MNV_F2_CHECK_WEIGHTS
+                auto check_weights = [&](int word) __attribute__((noinline)) {
+                    const uint4 *src = reinterpret_cast<const uint4 *>(F.frags + (size_t)c_star * S.frag_halfs);
+                    const uint4 *dst = reinterpret_cast<const uint4 *>(s_mem + Lo.frags + slot * Lo.frag_words);
+                    bool bad = false;
+                    for (int u = 0; u < S.frag_halfs / 512; ++u) {
+                        const uint4 a = src[u * 64 + lane], b = dst[u * 64 + lane];
+                        bad |= a.x != b.x || a.y != b.y || a.z != b.z || a.w != b.w;
+                    }
+                    const float *bsrc = F.biases + (size_t)c_star * S.bias_floats;
+                    const float *bdst = reinterpret_cast<const float *>(s_mem + Lo.bias + slot * Lo.bias_words);
+                    for (int u = lane; u < S.bias_floats; u += 64) bad |= __float_as_uint(bsrc[u]) != __float_as_uint(bdst[u]);
+                    if (__ballot(bad) != 0 && lane == 0 && F.diag) atomicAdd(F.diag + word, 1ull);
+                    if (lane == 0 && F.diag && (int)ld_relaxed(s_wc + 2 + 4 * slot) != c_star) atomicAdd(F.diag + 28, 1ull);
+                };
+                check_weights(28);
+#endif
                 // ---- encode: lane j builds column j of the B operand.  A column of one K tile is 64 bytes in operand order (the 8 halfs
                 //      of lane group g at byte 16 g: features 4 g .. 4 g + 3 and 16 + 4 g .. 16 + 4 g + 3), written as four 16-byte
                 //      stores.  Position features have compile-time places (p, then per octave three phase-0 and three phase-1/4
@@ -965,6 +1033,11 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                             for (int j = 0; j < 2; ++j) bf[kk][j] = __builtin_bit_cast(half8, tile_q[kk * (4 * kF2Cols) + ((2 * h + j) * 16 + col) * 4 + g]);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
+                            // One 16-row block at a time: without this compiler barrier the 12 operand loads of all four blocks are hoisted above the
+                            // first MFMA and the two column halves merged; that build produced an occasional wrong colour denominator (one
+                            // frame in ~100 at 1080p, tools/fused_stress.py) whose cause was not found -- LAB_NOTEBOOK.md, "the rare wrong
+                            // denominator".  With the barrier: 0 of 2560 frames, and 0 of 1280 under the slowed-consumer build that showed 22 %.
+                            asm volatile("" ::: "memory");
                             const f32x4 bv = bias_tile(mt);
 #pragma unroll
                             for (int kk = 0; kk < NKK0; ++kk) {
@@ -1006,6 +1079,9 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                 }
                 // done reading the slot.  With a slot per consumer the reference is kept until this consumer changes sub-module or idles (one
                 // that asks for a slot holds none, so a slot nobody reads always exists); with fewer slots it is dropped after every run.
+#ifdef MNV_F2_CHECK_WEIGHTS
+                check_weights(28);
+#endif
                 if (F.weight_slots < kF2NC) {
                     if (lane == 0) __hip_atomic_fetch_sub(s_wc + 2 + 4 * slot + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                     held_slot = -1;
@@ -1024,7 +1100,31 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
+#ifdef MNV_F2_CHECK_TILE
+                    auto readback = [&](int word) __attribute__((always_inline)) {
+                        bool bad = false;
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            if (mt < S.mt_out) {
+#pragma unroll
+                                for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const float back = *reinterpret_cast<volatile float *>(&s_out[(16 * mt + 4 * g + r) * 32 + nn * 16 + col]);
+                                        bad |= __float_as_uint(back) != __float_as_uint(acc[mt][2 * half + nn][r]);
+                                    }
+                            }
+                        }
+                        if (__ballot(bad) != 0 && lane == 0 && F.diag) atomicAdd(F.diag + word, 1ull);
+                    };
+                    readback(29);
+                    __builtin_amdgcn_wave_barrier();
+#endif
                     evaluate(half, std::true_type{});
+#ifdef MNV_F2_CHECK_TILE
+                    readback(30);
+                    __builtin_amdgcn_wave_barrier();
+#endif
                 }
                 if (F.diag) t_eval += wall_clock64() - t_c0;
             } else {

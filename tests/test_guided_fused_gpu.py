@@ -111,6 +111,36 @@ def test_fused_frame_at_cfg2_size(mnv, torch_gpu):
         assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref))
 
 
+def test_many_frames_in_a_row_stay_bit_identical(mnv, torch_gpu):
+    """The same frames over and over (8 poses x 12 launches at 1920x1080, about 9 M samples each): which samples share a window of the
+    network, which weight slot they find and when their owners composite them changes from launch to launch, the picture must not.
+    (tools/fused_stress.py is the long form of this; LAB_NOTEBOOK.md, "the rare wrong denominator", is why it exists.)"""
+    torch = torch_gpu
+    tree = cases.make_tree(mnv, cases.CFG2_TREE)
+    v = tree.host_view()
+    tree.move_to_device()
+    opt = mnv.RenderOptions.cli_defaults()
+    opt.basis_minmax[1] = 8
+    opt.max_guided_samples = 32
+    desc = mnv.mlp_desc(n_clusters=8, pos_octaves=4, hidden_width=64, hidden_layers=2, out_dim=v.data_dim + 1)
+    mlp = mnv.Mlp(desc, mlp_cases.make_params(mnv, desc, seed=4))
+    grid = make_grid(mnv)
+    w, h = 1920, 1080
+    out = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    bad = []
+    for pose in range(8):
+        cam = cases.cfg2_camera(mnv, pose, w, h, 1600.0)
+        ref, _, total = four_step_frame(mnv, torch, tree, cam, opt, mlp, grid, 32, 4)
+        ref_bits = torch.from_numpy(cases.bits(ref).view(np.int32)).cuda()
+        for rep in range(12):
+            out.fill_(float("nan"))
+            mnv.render_guided_fused(tree.accel, cam, opt, mlp, grid, rgba=out)
+            n_bad = int((out.view(torch.int32) != ref_bits).any(dim=-1).sum().item())
+            if n_bad:
+                bad.append((pose, rep, n_bad))
+    assert not bad, f"frames that differ from the four-step path (pose, launch, pixels): {bad}"
+
+
 def test_fused_frame_rejects_what_it_does_not_cover(mnv, torch_gpu):
     torch = torch_gpu
     spec = cases.CASES["rgba_d5"]

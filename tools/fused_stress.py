@@ -37,6 +37,11 @@ for pose in range(16):
         torch.cuda.synchronize()
         frames += 1
         n_bad = int((out.view(torch.int32) != ref.view(torch.int32)).any(dim=-1).sum().item())
-        if n_bad: bad_frames.append((pose, r, n_bad))
+        if n_bad:
+            bad = (out.view(torch.int32) != ref.view(torch.int32)).any(dim=-1)
+            ys, xs = torch.nonzero(bad, as_tuple=True)
+            d = (out - ref).abs().amax(dim=-1)[bad]
+            bad_frames.append((pose, r, n_bad, list(zip(xs.tolist()[:64], ys.tolist()[:64])), [round(float(v), 6) for v in d.tolist()[:64]]))
 mnv.set_fused_diag(None); mnv.set_fused_kernel(0)
-print({"kernel": version, "frames": frames, "bad_frames": bad_frames[:20], "n_bad_frames": len(bad_frames), "watchdog": int(diag[15].item())})
+print({"kernel": version, "frames": frames, "bad_frames": bad_frames[:20], "n_bad_frames": len(bad_frames), "watchdog": int(diag[15].item()),
+       "checks(weights, overwrite, registration, twice)": [int(x) for x in diag[28:32].tolist()]})
