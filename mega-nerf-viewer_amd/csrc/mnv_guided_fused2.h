@@ -32,9 +32,9 @@ namespace mnv {
 
 // Shape of a workgroup: NP producer wavefronts, NC consumer wavefronts (consumer c serves the rings of producers c * NP / NC ...),
 // NS weight slots in LDS shared by the consumers, rings of MNV_F2_RING slots.  The workgroup is a whole CU's worth of wavefronts at
-// 128 VGPRs.  Measured on cfg2 at 1080p (tools/f2_variants.sh, LAB_NOTEBOOK.md): 8 + 8 with 256-slot rings and two weight slots
-// 1.32 ms; 10 + 5 (256 slots, 2 weight slots) 1.39; 8 + 8 with 128-slot rings and four weight slots 1.45; 12 + 4 (128, 4) 1.53;
-// the one-role kernel 1.43.  Deep rings matter more than resident weights: the rays of an 8x8 tile reach a surface together, so
+// 128 VGPRs.  Measured on cfg2 at 1080p (tools/f2_variants.sh, LAB_NOTEBOOK.md): 8 + 8 with 256-slot rings and three weight slots
+// (158.5 KB of LDS) 1.24 ms, with two 1.31; 10 + 5 (256 slots, 2 weight slots: a third does not fit) 1.38; 12 + 4 (256, 2) 1.57;
+// 8 + 8 with 128-slot rings and four weight slots 1.45; the one-role kernel 1.43.  Deep rings matter more than resident weights: the rays of an 8x8 tile reach a surface together, so
 // a producer emits its samples in bursts that a 128-slot ring cannot absorb.
 #ifndef MNV_F2_NP
 #define MNV_F2_NP 8
@@ -43,7 +43,7 @@ namespace mnv {
 #define MNV_F2_NC 8
 #endif
 #ifndef MNV_F2_NS
-#define MNV_F2_NS 2
+#define MNV_F2_NS 3  // as many as fit beside the rings: launch_accel takes fewer when a network's fragments are larger
 #endif
 #ifndef MNV_F2_COLS
 #define MNV_F2_COLS 64  // columns (samples) of a network run: 64, or 32 (half the accumulators: a smaller register budget, more wavefronts)
