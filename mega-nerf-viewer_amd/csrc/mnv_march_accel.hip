@@ -1567,6 +1567,8 @@ int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity
         const int sh = a->view.grid2_level - std::max(h[3], 1);
         const uint64_t cells = (uint64_t)1 << (3 * std::min(sh, 10));
         const unsigned gy = (unsigned)std::min<uint64_t>(32, std::max<uint64_t>(1, cells / 256));
+        static const bool dbg = getenv("MNV_REFRESH_DEBUG") != nullptr;
+        if (dbg) fprintf(stderr, "[mnv refresh] n_new %d n_changed %d shallowest %d grid2_level %d slices %u\n", n_new, n_changed, h[3], a->view.grid2_level, gy);
         if (n_new > 0)
             hipLaunchKernelGGL(accel_patch_grid2, dim3((unsigned)n_new, gy), dim3(256), 0, stream, (const int32_t *)nullptr, old_capacity, t->parent, a->depth,
                                a->nodes, a->grid2, a->grid2_vox, a->view.grid2_level);
