@@ -1037,7 +1037,9 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                             // first MFMA and the two column halves merged; that build produced an occasional wrong colour denominator (one
                             // frame in ~100 at 1080p, tools/fused_stress.py) whose cause was not found -- LAB_NOTEBOOK.md, "the rare wrong
                             // denominator".  With the barrier: 0 of 2560 frames, and 0 of 1280 under the slowed-consumer build that showed 22 %.
+#ifndef MNV_F2_NO_L0_BARRIER  // (defined only to reproduce the failing build)
                             asm volatile("" ::: "memory");
+#endif
                             const f32x4 bv = bias_tile(mt);
 #pragma unroll
                             for (int kk = 0; kk < NKK0; ++kk) {

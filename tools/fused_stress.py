@@ -28,6 +28,7 @@ ref = torch.empty((H, W, 4), dtype=torch.float32, device="cuda"); out = torch.em
 diag = torch.zeros(32, dtype=torch.int64, device="cuda")
 mnv.set_fused_kernel(version); mnv.set_fused_diag(diag)
 bad_frames, frames = [], 0
+channel_counts = [0, 0, 0, 0]
 if track:
     import numpy as np
     opt.max_depth, opt.max_sample_count = 9, 9
@@ -63,7 +64,9 @@ for pose in range(16):
             bad = (out.view(torch.int32) != ref.view(torch.int32)).any(dim=-1)
             ys, xs = torch.nonzero(bad, as_tuple=True)
             d = (out - ref).abs().amax(dim=-1)[bad]
+            per_channel = [int(x) for x in (out.view(torch.int32) != ref.view(torch.int32))[bad].sum(dim=0).tolist()]
+            channel_counts = [a + b for a, b in zip(channel_counts, per_channel)]
             bad_frames.append((pose, r, n_bad, list(zip(xs.tolist()[:64], ys.tolist()[:64])), [round(float(v), 6) for v in d.tolist()[:64]]))
 mnv.set_fused_diag(None); mnv.set_fused_kernel(0)
-print({"kernel": version, "track": track, "frames": frames, "bad_frames": bad_frames[:20], "n_bad_frames": len(bad_frames), "watchdog": int(diag[15].item()),
+print({"kernel": version, "track": track, "frames": frames, "bad_frames": bad_frames[:20], "n_bad_frames": len(bad_frames), "differing pixels per channel (r, g, b, a)": channel_counts, "watchdog": int(diag[15].item()),
        "checks(weights, overwrite, registration, twice)": [int(x) for x in diag[28:32].tolist()]})
