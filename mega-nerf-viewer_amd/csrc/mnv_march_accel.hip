@@ -192,13 +192,16 @@ __global__ void accel_refresh_changed(const int32_t *changed_nodes, int32_t n, c
 // integer coordinates come from the walk up the parent words.
 __global__ void accel_patch_grid2(const int32_t *vox_pairs, int32_t first_chunk, const int32_t *parent, const int32_t *depth,
                                   const uint32_t *nodes, uint32_t *grid2, uint32_t *grid2_vox, int32_t L2) {
-    __shared__ uint32_t s_box[4];  // x, y, z at the voxel's own level; its depth (0: nothing to do)
+    __shared__ uint32_t s_box[5];  // x, y, z at the voxel's own level; its depth (0: nothing to do); the voxel
     if (threadIdx.x == 0) {
         int64_t pv = vox_pairs ? (int64_t)vox_pairs[2 * blockIdx.x] * 8 + vox_pairs[2 * blockIdx.x + 1] : (int64_t)parent[first_chunk + blockIdx.x];
         int32_t cur = (int32_t)(pv >> 3);
         const int32_t d = depth[cur];
         uint32_t x = 0, y = 0, z = 0;
-        if (d >= 1 && d <= L2) {
+        // (slices beyond the voxel's cell count leave before the walk up the parents: most voxels of a refinement step are deep and cover
+        // a few cells, the slices are sized for the shallowest)
+        const bool has_cells = d >= 1 && d <= L2 && (((uint64_t)1 << (3 * (L2 - d))) > (uint64_t)blockIdx.y * blockDim.x);
+        if (has_cells) {
             uint32_t slot = (uint32_t)(pv & 7);
             for (int k = 0; k < d; ++k) {
                 x |= ((slot >> 2) & 1u) << k;
@@ -213,7 +216,8 @@ __global__ void accel_patch_grid2(const int32_t *vox_pairs, int32_t first_chunk,
         s_box[0] = x;
         s_box[1] = y;
         s_box[2] = z;
-        s_box[3] = (d >= 1 && d <= L2) ? (uint32_t)d : 0u;
+        s_box[3] = has_cells ? (uint32_t)d : 0u;
+        s_box[4] = (uint32_t)pv;
     }
     __syncthreads();
     const int d = (int)s_box[3];
@@ -223,14 +227,14 @@ __global__ void accel_patch_grid2(const int32_t *vox_pairs, int32_t first_chunk,
     const uint64_t total = (uint64_t)1 << (3 * sh);
     for (uint64_t i = (uint64_t)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.y * blockDim.x) {
         const uint32_t ix = bx + (uint32_t)(i >> (2 * sh)), iy = by + (uint32_t)((i >> sh) & ((1u << sh) - 1u)), iz = bz + (uint32_t)(i & ((1u << sh) - 1u));
-        uint32_t chunk = 0, word = 0, vox = 0;
-        for (int32_t l = 1; l <= L2; ++l) {
+        // the walk starts at the voxel itself (every cell of its box passes through it), not at the root: a split voxel's cells end one
+        // level below it -- two dependent loads instead of L2
+        uint32_t vox = s_box[4], word = nodes[vox];
+        for (int32_t l = d + 1; l <= L2 && !(word & kLeafBit); ++l) {
             const int32_t s2 = L2 - l;
             const uint32_t cidx = (((ix >> s2) & 1u) << 2) | (((iy >> s2) & 1u) << 1) | ((iz >> s2) & 1u);
-            vox = chunk * 8u + cidx;
+            vox = word * 8u + cidx;
             word = nodes[vox];
-            if (word & kLeafBit) break;
-            chunk = word;
         }
         const uint32_t o = grid2_index(ix, iy, iz, L2);
         grid2[o] = word;
