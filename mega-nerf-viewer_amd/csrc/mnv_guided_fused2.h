@@ -5,21 +5,26 @@
 // Same four reference steps (src/renderer/cuda_renderer.cpp:107-139: get_samples_from_voxels rt_core.cuh:418-576, cumsum / masks,
 // query_submodules :165-203, render_nerf_results rt_core.cuh:334-416), same arithmetic, same frames bit for bit -- but the march and
 // the network no longer share one wavefront's registers and time:
-//   * a workgroup is NP PRODUCER wavefronts + one CONSUMER wavefront.  A producer marches an 8x8 tile, one ray per lane, on the packed
-//     accel exactly as guided_fused_kernel does and pushes every complete sample (world position, delta z, owner lane, cluster) into
-//     ITS ring in LDS (128 slots); it never touches the matrix cores.  The composite of a ray's samples happens in the owning lane,
-//     in ray order, as results arrive (a per-entry READY flag; one LDS poll per march iteration);
-//   * the consumer keeps, per lane, the state of two slots of every ring (pending? which sub-module?), picks the sub-module of the
-//     oldest waiting sample of a ring that needs service (or stays with the sub-module whose weights are in LDS while plenty of its
-//     samples wait), gathers up to 64 waiting samples OF THAT SUB-MODULE from all rings -- so a run fills its 64 columns although
-//     rays change sub-module between the front and the back of a surface -- encodes them, runs the network on the matrix cores (the
-//     identical v_mfma_f32_16x16x32_f16 sequence on the identical fragments as mlp_forward_kernel, A operands from LDS), turns every
-//     column into the sample's transmittance factor and colour denominators (SH basis of the owning ray from LDS) and writes those
-//     four floats over the sample's ring entry;
-//   * rings, results and the counters per ring (pushed / service request / evaluated) live in LDS; waves of one workgroup are
-//     co-resident by construction, so the spin-waits (s_sleep) cannot deadlock: a producer waits only after it has asked for service
-//     (its ring cannot take another step's samples, or its tile is finished), and the consumer serves such a ring's oldest sample
-//     first; the consumer never waits for a producer.
+//   * a workgroup is NP PRODUCER wavefronts + NC CONSUMER wavefronts (8 + 8: a whole CU's worth at 128 VGPRs).  A producer marches an
+//     8x8 tile, one ray per lane, on the packed accel exactly as guided_fused_kernel does and pushes every complete sample (world
+//     position, delta z, owner lane, cluster) into ITS ring in LDS (256 slots); it never touches the matrix cores.  The composite of a
+//     ray's samples happens in the owning lane, in ray order, as results arrive (a per-entry READY flag; one LDS poll per march iteration);
+//   * a consumer serves the ring(s) of its producer(s).  It keeps, per lane, the state of RING / 64 slots of every ring (waiting? which
+//     sub-module? -- in LDS between windows), picks a sub-module -- the one it ran last or one whose weights sit in a slot while plenty of
+//     its samples wait, otherwise that of the oldest waiting sample of the ring that asked for service -- gathers up to 64 waiting samples
+//     OF THAT SUB-MODULE by ballot (so a run fills its columns although rays change sub-module between the front and the back of a
+//     surface), takes the weights from a cache of NS slots in LDS shared by the workgroup's consumers (lock word, readers count, least
+//     recently used victim; 16 KB from L2 on a miss), encodes, runs the network on the matrix cores (the identical
+//     v_mfma_f32_16x16x32_f16 sequence on the identical fragments as mlp_forward_kernel), turns every column into the sample's
+//     transmittance factor and colour denominators (SH basis of the owning ray from LDS; two lanes per column) and writes those four
+//     floats over the sample's ring entry;
+//   * rings, results and the counters per ring (pushed / flush request / evaluated / producer has left / stall request) live in LDS;
+//     waves of one workgroup are co-resident by construction, so the spin-waits (s_sleep, under a watchdog) cannot deadlock: a producer
+//     waits only after it has asked for service (its ring cannot take another step's samples, or its tile is finished), and the consumer
+//     serves such a ring's oldest sample first; a consumer waits for another consumer only while that one fills a weight slot.
+// Debug builds: -DMNV_F2_CHECK_RINGS / _WEIGHTS / _TILE (protocol, weight-slot and output-tile self-checks into the diagnostics words 28-30),
+// -DMNV_F2_LOG (per-sample logs, tools/fused_log_diff.py), -DMNV_F2_NO_L0_BARRIER (the build with the rare wrong colour denominator,
+// LAB_NOTEBOOK.md); tools/fused_stress.py is the gate for every change to this file.
 #pragma once
 
 #include <type_traits>
@@ -34,8 +39,8 @@ namespace mnv {
 // NS weight slots in LDS shared by the consumers, rings of MNV_F2_RING slots.  The workgroup is a whole CU's worth of wavefronts at
 // 128 VGPRs.  Measured on cfg2 at 1080p (tools/f2_variants.sh, LAB_NOTEBOOK.md): 8 + 8 with 256-slot rings and three weight slots
 // (158.5 KB of LDS) 1.24 ms, with two 1.31; 10 + 5 (256 slots, 2 weight slots: a third does not fit) 1.38; 12 + 4 (256, 2) 1.57;
-// 8 + 8 with 128-slot rings and four weight slots 1.45; the one-role kernel 1.43.  Deep rings matter more than resident weights: the rays of an 8x8 tile reach a surface together, so
-// a producer emits its samples in bursts that a 128-slot ring cannot absorb.
+// 8 + 8 with 128-slot rings and four weight slots 1.45; the one-role kernel 1.43.  Deep rings matter more than resident weights: the rays
+// of an 8x8 tile reach a surface together, so a producer emits its samples in bursts that a 128-slot ring cannot absorb.
 #ifndef MNV_F2_NP
 #define MNV_F2_NP 8
 #endif
