@@ -23,8 +23,12 @@
 //     waits only after it has asked for service (its ring cannot take another step's samples, or its tile is finished), and the consumer
 //     serves such a ring's oldest sample first; a consumer waits for another consumer only while that one fills a weight slot.
 // Debug builds: -DMNV_F2_CHECK_RINGS / _WEIGHTS / _TILE (protocol, weight-slot and output-tile self-checks into the diagnostics words 28-30),
-// -DMNV_F2_LOG (per-sample logs, tools/fused_log_diff.py), -DMNV_F2_NO_L0_BARRIER (the build with the rare wrong colour denominator,
-// LAB_NOTEBOOK.md); tools/fused_stress.py is the gate for every change to this file.
+// -DMNV_F2_LOG (per-sample logs, tools/fused_log_diff.py); tools/fused_stress.py is the gate for every change to this file.
+// The whole library is built WITHOUT VOP3P packed-FP32 instructions (Makefile: NOPK).  Round 3's "rare wrong colour denominator" of
+// this kernel (one frame in ~100: the channel-1 sum of <= 16 columns of a window lacked its eighth term) was one such instruction in
+// the column evaluation -- v_pk_add_f32 v[42:43], v[46:47], v[42:43] op_sel:[0,1] op_sel_hi:[1,0], formed by the SLP vectoriser from
+// sh_channel's scalar sums -- whose low half read the HIGH dword of its second source as 0.0 in lanes 48-63, sporadically, beside the
+// co-resident consumers' MFMAs (LAB_NOTEBOOK.md, "the rare wrong denominator: cause"; tools/f2lab/).
 #pragma once
 
 #include <type_traits>
@@ -1038,13 +1042,6 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                             for (int j = 0; j < 2; ++j) bf[kk][j] = __builtin_bit_cast(half8, tile_q[kk * (4 * kF2Cols) + ((2 * h + j) * 16 + col) * 4 + g]);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
-                            // One 16-row block at a time: without this compiler barrier the 12 operand loads of all four blocks are hoisted above the
-                            // first MFMA and the two column halves merged; that build produced an occasional wrong colour denominator (one
-                            // frame in ~100 at 1080p, tools/fused_stress.py) whose cause was not found -- LAB_NOTEBOOK.md, "the rare wrong
-                            // denominator".  With the barrier: 0 of 2560 frames, and 0 of 1280 under the slowed-consumer build that showed 22 %.
-#ifndef MNV_F2_NO_L0_BARRIER  // (defined only to reproduce the failing build)
-                            asm volatile("" ::: "memory");
-#endif
                             const f32x4 bv = bias_tile(mt);
 #pragma unroll
                             for (int kk = 0; kk < NKK0; ++kk) {

@@ -6,7 +6,7 @@
 set -e
 LLVM=/opt/rocm/lib/llvm/bin; LAB=/tmp/asmlab; mkdir -p $LAB
 cd "$(dirname "$0")/../mega-nerf-viewer_amd"
-FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt"
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -Xclang -target-feature -Xclang -packed-fp32-ops"
 if [ "$1" = prepare ]; then
   /opt/rocm/bin/hipcc $FLAGS $2 --save-temps=obj -c csrc/mnv_march_accel.hip -o $LAB/accel.o 2> /dev/null
   cp $LAB/mnv_march_accel-hip-amdgcn-amd-amdhsa-gfx950.s $LAB/device.s
