@@ -43,6 +43,7 @@ extern "C" {
 #define MNV_E_IO (-4)          /* file / npz errors */
 #define MNV_E_NO_RCCL (-5)     /* mnv_comm_*: librccl.so.1 cannot be loaded */
 #define MNV_E_RCCL (-6)        /* mnv_comm_*: an RCCL call failed (text in mnv_last_error) */
+#define MNV_E_FAULT (-7)       /* an EARLIER asynchronous frame on this object is known to be wrong (mnv_render_guided_fused*: watchdog) */
 
 #define MNV_FORMAT_RGBA 0 /* reference include/data_format.hpp:8-12 */
 #define MNV_FORMAT_SH 1
@@ -535,8 +536,15 @@ int mnv_render_guided_fused(const mnv_accel *accel, const mnv_camera *cam, const
  * rays' constants and the weights of enough sub-modules fit a workgroup's LDS (the one-role kernel otherwise). */
 void mnv_set_fused_kernel(int version);
 /* Diagnostics of the fused kernels (process-wide): `words32` = NULL (default, none) or a device buffer of 32 64-bit words the
- * kernels add run counts and per-phase times to (tools/guided_bench.py names them).  Costs a few per cent while set. */
+ * kernels add run counts and per-phase times to (tools/guided_bench.py names them).  Costs a few per cent while set.  The library keeps
+ * only the address: the buffer must outlive every launch made while it is set (pass NULL before freeing it). */
 void mnv_set_fused_diag(unsigned long long *words32);
+/* The producer / consumer kernel waits with s_sleep polls under a watchdog (a bug ends in wrong pixels, never in a hung device).  A
+ * wait the watchdog abandons is counted in a device word of the accel -- always, with or without mnv_set_fused_diag.  The frame's own
+ * call has long returned (the entry points are asynchronous), so: the NEXT mnv_render_guided_fused* call on this accel prints one line
+ * on stderr and returns MNV_E_FAULT once per fault, and mnv_accel_fused_faults reads the count since mnv_accel_create (it waits for
+ * the device).  No wait has ever been abandoned in a test or stress run; the count is 0 on a healthy build. */
+int mnv_accel_fused_faults(const mnv_accel *accel, uint32_t *count_out);
 /* The same frame when refinement is on as well (BASELINE.json configs[4] has both switches on: cuda_renderer.cpp:107-156): the fused
  * kernel also writes the refinement trackers (rows pre-filled with -1 by the caller, as cuda_renderer.cpp:97-98) and, with `visited` +
  * `parent`, the visit marks -- what get_samples_from_voxels produces besides the samples (rt_core.cuh:475-507,561-574).  A ray that

@@ -29,6 +29,9 @@ MNV_E_INVALID = -1
 MNV_E_UNSUPPORTED = -2
 MNV_E_NO_DEVICE = -3
 MNV_E_IO = -4
+MNV_E_NO_RCCL = -5
+MNV_E_RCCL = -6
+MNV_E_FAULT = -7
 FORMAT_RGBA = 0
 FORMAT_SH = 1
 BASIS_MAX = 25
@@ -205,6 +208,7 @@ _SIGNATURES = {
     "mnv_set_colour_math": (None, [C.c_int]),
     "mnv_set_fused_kernel": (None, [C.c_int]),
     "mnv_set_fused_diag": (None, [C.c_void_p]),
+    "mnv_accel_fused_faults": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "mnv_set_ref_table_min_rays": (None, [C.c_int64]),
     "mnv_assemble_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, Partition, C.c_int32, C.c_int32, C.c_void_p]),
     "mnv_comm_get_unique_id": (C.c_int, [C.c_void_p]),
@@ -638,11 +642,26 @@ def set_fused_kernel(version: int) -> None:
     lib().mnv_set_fused_kernel(int(version))
 
 
+_fused_diag_keepalive = None
+
+
 def set_fused_diag(words32=None) -> None:
-    """Diagnostics buffer of the fused kernels: a device int64 tensor of at least 32 words, or None (default: no diagnostics)."""
+    """Diagnostics buffer of the fused kernels: a device int64 tensor of at least 32 words, or None (default: no diagnostics).
+    The library keeps only the device address: the tensor is held here until the next call, so that a caller that rebinds or drops
+    its own reference cannot leave the kernels adding into freed memory."""
+    global _fused_diag_keepalive
     if words32 is not None and words32.numel() < 32:
         raise ValueError("the diagnostics buffer holds 32 words")
     lib().mnv_set_fused_diag(_ptr(words32))
+    _fused_diag_keepalive = words32
+
+
+def accel_fused_faults(accel: int) -> int:
+    """Spin-waits of the producer / consumer kernel that its watchdog abandoned since the accel was created (0 on a healthy build);
+    waits for the device."""
+    n = C.c_uint32(0)
+    _check(lib().mnv_accel_fused_faults(C.c_void_p(accel), C.byref(n)))
+    return int(n.value)
 
 
 def set_ref_table_min_rays(min_rays: int) -> None:

@@ -112,6 +112,9 @@ struct mnv_accel {
     int32_t *flags = nullptr;             // [4] device scratch of refresh: changed, deepest depth, grids dirty
     int64_t reserved = 0;                 // chunks the nodes / rows / depth arrays have room for
     unsigned long long *stats = nullptr;  // MNV_STATS=1 diagnostics
+    uint32_t *fault_dev = nullptr;        // [1] guided_fused2_kernel: spin-waits abandoned by the watchdog since creation (always counted, with or without
+    uint32_t *fault_host = nullptr;       // mnv_set_fused_diag); pinned mirror, refreshed behind every fused launch -- mnv_accel_fused_faults
+    uint32_t fault_reported = 0;          // faults already answered with MNV_E_FAULT
     unsigned long long *timeline = nullptr;  // MNV_TIMELINE=<file> diagnostics: tile / wavefront time stamps of the last launch
     size_t timeline_bytes = 0, timeline_tiles = 0, timeline_waves = 0, timeline_tiles_per_frame = 0;
     // per-launch slots: [kNumQueues] ray-queue heads (64 B apart; a queue spans the frames of a batch) + [n_frames] camera blocks,

@@ -42,6 +42,7 @@ struct FusedGuided {
     int32_t batch_min;           // run the network once this many samples wait in a wavefront's pool (1 .. 64)
     unsigned long long *sample_counter;  // += samples evaluated (one atomic per wavefront); ONE word
     unsigned long long *diag;            // diagnostics (mnv_set_fused_diag, 32 words of the caller's): NULL = none
+    uint32_t *fault;                     // the accel's fault word: += 1 per wavefront that abandons a spin-wait (never NULL)
     int32_t switch_min;                  // guided_fused2_kernel: a consumer stays with its last sub-module while this many of its samples wait
     int32_t weight_slots;                // guided_fused2_kernel: sub-modules whose weights a workgroup keeps in LDS (<= kF2NS, what fits)
 };

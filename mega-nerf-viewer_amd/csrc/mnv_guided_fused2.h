@@ -547,7 +547,10 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
             if (F.diag) t_push += wall_clock64() - t_i3;
         }
         st_release(c_exit, 1u);
-        if (spins > kF2SpinLimit && F.diag && lane == 0) atomicAdd(F.diag + F2Diag::kWatchdog, 1ull);
+        if (spins > kF2SpinLimit && lane == 0) {  // the frame is wrong: say so whether or not anybody collects diagnostics
+            atomicAdd(F.fault, 1u);
+            if (F.diag) atomicAdd(F.diag + F2Diag::kWatchdog, 1ull);
+        }
         if (F.sample_counter) {
             int tot = n_eval;
 #pragma unroll
@@ -850,13 +853,23 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                 int slot = held_slot;
                 if (held_slot < 0 || c_star != lds_cluster) {
                     if (held_slot >= 0 && lane == 0) __hip_atomic_fetch_sub(s_wc + 2 + 4 * held_slot + 2, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    uint32_t res = 0u;  // slot | 8: fill it, | 16: somebody else is filling it
+                    uint32_t res = 0u;  // slot | 8: fill it, | 16: somebody else is filling it, | 32: gave up (watchdog)
                     if (lane == 0) {
+                        uint32_t lock_spins = 0u;
                         for (;;) {
+                            bool locked = false;
                             for (;;) {  // the lock: acquire, so that nothing below is read before the lock is held
                                 uint32_t expect = 0u;
-                                if (__hip_atomic_compare_exchange_strong(&s_wc[0], &expect, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                                if (__hip_atomic_compare_exchange_strong(&s_wc[0], &expect, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                                    locked = true;
+                                    break;
+                                }
                                 __builtin_amdgcn_s_sleep(0);
+                                if (++lock_spins > 64u * kF2SpinLimit) break;  // watchdog, as for every other wait of this kernel
+                            }
+                            if (!locked) {
+                                res = 32u;
+                                break;
                             }
                             int hit = -1, victim = -1;
                             uint32_t oldest = 0xffffffffu;
@@ -890,9 +903,18 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                             __hip_atomic_store(&s_wc[0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                             if (hit >= 0 || victim >= 0) break;
                             __builtin_amdgcn_s_sleep(1);  // every slot is being read and none holds this sub-module: a reader will let go
+                            if (++lock_spins > 64u * kF2SpinLimit) {
+                                res = 32u;
+                                break;
+                            }
                         }
                     }
                     res = (uint32_t)__builtin_amdgcn_readfirstlane((int)res);
+                    if (res & 32u) {  // no slot within the watchdog's patience: leave (counted below), the frame is reported as faulty
+                        spins = 64u * kF2SpinLimit + 1u;
+                        held_slot = -1;
+                        break;
+                    }
                     slot = (int)(res & 7u);
                     uint32_t *w4 = s_wc + 2 + 4 * slot;
                     if (res & 8u) {
@@ -919,7 +941,12 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                         ++n_reloads;
                         if (F.diag) t_reload += wall_clock64() - t_e0;
                     } else if (res & 16u) {
-                        while (__builtin_amdgcn_readfirstlane((int)ld_relaxed(w4 + 1)) != 0) __builtin_amdgcn_s_sleep(0);
+                        uint32_t fill_spins = 0u;
+                        while (__builtin_amdgcn_readfirstlane((int)ld_relaxed(w4 + 1)) != 0 && ++fill_spins <= 64u * kF2SpinLimit) __builtin_amdgcn_s_sleep(0);
+                        if (fill_spins > 64u * kF2SpinLimit) {
+                            spins = 64u * kF2SpinLimit + 1u;
+                            break;
+                        }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     lds_cluster = c_star;
@@ -1149,6 +1176,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
             }
             if (F.diag) t_busy += wall_clock64() - t_w0;
         }
+        if (spins > 64u * kF2SpinLimit && lane == 0) atomicAdd(F.fault, 1u);
         if (F.diag && lane == 0) {
             if (spins > 64u * kF2SpinLimit) atomicAdd(F.diag + F2Diag::kWatchdog, 1ull);
             atomicAdd(F.diag + F2Diag::kConsSimd + (__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3), 1ull);

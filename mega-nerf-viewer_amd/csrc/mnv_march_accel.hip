@@ -1294,6 +1294,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
         const bool trk = K.split_track || K.sample_track || K.visited;
         // producer / consumer wavefronts when one sub-module's weights fit a workgroup's LDS beside the rings (at least two workgroups per CU)
         FusedGuided F = *track->fused;
+        F.fault = accel->fault_dev;
         int slots = kF2NS;  // weight slots: as many as fit beside the rings (at least one per two consumers)
         const int f2_per_cu = (4 * kF2WavesPerSimd) / (kF2NP + kF2NC);  // workgroups per CU the kernel is built for
         while (slots > 1 && (size_t)f2_layout(nb, lds_level, F.S, slots).total * 4 > (size_t)160 * 1024 / f2_per_cu) --slots;
@@ -1373,6 +1374,8 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
                            accel->view.capacity);
         rc = (int)hipGetLastError();
     }
+    if (rc == 0 && track && track->fused)  // the fault word's pinned mirror follows the frame on its stream (guided_fused, mnv_accel_fused_faults)
+        rc = (int)hipMemcpyAsync(mut->fault_host, mut->fault_dev, 4, hipMemcpyDeviceToHost, stream);
     if (rc == 0) {
         rc = (int)hipEventRecord(mut->slot_done[slot], stream);
         mut->slot_used[slot] = true;
@@ -1506,6 +1509,10 @@ int mnv_accel_create_reserved(const mnv_tree_view *t, int64_t max_capacity, void
     if ((rc = check_hip(hipMalloc((void **)&a->rows, max_capacity * 8 * row_bytes), "hipMalloc(rows)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&a->depth, max_capacity * 4), "hipMalloc(depth)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&a->flags, 16), "hipMalloc(flag)"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&a->fault_dev, 4), "hipMalloc(fault)"))) return fail(rc);
+    if ((rc = check_hip(hipMemsetAsync(a->fault_dev, 0, 4, stream), "memset fault"))) return fail(rc);
+    if ((rc = check_hip(hipHostMalloc((void **)&a->fault_host, 4, hipHostMallocDefault), "hipHostMalloc(fault)"))) return fail(rc);
+    *a->fault_host = 0u;
     if ((rc = check_hip(hipMalloc((void **)&a->slots_dev, (size_t)kSlots * kSlotBytes), "hipMalloc(slots)"))) return fail(rc);
     for (int i = 0; i < kSlots; ++i)
         if ((rc = check_hip(hipEventCreateWithFlags(&a->slot_done[i], hipEventDisableTiming), "hipEventCreate(slot)"))) return fail(rc);
@@ -1626,6 +1633,8 @@ void mnv_accel_destroy(mnv_accel *a) {
     if (a->stats) (void)hipFree(a->stats);
     if (a->depth) (void)hipFree(a->depth);
     if (a->flags) (void)hipFree(a->flags);
+    if (a->fault_dev) (void)hipFree(a->fault_dev);
+    if (a->fault_host) (void)hipHostFree(a->fault_host);
     if (a->nodes) (void)hipFree(a->nodes);
     if (a->rows) (void)hipFree(a->rows);
     if (a->grid) (void)hipFree(a->grid);
@@ -1654,6 +1663,15 @@ int32_t mnv_partition_local_tiles(mnv_rect tile, mnv_partition part) { return pa
 void mnv_set_colour_math(int fast) { g_fast_colour.store(fast ? 1 : 0, std::memory_order_relaxed); }
 void mnv_set_fused_kernel(int version) { g_fused_kernel.store(version == 1 || version == 2 ? version : 0, std::memory_order_relaxed); }
 void mnv_set_fused_diag(unsigned long long *words32) { g_fused_diag.store(words32, std::memory_order_relaxed); }
+
+int mnv_accel_fused_faults(const mnv_accel *accel, uint32_t *count_out) {
+    if (!accel || !count_out) return set_error(MNV_E_INVALID, "null argument");
+    uint32_t v = 0;
+    const int rc = check_hip(hipMemcpy(&v, accel->fault_dev, 4, hipMemcpyDeviceToHost), "read fault word");  // waits for the device
+    if (rc) return rc;
+    *count_out = v;
+    return MNV_OK;
+}
 
 int mnv_assemble_tiles(const void *gathered, void *frames, int32_t width, int32_t height, mnv_partition part, int32_t n_frames,
                        int32_t bytes_per_pixel, void *hip_stream) {
@@ -1868,6 +1886,19 @@ static int guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv
                         float *sample_track, const int16_t *sample_counts, int32_t *visited, const int32_t *parent,
                         unsigned long long *sample_counter, void *hip_stream) {
     if (!accel || !cam || !opt || !mlp || !grid) return set_error(MNV_E_INVALID, "null argument");
+    {
+        // A spin-wait that the watchdog of guided_fused2_kernel abandoned leaves wrong pixels behind.  The launches are asynchronous, so the
+        // frame itself cannot answer for it: the NEXT call on this accel does, once per fault, and mnv_accel_fused_faults reads the count.
+        mnv_accel *mut = const_cast<mnv_accel *>(accel);
+        std::lock_guard<std::mutex> g(mut->launch_mutex);
+        const uint32_t seen = *static_cast<volatile uint32_t *>(mut->fault_host);
+        if (seen != mut->fault_reported) {
+            const uint32_t n = seen - mut->fault_reported;
+            mut->fault_reported = seen;
+            fprintf(stderr, "libmnv: %u wavefront(s) of an earlier fused guided-sampling frame on this accel abandoned a spin-wait (watchdog): that frame is wrong\n", n);
+            return set_error(MNV_E_FAULT, "an earlier fused guided-sampling frame on this accel ran into the kernel's watchdog and is wrong; mnv_set_fused_kernel(1) selects the kernel without spin-waits");
+        }
+    }
     if (visited && !parent) return set_error(MNV_E_INVALID, "visit marks on the packed layout need the parent array (the ancestors of the marked chunks)");
     if (opt->render_depth) return set_error(MNV_E_UNSUPPORTED, "the fused guided-sampling frame has no depth mode; use the four-step path");
     if (opt->max_guided_samples < 1) return set_error(MNV_E_INVALID, "max_guided_samples must be positive");

@@ -109,6 +109,7 @@ def test_fused_frame_at_cfg2_size(mnv, torch_gpu):
         torch.cuda.synchronize()
         assert int(counter.item()) == total and (w < 1920 or total > 5_000_000)
         assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref))
+    assert mnv.accel_fused_faults(tree.accel) == 0
 
 
 def oracle_frames(mnv, orc, torch, tree, cam, opt, mlp, desc, params, grid, max_g, dim):
@@ -223,6 +224,7 @@ def test_many_frames_in_a_row_stay_bit_identical(mnv, torch_gpu, fused_kernel):
             if n_bad:
                 bad.append((pose, rep, n_bad))
     assert not bad, f"frames that differ from the four-step path (pose, launch, pixels): {bad}"
+    assert mnv.accel_fused_faults(tree.accel) == 0  # the always-on count of abandoned spin-waits (include/mnv.h: mnv_accel_fused_faults)
 
 
 def test_fused_frame_rejects_what_it_does_not_cover(mnv, torch_gpu):

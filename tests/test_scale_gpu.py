@@ -61,6 +61,41 @@ def test_cfg4_merged_octree_4k_full_frame_and_world8_reassembly(mnv, orc, torch_
     assert a.min() >= 0.0 and a.max() <= 1.0 and np.isfinite(refs[0]["rgba"]).all()
 
 
+def test_bench_workload_cfg3_cfg4_full_tree_against_the_oracle(mnv, orc, torch_gpu):
+    """The tree bench.py times for BASELINE.json configs[2] / configs[3] (cases.CFG3_FULL: 7.2 M chunks, depth 11, inside the 5-10 M
+    of the config) -- not the 2.7 M-chunk stand-in of the test above: one pose at 1920x1080 and one at 3840x2160 on the tuned kernel,
+    float and RGBA8, bit for bit against the oracle; the oracle's integer counters of those poses equal the committed ones
+    (tests/golden/cfg3_counters.json: the numerator of the cfg3 / cfg4_n1 rooflines), and the reference-layout kernel agrees at 1080p."""
+    import json
+    import os
+
+    torch = torch_gpu
+    tree = cases.make_tree(mnv, cases.CFG3_FULL)
+    assert 5_000_000 < tree.capacity < 10_000_000
+    ot = orc.tree_from_view(tree.host_view())
+    tree.move_to_device()
+    opt = mnv.RenderOptions.cli_defaults()
+    committed = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg3_counters.json")))
+    assert committed["capacity"] == tree.capacity
+    for section, (w, h), pose in (("cfg3", (1920, 1080), 3), ("cfg4", (3840, 2160), 9)):
+        cam = cases.cfg3_camera(mnv, pose, w, h, fx=1400.0 * w / 1920)
+        ref = orc.render(ot, cam.c, opt, want_rgba8=True)
+        c = ref["counters"].as_dict()
+        assert all(committed[section]["poses"][str(pose)][k] == x for k, x in c.items()), (section, pose)
+        assert c["rays"] == w * h and c["rays_hit"] > 0.4 * w * h
+        out = torch.full((h, w, 4), float("nan"), dtype=torch.float32, device="cuda")
+        out8 = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        mnv.render_voxels_accel(tree.accel, cam, opt, rgba=out, rgba8=out8)
+        torch.cuda.synchronize()
+        assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref["rgba"])), section
+        assert np.array_equal(out8.cpu().numpy(), ref["rgba8"]), section
+        if section == "cfg3":
+            out.fill_(float("nan"))
+            mnv.render_voxels(tree.device_view(), cam, opt, rgba=out)
+            torch.cuda.synchronize()
+            assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref["rgba"]))
+
+
 def _renderer_on_cfg2(mnv, extra_capacity, w=1920, h=1080, **opt_over):
     tree = cases.make_tree(mnv, cases.CFG2_TREE)
     v = tree.host_view()

@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 txt = open(sys.argv[1]).read()
 frames = int(sys.argv[2])
+extra = sys.argv[3] if len(sys.argv) > 3 else ""
 
 
 def avg(name):
@@ -21,7 +22,7 @@ def avg(name):
 fetch, write, miss = avg("FETCH_SIZE"), avg("WRITE_SIZE"), avg("TCC_MISS_sum")
 import bench  # noqa: E402  (kernel_source_sha: the profile is only valid for the kernel sources it was taken with)
 
-out = {"kernel_source_sha": bench.kernel_source_sha(), "source": f"{sys.argv[1]} (rocprofv3 --pmc, separate passes, bench.py --steps 2 --warmup 1)",
+out = {"kernel_source_sha": bench.kernel_source_sha(), "source": f"{sys.argv[1]} (rocprofv3 --pmc, separate passes, bench.py {extra})".replace(" )", ")"),
        "kernel": "march_accel_kernel<9,256,0>", "frames_per_launch": frames, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "TCC_MISS": miss,
        "hbm_bytes_per_launch": int(2 * fetch * 1024 + write * 1024)}
 r128, r64, rall = avg("TCC_EA0_RDREQ_128B_sum"), avg("TCC_EA0_RDREQ_64B_sum"), avg("TCC_EA0_RDREQ_sum")

@@ -45,22 +45,32 @@ __global__ __launch_bounds__(1024) void probe(unsigned long long *bad, float *si
         A[1] = 2.0f + 0.003f * (float)((it * 7 + lane) & 1023);
         B[0] = 0.5f + 0.002f * (float)((it * 3 + lane) & 1023);
         B[1] = -1.25f - 0.004f * (float)((it * 5 + lane) & 1023);
-        float l0 = 0.f, l1 = 0.f;
-        if (LDS) {  // two LDS loads issued right before the packed add and still in flight when it reads its operands
-            const float *p = pad + ((it * 64 + lane) & 4095);
-            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %2 offset:256\n\t" : "=v"(l0), "=v"(l1) : "v"((uint32_t)(uintptr_t)p) : "memory");
+        if (LDS) {  // two LDS loads issued right before the packed add and still in flight when it reads its operands.  Their destinations
+                    // are registers the compiler does not know about (it cannot see that the data arrive later): v126 / v127, clobbered here
+                    // and at the wait below, far above what this kernel allocates
+            const float *p = pad + ((it * 64 + lane) & 2047);
+            asm volatile("ds_read_b32 v126, %0\n\tds_read_b32 v127, %0 offset:256\n\t" : : "v"((uint32_t)(uintptr_t)p) : "memory", "v126", "v127");
         }
         if (FORM == 0)      asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(D) : "v"(A), "v"(B));
         else if (FORM == 1) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(D) : "v"(A), "v"(B));
         else                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(D) : "v"(A), "v"(B));
         if (LDS) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            guard += l0 + l1;
+            float l0;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\tv_add_f32 %0, v126, v127" : "=v"(l0) : : "memory", "v126", "v127");
+            guard += l0;
         }
+        // the expected values by plain VOP2 instructions (written out: the compiler would vectorise `A[0] + B[1]` into the very instruction under test)
         float want0, want1;
-        if (FORM == 0) { want0 = A[0] + B[1]; want1 = A[1] + B[0]; }
-        else if (FORM == 1) { want0 = A[0] + B[0]; want1 = A[1] + B[1]; }
-        else { want0 = A[0] * B[1]; want1 = A[1] * B[0]; }
+        if (FORM == 0) {
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(want0) : "v"(A[0]), "v"(B[1]));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(want1) : "v"(A[1]), "v"(B[0]));
+        } else if (FORM == 1) {
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(want0) : "v"(A[0]), "v"(B[0]));
+            asm volatile("v_add_f32 %0, %1, %2" : "=v"(want1) : "v"(A[1]), "v"(B[1]));
+        } else {
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(want0) : "v"(A[0]), "v"(B[1]));
+            asm volatile("v_mul_f32 %0, %1, %2" : "=v"(want1) : "v"(A[1]), "v"(B[0]));
+        }
         if (D[0] != want0) wrong += 1ull;
         if (D[1] != want1) wrong += 1ull << 32;
     }

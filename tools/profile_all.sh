@@ -1,15 +1,19 @@
 #!/bin/bash
 # The committed profiles of a round: run on the GPU box (gpurun -- 'bash tools/profile_all.sh'), then tools/collect_profiles.py here.
 # ROUND=r03 (default) names the outputs.
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 bash tools/prof.sh ${R}_batch > /dev/null 2>&1
 python3 tools/make_traffic_json.py gpurun_out/${R}_batch/summary.txt 64 > gpurun_out/${R}_batch/traffic.json
 bash tools/prof_mem.sh ${R}_mem > gpurun_out/${R}_mem.txt 2>&1
 bash tools/prof_trace.sh ${R}_per_frame --per-frame --frame-streams 3 --steps 3 --warmup 1 > /dev/null 2>&1
 bash tools/prof_trace.sh ${R}_per_frame_1stream --per-frame --frame-streams 1 --steps 3 --warmup 1 > /dev/null 2>&1
 bash tools/prof_trace.sh ${R}_ref_layout --kernel ref_layout --per-frame --frame-streams 2 --laps 1 --steps 3 --warmup 1 > /dev/null 2>&1
-bash tools/prof_trace.sh ${R}_cfg3 --workload cfg3 --frame-streams 0 --steps 4 --warmup 1 > /dev/null 2>&1
-bash tools/prof_trace.sh ${R}_cfg4 --workload cfg4 --frame-streams 0 --steps 3 --warmup 1 > /dev/null 2>&1
+# cfg3 / cfg4 (the 7.2 M-chunk tree): kernel stats AND the HBM-traffic passes; profiles/${R}_traffic_cfg3.json / _cfg4.json feed bench.py's cfg3 / cfg4_n1 rooflines
+for wl in cfg3 cfg4; do
+  bash tools/prof_traffic.sh ${R}_${wl} --workload $wl > /dev/null 2>&1
+  python3 tools/make_traffic_json.py gpurun_out/${R}_${wl}/summary.txt 16 "--workload $wl" > gpurun_out/${R}_${wl}/traffic.json
+  cp gpurun_out/${R}_${wl}/traffic.json profiles/${R}_traffic_${wl}.json
+done
 export TMPDIR=/tmp
 mkdir -p gpurun_out/${R}_guided
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_guided/trace -- python3 tools/guided_bench.py 32 4 > gpurun_out/${R}_guided/trace.log 2>&1
