@@ -658,12 +658,13 @@ def main():
         exact = frames[(counter[0] - 1) % RING]
         rl_out = pf_out
         rl = {}
-        for k_rl in (1, 2):
-            sts_rl = [torch.cuda.Stream(device=dev) for _ in range(k_rl)]
+        for k_rl in (1, 2, -1, -3):   # negative: the same calls with mnv_set_tree_cache(1) on |k| streams
+            mnv.set_tree_cache(k_rl < 0)
+            sts_rl = [torch.cuda.Stream(device=dev) for _ in range(abs(k_rl))]
 
             def rl_step():
                 for i in range(N_POSES):
-                    mnv.render_voxels(dv_ref, cams[i], opt, rgba=rl_out[i], stream=sts_rl[i % k_rl].cuda_stream)
+                    mnv.render_voxels(dv_ref, cams[i], opt, rgba=rl_out[i], stream=sts_rl[i % abs(k_rl)].cuda_stream)
 
             rl_step()
             torch.cuda.synchronize(dev)
@@ -672,10 +673,19 @@ def main():
                 rl_step()
             torch.cuda.synchronize(dev)
             rl[k_rl] = (time.perf_counter() - t1) / 3 / N_POSES
+            if k_rl == 2:
+                rl_bad = int((rl_out[:N_POSES].view(torch.int32) != exact[:N_POSES].view(torch.int32)).any(dim=-1).sum().item())
+        rl_bad_cached = int((rl_out[:N_POSES].view(torch.int32) != exact[:N_POSES].view(torch.int32)).any(dim=-1).sum().item())
+        mnv.set_tree_cache(False)
         ref_layout = {"value": round(W * H / rl[2] / 1e6, 2), "unit": "Mrays/s", "frames_in_flight": 2, "ms_per_frame": round(rl[2] * 1e3, 5),
                       "one_stream": {"value": round(W * H / rl[1] / 1e6, 2), "ms_per_frame": round(rl[1] * 1e3, 5)},
-                      "pixels_not_bit_identical": int((rl_out[:N_POSES].view(torch.int32) != exact[:N_POSES].view(torch.int32)).any(dim=-1).sum().item()),
-                      "what": "one mnv_render_voxels call per 1920x1080 frame on the reference's own arrays (renderer_kernel.hpp:23-34): per-launch level-7 lookup table + walking kernel"}
+                      "pixels_not_bit_identical": rl_bad,
+                      "what": "one mnv_render_voxels call per 1920x1080 frame on the reference's own arrays (renderer_kernel.hpp:23-34): per-launch level-7 lookup table + walking kernel",
+                      "with_tree_cache": {"one_stream": {"value": round(W * H / rl[-1] / 1e6, 2), "ms_per_frame": round(rl[-1] * 1e3, 5)},
+                                          "three_in_flight": {"value": round(W * H / rl[-3] / 1e6, 2), "ms_per_frame": round(rl[-3] * 1e3, 5)},
+                                          "pixels_not_bit_identical": rl_bad_cached,
+                                          "what": "the same calls after mnv_set_tree_cache(1): the stateless entry point keeps the packed re-layout of the tree it saw (include/mnv.h; the caller "
+                                                  "invalidates after editing the arrays)"}}
 
     # ---- roofline of the dominant kernel (the march): algorithmic bytes per launch / launch time
     counters = load_counters(args.workload)

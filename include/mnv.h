@@ -221,6 +221,20 @@ void mnv_set_colour_math(int fast);
  * Process-wide; default 65536; 0 = always, a negative value = never.  Frames are bit-identical either way.
  */
 void mnv_set_ref_table_min_rays(int64_t min_rays);
+/*
+ * A memory for the stateless entry point.  viewer::render_voxels (renderer_kernel.hpp:23-34) takes the tree's arrays with every call
+ * and keeps nothing, because its caller may edit them in between (the refinement of cuda_renderer.cpp:205-381 does); mnv_render_voxels
+ * honours that by default and pays for it: it walks the reference's arrays (one stream: 0.62 ms per 1080p frame of cfg2 against 0.46 ms on
+ * the packed re-layout).  mnv_set_tree_cache(1) (process-wide, default 0) lets it keep, per tree -- identified by the addresses of
+ * `child` and `data`, `capacity` and the row format; up to four trees, least recently used out -- the packed re-layout of
+ * mnv_accel_create, built on the caller's stream at the first call (tens of milliseconds, once) and used for every later plain frame
+ * (no trackers, no visit marks: those always walk the arrays).  Frames are bit-identical either way.
+ *   THE RULE: after changing the contents of a cached tree's arrays in place, call mnv_tree_invalidate(child) (NULL: every tree) before the
+ *   next frame; a tree that moved or grew (other addresses, other capacity) is a new tree by itself.  Both calls wait for the device.
+ * Memory: the re-layout is about 3.6 x the tree (cfg2: 2.6 GB beside 0.72 GB).
+ */
+void mnv_set_tree_cache(int enable);
+void mnv_tree_invalidate(const void *child);
 
 /*
  * The un-permute step on the gathering rank: `gathered` is what the RCCL gather of the ranks'

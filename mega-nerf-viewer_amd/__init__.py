@@ -210,6 +210,8 @@ _SIGNATURES = {
     "mnv_set_fused_diag": (None, [C.c_void_p]),
     "mnv_accel_fused_faults": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "mnv_set_ref_table_min_rays": (None, [C.c_int64]),
+    "mnv_set_tree_cache": (None, [C.c_int]),
+    "mnv_tree_invalidate": (None, [C.c_void_p]),
     "mnv_assemble_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, Partition, C.c_int32, C.c_int32, C.c_void_p]),
     "mnv_comm_get_unique_id": (C.c_int, [C.c_void_p]),
     "mnv_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
@@ -662,6 +664,20 @@ def accel_fused_faults(accel: int) -> int:
     n = C.c_uint32(0)
     _check(lib().mnv_accel_fused_faults(C.c_void_p(accel), C.byref(n)))
     return int(n.value)
+
+
+def set_tree_cache(enable: bool) -> None:
+    """render_voxels (reference layout) keeps the packed re-layout of every tree it has seen (include/mnv.h: mnv_set_tree_cache);
+    after editing a tree's arrays in place call tree_invalidate()."""
+    lib().mnv_set_tree_cache(1 if enable else 0)
+
+
+def tree_invalidate(child=None) -> None:
+    """Forget the cached re-layout of the tree whose `child` array is this device tensor / address (None: all of them)."""
+    if child is None:
+        lib().mnv_tree_invalidate(None)
+    else:
+        lib().mnv_tree_invalidate(C.c_void_p(child if isinstance(child, int) else child.data_ptr()))
 
 
 def set_ref_table_min_rays(min_rays: int) -> None:

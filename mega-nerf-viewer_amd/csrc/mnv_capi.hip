@@ -1,6 +1,7 @@
 // mnv_capi.hip -- the extern "C" entry points of include/mnv.h that touch the device.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <mutex>
@@ -216,6 +217,77 @@ int mnv_take_timing(double *total_ms, int32_t *launches) {
     return MNV_OK;
 }
 
+// ---- mnv_set_tree_cache: the stateless entry point with a memory (see include/mnv.h) ------------------------------------------------
+namespace {
+struct CachedTree {
+    const void *child = nullptr, *data = nullptr;
+    int32_t capacity = 0, data_dim = 0, basis_dim = 0, format = 0;
+    int device = 0;
+    mnv_accel *accel = nullptr;
+    hipEvent_t built = nullptr;   // recorded on the stream that built the re-layout; launches on other streams wait for it
+    hipStream_t build_stream = nullptr;
+    uint64_t stamp = 0;
+};
+constexpr int kCachedTrees = 4;
+std::mutex g_cache_mu;
+CachedTree g_cache[kCachedTrees];
+std::atomic<int> g_cache_on{0};
+uint64_t g_cache_clock = 0;
+
+void drop(CachedTree &e) {
+    if (e.accel) {
+        (void)hipDeviceSynchronize();  // frames that still read the re-layout
+        mnv_accel_destroy(e.accel);
+    }
+    if (e.built) (void)hipEventDestroy(e.built);
+    e = CachedTree();
+}
+}  // namespace
+
+void mnv_set_tree_cache(int enable) {
+    g_cache_on.store(enable ? 1 : 0, std::memory_order_relaxed);
+    if (!enable) mnv_tree_invalidate(nullptr);
+}
+
+void mnv_tree_invalidate(const void *child) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (auto &e : g_cache)
+        if (e.accel && (!child || e.child == child)) drop(e);
+}
+
+// the cached re-layout of `tree` (built on `stream` at the first call), or NULL when this frame must take the stateless path
+static const mnv_accel *cached_accel(const mnv_tree_view *tree, hipStream_t stream) {
+    const int b = (tree->format == MNV_FORMAT_SH && tree->basis_dim >= 0) ? tree->basis_dim : -1;
+    if (!(b == -1 || b == 1 || b == 4 || b == 9 || b == 16 || b == 25)) return nullptr;  // what the packed layout has rows for
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    CachedTree *hit = nullptr, *victim = nullptr;
+    for (auto &e : g_cache)
+        if (e.accel && e.child == tree->child && e.data == tree->data && e.capacity == tree->capacity && e.data_dim == tree->data_dim &&
+            e.basis_dim == tree->basis_dim && e.format == tree->format && e.device == dev)
+            hit = &e;
+    if (!hit) {
+        for (auto &e : g_cache)  // a free entry, else the least recently used one
+            if (!victim || (victim->accel && (!e.accel || e.stamp < victim->stamp))) victim = &e;
+        if (victim->accel) drop(*victim);
+        mnv_accel *a = nullptr;
+        if (mnv_accel_create(tree, (void *)stream, &a) != MNV_OK) return nullptr;  // e.g. deeper than the packed layout goes: stateless path
+        hipEvent_t ev = nullptr;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, stream) != hipSuccess) {
+            mnv_accel_destroy(a);
+            return nullptr;
+        }
+        victim->child = tree->child; victim->data = tree->data; victim->capacity = tree->capacity; victim->data_dim = tree->data_dim;
+        victim->basis_dim = tree->basis_dim; victim->format = tree->format; victim->device = dev;
+        victim->accel = a; victim->built = ev; victim->build_stream = stream;
+        hit = victim;
+    }
+    hit->stamp = ++g_cache_clock;
+    if (hit->build_stream != stream && hipStreamWaitEvent(stream, hit->built, 0) != hipSuccess) return nullptr;
+    return hit->accel;
+}
+
 int mnv_render_voxels(const mnv_tree_view *tree, const mnv_camera *cam, const mnv_render_options *opt,
                       mnv_rect tile, float *rgba_out, uint8_t *rgba8_out, float *split_track,
                       float *sample_track, int32_t *visited, int track_visit, void *hip_stream) {
@@ -226,6 +298,11 @@ int mnv_render_voxels(const mnv_tree_view *tree, const mnv_camera *cam, const mn
     rc = fill_tree_params(P, tree);
     if (rc) return rc;
     if (track_visit && !visited) return set_error(MNV_E_INVALID, "track_visit set but visited is null");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (g_cache_on.load(std::memory_order_relaxed) && tree->N == 2 && !split_track && !sample_track && !track_visit) {
+        // plain frames of a tree this process has seen before run on the packed re-layout kept from that call (mnv_set_tree_cache)
+        if (const mnv_accel *a = cached_accel(tree, stream)) return mnv_render_voxels_accel(a, cam, opt, tile, rgba_out, rgba8_out, hip_stream);
+    }
     P.max_depth = opt->max_depth;
     P.max_sample_count = opt->max_sample_count;
     P.rgba = rgba_out;
@@ -234,7 +311,6 @@ int mnv_render_voxels(const mnv_tree_view *tree, const mnv_camera *cam, const mn
     P.sample_track = sample_track;
     P.visited = visited;
     P.track_visit = track_visit ? 1 : 0;
-    hipStream_t stream = (hipStream_t)hip_stream;
     LaunchTimer timer(stream);
     if (tree->N <= 0) return check_hip((hipError_t)launch_background(P, stream), "fill_background_kernel");
     return check_hip((hipError_t)launch_ref_layout(P, stream), "march_ref_layout_kernel");

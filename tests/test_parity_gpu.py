@@ -705,3 +705,58 @@ def test_binding_rejects_output_tensors_that_are_too_small_or_of_the_wrong_kind(
     ok = torch.empty((2, j_max, 24, 64, 4), dtype=torch.float32, device="cuda")
     mnv.render_voxels_accel_batch(tree.accel, [cam, cam], opt, part=(1, 3, 64, 24), rgba=ok)
     torch.cuda.synchronize()
+
+
+def test_tree_cache_of_the_stateless_entry_point(mnv, orc, torch_gpu):
+    """mnv_set_tree_cache(1): mnv_render_voxels -- the literal replacement of viewer::render_voxels (renderer_kernel.hpp:23-34), arrays
+    handed over with every call -- keeps the packed re-layout of the trees it has seen.  Frames are bit-identical to the stateless
+    path and to the oracle; an in-place edit of the arrays shows up after mnv_tree_invalidate (and, by the rule in include/mnv.h, not
+    before); frames with trackers still walk the arrays; five trees through four cache entries."""
+    torch = torch_gpu
+    names = ["sh9_d7_aniso", "rgba_d5", "sh4_d6", "shell_d7_sh9", "cfg1_sh1_d4"]
+    trees, views, cams, opts, refs = [], [], [], [], []
+    for n in names:
+        spec = cases.CASES[n]
+        t = cases.make_tree(mnv, spec["tree"])
+        refs.append(orc.render(orc.tree_from_view(t.host_view()), cases.make_camera(mnv, spec["camera"]).c, cases.make_options(mnv, spec["options"]))["rgba"])
+        t.move_to_device()
+        trees.append(t); views.append(t.device_view()); cams.append(cases.make_camera(mnv, spec["camera"])); opts.append(cases.make_options(mnv, spec["options"]))
+    try:
+        mnv.set_tree_cache(True)
+        side = torch.cuda.Stream()
+        for rnd in range(3):  # second and third round: cache hits (and re-builds of the evicted fifth tree), also from another stream
+            for i in range(len(names)):
+                out = torch.full((cams[i].height, cams[i].width, 4), float("nan"), dtype=torch.float32, device="cuda")
+                mnv.render_voxels(views[i], cams[i], opts[i], rgba=out, stream=side.cuda_stream if rnd == 2 else 0)
+                torch.cuda.synchronize()
+                assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(refs[i])), (names[i], rnd)
+        out = torch.empty((cams[0].height, cams[0].width, 4), dtype=torch.float32, device="cuda")
+        # frames with trackers take the walking kernel whatever the switch says
+        split = torch.full((cams[0].height, cams[0].width, 3), -1.0, dtype=torch.float32, device="cuda")
+        mnv.render_voxels(views[0], cams[0], opts[0], rgba=out, split_track=split)
+        torch.cuda.synchronize()
+        assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(refs[0])) and bool((split[..., 1] >= 0).any())
+        # an in-place edit of the arrays (the caller's own device copies here): every sigma set to zero -> an empty picture, but only
+        # once the cache has been told (include/mnv.h: THE RULE)
+        h_data, h_child, _ = trees[0].host_arrays()
+        d_data, d_child = torch.from_numpy(h_data.copy()).cuda(), torch.from_numpy(h_child.copy()).cuda()
+        mine = type(views[0]).from_buffer_copy(views[0])
+        mine.data, mine.child, mine.parent, mine.sample_counts = d_data.data_ptr(), d_child.data_ptr(), None, None
+        mnv.render_voxels(mine, cams[0], opts[0], rgba=out)
+        torch.cuda.synchronize()
+        assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(refs[0]))
+        d_data[..., -1] = 0
+        mnv.render_voxels(mine, cams[0], opts[0], rgba=out)       # stale by the rule: still the old picture
+        torch.cuda.synchronize()
+        assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(refs[0]))
+        mnv.tree_invalidate(d_child)
+        mnv.render_voxels(mine, cams[0], opts[0], rgba=out)
+        torch.cuda.synchronize()
+        empty = out.cpu().numpy()
+        assert np.all(empty[..., 3] == 0.0) and np.all(empty[..., :3] == opts[0].background_brightness)
+        mnv.set_tree_cache(False)                                   # and the stateless path sees the same arrays
+        mnv.render_voxels(mine, cams[0], opts[0], rgba=out)
+        torch.cuda.synchronize()
+        assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(empty))
+    finally:
+        mnv.set_tree_cache(False)

@@ -15,7 +15,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int FORM, int PRIO, int LDS>
+template <int FORM, int PRIO, int LDS, int LATE>
 __global__ __launch_bounds__(1024) void probe(unsigned long long *bad, float *sink, int iters, int n_mfma) {
     __shared__ float pad[4096];
     for (int i = threadIdx.x; i < 4096; i += 1024) pad[i] = (float)i * 0.25f;
@@ -71,25 +71,34 @@ __global__ __launch_bounds__(1024) void probe(unsigned long long *bad, float *si
             asm volatile("v_mul_f32 %0, %1, %2" : "=v"(want0) : "v"(A[0]), "v"(B[1]));
             asm volatile("v_mul_f32 %0, %1, %2" : "=v"(want1) : "v"(A[1]), "v"(B[0]));
         }
-        if (D[0] != want0) wrong += 1ull;
-        if (D[1] != want1) wrong += 1ull << 32;
+        if (LATE) {  // which of the two is wrong?  A third evaluation, eight idle cycles later, judges the packed result and the early VOP2 result
+            float late0;
+            asm volatile("s_nop 7\n\tv_add_f32 %0, %1, %2" : "=v"(late0) : "v"(A[0]), "v"(B[1]));
+            if (FORM == 2) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(late0) : "v"(A[0]), "v"(B[1]));
+            if (D[0] != late0) wrong += 1ull;           // low word: the packed instruction's low result differs from the late evaluation
+            if (want0 != late0) wrong += 1ull << 32;    // high word: the VOP2 instruction right behind the packed one differs from it
+        } else {
+            if (D[0] != want0) wrong += 1ull;
+            if (D[1] != want1) wrong += 1ull << 32;
+        }
     }
     if (guard == 123.456f) sink[1] = guard;
     if (wrong) atomicAdd(bad + (lane >> 4), wrong);
 }
 
-template <int FORM, int PRIO, int LDS>
+template <int FORM, int PRIO, int LDS, int LATE = 0>
 void run(int n_mfma) {
     unsigned long long *bad;
     float *sink;
     hipMalloc(&bad, 32);
     hipMalloc(&sink, 8);
     hipMemset(bad, 0, 32);
-    hipLaunchKernelGGL((probe<FORM, PRIO, LDS>), dim3(256), dim3(1024), 0, 0, bad, sink, 20000, n_mfma);
+    hipLaunchKernelGGL((probe<FORM, PRIO, LDS, LATE>), dim3(256), dim3(1024), 0, 0, bad, sink, 20000, n_mfma);
     unsigned long long h[4] = {0, 0, 0, 0};
     hipMemcpy(h, bad, 32, hipMemcpyDeviceToHost);
     const char *form = FORM == 0 ? "pk_add op_sel:[0,1]/[1,0]" : FORM == 1 ? "pk_add (no op_sel)      " : "pk_mul op_sel:[0,1]/[1,0]";
-    printf("%s  prio %d  lds-in-flight %d  mfma wavefronts %2d of 16 : wrong low results per lane quarter %llu %llu %llu %llu, wrong high results %llu %llu %llu %llu\n", form, PRIO ? 2 : 0, LDS,
+    printf(LATE ? "%s  prio %d  lds-in-flight %d  mfma wavefronts %2d of 16 : against a LATE evaluation, per lane quarter: packed low result wrong %llu %llu %llu %llu, the VOP2 add right behind it wrong %llu %llu %llu %llu\n"
+                : "%s  prio %d  lds-in-flight %d  mfma wavefronts %2d of 16 : wrong low results per lane quarter %llu %llu %llu %llu, wrong high results %llu %llu %llu %llu\n", form, PRIO ? 2 : 0, LDS,
            n_mfma, h[0] & 0xffffffffull, h[1] & 0xffffffffull, h[2] & 0xffffffffull, h[3] & 0xffffffffull, h[0] >> 32, h[1] >> 32, h[2] >> 32, h[3] >> 32);
     hipFree(bad);
     hipFree(sink);
@@ -109,5 +118,9 @@ int main() {
     sweep<0>();
     sweep<1>();
     sweep<2>();
+    for (int n : {0, 4, 8, 12}) {
+        run<0, 0, 0, 1>(n);
+        run<2, 0, 0, 1>(n);
+    }
     return 0;
 }
