@@ -361,10 +361,13 @@ def extras_cfg5(mnv, cases, torch, dev, tree, frames_each=6):
 
 
 def predicted_step(world, root_period, n_frames, workload):
-    """ms per step that the one-GPU emulation of one rank of `world` measured for this partition (profiles/r02_root_emulation.jsonl: rank 0's
+    """ms per step that the one-GPU emulation of one rank of `world` measured for this partition (the latest profiles/rNN_root_emulation.jsonl, tools/root_emulation.py: rank 0's
     march beside a device copy of the incoming tiles and the un-permute; 64 frames of cfg2 per step), so that the line of a real N-GPU run
     carries the model it is to be held against.  None when no such row exists."""
-    path = os.path.join(ROOT, "profiles", "r02_root_emulation.jsonl")
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_root_emulation.jsonl")))
+    path = found[-1] if found else ""
     if workload != "cfg2" or n_frames != 64 or not os.path.exists(path):
         return None
     rows = [json.loads(ln) for ln in open(path) if ln.strip()]
@@ -373,7 +376,7 @@ def predicted_step(world, root_period, n_frames, workload):
         return None
     best = min(rows, key=lambda r: abs(r.get("root_period", 0) - root_period))
     return {"ms_per_step": best["step_ms"], "rank0_march_only_ms": best["rank0_march_only_ms"], "other_ranks_march_ms": best["rank1_march_only_ms"],
-            "root_period_of_the_emulation": best["root_period"], "source": "profiles/r02_root_emulation.jsonl",
+            "root_period_of_the_emulation": best["root_period"], "source": os.path.relpath(path, ROOT), "kernel_source_sha_of_the_emulation": best.get("kernel_source_sha"),
             "assumes": ["RCCL's receive costs rank 0 no more than a device copy of the same bytes", "a CU-masked stream keeps the reserved units free under N processes",
                         "the peers' sends arrive while rank 0 marches (xGMI point-to-point links are not the bound)"]}
 
@@ -577,6 +580,8 @@ def main():
     if multi:
         tg.finish_all()
     sync_all()
+    if multi:
+        tg.take_timings()   # discard the channel-creating gather and the warm-up steps: per_rank reports the timed steps only
     mnv.set_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):

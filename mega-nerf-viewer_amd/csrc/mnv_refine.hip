@@ -66,63 +66,81 @@ struct Carver {
 
 // Tracker rows are (priority, chunk, child) as floats holding integers (rt_core.cuh:239-251,310-320);
 // lexicographic order of the rows == order of this packed key.  Rows with chunk < 0 are "no candidate".
-constexpr uint64_t kNoCandidate = 1ull << 51;
-constexpr int kKeyBits = 52;
+// Two key layouts.  WIDE (52 bits: 16 of priority, 32 of chunk, 3 of child) holds whatever the contract of include/mnv.h admits and
+// costs seven 8-bit radix passes.  COMPACT is what the march actually writes -- a voxel index below 2^27 (trees up to 16.7 M chunks)
+// and a priority in [-1, 2^PB - 2] (a depth for the split tracker: PB = 5; a sample count for the sample tracker: PB = 9) -- in
+// 27 + PB bits: four or five passes.  The pack kernel raises a flag for any row that does not fit and the caller repeats the call
+// with the wide layout (never seen in practice; the flag costs nothing, it travels with the counts the host reads anyway).
+constexpr int kVoxBits = 27;
+constexpr uint64_t kNoCandidateWide = 1ull << 51;
+constexpr int kKeyBitsWide = 52;
 
-__global__ void pack_tracker_keys(const float *__restrict__ track, int64_t n_rows, uint64_t *__restrict__ keys) {
+template <bool WIDE>
+__global__ void pack_tracker_keys(const float *__restrict__ track, int64_t n_rows, uint64_t *__restrict__ keys, int prio_bits, uint32_t *__restrict__ overflow) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
     const float prio = track[i * 3 + 0], chunk = track[i * 3 + 1], child = track[i * 3 + 2];
-    uint64_t key = kNoCandidate;
+    const uint64_t none = WIDE ? kNoCandidateWide : 1ull << (kVoxBits + prio_bits);
+    uint64_t key = none;
     if (chunk >= 0.f) {
-        const uint64_t p = (uint64_t)((int32_t)prio + 32768) & 0xffffu;
-        key = (p << 35) | ((uint64_t)(uint32_t)(int32_t)chunk << 3) | ((uint64_t)(int32_t)child & 7u);
+        if (WIDE) {
+            const uint64_t p = (uint64_t)((int32_t)prio + 32768) & 0xffffu;
+            key = (p << 35) | ((uint64_t)(uint32_t)(int32_t)chunk << 3) | ((uint64_t)(int32_t)child & 7u);
+        } else {
+            const int64_t vox = (int64_t)(int32_t)chunk * 8 + ((int32_t)child & 7), p = (int64_t)(int32_t)prio + 1;
+            if (vox >= ((int64_t)1 << kVoxBits) || p < 0 || p >= ((int64_t)1 << prio_bits)) *overflow = 1u;  // (benign race: every writer stores 1)
+            key = ((uint64_t)p << kVoxBits) | (uint64_t)vox;
+        }
     }
     keys[i] = key;
 }
 
-// info[0] = runs that are real candidates, info[1] = those with count >= 2
+// info[0] = runs that are real candidates, info[1] = those with count >= 2, info[3] = the largest count among the candidates
 __global__ void count_candidates(const uint64_t *__restrict__ unique_keys, const uint32_t *__restrict__ counts,
-                                 const uint32_t *__restrict__ n_runs, uint32_t *__restrict__ info) {
+                                 const uint32_t *__restrict__ n_runs, uint32_t *__restrict__ info, uint64_t none) {
     const uint32_t n = *n_runs;
-    uint32_t valid = 0, voted = 0;
+    uint32_t valid = 0, voted = 0, most = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if (unique_keys[i] != kNoCandidate) {
+        if (unique_keys[i] != none) {
             ++valid;
             voted += counts[i] >= 2u;
+            most = counts[i] > most ? counts[i] : most;
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
         valid += __shfl_down(valid, off);
         voted += __shfl_down(voted, off);
+        const uint32_t other = __shfl_down(most, off);
+        most = other > most ? other : most;
     }
     if ((threadIdx.x & 63) == 0) {
         if (valid) atomicAdd(&info[0], valid);
         if (voted) atomicAdd(&info[1], voted);
+        if (most) atomicMax(&info[3], most);
     }
 }
 
+template <bool WIDE>
 __global__ void unpack_nodes(const uint64_t *__restrict__ keys, int32_t n, int32_t *__restrict__ nodes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = keys[i];
-    nodes[2 * i + 0] = (int32_t)((k >> 3) & 0xffffffffu);
-    nodes[2 * i + 1] = (int32_t)(k & 7u);
+    const uint64_t vox = WIDE ? (k & 0x7ffffffffull) : (k & ((1ull << kVoxBits) - 1));
+    nodes[2 * i + 0] = (int32_t)(vox >> 3);
+    nodes[2 * i + 1] = (int32_t)(vox & 7u);
 }
 
-int select_candidates(const float *track, int64_t n_rows, int32_t max_out, bool need_votes, int32_t *nodes_out,
-                      int32_t *n_out, int32_t *n_candidates, hipStream_t stream) {
-    if (n_out) *n_out = 0;
-    if (n_candidates) *n_candidates = 0;
-    if (!track || n_rows < 0 || max_out < 0 || (max_out > 0 && !nodes_out)) return set_error(MNV_E_INVALID, "invalid tracker arguments");
-    if (n_rows == 0) return MNV_OK;
-    if (n_rows > 0x7fffffff) return set_error(MNV_E_UNSUPPORTED, "more than 2^31 - 1 tracker rows");
+template <bool WIDE>
+int select_candidates_as(const float *track, int64_t n_rows, int32_t max_out, bool need_votes, int32_t *nodes_out, int32_t *n_out, int32_t *n_candidates,
+                         bool *overflow, hipStream_t stream) {
     const size_t n = (size_t)n_rows;
+    const int prio_bits = need_votes ? 5 : 9, key_bits = WIDE ? kKeyBitsWide : kVoxBits + prio_bits + 1;  // + 1: the "no candidate" key
+    const uint64_t none = WIDE ? kNoCandidateWide : 1ull << (kVoxBits + prio_bits);
 
     size_t tmp_sort = 0, tmp_rle = 0, tmp_sort2 = 0;
     uint64_t *nk = nullptr;
     uint32_t *nc = nullptr;
-    (void)rocprim::radix_sort_keys(nullptr, tmp_sort, nk, nk, n, 0, kKeyBits, stream);
+    (void)rocprim::radix_sort_keys(nullptr, tmp_sort, nk, nk, n, 0, key_bits, stream);
     (void)rocprim::run_length_encode(nullptr, tmp_rle, nk, (unsigned int)n, nk, nc, nc, stream);
     (void)rocprim::radix_sort_pairs_desc(nullptr, tmp_sort2, nc, nc, nk, nk, n, 0, 32, stream);
     const size_t tmp_bytes = std::max(tmp_sort, std::max(tmp_rle, tmp_sort2));
@@ -137,45 +155,67 @@ int select_candidates(const float *track, int64_t n_rows, int32_t max_out, bool 
     uint64_t *keys = reinterpret_cast<uint64_t *>(ws + o_keys), *sorted = reinterpret_cast<uint64_t *>(ws + o_sorted);
     uint64_t *unique_keys = reinterpret_cast<uint64_t *>(ws + o_unique);
     uint32_t *counts = reinterpret_cast<uint32_t *>(ws + o_counts), *counts2 = reinterpret_cast<uint32_t *>(ws + o_counts2);
-    uint32_t *info = reinterpret_cast<uint32_t *>(ws + o_info);  // [0] valid, [1] voted, [2] runs
+    uint32_t *info = reinterpret_cast<uint32_t *>(ws + o_info);  // [0] valid, [1] voted, [2] runs, [3] largest count, [4] a row did not fit the compact key
     void *tmp = ws + o_tmp;
 
     if ((rc = check_hip(hipMemsetAsync(info, 0, 64, stream), "memset"))) return rc;
-    hipLaunchKernelGGL(pack_tracker_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, track, n_rows, keys);
+    hipLaunchKernelGGL(pack_tracker_keys<WIDE>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, track, n_rows, keys, prio_bits, info + 4);
     size_t t = tmp_bytes;
-    if ((rc = check_hip(rocprim::radix_sort_keys(tmp, t, keys, sorted, n, 0, kKeyBits, stream), "radix_sort_keys"))) return rc;
+    if ((rc = check_hip(rocprim::radix_sort_keys(tmp, t, keys, sorted, n, 0, key_bits, stream), "radix_sort_keys"))) return rc;
     t = tmp_bytes;
     if ((rc = check_hip(rocprim::run_length_encode(tmp, t, sorted, (unsigned int)n, unique_keys, counts, info + 2, stream), "run_length_encode")))
         return rc;
-    hipLaunchKernelGGL(count_candidates, dim3(256), dim3(256), 0, stream, unique_keys, counts, info + 2, info);
-    uint32_t h[3] = {0, 0, 0};
+    hipLaunchKernelGGL(count_candidates, dim3(256), dim3(256), 0, stream, unique_keys, counts, info + 2, info, none);
+    uint32_t h[5] = {0, 0, 0, 0, 0};
     if ((rc = check_hip(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, stream), "copy counts"))) return rc;
     if ((rc = check_hip(hipStreamSynchronize(stream), "select_candidates"))) return rc;
-    const uint32_t n_valid = h[0], n_voted = h[1], n_runs = h[2];
+    if (!WIDE && h[4]) {
+        *overflow = true;  // a row outside the compact key's range: the caller repeats with the wide layout
+        return MNV_OK;
+    }
+    const uint32_t n_valid = h[0], n_voted = h[1], most = h[3];
 
     const uint64_t *ordered = unique_keys;  // ascending (priority, chunk, child); "no candidate" sorts last
     uint32_t n_sel = n_valid;
     if (need_votes) {
         // cuda_renderer.cpp:213-217: rows (-count, priority, chunk, child) with count >= 2, sorted ascending ==
         // count descending, ties in key order -- a stable descending sort of the already key-ordered runs.
-        // The "no candidate" run would sort first by its count, so it is cut off before the sort.
+        // The "no candidate" run would sort first by its count, so it is cut off before the sort.  Only the bits the largest count
+        // has are sorted (it came with the other counts): one or two passes instead of four.
         n_sel = n_voted;
         if (n_voted > 0) {
+            int count_bits = 1;
+            while (count_bits < 32 && (most >> count_bits) != 0u) ++count_bits;
             t = tmp_bytes;
-            if ((rc = check_hip(rocprim::radix_sort_pairs_desc(tmp, t, counts, counts2, unique_keys, sorted, (size_t)n_valid, 0, 32, stream),
+            if ((rc = check_hip(rocprim::radix_sort_pairs_desc(tmp, t, counts, counts2, unique_keys, sorted, (size_t)n_valid, 0, count_bits, stream),
                                 "radix_sort_pairs_desc")))
                 return rc;
             ordered = sorted;
         }
     }
-    (void)n_runs;
     const int32_t n_write = (int32_t)std::min<uint32_t>(n_sel, (uint32_t)max_out);
-    if (n_write > 0) hipLaunchKernelGGL(unpack_nodes, dim3((n_write + 255) / 256), dim3(256), 0, stream, ordered, n_write, nodes_out);
+    if (n_write > 0) hipLaunchKernelGGL(unpack_nodes<WIDE>, dim3((n_write + 255) / 256), dim3(256), 0, stream, ordered, n_write, nodes_out);
     // the workspace is reused by the next call: finish before the lock is released
     if ((rc = check_hip(hipStreamSynchronize(stream), "unpack_nodes"))) return rc;
     if (n_out) *n_out = n_write;
     if (n_candidates) *n_candidates = (int32_t)n_sel;
     return MNV_OK;
+}
+
+int select_candidates(const float *track, int64_t n_rows, int32_t max_out, bool need_votes, int32_t *nodes_out,
+                      int32_t *n_out, int32_t *n_candidates, hipStream_t stream) {
+    if (n_out) *n_out = 0;
+    if (n_candidates) *n_candidates = 0;
+    if (!track || n_rows < 0 || max_out < 0 || (max_out > 0 && !nodes_out)) return set_error(MNV_E_INVALID, "invalid tracker arguments");
+    if (n_rows == 0) return MNV_OK;
+    if (n_rows > 0x7fffffff) return set_error(MNV_E_UNSUPPORTED, "more than 2^31 - 1 tracker rows");
+    static const bool force_wide = getenv("MNV_VOTE_WIDE_KEYS") != nullptr;  // (tests: the fallback path on ordinary inputs)
+    bool overflow = force_wide;
+    if (!overflow) {
+        const int rc = select_candidates_as<false>(track, n_rows, max_out, need_votes, nodes_out, n_out, n_candidates, &overflow, stream);
+        if (rc || !overflow) return rc;
+    }
+    return select_candidates_as<true>(track, n_rows, max_out, need_votes, nodes_out, n_out, n_candidates, &overflow, stream);
 }
 
 // union of the ranks' visit marks (mnv_merge_visit_marks)

@@ -128,7 +128,11 @@ class TileGatherer:
         self._sent = [torch.cuda.Event() for _ in range(depth)] if self._side is not None else None
         # `timing`: device time of every gather and (rank 0) un-permute on the side streams, for the per-rank report of bench.py --gpus N
         self._timing = bool(timing) and self._side is not None
-        self._t_events = []   # (gather begin, gather end, un-permute end or None)
+        # three events per slot, made once and reused (gather begin, gather end, un-permute end); a slot's previous measurement is read
+        # when the slot comes round again (its work finished `depth` steps ago) or by take_timings()
+        self._t_slot = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(depth)] if self._timing else None
+        self._t_armed = [False] * depth
+        self._t_values = []   # (gather ms, un-permute ms or None)
         if rank == 0:
             self._gathered = [torch.empty((part.world,) + shape, dtype=dtype, device=device) for _ in range(depth)]
             self._frames = [torch.empty(lead + (part.height, part.width, channels), dtype=dtype, device=device) for _ in range(depth)]
@@ -154,8 +158,10 @@ class TileGatherer:
         # after it and after the render just enqueued on the current stream
         side.wait_stream(torch.cuda.current_stream(side.device))
         with torch.cuda.stream(side):
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self._timing else None
-            if ev:
+            ev = None
+            if self._timing:
+                self._harvest(slot)
+                ev = self._t_slot[slot]
                 ev[0].record()
             if self.comm is not None:
                 self.comm.gather_tiles(self._local[slot], self._gathered[slot] if self.rank == 0 else None, root=0, stream=side.cuda_stream)
@@ -169,8 +175,15 @@ class TileGatherer:
                 if ev:
                     ev[2].record()
             if ev:
-                self._t_events.append(ev)
+                self._t_armed[slot] = True
         self._pending[slot] = True
+
+    def _harvest(self, slot: int) -> None:
+        if self._timing and self._t_armed[slot]:
+            ev = self._t_slot[slot]
+            ev[2 if self.rank == 0 else 1].synchronize()
+            self._t_values.append((ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]) if self.rank == 0 else None))
+            self._t_armed[slot] = False
 
     def finish(self, slot: int) -> None:
         w = self._pending[slot]
@@ -191,14 +204,25 @@ class TileGatherer:
             return
         torch.cuda.current_stream(self._side[slot].device).wait_event(self._sent[slot])
 
+    def wait_frame(self, slot: int) -> None:
+        """Rank 0: order the current stream after the un-permute that fills ``frame(slot)`` (``finish`` only waits for the gather, which
+        is what the next render into the slot needs).  A no-op for the host-staged and blocking variants, whose ``finish`` assembles."""
+        if self._side is not None and self.rank == 0:
+            torch.cuda.current_stream(self._side[slot].device).wait_stream(self._side[slot])
+
     def take_timings(self) -> dict:
         """Average device milliseconds per step of the gather (from its enqueue on the side stream, so waiting for the peers counts) and of
-        rank 0's un-permute since the last call; empty without `timing`.  Call after the streams were synchronised."""
-        if not self._t_events:
+        rank 0's un-permute since the last call (call it once after the warm-up to discard the channel set-up of the first gather);
+        empty without `timing`.  Waits for the slots' events."""
+        if not self._timing:
             return {}
-        g = [e[0].elapsed_time(e[1]) for e in self._t_events]
-        u = [e[1].elapsed_time(e[2]) for e in self._t_events] if self.rank == 0 else []
-        self._t_events = []
+        for slot in range(self.depth):
+            self._harvest(slot)
+        if not self._t_values:
+            return {}
+        g = [v[0] for v in self._t_values]
+        u = [v[1] for v in self._t_values if v[1] is not None]
+        self._t_values = []
         out = {"gather_ms": sum(g) / len(g), "gathers": len(g)}
         if u:
             out["unpermute_ms"] = sum(u) / len(u)

@@ -133,3 +133,97 @@ def test_tile_gatherer_over_the_c_abi_with_several_ranks_on_one_gpu(mnv, torch_g
             if p.is_alive():
                 p.kill()   # exactly the processes started above
     assert all(p.exitcode == 0 for p in procs)
+
+
+def _late_rank_main(rank, world, lib, idq, resq):
+    """Six steps through a ring of two slots, every step with its own cameras; rank 1 stalls for 1.5 s (hundreds of step times) before
+    steps 2 and 4.  Rank 0 keeps what every slot held when its turn came round again."""
+    import os
+    import sys
+    import time
+    import traceback
+
+    try:
+        os.environ["MNV_RCCL_LIBRARY"] = lib
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.environ["MNV_LIB_PATH"] = os.path.join(root, "mega-nerf-viewer_amd", "testhooks", "libmnv.so")
+        for p in (root, os.path.join(root, "tests"), os.path.join(root, "oracle")):
+            if p not in sys.path:
+                sys.path.insert(0, p)
+        import torch
+
+        import cases as cs
+        import mega_nerf_viewer_amd as mnv
+        from mega_nerf_viewer_amd.multigpu import TileGatherer, TilePartition
+
+        torch.cuda.set_device(0)
+        if rank == 0:
+            uid = mnv.comm_get_unique_id()
+            for _ in range(world - 1):
+                idq.put(uid)
+        else:
+            uid = idq.get(timeout=120)
+        comm = mnv.Comm(uid, world, rank)
+        spec = cs.CASES["sh9_d7_aniso"]
+        tree = cs.make_tree(mnv, spec["tree"])
+        tree.move_to_device()
+        w, h, n_steps, depth = 400, 248, 6, 2
+        cams_of = [[cs.make_camera(mnv, dict(spec["camera"], width=w, height=h, center=(-3.0 + 0.2 * k + 0.07 * s, 2.0 - 0.05 * s, 5.0))) for k in range(2)]
+                   for s in range(n_steps)]
+        opt = cs.make_options(mnv, spec["options"])
+        part = TilePartition(w, h, world, 64, 24, 3)
+        tg = TileGatherer(part, rank, torch.device("cuda", 0), dtype=torch.uint8, depth=depth, frames=2, comm=comm)
+        kept = {}
+        for s in range(n_steps):
+            slot = s % depth
+            if rank == 0 and s >= depth:
+                tg.wait_frame(slot)
+                kept[s - depth] = tg.frame(slot).clone()
+            tg.finish(slot)
+            if rank == 1 and s in (2, 4):
+                torch.cuda.synchronize()
+                time.sleep(1.5)
+            mnv.render_voxels_accel_batch(tree.accel, cams_of[s], opt, part=part.part(rank), rgba8=tg.local(slot), stream=torch.cuda.current_stream().cuda_stream)
+            tg.submit(slot)
+        tg.finish_all()
+        torch.cuda.synchronize()
+        if rank == 0:
+            for s in range(n_steps - depth, n_steps):
+                kept[s] = tg.frame(s % depth).clone()
+            bad = []
+            full = torch.empty((2, h, w, 4), dtype=torch.uint8, device="cuda")
+            for s in range(n_steps):
+                mnv.render_voxels_accel_batch(tree.accel, cams_of[s], opt, rgba8=full)
+                torch.cuda.synchronize()
+                if not torch.equal(kept[s], full):
+                    bad.append(s)
+            distinct = not torch.equal(kept[0], kept[1])
+            resq.put(("ok", (bad, distinct)))
+        comm.close()
+    except Exception:  # noqa: BLE001
+        resq.put(("error", f"rank {rank}: {traceback.format_exc()}"))
+
+
+def test_a_late_rank_cannot_hand_rank_0_a_half_written_slot(mnv, torch_gpu, fake_rccl):
+    """World 2 over the transport stand-in, ring of two slots: rank 1 arrives more than a step late, twice.  Rank 0's march runs ahead
+    by at most the ring's depth (finish(slot) orders the next render into a slot after the gather that read it), its gather waits for
+    the peer on the slot's own side stream, and every step's assembled frames equal the single-launch frames of that step's cameras --
+    the ordering `bench.py --gpus N` and mnv_render --gpus N rely on."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    idq, resq = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_late_rank_main, args=(r, 2, fake_rccl, idq, resq)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        kind, val = resq.get(timeout=600)
+        assert kind == "ok", val
+        bad, distinct = val
+        assert bad == [] and distinct, val
+    finally:
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()   # exactly the processes started above
+    assert all(p.exitcode == 0 for p in procs)

@@ -142,6 +142,33 @@ def test_selection_full_frame_against_oracle(mnv, torch_gpu):
     assert mnv.select_split_candidates(d_track, 0, None) == (0, ro.select_split_candidates(track, 0)[1])
 
 
+@pytest.mark.parametrize("what", ["large_chunk_index", "large_priority"])
+def test_selection_rows_beyond_the_compact_key_take_the_wide_layout(mnv, torch_gpu, what):
+    """The vote sorts 27 + 5 (sample selection: 27 + 9) bit keys -- what the march writes: voxel indices below 2^27, depths / sample counts as
+    priorities -- and repeats with the 52-bit layout of the contract in include/mnv.h when a row does not fit: chunk indices above 2^24
+    (trees beyond 16.7 M chunks) or priorities above 30 / 510 must give the numpy restatement's answer all the same."""
+    torch = torch_gpu
+    rng = np.random.default_rng(5)
+    n = 300_000
+    chunk = (rng.zipf(1.3, n) % 50_000).astype(np.int64)
+    prio = 1 + chunk % 9
+    if what == "large_chunk_index":
+        chunk = chunk * 4 + (1 << 24)          # exactly representable in binary32 (multiples of 4 above 2^24)
+    else:
+        prio = prio + 600                       # beyond both compact priority ranges
+    track = np.stack([prio.astype(np.float32), chunk.astype(np.float32), (chunk * 5 % 8).astype(np.float32)], 1)
+    track[rng.random(n) < 0.5] = (-1.0, -1.0, -1.0)
+    k = 20_000
+    d_track = torch.from_numpy(track).cuda()
+    nodes = torch.empty((k, 2), dtype=torch.int32, device="cuda")
+    n_out, n_cand = mnv.select_split_candidates(d_track, k, nodes)
+    want, want_n = ro.select_split_candidates(track, k)
+    assert want_n > 1000 and (n_out, n_cand) == (want.shape[0], want_n) and np.array_equal(nodes.cpu().numpy()[:n_out], want)
+    n_out, n_cand = mnv.select_sample_candidates(d_track, k, nodes)
+    want, want_n = ro.select_sample_candidates(track, k)
+    assert (n_out, n_cand) == (want.shape[0], want_n) and np.array_equal(nodes.cpu().numpy()[:n_out], want)
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_selection_does_not_depend_on_the_order_of_the_tracker_rows(mnv, torch_gpu, seed):
     """What refinement on several ranks rests on (VolumeRenderer::set_ranks): every rank votes on the all-gathered tracker rows, which

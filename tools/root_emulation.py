@@ -9,7 +9,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
 
 import torch  # noqa: E402
 
@@ -42,7 +42,8 @@ def main():
         gathered = torch.zeros((args.world, NF, part.j_max, MH, MW, 4), dtype=torch.uint8, device=dev)
         incoming = torch.zeros((args.world - 1, NF, part.j_max, MH, MW, 4), dtype=torch.uint8, device=dev)  # stands for the peers' buffers
         frames = torch.empty((NF, H, W, 4), dtype=torch.uint8, device=dev)
-        res = {"world": args.world, "root_period": M, "tiles_per_rank": [part.local_tiles(r) for r in range(args.world)]}
+        import bench
+        res = {"world": args.world, "root_period": M, "tiles_per_rank": [part.local_tiles(r) for r in range(args.world)], "kernel_source_sha": bench.kernel_source_sha()}
         for rank, root_work in ((1, False), (0, False), (0, True)):
             def run(n):
                 for k in range(n):

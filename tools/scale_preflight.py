@@ -117,26 +117,46 @@ def main():
         worker(int(args.worker[0]), int(args.worker[1]), int(args.worker[2]), args.worker[3])
         return 0
     n = args.gpus or gpu_count() or 1
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    import signal
     import tempfile
+    import time
 
+    deadline_s = 600   # ONE deadline for the whole run: a wedged rank takes its peers down with it instead of costing 600 s each
     with tempfile.TemporaryDirectory() as d:
-        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(r), str(n), str(port), os.path.join(d, f"r{r}.json")],
-                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(n)]
-        outs = []
-        for p in procs:
-            try:
-                o, _ = p.communicate(timeout=600)
-            except subprocess.TimeoutExpired:
-                p.kill()
-                o = "(timed out after 600 s)"
-            outs.append(o)
-        results = []
-        for r in range(n):
-            f = os.path.join(d, f"r{r}.json")
-            results.append(json.load(open(f)) if os.path.exists(f) else {"rank": r, "items": [{"name": "rank finished", "ok": False, "output": outs[r][-1500:]}]})
+        results = None
+        for attempt in range(3):   # the rendezvous port is free when probed, not necessarily when the workers bind it: retry on a lost race
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            logs = [open(os.path.join(d, f"r{r}.log"), "w") for r in range(n)]   # files, not pipes: a chatty rank (NCCL_DEBUG) cannot block on a full pipe
+            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(r), str(n), str(port), os.path.join(d, f"r{r}.json")],
+                                      stdout=logs[r], stderr=subprocess.STDOUT, start_new_session=True) for r in range(n)]
+            t_end, failed = time.time() + deadline_s, None
+            while any(p.poll() is None for p in procs):
+                bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+                if bad or time.time() > t_end:
+                    failed = f"rank(s) {bad} exited with an error" if bad else f"no result within {deadline_s} s"
+                    for p in procs:   # every worker leads its own session: kill exactly the groups started above
+                        if p.poll() is None:
+                            try:
+                                os.killpg(p.pid, signal.SIGKILL)
+                            except ProcessLookupError:
+                                pass
+                    break
+                time.sleep(0.2)
+            for p in procs:
+                p.wait()
+            for f in logs:
+                f.close()
+            outs = [open(os.path.join(d, f"r{r}.log")).read() for r in range(n)]
+            if failed and attempt < 2 and any("EADDRINUSE" in o or "Address already in use" in o for o in outs):
+                continue
+            results = []
+            for r in range(n):
+                f = os.path.join(d, f"r{r}.json")
+                results.append(json.load(open(f)) if os.path.exists(f) else
+                               {"rank": r, "items": [{"name": "rank finished", "ok": False, "why": failed, "output": outs[r][-1500:]}]})
+            break
     ok = all(it["ok"] for res in results for it in res["items"])
     if args.json:
         print(json.dumps({"ranks": n, "ok": ok, "results": results}))
