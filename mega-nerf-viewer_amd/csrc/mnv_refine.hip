@@ -68,8 +68,8 @@ struct Carver {
 // lexicographic order of the rows == order of this packed key.  Rows with chunk < 0 are "no candidate".
 // Two key layouts.  WIDE (52 bits: 16 of priority, 32 of chunk, 3 of child) holds whatever the contract of include/mnv.h admits and
 // costs seven 8-bit radix passes.  COMPACT is what the march actually writes -- a voxel index below 2^27 (trees up to 16.7 M chunks)
-// and a priority in [-1, 2^PB - 2] (a depth for the split tracker: PB = 5; a sample count for the sample tracker: PB = 9) -- in
-// 27 + PB bits: four or five passes.  The pack kernel raises a flag for any row that does not fit and the caller repeats the call
+// and a priority in [-1, 2^PB - 3] (a depth for the split tracker: PB = 5; a sample count for the sample tracker: PB = 9; the top value
+// of the field marks "no candidate", which must sort last) -- in 27 + PB bits: four or five passes.  The pack kernel raises a flag for any row that does not fit and the caller repeats the call
 // with the wide layout (never seen in practice; the flag costs nothing, it travels with the counts the host reads anyway).
 constexpr int kVoxBits = 27;
 constexpr uint64_t kNoCandidateWide = 1ull << 51;
@@ -80,7 +80,7 @@ __global__ void pack_tracker_keys(const float *__restrict__ track, int64_t n_row
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
     const float prio = track[i * 3 + 0], chunk = track[i * 3 + 1], child = track[i * 3 + 2];
-    const uint64_t none = WIDE ? kNoCandidateWide : 1ull << (kVoxBits + prio_bits);
+    const uint64_t none = WIDE ? kNoCandidateWide : (((1ull << prio_bits) - 1) << kVoxBits);
     uint64_t key = none;
     if (chunk >= 0.f) {
         if (WIDE) {
@@ -88,7 +88,7 @@ __global__ void pack_tracker_keys(const float *__restrict__ track, int64_t n_row
             key = (p << 35) | ((uint64_t)(uint32_t)(int32_t)chunk << 3) | ((uint64_t)(int32_t)child & 7u);
         } else {
             const int64_t vox = (int64_t)(int32_t)chunk * 8 + ((int32_t)child & 7), p = (int64_t)(int32_t)prio + 1;
-            if (vox >= ((int64_t)1 << kVoxBits) || p < 0 || p >= ((int64_t)1 << prio_bits)) *overflow = 1u;  // (benign race: every writer stores 1)
+            if (vox >= ((int64_t)1 << kVoxBits) || p < 0 || p >= ((int64_t)1 << prio_bits) - 1) *overflow = 1u;  // (benign race: every writer stores 1)
             key = ((uint64_t)p << kVoxBits) | (uint64_t)vox;
         }
     }
@@ -113,10 +113,25 @@ __global__ void count_candidates(const uint64_t *__restrict__ unique_keys, const
         const uint32_t other = __shfl_down(most, off);
         most = other > most ? other : most;
     }
+    // one atomic per workgroup: a thousand atomics on one address are served one after the other (40 us for this kernel in round 3's trace)
+    __shared__ uint32_t s_part[3][4];
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        if (valid) atomicAdd(&info[0], valid);
-        if (voted) atomicAdd(&info[1], voted);
-        if (most) atomicMax(&info[3], most);
+        s_part[0][wave] = valid;
+        s_part[1][wave] = voted;
+        s_part[2][wave] = most;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t v = 0, w = 0, m = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) {
+            v += s_part[0][k];
+            w += s_part[1][k];
+            m = s_part[2][k] > m ? s_part[2][k] : m;
+        }
+        if (v) atomicAdd(&info[0], v);
+        if (w) atomicAdd(&info[1], w);
+        if (m) atomicMax(&info[3], m);
     }
 }
 
@@ -134,8 +149,8 @@ template <bool WIDE>
 int select_candidates_as(const float *track, int64_t n_rows, int32_t max_out, bool need_votes, int32_t *nodes_out, int32_t *n_out, int32_t *n_candidates,
                          bool *overflow, hipStream_t stream) {
     const size_t n = (size_t)n_rows;
-    const int prio_bits = need_votes ? 5 : 9, key_bits = WIDE ? kKeyBitsWide : kVoxBits + prio_bits + 1;  // + 1: the "no candidate" key
-    const uint64_t none = WIDE ? kNoCandidateWide : 1ull << (kVoxBits + prio_bits);
+    const int prio_bits = need_votes ? 5 : 9, key_bits = WIDE ? kKeyBitsWide : kVoxBits + prio_bits;
+    const uint64_t none = WIDE ? kNoCandidateWide : (((1ull << prio_bits) - 1) << kVoxBits);
 
     size_t tmp_sort = 0, tmp_rle = 0, tmp_sort2 = 0;
     uint64_t *nk = nullptr;
@@ -165,7 +180,7 @@ int select_candidates_as(const float *track, int64_t n_rows, int32_t max_out, bo
     t = tmp_bytes;
     if ((rc = check_hip(rocprim::run_length_encode(tmp, t, sorted, (unsigned int)n, unique_keys, counts, info + 2, stream), "run_length_encode")))
         return rc;
-    hipLaunchKernelGGL(count_candidates, dim3(256), dim3(256), 0, stream, unique_keys, counts, info + 2, info, none);
+    hipLaunchKernelGGL(count_candidates, dim3(64), dim3(256), 0, stream, unique_keys, counts, info + 2, info, none);
     uint32_t h[5] = {0, 0, 0, 0, 0};
     if ((rc = check_hip(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, stream), "copy counts"))) return rc;
     if ((rc = check_hip(hipStreamSynchronize(stream), "select_candidates"))) return rc;
