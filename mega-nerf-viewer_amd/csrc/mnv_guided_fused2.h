@@ -76,6 +76,12 @@ constexpr int kF2RingWords = kF2Ring * (4 + 1 + 1 + 1);  // + a debug word per e
 constexpr int kF2RingWords = kF2Ring * (4 + 1 + 1);
 #endif  // float4 {x, y, z, dz} -> {att, d0, d1, d2} | meta | owner's next slot
 constexpr int kF2WavesPerSimd = MNV_F2_WAVES;      // register budget: 128 / 96 / 80 VGPRs
+#ifndef MNV_F2_L0_BLOCKS
+#define MNV_F2_L0_BLOCKS 1   // layer 0 one 16-row block at a time (a compiler barrier): see the comment at the barrier
+#endif
+#ifndef MNV_F2_OPAQUE_LANE
+#define MNV_F2_OPAQUE_LANE 1 // lane-derived addresses are recomputed per window instead of being hoisted out of the loop and spilled
+#endif
 constexpr bool kF2Default = true;                  // mnv_set_fused_kernel(0) picks this kernel when it fits
 constexpr uint32_t kF2Ready = 128u;                // meta bit: the entry holds its results
 static_assert(kF2NP % kF2NC == 0 && kF2RPC >= 1 && kF2RPC <= 4 && kF2Block <= 1024 && kF2NS >= 1 && kF2NS <= 7, "workgroup shape");
@@ -571,7 +577,16 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
     } else {
         // =================================================================================== consumer: the network
         __builtin_amdgcn_s_setprio(2);
-        const int g = lane >> 4, col = lane & 15;
+        // Lane-derived constants (tile / fragment / bias addresses) are loop invariants the compiler hoists out of the window loop -- into
+        // registers the 64 accumulators leave no room for, i.e. into scratch, to be reloaded (a ~0.3 us round trip each, eight in a row in
+        // the evaluation alone) in every window.  An opaque copy of the lane number per window makes them cheap values again.
+        auto opaque = [](int v) __attribute__((always_inline)) {
+#if MNV_F2_OPAQUE_LANE
+            asm volatile("" : "+v"(v));
+#endif
+            return v;
+        };
+        int g = lane >> 4, col = lane & 15;
         const int ci = wave - kF2NP, rbase = ci * kF2RPC;  // this consumer and the first of its rings
         uint32_t *s_cols = s_mem + Lo.cols + 64 * ci;
         uint32_t *s_tile = s_mem + Lo.tile + ci * Lo.tile_words;
@@ -670,6 +685,11 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
             }
             spins = 0;
             const unsigned long long t_w0 = F.diag ? wall_clock64() : 0;
+            {
+                const int lw = opaque(lane);
+                g = lw >> 4;
+                col = lw & 15;
+            }
             // ---- the window: up to 64 waiting samples of ONE sub-module, gathered from all rings of this consumer.  select(c, first, half)
             //      lists them in s_cols (ring `first` first, and of that ring the half `half` first) without taking them yet.
             uint32_t taken[kF2RPC];
@@ -783,7 +803,8 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
             //      the first channel, share 1 the other two; the four floats replace the sample in its ring entry
             auto evaluate = [&](int half, auto valid_tag) __attribute__((always_inline)) {
                 constexpr bool kValid = decltype(valid_tag)::value;
-                const int c32 = lane & 31, share = lane >> 5, jc = half * 32 + c32;
+                const int le = opaque(lane);
+                const int c32 = le & 31, share = le >> 5, jc = half * 32 + c32;
                 const bool on = jc < n;
                 if (on) {
                     const uint32_t where_j = s_cols[jc];
@@ -1069,6 +1090,13 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                             for (int j = 0; j < 2; ++j) bf[kk][j] = __builtin_bit_cast(half8, tile_q[kk * (4 * kF2Cols) + ((2 * h + j) * 16 + col) * 4 + g]);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
+#if MNV_F2_L0_BLOCKS
+                            // A scheduling hint, nothing else: without it the compiler hoists the 12 operand loads of all four 16-row blocks above
+                            // the first MFMA and merges the two column halves -- 64 accumulators AND 48 operand registers live at once, and the
+                            // addresses of the evaluation go to scratch (38 instead of 15 scratch reloads in the kernel; 1.30 instead of 1.25 ms).
+                            // (Round 3 knew this barrier as the thing that hid the wrong denominator; that was the packed add, header comment.)
+                            asm volatile("" ::: "memory");
+#endif
                             const f32x4 bv = bias_tile(mt);
 #pragma unroll
                             for (int kk = 0; kk < NKK0; ++kk) {

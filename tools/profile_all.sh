@@ -10,8 +10,9 @@ bash tools/prof_trace.sh ${R}_per_frame_1stream --per-frame --frame-streams 1 --
 bash tools/prof_trace.sh ${R}_ref_layout --kernel ref_layout --per-frame --frame-streams 2 --laps 1 --steps 3 --warmup 1 > /dev/null 2>&1
 # cfg3 / cfg4 (the 7.2 M-chunk tree): kernel stats AND the HBM-traffic passes; profiles/${R}_traffic_cfg3.json / _cfg4.json feed bench.py's cfg3 / cfg4_n1 rooflines
 for wl in cfg3 cfg4; do
-  bash tools/prof_traffic.sh ${R}_${wl} --workload $wl > /dev/null 2>&1
-  python3 tools/make_traffic_json.py gpurun_out/${R}_${wl}/summary.txt 16 "--workload $wl" > gpurun_out/${R}_${wl}/traffic.json
+  # --laps 1: 16 frames per launch, the launch shape of the default bench line's cfg3 / cfg4_n1 objects
+  bash tools/prof_traffic.sh ${R}_${wl} --workload $wl --laps 1 > /dev/null 2>&1
+  python3 tools/make_traffic_json.py gpurun_out/${R}_${wl}/summary.txt 16 "--workload $wl --laps 1" > gpurun_out/${R}_${wl}/traffic.json
   cp gpurun_out/${R}_${wl}/traffic.json profiles/${R}_traffic_${wl}.json
 done
 export TMPDIR=/tmp
