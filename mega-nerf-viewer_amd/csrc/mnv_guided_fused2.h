@@ -60,7 +60,11 @@ namespace mnv {
 #ifndef MNV_F2_WAVES
 #define MNV_F2_WAVES 4  // wavefronts per SIMD the kernel is compiled for: 4 (128 VGPRs), 5 (96), 6 (80)
 #endif
-constexpr int kF2NP = MNV_F2_NP, kF2NC = MNV_F2_NC, kF2NS = MNV_F2_NS, kF2RPC = kF2NP / kF2NC;  // RPC: rings per consumer
+#ifndef MNV_F2_SHARE
+#define MNV_F2_SHARE 1  // consumers that serve one group of rings together (1, 2 or 4): slot s of a ring of the group belongs to the
+#endif                  // consumer s % SHARE of the group -- a tile's burst of samples is drained by SHARE consumers instead of one
+constexpr int kF2NP = MNV_F2_NP, kF2NC = MNV_F2_NC, kF2NS = MNV_F2_NS, kF2SH = MNV_F2_SHARE, kF2ShLog = kF2SH == 4 ? 2 : kF2SH - 1;
+constexpr int kF2RPC = kF2NP * kF2SH / kF2NC;  // RPC: rings a consumer watches (those of its group)
 constexpr int kF2Cols = MNV_F2_COLS, kF2NT = kF2Cols / 16, kF2Halves = kF2Cols / 32;
 static_assert(kF2Cols == 64 || kF2Cols == 32, "a run is 64 or 32 columns");
 constexpr int kF2Block = 64 * (kF2NP + kF2NC);
@@ -68,7 +72,8 @@ constexpr int kF2Block = 64 * (kF2NP + kF2NC);
 #define MNV_F2_RING 256
 #endif
 constexpr int kF2Ring = MNV_F2_RING;               // slots per producer ring (128 or 256): one march step adds at most 64 samples
-constexpr int kF2RingLog = kF2Ring == 256 ? 8 : 7, kF2RH = kF2Ring / 64;  // RH: slots of a ring that one consumer lane watches
+constexpr int kF2RingLog = kF2Ring == 256 ? 8 : 7, kF2RH = kF2Ring / 64 / kF2SH;  // RH: slots of a ring that one consumer lane watches
+constexpr int kF2WCL = (kF2RH + 1) / 2;  // words of two 16-bit sub-module ids per lane and ring
 static_assert(kF2Ring == 128 || kF2Ring == 256, "ring size");
 #ifdef MNV_F2_LOG
 constexpr int kF2RingWords = kF2Ring * (4 + 1 + 1 + 1);  // + a debug word per entry (where in which window the consumer evaluated it)
@@ -84,7 +89,9 @@ constexpr int kF2WavesPerSimd = MNV_F2_WAVES;      // register budget: 128 / 96 
 #endif
 constexpr bool kF2Default = true;                  // mnv_set_fused_kernel(0) picks this kernel when it fits
 constexpr uint32_t kF2Ready = 128u;                // meta bit: the entry holds its results
-static_assert(kF2NP % kF2NC == 0 && kF2RPC >= 1 && kF2RPC <= 4 && kF2Block <= 1024 && kF2NS >= 1 && kF2NS <= 7, "workgroup shape");
+static_assert((kF2NP * kF2SH) % kF2NC == 0 && kF2NC % kF2SH == 0 && (kF2SH == 1 || kF2SH == 2 || kF2SH == 4) && kF2RH >= 1 && kF2RPC >= 1 && kF2RPC <= 4 &&
+                  kF2Block <= 1024 && kF2NS >= 1 && kF2NS <= 7,
+              "workgroup shape");
 // Watchdog of the spin-waits: a wait that lasts this many polls (s_sleep 1-2 each: tens of milliseconds; a healthy wait is a few
 // microseconds) is abandoned and the wavefront leaves -- wrong pixels and a count in the diagnostics buffer instead of a hung device.
 // No schedule of co-resident waves reaches it (header comment); it exists so that a bug cannot take the machine down.
@@ -103,7 +110,7 @@ __host__ __device__ inline F2Layout f2_layout(int nb, int lds_level, const MlpSh
     L.ctrl = L.rings + kF2NP * kF2RingWords;
     L.cols = L.ctrl + 8 * kF2NP;                          // 8 words per ring
     L.watch = L.cols + 64 * kF2NC;                        // column -> (ring, slot) of every consumer's current window
-    L.wcache = L.watch + (kF2RPC * (kF2RH / 2) + 1) * 64 * kF2NC;       // per consumer and lane: what waits in the slots the lane watches (between windows the registers belong to the network)
+    L.wcache = L.watch + (kF2RPC * kF2WCL + 1) * 64 * kF2NC;       // per consumer and lane: what waits in the slots the lane watches (between windows the registers belong to the network)
     L.frags = L.wcache + 32;                              // weight cache: lock, clock, per slot {cluster, state, readers, stamp}
     L.frag_words = S.frag_halfs / 2;
     L.bias_words = (S.bias_floats + 3) & ~3;
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
         const int cells = 1 << (3 * LL);
         if (threadIdx.x < 32) s_exp[threadIdx.x] = kExp2fTab[threadIdx.x];
         for (int i = threadIdx.x; i < 8 * kF2NP; i += kF2Block) s_ctrl[i] = 0u;
-        for (int i = threadIdx.x; i < (kF2RPC * (kF2RH / 2) + 1) * 64 * kF2NC; i += kF2Block) s_mem[Lo.watch + i] = 0u;
+        for (int i = threadIdx.x; i < (kF2RPC * kF2WCL + 1) * 64 * kF2NC; i += kF2Block) s_mem[Lo.watch + i] = 0u;
         if (threadIdx.x < 32) s_mem[Lo.wcache + threadIdx.x] = threadIdx.x >= 2 && ((threadIdx.x - 2) & 3) == 0 ? 0xffffffffu : 0u;  // slots: no cluster
         for (int i = threadIdx.x; i < cells; i += kF2Block) {
             const int G = 1 << LL;
@@ -587,7 +594,11 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
             return v;
         };
         int g = lane >> 4, col = lane & 15;
-        const int ci = wave - kF2NP, rbase = ci * kF2RPC;  // this consumer and the first of its rings
+        const int ci = wave - kF2NP, rbase = (ci / kF2SH) * kF2RPC;  // this consumer and the first ring of its group
+        const uint32_t par = (uint32_t)(ci % kF2SH);                  // ... of whose rings it watches the slots s with s % SH == par
+        auto slot_of = [&](int h) __attribute__((always_inline)) -> uint32_t { return (uint32_t)kF2SH * ((uint32_t)lane + 64u * (uint32_t)h) + par; };  // the h-th slot this lane watches
+        // entries with numbers in [a, b) that are this consumer's (numbers are monotonic, the ring size is a multiple of SH)
+        auto mine_in = [&](uint32_t a, uint32_t b) __attribute__((always_inline)) -> uint32_t { return ((b + (uint32_t)(kF2SH - 1) - par) >> kF2ShLog) - ((a + (uint32_t)(kF2SH - 1) - par) >> kF2ShLog); };
         uint32_t *s_cols = s_mem + Lo.cols + 64 * ci;
         uint32_t *s_tile = s_mem + Lo.tile + ci * Lo.tile_words;
         float *s_out = reinterpret_cast<float *>(s_tile);
@@ -598,12 +609,12 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
         // this lane watches slots `lane + 64 h` (h < RH) of every ring: is an unevaluated sample there, and of which sub-module
         // (kept in LDS between windows -- s_watch[k * 64 + lane]: first the cluster words (two 16-bit clusters each), then the waiting
         // bits -- so that nothing of it occupies registers while the network runs)
-        constexpr int WCL = kF2RH / 2, WWORDS = kF2RPC * WCL + 1;
+        constexpr int WCL = kF2WCL, WWORDS = kF2RPC * WCL + 1;
         static_assert(kF2RPC * kF2RH <= 32, "waiting bits fit a word");
         uint32_t *s_watch = s_mem + Lo.watch + ci * WWORDS * 64 + lane;
-        uint32_t scan[kF2RPC], evald[kF2RPC];  // per ring (wave-uniform): entries registered, evaluated
+        uint32_t scan[kF2RPC], mine[kF2RPC], evald[kF2RPC];  // per ring (wave-uniform): entries seen; of those, this consumer's; of those, evaluated
 #pragma unroll
-        for (int p = 0; p < kF2RPC; ++p) scan[p] = evald[p] = 0u;
+        for (int p = 0; p < kF2RPC; ++p) scan[p] = mine[p] = evald[p] = 0u;
         int lds_cluster = -1;  // the sub-module this consumer ran last (its weights are most likely still in a slot)
         int held_slot = -1;    // the weight slot this consumer holds a reader's reference on
         uint32_t spins = 0;
@@ -640,19 +651,20 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                         const uint32_t *meta_p = ring_meta(p);
 #pragma unroll
                         for (int h = 0; h < kF2RH; ++h) {
-                            if ((((uint32_t)lane + 64u * h - scan[p]) & (kF2Ring - 1)) < fresh) {
+                            if (((slot_of(h) - scan[p]) & (kF2Ring - 1)) < fresh) {
 #ifdef MNV_F2_CHECK_RINGS
                                 if (((watch_pend >> (kF2RH * p + h)) & 1u) && F.diag) atomicAdd(F.diag + 29, 1ull << 32);  // the slot's previous entry still waits
-                                if ((meta_p[lane + 64 * h] & kF2Ready) && F.diag) atomicAdd(F.diag + 29, 1ull << 40);      // a fresh entry that is already marked
+                                if ((meta_p[slot_of(h)] & kF2Ready) && F.diag) atomicAdd(F.diag + 29, 1ull << 40);      // a fresh entry that is already marked
 #endif
-                                const uint32_t c16 = (meta_p[lane + 64 * h] >> 8) & 0xffffu;
+                                const uint32_t c16 = (meta_p[slot_of(h)] >> 8) & 0xffffu;
                                 watch_cl[p][h >> 1] = (h & 1) ? (watch_cl[p][h >> 1] & 0xffffu) | (c16 << 16) : (watch_cl[p][h >> 1] & 0xffff0000u) | c16;
                                 watch_pend |= 1u << (kF2RH * p + h);
                             }
                         }
+                        mine[p] += mine_in(scan[p], tl[p]);
                         scan[p] = tl[p];
                     }
-                    const uint32_t waiting = scan[p] - evald[p];
+                    const uint32_t waiting = mine[p] - evald[p];
                     total += waiting;
                     // a stalled producer (no room for another step) needs its OLDEST samples; one that has finished its tile needs all of them
                     if (waiting != 0u && sl[p] == tl[p] && (service < 0 || !service_stall)) {
@@ -720,7 +732,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                                     const uint32_t k = (uint32_t)__popcll(msk), tk = k < (uint32_t)(kF2Cols - n) ? k : (uint32_t)(kF2Cols - n);
                                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(msk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)msk, 0u));
                                     if (match && rank < tk) {
-                                        s_cols[n + (int)rank] = ((uint32_t)p << kF2RingLog) | ((uint32_t)h << 6) | (uint32_t)lane;
+                                        s_cols[n + (int)rank] = ((uint32_t)p << kF2RingLog) | slot_of(h);
                                         sel_bits |= 1u << (kF2RH * p + h);
                                     }
                                     n = __builtin_amdgcn_readfirstlane(n + (int)tk);
@@ -756,8 +768,8 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                     uint32_t best = 0u;
 #pragma unroll
                     for (int p = 0; p < kF2RPC; ++p) {
-                        if (scan[p] - evald[p] > best) {
-                            best = scan[p] - evald[p];
+                        if (mine[p] - evald[p] > best) {
+                            best = mine[p] - evald[p];
                             target = p;
                         }
                     }
@@ -770,7 +782,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                         uint32_t far = 0u, far_h = 0u;
 #pragma unroll
                         for (int h = 0; h < kF2RH; ++h) {
-                            const uint32_t d = (watch_pend >> (kF2RH * p + h)) & 1u ? ((scan[p] - 1u - ((uint32_t)lane + 64u * h)) & (kF2Ring - 1)) + 1u : 0u;
+                            const uint32_t d = (watch_pend >> (kF2RH * p + h)) & 1u ? ((scan[p] - 1u - slot_of(h)) & (kF2Ring - 1)) + 1u : 0u;
                             if (d > far) {
                                 far = d;
                                 far_h = (uint32_t)h;
@@ -1199,7 +1211,11 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
             for (int p = 0; p < kF2RPC; ++p) {
                 if (taken[p] != 0u) {
                     evald[p] += taken[p];
-                    st_release(s_rctrl + 8 * p + 2, evald[p]);
+                    if constexpr (kF2SH == 1) {
+                        st_release(s_rctrl + 8 * p + 2, evald[p]);
+                    } else {  // several consumers evaluate entries of this ring: the count of evaluated entries is a sum
+                        if (lane == 0) __hip_atomic_fetch_add(s_rctrl + 8 * p + 2, taken[p], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
             if (F.diag) t_busy += wall_clock64() - t_w0;

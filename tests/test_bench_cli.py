@@ -38,3 +38,51 @@ def test_kernel_source_sha_is_stable_and_matches_the_binding():
 
     a, b = bench.kernel_source_sha(), bench.kernel_source_sha()
     assert a == b and len(a) == 16
+
+
+def test_roofline_fraction_is_never_above_one():
+    """bench.py: where the algorithmic bytes of SURVEY 8(d) exceed the peak (cfg4: neighbouring 4K rays share lines, the model counts every
+    ray's loads) the reported `frac` is the measured HBM traffic's, the algorithmic figure is kept as `algorithmic_over_peak`, and without
+    counter traffic there is no fraction at all -- never a number above 1."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    f = bench.roofline_fractions(7200.0, 78.3e9, 15.9)          # the headline: algorithmic below the peak
+    assert f["frac"] == f["algorithmic_over_peak"] == 0.9 and 0.6 < f["frac_real_hbm"] < 0.63
+    f = bench.roofline_fractions(9365.0, 70.3e9, 22.19)         # cfg4_n1: algorithmic above the peak -> the real traffic's fraction
+    assert f["algorithmic_over_peak"] > 1.0 and f["frac"] == f["frac_real_hbm"] and 0.39 < f["frac"] < 0.41
+    f = bench.roofline_fractions(9365.0, None, 22.19)           # ... and no counters: no fraction
+    assert f["frac"] is None and f["frac_real_hbm"] is None and f["algorithmic_over_peak"] > 1.0
+
+
+def test_committed_counters_cover_all_poses_of_every_bench_workload():
+    """The numerators of the three rooflines: 16 poses each, the algorithmic-bytes field equal to the formula applied to the counters."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    for wl, rays in (("cfg2", 1920 * 1080), ("cfg3", 1920 * 1080), ("cfg4", 3840 * 2160)):
+        c = bench.load_counters(wl)
+        assert c is not None and sorted(c["poses"], key=int) == [str(i) for i in range(16)], wl
+        for p in c["poses"].values():
+            assert p["rays"] == rays and p["algorithmic_bytes"] == bench.alg_bytes(p), wl
+    # cfg3's rays are 1.8 x as long as cfg2's: what puts it at 0.54 x the headline's ray rate at the same efficiency per step (DESIGN.md 5.2)
+    steps = {wl: sum(p["steps"] for p in bench.load_counters(wl)["poses"].values()) / (16 * 1920 * 1080) for wl in ("cfg2", "cfg3")}
+    assert 1.7 < steps["cfg3"] / steps["cfg2"] < 2.0
+
+
+def test_committed_traffic_belongs_to_one_kernel_source_and_launch_shape(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import json
+
+    import bench
+
+    fake = tmp_path / "profiles"
+    fake.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda: "f" * 16)
+    (fake / "r09_traffic_cfg3.json").write_text(json.dumps({"kernel_source_sha": "0" * 16, "frames_per_launch": 16, "hbm_bytes_per_launch": 1}))
+    assert bench.committed_traffic("cfg3", 16) == (None, None)          # another source
+    monkeypatch.setattr(bench, "kernel_source_sha", lambda: "0" * 16)
+    assert bench.committed_traffic("cfg3", 16) == (1, os.path.join("profiles", "r09_traffic_cfg3.json"))
+    assert bench.committed_traffic("cfg3", 64) == (None, None)          # another launch shape
+    assert bench.committed_traffic("cfg4", 16) == (None, None)          # another workload
