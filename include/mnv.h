@@ -59,8 +59,10 @@ typedef struct mnv_tree_view {
     const int16_t *sample_counts; /* [capacity][N^3], may be NULL, n3tree.cpp:191-193 */
     float offset[3];
     float scale[3];
-    int32_t N;         /* spatial branching factor: N = 2 ONLY on the device (both kernels; MNV_E_UNSUPPORTED otherwise).  The reference's
-                          descent (rt_core.cuh:137-143) multiplies by tree.N, but its loader warns about N != 2 (n3tree.cpp:85-87) */
+    int32_t N;         /* spatial branching factor per axis.  N = 2 (every PlenOctree file) everywhere; mnv_render_voxels also takes
+                          3 <= N <= 16 (arrays [capacity][N^3]...) through a general walk, as the reference's descent multiplies by tree.N
+                          (rt_core.cuh:137-143; its loader warns about N != 2, n3tree.cpp:85-87).  The packed accel, the sample march and the
+                          refinement entry points answer MNV_E_UNSUPPORTED for N != 2 (generate_samples is N == 2 in the reference too) */
     int32_t data_dim;  /* halfs per voxel row; sigma is column data_dim-1 */
     int32_t format;    /* MNV_FORMAT_* */
     int32_t basis_dim; /* SH basis functions per channel, -1 if none */

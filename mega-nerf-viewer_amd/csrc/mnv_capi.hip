@@ -103,8 +103,7 @@ void fill_camera(CamBlock &C, const mnv_camera *cam) {
 
 int fill_tree_params(MarchParams &P, const mnv_tree_view *t) {
     if (!t) return set_error(MNV_E_INVALID, "tree view is null");
-    if (t->N != 2 && t->N > 0)
-        return set_error(MNV_E_UNSUPPORTED, "only N == 2 octrees are supported (the reference warns the same, n3tree.cpp:85-87)");
+    if (t->N > 16) return set_error(MNV_E_UNSUPPORTED, "branching factors above 16 per axis are not supported");
     if (t->N > 0 && (!t->data || !t->child)) return set_error(MNV_E_INVALID, "tree arrays are null");
     if (t->N > 0 && t->data_dim < 1) return set_error(MNV_E_INVALID, "data_dim < 1");
     if (t->N > 0 && t->format == MNV_FORMAT_SH && t->basis_dim >= 0 && 3 * t->basis_dim + 1 > t->data_dim)
@@ -121,6 +120,7 @@ int fill_tree_params(MarchParams &P, const mnv_tree_view *t) {
     P.basis_dim = t->basis_dim;
     P.format = t->format;
     P.capacity = t->capacity;
+    P.N = t->N;
     return MNV_OK;
 }
 

@@ -59,6 +59,7 @@ struct MarchParams : FrameParams {
     float *sample_track;
     int32_t *visited;
     int32_t track_visit;
+    int32_t N;  // branching factor per axis (TreeSpec::N): 2 for every PlenOctree; other values take the reference-layout kernel's general walk
 };
 
 // glibc 2.35 expf table: tab[i] = asuint64(2^(i/32)) - (i << 47)

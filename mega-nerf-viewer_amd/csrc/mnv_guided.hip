@@ -356,6 +356,8 @@ int mnv_get_samples_from_voxels(const mnv_tree_view *tree, const mnv_camera *cam
     if (rc) return rc;
     rc = fill_tree_params(S.M, tree);
     if (rc) return rc;
+    if (tree->N > 0 && tree->N != 2)
+        return set_error(MNV_E_UNSUPPORTED, "the sample march supports N == 2 trees (generate_samples is written for N == 2 in the reference as well, renderer_kernel.cu:88-168)");
     S.M.max_depth = opt->max_depth;
     S.M.max_sample_count = opt->max_sample_count;
     S.M.split_track = split_track;

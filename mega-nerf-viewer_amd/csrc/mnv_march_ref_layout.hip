@@ -88,14 +88,18 @@ __global__ __launch_bounds__(256) void ref_top_build_kernel(const int32_t *__res
 constexpr int kRefWaves = MNV_REF_WG_WAVES, kRefThreads = 64 * kRefWaves;
 constexpr int kRefBlockW = kRefWaves >= 2 ? 16 : 8, kRefBlockH = kRefWaves == 4 ? 16 : 8;
 
-template <int BASIS /* -1 RGBA, 0 DC-only with runtime stride, 1/4/9/16/25 */>
+// GEN: the walk for a branching factor N != 2 (rt_core.cuh:137-143 multiplies by tree.N): no lookup tables, N^3 voxels per chunk, cube size
+// N^depth by repeated multiplication (exact as long as the power is representable, like the oracle's).  N == 2 never takes it.
+template <int BASIS /* -1 RGBA, 0 DC-only with runtime stride, 1/4/9/16/25 */, bool GEN = false>
 __global__ __launch_bounds__(kRefThreads) void march_ref_layout_kernel(const MarchParams P, const uint2 *__restrict__ gtop3, const uint2 *__restrict__ gtab, const int G) {
     __shared__ uint64_t s_exp[32];
     constexpr int TL = 3, TG = 1 << TL;  // level and cells per axis of the table in LDS
     __shared__ uint2 s_top[TG * TG * TG];
     load_exp_table(s_exp);
     // level-3 cell -> the leaf of depth <= 3 that covers it, or the chunk holding its depth-4 voxels
-    const bool use_top = !P.track_visit && P.capacity < (1 << 25);
+    const bool use_top = !GEN && !P.track_visit && P.capacity < (1 << 25);
+    const int N = GEN ? P.N : 2, N3 = GEN ? P.N * P.N * P.N : 8;
+    const float fN = GEN ? (float)P.N : 2.f;
     if (use_top) {
         for (int i = threadIdx.x; i < TG * TG * TG; i += kRefThreads) {
             if (gtab) {
@@ -192,12 +196,12 @@ __global__ __launch_bounds__(kRefThreads) void march_ref_layout_kernel(const Mar
                 cidx = 0;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
-                    pos[i] *= 2.f;
+                    pos[i] *= fN;
                     const float f = floorf(pos[i]);
-                    cidx = cidx * 2 + (int)f;
+                    cidx = cidx * N + (int)f;
                     pos[i] -= f;
                 }
-                const int32_t skip = P.child[(int64_t)chunk * 8 + cidx];
+                const int32_t skip = P.child[(int64_t)chunk * N3 + cidx];
                 if (skip == 0) break;
                 ++depth;
                 chunk += skip;
@@ -210,9 +214,13 @@ __global__ __launch_bounds__(kRefThreads) void march_ref_layout_kernel(const Mar
                 tu = fminf(tu, fmaxf(t1, t2));
             }
             // powf(2, depth) is exactly 2^depth; dividing by a power of two is exact scaling
-            const float cube = __uint_as_float((uint32_t)(127 + depth) << 23);
+            float cube = __uint_as_float((uint32_t)(127 + depth) << 23);
+            if constexpr (GEN) {
+                cube = 1.f;
+                for (int i = 0; i < depth; ++i) cube *= fN;
+            }
             const float delta_t = tu / cube + P.step_size;
-            const uint16_t *row = P.data + ((int64_t)chunk * 8 + cidx) * P.data_dim;
+            const uint16_t *row = P.data + ((int64_t)chunk * N3 + cidx) * P.data_dim;
             const float sigma = half_bits_to_float(sigma_bits != kNoSigma ? (uint16_t)sigma_bits : row[P.data_dim - 1]);
 
             if (sigma > P.sigma_thresh) {
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(kRefThreads) void march_ref_layout_kernel(const Mar
                         max_weight = weight;
                     }
                     if (P.sample_counts) {
-                        const int16_t sc = P.sample_counts[(int64_t)chunk * 8 + cidx];
+                        const int16_t sc = P.sample_counts[(int64_t)chunk * N3 + cidx];
                         if (weight > max_sample_weight && sc < P.max_sample_count) {
                             sa_chunk = (float)chunk;
                             sa_child = (float)cidx;
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(kRefThreads) void march_ref_layout_kernel(const Mar
                     sp_prio = (float)depth;
                 }
                 if (P.sample_counts) {
-                    const int16_t sc = P.sample_counts[(int64_t)chunk * 8 + cidx];
+                    const int16_t sc = P.sample_counts[(int64_t)chunk * N3 + cidx];
                     if (max_sample_weight == -1.f && sc < P.max_sample_count) {
                         sa_chunk = (float)chunk;
                         sa_child = (float)cidx;
@@ -309,7 +317,8 @@ int launch_ref_layout(const MarchParams &P, hipStream_t stream) {
     int b = P.format == 1 ? P.basis_dim : -1;
     if (P.format == 1 && b < 0) b = -1;  // SH without digits behaves like the RGBA branch (:285)
     const int64_t min_rays = g_top_min_rays.load(std::memory_order_relaxed);
-    const bool big = min_rays >= 0 && (int64_t)P.tw * P.th >= min_rays;
+    const bool gen = P.N != 2;
+    const bool big = !gen && min_rays >= 0 && (int64_t)P.tw * P.th >= min_rays;
     uint2 *scratch = nullptr;
     int G = 7;
     // the per-launch lookup table (see the head of this file): stream-ordered scratch, released behind the march
@@ -324,7 +333,11 @@ int launch_ref_layout(const MarchParams &P, hipStream_t stream) {
         }
     }
     const uint2 *gtop3 = scratch, *gtab = scratch ? scratch + 512 : nullptr;
-#define MNV_LAUNCH(B) hipLaunchKernelGGL(march_ref_layout_kernel<B>, grid, block, 0, stream, P, gtop3, gtab, G)
+#define MNV_LAUNCH(B)                                                                                                   \
+    do {                                                                                                                \
+        if (gen) hipLaunchKernelGGL((march_ref_layout_kernel<B, true>), grid, block, 0, stream, P, gtop3, gtab, G);     \
+        else hipLaunchKernelGGL((march_ref_layout_kernel<B, false>), grid, block, 0, stream, P, gtop3, gtab, G);        \
+    } while (0)
     switch (b) {
         case -1: MNV_LAUNCH(-1); break;
         case 4: MNV_LAUNCH(4); break;

@@ -253,7 +253,7 @@ def test_invalid_arguments_report_errors(mnv, torch_gpu):
     cam = mnv.Camera(16, 16)
     opt = mnv.RenderOptions.defaults()
     v = mnv.TreeView()
-    v.N = 3
+    v.N = 17  # branching factors up to 16 take the general walk (test_general_branching_factor_bit_exact); beyond: refused
     with pytest.raises(mnv.MnvError) as e:
         mnv.render_voxels(v, cam, opt, rgba=None)
     assert e.value.code == mnv.MNV_E_UNSUPPORTED
@@ -760,3 +760,67 @@ def test_tree_cache_of_the_stateless_entry_point(mnv, orc, torch_gpu):
         assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(empty))
     finally:
         mnv.set_tree_cache(False)
+
+
+def _n_ary_tree(n, depth, data_dim, refine_prob, seed):
+    """A random N^3-ary tree in the reference's array layout (n3tree.cpp:92-107,183-188): child[chunk][N^3] relative chunk offsets
+    (0 = leaf), data[chunk][N^3][data_dim] binary16 with sigma in the last column.  Breadth-first, like svox writes them."""
+    rng = np.random.default_rng(seed)
+    n3 = n ** 3
+    children = [np.zeros(n3, np.int32)]
+    level = [0]
+    for d in range(1, depth):
+        nxt = []
+        for c in level:
+            for k in range(n3):
+                if rng.random() < refine_prob:
+                    children.append(np.zeros(n3, np.int32))
+                    children[c][k] = len(children) - 1 - c
+                    nxt.append(len(children) - 1)
+        level = nxt
+    child = np.stack(children)
+    cap = child.shape[0]
+    data = (rng.standard_normal((cap, n3, data_dim)) * 1.2).astype(np.float16)
+    sigma = rng.uniform(0.0, 40.0, (cap, n3)) * (rng.random((cap, n3)) < 0.45)
+    data[..., -1] = sigma.astype(np.float16)
+    return np.ascontiguousarray(child), np.ascontiguousarray(data.view(np.uint16))
+
+
+@pytest.mark.parametrize("n,depth,basis,fmt", [(3, 4, 4, 1), (3, 3, -1, 0), (4, 3, 9, 1), (5, 2, 1, 1)])
+def test_general_branching_factor_bit_exact(mnv, orc, torch_gpu, n, depth, basis, fmt):
+    """rt_core.cuh:137-143 descends with `tree.N`, not 2: mnv_render_voxels takes N^3-ary trees through the general walk of the
+    reference-layout kernel (no lookup tables; cube size N^depth by repeated multiplication, as the oracle) -- pixels, RGBA8 and the
+    tracker rows bit for bit against the oracle.  (PlenOctree files are N = 2; the reference's loader warns about anything else,
+    n3tree.cpp:85-87; the packed accel, the sample march and the refinement kernels stay N == 2.)"""
+    torch = torch_gpu
+    dd = 3 * basis + 1 if fmt == 1 else 4
+    child, data = _n_ary_tree(n, depth, dd, 0.35 if n < 5 else 0.5, seed=n * 10 + depth)
+    v = mnv.TreeView()
+    v.N, v.data_dim, v.format, v.basis_dim, v.capacity = n, dd, fmt, basis, child.shape[0]
+    for i in range(3):
+        v.offset[i], v.scale[i] = 0.5, 0.5
+    v.data, v.child = data.ctypes.data, child.ctypes.data
+    cam = mnv.Camera(160, 120, 260.0).set_pose((-2.2, 1.3, 1.7), (-0.72, 0.42, 0.55))
+    opt = mnv.RenderOptions.cli_defaults()
+    opt.basis_minmax[0], opt.basis_minmax[1] = 0, max(basis - 1, 0)
+    opt.max_depth, opt.max_sample_count = depth, 6
+    sc = np.random.default_rng(3).integers(0, 12, size=(child.shape[0], n ** 3)).astype(np.int16)
+    ref = orc.render(orc.tree_from_view(v, sample_counts=sc), cam.c, opt, want_rgba8=True, want_trackers=True)
+    assert ref["counters"].rays_hit > 0.3 * 160 * 120 and ref["counters"].max_steps > 4
+    d_data, d_child, d_sc = torch.from_numpy(data.view(np.int16)).cuda(), torch.from_numpy(child).cuda(), torch.from_numpy(sc).cuda()
+    dv = type(v).from_buffer_copy(v)
+    dv.data, dv.child, dv.sample_counts = d_data.data_ptr(), d_child.data_ptr(), d_sc.data_ptr()
+    out = torch.full((120, 160, 4), float("nan"), dtype=torch.float32, device="cuda")
+    out8 = torch.zeros((120, 160, 4), dtype=torch.uint8, device="cuda")
+    split = torch.full((120, 160, 3), -1.0, dtype=torch.float32, device="cuda")
+    sample = torch.full((120, 160, 3), -1.0, dtype=torch.float32, device="cuda")
+    mnv.render_voxels(dv, cam, opt, rgba=out, rgba8=out8, split_track=split, sample_track=sample)
+    torch.cuda.synchronize()
+    assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref["rgba"]))
+    assert np.array_equal(out8.cpu().numpy(), ref["rgba8"])
+    assert np.array_equal(split.cpu().numpy(), ref["split"]) and np.array_equal(sample.cpu().numpy(), ref["sample"])
+    assert (ref["split"][..., 1] >= 0).any()
+    # the paths that stay N == 2 say so
+    with pytest.raises(mnv.MnvError) as e:
+        mnv.accel_create(dv)
+    assert e.value.code == mnv.MNV_E_UNSUPPORTED
