@@ -475,8 +475,6 @@ void VolumeRenderer::render() {
     if (refine && options.use_splitting) {
         split = I.split_tracker.get<float>(n_px * 3);
         sample = I.sample_tracker.get<float>(n_px * 3);
-        I.fill_f32(split, n_px * 3, -1.f);
-        I.fill_f32(sample, n_px * 3, -1.f);
     }
     // splits and resampled leaves are patched into the packed accel as they happen (mnv_accel_refresh); a prune renumbers
     // the chunks, after which the march reads the reference-layout arrays until the accel has been rebuilt -- once the
@@ -493,6 +491,13 @@ void VolumeRenderer::render() {
                       (!track_visit || tree.device.parent) && !options.render_depth && I.mlp_desc.hidden_width == 64 && I.fused_inputs_ok &&
                       (tree.data_format.format != DataFormat::SH || tree.data_format.basis_dim == 1 || tree.data_format.basis_dim == 4 ||
                        tree.data_format.basis_dim == 9 || tree.data_format.basis_dim == 16);
+    if (split && !fuse) {
+        // cuda_renderer.cpp:97-98.  (The fused kernel writes all three words of both rows for every pixel of the frame it renders -- the
+        // rows of a ray without a candidate are (max + 1, -1, -1), what the fill and the reference's kernel leave -- so the 2 x 25 MB fill
+        // is skipped there: 50 us of a 3 ms configs[4] frame.)
+        I.fill_f32(split, n_px * 3, -1.f);
+        I.fill_f32(sample, n_px * 3, -1.f);
+    }
     if (fuse) {
         unsigned long long *counter = I.fused_counter.get<unsigned long long>(1);
         hip_check(hipMemsetAsync(counter, 0, sizeof(unsigned long long), I.stream), "clear sample counter");
