@@ -1,0 +1,27 @@
+"""Time of mnv_select_split_candidates / _sample_candidates on a REAL 1920x1080 tracker frame of the cfg2 tree (the march's own rows: neighbouring
+pixels name the same voxels, shallow leaves collect many votes).  MNV_VOTE_SORT=1 selects the sorting path."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+import numpy as np, torch, cases
+import mega_nerf_viewer_amd as mnv
+W, H = 1920, 1080
+tree = cases.make_tree(mnv, cases.CFG2_TREE); v = tree.host_view(); tree.move_to_device(need_sample_counts=True)
+opt = mnv.RenderOptions.cli_defaults(); opt.max_depth, opt.max_sample_count = 12, 64
+cam = cases.cfg2_camera(mnv, 3, W, H, 1600.0)
+out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+split = torch.full((H, W, 3), -1.0, dtype=torch.float32, device="cuda"); sample = torch.full((H, W, 3), -1.0, dtype=torch.float32, device="cuda")
+sc = torch.full((v.capacity, 8), 8, dtype=torch.int16, device="cuda")
+mnv.render_voxels_accel_track(tree.accel, cam, opt, rgba=out, split_track=split, sample_track=sample, sample_counts=sc)
+torch.cuda.synchronize()
+k = 4096
+nodes = torch.empty((k, 2), dtype=torch.int32, device="cuda")
+t = split.view(-1, 3)
+valid = int((t[:, 1] >= 0).sum()); uniq, cnt = torch.unique(t[t[:, 1] >= 0], dim=0, return_counts=True)
+print("rows", t.shape[0], "valid", valid, "distinct", uniq.shape[0], "largest count", int(cnt.max()), "counts >= 2:", int((cnt >= 2).sum()))
+for name, fn, tr in (("split", mnv.select_split_candidates, split.view(-1, 3)), ("sample", mnv.select_sample_candidates, sample.view(-1, 3))):
+    for _ in range(3): r = fn(tr, k, nodes)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): r = fn(tr, k, nodes)
+    torch.cuda.synchronize()
+    print(name, "path", "sort" if os.environ.get("MNV_VOTE_SORT") else "count", round((time.perf_counter() - t0) / 20 * 1e3, 4), "ms per call", r, nodes[:3].tolist())
