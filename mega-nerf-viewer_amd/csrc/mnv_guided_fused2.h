@@ -60,6 +60,13 @@ namespace mnv {
 #ifndef MNV_F2_WAVES
 #define MNV_F2_WAVES 4  // wavefronts per SIMD the kernel is compiled for: 4 (128 VGPRs), 5 (96), 6 (80)
 #endif
+#ifndef MNV_F2_CONS_PRIO
+#define MNV_F2_CONS_PRIO 0  // s_setprio of the network wavefronts (2 until round 4: their windows 6.6 instead of 8.6 us, but the march -- the
+                            // bound of the 8 + 8 shape -- 3 % slower: 1.223 against 1.194 ms per frame) ...
+#endif
+#ifndef MNV_F2_PROD_PRIO
+#define MNV_F2_PROD_PRIO 0  // ... and of the marching ones
+#endif
 #ifndef MNV_F2_SHARE
 #define MNV_F2_SHARE 1  // consumers that serve one group of rings together (1, 2 or 4): slot s of a ring of the group belongs to the
 #endif                  // consumer s % SHARE of the group -- a tile's burst of samples is drained by SHARE consumers instead of one
@@ -175,6 +182,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
 
     if (wave < kF2NP) {
         // =================================================================================== producer: march, push, composite
+        if (MNV_F2_PROD_PRIO) __builtin_amdgcn_s_setprio(MNV_F2_PROD_PRIO);
         float4 *r_data = reinterpret_cast<float4 *>(s_mem + Lo.rings + wave * kF2RingWords);
         uint32_t *r_meta = reinterpret_cast<uint32_t *>(r_data + kF2Ring), *r_next = r_meta + kF2Ring;
         uint32_t *c_tail = s_ctrl + 8 * wave, *c_flush = c_tail + 1, *c_ready = c_tail + 2, *c_exit = c_tail + 3, *c_stall = c_tail + 4;
@@ -583,7 +591,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
         }
     } else {
         // =================================================================================== consumer: the network
-        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(MNV_F2_CONS_PRIO);
         // Lane-derived constants (tile / fragment / bias addresses) are loop invariants the compiler hoists out of the window loop -- into
         // registers the 64 accumulators leave no room for, i.e. into scratch, to be reloaded (a ~0.3 us round trip each, eight in a row in
         // the evaluation alone) in every window.  An opaque copy of the lane number per window makes them cheap values again.

@@ -42,7 +42,8 @@ struct MlpLaunch {
     int32_t result_stride;
     const int32_t *order;       // rows sorted by cluster
     const int32_t *seg_start;   // [n_clusters + 1]: first position of each cluster in `order`
-    const int32_t *tile_start;  // [n_clusters + 1]: first 256-row tile of each cluster; [n_clusters] = number of tiles
+    const int32_t *tile_start;  // [n_clusters + 1]: first tile (workgroup) of each cluster; [n_clusters] = number of tiles
+    int32_t rows_per_block;     // rows of one cluster a workgroup takes (a multiple of kRowsPerPass, at most kRowsPerBlock)
 };
 
 // ---------------------------------------------------------------- counting sort by cluster
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void mlp_histogram(const int16_t *__restrict__
 
 // one block: exclusive scans of the counts -> segment starts and first tile of every cluster
 __global__ void mlp_plan(const int32_t *__restrict__ counts, int32_t n_clusters, int32_t *__restrict__ seg_start,
-                         int32_t *__restrict__ cursor, int32_t *__restrict__ tile_start) {
+                         int32_t *__restrict__ cursor, int32_t *__restrict__ tile_start, int32_t rows_per_block) {
     __shared__ int32_t s_start[kMaxClusters + 1], s_tile[kMaxClusters + 1];
     if (threadIdx.x == 0) {
         int32_t a = 0, t = 0;
@@ -102,7 +103,7 @@ __global__ void mlp_plan(const int32_t *__restrict__ counts, int32_t n_clusters,
             s_start[c] = a;
             s_tile[c] = t;
             a += counts[c];
-            t += (counts[c] + kRowsPerBlock - 1) / kRowsPerBlock;
+            t += (counts[c] + rows_per_block - 1) / rows_per_block;
         }
         s_start[n_clusters] = a;
         s_tile[n_clusters] = t;
@@ -162,8 +163,8 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_forward_kernel(const MlpLau
         else hi = mid;
     }
     const int cluster = lo;
-    const int block_first = L.seg_start[cluster] + ((int)blockIdx.x - L.tile_start[cluster]) * kRowsPerBlock;
-    const int block_rows = min(kRowsPerBlock, L.seg_start[cluster + 1] - block_first);
+    const int block_first = L.seg_start[cluster] + ((int)blockIdx.x - L.tile_start[cluster]) * L.rows_per_block;
+    const int block_rows = min(L.rows_per_block, L.seg_start[cluster + 1] - block_first);
 
     // weights and biases of this cluster -> LDS
     const half8 *s_frag = reinterpret_cast<const half8 *>(lds);
@@ -517,7 +518,14 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
         return set_error(MNV_E_INVALID, "invalid sample / result shapes");
     if (n == 0) return MNV_OK;
     hipStream_t stream = (hipStream_t)hip_stream;
-    const int64_t max_tiles = n / kRowsPerBlock + S.n_clusters + 1;
+    // A workgroup stages its cluster's weights once and runs up to kPasses passes of 256 rows under them.  A small batch (the 262 k rows of a
+    // refinement step's 4096 splits: 134 workgroups of 2048 rows on 256 CUs, 51 us) takes fewer passes per workgroup, so that the device
+    // holds about four workgroups per CU.
+    const int64_t cus = m->num_cus > 0 ? m->num_cus : 256;
+    int passes = kPasses;
+    while (passes > 1 && n / ((int64_t)kRowsPerPass * passes) < cus * 4) passes >>= 1;
+    const int32_t rows_per_block = kRowsPerPass * passes;
+    const int64_t max_tiles = n / rows_per_block + S.n_clusters + 1;
     const size_t table = (size_t)(kMaxClusters + 64) * 4;
     const size_t o_counts = 0, o_start = o_counts + table, o_cursor = o_start + table, o_tiles = o_cursor + table, o_order = o_tiles + table;
     const size_t need = o_order + (size_t)n * 4;
@@ -539,7 +547,7 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
     if ((rc = check_hip(hipMemsetAsync(counts, 0, kMaxClusters * 4, stream), "memset"))) return rc;
     const unsigned nb = (unsigned)((n + kSortRows - 1) / kSortRows);
     hipLaunchKernelGGL(mlp_histogram, dim3(nb), dim3(256), 0, stream, cluster_indices, n, S.n_clusters, counts, results, result_stride, S.out_dim);
-    hipLaunchKernelGGL(mlp_plan, dim3(1), dim3(256), 0, stream, counts, S.n_clusters, seg_start, cursor, tile_start);
+    hipLaunchKernelGGL(mlp_plan, dim3(1), dim3(256), 0, stream, counts, S.n_clusters, seg_start, cursor, tile_start, rows_per_block);
     hipLaunchKernelGGL(mlp_scatter, dim3(nb), dim3(256), 0, stream, cluster_indices, n, S.n_clusters, cursor, order);
 
     MlpLaunch L;
@@ -554,6 +562,7 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
     L.order = order;
     L.seg_start = seg_start;
     L.tile_start = tile_start;
+    L.rows_per_block = rows_per_block;
     const size_t lds_bytes = (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4 + 4 * 16 * 64 * 4;  // + the encode tiles: 256 samples x 64 bytes
     if (S.hidden_width == 64) {
         auto kern = mlp_forward_kernel<4, 4, 4>;

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <vector>
 
+#include <rocprim/block/block_sort.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_run_length_encode.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -75,8 +76,8 @@ constexpr int kVoxBits = 27;
 constexpr uint64_t kNoCandidateWide = 1ull << 51;
 constexpr int kKeyBitsWide = 52;
 
-template <bool WIDE>
-__global__ void pack_tracker_keys(const float *__restrict__ track, int64_t n_rows, uint64_t *__restrict__ keys, int prio_bits, uint32_t *__restrict__ overflow) {
+template <bool WIDE, typename KeyT = uint64_t>
+__global__ void pack_tracker_keys(const float *__restrict__ track, int64_t n_rows, KeyT *__restrict__ keys, int prio_bits, uint32_t *__restrict__ overflow) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rows) return;
     const float prio = track[i * 3 + 0], chunk = track[i * 3 + 1], child = track[i * 3 + 2];
@@ -92,7 +93,7 @@ __global__ void pack_tracker_keys(const float *__restrict__ track, int64_t n_row
             key = ((uint64_t)p << kVoxBits) | (uint64_t)vox;
         }
     }
-    keys[i] = key;
+    keys[i] = (KeyT)key;
 }
 
 // info[0] = runs that are real candidates, info[1] = those with count >= 2, info[3] = the largest count among the candidates
@@ -217,6 +218,326 @@ int select_candidates_as(const float *track, int64_t n_rows, int32_t max_out, bo
     return MNV_OK;
 }
 
+// ---- the compact-key path without a host round trip in the middle and without a sort of the counts
+// What the caller keeps of the vote is its first max_out rows (split_batch_size: 4096) and the number of voted voxels; sorting all
+// ~2 x 10^5 runs by count (rocPRIM picks a merge sort at that size: a block sort and 18 merge launches, 155 us of a configs[4]
+// frame's trace) to keep 4096 of them is a selection problem: a histogram of the counts gives the count T of the last row that fits,
+// the runs above T (fewer than max_out) are sorted by (count descending, key) in ONE workgroup, and of the runs AT T the first ones in
+// key order fill the rest -- an order-preserving compaction in which every wavefront owns a contiguous range of runs.  Every kernel takes
+// the number of runs from device memory, so the host waits once, at the end.  Rows in the order of cuda_renderer.cpp:213-217 as before.
+constexpr int kVoteBins = 2048;   // histogram of min(count, kVoteBins - 1); a threshold in the last bin cannot be resolved -> full sort
+constexpr int kVoteTop = 8192;    // the single-workgroup sort's capacity == the largest max_out this path serves (render_options.hpp:49: 4192)
+constexpr int kVoteGrid = 256;    // workgroups of 256 threads; wavefront w of the grid owns runs [w * per, (w + 1) * per)
+constexpr int kVoteWaves = kVoteGrid * 4;
+static_assert(kVoteGrid == 256, "vote_totals: one partial per thread of a 256-thread workgroup");
+enum VoteWord { kValid = 0, kVoted = 1, kRuns = 2, kMost = 3, kOverflow = 4, kThresh = 5, kAbove = 6, kTies = 7, kFallback = 8, kWrite = 9, kCursor = 10, kVoteWords = 16 };
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void vote_stats(const KeyT *__restrict__ unique_keys, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ info,
+                                                  uint32_t *__restrict__ hist, uint32_t *__restrict__ partial, KeyT none, int with_hist) {
+    __shared__ uint32_t lh[kVoteBins];
+    __shared__ uint32_t s_part[3][4];
+    if (with_hist)
+        for (int b = threadIdx.x; b < kVoteBins; b += 256) lh[b] = 0;
+    __syncthreads();
+    const uint32_t n = info[kRuns];
+    uint32_t valid = 0, voted = 0, most = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (unique_keys[i] != none) {
+            const uint32_t c = counts[i];
+            ++valid;
+            most = c > most ? c : most;
+            if (c >= 2u) {
+                ++voted;
+                if (with_hist) atomicAdd(&lh[c < (uint32_t)kVoteBins - 1 ? c : (uint32_t)kVoteBins - 1], 1u);
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        valid += __shfl_down(valid, off);
+        voted += __shfl_down(voted, off);
+        const uint32_t other = __shfl_down(most, off);
+        most = other > most ? other : most;
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_part[0][wave] = valid;
+        s_part[1][wave] = voted;
+        s_part[2][wave] = most;
+    }
+    __syncthreads();
+    if (with_hist)
+        for (int b = threadIdx.x; b < kVoteBins; b += 256)
+            if (lh[b]) atomicAdd(&hist[b], lh[b]);
+    if (threadIdx.x == 0) {  // per-workgroup partial sums: 768 atomics on three addresses are served one after the other (10 us)
+        uint32_t v = 0, w = 0, m = 0;
+        for (int k = 0; k < 4; ++k) {
+            v += s_part[0][k];
+            w += s_part[1][k];
+            m = s_part[2][k] > m ? s_part[2][k] : m;
+        }
+        partial[blockIdx.x] = v;
+        partial[kVoteGrid + blockIdx.x] = w;
+        partial[2 * kVoteGrid + blockIdx.x] = m;
+    }
+}
+
+// totals of vote_stats' partials, by a workgroup of 256 threads (kVoteGrid == 256); `record`: this workgroup writes them to info
+__device__ inline void vote_totals(const uint32_t *__restrict__ partial, uint32_t *__restrict__ info, bool record, uint32_t *valid, uint32_t *voted) {
+    __shared__ uint32_t s_tot[3][4];
+    const int t = threadIdx.x;
+    uint32_t v = partial[t], w = partial[kVoteGrid + t], m = partial[2 * kVoteGrid + t];
+    for (int off = 32; off > 0; off >>= 1) {
+        v += __shfl_xor(v, off);
+        w += __shfl_xor(w, off);
+        const uint32_t other = __shfl_xor(m, off);
+        m = other > m ? other : m;
+    }
+    if ((t & 63) == 0) {
+        s_tot[0][t >> 6] = v;
+        s_tot[1][t >> 6] = w;
+        s_tot[2][t >> 6] = m;
+    }
+    __syncthreads();
+    v = s_tot[0][0] + s_tot[0][1] + s_tot[0][2] + s_tot[0][3];
+    w = s_tot[1][0] + s_tot[1][1] + s_tot[1][2] + s_tot[1][3];
+    m = max(max(s_tot[2][0], s_tot[2][1]), max(s_tot[2][2], s_tot[2][3]));
+    if (record && t == 0) {
+        info[kValid] = v;
+        info[kVoted] = w;
+        info[kMost] = m;
+    }
+    *valid = v;
+    *voted = w;
+}
+
+// the range of runs wavefront w of the grid owns (a multiple of 64 long, so a wavefront's loads stay aligned)
+__device__ inline void vote_range(uint32_t n, int w, uint32_t *begin, uint32_t *end) {
+    const uint32_t per = ((n + kVoteWaves - 1) / kVoteWaves + 63u) & ~63u;
+    const uint64_t b = (uint64_t)w * per, e = b + per;
+    *begin = b < n ? (uint32_t)b : n;
+    *end = e < n ? (uint32_t)e : n;
+}
+
+// threshold from the histogram (every workgroup computes the same one; workgroup 0 records it), then: runs above it appended to
+// `above` as (~count, key) words, runs at it counted per wavefront
+__global__ __launch_bounds__(256) void vote_gather(const uint32_t *__restrict__ unique_keys, const uint32_t *__restrict__ counts, uint32_t *__restrict__ info,
+                                                   const uint32_t *__restrict__ hist, const uint32_t *__restrict__ partial, uint32_t *__restrict__ tie_count,
+                                                   uint64_t *__restrict__ above, uint32_t none, uint32_t max_out) {
+    __shared__ uint32_t s_sum[2][256];
+    __shared__ uint32_t s_t[3];
+    const int t = threadIdx.x;
+    uint32_t valid, voted;
+    vote_totals(partial, info, blockIdx.x == 0, &valid, &voted);
+    if (max_out == 0) return;  // (a count-only call: one workgroup, for the totals)
+    uint32_t mine[8], part = 0;
+    for (int j = 0; j < 8; ++j) {
+        mine[j] = hist[8 * t + j];
+        part += mine[j];
+    }
+    s_sum[0][t] = part;
+    __syncthreads();
+    int cur = 0;
+    for (int step = 1; step < 256; step <<= 1) {  // inclusive suffix sums: s_sum[cur][t] = bins of chunks t .. 255
+        s_sum[cur ^ 1][t] = s_sum[cur][t] + (t + step < 256 ? s_sum[cur][t + step] : 0u);
+        cur ^= 1;
+        __syncthreads();
+    }
+    const uint32_t incl = s_sum[cur][t], excl = incl - part;
+    if (voted <= max_out) {
+        if (t == 0) {
+            s_t[0] = 1u;  // every voted run is "above"
+            s_t[1] = voted;
+            s_t[2] = 0u;
+        }
+    } else if (excl < max_out && incl >= max_out) {  // the max_out-th largest count lies in this thread's bins (exactly one thread)
+        uint32_t acc = excl;
+        for (int j = 7; j >= 0; --j) {
+            if (acc + mine[j] >= max_out) {
+                s_t[0] = (uint32_t)(8 * t + j);
+                s_t[1] = acc;
+                s_t[2] = max_out - acc;
+                break;
+            }
+            acc += mine[j];
+        }
+    }
+    __syncthreads();
+    const uint32_t T = s_t[0];
+    if (blockIdx.x == 0 && t == 0) {
+        info[kThresh] = T;
+        info[kAbove] = s_t[1];
+        info[kTies] = s_t[2];
+        info[kFallback] = T >= (uint32_t)kVoteBins - 1 ? 1u : 0u;
+        info[kWrite] = voted < max_out ? voted : max_out;
+    }
+    if (T >= (uint32_t)kVoteBins - 1) return;
+    const int lane = t & 63, w = blockIdx.x * 4 + (t >> 6);
+    uint32_t begin, end, ties = 0;
+    vote_range(info[kRuns], w, &begin, &end);
+    for (uint32_t i0 = begin; i0 < end; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        uint32_t key = none, c = 0;
+        if (i < end) {
+            key = unique_keys[i];
+            c = counts[i];
+        }
+        const bool ok = key != none, is_above = ok && c > T, is_tie = ok && c == T && T >= 2u;
+        const uint64_t m = __ballot(is_above);
+        if (m) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&info[kCursor], (uint32_t)__popcll(m));
+            base = __shfl(base, 0);
+            if (is_above) above[base + __popcll(m & ((1ull << lane) - 1))] = ((uint64_t)(0xffffffffu - c) << 32) | key;
+        }
+        ties += (uint32_t)__popcll(__ballot(is_tie));
+    }
+    if (lane == 0) tie_count[w] = ties;
+}
+
+__device__ inline void vote_write_node(int32_t *__restrict__ nodes, uint32_t at, uint32_t key) {
+    const uint32_t vox = key & ((1u << kVoxBits) - 1u);
+    nodes[2 * at + 0] = (int32_t)(vox >> 3);
+    nodes[2 * at + 1] = (int32_t)(vox & 7u);
+}
+
+// the runs above the threshold, sorted by (count descending, key ascending): rows 0 .. above-1 of the result
+template <int PER>
+using VoteSort = rocprim::block_sort<uint64_t, 1024, PER, rocprim::empty_type, rocprim::block_sort_algorithm::stable_merge_sort>;
+
+template <int PER>  // 1024 * PER rows at most (PER 4: 32 KB of LDS; PER 8: 64 KB and a bit, hence not a static array)
+__global__ __launch_bounds__(1024) void vote_sort_above(const uint64_t *__restrict__ above, const uint32_t *__restrict__ info, int32_t *__restrict__ nodes) {
+    extern __shared__ __align__(16) unsigned char vote_lds[];
+    typename VoteSort<PER>::storage_type &storage = *reinterpret_cast<typename VoteSort<PER>::storage_type *>(vote_lds);
+    if (info[kFallback]) return;
+    const uint32_t n = info[kAbove];
+    uint64_t v[PER];
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t at = threadIdx.x * PER + j;
+        v[j] = at < n ? above[at] : ~0ull;
+    }
+    VoteSort<PER>().sort(v, storage);
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t at = threadIdx.x * PER + j;
+        if (at < n) vote_write_node(nodes, at, (uint32_t)v[j]);
+    }
+}
+
+template <int PER>
+int launch_vote_sort(const uint64_t *above, const uint32_t *info, int32_t *nodes, hipStream_t stream) {
+    const int bytes = (int)sizeof(typename VoteSort<PER>::storage_type);
+    const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&vote_sort_above<PER>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes), "lds attr");
+    if (rc) return rc;
+    hipLaunchKernelGGL(vote_sort_above<PER>, dim3(1), dim3(1024), bytes, stream, above, info, nodes);
+    return MNV_OK;
+}
+
+// the first info[kTies] runs AT the threshold, in key order: rows above .. above+ties-1
+__global__ __launch_bounds__(256) void vote_ties(const uint32_t *__restrict__ unique_keys, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ info,
+                                                 const uint32_t *__restrict__ tie_count, int32_t *__restrict__ nodes, uint32_t none) {
+    const uint32_t want = info[kTies], T = info[kThresh], first = info[kAbove];
+    if (want == 0 || info[kFallback]) return;
+    const int lane = threadIdx.x & 63, w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint32_t base = 0;
+    for (int u = lane; u < w; u += 64) base += tie_count[u];
+    for (int off = 32; off > 0; off >>= 1) base += __shfl_xor(base, off);
+    uint32_t begin, end;
+    vote_range(info[kRuns], w, &begin, &end);
+    for (uint32_t i0 = begin; i0 < end && base < want; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        uint32_t key = none, c = 0;
+        if (i < end) {
+            key = unique_keys[i];
+            c = counts[i];
+        }
+        const bool is_tie = key != none && c == T;
+        const uint64_t m = __ballot(is_tie);
+        const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (is_tie && at < want) vote_write_node(nodes, first + at, key);
+        base += (uint32_t)__popcll(m);
+    }
+}
+
+// no vote (the sample tracker): the first valid runs in key order
+template <typename KeyT>
+__global__ __launch_bounds__(256) void vote_head(const KeyT *__restrict__ unique_keys, const uint32_t *__restrict__ partial, uint32_t *__restrict__ info,
+                                                 int32_t *__restrict__ nodes, uint32_t max_out) {
+    uint32_t valid, voted;
+    vote_totals(partial, info, blockIdx.x == 0, &valid, &voted);
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x, n = valid < max_out ? valid : max_out;
+    if (i == 0) info[kWrite] = n;
+    if (i < n) vote_write_node(nodes, i, (uint32_t)(unique_keys[i] & ((1u << kVoxBits) - 1u)));
+}
+
+template <typename KeyT>
+int select_candidates_compact(const float *track, int64_t n_rows, int32_t max_out, bool need_votes, int32_t *nodes_out, int32_t *n_out, int32_t *n_candidates,
+                              bool *overflow, bool *full_sort, hipStream_t stream) {
+    const size_t n = (size_t)n_rows;
+    const int prio_bits = need_votes ? 5 : 9, key_bits = kVoxBits + prio_bits;
+    const KeyT none = (KeyT)(((1ull << prio_bits) - 1) << kVoxBits);
+
+    size_t tmp_sort = 0, tmp_rle = 0;
+    KeyT *nk = nullptr;
+    uint32_t *nc = nullptr;
+    (void)rocprim::radix_sort_keys(nullptr, tmp_sort, nk, nk, n, 0, key_bits, stream);
+    (void)rocprim::run_length_encode(nullptr, tmp_rle, nk, (unsigned int)n, nk, nc, nc, stream);
+    const size_t tmp_bytes = std::max(tmp_sort, tmp_rle);
+
+    Carver c;
+    const size_t o_keys = c.take(n * sizeof(KeyT)), o_sorted = c.take(n * sizeof(KeyT)), o_unique = c.take(n * sizeof(KeyT)), o_counts = c.take(n * 4);
+    const size_t state_bytes = (size_t)(kVoteWords + kVoteBins + kVoteWaves + 3 * kVoteGrid) * 4;
+    const size_t o_state = c.take(state_bytes), o_above = c.take((size_t)kVoteTop * 8), o_tmp = c.take(tmp_bytes);
+    std::lock_guard<std::mutex> lock(g_ws_mutex);
+    uint8_t *ws = nullptr;
+    int rc = ws_reserve(c.off, &ws);
+    if (rc) return rc;
+    KeyT *keys = reinterpret_cast<KeyT *>(ws + o_keys), *sorted = reinterpret_cast<KeyT *>(ws + o_sorted), *unique_keys = reinterpret_cast<KeyT *>(ws + o_unique);
+    uint32_t *counts = reinterpret_cast<uint32_t *>(ws + o_counts);
+    uint32_t *info = reinterpret_cast<uint32_t *>(ws + o_state), *hist = info + kVoteWords, *tie_count = hist + kVoteBins, *partial = tie_count + kVoteWaves;
+    uint64_t *above = reinterpret_cast<uint64_t *>(ws + o_above);
+    void *tmp = ws + o_tmp;
+
+    if ((rc = check_hip(hipMemsetAsync(info, 0, state_bytes, stream), "memset"))) return rc;
+    hipLaunchKernelGGL((pack_tracker_keys<false, KeyT>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, track, n_rows, keys, prio_bits, info + kOverflow);
+    size_t t = tmp_bytes;
+    if ((rc = check_hip(rocprim::radix_sort_keys(tmp, t, keys, sorted, n, 0, key_bits, stream), "radix_sort_keys"))) return rc;
+    t = tmp_bytes;
+    if ((rc = check_hip(rocprim::run_length_encode(tmp, t, sorted, (unsigned int)n, unique_keys, counts, info + kRuns, stream), "run_length_encode")))
+        return rc;
+    const bool select = need_votes && max_out > 0;
+    hipLaunchKernelGGL(vote_stats<KeyT>, dim3(kVoteGrid), dim3(256), 0, stream, unique_keys, counts, info, hist, partial, none, select ? 1 : 0);
+    if constexpr (sizeof(KeyT) == 4) {
+        if (need_votes)
+            hipLaunchKernelGGL(vote_gather, dim3(select ? kVoteGrid : 1), dim3(256), 0, stream, unique_keys, counts, info, hist, partial, tie_count, above, none,
+                               (uint32_t)max_out);
+        if (select) {
+            // fewer rows above the threshold than max_out: the smaller sort when the batch allows it
+            if ((rc = max_out <= 1024 ? launch_vote_sort<1>(above, info, nodes_out, stream)
+                      : max_out <= 4096 ? launch_vote_sort<4>(above, info, nodes_out, stream) : launch_vote_sort<kVoteTop / 1024>(above, info, nodes_out, stream)))
+                return rc;
+            hipLaunchKernelGGL(vote_ties, dim3(kVoteGrid), dim3(256), 0, stream, unique_keys, counts, info, tie_count, nodes_out, none);
+        }
+    }
+    if (!need_votes)  // (max_out == 0: one workgroup, for the totals)
+        hipLaunchKernelGGL(vote_head<KeyT>, dim3((unsigned)std::max((max_out + 255) / 256, 1)), dim3(256), 0, stream, unique_keys, partial, info, nodes_out,
+                           (uint32_t)max_out);
+    uint32_t h[kVoteWords] = {};
+    if ((rc = check_hip(hipMemcpyAsync(h, info, sizeof(h), hipMemcpyDeviceToHost, stream), "copy counts"))) return rc;
+    // (the workspace is reused by the next call: finished before the lock is released)
+    if ((rc = check_hip(hipStreamSynchronize(stream), "select_candidates"))) return rc;
+    if (h[kOverflow]) {
+        *overflow = true;  // a row outside the compact key's range: the caller repeats with the wide layout
+        return MNV_OK;
+    }
+    if (select && h[kFallback]) {
+        *full_sort = true;  // more than max_out voxels with >= kVoteBins - 1 votes each: the caller repeats with the sort of all counts
+        return MNV_OK;
+    }
+    if (n_out) *n_out = max_out > 0 ? (int32_t)h[kWrite] : 0;
+    if (n_candidates) *n_candidates = (int32_t)(need_votes ? h[kVoted] : h[kValid]);
+    return MNV_OK;
+}
+
 int select_candidates(const float *track, int64_t n_rows, int32_t max_out, bool need_votes, int32_t *nodes_out,
                       int32_t *n_out, int32_t *n_candidates, hipStream_t stream) {
     if (n_out) *n_out = 0;
@@ -224,8 +545,14 @@ int select_candidates(const float *track, int64_t n_rows, int32_t max_out, bool 
     if (!track || n_rows < 0 || max_out < 0 || (max_out > 0 && !nodes_out)) return set_error(MNV_E_INVALID, "invalid tracker arguments");
     if (n_rows == 0) return MNV_OK;
     if (n_rows > 0x7fffffff) return set_error(MNV_E_UNSUPPORTED, "more than 2^31 - 1 tracker rows");
-    static const bool force_wide = getenv("MNV_VOTE_WIDE_KEYS") != nullptr;  // (tests: the fallback path on ordinary inputs)
-    bool overflow = force_wide;
+    static const bool force_wide = getenv("MNV_VOTE_WIDE_KEYS") != nullptr;       // (tests: the fallback paths on ordinary inputs)
+    static const bool force_full_sort = getenv("MNV_VOTE_FULL_SORT") != nullptr;
+    bool overflow = force_wide, full_sort = force_full_sort || (need_votes && max_out > kVoteTop);
+    if (!overflow && !full_sort) {
+        const int rc = need_votes ? select_candidates_compact<uint32_t>(track, n_rows, max_out, true, nodes_out, n_out, n_candidates, &overflow, &full_sort, stream)
+                                  : select_candidates_compact<uint64_t>(track, n_rows, max_out, false, nodes_out, n_out, n_candidates, &overflow, &full_sort, stream);
+        if (rc || (!overflow && !full_sort)) return rc;
+    }
     if (!overflow) {
         const int rc = select_candidates_as<false>(track, n_rows, max_out, need_votes, nodes_out, n_out, n_candidates, &overflow, stream);
         if (rc || !overflow) return rc;

@@ -85,6 +85,21 @@ struct VolumeRenderer::Impl {
     int quiet_frames = 0;
     long reuse_total = 0;
     uint64_t frame = 0;
+    // the fused guided kernel's sample count: copied to pinned memory behind the kernel and read at the frame's LAST wait (the vote's,
+    // the tree edit's) instead of at a wait of its own right behind the march -- 20-40 us of a refinement frame
+    unsigned long long *count_host = nullptr;
+    bool count_pending = false;
+    void read_count_later(const unsigned long long *counter) {
+        if (!count_host) hip_check(hipHostMalloc((void **)&count_host, sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc(sample count)");
+        hip_check(hipMemcpyAsync(count_host, counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream), "read sample counter");
+        count_pending = true;
+    }
+    void finish_count(FrameStats &st) {
+        if (!count_pending) return;
+        hip_check(hipStreamSynchronize(stream), "guided frame");
+        st.guided_samples = (long)*count_host;
+        count_pending = false;
+    }
 
     Impl() {
         slots.resize(1);
@@ -93,6 +108,7 @@ struct VolumeRenderer::Impl {
     }
     ~Impl() {
         free_frame();
+        if (count_host) (void)hipHostFree(count_host);
         if (mlp) mnv_mlp_destroy(mlp);
         for (Slot &s : slots)
             if (s.stream) (void)hipStreamDestroy(s.stream);
@@ -506,12 +522,9 @@ void VolumeRenderer::render() {
                                                 split ? tree.device.sample_counts : nullptr, track_visit ? visited : nullptr, tree.device.parent, counter,
                                                 I.stream),
                   "mnv_render_guided_fused_track");
-        unsigned long long n = 0;
-        hip_check(hipMemcpyAsync(&n, counter, sizeof(n), hipMemcpyDeviceToHost, I.stream), "read sample counter");
-        hip_check(hipStreamSynchronize(I.stream), "guided frame");
+        I.read_count_later(counter);
         stats.used_accel = true;
         stats.fused = true;
-        stats.guided_samples = (long)n;
         I.can_reuse_results = false;
     } else if (refine && options.use_guided_sampling) {
         // cuda_renderer.cpp:109-139
@@ -572,6 +585,7 @@ void VolumeRenderer::render() {
     }
 
     if (refine) I.refine_after_frame(options, stats, seed, track_visit);
+    I.finish_count(stats);
     ++I.frame;
     stats.capacity = tree.capacity;
 }
@@ -630,11 +644,8 @@ void VolumeRenderer::render_ranks() {
                                                      split ? tree.device.sample_counts : nullptr, track_visit ? visited : nullptr, tree.device.parent, counter,
                                                      I.stream),
                   "mnv_render_guided_fused_track_part");
-        unsigned long long n = 0;
-        hip_check(hipMemcpyAsync(&n, counter, sizeof(n), hipMemcpyDeviceToHost, I.stream), "read sample counter");
-        hip_check(hipStreamSynchronize(I.stream), "guided frame");
+        I.read_count_later(counter);  // (this rank's share)
         stats.fused = true;
-        stats.guided_samples = (long)n;  // this rank's share
     } else {
         mnv_check(mnv_render_voxels_accel_visit_part(tree.device.accel, &cv, options.c_abi(), full, I.part, local, local8, my_split, my_sample,
                                                      tree.device.sample_counts, track_visit ? visited : nullptr, tree.device.parent, I.stream),
@@ -664,6 +675,7 @@ void VolumeRenderer::render_ranks() {
         mnv_check(mnv_merge_visit_marks(marks, world, (int32_t)cap, visited, I.stream), "mnv_merge_visit_marks");
     }
     if (refine) I.refine_after_frame(options, stats, seed, track_visit);
+    I.finish_count(stats);
     ++I.frame;
     stats.capacity = tree.capacity;
 }

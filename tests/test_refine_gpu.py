@@ -410,3 +410,78 @@ def test_accel_follows_a_prune_in_place(mnv, orc, torch_gpu, tree_spec, cam_args
                 assert torch.equal(outs[0][0].view(torch.int32), before.view(torch.int32))   # the pruning view is unchanged by the prune
     finally:
         mnv.accel_destroy(fresh)
+
+
+def _vote_tracker(kind, rng):
+    """Tracker frames that put the threshold count of the vote's selection in different places."""
+    if kind == "heavy_tail":        # a frame's shape: most voxels once or twice, a few thousands of times
+        n = 1920 * 1080
+        chunk = (rng.zipf(1.3, n) % 1_400_000).astype(np.int64)
+        empty = 0.6
+    elif kind == "mostly_ties":     # nearly every voted voxel has exactly two votes: the rows AT the threshold fill the batch, in key order
+        n = 600_000
+        chunk = np.repeat(rng.permutation(1_000_000)[: n // 2], 2).astype(np.int64)
+        chunk[:3000] = chunk[0]
+        chunk = rng.permutation(chunk)
+        empty = 0.1
+    elif kind == "few_voted":       # fewer voted voxels than the batch holds
+        n = 200_000
+        chunk = rng.permutation(3_000_000)[:n].astype(np.int64)
+        chunk[:900] = np.repeat(chunk[:300], 3)
+        chunk[900:1000] = chunk[0]
+        empty = 0.3
+    else:                           # "popular": more voxels with >= 2047 votes than the batch holds -> the sort of all counts
+        n = 40 * 2100 + 50_000
+        chunk = np.concatenate([np.repeat(np.arange(40) * 977 + 5, 2100), rng.permutation(500_000)[:50_000]]).astype(np.int64)
+        chunk = rng.permutation(chunk)
+        empty = 0.0
+    track = np.stack([(1 + chunk % 10).astype(np.float32), chunk.astype(np.float32), (chunk * 5 % 8).astype(np.float32)], 1)
+    if empty:
+        track[rng.random(n) < empty] = (11.0, -1.0, -1.0)
+    return track
+
+
+@pytest.mark.parametrize("kind,ks", [("heavy_tail", (1, 7, 4096, 4192, 8192)), ("mostly_ties", (64, 4096)), ("few_voted", (4096,)), ("popular", (8, 64))])
+def test_selection_of_a_batch_without_sorting_all_counts(mnv, torch_gpu, kind, ks):
+    """Batches up to 8192 rows (split_batch_size: 4096 on the command line, 4192 in render_options.hpp:49) are SELECTED: histogram of the
+    counts -> the count of the last row that fits -> the runs above it sorted in one workgroup, the runs at it taken in key order
+    (csrc/mnv_refine.hip, select_candidates_compact).  Same rows in the same order as the numpy restatement's full sort, wherever the
+    threshold falls: in the tail, at two votes with tens of thousands of ties, nowhere (fewer voted voxels than the batch), or in the
+    histogram's last bin (falls back to the sort of all counts)."""
+    torch = torch_gpu
+    track = _vote_tracker(kind, np.random.default_rng(31))
+    d_track = torch.from_numpy(track).cuda()
+    for k in ks:
+        nodes = torch.full((k, 2), -9, dtype=torch.int32, device="cuda")
+        n_out, n_cand = mnv.select_split_candidates(d_track, k, nodes)
+        want, want_n = ro.select_split_candidates(track, k)
+        assert (n_out, n_cand) == (want.shape[0], want_n), (kind, k)
+        got = nodes.cpu().numpy()
+        assert np.array_equal(got[:n_out], want) and np.all(got[n_out:] == -9), (kind, k)
+        nodes.fill_(-9)
+        n_out, n_cand = mnv.select_sample_candidates(d_track, k, nodes)
+        want, want_n = ro.select_sample_candidates(track, k)
+        assert (n_out, n_cand) == (want.shape[0], want_n) and np.array_equal(nodes.cpu().numpy()[:n_out], want), (kind, k)
+
+
+def test_selection_paths_agree(mnv, torch_gpu, tmp_path):
+    """MNV_VOTE_FULL_SORT=1 (read once per process) forces the sort of all counts for small batches too: a child process votes on the same
+    tracker with it and must write the same rows."""
+    import subprocess
+    import sys
+
+    torch = torch_gpu
+    track = _vote_tracker("heavy_tail", np.random.default_rng(32))
+    np.save(tmp_path / "track.npy", track)
+    k = 4096
+    nodes = torch.full((k, 2), -9, dtype=torch.int32, device="cuda")
+    n_out, n_cand = mnv.select_split_candidates(torch.from_numpy(track).cuda(), k, nodes)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (f"import sys; sys.path.insert(0, {root!r}); import numpy as np, torch, mega_nerf_viewer_amd as mnv\n"
+            f"t = torch.from_numpy(np.load({str(tmp_path / 'track.npy')!r})).cuda(); nodes = torch.full(({k}, 2), -9, dtype=torch.int32, device='cuda')\n"
+            f"r = mnv.select_split_candidates(t, {k}, nodes); np.save({str(tmp_path / 'nodes.npy')!r}, nodes.cpu().numpy()); print(r[0], r[1])\n")
+    env = dict(os.environ, MNV_VOTE_FULL_SORT="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split()[-2:] == [str(n_out), str(n_cand)]
+    assert np.array_equal(np.load(tmp_path / "nodes.npy"), nodes.cpu().numpy())

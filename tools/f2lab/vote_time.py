@@ -1,5 +1,5 @@
 """Time of mnv_select_split_candidates / _sample_candidates on a REAL 1920x1080 tracker frame of the cfg2 tree (the march's own rows: neighbouring
-pixels name the same voxels, shallow leaves collect many votes).  MNV_VOTE_SORT=1 selects the sorting path."""
+pixels name the same voxels, shallow leaves collect many votes).  MNV_VOTE_FULL_SORT=1 selects the sort of all counts instead of the selection."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
@@ -24,4 +24,4 @@ for name, fn, tr in (("split", mnv.select_split_candidates, split.view(-1, 3)), 
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): r = fn(tr, k, nodes)
     torch.cuda.synchronize()
-    print(name, "path", "sort" if os.environ.get("MNV_VOTE_SORT") else "count", round((time.perf_counter() - t0) / 20 * 1e3, 4), "ms per call", r, nodes[:3].tolist())
+    print(name, "path", "full sort" if os.environ.get("MNV_VOTE_FULL_SORT") else "selection", round((time.perf_counter() - t0) / 20 * 1e3, 4), "ms per call", r, nodes[:3].tolist())
