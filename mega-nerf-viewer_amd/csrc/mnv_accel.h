@@ -109,7 +109,9 @@ struct mnv_accel {
     uint8_t *rows_spare = nullptr;        // survivors out of place, then the sets swap)
     int32_t *depth_spare = nullptr;
     int32_t *depth = nullptr;             // [reserved] depth of the voxels of each chunk (root chunk: 1); kept for mnv_accel_refresh
-    int32_t *flags = nullptr;             // [4] device scratch of refresh: changed, deepest depth, grids dirty
+    int32_t *flags = nullptr;             // [8] device scratch of refresh: changed, deepest depth, grids dirty, shallowest voxel, patch items (appended / changed)
+    uint32_t *patch_prefix = nullptr;     // refresh: first patch item of every affected voxel (grow-only)
+    size_t patch_prefix_words = 0;
     int64_t reserved = 0;                 // chunks the nodes / rows / depth arrays have room for
     unsigned long long *stats = nullptr;  // MNV_STATS=1 diagnostics
     uint32_t *fault_dev = nullptr;        // [1] guided_fused2_kernel: spin-waits abandoned by the watchdog since creation (always counted, with or without

@@ -236,8 +236,11 @@ uint64_t g_cache_clock = 0;
 
 void drop(CachedTree &e) {
     if (e.accel) {
-        (void)hipDeviceSynchronize();  // frames that still read the re-layout
+        int cur = 0;
+        const bool other = hipGetDevice(&cur) == hipSuccess && cur != e.device && hipSetDevice(e.device) == hipSuccess;
+        (void)hipDeviceSynchronize();  // frames that still read the re-layout (launched under g_cache_mu, so all of them are queued by now)
         mnv_accel_destroy(e.accel);
+        if (other) (void)hipSetDevice(cur);
     }
     if (e.built) (void)hipEventDestroy(e.built);
     e = CachedTree();
@@ -255,13 +258,14 @@ void mnv_tree_invalidate(const void *child) {
         if (e.accel && (!child || e.child == child)) drop(e);
 }
 
-// the cached re-layout of `tree` (built on `stream` at the first call), or NULL when this frame must take the stateless path
+// the cached re-layout of `tree` (built on `stream` at the first call), or NULL when this frame must take the stateless path.
+// Called with g_cache_mu held, and the caller launches its frame before releasing it: an eviction on another thread (drop: device-wide
+// wait, then destroy) can then never fall between the look-up and the launch.
 static const mnv_accel *cached_accel(const mnv_tree_view *tree, hipStream_t stream) {
     const int b = (tree->format == MNV_FORMAT_SH && tree->basis_dim >= 0) ? tree->basis_dim : -1;
     if (!(b == -1 || b == 1 || b == 4 || b == 9 || b == 16 || b == 25)) return nullptr;  // what the packed layout has rows for
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(g_cache_mu);
     CachedTree *hit = nullptr, *victim = nullptr;
     for (auto &e : g_cache)
         if (e.accel && e.child == tree->child && e.data == tree->data && e.capacity == tree->capacity && e.data_dim == tree->data_dim &&
@@ -301,6 +305,7 @@ int mnv_render_voxels(const mnv_tree_view *tree, const mnv_camera *cam, const mn
     hipStream_t stream = (hipStream_t)hip_stream;
     if (g_cache_on.load(std::memory_order_relaxed) && tree->N == 2 && !split_track && !sample_track && !track_visit) {
         // plain frames of a tree this process has seen before run on the packed re-layout kept from that call (mnv_set_tree_cache)
+        std::lock_guard<std::mutex> lk(g_cache_mu);
         if (const mnv_accel *a = cached_accel(tree, stream)) return mnv_render_voxels_accel(a, cam, opt, tile, rgba_out, rgba8_out, hip_stream);
     }
     P.max_depth = opt->max_depth;

@@ -152,8 +152,10 @@ __global__ void accel_refresh_depth(const int32_t *parent, int32_t *depth, int32
 
 // node words of the appended chunks' voxels and the link word of the voxel each of them hangs under;
 // flags[2] = 1 when that voxel was shallow enough to be held by a lookup grid
+__device__ __forceinline__ uint32_t patch_items(int32_t d, int32_t L2);
+
 __global__ void accel_refresh_nodes(const int32_t *child, const int32_t *parent, const uint16_t *data, const int32_t *depth, uint32_t *nodes,
-                                    int32_t first, int32_t capacity, int32_t data_dim, int32_t grid_depth, int32_t *flags) {
+                                    int32_t first, int32_t capacity, int32_t data_dim, int32_t grid_depth, int32_t *flags, uint32_t *items, int32_t L2) {
     const int64_t v = (int64_t)first * 8 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= (int64_t)capacity * 8) return;
     const int32_t c = (int32_t)(v >> 3);
@@ -167,65 +169,117 @@ __global__ void accel_refresh_nodes(const int32_t *child, const int32_t *parent,
         const int32_t pv = parent[c];
         nodes[pv] = (uint32_t)c;
         if (depth[pv >> 3] <= grid_depth) flags[2] = 1;
-        atomicMin(&flags[3], depth[pv >> 3]);  // the shallowest voxel that stopped being a leaf: how many lookup cells need a patch
+        atomicMin(&flags[3], depth[pv >> 3]);  // the shallowest voxel that stopped being a leaf
+        if (items) items[c - first] = patch_items(depth[pv >> 3], L2);  // (accel_patch_plan turns the counts into first items)
     }
 }
 
 // existing leaves whose data row was rewritten (mnv_apply_sample_results): sigma in the node word, colour row
 __global__ void accel_refresh_changed(const int32_t *changed_nodes, int32_t n, const int32_t *child, const uint16_t *data, const int32_t *depth,
                                       uint32_t *nodes, uint16_t *rows, int32_t data_dim, int32_t per_chan, int32_t chan_halfs,
-                                      int32_t row_halfs, int32_t grid_depth, int32_t *flags) {
+                                      int32_t row_halfs, int32_t grid_depth, int32_t *flags, uint32_t *items, int32_t L2) {
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int32_t c = changed_nodes[2 * i];
     const int64_t v = (int64_t)c * 8 + changed_nodes[2 * i + 1];
-    if (child[v] != 0) return;
+    if (child[v] != 0) {
+        if (items) items[i] = 0u;
+        return;
+    }
     nodes[v] = kLeafBit | (((uint32_t)depth[c] & 0x7fu) << 16) | (uint32_t)data[v * data_dim + data_dim - 1];
     for (int ch = 0; ch < 3; ++ch)
         for (int32_t k = 0; k < chan_halfs; ++k) rows[v * row_halfs + ch * chan_halfs + k] = k < per_chan ? data[v * data_dim + ch * per_chan + k] : (uint16_t)0;
     if (depth[c] <= grid_depth) flags[2] = 1;
     atomicMin(&flags[3], depth[c]);
+    if (items) items[i] = patch_items(depth[c], L2);
 }
 
-// Rewrite the level-L2 lookup cells covered by voxels that stopped being (or changed as) leaves.  Block (b, s): voxel b of the
-// list -- vox_list[b], or the parent voxel of chunk first_chunk + b when vox_list is NULL -- slice s of its cells.  The voxel's
-// integer coordinates come from the walk up the parent words.
-__global__ void accel_patch_grid2(const int32_t *vox_pairs, int32_t first_chunk, const int32_t *parent, const int32_t *depth,
-                                  const uint32_t *nodes, uint32_t *grid2, uint32_t *grid2_vox, int32_t L2) {
-    __shared__ uint32_t s_box[5];  // x, y, z at the voxel's own level; its depth (0: nothing to do); the voxel
+// Rewrite the level-L2 lookup cells covered by voxels that stopped being (or changed as) leaves -- voxel b of the list is vox_list[b],
+// or the parent voxel of chunk first_chunk + b when vox_list is NULL.  A voxel of depth d covers 8^(L2 - d) cells: one for most of a
+// refinement step's voxels, two million for the depth-2 voxels the vote prefers.  A fixed number of slices per voxel either drowns
+// the device in empty workgroups or leaves the shallow voxels to a few thousand threads (round 3: 32 slices, 60 us of a configs[4]
+// frame), so the work is cut into ITEMS of kPatchCells cells: accel_patch_plan counts every voxel's items and scans the counts, the
+// host reads the total with the refresh flags it waits for anyway, and accel_patch_grid2 runs one workgroup per item.
+constexpr int kPatchCells = 4096;
+
+__device__ __forceinline__ int64_t patch_voxel(const int32_t *vox_pairs, int32_t first_chunk, const int32_t *parent, int32_t b) {
+    return vox_pairs ? (int64_t)vox_pairs[2 * b] * 8 + vox_pairs[2 * b + 1] : (int64_t)parent[first_chunk + b];
+}
+
+__device__ __forceinline__ uint32_t patch_items(int32_t d, int32_t L2) {
+    return d >= 1 && d <= L2 ? (uint32_t)((((uint64_t)1 << (3 * (L2 - d))) + kPatchCells - 1) / kPatchCells) : 0u;
+}
+
+// in: prefix[b] = items of voxel b (written by the refresh kernels); out: prefix[b] = items of voxels 0 .. b-1, prefix[n] = all of
+// them, also written to *total.  One workgroup of 1024 threads.
+__global__ __launch_bounds__(1024) void accel_patch_plan(int32_t n, uint32_t *prefix, int32_t *total) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_run;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_run = 0u;
+    __syncthreads();
+    for (int32_t base = 0; base < n; base += 1024) {
+        const int32_t b = base + t;
+        const uint32_t items = b < n ? prefix[b] : 0u;
+        uint32_t incl = items;  // inclusive scan: within the wavefront, then over the 16 wavefronts
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t other = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= o) incl += other;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = s_run;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        if (b < n) prefix[b] = before + incl - items;
+        __syncthreads();
+        if (t == 1023) s_run = before + incl;
+        __syncthreads();
+    }
+    if (t == 0) {
+        prefix[n] = s_run;
+        *total = (int32_t)s_run;
+    }
+}
+
+// workgroup i: item i.  The voxel's integer coordinates come from the walk up the parent words.
+__global__ __launch_bounds__(256) void accel_patch_grid2(const int32_t *vox_pairs, int32_t first_chunk, int32_t n, const uint32_t *prefix, const int32_t *parent,
+                                                         const int32_t *depth, const uint32_t *nodes, uint32_t *grid2, uint32_t *grid2_vox, int32_t L2) {
+    __shared__ uint32_t s_box[6];  // x, y, z at the voxel's own level; its depth; the voxel; the item's number among the voxel's items
     if (threadIdx.x == 0) {
-        int64_t pv = vox_pairs ? (int64_t)vox_pairs[2 * blockIdx.x] * 8 + vox_pairs[2 * blockIdx.x + 1] : (int64_t)parent[first_chunk + blockIdx.x];
+        int32_t lo = 0, hi = n;  // the last voxel whose first item is <= this one (voxels without cells have no items and are never met)
+        while (hi - lo > 1) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (prefix[mid] <= blockIdx.x) lo = mid;
+            else hi = mid;
+        }
+        const int64_t pv = patch_voxel(vox_pairs, first_chunk, parent, lo);
         int32_t cur = (int32_t)(pv >> 3);
         const int32_t d = depth[cur];
-        uint32_t x = 0, y = 0, z = 0;
-        // (slices beyond the voxel's cell count leave before the walk up the parents: most voxels of a refinement step are deep and cover
-        // a few cells, the slices are sized for the shallowest)
-        const bool has_cells = d >= 1 && d <= L2 && (((uint64_t)1 << (3 * (L2 - d))) > (uint64_t)blockIdx.y * blockDim.x);
-        if (has_cells) {
-            uint32_t slot = (uint32_t)(pv & 7);
-            for (int k = 0; k < d; ++k) {
-                x |= ((slot >> 2) & 1u) << k;
-                y |= ((slot >> 1) & 1u) << k;
-                z |= (slot & 1u) << k;
-                if (cur == 0) break;
-                const int32_t p = parent[cur];
-                slot = (uint32_t)(p & 7);
-                cur = p >> 3;
-            }
+        uint32_t x = 0, y = 0, z = 0, slot = (uint32_t)(pv & 7);
+        for (int k = 0; k < d; ++k) {
+            x |= ((slot >> 2) & 1u) << k;
+            y |= ((slot >> 1) & 1u) << k;
+            z |= (slot & 1u) << k;
+            if (cur == 0) break;
+            const int32_t p = parent[cur];
+            slot = (uint32_t)(p & 7);
+            cur = p >> 3;
         }
         s_box[0] = x;
         s_box[1] = y;
         s_box[2] = z;
-        s_box[3] = has_cells ? (uint32_t)d : 0u;
+        s_box[3] = (uint32_t)d;
         s_box[4] = (uint32_t)pv;
+        s_box[5] = blockIdx.x - prefix[lo];
     }
     __syncthreads();
     const int d = (int)s_box[3];
-    if (d == 0) return;
     const int sh = L2 - d;  // the voxel covers (2^sh)^3 cells
     const uint32_t bx = s_box[0] << sh, by = s_box[1] << sh, bz = s_box[2] << sh;
-    const uint64_t total = (uint64_t)1 << (3 * sh);
-    for (uint64_t i = (uint64_t)blockIdx.y * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.y * blockDim.x) {
+    const uint64_t total = (uint64_t)1 << (3 * sh), first = (uint64_t)s_box[5] * kPatchCells;
+    const uint64_t last = first + kPatchCells < total ? first + kPatchCells : total;
+    for (uint64_t i = first + threadIdx.x; i < last; i += blockDim.x) {
         const uint32_t ix = bx + (uint32_t)(i >> (2 * sh)), iy = by + (uint32_t)((i >> sh) & ((1u << sh) - 1u)), iz = bz + (uint32_t)(i & ((1u << sh) - 1u));
         // the walk starts at the voxel itself (every cell of its box passes through it), not at the root: a split voxel's cells end one
         // level below it -- two dependent loads instead of L2
@@ -1508,7 +1562,7 @@ int mnv_accel_create_reserved(const mnv_tree_view *t, int64_t max_capacity, void
     if ((rc = check_hip(hipMalloc((void **)&a->nodes, max_capacity * 8 * 4), "hipMalloc(nodes)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&a->rows, max_capacity * 8 * row_bytes), "hipMalloc(rows)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&a->depth, max_capacity * 4), "hipMalloc(depth)"))) return fail(rc);
-    if ((rc = check_hip(hipMalloc((void **)&a->flags, 16), "hipMalloc(flag)"))) return fail(rc);
+    if ((rc = check_hip(hipMalloc((void **)&a->flags, 32), "hipMalloc(flag)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&a->fault_dev, 4), "hipMalloc(fault)"))) return fail(rc);
     if ((rc = check_hip(hipMemsetAsync(a->fault_dev, 0, 4, stream), "memset fault"))) return fail(rc);
     if ((rc = check_hip(hipHostMalloc((void **)&a->fault_host, 4, hipHostMallocDefault), "hipHostMalloc(fault)"))) return fail(rc);
@@ -1550,20 +1604,45 @@ int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity
     const int b = (t->format == MNV_FORMAT_SH && t->basis_dim >= 0) ? t->basis_dim : -1;
     const int per_chan = b > 0 ? b : 1, chan_halfs = b > 0 ? chan_bytes_for(b) / 2 : 1, row_halfs = a->view.row_bytes / 2;
     const int grid_depth = a->view.grid_level;  // leaves this shallow sit in the small (LDS-staged) lookup grid
-    int32_t h[4] = {0, a->view.max_depth, 0, 127};  // [1] deepest depth, [2] the small lookup grid is affected, [3] shallowest affected voxel
+    // [1] deepest depth, [2] the small lookup grid is affected, [3] shallowest affected voxel, [4] / [5] patch items of the appended / changed voxels
+    int32_t h[8] = {0, a->view.max_depth, 0, 127, 0, 0, 0, 0};
     if ((rc = check_hip(hipMemcpyAsync(a->flags, h, sizeof(h), hipMemcpyHostToDevice, stream), "refresh flags"))) return rc;
     const int32_t n_new = t->capacity - old_capacity;
+    // the level-L2 grid: only the cells the affected voxels cover, cut into items (accel_patch_grid2).  The refresh kernels count every
+    // voxel's items, accel_patch_plan scans the counts, the totals come back with the flags.
+    const bool patch_changed = n_changed > 0 && t->parent != nullptr && a->view.grid2_level > 0;
+    const bool patch_new = n_new > 0 && a->view.grid2_level > 0;
+    uint32_t *prefix_new = nullptr, *prefix_changed = nullptr;
+    if (patch_new || patch_changed) {
+        const size_t words = (size_t)n_new + 1 + (size_t)(patch_changed ? n_changed : 0) + 1;
+        if (a->patch_prefix_words < words) {
+            if (a->patch_prefix) {
+                if ((rc = check_hip(hipStreamSynchronize(stream), "accel refresh"))) return rc;
+                (void)hipFree(a->patch_prefix);
+                a->patch_prefix = nullptr;
+                a->patch_prefix_words = 0;
+            }
+            if ((rc = check_hip(hipMalloc((void **)&a->patch_prefix, (words + words / 4) * 4), "hipMalloc(patch items)"))) return rc;
+            a->patch_prefix_words = words + words / 4;
+        }
+        if (patch_new) prefix_new = a->patch_prefix;
+        if (patch_changed) prefix_changed = a->patch_prefix + n_new + 1;
+    }
     if (n_new > 0) {
         hipLaunchKernelGGL(accel_refresh_depth, dim3((n_new + 255) / 256), dim3(256), 0, stream, t->parent, a->depth, old_capacity, t->capacity, a->flags);
         const int64_t nv = (int64_t)n_new * 8;
         hipLaunchKernelGGL(accel_refresh_nodes, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, t->child, t->parent, t->data, a->depth, a->nodes,
-                           old_capacity, t->capacity, t->data_dim, grid_depth, a->flags);
+                           old_capacity, t->capacity, t->data_dim, grid_depth, a->flags, prefix_new, a->view.grid2_level);
         hipLaunchKernelGGL(accel_pack_rows, dim3((unsigned)((nv * 3 + 255) / 256)), dim3(256), 0, stream, t->data + (int64_t)old_capacity * 8 * t->data_dim,
                            reinterpret_cast<uint16_t *>(a->rows) + (int64_t)old_capacity * 8 * row_halfs, nv, t->data_dim, per_chan, chan_halfs, row_halfs);
+        if (patch_new) hipLaunchKernelGGL(accel_patch_plan, dim3(1), dim3(1024), 0, stream, n_new, prefix_new, a->flags + 4);
     }
-    if (n_changed > 0)
+    if (n_changed > 0) {
         hipLaunchKernelGGL(accel_refresh_changed, dim3((n_changed + 255) / 256), dim3(256), 0, stream, changed_nodes, n_changed, t->child, t->data, a->depth,
-                           a->nodes, reinterpret_cast<uint16_t *>(a->rows), t->data_dim, per_chan, chan_halfs, row_halfs, grid_depth, a->flags);
+                           a->nodes, reinterpret_cast<uint16_t *>(a->rows), t->data_dim, per_chan, chan_halfs, row_halfs, grid_depth, a->flags, prefix_changed,
+                           a->view.grid2_level);
+        if (patch_changed) hipLaunchKernelGGL(accel_patch_plan, dim3(1), dim3(1024), 0, stream, n_changed, prefix_changed, a->flags + 5);
+    }
     if ((rc = check_hip(hipMemcpyAsync(h, a->flags, sizeof(h), hipMemcpyDeviceToHost, stream), "read flags"))) return rc;
     if ((rc = check_hip(hipStreamSynchronize(stream), "accel refresh"))) return rc;
     if (h[1] > 23) return set_error(MNV_E_UNSUPPORTED, "accel supports trees up to depth 23; use mnv_render_voxels");
@@ -1571,22 +1650,17 @@ int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity
         const int64_t gcells = (int64_t)1 << (3 * a->view.grid_level);
         hipLaunchKernelGGL(accel_build_grid, dim3((unsigned)((gcells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid, a->grid_vox, a->view.grid_level);
     }
-    if (a->view.grid2_level > 0 && h[3] <= a->view.grid2_level) {
-        // the level-L2 grid: only the cells the affected voxels cover (voxels deeper than L2 cover none: then nothing is launched).  A
-        // voxel of depth d covers 8^(L2 - d) cells; the slices per voxel (grid.y) follow the shallowest one instead of a fixed 32
-        // (131 k mostly idle workgroups for 4096 splits: 0.19 ms per refinement frame).
-        const int sh = a->view.grid2_level - std::max(h[3], 1);
-        const uint64_t cells = (uint64_t)1 << (3 * std::min(sh, 10));
-        const unsigned gy = (unsigned)std::min<uint64_t>(32, std::max<uint64_t>(1, cells / 256));
+    if (a->view.grid2_level > 0) {
         static const bool dbg = getenv("MNV_REFRESH_DEBUG") != nullptr;
-        if (dbg) fprintf(stderr, "[mnv refresh] n_new %d n_changed %d shallowest %d grid2_level %d slices %u\n", n_new, n_changed, h[3], a->view.grid2_level, gy);
-        if (n_new > 0)
-            hipLaunchKernelGGL(accel_patch_grid2, dim3((unsigned)n_new, gy), dim3(256), 0, stream, (const int32_t *)nullptr, old_capacity, t->parent, a->depth,
+        if (dbg)
+            fprintf(stderr, "[mnv refresh] n_new %d n_changed %d shallowest %d grid2_level %d patch items %d + %d\n", n_new, n_changed, h[3], a->view.grid2_level, h[4], h[5]);
+        if (h[4] > 0)
+            hipLaunchKernelGGL(accel_patch_grid2, dim3((unsigned)h[4]), dim3(256), 0, stream, (const int32_t *)nullptr, old_capacity, n_new, prefix_new, t->parent,
+                               a->depth, a->nodes, a->grid2, a->grid2_vox, a->view.grid2_level);
+        if (h[5] > 0)
+            hipLaunchKernelGGL(accel_patch_grid2, dim3((unsigned)h[5]), dim3(256), 0, stream, changed_nodes, 0, n_changed, prefix_changed, t->parent, a->depth,
                                a->nodes, a->grid2, a->grid2_vox, a->view.grid2_level);
-        if (n_changed > 0 && t->parent)
-            hipLaunchKernelGGL(accel_patch_grid2, dim3((unsigned)n_changed, gy), dim3(256), 0, stream, changed_nodes, 0, t->parent, a->depth, a->nodes, a->grid2,
-                               a->grid2_vox, a->view.grid2_level);
-        else if (n_changed > 0) {
+        if (n_changed > 0 && !t->parent && h[3] <= a->view.grid2_level) {  // no parent array to walk up: the whole grid
             const int64_t g2cells = (int64_t)1 << (3 * a->view.grid2_level);
             hipLaunchKernelGGL(accel_build_grid2, dim3((unsigned)((g2cells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid2, a->grid2_vox,
                                a->view.grid2_level);
@@ -1633,6 +1707,7 @@ void mnv_accel_destroy(mnv_accel *a) {
     if (a->stats) (void)hipFree(a->stats);
     if (a->depth) (void)hipFree(a->depth);
     if (a->flags) (void)hipFree(a->flags);
+    if (a->patch_prefix) (void)hipFree(a->patch_prefix);
     if (a->fault_dev) (void)hipFree(a->fault_dev);
     if (a->fault_host) (void)hipHostFree(a->fault_host);
     if (a->nodes) (void)hipFree(a->nodes);
