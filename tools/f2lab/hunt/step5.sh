@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/../.."
+cd "$(dirname "$0")/../../.."
 mkdir -p gpurun_out/f2lab
 MNV_LIB_PATH=$PWD/variants/libmnv_P20.so timeout 900 python3 tools/f2lab/probe.py 20 12 0.001953125 > gpurun_out/f2lab/probe_P20.txt 2>&1
 MNV_LIB_PATH=$PWD/variants/libmnv_P8.so timeout 900 python3 tools/f2lab/probe.py 8 12 0.001953125 > gpurun_out/f2lab/probe_P8.txt 2>&1

@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/../.."
+cd "$(dirname "$0")/../../.."
 mkdir -p gpurun_out/f2lab
 for v in Q1 Q2 Q3 Q4; do
   MNV_LIB_PATH=$PWD/variants/libmnv_$v.so timeout 900 python3 tools/f2lab/probe2.py 16 6 1 > gpurun_out/f2lab/probe2_$v.txt 2>&1

@@ -3,7 +3,7 @@
 #  1. the delay reproducer assembled from the NEW build: 16 poses x 63 launches = 1008 frames
 #  2. the plain new build: 640 frames, + 320 frames with trackers / visit marks
 #  3. the fused tests (oracle comparison included) and the guided-frame timing
-cd "$(dirname "$0")/../.."
+cd "$(dirname "$0")/../../.."
 mkdir -p gpurun_out/f2lab
 MNV_LIB_PATH=$PWD/variants/libmnv_newdelay.so timeout 1500 python3 tools/fused_stress.py 63 2 > gpurun_out/f2lab/verify_newdelay_1008.txt 2>&1; tail -1 gpurun_out/f2lab/verify_newdelay_1008.txt
 MNV_LIB_PATH=$PWD/variants/libmnv_repro.so timeout 600 python3 tools/fused_stress.py 2 2 > gpurun_out/f2lab/verify_oldrepro_32.txt 2>&1; tail -1 gpurun_out/f2lab/verify_oldrepro_32.txt | cut -c1-300
