@@ -485,3 +485,39 @@ def test_selection_paths_agree(mnv, torch_gpu, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.split()[-2:] == [str(n_out), str(n_cand)]
     assert np.array_equal(np.load(tmp_path / "nodes.npy"), nodes.cpu().numpy())
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_selection_random_trackers_against_the_restatement(mnv, torch_gpu, seed):
+    """Random tracker frames -- row count, share of empty rows, how votes concentrate, priorities as a function of the voxel or not (rows of
+    one voxel with different priorities are different candidates, cuda_renderer.cpp:208) -- and random batch sizes on both sides of the
+    selection path's limits (8192 rows, 2047 votes): the numpy restatement's rows in its order, from either path."""
+    torch = torch_gpu
+    rng = np.random.default_rng(9000 + seed)
+    n = int(10 ** rng.uniform(1.0, 5.8))
+    n_vox = max(1, int(n * 10 ** rng.uniform(-3.0, 0.3)))
+    kind = seed % 4
+    if kind == 0:
+        vox = rng.integers(0, n_vox, n)                                   # uniform: counts cluster around n / n_vox
+    elif kind == 1:
+        vox = rng.zipf(rng.uniform(1.1, 2.0), n) % n_vox                  # heavy tail
+    elif kind == 2:
+        vox = np.repeat(rng.integers(0, 1 << 24, (n + 1) // 2), 2)[:n]    # pairs: the threshold sits at two votes, everything ties
+    else:
+        vox = np.where(rng.random(n) < 0.5, rng.integers(0, 8, n), rng.integers(0, n_vox, n))  # a handful of voxels with half of the votes
+    vox = rng.permutation(vox.astype(np.int64))
+    prio = 1 + vox % 11 if seed % 3 else rng.integers(0, 12, n)
+    track = np.stack([prio.astype(np.float32), (vox >> 3).astype(np.float32), (vox & 7).astype(np.float32)], 1)
+    track[rng.random(n) < rng.uniform(0.0, 0.95)] = (13.0, -1.0, -1.0)
+    d_track = torch.from_numpy(np.ascontiguousarray(track)).cuda()
+    for k in sorted({1, int(rng.integers(2, 200)), int(rng.integers(200, 8193)), int(rng.integers(8193, 30000))}):
+        nodes = torch.full((k, 2), -9, dtype=torch.int32, device="cuda")
+        n_out, n_cand = mnv.select_split_candidates(d_track, k, nodes)
+        want, want_n = ro.select_split_candidates(track, k)
+        assert (n_out, n_cand) == (want.shape[0], want_n), (seed, k)
+        got = nodes.cpu().numpy()
+        assert np.array_equal(got[:n_out], want) and np.all(got[n_out:] == -9), (seed, k)
+        nodes.fill_(-9)
+        n_out, n_cand = mnv.select_sample_candidates(d_track, k, nodes)
+        want, want_n = ro.select_sample_candidates(track, k)
+        assert (n_out, n_cand) == (want.shape[0], want_n) and np.array_equal(nodes.cpu().numpy()[:n_out], want), (seed, k)
