@@ -323,3 +323,46 @@ def test_cfg5_on_several_ranks_at_scale(mnv, torch_gpu, fake_rccl, world):
     assert all(c > 0 and 0 < a <= 4096 and fused == 1 for c, a, _, fused in one[0][0])
     assert all(many[r][0] == one[0][0] for r in range(world))
     assert many[0][1] == one[0][1]
+
+
+def test_8k_frame_and_odd_sizes_beyond_the_configs(mnv, orc, torch_gpu):
+    """Maximum sizes: one 7680x4320 frame (33 M rays, 518 k tiles: four times configs[3]'s) of the cfg2 tree -- too large for the CPU
+    oracle in a test, so the two kernels (different layouts, different traversals) check each other bit for bit, 64 x 64 windows of
+    the frame are checked against the oracle, and a tile of it equals the same rectangle rendered alone; then frame sizes that are no multiple of
+    anything (1 x 1, 1 x 977, 8191 x 3) against the oracle."""
+    torch = torch_gpu
+    tree = cases.make_tree(mnv, cases.CFG2_TREE)
+    ot = orc.tree_from_view(tree.host_view())
+    tree.move_to_device()
+    opt = mnv.RenderOptions.cli_defaults()
+    W, H = 7680, 4320
+    cam = cases.cfg2_camera(mnv, 3, W, H, 6400.0)
+    a = torch.full((H, W, 4), float("nan"), dtype=torch.float32, device="cuda")
+    b = torch.full((H, W, 4), float("nan"), dtype=torch.float32, device="cuda")
+    mnv.render_voxels_accel(tree.accel, cam, opt, rgba=a)
+    mnv.render_voxels(tree.device_view(), cam, opt, rgba=b)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(a).any()) and torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert 0.3 < float((a[..., 3] > 0).float().mean()) < 0.9          # the shell fills a good part of the frame
+    for x0, y0 in ((0, 0), (W - 64, H - 64), (W // 2 - 32, H // 2 - 32), (2441, 1013), (5207, 3301)):
+        tile = (x0, y0, 64, 64)
+        ref = orc.render(ot, cam.c, opt, tile=tile)
+        assert np.array_equal(cases.bits(a[y0:y0 + 64, x0:x0 + 64].cpu().numpy()), cases.bits(ref["rgba"])), tile
+        t = torch.empty((64, 64, 4), dtype=torch.float32, device="cuda")
+        mnv.render_voxels_accel(tree.accel, cam, opt, tile=tile, rgba=t)
+        torch.cuda.synchronize()
+        assert torch.equal(t.view(torch.int32), a[y0:y0 + 64, x0:x0 + 64].contiguous().view(torch.int32)), tile
+    del a, b
+    for w, h in ((1, 1), (1, 977), (8191, 3)):
+        cam = cases.cfg2_camera(mnv, 7, w, h, 900.0)
+        ref = orc.render(ot, cam.c, opt, want_rgba8=True)
+        for which in ("accel", "ref_layout"):
+            out = torch.full((h, w, 4), float("nan"), dtype=torch.float32, device="cuda")
+            out8 = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+            if which == "accel":
+                mnv.render_voxels_accel(tree.accel, cam, opt, rgba=out, rgba8=out8)
+            else:
+                mnv.render_voxels(tree.device_view(), cam, opt, rgba=out, rgba8=out8)
+            torch.cuda.synchronize()
+            assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref["rgba"])), (w, h, which)
+            assert np.array_equal(out8.cpu().numpy(), ref["rgba8"]), (w, h, which)
