@@ -302,6 +302,29 @@ def extras_cfg5(mnv, cases, torch, dev, tree, frames_each=6):
     e1.record()
     torch.cuda.synchronize(dev)
     guided_ms = e0.elapsed_time(e1) / (reps * len(cams))
+    # the same frames with three in flight on HIP streams (the entry point is re-entrant across streams, like the plain march): a frame's
+    # tail -- workgroups that have run dry while the longest tiles finish -- runs under the next frame's start.  Throughput, not latency.
+    in_flight = 3
+    sts = [torch.cuda.Stream(device=dev) for _ in range(in_flight)]
+    outs = torch.empty((len(cams), h, w, 4), dtype=torch.float32, device=dev)
+    one_stream = torch.empty_like(outs)
+    for i, c in enumerate(cams):
+        mnv.render_guided_fused(tree.accel, c, opt, mlp, g, rgba=one_stream[i])
+    torch.cuda.synchronize(dev)
+
+    def lap():
+        for i, c in enumerate(cams):
+            mnv.render_guided_fused(tree.accel, c, opt, mlp, g, rgba=outs[i], stream=sts[i % in_flight].cuda_stream)
+
+    lap()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        lap()
+    torch.cuda.synchronize(dev)
+    guided_flight_ms = (time.perf_counter() - t0) / (reps * len(cams)) * 1e3
+    flight_bad = int((outs.view(torch.int32) != one_stream.view(torch.int32)).any(dim=-1).sum().item())
+    del outs, one_stream
     # the same frame through the four kernels the fused one replaces: sample march -> compaction -> network -> composite
     n_px, dd = w * h, v.data_dim
     num = torch.zeros(n_px, dtype=torch.int16, device=dev)
@@ -352,6 +375,8 @@ def extras_cfg5(mnv, cases, torch, dev, tree, frames_each=6):
            "network_evals_per_s": round(evals / (guided_ms * 1e-3), 0), "mfma_frac": round(evals * flops_per_eval / (guided_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 5),
            "mfma_note": "network flops of the padded 32-64-64-32 tiles / whole-kernel time / 2.5 PFLOP/s: the kernel is the march AND the network",
            "pixels_not_bit_identical_vs_four_step": n_bad,
+           "guided_in_flight": {"frames_in_flight": in_flight, "ms_per_frame": round(guided_flight_ms, 4), "Mrays_per_s": round(w * h / guided_flight_ms / 1e3, 1),
+                                "pixels_not_bit_identical_vs_one_stream": flight_bad},
            "both_ms_per_frame": round(both_ms, 4), "both_network_evals_per_frame": int(st["guided_samples"]), "both_added_per_frame": int(st["added"]), "both_fused": int(st["fused"]),
            "what": "cfg2 tree at 1920x1080: guided = mnv_render_guided_fused (one kernel per frame, 8 sub-modules, 64x2 network, quota 32), HIP events over 24 frames; "
                    "both = VolumeRenderer::render with use_splitting + use_guided_sampling (4096 splits x 8 corners x 8 samples per frame), wall time per frame"}

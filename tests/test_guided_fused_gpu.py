@@ -348,3 +348,39 @@ def test_fused_frame_of_a_sub_rectangle(mnv, torch_gpu):
     torch.cuda.synchronize()
     assert torch.equal(win.view(torch.int32), full[y0:y0 + h, x0:x0 + w].contiguous().view(torch.int32))
     assert torch.isnan(guard[0]).all() and torch.isnan(guard[h + 1]).all()
+
+
+def test_fused_frames_in_flight_on_several_streams(mnv, torch_gpu):
+    """mnv_render_guided_fused is re-entrant across HIP streams like the plain march (per-launch queue heads and camera blocks live in the
+    accel's slot ring): twelve frames of the cfg2 tree, three in flight at a time, each equal to the frame rendered alone, the shared sample
+    counter equal to the sum, no fault."""
+    torch = torch_gpu
+    tree = cases.make_tree(mnv, cases.CFG2_TREE)
+    v = tree.host_view()
+    tree.move_to_device()
+    opt = mnv.RenderOptions.cli_defaults()
+    opt.basis_minmax[1] = 8
+    opt.max_guided_samples = 32
+    desc = mnv.mlp_desc(n_clusters=6, pos_octaves=4, dir_octaves=2, need_viewdir=False, hidden_width=64, hidden_layers=2, out_dim=v.data_dim + 1)
+    mlp = mnv.Mlp(desc, mlp_cases.make_params(mnv, desc, seed=21))
+    grid = make_grid(mnv)
+    w, h, n = 960, 540, 12
+    cams = [cases.cfg2_camera(mnv, p, w, h, 800.0) for p in range(n)]
+    alone = torch.empty((n, h, w, 4), dtype=torch.float32, device="cuda")
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for i, cam in enumerate(cams):
+        mnv.render_guided_fused(tree.accel, cam, opt, mlp, grid, rgba=alone[i], sample_counter=counter)
+    torch.cuda.synchronize()
+    total = int(counter.item())
+    counter.zero_()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    torch.cuda.synchronize()
+    flight = torch.full((n, h, w, 4), float("nan"), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for lap in range(2):
+        for i, cam in enumerate(cams):
+            mnv.render_guided_fused(tree.accel, cam, opt, mlp, grid, rgba=flight[i], sample_counter=counter, stream=streams[i % 3].cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(flight.view(torch.int32), alone.view(torch.int32))
+    assert int(counter.item()) == 2 * total and total > 1_000_000
+    assert mnv.accel_fused_faults(tree.accel) == 0
