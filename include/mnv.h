@@ -664,6 +664,12 @@ int mnv_renderer_download(mnv_renderer *r, float *rgba_host, uint8_t *rgba8_host
  * mnv_renderer_download_slot waits for that slot's frame only.  count = 1 restores the one-stream behaviour.
  */
 int mnv_renderer_set_frames_in_flight(mnv_renderer *r, int32_t count);
+/* VolumeRenderer::guided_in_flight (default off): guided-sampling frames that change nothing -- use_guided_sampling without use_splitting, a
+ * network the fused kernel covers, a tree below 3/4 of its capacity -- rotate over the slots like plain frames (1.20 -> 1.09 ms per 1080p
+ * frame on the cfg2 tree with three in flight).  Such a frame's sample count is not known when mnv_renderer_render returns: the stats carry
+ * guided_samples = -1 and mnv_renderer_slot_guided_samples waits for the frame of `slot` and returns its count. */
+int mnv_renderer_set_guided_in_flight(mnv_renderer *r, int enable);
+int mnv_renderer_slot_guided_samples(mnv_renderer *r, int32_t slot, int64_t *count_out);
 /* VolumeRenderer::use_fused_guided (default on): guided-sampling frames that need nothing but the picture run as one kernel;
  * off = always the four steps of cuda_renderer.cpp:107-139 (sample march, compaction, networks, composite) */
 int mnv_renderer_set_fused_guided(mnv_renderer *r, int enable);

@@ -282,6 +282,8 @@ _SIGNATURES = {
     "mnv_renderer_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_renderer_sync_tree": (C.c_int, [C.c_void_p]),
     "mnv_renderer_set_frames_in_flight": (C.c_int, [C.c_void_p, C.c_int32]),
+    "mnv_renderer_set_guided_in_flight": (C.c_int, [C.c_void_p, C.c_int]),
+    "mnv_renderer_slot_guided_samples": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "mnv_renderer_last_slot": (C.c_int32, [C.c_void_p]),
     "mnv_renderer_set_fused_guided": (C.c_int, [C.c_void_p, C.c_int]),
     "mnv_renderer_set_ranks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
@@ -942,6 +944,16 @@ class Renderer:
 
     def set_frames_in_flight(self, count: int) -> None:
         _check(lib().mnv_renderer_set_frames_in_flight(self._h, int(count)))
+
+    def set_guided_in_flight(self, on: bool) -> None:
+        """Guided-sampling frames that change nothing rotate over the frame slots like plain frames (default off); their sample count:
+        slot_guided_samples(last_slot())."""
+        _check(lib().mnv_renderer_set_guided_in_flight(self._h, 1 if on else 0))
+
+    def slot_guided_samples(self, slot: int) -> int:
+        n = C.c_int64(0)
+        _check(lib().mnv_renderer_slot_guided_samples(self._h, int(slot), C.byref(n)))
+        return int(n.value)
 
     def set_fused_guided(self, enable: bool) -> None:
         _check(lib().mnv_renderer_set_fused_guided(self._h, int(enable)))

@@ -310,6 +310,23 @@ int mnv_renderer_set_frames_in_flight(mnv_renderer *r, int32_t count) {
     });
 }
 
+int mnv_renderer_set_guided_in_flight(mnv_renderer *r, int enable) {
+    if (!r) return mnv::set_error(MNV_E_INVALID, "null argument");
+    return guarded([&] {
+        r->rend.sync_tree_streams();
+        r->rend.guided_in_flight = enable != 0;
+        return MNV_OK;
+    });
+}
+
+int mnv_renderer_slot_guided_samples(mnv_renderer *r, int32_t slot, int64_t *count_out) {
+    if (!r || !count_out) return mnv::set_error(MNV_E_INVALID, "null argument");
+    return guarded([&] {
+        *count_out = (int64_t)r->rend.slot_guided_samples(slot);
+        return MNV_OK;
+    });
+}
+
 int mnv_renderer_set_fused_guided(mnv_renderer *r, int enable) {
     if (!r) return mnv::set_error(MNV_E_INVALID, "null argument");
     r->rend.use_fused_guided = enable != 0;

@@ -25,6 +25,8 @@
 //                    all-gathered, every rank applies the same tree edits to its replica).
 //   --in_flight K    plain frames in flight (default 3; VolumeRenderer::frames_in_flight): frame k is downloaded and written
 //                    after frames k+1 .. k+K-1 have been issued
+//   --guided_in_flight   guided-sampling frames without splitting rotate over the slots as well (VolumeRenderer::guided_in_flight); their
+//                    sample counts are printed when the frame is written
 #include <hip/hip_runtime_api.h>
 
 #include <sys/mman.h>
@@ -76,7 +78,7 @@ Args parse(int argc, char **argv) {
         {"s", "step_size"}, {"e", "stop_thresh"}, {"a", "sigma_thresh"}, {"c", "max_tree_capacity"}, {"x", "split_batch_size"},
         {"n", "nerf_batch_size"}, {"v", "samples_per_voxel"}, {"b", "bounds_only"}, {"y", "appearance_embedding"},
         {"z", "max_guided_samples"}, {"w", "width"}, {"h", "height"}};
-    static const char *flags[] = {"bounds_only", "raw", "help", "use_splitting", "use_guided_sampling"};
+    static const char *flags[] = {"bounds_only", "raw", "help", "use_splitting", "use_guided_sampling", "guided_in_flight"};
     Args a;
     for (int i = 1; i < argc; ++i) {
         std::string t = argv[i];
@@ -105,7 +107,7 @@ void usage() {
     std::puts("usage: mnv_render npz_file [--bg 0.0] [-s step_size] [-e stop_thresh] [-a sigma_thresh] [-c max_tree_capacity]\n"
               "                  [-w width] [-h height] [--fx 1111] [--fy -1] [--cx -1] [--cy -1] [--center x,y,z] [--back x,y,z]\n"
               "                  [--origin x,y,z] [--world_up x,y,z] [-b] [--out PREFIX] [--raw] [--frames N] [--orbit DEG] [--gpu ID]\n"
-              "                  [--in_flight K] [--gpus N [--reserve_cus R] [--root_period M]]\n"
+              "                  [--in_flight K] [--guided_in_flight] [--gpus N [--reserve_cus R] [--root_period M]]\n"
               "                  [--model_path MODEL.npz [--use_splitting] [--use_guided_sampling] [-x split_batch_size] [-v samples_per_voxel]\n"
               "                   [-y appearance_embedding] [-z max_guided_samples] [--max_depth D] [--max_sample_count C] [--seed S]\n"
               "                   [--save_tree FILE.npz]]");
@@ -224,7 +226,8 @@ void print_refine_stats(long f, const viewer::VolumeRenderer::FrameStats &st) {
     if (st.split_candidates || st.added) std::printf("  split candidates %d, added %d%s", st.split_candidates, st.added, st.full ? " (full)" : "");
     if (st.sample_candidates) std::printf("  sample candidates %d, resampled %d", st.sample_candidates, st.resampled);
     if (st.pruned) std::printf("  pruned %d", st.pruned > 0 ? st.pruned : 0);
-    if (st.guided_samples) std::printf("  guided samples %ld", st.guided_samples);
+    if (st.guided_samples > 0) std::printf("  guided samples %ld", st.guided_samples);
+    if (st.guided_samples < 0) std::printf("  guided samples: in flight");
     std::printf("\n");
 }
 
@@ -537,12 +540,14 @@ int main(int argc, char **argv) {
         std::vector<uint8_t> rgba8;
         mnv_set_timing(1);
         rend.frames_in_flight = (int)std::max<long>(1, args.l("in_flight", rend.frames_in_flight));
+        rend.guided_in_flight = args.has("guided_in_flight");
         std::deque<std::pair<long, int>> pending;  // (frame, slot) rendered but not yet written
         auto write_oldest = [&]() {
             const long f = pending.front().first;
             const int slot = pending.front().second;
             pending.pop_front();
             rend.download_slot(slot, args.has("raw") ? &rgba : nullptr, &rgba8);
+            if (refine && rend.guided_in_flight) std::printf("frame %ld: guided samples %ld\n", f, rend.slot_guided_samples(slot));
             write_frame(out, f, width, height, rgba8.data(), args.has("raw") ? rgba.data() : nullptr);
         };
         const auto wall0 = std::chrono::steady_clock::now();
@@ -568,7 +573,7 @@ int main(int argc, char **argv) {
         }
         const double ms = rend.take_average_ms();
         std::printf("%s: %ld frame(s) %dx%d, %.3f ms per launch on the device, %.3f ms/frame wall (%d in flight%s), %.1f Mrays/s\n", rend.get_backend(), frames,
-                    width, height, ms, wall_ms / frames, refine ? 1 : rend.frames_in_flight, out.empty() ? "" : ", incl. download + file output",
+                    width, height, ms, wall_ms / frames, refine && !rend.overlaps_next() ? 1 : rend.frames_in_flight, out.empty() ? "" : ", incl. download + file output",
                     wall_ms > 0 ? (double)width * height * frames / wall_ms / 1e3 : 0.0);
         return 0;
     } catch (const std::exception &e) {

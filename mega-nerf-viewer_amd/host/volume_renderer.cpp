@@ -54,6 +54,8 @@ struct VolumeRenderer::Impl {
         hipStream_t stream = nullptr;
         float *rgba = nullptr;
         uint8_t *rgba8 = nullptr;
+        unsigned long long *count_dev = nullptr, *count_host = nullptr;  // guided frames in flight: this slot's sample counter and its pinned copy
+        bool counted = false;                                             // ... which a frame on this slot has written (or is about to)
     };
     std::vector<Slot> slots;
     int cur = 0;            // slot of the most recent render()
@@ -110,8 +112,11 @@ struct VolumeRenderer::Impl {
         free_frame();
         if (count_host) (void)hipHostFree(count_host);
         if (mlp) mnv_mlp_destroy(mlp);
-        for (Slot &s : slots)
+        for (Slot &s : slots) {
+            if (s.count_dev) (void)hipFree(s.count_dev);
+            if (s.count_host) (void)hipHostFree(s.count_host);
             if (s.stream) (void)hipStreamDestroy(s.stream);
+        }
     }
     void sync_all() {
         for (Slot &s : slots) hip_check(hipStreamSynchronize(s.stream), "hipStreamSynchronize");
@@ -456,7 +461,24 @@ void VolumeRenderer::render() {
             I.ensure_slots(frames_in_flight);
             I.use_slot((I.cur + 1) % frames_in_flight);
             I.overlapped = true;
-            mnv_check(mnv_render_voxels_accel(I.tree->device.accel, &cv, options.c_abi(), full, I.rgba, I.rgba8, I.slots[I.cur].stream), "mnv_render_voxels_accel");
+            Impl::Slot &S = I.slots[I.cur];
+            if (I.mlp != nullptr && options.use_guided_sampling) {  // (overlaps_next: a guided-sampling frame that changes nothing, guided_in_flight)
+                if (!S.count_dev) {
+                    hip_check(hipMalloc((void **)&S.count_dev, sizeof(unsigned long long)), "hipMalloc(sample counter)");
+                    hip_check(hipHostMalloc((void **)&S.count_host, sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc(sample count)");
+                }
+                hip_check(hipMemsetAsync(S.count_dev, 0, sizeof(unsigned long long), S.stream), "clear sample counter");
+                mnv_check(mnv_render_guided_fused(I.tree->device.accel, &cv, options.c_abi(), full, I.mlp, &I.grid, I.rgba, I.rgba8, S.count_dev, S.stream),
+                          "mnv_render_guided_fused");
+                hip_check(hipMemcpyAsync(S.count_host, S.count_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream), "read sample counter");
+                S.counted = true;
+                stats.fused = true;
+                stats.guided_samples = -1;  // in flight: slot_guided_samples(last_slot())
+                ++I.quiet_frames;           // (what refine_after_frame does for a frame without splitting)
+            } else {
+                S.counted = false;
+                mnv_check(mnv_render_voxels_accel(I.tree->device.accel, &cv, options.c_abi(), full, I.rgba, I.rgba8, S.stream), "mnv_render_voxels_accel");
+            }
             stats.used_accel = true;
             stats.capacity = I.tree->capacity;
             ++I.frame;
@@ -464,6 +486,7 @@ void VolumeRenderer::render() {
         }
         if (I.overlapped) I.sync_all();
         I.use_slot(0);
+        I.slots[0].counted = false;  // (this frame's sample count is in `stats`)
         I.tree_stream_dirty = true;  // what follows runs on slot 0's stream and may edit the tree
     }
     if (I.comm) {
@@ -690,9 +713,26 @@ int VolumeRenderer::last_slot() const { return impl_->cur; }
 
 bool VolumeRenderer::overlaps_next() const {
     const Impl &I = *impl_;
+    if (I.comm || frames_in_flight <= 1 || I.tree == nullptr || I.tree->N <= 0 || !I.tree->device.accel || I.accel_stale) return false;
     const bool refine_now = I.mlp != nullptr && (options.use_splitting || options.use_guided_sampling);
-    const bool plain = !I.comm && !refine_now && I.tree != nullptr && I.tree->N > 0 && I.tree->device.accel && !I.accel_stale;
-    return plain && frames_in_flight > 1;
+    if (!refine_now) return true;  // a plain frame on the packed accel
+    // a guided-sampling frame that changes nothing and wants nothing but the picture: the fused kernel, no splitting, no visit marks (a tree
+    // below 3/4 of its capacity and no prune pending: render()'s track_visit is then false whatever the camera did)
+    const N3Tree &tree = *I.tree;
+    const bool covered = I.mlp_desc.hidden_width == 64 && I.fused_inputs_ok && I.mlp_desc.out_dim == tree.data_dim + 1 &&
+                         (tree.data_format.format != DataFormat::SH || tree.data_format.basis_dim == 1 || tree.data_format.basis_dim == 4 ||
+                          tree.data_format.basis_dim == 9 || tree.data_format.basis_dim == 16);
+    return guided_in_flight && use_fused_guided && options.use_guided_sampling && !options.use_splitting && !options.render_depth && covered &&
+           !I.prune_happened && !I.want_marks && tree.capacity <= I.max_tree_capacity * 3 / 4;
+}
+
+long VolumeRenderer::slot_guided_samples(int slot) {
+    Impl &I = *impl_;
+    if (slot < 0 || slot >= (int)I.slots.size()) throw std::runtime_error("slot_guided_samples: no such frame slot");
+    Impl::Slot &S = I.slots[slot];
+    if (!S.counted) return slot == I.cur ? stats.guided_samples : 0;
+    hip_check(hipStreamSynchronize(S.stream), "slot_guided_samples");
+    return (long)*S.count_host;
 }
 
 int VolumeRenderer::next_slot() const { return overlaps_next() ? (impl_->cur + 1) % frames_in_flight : 0; }

@@ -157,6 +157,15 @@ def test_mnv_render_guided_sampling_across_ranks(mnv, torch_gpu, tmp_path, fake_
         assert a == open(f"{dist}_{f:04d}.f32", "rb").read(), f
         assert open(f"{one}_{f:04d}.ppm", "rb").read() == open(f"{dist}_{f:04d}.ppm", "rb").read(), f
         assert a != open(f"{plain}_{f:04d}.f32", "rb").read()     # the networks' colours, not the tree's
+    if world == 1:
+        # --guided_in_flight: the same frames, three in flight on HIP streams; the sample counts arrive when a frame is written
+        flight = str(tmp_path / "flight")
+        r4 = subprocess.run(common + ["--out", flight, "--guided_in_flight"], capture_output=True, text=True, timeout=600)
+        assert r4.returncode == 0 and "guided samples: in flight" in r4.stdout and "(3 in flight" in r4.stdout, r4.stderr + r4.stdout
+        counts = lambda out: sorted(re.findall(r"frame (\d+):.*guided samples (\d+)", out))
+        assert counts(r4.stdout) == counts(r1.stdout) and len(counts(r1.stdout)) == frames
+        for f in range(frames):
+            assert open(f"{one}_{f:04d}.f32", "rb").read() == open(f"{flight}_{f:04d}.f32", "rb").read(), f
 
 
 @pytest.mark.parametrize("world,guided", [(1, False), (3, False), (3, True), (8, True)])

@@ -384,3 +384,41 @@ def test_fused_frames_in_flight_on_several_streams(mnv, torch_gpu):
     assert torch.equal(flight.view(torch.int32), alone.view(torch.int32))
     assert int(counter.item()) == 2 * total and total > 1_000_000
     assert mnv.accel_fused_faults(tree.accel) == 0
+
+
+def test_volume_renderer_guided_frames_in_flight(mnv, torch_gpu, fused_kernel):
+    """VolumeRenderer::guided_in_flight: guided-sampling frames that change nothing rotate over the frame slots; every frame and its sample
+    count equal what the one-at-a-time renderer gives for the same camera, and a frame that cannot overlap (splitting switched on) falls back
+    to slot 0 with its count in the stats."""
+    from test_renderer_refine_gpu import setup
+
+    poses = [((-3.0 + 0.1 * k, 2.0, 5.0 - 0.1 * k), (-0.45, 0.3, 0.75)) for k in range(7)]
+    serial = []
+    r, tree, desc, params, cam_spec = setup(mnv, "sh9_d7_aniso", 400000, use_guided_sampling=True, max_guided_samples=24)
+    for center, back in poses:
+        r.set_camera(center, back, fx=cam_spec["fx"])
+        st = r.render()
+        assert st["fused"] == 1 and st["guided_samples"] > 0 and r.last_slot() == 0
+        serial.append((r.download(), st["guided_samples"]))
+    r, tree, desc, params, cam_spec = setup(mnv, "sh9_d7_aniso", 400000, use_guided_sampling=True, max_guided_samples=24)
+    r.set_guided_in_flight(True)
+    r.set_frames_in_flight(3)
+    slots = []
+    for center, back in poses:
+        r.set_camera(center, back, fx=cam_spec["fx"])
+        st = r.render()
+        assert st["fused"] == 1 and st["used_accel"] == 1 and st["guided_samples"] == -1
+        slots.append(r.last_slot())
+        if len(slots) >= 3:  # frame k is read once frames k + 1 and k + 2 have been issued
+            k = len(slots) - 3
+            assert r.slot_guided_samples(slots[k]) == serial[k][1]
+            assert np.array_equal(cases.bits(r.download_slot(slots[k])), cases.bits(serial[k][0])), k
+    assert slots[:4] == [1, 2, 0, 1]
+    for k in (len(poses) - 2, len(poses) - 1):
+        assert r.slot_guided_samples(slots[k]) == serial[k][1]
+        assert np.array_equal(cases.bits(r.download_slot(slots[k])), cases.bits(serial[k][0])), k
+    # a frame that edits the tree does not overlap
+    r.options.use_splitting, r.options.max_depth = True, 9
+    st = r.render()
+    assert r.last_slot() == 0 and st["guided_samples"] > 0 and st["split_candidates"] > 0
+    assert r.slot_guided_samples(0) == st["guided_samples"]
