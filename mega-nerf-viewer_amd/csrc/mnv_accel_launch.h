@@ -1,0 +1,176 @@
+// mnv_accel_launch.h -- what the translation units of the packed-layout ("accel") path share: the launch block of the march
+// kernels, the row / lookup-grid index helpers, the tracker block of a launch and the functions that cross the unit boundaries.
+//   mnv_accel_build.hip          build kernels, mnv_accel_create / _rebuild / _destroy
+//   mnv_accel_refresh_prune.hip  mnv_accel_refresh (patch after a refinement step), accel_apply_prune (the layout follows a prune)
+//   mnv_march_accel_kernel.h     march_accel_kernel (the tuned march), instantiated by mnv_accel_march.hip
+//   mnv_guided_fused*.h          the guided-sampling frame as one kernel, instantiated by mnv_accel_fused.hip
+//   mnv_accel_capi.hip           launch planning (launch_accel), tile assembly, the C-ABI entry points
+#pragma once
+
+#include "mnv_accel.h"
+#include "mnv_internal.h"
+#include "mnv_mlp.h"
+
+namespace mnv {
+
+// Brick-ordered index of cell (cx,cy,cz) of the level-L2 grid: 4x4x4-cell bricks (256 B) in
+// row-major brick order, so that the cells neighbouring rays touch share cache lines.
+__host__ __device__ __forceinline__ uint32_t grid2_index(uint32_t cx, uint32_t cy, uint32_t cz, int L2) {
+    const int LB = L2 - 2;
+    const uint32_t brick = (((((cx >> 2) << LB) + (cy >> 2))) << LB) + (cz >> 2);
+    return (brick << 6) | ((cx & 3u) << 4) | ((cy & 3u) << 2) | (cz & 3u);
+}
+
+struct AccelLaunch {
+    FrameParams P;   // tile, options, outputs (P.cam is unused: cameras come from `cams`)
+    AccelView A;
+    const CamBlock *__restrict__ cams;  // [n_frames] device array (written by stage_launch_kernel)
+    uint32_t n_frames;
+    uint32_t frame_stride_px;  // pixels between consecutive frames in the output buffers
+    uint32_t *queue;           // [kNumQueues] heads, 64 B apart; queue q = band q of every frame, frame-major
+    uint32_t tiles_x, n_tiles;
+    uint32_t tile_wlog;                   // log2 of the ray-tile width (tile = 2^wlog x 2^(6-wlog) pixels, 8x8 by default)
+    uint32_t band_begin[kNumQueues + 1];  // tile ranges per queue
+    int32_t lds_level;                    // levels staged in LDS (<= A.grid_level)
+    int32_t refill_min;                   // refill a wavefront once this many lanes are idle
+    // interleaved macro-tile partition (part_world = 0: plain tile)
+    int32_t part_rank, part_world, part_period;  // part_period: mnv_partition.root_period
+    uint32_t macro_w, macro_h;            // macro tile size in pixels
+    uint32_t macros_x;                    // macro tiles per row of the rectangle
+    uint32_t micro_x, micro_per_macro;    // 8x8 micro tiles per macro-tile row / per macro tile
+    unsigned long long *stats;            // MODE 1 only: 16 counters
+    int32_t count_stats;                  // MODE 1 only: 0 = ablation run without the counters' atomics
+    unsigned long long *timeline;         // MODE 1 only (MNV_TIMELINE): per tile {t_grab, t_done, wave, iterations}, then per wave {t_entry, t_exit} (100 MHz ticks)
+    uint32_t timeline_tiles;              // tile records (n_tiles * n_frames)
+    // MODE 2 only: refinement trackers (rt_core.cuh:179-180,237-252,308-321), indexed like the pixels
+    float *split_track, *sample_track;
+    const int16_t *sample_counts;         // reference layout [capacity][8], may be NULL
+    int32_t max_depth, max_sample_count;
+    int32_t *visited;                     // MODE 2 / 3 only: visit marks [capacity]; the march marks the chunk of every leaf it steps through,
+                                          // close_visit_marks adds the ancestors (= every chunk of every descent, rt_core.cuh:132-134)
+    int32_t ablate;                       // diagnostics only (breaks results): 1 no colour, 2 no dense samples, 4 cached rows
+    // MODE 3 only: the sample-emitting march of guided sampling (rt_core.cuh:418-576) -- no colour, rows of
+    // (z, world xyz[, view dir][, embedding]) per dense step and the trackers of MODE 2
+    int32_t max_guided_samples, samples_dim, need_viewdir, appearance_embedding;
+    int16_t *num_samples;
+    float *samples;
+    int16_t *cluster_indices;
+    int32_t grid_dim[2];
+    float min_position[3], range[3];
+};
+
+// ray id -> pixel of the rectangle (bx, by) and index of the pixel in the output buffer
+__device__ __forceinline__ bool ray_pixel(const AccelLaunch &K, uint32_t id, int &bx, int &by, uint32_t &pix) {
+    const uint32_t tile = id >> 6, w = id & 63u;
+    if (K.part_world < 1) {
+        const uint32_t tx = tile % K.tiles_x, ty = tile / K.tiles_x;
+        bx = (int)((tx << K.tile_wlog) + (w & ((1u << K.tile_wlog) - 1u)));
+        by = (int)((ty << (6 - K.tile_wlog)) + (w >> K.tile_wlog));
+        pix = (uint32_t)by * (uint32_t)K.P.tw + (uint32_t)bx;
+    } else {
+        const uint32_t j = tile / K.micro_per_macro, u = tile % K.micro_per_macro;
+        const uint32_t mx = u % K.micro_x, my = u / K.micro_x;
+        const uint32_t m = part_tile_of(j, K.part_rank, K.part_world, K.part_period);
+        const uint32_t MX = m % K.macros_x, MY = m / K.macros_x;
+        const uint32_t lx = mx * 8 + (w & 7u), ly = my * 8 + (w >> 3);
+        bx = (int)(MX * K.macro_w + lx);
+        by = (int)(MY * K.macro_h + ly);
+        pix = (j * K.macro_h + ly) * K.macro_w + lx;
+    }
+    return bx < K.P.tw && by < K.P.th;
+}
+
+__device__ __forceinline__ float lane_read(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ uint32_t lane_read(uint32_t v, int src_lane) {
+    return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
+
+// bytes of one colour channel block of a packed row: basis_dim halfs padded to a whole dword
+__host__ __device__ constexpr int chan_bytes_for(int basis) { return basis > 0 ? ((2 * basis + 3) / 4) * 4 : 4; }
+// bytes of a packed row: three channel blocks rounded up to a power of two (16 ... 256), so that a
+// row never straddles a 128-B cache line (SH9: 3 * 20 = 60 -> 64 B)
+__host__ __device__ constexpr int row_bytes_pow2(int basis) {
+    if (basis <= 0) return 8;
+    int r = 16;
+    while (r < 3 * chan_bytes_for(basis)) r *= 2;
+    return r;
+}
+// channel block as dwords with 4-byte alignment (the compiler picks the widest legal loads)
+template <int N>
+struct __attribute__((packed, aligned(4))) ChanWords {
+    uint32_t w[N];
+};
+
+// Columns per network run of guided_fused_kernel: W = 16 * MNV_FUSED_NT samples; 64 / W lanes share a column in the per-column phases
+// (encode, evaluation).  NT = 4: 64 accumulator + 32 activation registers -> 254 VGPRs, 2 wavefronts per SIMD.  NT = 2: half of that ->
+// 3 wavefronts per SIMD (168 VGPRs), which is what the march part of the kernel wants; the weights are then fetched twice per 64 samples.
+#ifndef MNV_FUSED_NT
+#define MNV_FUSED_NT 4
+#endif
+constexpr int kFNT = MNV_FUSED_NT, kFW = 16 * kFNT, kFParts = 64 / kFW;  // column tiles, columns and lanes per column of a run
+
+struct FusedGuided {
+    MlpShape S;
+    const uint16_t *frags;       // [n_clusters][frag_halfs]
+    const float *biases;         // [n_clusters][bias_floats]
+    const uint16_t *embeddings;  // [n_clusters][n_embeddings][embedding_dim]
+    int32_t grid_dim[2];
+    float min_position[3], range[3];
+    int32_t max_guided_samples, appearance_embedding;
+    int32_t batch_min;           // run the network once this many samples wait in a wavefront's pool (1 .. 64)
+    unsigned long long *sample_counter;  // += samples evaluated (one atomic per wavefront); ONE word
+    unsigned long long *diag;            // diagnostics (mnv_set_fused_diag, 32 words of the caller's): NULL = none
+    uint32_t *fault;                     // the accel's fault word: += 1 per wavefront that abandons a spin-wait (never NULL)
+    int32_t switch_min;                  // guided_fused2_kernel: a consumer stays with its last sub-module while this many of its samples wait
+    int32_t weight_slots;                // guided_fused2_kernel: sub-modules whose weights a workgroup keeps in LDS (<= kF2NS, what fits)
+};
+
+// wavefronts per SIMD the march kernel is built for (= workgroups of 256 threads per CU)
+#ifndef MNV_TRACK_WAVES
+#define MNV_TRACK_WAVES 6  // tracker / sample modes carry six more live values per ray
+#endif
+#ifndef MNV_MIN_WAVES
+#define MNV_MIN_WAVES 8  // register budget for 8 waves per SIMD: the few spills land in the ray set-up (A/B in DESIGN.md)
+#endif
+
+// world > 1, or a single rank that asks for the macro-tile-major layout by naming a tile size
+inline bool is_partitioned(mnv_partition part) { return part.world > 1 || (part.world == 1 && part.tile_w > 0); }
+inline int32_t root_period_of(mnv_partition part) { return part.world > 1 && part.root_period >= 2 ? part.root_period : 0; }
+inline int row_bytes_for(int basis) { return row_bytes_pow2(basis); }
+
+// Refinement trackers of one launch (all device pointers; rows indexed like the pixels).
+struct AccelTrack {
+    float *split_track, *sample_track;
+    const int16_t *sample_counts;
+    int32_t max_depth, max_sample_count;
+    // sample emission (MODE 3) when samples != NULL
+    int16_t *num_samples;
+    float *samples;
+    int16_t *cluster_indices;
+    int32_t max_guided_samples, samples_dim, need_viewdir, appearance_embedding;
+    const mnv_cluster_grid *grid;
+    const FusedGuided *fused;  // non-NULL: guided_fused_kernel instead of the march (no trackers, one frame)
+    int32_t *visited;          // visit marks (tracker / sample modes) ...
+    const int32_t *parent;     // ... closed under the parent words after the march
+};
+
+constexpr int kUnsupportedBasis = -1000;  // not a hipError_t
+
+// (Re)build every derived array of `a` from the tree (mnv_accel_build.hip)
+int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream);
+// the two lookup grids, whole, from the node words (mnv_accel_build.hip; the refresh rebuilds the small one, or both without a parent array)
+void launch_pack_rows(const uint16_t *data, uint16_t *rows, int64_t nvox, int32_t data_dim, int32_t per_chan, int32_t chan_halfs, int32_t row_halfs,
+                      hipStream_t stream);
+void launch_build_grid(const uint32_t *nodes, uint32_t *grid, uint32_t *grid_vox, int32_t L, hipStream_t stream);
+void launch_build_grid2(const uint32_t *nodes, uint32_t *grid2, uint32_t *grid2_vox, int32_t L2, hipStream_t stream);
+// march_accel_kernel for the row format `basis` (-1 RGBA, 1 / 4 / 9 / 16 / 25 SH) in the mode the launch block asks for
+// (mnv_accel_march.hip); kUnsupportedBasis or a hipError_t
+int launch_march(const AccelLaunch &K, int basis, bool colourless, int n_blocks, size_t lds_bytes, hipStream_t stream);
+// guided_fused2_kernel / guided_fused_kernel (mnv_accel_fused.hip); kUnsupportedBasis or a hipError_t
+int launch_fused(const mnv_accel *accel, const AccelLaunch &K, const FusedGuided &fused, int basis, int lds_level, uint64_t n_waves_needed,
+                 hipStream_t stream);
+unsigned long long *fused_diag_words();  // mnv_set_fused_diag
+
+}  // namespace mnv

@@ -1,5 +1,5 @@
 // mnv_guided_fused.h -- the guided-sampling frame as ONE kernel (BASELINE.json configs[4]: "per-sample tiny-MLP fused into
-// the HIP march kernel").  Included by mnv_march_accel.hip (it shares AccelLaunch, the ray queues and the launch slots).
+// the HIP march kernel").  Instantiated by mnv_accel_fused.hip (it shares AccelLaunch, the ray queues and the launch slots with the march).
 //
 // What the reference does with four steps and three global buffers per frame (src/renderer/cuda_renderer.cpp:107-139):
 //     get_samples_from_voxels   rt_core.cuh:418-576     every dense march step emits (z, world xyz[, dir][, embedding])
@@ -25,38 +25,16 @@
 // -- the first version -- filled 23 of 64 columns on average: passes per tile = samples of its longest ray).
 #pragma once
 
+#include "mnv_accel_launch.h"
 #include "mnv_mlp.h"
 
 #pragma clang fp contract(off)
 
 namespace mnv {
 
-struct FusedGuided {
-    MlpShape S;
-    const uint16_t *frags;       // [n_clusters][frag_halfs]
-    const float *biases;         // [n_clusters][bias_floats]
-    const uint16_t *embeddings;  // [n_clusters][n_embeddings][embedding_dim]
-    int32_t grid_dim[2];
-    float min_position[3], range[3];
-    int32_t max_guided_samples, appearance_embedding;
-    int32_t batch_min;           // run the network once this many samples wait in a wavefront's pool (1 .. 64)
-    unsigned long long *sample_counter;  // += samples evaluated (one atomic per wavefront); ONE word
-    unsigned long long *diag;            // diagnostics (mnv_set_fused_diag, 32 words of the caller's): NULL = none
-    uint32_t *fault;                     // the accel's fault word: += 1 per wavefront that abandons a spin-wait (never NULL)
-    int32_t switch_min;                  // guided_fused2_kernel: a consumer stays with its last sub-module while this many of its samples wait
-    int32_t weight_slots;                // guided_fused2_kernel: sub-modules whose weights a workgroup keeps in LDS (<= kF2NS, what fits)
-};
-
-// Columns per network run: W = 16 * MNV_FUSED_NT samples; 64 / W lanes share a column in the per-column phases (encode, evaluation).
-// NT = 4: 64 accumulator + 32 activation registers -> 254 VGPRs, 2 wavefronts per SIMD.  NT = 2: half of that -> 3 wavefronts per
-// SIMD (168 VGPRs), which is what the march part of the kernel wants; the weights are then fetched twice per 64 samples (from L2).
-#ifndef MNV_FUSED_NT
-#define MNV_FUSED_NT 4
-#endif
 #ifndef MNV_FUSED_WAVES
 #define MNV_FUSED_WAVES (MNV_FUSED_NT >= 4 ? 2 : (MNV_FUSED_NT == 2 ? 3 : 4))  // workgroups per CU = wavefronts per SIMD
 #endif
-constexpr int kFNT = MNV_FUSED_NT, kFW = 16 * kFNT, kFParts = 64 / kFW;  // column tiles, columns and lanes per column of a run
 
 constexpr int kFRayRows = 3 + 3 + 5;  // per-ray LDS rows besides the SH basis: view direction, world-space unit direction, held-back sample
 // LDS of one 256-thread workgroup: exp table (256 B) | top-of-tree grid ((2^lds_level)^3 words) | per-ray constants

@@ -1,5 +1,5 @@
 // mnv_guided_fused2.h -- the guided-sampling frame as ONE kernel with SPECIALISED wavefronts (BASELINE.json configs[4]).
-// Included by mnv_march_accel.hip after mnv_guided_fused.h, whose kernel (one wavefront does both jobs) it replaces wherever the
+// Included by mnv_accel_fused.hip after mnv_guided_fused.h, whose kernel (one wavefront does both jobs) it replaces wherever the
 // network's weights fit a workgroup's LDS; that kernel stays as the path for deeper networks and as a second checker.
 //
 // Same four reference steps (src/renderer/cuda_renderer.cpp:107-139: get_samples_from_voxels rt_core.cuh:418-576, cumsum / masks,

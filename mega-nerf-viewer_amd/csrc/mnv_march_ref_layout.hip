@@ -18,7 +18,7 @@
 //    refinement does, and is not asked to say so;
 //  * smaller launches (and when the scratch allocation fails): each workgroup derives the level-3 table itself.
 // The tuned path (packed layout, LDS top grid, persistent waves) is
-// mnv_march_accel.hip; both produce bit-identical pixels.
+// mnv_march_accel_kernel.h; both produce bit-identical pixels.
 #include <atomic>
 
 #include "mnv_device.h"
