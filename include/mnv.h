@@ -146,6 +146,23 @@ int mnv_render_voxels(const mnv_tree_view *tree, const mnv_camera *cam, const mn
                       float *sample_track, int32_t *visited, int track_visit, void *hip_stream);
 
 /*
+ * The reference's LIVE call shape.  VolumeRenderer::Impl::render passes offscreen == false to all three launchers
+ * (src/renderer/cuda_renderer.cpp:111-113,135-136,141-142): the kernels then read, per pixel, a ray limit from the depth attachment
+ * (float t_max = surf2Dread(surf_obj_depth), renderer_kernel.cu:277-280,354-357) and composite over the pixel that is already in
+ * the image instead of over background_brightness (renderer_kernel.cu:230-234,260-264) -- how the volume goes behind / in front of
+ * the wireframe mesh the GL pass drew.  The two cudaArray_t attachments become two linear device arrays, indexed like the outputs:
+ */
+typedef struct mnv_frame_inputs {
+    const float *tmax_px;       /* device float [tile.h][tile.w]: t_max of every pixel; NULL = 1e9f everywhere (offscreen == true) */
+    const uint8_t *rgba8_init;  /* device uint8 [tile.h][tile.w][4]: the image under the volume; NULL = background_brightness
+                                   (offscreen == true).  May be the same buffer as rgba8_out (the reference reads and writes one surface). */
+} mnv_frame_inputs;
+/* mnv_render_voxels with the inputs of offscreen == false; inputs == NULL (or both members NULL) is mnv_render_voxels exactly. */
+int mnv_render_voxels_ex(const mnv_tree_view *tree, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                         const mnv_frame_inputs *inputs, float *rgba_out, uint8_t *rgba8_out, float *split_track, float *sample_track,
+                         int32_t *visited, int track_visit, void *hip_stream);
+
+/*
  * Packed device re-layout of a tree ("accel"): one 32-bit word per voxel
  * (child link or leaf sigma), colour rows padded to 64 B, plus a dense
  * top-of-tree lookup grid.  Built once per tree upload -- the counterpart of
@@ -182,6 +199,9 @@ int32_t mnv_accel_grid2_level(const mnv_accel *accel);
 int mnv_accel_set_cu_budget(mnv_accel *accel, int32_t num_cus);
 int mnv_render_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt,
                             mnv_rect tile, float *rgba_out, uint8_t *rgba8_out, void *hip_stream);
+/* the same with the per-pixel inputs of the reference's offscreen == false call shape (mnv_frame_inputs above) */
+int mnv_render_voxels_accel_ex(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                               const mnv_frame_inputs *inputs, float *rgba_out, uint8_t *rgba8_out, void *hip_stream);
 
 /*
  * Interleaved macro-tile partition of `tile` for multi-GPU rendering: the
@@ -233,6 +253,11 @@ void mnv_set_ref_table_min_rays(int64_t min_rays);
  * (no trackers, no visit marks: those always walk the arrays).  Frames are bit-identical either way.
  *   THE RULE: after changing the contents of a cached tree's arrays in place, call mnv_tree_invalidate(child) (NULL: every tree) before the
  *   next frame; a tree that moved or grew (other addresses, other capacity) is a new tree by itself.  Both calls wait for the device.
+ *   FREEING a cached tree's arrays counts as changing them: an allocator that hands the same addresses to the next tree of the same
+ *   capacity and row format (torch's caching allocator does) would otherwise be answered with the old tree's frames -- invalidate when a
+ *   tree dies.  offset / scale are not part of a tree's identity: every frame uses the ones of the view it was called with.
+ *   A tree whose re-layout cannot be built (deeper than 23 levels, out of memory) is remembered as such and rendered on the stateless
+ *   path without another attempt until it is invalidated.
  * Memory: the re-layout is about 3.6 x the tree (cfg2: 2.6 GB beside 0.72 GB).
  */
 void mnv_set_tree_cache(int enable);

@@ -55,8 +55,27 @@ inline mnv_camera mnv_view(const Camera &c) {
 
 static_assert(sizeof(RenderOptions) == sizeof(mnv_render_options), "RenderOptions and mnv_render_options are the same POD");
 
-// Replacement body of viewer::render_voxels (src/cuda/renderer_kernel.cu:396-437) for a build without GL interop: the two
-// cudaArray_t targets become a linear float RGBA image (and / or RGBA8) in device memory.
+// Replacement body of viewer::render_voxels (src/cuda/renderer_kernel.cu:396-437) with its ORIGINAL eleven parameters
+// (include/cuda/renderer_kernel.hpp:23-34); what changes is the type of the two render targets: a build without CUDA-GL interop has no
+// cudaArray_t, so image_arr is a linear RGBA8 image in device memory ([height][width][4], read AND written like the surface) and depth_arr
+// a linear float depth image ([height][width]).  offscreen is honoured as the kernel honours it (renderer_kernel.cu:225-234,260-264,
+// 277-280): true = composite over opt.background_brightness with t_max = 1e9f, false = over the pixels already in image_arr with
+// t_max from depth_arr -- the only way cuda_renderer.cpp:141-142 calls it.
+inline void render_voxels(N3Tree &tree, const Camera &cam, const RenderOptions &opt, uint8_t *&image_arr /* was cudaArray_t& */,
+                          float *&depth_arr /* was cudaArray_t& */, hipStream_t &stream, const torch::Tensor &to_split,
+                          const torch::Tensor &to_sample, const torch::Tensor &visited, const bool track_visit, const bool offscreen) {
+    const mnv_tree_view tv = mnv_view(tree);
+    const mnv_camera cv = mnv_view(cam);
+    const mnv_rect full{0, 0, cam.width, cam.height};
+    const mnv_frame_inputs in{offscreen ? nullptr : depth_arr, offscreen ? nullptr : image_arr};
+    const int rc = mnv_render_voxels_ex(&tv, &cv, reinterpret_cast<const mnv_render_options *>(&opt), full, &in, nullptr, image_arr,
+                                        to_split.defined() ? to_split.data_ptr<float>() : nullptr,
+                                        to_sample.defined() ? to_sample.data_ptr<float>() : nullptr,
+                                        visited.defined() ? visited.data_ptr<int32_t>() : nullptr, track_visit ? 1 : 0, (void *)stream);
+    if (rc != MNV_OK) throw std::runtime_error(mnv_last_error());  // instead of cuda_assert's exit()
+}
+
+// The same launcher for the offline batch render (north star: no window): linear float RGBA (and / or RGBA8) out, offscreen.
 inline void render_voxels(N3Tree &tree, const Camera &cam, const RenderOptions &opt, float *rgba_linear, uint8_t *rgba8_linear,
                           void *stream, float *to_split, float *to_sample, int32_t *visited, bool track_visit) {
     const mnv_tree_view tv = mnv_view(tree);
@@ -64,7 +83,7 @@ inline void render_voxels(N3Tree &tree, const Camera &cam, const RenderOptions &
     const mnv_rect full{0, 0, cam.width, cam.height};
     const int rc = mnv_render_voxels(&tv, &cv, reinterpret_cast<const mnv_render_options *>(&opt), full, rgba_linear, rgba8_linear, to_split,
                                      to_sample, visited, track_visit ? 1 : 0, stream);
-    if (rc != MNV_OK) throw std::runtime_error(mnv_last_error());  // instead of cuda_assert's exit()
+    if (rc != MNV_OK) throw std::runtime_error(mnv_last_error());
 }
 
 // The tuned path: build once where the reference calls tree->move_to_device (cuda_renderer.cpp:498-505) ...
@@ -75,7 +94,17 @@ inline mnv_accel *make_accel(N3Tree &tree, long max_tree_capacity, void *stream)
     return accel;
 }
 
-// ... and render with it (no refinement active)
+// ... and render with it (no refinement active); the eleven-parameter shape on the packed layout:
+inline void render_voxels(const mnv_accel *accel, const Camera &cam, const RenderOptions &opt, uint8_t *&image_arr, float *&depth_arr,
+                          hipStream_t &stream, const bool offscreen) {
+    const mnv_camera cv = mnv_view(cam);
+    const mnv_rect full{0, 0, cam.width, cam.height};
+    const mnv_frame_inputs in{offscreen ? nullptr : depth_arr, offscreen ? nullptr : image_arr};
+    if (mnv_render_voxels_accel_ex(accel, &cv, reinterpret_cast<const mnv_render_options *>(&opt), full, &in, nullptr, image_arr, (void *)stream) != MNV_OK)
+        throw std::runtime_error(mnv_last_error());
+}
+
+// the offline shape
 inline void render_voxels(const mnv_accel *accel, const Camera &cam, const RenderOptions &opt, float *rgba_linear, uint8_t *rgba8_linear,
                           void *stream) {
     const mnv_camera cv = mnv_view(cam);

@@ -114,6 +114,11 @@ class Rect(C.Structure):
     _fields_ = [("x0", C.c_int32), ("y0", C.c_int32), ("w", C.c_int32), ("h", C.c_int32)]
 
 
+class FrameInputs(C.Structure):
+    """mnv_frame_inputs: the per-pixel arrays of the reference's offscreen == false call shape (device pointers, either may be NULL)."""
+    _fields_ = [("tmax_px", C.c_void_p), ("rgba8_init", C.c_void_p)]
+
+
 class Partition(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("tile_w", C.c_int32), ("tile_h", C.c_int32), ("root_period", C.c_int32)]
 
@@ -190,6 +195,10 @@ _SIGNATURES = {
     "mnv_camera_set_pose": (None, [C.POINTER(CameraStruct), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "mnv_render_voxels": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mnv_render_voxels_ex": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.POINTER(FrameInputs),
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "mnv_render_voxels_accel_ex": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.POINTER(FrameInputs),
+                                             C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_accel_create": (C.c_int, [C.POINTER(TreeView), C.c_void_p, C.POINTER(C.c_void_p)]),
     "mnv_accel_create_reserved": (C.c_int, [C.POINTER(TreeView), C.c_int64, C.c_void_p, C.POINTER(C.c_void_p)]),
     "mnv_accel_refresh": (C.c_int, [C.c_void_p, C.POINTER(TreeView), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
@@ -533,11 +542,29 @@ def _ptr(t) -> Optional[int]:
     return t.data_ptr()
 
 
+def _frame_inputs(tmax_px, rgba8_init, pixels: int):
+    """mnv_frame_inputs of the reference's offscreen == false call shape, or None when neither array is given."""
+    if tmax_px is None and rgba8_init is None:
+        return None
+    import torch
+
+    if tmax_px is not None and (not tmax_px.is_cuda or not tmax_px.is_contiguous() or tmax_px.dtype != torch.float32 or tmax_px.numel() < pixels):
+        raise MnvError(MNV_E_INVALID, f"tmax_px must be a contiguous float32 device tensor with at least {pixels} elements")
+    _check_out("rgba8_init", rgba8_init, pixels, "u8")
+    return FrameInputs(tmax_px.data_ptr() if tmax_px is not None else None, rgba8_init.data_ptr() if rgba8_init is not None else None)
+
+
 def render_voxels(tree_view: TreeView, cam: Camera, opt: RenderOptions, tile=None, rgba=None, rgba8=None,
-                  split_track=None, sample_track=None, visited=None, track_visit=False, stream: int = 0) -> None:
-    """viewer::render_voxels on reference-layout device arrays (asynchronous on `stream`)."""
+                  split_track=None, sample_track=None, visited=None, track_visit=False, stream: int = 0, tmax_px=None, rgba8_init=None) -> None:
+    """viewer::render_voxels on reference-layout device arrays (asynchronous on `stream`).  tmax_px / rgba8_init: the depth attachment and
+    the image under the volume of the reference's offscreen == false call shape (indexed like the outputs; rgba8_init may be rgba8)."""
     if tile is None:
         tile = (0, 0, cam.width, cam.height)
+    inputs = _frame_inputs(tmax_px, rgba8_init, tile[2] * tile[3])
+    if inputs is not None:
+        _check(lib().mnv_render_voxels_ex(C.byref(tree_view), C.byref(cam.c), C.byref(opt), Rect(*tile), C.byref(inputs), _ptr(rgba), _ptr(rgba8),
+                                          _ptr(split_track), _ptr(sample_track), _ptr(visited), int(track_visit), C.c_void_p(stream)))
+        return
     _check(lib().mnv_render_voxels(C.byref(tree_view), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba), _ptr(rgba8),
                                    _ptr(split_track), _ptr(sample_track), _ptr(visited), int(track_visit), C.c_void_p(stream)))
 
@@ -589,12 +616,18 @@ def _pixels(tile, n_frames: int, part) -> int:
     return n_frames * j_max * tw * th
 
 
-def render_voxels_accel(accel: int, cam: Camera, opt: RenderOptions, tile=None, rgba=None, rgba8=None, stream: int = 0) -> None:
-    """The tuned march on the packed layout (asynchronous on `stream`)."""
+def render_voxels_accel(accel: int, cam: Camera, opt: RenderOptions, tile=None, rgba=None, rgba8=None, stream: int = 0, tmax_px=None,
+                        rgba8_init=None) -> None:
+    """The tuned march on the packed layout (asynchronous on `stream`); tmax_px / rgba8_init as in render_voxels."""
     if tile is None:
         tile = (0, 0, cam.width, cam.height)
     _check_out("rgba", rgba, tile[2] * tile[3], "f32")
     _check_out("rgba8", rgba8, tile[2] * tile[3], "u8")
+    inputs = _frame_inputs(tmax_px, rgba8_init, tile[2] * tile[3])
+    if inputs is not None:
+        _check(lib().mnv_render_voxels_accel_ex(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), C.byref(inputs), _ptr(rgba),
+                                                _ptr(rgba8), C.c_void_p(stream)))
+        return
     _check(lib().mnv_render_voxels_accel(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba), _ptr(rgba8),
                                          C.c_void_p(stream)))
 

@@ -291,9 +291,11 @@ int mnv_render_voxels_accel_part(const mnv_accel *accel, const mnv_camera *cam, 
     return mnv_render_voxels_accel_batch(accel, cam, 1, opt, tile, part, rgba_out, rgba8_out, hip_stream);
 }
 
+// inputs: the per-pixel arrays of the reference's offscreen == false call shape (NULL: offscreen).  xform: offset[3] + scale[3] of the
+// caller's tree view when they may differ from the ones the accel was built with (the tree cache of mnv_render_voxels), else NULL.
 static int render_accel(const mnv_accel *accel, const mnv_camera *cams, int32_t n_cams, const mnv_render_options *opt,
                         mnv_rect tile, mnv_partition part, float *rgba_out, uint8_t *rgba8_out, const AccelTrack *track,
-                        void *hip_stream) {
+                        void *hip_stream, const mnv_frame_inputs *inputs = nullptr, const float *xform = nullptr) {
     if (!accel) return set_error(MNV_E_INVALID, "accel is null");
     if (!cams || n_cams < 1 || n_cams > MNV_MAX_BATCH) return set_error(MNV_E_INVALID, "need 1 .. MNV_MAX_BATCH cameras");
     if (is_partitioned(part) && (part.rank < 0 || part.rank >= part.world || part.tile_w < 8 || part.tile_h < 8 ||
@@ -309,10 +311,14 @@ static int render_accel(const mnv_accel *accel, const mnv_camera *cams, int32_t 
     // pixel indices of a launch are 32 bits wide (frame f starts at f * pixels per frame)
     if ((uint64_t)(tile.w > 0 ? tile.w : 0) * (uint64_t)(tile.h > 0 ? tile.h : 0) * (uint64_t)n_cams > 0xffffffffull)
         return set_error(MNV_E_UNSUPPORTED, "more than 2^32 pixels in one launch: render fewer frames per call");
-    std::memcpy(P.offset, accel->view.offset, sizeof(P.offset));
-    std::memcpy(P.scale, accel->view.scale, sizeof(P.scale));
+    std::memcpy(P.offset, xform ? xform : accel->view.offset, sizeof(P.offset));
+    std::memcpy(P.scale, xform ? xform + 3 : accel->view.scale, sizeof(P.scale));
     P.rgba = rgba_out;
     P.rgba8 = rgba8_out;
+    if (inputs) {
+        P.tmax_px = inputs->tmax_px;
+        P.rgba8_init = inputs->rgba8_init;
+    }
     CamBlock blocks[MNV_MAX_BATCH];
     for (int i = 0; i < n_cams; ++i) {
         fill_camera(blocks[i], &cams[i]);
@@ -323,6 +329,12 @@ static int render_accel(const mnv_accel *accel, const mnv_camera *cams, int32_t 
     rc = launch_accel(accel, P, blocks, n_cams, part, track, stream);
     if (rc == kUnsupportedBasis) return set_error(MNV_E_UNSUPPORTED, "unsupported basis_dim for the accel path");
     return check_hip((hipError_t)rc, "march_accel_kernel");
+}
+
+int mnv_render_voxels_accel_ex(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                               const mnv_frame_inputs *inputs, float *rgba_out, uint8_t *rgba8_out, void *hip_stream) {
+    const mnv_partition whole = {0, 1, 0, 0, 0};
+    return render_accel(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, nullptr, hip_stream, inputs);
 }
 
 int mnv_render_voxels_accel_batch(const mnv_accel *accel, const mnv_camera *cams, int32_t n_cams,
@@ -517,3 +529,14 @@ static int guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv
 }
 
 }  // extern "C"
+
+namespace mnv {
+int render_accel_for_tree(const mnv_accel *accel, const mnv_tree_view *tree, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                          const mnv_frame_inputs *inputs, float *rgba_out, uint8_t *rgba8_out, hipStream_t stream) {
+    float xform[6];
+    std::memcpy(xform, tree->offset, sizeof(tree->offset));
+    std::memcpy(xform + 3, tree->scale, sizeof(tree->scale));
+    const mnv_partition whole = {0, 1, 0, 0, 0};
+    return render_accel(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, nullptr, (void *)stream, inputs, xform);
+}
+}  // namespace mnv

@@ -223,7 +223,9 @@ struct CachedTree {
     const void *child = nullptr, *data = nullptr;
     int32_t capacity = 0, data_dim = 0, basis_dim = 0, format = 0;
     int device = 0;
-    mnv_accel *accel = nullptr;
+    bool used = false;            // the entry names a tree
+    mnv_accel *accel = nullptr;   // NULL in a used entry: the re-layout of this tree could not be built (deeper than the packed layout goes,
+                                  // out of memory) -- remembered, so that the build is not retried with every frame (mnv_tree_invalidate forgets)
     hipEvent_t built = nullptr;   // recorded on the stream that built the re-layout; launches on other streams wait for it
     hipStream_t build_stream = nullptr;
     uint64_t stamp = 0;
@@ -255,12 +257,14 @@ void mnv_set_tree_cache(int enable) {
 void mnv_tree_invalidate(const void *child) {
     std::lock_guard<std::mutex> lk(g_cache_mu);
     for (auto &e : g_cache)
-        if (e.accel && (!child || e.child == child)) drop(e);
+        if (e.used && (!child || e.child == child)) drop(e);
 }
 
 // the cached re-layout of `tree` (built on `stream` at the first call), or NULL when this frame must take the stateless path.
 // Called with g_cache_mu held, and the caller launches its frame before releasing it: an eviction on another thread (drop: device-wide
-// wait, then destroy) can then never fall between the look-up and the launch.
+// wait, then destroy) can then never fall between the look-up and the launch.  The key is the arrays' identity (addresses, capacity, row
+// format, device); offset and scale are NOT part of it -- the frame takes them from the call's tree view (render_accel_for_tree), so the
+// same arrays under another transform render with that transform.
 static const mnv_accel *cached_accel(const mnv_tree_view *tree, hipStream_t stream) {
     const int b = (tree->format == MNV_FORMAT_SH && tree->basis_dim >= 0) ? tree->basis_dim : -1;
     if (!(b == -1 || b == 1 || b == 4 || b == 9 || b == 16 || b == 25)) return nullptr;  // what the packed layout has rows for
@@ -268,26 +272,31 @@ static const mnv_accel *cached_accel(const mnv_tree_view *tree, hipStream_t stre
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     CachedTree *hit = nullptr, *victim = nullptr;
     for (auto &e : g_cache)
-        if (e.accel && e.child == tree->child && e.data == tree->data && e.capacity == tree->capacity && e.data_dim == tree->data_dim &&
+        if (e.used && e.child == tree->child && e.data == tree->data && e.capacity == tree->capacity && e.data_dim == tree->data_dim &&
             e.basis_dim == tree->basis_dim && e.format == tree->format && e.device == dev)
             hit = &e;
     if (!hit) {
-        for (auto &e : g_cache)  // a free entry, else the least recently used one
-            if (!victim || (victim->accel && (!e.accel || e.stamp < victim->stamp))) victim = &e;
-        if (victim->accel) drop(*victim);
+        // build first, evict afterwards: a tree whose re-layout cannot be built must not cost another tree its entry
         mnv_accel *a = nullptr;
-        if (mnv_accel_create(tree, (void *)stream, &a) != MNV_OK) return nullptr;  // e.g. deeper than the packed layout goes: stateless path
         hipEvent_t ev = nullptr;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, stream) != hipSuccess) {
+        if (mnv_accel_create(tree, (void *)stream, &a) != MNV_OK) a = nullptr;  // e.g. deeper than the packed layout goes: stateless path
+        if (a && (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, stream) != hipSuccess)) {
             mnv_accel_destroy(a);
+            if (ev) (void)hipEventDestroy(ev);
             return nullptr;
         }
+        for (auto &e : g_cache)  // a free entry, else a remembered failure, else the least recently used one
+            if (!victim || (victim->used && (!e.used || (!e.accel && victim->accel) || ((!e.accel == !victim->accel) && e.stamp < victim->stamp)))) victim = &e;
+        if (!a && victim->used && victim->accel) return nullptr;  // nothing but live re-layouts to evict: do not remember the failure at their cost
+        if (victim->used) drop(*victim);
+        victim->used = true;
         victim->child = tree->child; victim->data = tree->data; victim->capacity = tree->capacity; victim->data_dim = tree->data_dim;
         victim->basis_dim = tree->basis_dim; victim->format = tree->format; victim->device = dev;
         victim->accel = a; victim->built = ev; victim->build_stream = stream;
         hit = victim;
     }
     hit->stamp = ++g_cache_clock;
+    if (!hit->accel) return nullptr;  // remembered failure
     if (hit->build_stream != stream && hipStreamWaitEvent(stream, hit->built, 0) != hipSuccess) return nullptr;
     return hit->accel;
 }
@@ -295,6 +304,12 @@ static const mnv_accel *cached_accel(const mnv_tree_view *tree, hipStream_t stre
 int mnv_render_voxels(const mnv_tree_view *tree, const mnv_camera *cam, const mnv_render_options *opt,
                       mnv_rect tile, float *rgba_out, uint8_t *rgba8_out, float *split_track,
                       float *sample_track, int32_t *visited, int track_visit, void *hip_stream) {
+    return mnv_render_voxels_ex(tree, cam, opt, tile, nullptr, rgba_out, rgba8_out, split_track, sample_track, visited, track_visit, hip_stream);
+}
+
+int mnv_render_voxels_ex(const mnv_tree_view *tree, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                         const mnv_frame_inputs *inputs, float *rgba_out, uint8_t *rgba8_out, float *split_track, float *sample_track,
+                         int32_t *visited, int track_visit, void *hip_stream) {
     MarchParams P;
     std::memset(static_cast<void *>(&P), 0, sizeof(P));
     int rc = fill_params(P, cam, opt, tile);
@@ -306,12 +321,16 @@ int mnv_render_voxels(const mnv_tree_view *tree, const mnv_camera *cam, const mn
     if (g_cache_on.load(std::memory_order_relaxed) && tree->N == 2 && !split_track && !sample_track && !track_visit) {
         // plain frames of a tree this process has seen before run on the packed re-layout kept from that call (mnv_set_tree_cache)
         std::lock_guard<std::mutex> lk(g_cache_mu);
-        if (const mnv_accel *a = cached_accel(tree, stream)) return mnv_render_voxels_accel(a, cam, opt, tile, rgba_out, rgba8_out, hip_stream);
+        if (const mnv_accel *a = cached_accel(tree, stream)) return render_accel_for_tree(a, tree, cam, opt, tile, inputs, rgba_out, rgba8_out, stream);
     }
     P.max_depth = opt->max_depth;
     P.max_sample_count = opt->max_sample_count;
     P.rgba = rgba_out;
     P.rgba8 = rgba8_out;
+    if (inputs) {
+        P.tmax_px = inputs->tmax_px;
+        P.rgba8_init = inputs->rgba8_init;
+    }
     P.split_track = split_track;
     P.sample_track = sample_track;
     P.visited = visited;

@@ -45,7 +45,15 @@ struct FrameParams {
     // outputs
     float *rgba;
     uint8_t *rgba8;
+    // what the reference's kernels read per pixel when they are called with offscreen == false (mnv_frame_inputs; both indexed like
+    // the outputs, both may be NULL = the offscreen branch): the depth attachment (renderer_kernel.cu:277-280) and the pixel
+    // that is already in the image (renderer_kernel.cu:230-234,260-264)
+    const float *tmax_px;
+    const uint8_t *rgba8_init;
 };
+
+// t_max of pixel p: renderer_kernel.cu:277-280
+__device__ __forceinline__ float frame_tmax(const FrameParams &P, int64_t p) { return P.tmax_px ? P.tmax_px[p] : 1e9f; }
 
 // Full argument block of the reference-layout kernel: + TreeSpec (data_spec.hpp:25-50) and
 // the refinement trackers.
@@ -238,7 +246,7 @@ struct RaySetup {
 // (1 for DC-only / RGBA).
 template <int BASIS>
 __device__ __forceinline__ void setup_ray(const FrameParams &P, const CamBlock &C, int ix, int iy,
-                                          RaySetup<(BASIS > 0 ? BASIS : 1)> &r) {
+                                          RaySetup<(BASIS > 0 ? BASIS : 1)> &r, float t_max = 1e9f) {
     const float xyz0 = (ix + 0.5f - C.cx) / C.fx;
     const float xyz1 = -(iy + 0.5f - C.cy) / C.fy;
     const float xyz2 = -1.0f;
@@ -276,7 +284,7 @@ __device__ __forceinline__ void setup_ray(const FrameParams &P, const CamBlock &
     dir[1] *= delta_scale;
     dir[2] *= delta_scale;
     r.delta_scale = delta_scale;
-    const float tmax_bg = 1e9f / delta_scale;  // :183 with t_max = 1e9f (offscreen)
+    const float tmax_bg = t_max / delta_scale;  // :183 (t_max: 1e9f offscreen, the pixel's depth otherwise, renderer_kernel.cu:277-280)
 
     float tmin = 0.0f, tmax = 1e4f;
 #pragma unroll
@@ -339,14 +347,22 @@ __device__ __forceinline__ uint32_t pack_u8(float v) {
     return (uint32_t)s;
 }
 
-// renderer_kernel.cu:215-241 offscreen branch + the two output formats.
+// renderer_kernel.cu:215-241, both branches, + the two output formats.  rgba8_init may be the same buffer as rgba8 (the reference
+// reads and writes one surface): a pixel is read and written by the same lane.
 __device__ __forceinline__ void composite_and_write(const FrameParams &P, int64_t p, float o0, float o1,
                                                     float o2, float o3) {
     const float nalpha = 1.f - o3;
-    const float remain = P.background_brightness * nalpha;
-    o0 += remain;
-    o1 += remain;
-    o2 += remain;
+    if (P.rgba8_init) {  // :230-234 (offscreen == false): over the pixel already there
+        const uint32_t px = reinterpret_cast<const uint32_t *>(P.rgba8_init)[p];
+        o0 += (float)(int)(px & 0xffu) / 255.f * nalpha;
+        o1 += (float)(int)((px >> 8) & 0xffu) / 255.f * nalpha;
+        o2 += (float)(int)((px >> 16) & 0xffu) / 255.f * nalpha;
+    } else {  // :225-229
+        const float remain = P.background_brightness * nalpha;
+        o0 += remain;
+        o1 += remain;
+        o2 += remain;
+    }
     if (P.rgba) reinterpret_cast<float4 *>(P.rgba)[p] = make_float4(o0, o1, o2, o3);
     if (P.rgba8)
         reinterpret_cast<uint32_t *>(P.rgba8)[p] =

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void get_samples_kernel(const SampleParams S) 
     const int64_t p = (int64_t)by * P.tw + bx;
 
     RaySetup<1> r;  // no SH basis needed here
-    setup_ray<0>(P, P.cam, P.x0 + bx, P.y0 + by, r);
+    setup_ray<0>(P, P.cam, P.x0 + bx, P.y0 + by, r, frame_tmax(P, p));
     // world-space ray for the emitted sample positions: true_dir / true_cen / vdir (renderer_kernel.cu:348-351)
     const float *m = P.cam.c2w;
     float true_dir[3], vdir[3];

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                         }
                         if constexpr (MODE == 3) ns = K.num_samples[pix];
                         RaySetup<NB> r;
-                        setup_ray<(BASIS > 0 ? BASIS : 0)>(P, *Cp, P.x0 + bx, P.y0 + by, r);
+                        setup_ray<(BASIS > 0 ? BASIS : 0)>(P, *Cp, P.x0 + bx, P.y0 + by, r, frame_tmax(P, pix));
                         if constexpr (BASIS == 0)
                             r.basis[0] = (0 < P.basis_min || 0 > P.basis_max) ? 0.f : (float)0.28209479177387814;
                         o0 = o1 = o2 = 0.f;

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kRefThreads) void march_ref_layout_kernel(const Mar
 
     constexpr int NB = BASIS > 0 ? BASIS : 1;
     RaySetup<NB> r;
-    setup_ray<(BASIS > 0 ? BASIS : 0)>(P, P.cam, ix, iy, r);
+    setup_ray<(BASIS > 0 ? BASIS : 0)>(P, P.cam, ix, iy, r, frame_tmax(P, p));
     if constexpr (BASIS == 0) {  // DC only: basis[0] subject to minmax mask
         r.basis[0] = (0 < P.basis_min || 0 > P.basis_max) ? 0.f : (float)0.28209479177387814;
     }

@@ -459,6 +459,16 @@ int orc_render_voxels(const orc_tree *tree, const orc_camera *cam, const orc_opt
                       float *rgba, uint8_t *rgba8, float *split_track, float *sample_track,
                       int32_t *visited, int track_visit, int32_t *steps_out, orc_counters *ctr,
                       int n_threads) {
+    return orc_render_voxels_ex(tree, cam, opt, x0, y0, w, h, NULL, NULL, rgba, rgba8, split_track, sample_track, visited, track_visit,
+                                steps_out, ctr, n_threads);
+}
+
+int orc_render_voxels_ex(const orc_tree *tree, const orc_camera *cam, const orc_options *opt,
+                         int32_t x0, int32_t y0, int32_t w, int32_t h,
+                         const float *tmax_px, const uint8_t *rgba8_init,
+                         float *rgba, uint8_t *rgba8, float *split_track, float *sample_track,
+                         int32_t *visited, int track_visit, int32_t *steps_out, orc_counters *ctr,
+                         int n_threads) {
     if (!tree || !cam || !opt || w < 0 || h < 0) return -1;
     if (tree->N > 0 && (!tree->data || !tree->child)) return -1;
     uint64_t c_rays = 0, c_inb = 0, c_hit = 0, c_steps = 0, c_levels = 0, c_hits = 0, c_stop = 0, c_max = 0;
@@ -500,15 +510,24 @@ int orc_render_voxels(const orc_tree *tree, const orc_camera *cam, const orc_opt
                 for (int i = 0; i < 3; ++i) cen[i] = tree->offset[i] + tree->scale[i] * m[9 + i]; /* :272-275 */
                 float vdir[3] = {dir[0], dir[1], dir[2]};
                 rodrigues(opt->rot_dirs, vdir); /* :282-283 */
-                trace_ray(tree, visited, dir, vdir, cen, opt, 1e9f, out, &trk[1], &trk[2], &trk[0],
+                /* renderer_kernel.cu:277-280: t_max = 1e9f offscreen, else the pixel of the depth attachment */
+                const float t_max = tmax_px ? tmax_px[p] : 1e9f;
+                trace_ray(tree, visited, dir, vdir, cen, opt, t_max, out, &trk[1], &trk[2], &trk[0],
                           &trk[4], &trk[5], &trk[3], track_visit, &st);
             }
-            /* composite_and_write, offscreen branch :224-229 */
+            /* composite_and_write :224-234 */
             const float nalpha = 1.f - out[3];
-            const float remain = opt->background_brightness * nalpha;
-            out[0] += remain;
-            out[1] += remain;
-            out[2] += remain;
+            if (rgba8_init) { /* offscreen == false, :230-234: over the pixel already in the image (uint8 / 255.f * nalpha) */
+                const uint8_t init[3] = {rgba8_init[p * 4 + 0], rgba8_init[p * 4 + 1], rgba8_init[p * 4 + 2]}; /* (may alias rgba8) */
+                out[0] += init[0] / 255.f * nalpha;
+                out[1] += init[1] / 255.f * nalpha;
+                out[2] += init[2] / 255.f * nalpha;
+            } else { /* offscreen branch :225-229 */
+                const float remain = opt->background_brightness * nalpha;
+                out[0] += remain;
+                out[1] += remain;
+                out[2] += remain;
+            }
             if (rgba) memcpy(rgba + p * 4, out, sizeof(out));
             if (rgba8) {
                 rgba8[p * 4 + 0] = pack_u8(out[0]);

@@ -132,6 +132,14 @@ int orc_render_voxels(const orc_tree *tree, const orc_camera *cam, const orc_opt
                       float *split_track, float *sample_track,
                       int32_t *visited, int track_visit,
                       int32_t *steps_out, orc_counters *ctr, int n_threads);
+/* The same with the two per-pixel inputs of the reference's offscreen == false call shape (renderer_kernel.cu:260-264,277-280,
+ * 230-234), indexed like the outputs: tmax_px [h][w] float (NULL: 1e9f), rgba8_init [h][w][4] uint8 (NULL: background_brightness). */
+int orc_render_voxels_ex(const orc_tree *tree, const orc_camera *cam, const orc_options *opt,
+                         int32_t x0, int32_t y0, int32_t w, int32_t h,
+                         const float *tmax_px, const uint8_t *rgba8_init,
+                         float *rgba, uint8_t *rgba8, float *split_track, float *sample_track,
+                         int32_t *visited, int track_visit, int32_t *steps_out, orc_counters *ctr,
+                         int n_threads);
 
 /* Cluster grid of the guided-sampling path (cuda_renderer.cpp:524-539 model attributes). */
 typedef struct {

@@ -72,6 +72,11 @@ def lib():
                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_void_p, C.POINTER(OrcCounters), C.c_int]
+        h.orc_render_voxels_ex.restype = C.c_int
+        h.orc_render_voxels_ex.argtypes = [C.POINTER(OrcTree), C.POINTER(OrcCamera), C.POINTER(OrcOptions),
+                                           C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.POINTER(OrcCounters), C.c_int]
         h.orc_get_samples_from_voxels.restype = C.c_int
         h.orc_get_samples_from_voxels.argtypes = [C.POINTER(OrcTree), C.POINTER(OrcCamera), C.POINTER(OrcOptions), C.c_void_p, C.c_void_p,
                                                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
@@ -120,8 +125,9 @@ def physical_cores():
 
 
 def render(tree: OrcTree, cam_struct, opt_struct, tile=None, *, want_rgba8=False, want_trackers=False,
-           want_steps=False, visited=None, track_visit=False, n_threads=0):
-    """Render a tile with the oracle.  Returns dict(rgba, rgba8, split, sample, steps, counters)."""
+           want_steps=False, visited=None, track_visit=False, n_threads=0, tmax_px=None, rgba8_init=None):
+    """Render a tile with the oracle.  Returns dict(rgba, rgba8, split, sample, steps, counters).  tmax_px [h][w] float32 / rgba8_init
+    [h][w][4] uint8: the per-pixel inputs of the reference's offscreen == false call shape (renderer_kernel.cu:230-234,277-280)."""
     cam = _copy_struct(OrcCamera(), cam_struct)
     opt = _copy_struct(OrcOptions(), opt_struct)
     if tile is None:
@@ -134,8 +140,14 @@ def render(tree: OrcTree, cam_struct, opt_struct, tile=None, *, want_rgba8=False
     steps = np.empty((h, w), np.int32) if want_steps else None
     ctr = OrcCounters()
     p = lambda a: a.ctypes.data if a is not None else None
-    rc = lib().orc_render_voxels(C.byref(tree), C.byref(cam), C.byref(opt), x0, y0, w, h, p(rgba), p(rgba8), p(split),
-                                 p(sample), p(visited), int(track_visit), p(steps), C.byref(ctr), n_threads)
+    if tmax_px is not None:
+        tmax_px = np.ascontiguousarray(tmax_px, np.float32)
+        assert tmax_px.size == w * h
+    if rgba8_init is not None:
+        rgba8_init = np.ascontiguousarray(rgba8_init, np.uint8)
+        assert rgba8_init.size == w * h * 4
+    rc = lib().orc_render_voxels_ex(C.byref(tree), C.byref(cam), C.byref(opt), x0, y0, w, h, p(tmax_px), p(rgba8_init), p(rgba), p(rgba8),
+                                    p(split), p(sample), p(visited), int(track_visit), p(steps), C.byref(ctr), n_threads)
     if rc != 0:
         raise RuntimeError("orc_render_voxels: invalid arguments")
     return dict(rgba=rgba, rgba8=rgba8, split=split, sample=sample, steps=steps, counters=ctr)

@@ -50,6 +50,44 @@ def render_npz(npz_path, cam_struct, opt_struct, n_probe=4096, contract=False):
     return dict(rgba=rgba, data_probe=dp, child_probe=cp, parent_probe=pp, meta=list(meta))
 
 
+def render_onscreen_npz(npz_path, cam_struct, opt_struct, tmax_px=None, rgba8_init=None):
+    """The reference's march in its live call shape (offscreen == false): per-pixel t_max [h][w] float32 and / or the image under the
+    volume [h][w][4] uint8.  -> float RGBA [h][w][4]."""
+    h = lib()
+    h.ref_render_onscreen_npz.restype = C.c_int
+    w, ht = cam_struct.width, cam_struct.height
+    rgba = np.empty((ht, w, 4), np.float32)
+    if tmax_px is not None:
+        tmax_px = np.ascontiguousarray(tmax_px, np.float32)
+    if rgba8_init is not None:
+        rgba8_init = np.ascontiguousarray(rgba8_init, np.uint8)
+    ptr = lambda a: C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)  # noqa: E731
+    wd, hh, fx, fy, cx, cy, c2w = _cam_args(cam_struct)
+    rc = h.ref_render_onscreen_npz(os.fsencode(npz_path), C.c_int(wd), C.c_int(hh), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), c2w,
+                                   C.byref(opt_struct), C.c_int(C.sizeof(opt_struct)), ptr(tmax_px), ptr(rgba8_init), ptr(rgba))
+    if rc != 0:
+        raise RuntimeError(f"ref_render_onscreen_npz failed with {rc}")
+    return rgba
+
+
+def dropin_onscreen_npz(npz_path, cam_spec, opt_struct, image, depth, path=0, offscreen=False):
+    """The reference's eleven-parameter render_voxels call through include/mnv_reference_binding.hpp: `image` [h][w][4] uint8 is read
+    (what is under the volume) and returned overwritten, `depth` [h][w] float32 is the depth attachment."""
+    h = lib()
+    h.ref_dropin_onscreen_npz.restype = C.c_int
+    image = np.ascontiguousarray(image, np.uint8).copy()
+    depth = np.ascontiguousarray(depth, np.float32)
+    f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
+    rc = h.ref_dropin_onscreen_npz(os.fsencode(npz_path), C.c_int(cam_spec["width"]), C.c_int(cam_spec["height"]), C.c_float(cam_spec["fx"]),
+                                   C.c_float(cam_spec.get("fy", -1.0)), C.c_float(cam_spec.get("cx", -1.0)), C.c_float(cam_spec.get("cy", -1.0)),
+                                   f3(cam_spec["center"]), f3(cam_spec["back"]), f3(cam_spec.get("up", (0.0, 0.0, 1.0))), C.byref(opt_struct),
+                                   C.c_int(C.sizeof(opt_struct)), C.c_int(path), C.c_int(1 if offscreen else 0), C.c_void_p(image.ctypes.data),
+                                   C.c_void_p(depth.ctypes.data))
+    if rc != 0:
+        raise RuntimeError(f"ref_dropin_onscreen_npz failed with {rc}")
+    return image
+
+
 def render_track_npz(npz_path, cam_struct, opt_struct, capacity, sample_counts=None, track_visit=True):
     """The reference's march with its trackers: dict(rgba [h,w,4], split [h,w,3], sample [h,w,3], visited [capacity])."""
     h = lib()

@@ -53,8 +53,10 @@ std::unique_ptr<Camera> make_camera(int width, int height, float fx, float fy, f
     return cam;
 }
 
+// restated wrapper of render_voxels_kernel (renderer_kernel.cu:243-292) with composite_and_write (:215-241): the two surface reads of
+// the offscreen == false branch (the image pixel :260-264, the depth pixel :277-280) come from linear arrays (NULL: offscreen == true)
 __global__ void ref_render_voxels_kernel(const internal::TreeSpec tree, const CameraSpec cam, const RenderOptions opt,
-                                         float *rgba,
+                                         float *rgba, const float *tmax_px, const uint8_t *image_rgbx,
                                          torch::PackedTensorAccessor32<float, 2, torch::RestrictPtrTraits> to_split,
                                          torch::PackedTensorAccessor32<float, 2, torch::RestrictPtrTraits> to_sample,
                                          torch::PackedTensorAccessor32<int32_t, 1, torch::RestrictPtrTraits> visited,
@@ -68,6 +70,7 @@ __global__ void ref_render_voxels_kernel(const internal::TreeSpec tree, const Ca
         screen2worlddir(x, y, cam, dir, cen);
         for (int i = 0; i < 3; ++i) cen[i] = tree.offset[i] + tree.scale[i] * cen[i];
         float t_max = 1e9f;
+        if (tmax_px) t_max = tmax_px[idx];
         float vdir[3] = {dir[0], dir[1], dir[2]};
         float aa[3] = {opt.rot_dirs[0], opt.rot_dirs[1], opt.rot_dirs[2]};
         rodrigues(aa, vdir);
@@ -76,10 +79,17 @@ __global__ void ref_render_voxels_kernel(const internal::TreeSpec tree, const Ca
                                         &to_sample[idx][2], &to_sample[idx][0], track_visit);
     }
     const float nalpha = 1.f - out[3];
-    const float remain = opt.background_brightness * nalpha;
-    out[0] += remain;
-    out[1] += remain;
-    out[2] += remain;
+    if (image_rgbx) {
+        const uint8_t *rgbx_init = image_rgbx + (size_t)idx * 4;
+        out[0] += rgbx_init[0] / 255.f * nalpha;
+        out[1] += rgbx_init[1] / 255.f * nalpha;
+        out[2] += rgbx_init[2] / 255.f * nalpha;
+    } else {
+        const float remain = opt.background_brightness * nalpha;
+        out[0] += remain;
+        out[1] += remain;
+        out[2] += remain;
+    }
     rgba[idx * 4 + 0] = out[0];
     rgba[idx * 4 + 1] = out[1];
     rgba[idx * 4 + 2] = out[2];
@@ -180,7 +190,7 @@ int ref_render_npz(const char *npz_path, int width, int height, float fx, float 
         const int threads = 512;  // auto_cuda_threads() picks 512 or 1024 (renderer_kernel.cu:14-28)
         const int blocks = N_BLOCKS_NEEDED(n, threads);
         hipLaunchKernelGGL(ref_render_voxels_kernel, dim3(blocks), dim3(threads), 0, 0, viewer::internal::TreeSpec(tree), cam, opt,
-                           out.data_ptr<float>(), to_split.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
+                           out.data_ptr<float>(), (const float *)nullptr, (const uint8_t *)nullptr, to_split.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
                            to_sample.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
                            visited.packed_accessor32<int32_t, 1, torch::RestrictPtrTraits>(), false);
         if (hipDeviceSynchronize() != hipSuccess) return -4;
@@ -188,6 +198,48 @@ int ref_render_npz(const char *npz_path, int width, int height, float fx, float 
         memcpy(rgba_host, h.data_ptr<float>(), n * 4 * sizeof(float));
     } catch (const std::exception &e) {
         fprintf(stderr, "ref_render_npz: %s\n", e.what());
+        return -1;
+    }
+    return 0;
+}
+
+// The reference's march in its live call shape, offscreen == false (cuda_renderer.cpp:141-142): tmax_host [h][w] float = the depth
+// attachment, image_host [h][w][4] uint8 = the image the volume is composited over (either may be NULL = that half offscreen).
+int ref_render_onscreen_npz(const char *npz_path, int width, int height, float fx, float fy, float cx, float cy, const float *c2w12,
+                            const void *opt_bytes, int opt_size, const float *tmax_host, const uint8_t *image_host, float *rgba_host) {
+    using namespace viewer;
+    if (opt_size != (int)sizeof(RenderOptions)) return -2;
+    RenderOptions opt;
+    memcpy(&opt, opt_bytes, sizeof(opt));
+    try {
+        N3Tree tree;
+        tree.open(npz_path);
+        if (tree.N == 0) return -3;
+        tree.move_to_device(tree.capacity, true, true);
+        tree.sample_counts.fill_(8);
+        auto camera = make_camera(width, height, fx, fy, cx, cy, c2w12);
+        const CameraSpec cam(*camera);
+        const int64_t n = (int64_t)width * height;
+        auto fopt = torch::TensorOptions().device(torch::kCUDA).dtype(torch::kFloat32);
+        torch::Tensor out = torch::zeros({n, 4}, fopt);
+        torch::Tensor to_split = torch::full({n, 3}, -1.f, fopt), to_sample = torch::full({n, 3}, -1.f, fopt);
+        torch::Tensor visited = torch::zeros({tree.capacity}, torch::TensorOptions().device(torch::kCUDA).dtype(torch::kInt32));
+        torch::Tensor tmax, image;
+        if (tmax_host) tmax = torch::from_blob((void *)tmax_host, {n}, torch::kFloat32).clone().to(torch::kCUDA);
+        if (image_host) image = torch::from_blob((void *)image_host, {n, 4}, torch::kUInt8).clone().to(torch::kCUDA);
+        const int threads = 512;
+        const int blocks = N_BLOCKS_NEEDED(n, threads);
+        hipLaunchKernelGGL(ref_render_voxels_kernel, dim3(blocks), dim3(threads), 0, 0, viewer::internal::TreeSpec(tree), cam, opt,
+                           out.data_ptr<float>(), tmax_host ? (const float *)tmax.data_ptr<float>() : (const float *)nullptr,
+                           image_host ? (const uint8_t *)image.data_ptr<uint8_t>() : (const uint8_t *)nullptr,
+                           to_split.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
+                           to_sample.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
+                           visited.packed_accessor32<int32_t, 1, torch::RestrictPtrTraits>(), false);
+        if (hipDeviceSynchronize() != hipSuccess) return -4;
+        torch::Tensor h = out.cpu();
+        memcpy(rgba_host, h.data_ptr<float>(), n * 4 * sizeof(float));
+    } catch (const std::exception &e) {
+        fprintf(stderr, "ref_render_onscreen_npz: %s\n", e.what());
         return -1;
     }
     return 0;
@@ -224,7 +276,7 @@ int ref_render_track_npz(const char *npz_path, int width, int height, float fx, 
         const int threads = 512;
         const int blocks = N_BLOCKS_NEEDED(n, threads);
         hipLaunchKernelGGL(ref_render_voxels_kernel, dim3(blocks), dim3(threads), 0, 0, viewer::internal::TreeSpec(tree), cam, opt,
-                           out.data_ptr<float>(), to_split.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
+                           out.data_ptr<float>(), (const float *)nullptr, (const uint8_t *)nullptr, to_split.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
                            to_sample.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
                            visited.packed_accessor32<int32_t, 1, torch::RestrictPtrTraits>(), track_visit != 0);
         if (hipDeviceSynchronize() != hipSuccess) return -4;
@@ -414,6 +466,54 @@ int ref_dropin_render_npz(const char *npz_path, int width, int height, float fx,
         if (visited_host) memcpy(visited_host, visited.cpu().data_ptr<int32_t>(), (size_t)tree.capacity * sizeof(int32_t));
     } catch (const std::exception &e) {
         fprintf(stderr, "ref_dropin_render_npz: %s\n", e.what());
+        return -1;
+    }
+    return 0;
+}
+
+// The same demonstration for the reference's LIVE call: render_voxels(tree, cam, opt, image_arr, depth_arr, stream, to_split, to_sample,
+// visited, track_visit, offscreen = false) through the eleven-parameter binding.  image_host [h][w][4] is read (the image under the
+// volume) and overwritten (the frame); depth_host [h][w].  path: 0 = reference arrays, 1 = packed accel.
+int ref_dropin_onscreen_npz(const char *npz_path, int width, int height, float fx, float fy, float cx, float cy, const float *center3,
+                            const float *back3, const float *up3, const void *opt_bytes, int opt_size, int path, int offscreen,
+                            uint8_t *image_host, const float *depth_host) {
+    using namespace viewer;
+    if (opt_size != (int)sizeof(RenderOptions)) return -2;
+    RenderOptions opt;
+    memcpy(&opt, opt_bytes, sizeof(opt));
+    try {
+        N3Tree tree;
+        tree.open(npz_path);
+        if (tree.N == 0) return -3;
+        tree.move_to_device(tree.capacity, true, true);
+        tree.sample_counts.fill_(8);
+        Camera cam(width, height, fx, fy, cx, cy);
+        cam.center = glm::vec3(center3[0], center3[1], center3[2]);
+        cam.v_back = glm::vec3(back3[0], back3[1], back3[2]);
+        cam.v_world_up = glm::vec3(up3[0], up3[1], up3[2]);
+        cam._update();
+        const int64_t n = (int64_t)width * height;
+        auto fopt = torch::TensorOptions().device(torch::kCUDA).dtype(torch::kFloat32);
+        torch::Tensor image = torch::from_blob((void *)image_host, {n, 4}, torch::kUInt8).clone().to(torch::kCUDA);
+        torch::Tensor depth = torch::from_blob((void *)depth_host, {n}, torch::kFloat32).clone().to(torch::kCUDA);
+        torch::Tensor to_split = torch::full({n, 3}, -1.f, fopt), to_sample = torch::full({n, 3}, -1.f, fopt);
+        torch::Tensor visited = torch::zeros({tree.capacity}, torch::TensorOptions().device(torch::kCUDA).dtype(torch::kInt32));
+        uint8_t *image_arr = image.data_ptr<uint8_t>();
+        float *depth_arr = depth.data_ptr<float>();
+        hipStream_t stream = nullptr;
+        if (hipDeviceSynchronize() != hipSuccess) return -4;
+        if (path == 0) {
+            render_voxels(tree, cam, opt, image_arr, depth_arr, stream, to_split, to_sample, visited, false, offscreen != 0);
+        } else {
+            mnv_accel *accel = make_accel(tree, tree.capacity, nullptr);
+            render_voxels(accel, cam, opt, image_arr, depth_arr, stream, offscreen != 0);
+            if (hipDeviceSynchronize() != hipSuccess) return -4;
+            mnv_accel_destroy(accel);
+        }
+        if (hipDeviceSynchronize() != hipSuccess) return -4;
+        memcpy(image_host, image.cpu().data_ptr<uint8_t>(), n * 4);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "ref_dropin_onscreen_npz: %s\n", e.what());
         return -1;
     }
     return 0;

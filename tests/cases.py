@@ -116,3 +116,34 @@ def cfg2_camera(mnv, pose=0, width=1920, height=1080, fx=1600.0):
 def bits(a):
     """uint32 view for bit-exact comparison of float32 arrays."""
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+# The reference's live call shape, offscreen == false (cuda_renderer.cpp:141-142; renderer_kernel.cu:230-234,260-264,277-280): a depth
+# attachment (per-pixel t_max) and an image under the volume.  name -> (base case, which inputs, seed)
+ONSCREEN = {
+    "onscreen_depth": ("shell_d7_sh9", ("tmax",), 101),           # clipped by a depth image only; background_brightness composite
+    "onscreen_image": ("sh4_d6", ("image",), 102),                # composite over an image only; t_max = 1e9f
+    "onscreen_both": ("sh9_d7_aniso", ("tmax", "image"), 103),    # what the viewer's render loop passes
+    "onscreen_terrain": ("terrain_d7_aniso", ("tmax", "image"), 104),
+}
+
+
+def onscreen_inputs(name, cam):
+    """Deterministic stand-ins for the two GL attachments: tmax_px [h][w] float32 -- world-space ray limits scattered around the
+    camera's distance to the scene centre, 15 % "no mesh" (1e9f, the clear value), 5 % "mesh right in front of the camera" (0) --
+    and rgba8_init [h][w][4] uint8 -- blocks + noise, alpha byte arbitrary.  Either is None when the case does not use it."""
+    _, which, seed = ONSCREEN[name]
+    rng = np.random.default_rng(seed)
+    h, w = cam.height, cam.width
+    c2w = np.array(list(cam.c.c2w), np.float64)
+    dist = float(np.linalg.norm(c2w[9:12]))
+    tmax = (dist * rng.uniform(0.55, 1.35, size=(h, w))).astype(np.float32)
+    u = rng.uniform(size=(h, w))
+    tmax[u < 0.15] = np.float32(1e9)
+    tmax[u > 0.95] = np.float32(0.0)
+    yy, xx = np.mgrid[0:h, 0:w]
+    image = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    block = (((yy // 16) + (xx // 16)) % 2).astype(bool)
+    image[block, :3] = (image[block, :3] // 4 + np.uint8(180))          # bright blocks
+    image[(yy % 37 == 0) | (xx % 41 == 0), :3] = (0, 255, 1)            # saturated and near-zero channel values
+    return (tmax if "tmax" in which else None), (np.ascontiguousarray(image) if "image" in which else None)

@@ -1,0 +1,61 @@
+"""Golden vectors of the reference's LIVE call shape (render_voxels with offscreen == false, src/renderer/cuda_renderer.cpp:141-142):
+the reference's own march (rt_core.cuh, compiled for gfx950 by oracle/Makefile.ref) run with a per-pixel t_max from a depth image
+(renderer_kernel.cu:277-280) and composited over an image (renderer_kernel.cu:230-234) -- the per-pixel wrapper is restated in
+oracle/ref_driver.hip because the reference reads both through surface objects, which gfx950 does not have.
+
+Run on the GPU box:   python tests/golden/make_onscreen_goldens.py gpurun_out/goldens
+then copy gpurun_out/goldens/ref_onscreen_*.npz and ref_onscreen_stats.json into tests/golden/ and commit them.
+Inputs are tests/cases.py::onscreen_inputs (seeded); only the reference's float RGBA frames are stored."""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+import cases  # noqa: E402
+import mega_nerf_viewer_amd as mnv  # noqa: E402
+import mnv_oracle as orc  # noqa: E402
+import mnv_ref  # noqa: E402
+from make_goldens import cmp  # noqa: E402
+
+
+def main(outdir):
+    os.makedirs(outdir, exist_ok=True)
+    tmp = tempfile.mkdtemp()
+    stats = {}
+    for name, (base, which, _) in cases.ONSCREEN.items():
+        spec = cases.CASES[base]
+        tree = cases.make_tree(mnv, spec["tree"])
+        cam = cases.make_camera(mnv, spec["camera"])
+        opt = cases.make_options(mnv, spec["options"])
+        tmax, image = cases.onscreen_inputs(name, cam)
+        path = os.path.join(tmp, name + ".npz")
+        tree.save_npz(path)
+        ref = mnv_ref.render_onscreen_npz(path, cam.c, opt, tmax_px=tmax, rgba8_init=image)
+        plain = mnv_ref.render_npz(path, cam.c, opt, n_probe=0)["rgba"]
+        o = orc.render(orc.tree_from_view(tree.host_view()), cam.c, opt, tmax_px=tmax, rgba8_init=image)["rgba"]
+        tree.move_to_device()
+        out = torch.empty((cam.height, cam.width, 4), dtype=torch.float32, device="cuda")
+        mnv.render_voxels_accel(tree.accel, cam, opt, rgba=out, tmax_px=None if tmax is None else torch.from_numpy(tmax).cuda(),
+                                rgba8_init=None if image is None else torch.from_numpy(image).cuda())
+        torch.cuda.synchronize()
+        hip = out.cpu().numpy()
+        stats[name] = {"base_case": base, "inputs": list(which), "oracle_vs_ref": cmp(o, ref), "hip_vs_ref": cmp(hip, ref), "hip_vs_oracle": cmp(hip, o),
+                       "pixels_changed_by_the_inputs": int((ref != plain).any(axis=-1).sum()), "shape": list(ref.shape)}
+        print(name, json.dumps(stats[name]), flush=True)
+        np.savez_compressed(os.path.join(outdir, f"ref_{name}.npz"), rgba=ref)
+        os.remove(path)
+    with open(os.path.join(outdir, "ref_onscreen_stats.json"), "w") as f:
+        json.dump(stats, f, indent=1)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "goldens"))

@@ -177,3 +177,23 @@ def test_camera_pose_matches_reference_camera(mnv, orc):
         f3 = lambda v: (C.c_float * 3)(*[float(x) for x in v])  # noqa: E731
         orc.lib().orc_camera_pose(f3(center), f3(back), f3(up), out)
         assert np.array_equal(np.float32(list(out)).view(np.uint32), want1.view(np.uint32))
+
+
+@pytest.mark.parametrize("name", list(cases.ONSCREEN))
+def test_oracle_matches_reference_in_its_live_call_shape(mnv, orc, name):
+    """offscreen == false (cuda_renderer.cpp:141-142): per-pixel t_max from a depth image and the composite over an image
+    (renderer_kernel.cu:230-234,277-280) -- the oracle against frames of the reference's own march run with the same inputs
+    (tests/golden/make_onscreen_goldens.py)."""
+    base = cases.ONSCREEN[name][0]
+    spec = cases.CASES[base]
+    tree = cases.make_tree(mnv, spec["tree"])
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    tmax, image = cases.onscreen_inputs(name, cam)
+    g = np.load(os.path.join(GOLD, f"ref_{name}.npz"))["rgba"]
+    got = orc.render(orc.tree_from_view(tree.host_view()), cam.c, opt, tmax_px=tmax, rgba8_init=image)["rgba"]
+    diff = np.abs(got.astype(np.float64) - g.astype(np.float64))
+    assert diff.max() <= TOL, f"{name}: max|d| = {diff.max():.3e}"
+    st = json.load(open(os.path.join(GOLD, "ref_onscreen_stats.json")))[name]
+    assert st["hip_vs_oracle"]["px_not_bit_identical"] == 0 and st["hip_vs_ref"]["max_abs"] <= TOL
+    assert st["pixels_changed_by_the_inputs"] > 0.05 * g.shape[0] * g.shape[1]

@@ -762,6 +762,73 @@ def test_tree_cache_of_the_stateless_entry_point(mnv, orc, torch_gpu):
         mnv.set_tree_cache(False)
 
 
+def test_tree_cache_takes_the_transform_from_the_call(mnv, orc, torch_gpu):
+    """The cached re-layout is keyed by the arrays, not by offset / scale: the same device arrays under another transform (a re-centred
+    scene) render with the transform of the view they are called with, bit-identical to the oracle -- not with the one the re-layout
+    was built under."""
+    torch = torch_gpu
+    spec = cases.CASES["sh9_d7_aniso"]
+    tree = cases.make_tree(mnv, spec["tree"])
+    cam, opt = cases.make_camera(mnv, spec["camera"]), cases.make_options(mnv, spec["options"])
+    hv = tree.host_view()
+    tree.move_to_device()
+    dv = tree.device_view()
+    try:
+        mnv.set_tree_cache(True)
+        for k, (off, sc) in enumerate([(tuple(hv.offset), tuple(hv.scale)), ((0.45, 0.55, 0.5), (0.4, 0.3, 0.15)), ((0.5, 0.5, 0.5), (0.25, 0.25, 0.25))]):
+            h2, d2 = type(hv).from_buffer_copy(hv), type(dv).from_buffer_copy(dv)
+            for i in range(3):
+                h2.offset[i] = d2.offset[i] = off[i]
+                h2.scale[i] = d2.scale[i] = sc[i]
+            want = orc.render(orc.tree_from_view(h2), cam.c, opt)["rgba"]
+            out = torch.full((cam.height, cam.width, 4), float("nan"), dtype=torch.float32, device="cuda")
+            mnv.render_voxels(d2, cam, opt, rgba=out)
+            torch.cuda.synchronize()
+            assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(want)), f"transform {k}"
+    finally:
+        mnv.set_tree_cache(False)
+
+
+def test_tree_cache_remembers_a_tree_it_cannot_re_lay_out(mnv, orc, torch_gpu):
+    """A tree deeper than the packed layout goes (24 levels): every frame takes the stateless walk, the failed build is not repeated
+    per frame (second frame much faster than the first is not asserted -- only that frames stay right and other entries survive)."""
+    torch = torch_gpu
+    depth = 25
+    child = np.zeros((depth, 2, 2, 2), np.int32)
+    data = np.zeros((depth, 2, 2, 2, 4), np.float16)
+    for c in range(depth - 1):
+        child[c, 1, 0, 1] = 1          # a chain of chunks through one corner-ish voxel
+    data[..., 3] = 0.0
+    data[:, 0, 1, 0, :] = (0.8, 0.3, 0.1, 30.0)
+    data[depth - 1, :, :, :, :] = (0.2, 0.9, 0.4, 500.0)
+    deep = mnv.N3Tree.from_arrays(data, child, data_format="RGBA")
+    spec = cases.CASES["sh4_d6"]
+    other = cases.make_tree(mnv, spec["tree"])
+    ocam, oopt = cases.make_camera(mnv, spec["camera"]), cases.make_options(mnv, spec["options"])
+    cam = mnv.Camera(96, 96, 300.0)
+    opt = mnv.RenderOptions.defaults()
+    want_deep = orc.render(orc.tree_from_view(deep.host_view()), cam.c, opt)["rgba"]
+    want_other = orc.render(orc.tree_from_view(other.host_view()), ocam.c, oopt)["rgba"]
+    other.move_to_device()
+    # (N3Tree.move_to_device builds the packed layout and would refuse this tree: the arrays go up by hand)
+    d_data, d_child = torch.from_numpy(data.view(np.uint16).copy()).cuda(), torch.from_numpy(child.copy()).cuda()
+    deep_view = type(deep.host_view()).from_buffer_copy(deep.host_view())
+    deep_view.data, deep_view.child, deep_view.parent, deep_view.sample_counts = d_data.data_ptr(), d_child.data_ptr(), None, None
+    try:
+        mnv.set_tree_cache(True)
+        for _ in range(3):
+            out = torch.full((ocam.height, ocam.width, 4), float("nan"), dtype=torch.float32, device="cuda")
+            mnv.render_voxels(other.device_view(), ocam, oopt, rgba=out)
+            torch.cuda.synchronize()
+            assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(want_other))
+            out = torch.full((96, 96, 4), float("nan"), dtype=torch.float32, device="cuda")
+            mnv.render_voxels(deep_view, cam, opt, rgba=out)
+            torch.cuda.synchronize()
+            assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(want_deep))
+    finally:
+        mnv.set_tree_cache(False)
+
+
 def _n_ary_tree(n, depth, data_dim, refine_prob, seed):
     """A random N^3-ary tree in the reference's array layout (n3tree.cpp:92-107,183-188): child[chunk][N^3] relative chunk offsets
     (0 = leaf), data[chunk][N^3][data_dim] binary16 with sigma in the last column.  Breadth-first, like svox writes them."""
