@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "mnv_accel_launch.h"
+#include "mnv_knobs.h"
 
 namespace mnv {
 
@@ -155,7 +156,7 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
     int L2 = max_depth - 1 < kMaxGrid2Level ? max_depth - 1 : kMaxGrid2Level;
     const int64_t budget = std::max<int64_t>((int64_t)128 << 20, 2 * (nvox * 4 + nvox * row_bytes));
     while (L2 > L && ((int64_t)8 << (3 * L2)) > budget) --L2;
-    static const int env_l2 = getenv("MNV_GRID2_LEVEL") ? atoi(getenv("MNV_GRID2_LEVEL")) : -1;
+    static const int env_l2 = knob_int(KNOB_GRID2_LEVEL, -1);
     if (env_l2 >= 0 && env_l2 <= kMaxGrid2Level && env_l2 < max_depth) L2 = env_l2;
     if (L2 <= L || L2 < 2) L2 = 0;
     int64_t g2cells = 0;
@@ -262,7 +263,7 @@ int mnv_accel_rebuild(mnv_accel *a, const mnv_tree_view *t, void *hip_stream) {
 
 void mnv_accel_destroy(mnv_accel *a) {
     if (!a) return;
-    if (a->stats && getenv("MNV_STATS")) {
+    if (a->stats && knob_set(KNOB_STATS)) {
         unsigned long long h[16];
         if (hipMemcpy(h, a->stats, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
             unsigned long long ph[8] = {};
@@ -276,14 +277,14 @@ void mnv_accel_destroy(mnv_accel *a) {
                         h[2 * i] ? (double)h[2 * i + 1] / (double)h[2 * i] : 0.0);
         }
     }
-    if (a->timeline && getenv("MNV_TIMELINE")) {
+    if (a->timeline && knob_str(KNOB_TIMELINE)) {
         const size_t words = a->timeline_tiles * 4 + a->timeline_waves * 2;
         std::vector<unsigned long long> h(words + 3);
         h[0] = a->timeline_tiles;
         h[1] = a->timeline_waves;
         h[2] = a->timeline_tiles_per_frame;
         if (hipMemcpy(h.data() + 3, a->timeline, words * 8, hipMemcpyDeviceToHost) == hipSuccess) {
-            if (FILE *f = fopen(getenv("MNV_TIMELINE"), "wb")) {
+            if (FILE *f = fopen(knob_str(KNOB_TIMELINE), "wb")) {
                 fwrite(h.data(), 8, h.size(), f);
                 fclose(f);
             }

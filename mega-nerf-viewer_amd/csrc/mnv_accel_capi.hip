@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "mnv_accel_launch.h"
+#include "mnv_knobs.h"
 
 namespace mnv {
 
@@ -99,7 +100,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     K.part_rank = part.rank;
     K.part_world = is_partitioned(part) ? part.world : 0;
     K.part_period = root_period_of(part);
-    static const int env_wlog = getenv("MNV_TILE_WLOG") ? atoi(getenv("MNV_TILE_WLOG")) : 3;
+    static const int env_wlog = knob_int(KNOB_TILE_WLOG, 3);
     K.tile_wlog = (env_wlog >= 0 && env_wlog <= 6) ? (uint32_t)env_wlog : 3u;
     if (!is_partitioned(part)) {
         const uint32_t tile_w = 1u << K.tile_wlog, tile_h = 64u >> K.tile_wlog;
@@ -122,7 +123,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
         // contiguous runs of micro tiles (in local macro-tile order) per queue
         for (int q = 0; q <= kNumQueues; ++q) K.band_begin[q] = (uint32_t)(((uint64_t)K.n_tiles * q) / kNumQueues);
     }
-    static const int env_queues = getenv("MNV_QUEUES") ? atoi(getenv("MNV_QUEUES")) : kNumQueues;
+    static const int env_queues = knob_int(KNOB_QUEUES, kNumQueues);
     if (env_queues >= 1 && env_queues < kNumQueues) {
         // diagnostics: fewer, larger queues (queue q of the first env_queues covers 1/env_queues of the tiles)
         const uint32_t total = K.band_begin[kNumQueues];
@@ -166,7 +167,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     if (e != hipSuccess) return (int)e;
 
     // diagnostics knobs; read once
-    static const int env_level = getenv("MNV_LDS_LEVEL") ? atoi(getenv("MNV_LDS_LEVEL")) : -1;
+    static const int env_level = knob_int(KNOB_LDS_LEVEL, -1);
     int lds_level = accel->view.grid_level < 3 ? accel->view.grid_level : 3;  // 2 KB; level 4 (16 KB) measured equal and costs occupancy
     if (env_level >= 1 && env_level <= accel->view.grid_level) lds_level = env_level;
     K.lds_level = lds_level;
@@ -174,14 +175,14 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     const bool colourless = K.samples != nullptr || (P.render_depth && !K.split_track && !K.sample_track && !K.visited);
     const int nb_lds = colourless ? 9 : (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim > 0) ? accel->view.basis_dim : 1;
     const size_t lds_bytes = 256 + (nb_lds >= 16 ? 1024 : 0) + (size_t)(nb_lds + 2) * 256 * 4 + ((size_t)4 << (3 * lds_level));
-    static const int env_bpc = getenv("MNV_BLOCKS_PER_CU") ? atoi(getenv("MNV_BLOCKS_PER_CU")) : 0;
-    static const int env_refill = getenv("MNV_REFILL_MIN") ? atoi(getenv("MNV_REFILL_MIN")) : 0;
-    static const int env_ablate = getenv("MNV_ABLATE") ? atoi(getenv("MNV_ABLATE")) : 0;
+    static const int env_bpc = knob_int(KNOB_BLOCKS_PER_CU, 0);
+    static const int env_refill = knob_int(KNOB_REFILL_MIN, 0);
+    static const int env_ablate = knob_int(KNOB_ABLATE, 0);
     K.ablate = env_ablate;
-    static const bool env_stats = getenv("MNV_STATS") != nullptr;
-    static const char *env_timeline = getenv("MNV_TIMELINE");
+    static const bool env_stats = knob_set(KNOB_STATS);
+    static const char *env_timeline = knob_str(KNOB_TIMELINE);
     K.stats = (env_stats || env_ablate || env_timeline) ? accel->stats : nullptr;  // all three run on the diagnostics instantiation
-    static const int env_stats_level = getenv("MNV_STATS") ? std::max(1, atoi(getenv("MNV_STATS"))) : 0;
+    static const int env_stats_level = env_stats ? std::max(1, knob_int(KNOB_STATS, 1)) : 0;
     K.count_stats = env_stats ? env_stats_level : 0;
     K.refill_min = (env_refill > 0 && n_frames == 1) ? env_refill : 64;  // batches refill whole tiles (a grab must not straddle frames);  // sweep in DESIGN.md: 16 -> 0.606 ms, 32 -> 0.535, 48 -> 0.507, 56 -> 0.504, 64 -> 0.506
     int blocks_per_cu = lds_level >= 5 ? 1 : (lds_level == 4 ? 6 : 8);
@@ -258,7 +259,7 @@ int mnv_assemble_tiles(const void *gathered, void *frames, int32_t width, int32_
     const int32_t period = root_period_of(part);
     const int32_t j_max = (int32_t)part_j_max((int64_t)macros_x * macros_y, part.world, period);
     hipStream_t stream = (hipStream_t)hip_stream;
-    static const bool env_narrow = getenv("MNV_ASSEMBLE_NARROW") != nullptr;  // diagnostics: one RGBA8 pixel per thread
+    static const bool env_narrow = knob_set(KNOB_ASSEMBLE_NARROW);  // diagnostics: one RGBA8 pixel per thread
     if (bytes_per_pixel == 4 && width % 4 == 0 && !env_narrow) {
         // RGBA8: tile rows and frame rows are contiguous runs of pixels and tile_w is a multiple of 8, so the same index arithmetic
         // holds in units of four pixels: 16 bytes per thread instead of 4 (rank 0 runs this beside its march on the few compute
@@ -510,11 +511,11 @@ static int guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv
     }
     F.max_guided_samples = opt->max_guided_samples;
     F.appearance_embedding = opt->appearance_embedding;
-    static const int env_batch = getenv("MNV_FUSED_BATCH_MIN") ? atoi(getenv("MNV_FUSED_BATCH_MIN")) : kFW;
+    static const int env_batch = knob_int(KNOB_FUSED_BATCH_MIN, kFW);
     F.batch_min = env_batch < 1 ? 1 : (env_batch > kFW ? kFW : env_batch);
     F.sample_counter = sample_counter;
     F.diag = fused_diag_words();
-    static const int env_switch = getenv("MNV_F2_SWITCH_MIN") ? atoi(getenv("MNV_F2_SWITCH_MIN")) : 32;
+    static const int env_switch = knob_int(KNOB_F2_SWITCH_MIN, 32);
     F.switch_min = env_switch;
     AccelTrack track = {};
     track.fused = &F;

@@ -4,6 +4,7 @@
 
 #include "mnv_guided_fused.h"   // guided_fused_kernel: march + per-sample network + composite in one kernel, every wavefront both roles
 #include "mnv_guided_fused2.h"  // guided_fused2_kernel: the same frame with producer (march) and consumer (network) wavefronts
+#include "mnv_knobs.h"
 
 namespace mnv {
 
@@ -32,7 +33,7 @@ int launch_fused(const mnv_accel *accel, const AccelLaunch &K, const FusedGuided
         int per_cu = (int)((size_t)160 * 1024 / f2_bytes);
         const int by_regs = (4 * kF2WavesPerSimd) / (kF2NP + kF2NC);
         if (per_cu > by_regs) per_cu = by_regs;
-        static const int env_f2 = getenv("MNV_F2_BLOCKS_PER_CU") ? atoi(getenv("MNV_F2_BLOCKS_PER_CU")) : 0;
+        static const int env_f2 = knob_int(KNOB_F2_BLOCKS_PER_CU, 0);
         if (env_f2 > 0 && env_f2 < per_cu) per_cu = env_f2;
         int fb = accel->num_cus * per_cu;
         if ((uint64_t)fb * kF2NP > n_waves_needed) fb = (int)((n_waves_needed + kF2NP - 1) / kF2NP);

@@ -5,6 +5,7 @@
 #include <cstdlib>
 
 #include "mnv_accel_launch.h"
+#include "mnv_knobs.h"
 
 namespace mnv {
 
@@ -347,7 +348,7 @@ int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity
         launch_build_grid(a->nodes, a->grid, a->grid_vox, a->view.grid_level, stream);
     }
     if (a->view.grid2_level > 0) {
-        static const bool dbg = getenv("MNV_REFRESH_DEBUG") != nullptr;
+        static const bool dbg = knob_set(KNOB_REFRESH_DEBUG);
         if (dbg)
             fprintf(stderr, "[mnv refresh] n_new %d n_changed %d shallowest %d grid2_level %d patch items %d + %d\n", n_new, n_changed, h[3], a->view.grid2_level, h[4], h[5]);
         if (h[4] > 0)

@@ -1,0 +1,28 @@
+// mnv_knobs.cpp -- see mnv_knobs.h.  Compiled twice: plain for libmnv.so (no getenv, no names), with MNV_TEST_HOOKS for testhooks/libmnv.so.
+#include "mnv_knobs.h"
+
+#ifdef MNV_TEST_HOOKS
+#include <cstdlib>
+#endif
+
+namespace mnv {
+
+#ifdef MNV_TEST_HOOKS
+static const char *const kKnobNames[KNOB_COUNT] = {
+    "MNV_TILE_WLOG",      "MNV_QUEUES",           "MNV_LDS_LEVEL",      "MNV_BLOCKS_PER_CU",   "MNV_REFILL_MIN",     "MNV_ABLATE",
+    "MNV_STATS",          "MNV_TIMELINE",         "MNV_GRID2_LEVEL",    "MNV_BRICK_LEVELS",    "MNV_F2_BLOCKS_PER_CU", "MNV_F2_SWITCH_MIN",
+    "MNV_FUSED_BATCH_MIN", "MNV_VOTE_WIDE_KEYS",  "MNV_VOTE_FULL_SORT", "MNV_ASSEMBLE_NARROW", "MNV_REFRESH_DEBUG",  "MNV_SYNTH_TIMING",
+};
+const char *knob_str(Knob k) { return k >= 0 && k < KNOB_COUNT ? std::getenv(kKnobNames[k]) : nullptr; }
+int knob_int(Knob k, int dflt) {
+    const char *v = knob_str(k);
+    return v ? std::atoi(v) : dflt;
+}
+bool knob_set(Knob k) { return knob_str(k) != nullptr; }
+#else
+const char *knob_str(Knob) { return nullptr; }
+int knob_int(Knob, int dflt) { return dflt; }
+bool knob_set(Knob) { return false; }
+#endif
+
+}  // namespace mnv

@@ -24,6 +24,7 @@
 #include <rocprim/iterator/transform_iterator.hpp>
 
 #include "mnv_internal.h"
+#include "mnv_knobs.h"
 
 namespace mnv {
 
@@ -545,8 +546,8 @@ int select_candidates(const float *track, int64_t n_rows, int32_t max_out, bool 
     if (!track || n_rows < 0 || max_out < 0 || (max_out > 0 && !nodes_out)) return set_error(MNV_E_INVALID, "invalid tracker arguments");
     if (n_rows == 0) return MNV_OK;
     if (n_rows > 0x7fffffff) return set_error(MNV_E_UNSUPPORTED, "more than 2^31 - 1 tracker rows");
-    static const bool force_wide = getenv("MNV_VOTE_WIDE_KEYS") != nullptr;       // (tests: the fallback paths on ordinary inputs)
-    static const bool force_full_sort = getenv("MNV_VOTE_FULL_SORT") != nullptr;
+    static const bool force_wide = knob_set(KNOB_VOTE_WIDE_KEYS);       // (tests: the fallback paths on ordinary inputs)
+    static const bool force_full_sort = knob_set(KNOB_VOTE_FULL_SORT);
     bool overflow = force_wide, full_sort = force_full_sort || (need_votes && max_out > kVoteTop);
     if (!overflow && !full_sort) {
         const int rc = need_votes ? select_candidates_compact<uint32_t>(track, n_rows, max_out, true, nodes_out, n_out, n_candidates, &overflow, &full_sort, stream)

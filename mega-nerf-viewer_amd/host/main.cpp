@@ -237,6 +237,13 @@ void print_refine_stats(long f, const viewer::VolumeRenderer::FrameStats &st) {
 // Test hook, compiled only into the -DMNV_TEST_HOOKS build (testhooks/mnv_render): MNV_RANKS_SHARE_GPU=1 puts every rank on device --gpu
 // (with a transport stand-in for RCCL, which refuses two ranks on one device: tests/shim/fake_rccl.cpp) so that the world > 1 paths can
 // run on a one-GPU machine.  The shipped binary gives rank r device --gpu + r, always.
+static bool save_every_rank() {  // test hook as well: every rank writes its replica of the refined tree
+#ifdef MNV_TEST_HOOKS
+    return std::getenv("MNV_SAVE_EVERY_RANK") != nullptr;
+#else
+    return false;
+#endif
+}
 static bool ranks_share_gpu() {
 #ifdef MNV_TEST_HOOKS
     return std::getenv("MNV_RANKS_SHARE_GPU") != nullptr;
@@ -287,7 +294,7 @@ int run_rank_refine(const Args &args, int rank, int world, Rendezvous *rv) {
     const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     if (args.has("save_tree")) {  // every rank holds the same tree; rank r > 0 writes <name>.rank<r> when asked to (MNV_SAVE_EVERY_RANK: tests)
         const std::string name = args.get("save_tree", "");
-        if (rank == 0 || std::getenv("MNV_SAVE_EVERY_RANK")) {
+        if (rank == 0 || save_every_rank()) {
             rend.sync_tree();
             tree.save_npz(rank == 0 ? name : name + ".rank" + std::to_string(rank) + ".npz");
         }

@@ -11,6 +11,7 @@
 #include <thread>
 #include <vector>
 
+#include "../csrc/mnv_knobs.h"
 #include "n3tree.hpp"
 
 namespace viewer::synth {
@@ -150,7 +151,7 @@ namespace {
 struct Timer {
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
     void lap(const char *what) {
-        if (!getenv("MNV_SYNTH_TIMING")) return;
+        if (!mnv::knob_set(mnv::KNOB_SYNTH_TIMING)) return;
         auto t1 = std::chrono::steady_clock::now();
         std::fprintf(stderr, "[synth] %s: %.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
         t0 = t1;

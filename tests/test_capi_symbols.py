@@ -76,9 +76,22 @@ def test_the_shipped_binaries_carry_no_test_hooks(mnv):
         return name.encode() in open(path, "rb").read()
 
     exe = os.path.join(ROOT, "mega-nerf-viewer_amd", "mnv_render")
-    assert not mentions(mnv.LIB_PATH if not os.environ.get("MNV_LIB_PATH") else os.path.join(ROOT, "mega-nerf-viewer_amd", "libmnv.so"), "MNV_RCCL_LIBRARY")
+    shipped = mnv.LIB_PATH if not os.environ.get("MNV_LIB_PATH") else os.path.join(ROOT, "mega-nerf-viewer_amd", "libmnv.so")
+    assert not mentions(shipped, "MNV_RCCL_LIBRARY")
     assert not mentions(exe, "MNV_RANKS_SHARE_GPU")
     assert mentions(hooks.HOOKS_LIB, "MNV_RCCL_LIBRARY") and mentions(hooks.HOOKS_EXE, "MNV_RANKS_SHARE_GPU")
+    # ... nor be steered by a stray measurement knob in a user's shell (MNV_STATS, MNV_BLOCKS_PER_CU, MNV_ABLATE ...): the shipped
+    # library and binary name NO environment variable of their own; every knob of csrc/mnv_knobs.h lives in the test-hook build
+    import re
+
+    def env_names(path):
+        return sorted(set(m.decode() for m in re.findall(rb"MNV_[A-Z][A-Z0-9_]{2,}", open(path, "rb").read())))
+
+    allowed = {"MNV_LIB_PATH", "MNV_MAX_BATCH"}  # (the second is a macro named in an error message)
+    assert set(env_names(shipped)) <= allowed, env_names(shipped)
+    assert set(env_names(exe)) <= allowed, env_names(exe)
+    knobs = re.findall(r"KNOB_([A-Z0-9_]+),", open(os.path.join(ROOT, "mega-nerf-viewer_amd", "csrc", "mnv_knobs.h")).read())
+    assert len(knobs) >= 15 and all(("MNV_" + k) in env_names(hooks.HOOKS_LIB) for k in knobs)
 
 
 def test_no_packed_fp32_instructions_in_the_code_objects(mnv):

@@ -465,7 +465,7 @@ def test_selection_of_a_batch_without_sorting_all_counts(mnv, torch_gpu, kind, k
 
 
 def test_selection_paths_agree(mnv, torch_gpu, tmp_path):
-    """MNV_VOTE_FULL_SORT=1 (read once per process) forces the sort of all counts for small batches too: a child process votes on the same
+    """MNV_VOTE_FULL_SORT=1 (test-hook build of the library, read once per process) forces the sort of all counts for small batches too: a child process votes on the same
     tracker with it and must write the same rows."""
     import subprocess
     import sys
@@ -480,7 +480,9 @@ def test_selection_paths_agree(mnv, torch_gpu, tmp_path):
     code = (f"import sys; sys.path.insert(0, {root!r}); import numpy as np, torch, mega_nerf_viewer_amd as mnv\n"
             f"t = torch.from_numpy(np.load({str(tmp_path / 'track.npy')!r})).cuda(); nodes = torch.full(({k}, 2), -9, dtype=torch.int32, device='cuda')\n"
             f"r = mnv.select_split_candidates(t, {k}, nodes); np.save({str(tmp_path / 'nodes.npy')!r}, nodes.cpu().numpy()); print(r[0], r[1])\n")
-    env = dict(os.environ, MNV_VOTE_FULL_SORT="1")
+    import hooks
+
+    env = hooks.hooks_env(MNV_VOTE_FULL_SORT="1")  # the knob exists in the test-hook build only (csrc/mnv_knobs.h)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.split()[-2:] == [str(n_out), str(n_cand)]

@@ -1,3 +1,6 @@
+import os as _os
+# the MNV_* knobs this tool reads exist in the test-hook build of the library only (csrc/mnv_knobs.h)
+_os.environ.setdefault("MNV_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "mega-nerf-viewer_amd", "testhooks", "libmnv.so"))
 import os, sys, time
 sys.path[:0]=[os.getcwd(), os.path.join(os.getcwd(),"tests")]
 import torch, mega_nerf_viewer_amd as mnv

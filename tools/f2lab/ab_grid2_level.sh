@@ -1,4 +1,6 @@
 #!/bin/bash
+# the knobs below exist in the test-hook build of the library only (csrc/mnv_knobs.h)
+export MNV_LIB_PATH=${MNV_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/mega-nerf-viewer_amd/testhooks/libmnv.so}
 # cfg3 is bound by real HBM traffic: does a coarser second lookup grid (fits the MALL, more node loads per deep step) help THERE?
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04

@@ -1,4 +1,6 @@
 #!/bin/bash
+# the knobs below exist in the test-hook build of the library only (csrc/mnv_knobs.h)
+export MNV_LIB_PATH=${MNV_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/mega-nerf-viewer_amd/testhooks/libmnv.so}
 # window / switch thresholds of the producer / consumer kernel re-swept (they were tuned while the consumers ran at a raised priority)
 cd "$(dirname "$0")/../.."
 for bm in 24 32 48 64 96; do for sm in 16 32 48; do

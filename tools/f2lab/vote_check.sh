@@ -1,4 +1,6 @@
 #!/bin/bash
+# the knobs below exist in the test-hook build of the library only (csrc/mnv_knobs.h)
+export MNV_LIB_PATH=${MNV_LIB_PATH:-$(cd "$(dirname "$0")/../.." && pwd)/mega-nerf-viewer_amd/testhooks/libmnv.so}
 # the vote as a selection: tests, time per call on a real tracker frame (both paths), configs[4] frame, kernel list
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/r04; timeout 900 python3 -m pytest tests/test_refine_gpu.py tests/test_renderer_refine_gpu.py -x -q > gpurun_out/r04/vote_tests.log 2>&1; tail -4 gpurun_out/r04/vote_tests.log

@@ -1,5 +1,8 @@
 """Time of mnv_select_split_candidates / _sample_candidates on a REAL 1920x1080 tracker frame of the cfg2 tree (the march's own rows: neighbouring
 pixels name the same voxels, shallow leaves collect many votes).  MNV_VOTE_FULL_SORT=1 selects the sort of all counts instead of the selection."""
+import os as _os
+# the MNV_* knobs this tool reads exist in the test-hook build of the library only (csrc/mnv_knobs.h)
+_os.environ.setdefault("MNV_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))), "mega-nerf-viewer_amd", "testhooks", "libmnv.so"))
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]

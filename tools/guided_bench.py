@@ -1,6 +1,9 @@
 """Guided-sampling frame on the cfg2 tree at 1920x1080: the fused kernel (mnv_render_guided_fused) against the four-step path
 (sample march on the accel -> mnv_compact_guided_samples -> mnv_query_submodules -> mnv_render_nerf_results), device time per
 frame from HIP events, frames compared bit for bit.  usage: python3 tools/guided_bench.py [max_guided_samples] [pos_octaves]"""
+import os as _os
+# the MNV_* knobs this tool reads exist in the test-hook build of the library only (csrc/mnv_knobs.h)
+_os.environ.setdefault("MNV_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "mega-nerf-viewer_amd", "testhooks", "libmnv.so"))
 import json
 import os
 import sys

@@ -1,5 +1,8 @@
 """Device time of the sample-emitting march alone (mnv_get_samples_from_voxels_accel) on the cfg2 tree at 1080p; MNV_BLOCKS_PER_CU sets
 the wavefronts per SIMD.  Used to split the fused guided frame's time into march and network."""
+import os as _os
+# the MNV_* knobs this tool reads exist in the test-hook build of the library only (csrc/mnv_knobs.h)
+_os.environ.setdefault("MNV_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "mega-nerf-viewer_amd", "testhooks", "libmnv.so"))
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]

@@ -7,6 +7,9 @@ wavefront entered and left the kernel; libmnv writes the records of the last lau
 renders, lets the handle go and reports: kernel span, wavefront exit-time distribution, busy wavefronts over time, the
 longest tiles and when they were started -- what an order that starts expensive tiles first could save.
 """
+import os as _os
+# the MNV_* knobs this tool reads exist in the test-hook build of the library only (csrc/mnv_knobs.h)
+_os.environ.setdefault("MNV_LIB_PATH", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "mega-nerf-viewer_amd", "testhooks", "libmnv.so"))
 import argparse
 import json
 import os
