@@ -206,6 +206,7 @@ _SIGNATURES = {
     "mnv_accel_destroy": (None, [C.c_void_p]),
     "mnv_accel_device_bytes": (C.c_size_t, [C.c_void_p]),
     "mnv_accel_grid2_level": (C.c_int32, [C.c_void_p]),
+    "mnv_accel_brick_levels": (C.c_int32, [C.c_void_p]),
     "mnv_accel_set_cu_budget": (C.c_int, [C.c_void_p, C.c_int32]),
     "mnv_stream_create_reserved": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
     "mnv_stream_destroy": (C.c_int, [C.c_void_p]),
@@ -1029,7 +1030,8 @@ def render_voxels_accel_batch(accel: int, cams, opt: RenderOptions, tile=None, p
 
 def accel_info(accel: int) -> dict:
     """Device bytes of the packed layout and the level of its second lookup grid."""
-    return {"device_bytes": int(lib().mnv_accel_device_bytes(accel)), "grid2_level": int(lib().mnv_accel_grid2_level(accel))}
+    return {"device_bytes": int(lib().mnv_accel_device_bytes(accel)), "grid2_level": int(lib().mnv_accel_grid2_level(accel)),
+            "brick_levels": int(lib().mnv_accel_brick_levels(C.c_void_p(accel)))}
 
 
 def accel_set_cu_budget(accel: int, num_cus: int) -> None:

@@ -16,6 +16,12 @@
 //   grid2 / grid2_vox [2^L2]^3 u32   the same two arrays at level L2 <= min(max_depth-1, 9), in
 //                            4x4x4-cell brick order; a step below the LDS grid costs one load
 //                            here plus one node load per level below L2
+//   bricks [capacity][64] {u32 word, u32 vox}   (trees with leaves two or more levels below L2 only; dropped by a tree edit, rebuilt by
+//                            mnv_accel_rebuild) the TWO levels below the second lookup grid in one 8-byte load: brick c belongs to chunk c
+//                            of depth L2 + 1 (the chunk a non-leaf grid2 cell names) and holds, for each of the 4x4x4 cells of level
+//                            L2 + 2 under it, the node word of the covering voxel (a leaf of depth L2 + 1 / L2 + 2, or the child chunk of
+//                            a depth-(L2 + 2) voxel) and that voxel's index -- replaces two dependent 4-byte node loads from two
+//                            scattered 32-byte chunks by one load from a 512-byte brick that neighbouring rays share
 // The in-leaf coordinates the march needs are frac(pos * 2^depth); x*2, floorf and
 // x - floorf(x) are exact in binary32 for x in [0,2), so any traversal that reaches the
 // same leaf reproduces the reference's iterated descent bit for bit.
@@ -89,6 +95,7 @@ struct AccelView {
     const uint32_t *grid2;      // [2^L2]^3 brick-ordered second lookup grid (NULL when grid2_level == 0)
     const uint32_t *grid2_vox;
     int32_t grid2_level;
+    const uint2 *bricks;        // [capacity][64] {word, vox}: levels grid2_level + 1 and + 2 (NULL: none, the node words are walked)
     int32_t max_depth;          // deepest voxel depth of the tree (<= 23)
     int32_t row_bytes;
     float offset[3], scale[3];
@@ -105,6 +112,9 @@ struct mnv_accel {
     uint32_t *grid_vox = nullptr;
     uint32_t *grid2 = nullptr;
     uint32_t *grid2_vox = nullptr;
+    uint2 *bricks = nullptr;              // [reserved][64]; view.bricks is NULL while they are stale (after mnv_accel_refresh / a prune)
+    uint32_t *shadow_nodes = nullptr;     // MNV_ABLATE shadow loads (test-hook build, diagnostics instantiation): copies of nodes / rows at other
+    uint8_t *shadow_rows = nullptr;       // addresses, read with the same access pattern to attribute the HBM traffic by array
     uint32_t *nodes_spare = nullptr;      // second set of nodes / rows / depth, allocated by the first prune (accel_apply_prune writes the
     uint8_t *rows_spare = nullptr;        // survivors out of place, then the sets swap)
     int32_t *depth_spare = nullptr;

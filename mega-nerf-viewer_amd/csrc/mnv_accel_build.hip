@@ -99,6 +99,28 @@ __global__ void accel_build_grid2(const uint32_t *nodes, uint32_t *grid2, uint32
 
 // (Re)build every derived array of `a` from the tree: chunk depths, node words, colour rows, lookup grids.  The big arrays
 // (nodes, rows, depth) are sized for a->reserved chunks and kept; the grids are reallocated only when their level changes.
+// bricks[c][cell] for every chunk c of depth L2 + 1: cell = (x2 << 4) | (y2 << 2) | z2, the high bit of each pair is the child index at depth
+// L2 + 1, the low bit at depth L2 + 2 -- the node word and the voxel index of the voxel of depth <= L2 + 2 that covers the cell
+__global__ void accel_build_bricks(const uint32_t *nodes, const int32_t *depth, uint2 *bricks, int32_t capacity, int32_t L2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)capacity * 64) return;
+    const int32_t c = (int32_t)(i >> 6);
+    if (depth[c] != L2 + 1) return;
+    const uint32_t cell = (uint32_t)(i & 63), x2 = cell >> 4, y2 = (cell >> 2) & 3u, z2 = cell & 3u;
+    uint32_t vox = (uint32_t)c * 8u + (((x2 >> 1) << 2) | ((y2 >> 1) << 1) | (z2 >> 1));
+    uint32_t word = nodes[vox];
+    if (!(word & kLeafBit)) {
+        vox = word * 8u + (((x2 & 1u) << 2) | ((y2 & 1u) << 1) | (z2 & 1u));
+        word = nodes[vox];
+    }
+    bricks[i] = make_uint2(word, vox);
+}
+
+void launch_build_bricks(const uint32_t *nodes, const int32_t *depth, uint2 *bricks, int32_t capacity, int32_t L2, hipStream_t stream) {
+    const int64_t n = (int64_t)capacity * 64;
+    hipLaunchKernelGGL(accel_build_bricks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, nodes, depth, bricks, capacity, L2);
+}
+
 void launch_pack_rows(const uint16_t *data, uint16_t *rows, int64_t nvox, int32_t data_dim, int32_t per_chan, int32_t chan_halfs, int32_t row_halfs,
                       hipStream_t stream) {
     hipLaunchKernelGGL(accel_pack_rows, dim3((unsigned)((nvox * 3 + 255) / 256)), dim3(256), 0, stream, data, rows, nvox, data_dim, per_chan, chan_halfs, row_halfs);
@@ -173,8 +195,21 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
         }
         hipLaunchKernelGGL(accel_build_grid2, dim3((unsigned)((g2cells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid2, a->grid2_vox, L2);
     }
+    // bricks: the two levels below the second grid in one load, for trees that have them (depth >= L2 + 2).  A depth-11 tree (cfg3) then
+    // takes LDS grid -> grid2 -> brick instead of LDS grid -> grid2 -> node -> node; a depth-10 tree (cfg2) has one level below L2 = 9 and
+    // keeps its single node load.
+    static const int env_bricks = knob_int(KNOB_BRICK_LEVELS, 2);
+    const bool want_bricks = env_bricks >= 2 && L2 > 0 && max_depth >= L2 + 2;
+    if (want_bricks) {
+        if (!a->bricks && (rc = check_hip(hipMalloc((void **)&a->bricks, (size_t)max_capacity * 64 * sizeof(uint2)), "hipMalloc(bricks)"))) return fail(rc);
+        launch_build_bricks(a->nodes, depth, a->bricks, t->capacity, L2, stream);
+    } else if (a->bricks) {
+        (void)hipFree(a->bricks);
+        a->bricks = nullptr;
+    }
     if ((rc = check_hip(hipGetLastError(), "accel build launch"))) return fail(rc);
     if ((rc = check_hip(hipStreamSynchronize(stream), "accel build"))) return fail(rc);
+    a->view.bricks = want_bricks ? a->bricks : nullptr;
 
     a->view.nodes = a->nodes;
     a->view.rows = a->rows;
@@ -194,7 +229,7 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
     a->view.basis_dim = t->basis_dim;
     a->view.format = t->format;
     a->view.capacity = t->capacity;
-    a->bytes = (size_t)(nvox * 4 + nvox * row_bytes + gcells * 8 + g2cells * 8);
+    a->bytes = (size_t)(nvox * 4 + nvox * row_bytes + gcells * 8 + g2cells * 8) + (a->bricks ? (size_t)max_capacity * 64 * sizeof(uint2) : 0);
     return MNV_OK;
 }
 
@@ -233,7 +268,13 @@ int mnv_accel_create_reserved(const mnv_tree_view *t, int64_t max_capacity, void
     const int row_bytes = row_bytes_for(b);
     a->reserved = max_capacity;
     if ((rc = check_hip(hipMalloc((void **)&a->nodes, max_capacity * 8 * 4), "hipMalloc(nodes)"))) return fail(rc);
-    if ((rc = check_hip(hipMalloc((void **)&a->rows, max_capacity * 8 * row_bytes), "hipMalloc(rows)"))) return fail(rc);
+    {
+        static const int rows_mem = knob_int(KNOB_ROWS_MEM, 0);  // measurement: does the L2 fetch less than a 128-byte line for rows it does not cache?
+        const size_t bytes = (size_t)max_capacity * 8 * row_bytes;
+        const hipError_t e = rows_mem == 0 ? hipMalloc((void **)&a->rows, bytes)
+                                           : hipExtMallocWithFlags((void **)&a->rows, bytes, rows_mem == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
+        if ((rc = check_hip(e, "hipMalloc(rows)"))) return fail(rc);
+    }
     if ((rc = check_hip(hipMalloc((void **)&a->depth, max_capacity * 4), "hipMalloc(depth)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&a->flags, 32), "hipMalloc(flag)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&a->fault_dev, 4), "hipMalloc(fault)"))) return fail(rc);
@@ -291,6 +332,9 @@ void mnv_accel_destroy(mnv_accel *a) {
         }
     }
     if (a->timeline) (void)hipFree(a->timeline);
+    if (a->bricks) (void)hipFree(a->bricks);
+    if (a->shadow_nodes) (void)hipFree(a->shadow_nodes);
+    if (a->shadow_rows) (void)hipFree(a->shadow_rows);
     if (a->nodes_spare) (void)hipFree(a->nodes_spare);
     if (a->rows_spare) (void)hipFree(a->rows_spare);
     if (a->depth_spare) (void)hipFree(a->depth_spare);
@@ -315,6 +359,7 @@ void mnv_accel_destroy(mnv_accel *a) {
 
 size_t mnv_accel_device_bytes(const mnv_accel *a) { return a ? a->bytes : 0; }
 int32_t mnv_accel_grid2_level(const mnv_accel *a) { return a ? a->view.grid2_level : -1; }
+int32_t mnv_accel_brick_levels(const mnv_accel *a) { return a ? (a->view.bricks ? 2 : 0) : -1; }
 
 int mnv_accel_set_cu_budget(mnv_accel *a, int32_t num_cus) {
     if (!a) return set_error(MNV_E_INVALID, "accel is null");

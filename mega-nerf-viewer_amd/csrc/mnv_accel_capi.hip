@@ -182,6 +182,25 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     static const bool env_stats = knob_set(KNOB_STATS);
     static const char *env_timeline = knob_str(KNOB_TIMELINE);
     K.stats = (env_stats || env_ablate || env_timeline) ? accel->stats : nullptr;  // all three run on the diagnostics instantiation
+    static const int env_shadow = knob_int(KNOB_SHADOW, 0);
+    if (env_shadow & (16 | 32 | 64)) {
+        // shadow loads (test-hook build + a -DMNV_SHADOW_MASK variant of the march): copies of the arrays at other addresses, made once
+        const size_t nvox = (size_t)accel->reserved * 8;
+        auto shadow = [&](void **dst, const void *src, size_t bytes) -> int {
+            if (*dst || !src) return 0;
+            hipError_t es = hipMalloc(dst, bytes);
+            if (es == hipSuccess) es = hipMemcpyAsync(*dst, src, bytes, hipMemcpyDeviceToDevice, stream);
+            return (int)es;
+        };
+        int es = 0;
+        if (env_shadow & 16) es = shadow((void **)&mut->shadow_nodes, accel->nodes, nvox * 4);
+        if (!es && (env_shadow & 32)) es = shadow((void **)&mut->shadow_rows, accel->rows, nvox * (size_t)accel->view.row_bytes);
+        if (!es && (env_shadow & 64) && accel->bricks) es = shadow((void **)&mut->shadow_nodes, accel->bricks, nvox * 64);  // (bits 16 and 64 are not combined)
+        if (es) return es;
+        K.shadow_nodes = accel->shadow_nodes;
+        K.shadow_rows = accel->shadow_rows;
+        K.shadow_bricks = reinterpret_cast<const uint2 *>(accel->shadow_nodes);
+    }
     static const int env_stats_level = env_stats ? std::max(1, knob_int(KNOB_STATS, 1)) : 0;
     K.count_stats = env_stats ? env_stats_level : 0;
     K.refill_min = (env_refill > 0 && n_frames == 1) ? env_refill : 64;  // batches refill whole tiles (a grab must not straddle frames);  // sweep in DESIGN.md: 16 -> 0.606 ms, 32 -> 0.535, 48 -> 0.507, 56 -> 0.504, 64 -> 0.506
@@ -214,6 +233,8 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     const int b = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim >= 0) ? accel->view.basis_dim : -1;
     if (track && track->fused) {
         rc = launch_fused(accel, K, *track->fused, b, lds_level, n_waves_needed, stream);
+    } else if (K.A.bricks && !K.split_track && !K.sample_track && !K.visited && !K.samples) {
+        rc = launch_march_brick(K, b, colourless, n_blocks, lds_bytes, stream);
     } else {
         rc = launch_march(K, b, colourless, n_blocks, lds_bytes, stream);
     }

@@ -11,7 +11,7 @@ static std::atomic<int> g_fast_colour{0};
 template <int BASIS, int MODE>
 static int launch_variant2(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
     constexpr int BLOCK = 256;
-    auto kern = march_accel_kernel<BASIS, BLOCK, MODE>;
+    auto kern = march_accel_kernel<BASIS, BLOCK, MODE, false>;
     if (lds_bytes > 65536) {  // diagnostics only (MNV_LDS_LEVEL=5); the attribute is per device, so set it on every such launch
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return (int)e;
@@ -53,5 +53,7 @@ int launch_march(const AccelLaunch &K, int b, bool colourless, int n_blocks, siz
 }
 
 }  // namespace mnv
+
+bool mnv::fast_colour_selected() { return mnv::g_fast_colour.load(std::memory_order_relaxed) != 0; }
 
 extern "C" void mnv_set_colour_math(int fast) { mnv::g_fast_colour.store(fast ? 1 : 0, std::memory_order_relaxed); }

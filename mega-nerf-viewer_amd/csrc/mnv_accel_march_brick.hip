@@ -1,0 +1,46 @@
+// mnv_accel_march_brick.hip -- the instantiations of march_accel_kernel for trees with bricks (AccelView::bricks: the two levels below the
+// second lookup grid in one load): plain, fast-colour and depth frames, and the diagnostics instantiation of the SH9 kernel.  Tracker /
+// sample / fused frames of such trees walk the node words (mnv_accel_march.hip, mnv_accel_fused.hip): every lookup array stays valid.
+#include "mnv_march_accel_kernel.h"
+
+namespace mnv {
+
+template <int BASIS, int MODE>
+static int launch_brick2(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
+    constexpr int BLOCK = 256;
+    auto kern = march_accel_kernel<BASIS, BLOCK, MODE, true>;
+    if (lds_bytes > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_blocks), dim3(BLOCK), lds_bytes, stream, K);
+    return (int)hipGetLastError();
+}
+
+template <int BASIS>
+static int launch_brick(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
+    if constexpr (BASIS == 9) {
+        if (K.stats) return launch_brick2<BASIS, 1>(K, n_blocks, lds_bytes, stream);
+        if (K.P.render_depth) return launch_brick2<BASIS, 5>(K, n_blocks, lds_bytes, stream);
+    }
+    if constexpr (BASIS >= 1) {
+        if (fast_colour_selected()) return launch_brick2<BASIS, 4>(K, n_blocks, lds_bytes, stream);
+    }
+    return launch_brick2<BASIS, 0>(K, n_blocks, lds_bytes, stream);
+}
+
+int launch_march_brick(const AccelLaunch &K, int b, bool colourless, int n_blocks, size_t lds_bytes, hipStream_t stream) {
+    if (colourless) return launch_brick<9>(K, n_blocks, lds_bytes, stream);
+    switch (b) {
+        case -1: return launch_brick<-1>(K, n_blocks, lds_bytes, stream);
+        case 1: return launch_brick<1>(K, n_blocks, lds_bytes, stream);
+        case 4: return launch_brick<4>(K, n_blocks, lds_bytes, stream);
+        case 9: return launch_brick<9>(K, n_blocks, lds_bytes, stream);
+        case 16: return launch_brick<16>(K, n_blocks, lds_bytes, stream);
+        case 25: return launch_brick<25>(K, n_blocks, lds_bytes, stream);
+        default: break;
+    }
+    return kUnsupportedBasis;
+}
+
+}  // namespace mnv

@@ -12,7 +12,7 @@ enum Knob {
     KNOB_LDS_LEVEL,        // levels of the lookup grid staged in LDS
     KNOB_BLOCKS_PER_CU,    // persistent workgroups per compute unit
     KNOB_REFILL_MIN,       // idle lanes before a wavefront refills (single-frame launches)
-    KNOB_ABLATE,           // diagnostics instantiation: bit mask of ablations / shadow loads (breaks or inflates results)
+    KNOB_ABLATE,           // diagnostics instantiation: bit mask of ablations (break results)
     KNOB_STATS,            // diagnostics instantiation: counters (1) / phase clocks (2)
     KNOB_TIMELINE,         // string: file for the tile / wavefront time stamps of the last launch
     KNOB_GRID2_LEVEL,      // level of the second lookup grid
@@ -25,6 +25,8 @@ enum Knob {
     KNOB_ASSEMBLE_NARROW,  // one RGBA8 pixel per thread in mnv_assemble_tiles
     KNOB_REFRESH_DEBUG,    // mnv_accel_refresh prints what it patched
     KNOB_SYNTH_TIMING,     // the synthetic-tree generators print their phases
+    KNOB_ROWS_MEM,         // memory type of the colour rows: 0 default, 1 uncached (hipDeviceMallocUncached), 2 fine-grained
+    KNOB_SHADOW,           // allocate the copies the -DMNV_SHADOW_MASK variants of the march read (16 nodes, 32 rows, 64 bricks)
     KNOB_COUNT
 };
 

@@ -28,12 +28,21 @@
 
 namespace mnv {
 
+// Attribution of the L2 misses by array (tools/traffic_by_array.sh builds variants of the library with -DMNV_SHADOW_MASK=<bits>): every load
+// of the chosen array is repeated at the same index of a copy at other addresses -- results stay right, the miss counters grow by about
+// that array's share.  8 grid2 (its shadow is grid2_vox), 16 nodes, 32 rows, 64 bricks.  0 in every shipped build.
+#ifndef MNV_SHADOW_MASK
+#define MNV_SHADOW_MASK 0
+#endif
+constexpr int kShadow = MNV_SHADOW_MASK;
+
 // One step of the march on integer cell coordinates.  pos in [0, 1-1e-6] is scaled by 2^Lq
 // (Lq = deepest voxel depth of the tree, <= 23: the product is exact and < 2^24) and truncated;
 // bit (Lq - d) of each coordinate is the child index at depth d, and the cell numbers of the two
 // lookup grids are plain shifts.  The in-leaf coordinates are fract(pos * 2^depth), which equals the
 // reference's iterated x*2 - floor(x*2) bit for bit (all three operations are exact in binary32).
-template <int BASIS, int BLOCK, int MODE /* 0 plain, 1 statistics, 2 refinement trackers, 3 trackers + emitted samples instead of colour, 4 plain with fast colour math, 5 depth image (render_depth) */>
+template <int BASIS, int BLOCK, int MODE /* 0 plain, 1 statistics, 2 refinement trackers, 3 trackers + emitted samples instead of colour, 4 plain with fast colour math, 5 depth image (render_depth) */,
+          bool BRICK = false /* the two levels below the second lookup grid come from A.bricks (one 8-byte load) instead of two node loads */>
 // A/B knobs (tools/build_variant.sh): explicit register budgets on top of the launch bounds
 #if defined(MNV_NUM_VGPR) && defined(MNV_NUM_SGPR)
 #define MNV_EXTRA_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(MNV_NUM_VGPR), amdgpu_num_sgpr(MNV_NUM_SGPR)))
@@ -363,6 +372,28 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                         word = A.grid2[vox];
                         src = 1;
                         sh = sh2;
+                        if constexpr ((kShadow & 8) != 0) {  // shadow load: the same cell of grid2_vox (same size, same order, other addresses)
+                            const uint32_t w2 = A.grid2_vox[vox];
+                            asm volatile("" ::"v"(w2));
+                        }
+                        if constexpr (BRICK) {
+                            // two levels in one load: cell (x2, y2, z2) of the brick of the chunk the grid cell names
+                            if (!(word & kLeafBit)) {
+                                stat(6, true);
+                                sh -= 2;
+                                uint32_t c = (word << 2) | __builtin_amdgcn_ubfe(q[0], (uint32_t)sh, 2u);
+                                c = (c << 2) | __builtin_amdgcn_ubfe(q[1], (uint32_t)sh, 2u);
+                                c = (c << 2) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh, 2u);
+                                const uint2 bw = A.bricks[c];
+                                word = bw.x;
+                                vox = bw.y;
+                                src = 2;
+                                if constexpr ((kShadow & 64) != 0) {
+                                    const uint2 b2 = K.shadow_bricks[c];
+                                    asm volatile("" ::"v"(b2.x));
+                                }
+                            }
+                        }
                     }
                     while (!(word & kLeafBit)) {
                         stat(6, true);
@@ -372,6 +403,10 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                         vox = (v << 1) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh, 1u);
                         word = A.nodes[vox];
                         src = 2;
+                        if constexpr ((kShadow & 16) != 0) {
+                            const uint32_t w2 = K.shadow_nodes[vox];
+                            asm volatile("" ::"v"(w2));
+                        }
                     }
                 }
                 if constexpr (MODE == 1) {
@@ -543,6 +578,10 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                     uint32_t vx = vox;
                     if (ablate(4)) vx &= 0xffffu;  // diagnostics: rows served from cache (wrong colours)
                     const uint8_t *row = A.rows + (int64_t)vx * ROW_BYTES;
+                    if constexpr ((kShadow & 32) != 0) {  // shadow load: one dword of the same row of the copy (one more line fill)
+                        const uint32_t w2 = *reinterpret_cast<const uint32_t *>(K.shadow_rows + (int64_t)vx * ROW_BYTES);
+                        asm volatile("" ::"v"(w2));
+                    }
                     const ChanWords<NW> c0 = *reinterpret_cast<const ChanWords<NW> *>(row);
                     const ChanWords<NW> c1 = *reinterpret_cast<const ChanWords<NW> *>(row + CHAN_BYTES);
                     const ChanWords<NW> c2 = *reinterpret_cast<const ChanWords<NW> *>(row + 2 * CHAN_BYTES);

@@ -24,6 +24,7 @@ static inline uint64_t d2u(double d) { uint64_t u; memcpy(&u, &d, 8); return u; 
 static inline double u2d(uint64_t u) { double d; memcpy(&d, &u, 8); return d; }
 
 /* CUDA min/max on floats (rt_core.cuh uses the unqualified device overloads). */
+static uint64_t *g_depth_hist = NULL; /* analysis hook, see orc_set_depth_histogram */
 static inline float fminf_(float a, float b) { return a < b ? a : b; }
 static inline float fmaxf_(float a, float b) { return a > b ? a : b; }
 
@@ -358,6 +359,13 @@ static void trace_ray(const orc_tree *tree, int32_t *visited, float dir[3], cons
         const uint16_t *row = tree->data + ((int64_t)chunk * N3 + child_idx) * data_dim;
         const float sigma = orc_half_to_float(row[data_dim - 1]); /* :231 */
         ++st->steps;
+        if (g_depth_hist) { /* analysis hook (orc_set_depth_histogram): steps by leaf depth, empty | dense */
+            const int dense_step = sigma > opt->sigma_thresh;
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+            g_depth_hist[dense_step * 32 + (depth < 31 ? depth : 31)] += 1;
+        }
 
         if (sigma > opt->sigma_thresh) { /* :233 */
             ++st->hits;
@@ -444,6 +452,10 @@ static void trace_ray(const orc_tree *tree, int32_t *visited, float dir[3], cons
         out[3] = 1.f - light_intensity;
     }
 }
+
+/* analysis hook, not part of any parity check: hist[0][d] += 1 per march step that lands in an empty leaf of depth d (sigma <= sigma_thresh),
+ * hist[1][d] per dense step; NULL switches it off */
+void orc_set_depth_histogram(uint64_t *hist_2x32) { g_depth_hist = hist_2x32; }
 
 static inline uint8_t pack_u8(float v) {
     /* renderer_kernel.cu:237 uint8_t(v * 255): truncation; the CUDA float->u8

@@ -205,6 +205,10 @@ int orc_mlp_forward(const orc_mlp_desc *desc, const uint16_t *params, const int1
 
 int orc_num_threads(void);
 
+/* Analysis hook (no parity test depends on it): while `hist_2x32` is non-NULL every march step of orc_render_voxels adds 1 to
+ * hist[dense][leaf depth] (dense = sigma > sigma_thresh).  tools/step_depths.py uses it to say where a workload's steps land. */
+void orc_set_depth_histogram(uint64_t *hist_2x32);
+
 #ifdef __cplusplus
 }
 #endif

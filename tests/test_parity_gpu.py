@@ -509,6 +509,50 @@ def test_tree_depth_extremes_bit_exact(mnv, orc, torch_gpu, depth, refine, basis
         assert np.array_equal(cases.bits(got), cases.bits(ref["rgba"])), (depth, which)
 
 
+@pytest.mark.parametrize("depth,basis,fmt_kw", [(10, 9, {}), (11, 4, {}), (12, 9, {}), (13, 1, {}), (11, -1, dict(fmt=0)), (11, 16, {})])
+def test_bricks_below_the_second_grid_bit_exact(mnv, orc, torch_gpu, depth, basis, fmt_kw):
+    """Trees with leaves two or more levels below the second lookup grid carry bricks (the two levels below the grid in one 8-byte
+    load: AccelView::bricks): plain, fast-colour-off and depth frames read them and stay bit-identical to the oracle; a tree edit
+    (mnv_accel_refresh) drops them -- frames walk the node words, still right -- and mnv_accel_rebuild derives them again."""
+    torch = torch_gpu
+    spec = dict(kind="random", depth=depth, basis_dim=basis, refine_prob=0.42, empty_prob=0.93, sigma_max=40.0, seed=300 + depth + basis, **fmt_kw)
+    tree = cases.make_tree(mnv, spec)
+    cam = mnv.Camera(200, 144, 500.0).set_pose((-2.5, 1.4, 1.8), (-0.74, 0.4, 0.54))
+    opt = mnv.RenderOptions.cli_defaults()
+    t = orc.tree_from_view(tree.host_view())
+    ref = orc.render(t, cam.c, opt)
+    assert ref["counters"].hits > 5000 and ref["counters"].levels > 3.5 * ref["counters"].steps   # mostly empty: rays go deep
+    tree.move_to_device(need_parent=True)
+    info = mnv.accel_info(tree.accel)
+    assert info["brick_levels"] == 2 and depth >= info["grid2_level"] + 2, info
+    got, _ = _render_gpu(mnv, torch, tree, cam, opt, "accel")
+    assert np.array_equal(cases.bits(got), cases.bits(ref["rgba"]))
+    if basis != -1:
+        opt_d = mnv.RenderOptions.cli_defaults()
+        opt_d.render_depth = True
+        want_d = orc.render(t, cam.c, opt_d)["rgba"]
+        got_d, _ = _render_gpu(mnv, torch, tree, cam, opt_d, "accel")
+        assert np.array_equal(cases.bits(got_d), cases.bits(want_d))
+    # a sub-rectangle and a batch of two cameras through the same kernel
+    cam2 = mnv.Camera(200, 144, 500.0).set_pose((2.2, -1.9, 1.1), (0.7, -0.6, 0.39))
+    ref2 = orc.render(t, cam2.c, opt)["rgba"]
+    out = torch.empty((2, cam.height, cam.width, 4), dtype=torch.float32, device="cuda")
+    mnv.render_voxels_accel_batch(tree.accel, [cam, cam2], opt, rgba=out)
+    torch.cuda.synchronize()
+    assert np.array_equal(cases.bits(out[0].cpu().numpy()), cases.bits(ref["rgba"])) and np.array_equal(cases.bits(out[1].cpu().numpy()), cases.bits(ref2))
+    # stale after a refresh (no change needed for the flag to drop: an empty edit list is a no-op, so rewrite one row in place)
+    dv = tree.device_view()
+    changed = torch.tensor([[0, 0]], dtype=torch.int32, device="cuda")
+    mnv.accel_refresh(tree.accel, dv, dv.capacity, changed_nodes=changed)
+    assert mnv.accel_info(tree.accel)["brick_levels"] == 0
+    got, _ = _render_gpu(mnv, torch, tree, cam, opt, "accel")
+    assert np.array_equal(cases.bits(got), cases.bits(ref["rgba"]))
+    mnv.accel_rebuild(tree.accel, dv)
+    assert mnv.accel_info(tree.accel)["brick_levels"] == 2
+    got, _ = _render_gpu(mnv, torch, tree, cam, opt, "accel")
+    assert np.array_equal(cases.bits(got), cases.bits(ref["rgba"]))
+
+
 @pytest.mark.parametrize("step", [1e-4, 1.5e-3, 3e-3, 5e-2])
 def test_extreme_opacity_exercises_expf_tails(mnv, orc, torch_gpu, step):
     """sigma up to the binary16 maximum: the opacity exponent -dt * scale * sigma sweeps through the

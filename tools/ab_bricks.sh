@@ -1,0 +1,12 @@
+#!/bin/bash
+# A/B of the bricks below the second lookup grid (AccelView::bricks) on the deep-tree workloads: MNV_BRICK_LEVELS=0 builds the accel without them.
+# The knob exists in the test-hook build of the library only (csrc/mnv_knobs.h).   usage (via gpurun): bash tools/ab_bricks.sh [workloads...]
+export MNV_LIB_PATH=${MNV_LIB_PATH:-$(cd "$(dirname "$0")/.." && pwd)/mega-nerf-viewer_amd/testhooks/libmnv.so}
+for wl in ${@:-cfg3 cfg4}; do
+  for B in 2 0; do
+    MNV_BRICK_LEVELS=$B timeout 900 python3 bench.py --workload $wl --laps 1 --steps 5 --warmup 2 --no-cpu-baseline --no-extras --frame-streams 0 2>/dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$wl bricks $B:', d['value'], 'Mrays/s', d['roofline']['avg_launch_ms'], 'ms per launch')"
+  done
+done
