@@ -16,12 +16,19 @@
 //   grid2 / grid2_vox [2^L2]^3 u32   the same two arrays at level L2 <= min(max_depth-1, 9), in
 //                            4x4x4-cell brick order; a step below the LDS grid costs one load
 //                            here plus one node load per level below L2
-//   bricks [capacity][64] {u32 word, u32 vox}   (trees with leaves two or more levels below L2 only; dropped by a tree edit, rebuilt by
-//                            mnv_accel_rebuild) the TWO levels below the second lookup grid in one 8-byte load: brick c belongs to chunk c
-//                            of depth L2 + 1 (the chunk a non-leaf grid2 cell names) and holds, for each of the 4x4x4 cells of level
-//                            L2 + 2 under it, the node word of the covering voxel (a leaf of depth L2 + 1 / L2 + 2, or the child chunk of
-//                            a depth-(L2 + 2) voxel) and that voxel's index -- replaces two dependent 4-byte node loads from two
-//                            scattered 32-byte chunks by one load from a 512-byte brick that neighbouring rays share
+//   recs [capacity][8] {u32 child, u32 codes}   brick records (trees with leaves two or more levels below L2 only; dropped by a tree edit,
+//                            derived again by mnv_accel_rebuild): record c belongs to chunk c of depth L2 + 1 -- the chunk a non-leaf grid2
+//                            cell names -- and describes the 4x4x4 cells of level L2 + 2 under it in 64 bytes.  Entry s1 (one 8-byte load):
+//                              child   chunk of the children of voxel s1 (0: that voxel is a leaf)
+//                              codes   two bits per sub-cell s2 (bits 2 * s2):
+//                                      0 walk the node words (inner voxel of depth L2 + 2, or voxel s1 is a leaf with sigma != 0)
+//                                      1 voxel s1 is a leaf (depth L2 + 1) with sigma bits 0      2 leaf of depth L2 + 2, sigma bits 0
+//                                      3 leaf of depth L2 + 2, sigma != 0: voxel child * 8 + s2; its sigma is read with its colour row
+//                            Near a thin surface most fine steps land in EMPTY leaves of the last two levels: a 128-byte line of node words
+//                            describes 32 voxels, a line of records 128 cells, and the level in between is not read at all (cfg3: node
+//                            words were 41 % of the L2 misses, profiles/r05_traffic_cfg3_by_array.json).
+//   rows: the half behind the three channel blocks (half 3 * chan_halfs; every format has it spare) holds the voxel's sigma, so that a
+//                            dense sample found through a record needs no node word at all.
 // The in-leaf coordinates the march needs are frac(pos * 2^depth); x*2, floorf and
 // x - floorf(x) are exact in binary32 for x in [0,2), so any traversal that reaches the
 // same leaf reproduces the reference's iterated descent bit for bit.
@@ -44,6 +51,7 @@ constexpr int kNumQueues = 8;     // one ray queue per XCD
 constexpr int kSlots = 64;        // per-launch parameter slots in flight
 constexpr size_t kSlotBytes = (size_t)MNV_MAX_BATCH * (kNumQueues * 64 + sizeof(mnv::CamBlock));
 constexpr int kMaxGrid2Level = 9;  // 8^9 * 4 B = 512 MiB per array
+constexpr int kRecWords = 16;      // a brick record: 8 entries {child chunk, 8 two-bit sub-cell codes} = 64 B
 
 // Interleaved macro-tile partition (mnv_partition in include/mnv.h).  Tiles are dealt in rounds of `world`; with a root period
 // M >= 2 every M-th round leaves rank 0 out, so a period is L = world * M - 1 tiles of which rank 0 owns M - 1 and the others M.
@@ -95,7 +103,8 @@ struct AccelView {
     const uint32_t *grid2;      // [2^L2]^3 brick-ordered second lookup grid (NULL when grid2_level == 0)
     const uint32_t *grid2_vox;
     int32_t grid2_level;
-    const uint2 *bricks;        // [capacity][64] {word, vox}: levels grid2_level + 1 and + 2 (NULL: none, the node words are walked)
+    const uint2 *recs;          // [capacity][8] brick records of levels grid2_level + 1 and + 2 (NULL: none, the node words are walked)
+    int32_t sigma_off;          // byte offset of the sigma half inside a colour row
     int32_t max_depth;          // deepest voxel depth of the tree (<= 23)
     int32_t row_bytes;
     float offset[3], scale[3];
@@ -112,7 +121,7 @@ struct mnv_accel {
     uint32_t *grid_vox = nullptr;
     uint32_t *grid2 = nullptr;
     uint32_t *grid2_vox = nullptr;
-    uint2 *bricks = nullptr;              // [reserved][64]; view.bricks is NULL while they are stale (after mnv_accel_refresh / a prune)
+    uint2 *recs = nullptr;                // [reserved][8]; view.recs is NULL while they are stale (after mnv_accel_refresh / a prune)
     uint32_t *shadow_nodes = nullptr;     // MNV_ABLATE shadow loads (test-hook build, diagnostics instantiation): copies of nodes / rows at other
     uint8_t *shadow_rows = nullptr;       // addresses, read with the same access pattern to attribute the HBM traffic by array
     uint32_t *nodes_spare = nullptr;      // second set of nodes / rows / depth, allocated by the first prune (accel_apply_prune writes the

@@ -54,8 +54,12 @@ __global__ void accel_pack_rows(const uint16_t *data, uint16_t *rows, int64_t nv
     const uint16_t *src = data + v * data_dim + c * per_chan;
     uint16_t *dst = rows + v * row_halfs + c * chan_halfs;
     for (int32_t k = 0; k < chan_halfs; ++k) dst[k] = k < per_chan ? src[k] : (uint16_t)0;
-    if (c == 2)
-        for (int32_t k = 3 * chan_halfs; k < row_halfs; ++k) rows[v * row_halfs + k] = 0;
+    if (c == 2) {
+        // the half behind the three channel blocks carries the voxel's sigma (every format has it spare): a dense sample found through a
+        // brick record reads it with its colours instead of a node word
+        rows[v * row_halfs + 3 * chan_halfs] = data[v * data_dim + data_dim - 1];
+        for (int32_t k = 3 * chan_halfs + 1; k < row_halfs; ++k) rows[v * row_halfs + k] = 0;
+    }
 }
 
 // grid[(ix*G + iy)*G + iz] = word of the voxel of depth <= L that covers cell (ix,iy,iz)
@@ -99,26 +103,28 @@ __global__ void accel_build_grid2(const uint32_t *nodes, uint32_t *grid2, uint32
 
 // (Re)build every derived array of `a` from the tree: chunk depths, node words, colour rows, lookup grids.  The big arrays
 // (nodes, rows, depth) are sized for a->reserved chunks and kept; the grids are reallocated only when their level changes.
-// bricks[c][cell] for every chunk c of depth L2 + 1: cell = (x2 << 4) | (y2 << 2) | z2, the high bit of each pair is the child index at depth
-// L2 + 1, the low bit at depth L2 + 2 -- the node word and the voxel index of the voxel of depth <= L2 + 2 that covers the cell
-__global__ void accel_build_bricks(const uint32_t *nodes, const int32_t *depth, uint2 *bricks, int32_t capacity, int32_t L2) {
+// brick record of every chunk c of depth L2 + 1 (layout: mnv_accel.h); one thread per (chunk, voxel s1)
+__global__ void accel_build_recs(const uint32_t *nodes, const int32_t *depth, uint2 *recs, int32_t capacity, int32_t L2) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)capacity * 64) return;
-    const int32_t c = (int32_t)(i >> 6);
-    if (depth[c] != L2 + 1) return;
-    const uint32_t cell = (uint32_t)(i & 63), x2 = cell >> 4, y2 = (cell >> 2) & 3u, z2 = cell & 3u;
-    uint32_t vox = (uint32_t)c * 8u + (((x2 >> 1) << 2) | ((y2 >> 1) << 1) | (z2 >> 1));
-    uint32_t word = nodes[vox];
-    if (!(word & kLeafBit)) {
-        vox = word * 8u + (((x2 & 1u) << 2) | ((y2 & 1u) << 1) | (z2 & 1u));
-        word = nodes[vox];
+    if (i >= (int64_t)capacity * 8) return;
+    if (depth[i >> 3] != L2 + 1) return;
+    const uint32_t w1 = nodes[i];
+    uint32_t child = 0u, codes = 0u;
+    if (w1 & kLeafBit) {
+        if ((w1 & 0xffffu) == 0u) codes = 0x5555u;  // an empty leaf of depth L2 + 1: code 1 for its eight sub-cells
+    } else {
+        child = w1;
+        for (uint32_t s2 = 0; s2 < 8; ++s2) {
+            const uint32_t w2 = nodes[(int64_t)w1 * 8 + s2];
+            if (w2 & kLeafBit) codes |= ((w2 & 0xffffu) == 0u ? 2u : 3u) << (2 * s2);
+        }
     }
-    bricks[i] = make_uint2(word, vox);
+    recs[i] = make_uint2(child, codes);
 }
 
-void launch_build_bricks(const uint32_t *nodes, const int32_t *depth, uint2 *bricks, int32_t capacity, int32_t L2, hipStream_t stream) {
-    const int64_t n = (int64_t)capacity * 64;
-    hipLaunchKernelGGL(accel_build_bricks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, nodes, depth, bricks, capacity, L2);
+void launch_build_recs(const uint32_t *nodes, const int32_t *depth, uint2 *recs, int32_t capacity, int32_t L2, hipStream_t stream) {
+    const int64_t n = (int64_t)capacity * 8;
+    hipLaunchKernelGGL(accel_build_recs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, nodes, depth, recs, capacity, L2);
 }
 
 void launch_pack_rows(const uint16_t *data, uint16_t *rows, int64_t nvox, int32_t data_dim, int32_t per_chan, int32_t chan_halfs, int32_t row_halfs,
@@ -195,21 +201,21 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
         }
         hipLaunchKernelGGL(accel_build_grid2, dim3((unsigned)((g2cells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid2, a->grid2_vox, L2);
     }
-    // bricks: the two levels below the second grid in one load, for trees that have them (depth >= L2 + 2).  A depth-11 tree (cfg3) then
-    // takes LDS grid -> grid2 -> brick instead of LDS grid -> grid2 -> node -> node; a depth-10 tree (cfg2) has one level below L2 = 9 and
-    // keeps its single node load.
+    // brick records: the two levels below the second grid from one 64-byte record per depth-(L2 + 1) chunk, for trees that have two such
+    // levels (depth >= L2 + 2).  A depth-11 tree (cfg3) then takes LDS grid -> grid2 -> record [-> row] instead of LDS grid -> grid2 ->
+    // node -> node [-> row]; a depth-10 tree (cfg2) has one level below L2 = 9 and keeps its single node load.
     static const int env_bricks = knob_int(KNOB_BRICK_LEVELS, 2);
-    const bool want_bricks = env_bricks >= 2 && L2 > 0 && max_depth >= L2 + 2;
-    if (want_bricks) {
-        if (!a->bricks && (rc = check_hip(hipMalloc((void **)&a->bricks, (size_t)max_capacity * 64 * sizeof(uint2)), "hipMalloc(bricks)"))) return fail(rc);
-        launch_build_bricks(a->nodes, depth, a->bricks, t->capacity, L2, stream);
-    } else if (a->bricks) {
-        (void)hipFree(a->bricks);
-        a->bricks = nullptr;
+    const bool want_recs = env_bricks >= 2 && L2 > 0 && max_depth >= L2 + 2;
+    if (want_recs) {
+        if (!a->recs && (rc = check_hip(hipMalloc((void **)&a->recs, (size_t)max_capacity * kRecWords * 4), "hipMalloc(brick records)"))) return fail(rc);
+        launch_build_recs(a->nodes, depth, a->recs, t->capacity, L2, stream);
+    } else if (a->recs) {
+        (void)hipFree(a->recs);
+        a->recs = nullptr;
     }
     if ((rc = check_hip(hipGetLastError(), "accel build launch"))) return fail(rc);
     if ((rc = check_hip(hipStreamSynchronize(stream), "accel build"))) return fail(rc);
-    a->view.bricks = want_bricks ? a->bricks : nullptr;
+    a->view.recs = want_recs ? a->recs : nullptr;
 
     a->view.nodes = a->nodes;
     a->view.rows = a->rows;
@@ -221,6 +227,7 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
     a->view.grid2_level = L2;
     a->view.max_depth = max_depth;
     a->view.row_bytes = row_bytes;
+    a->view.sigma_off = 3 * (b > 0 ? chan_bytes_for(b) : 2);
     for (int i = 0; i < 3; ++i) {
         a->view.offset[i] = t->offset[i];
         a->view.scale[i] = t->scale[i];
@@ -229,7 +236,7 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
     a->view.basis_dim = t->basis_dim;
     a->view.format = t->format;
     a->view.capacity = t->capacity;
-    a->bytes = (size_t)(nvox * 4 + nvox * row_bytes + gcells * 8 + g2cells * 8) + (a->bricks ? (size_t)max_capacity * 64 * sizeof(uint2) : 0);
+    a->bytes = (size_t)(nvox * 4 + nvox * row_bytes + gcells * 8 + g2cells * 8) + (a->recs ? (size_t)max_capacity * kRecWords * 4 : 0);
     return MNV_OK;
 }
 
@@ -332,7 +339,7 @@ void mnv_accel_destroy(mnv_accel *a) {
         }
     }
     if (a->timeline) (void)hipFree(a->timeline);
-    if (a->bricks) (void)hipFree(a->bricks);
+    if (a->recs) (void)hipFree(a->recs);
     if (a->shadow_nodes) (void)hipFree(a->shadow_nodes);
     if (a->shadow_rows) (void)hipFree(a->shadow_rows);
     if (a->nodes_spare) (void)hipFree(a->nodes_spare);
@@ -359,7 +366,7 @@ void mnv_accel_destroy(mnv_accel *a) {
 
 size_t mnv_accel_device_bytes(const mnv_accel *a) { return a ? a->bytes : 0; }
 int32_t mnv_accel_grid2_level(const mnv_accel *a) { return a ? a->view.grid2_level : -1; }
-int32_t mnv_accel_brick_levels(const mnv_accel *a) { return a ? (a->view.bricks ? 2 : 0) : -1; }
+int32_t mnv_accel_brick_levels(const mnv_accel *a) { return a ? (a->view.recs ? 2 : 0) : -1; }
 
 int mnv_accel_set_cu_budget(mnv_accel *a, int32_t num_cus) {
     if (!a) return set_error(MNV_E_INVALID, "accel is null");

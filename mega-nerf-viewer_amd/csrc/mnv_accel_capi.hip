@@ -195,11 +195,11 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
         int es = 0;
         if (env_shadow & 16) es = shadow((void **)&mut->shadow_nodes, accel->nodes, nvox * 4);
         if (!es && (env_shadow & 32)) es = shadow((void **)&mut->shadow_rows, accel->rows, nvox * (size_t)accel->view.row_bytes);
-        if (!es && (env_shadow & 64) && accel->bricks) es = shadow((void **)&mut->shadow_nodes, accel->bricks, nvox * 64);  // (bits 16 and 64 are not combined)
+        if (!es && (env_shadow & 64) && accel->recs) es = shadow((void **)&mut->shadow_nodes, accel->recs, (size_t)accel->reserved * kRecWords * 4);  // (bits 16 and 64 are not combined)
         if (es) return es;
         K.shadow_nodes = accel->shadow_nodes;
         K.shadow_rows = accel->shadow_rows;
-        K.shadow_bricks = reinterpret_cast<const uint2 *>(accel->shadow_nodes);
+        K.shadow_recs = reinterpret_cast<const uint2 *>(accel->shadow_nodes);
     }
     static const int env_stats_level = env_stats ? std::max(1, knob_int(KNOB_STATS, 1)) : 0;
     K.count_stats = env_stats ? env_stats_level : 0;
@@ -233,7 +233,9 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     const int b = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim >= 0) ? accel->view.basis_dim : -1;
     if (track && track->fused) {
         rc = launch_fused(accel, K, *track->fused, b, lds_level, n_waves_needed, stream);
-    } else if (K.A.bricks && !K.split_track && !K.sample_track && !K.visited && !K.samples) {
+    } else if (K.A.recs && !K.split_track && !K.sample_track && !K.visited && !K.samples && !(P.sigma_thresh < 0.f) && b < 16) {
+        // (a record calls a leaf whose sigma bits are 0 "not dense" without reading it: true for every sigma_thresh >= 0; SH16 / SH25 rows are
+        // evaluated by the cooperative pass, which has no brick variant)
         rc = launch_march_brick(K, b, colourless, n_blocks, lds_bytes, stream);
     } else {
         rc = launch_march(K, b, colourless, n_blocks, lds_bytes, stream);

@@ -49,9 +49,9 @@ struct AccelLaunch {
     int32_t *visited;                     // MODE 2 / 3 only: visit marks [capacity]; the march marks the chunk of every leaf it steps through,
                                           // close_visit_marks adds the ancestors (= every chunk of every descent, rt_core.cuh:132-134)
     int32_t ablate;                       // diagnostics only (breaks results): 1 no colour, 2 no dense samples, 4 cached rows
-    const uint32_t *shadow_nodes;         // -DMNV_SHADOW_MASK variants only: copies of nodes / rows / bricks for the shadow loads
+    const uint32_t *shadow_nodes;         // -DMNV_SHADOW_MASK variants only: copies of nodes / rows / brick records for the shadow loads
     const uint8_t *shadow_rows;
-    const uint2 *shadow_bricks;
+    const uint2 *shadow_recs;
     // MODE 3 only: the sample-emitting march of guided sampling (rt_core.cuh:418-576) -- no colour, rows of
     // (z, world xyz[, view dir][, embedding]) per dense step and the trackers of MODE 2
     int32_t max_guided_samples, samples_dim, need_viewdir, appearance_embedding;
@@ -166,14 +166,14 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream);
 // the two lookup grids, whole, from the node words (mnv_accel_build.hip; the refresh rebuilds the small one, or both without a parent array)
 void launch_pack_rows(const uint16_t *data, uint16_t *rows, int64_t nvox, int32_t data_dim, int32_t per_chan, int32_t chan_halfs, int32_t row_halfs,
                       hipStream_t stream);
-// bricks of the chunks of depth L2 + 1 (cells of level L2 + 2); one thread per (chunk, cell)
-void launch_build_bricks(const uint32_t *nodes, const int32_t *depth, uint2 *bricks, int32_t capacity, int32_t L2, hipStream_t stream);
+// brick records of the chunks of depth L2 + 1 (mnv_accel.h); one thread per chunk
+void launch_build_recs(const uint32_t *nodes, const int32_t *depth, uint2 *recs, int32_t capacity, int32_t L2, hipStream_t stream);
 void launch_build_grid(const uint32_t *nodes, uint32_t *grid, uint32_t *grid_vox, int32_t L, hipStream_t stream);
 void launch_build_grid2(const uint32_t *nodes, uint32_t *grid2, uint32_t *grid2_vox, int32_t L2, hipStream_t stream);
 // march_accel_kernel for the row format `basis` (-1 RGBA, 1 / 4 / 9 / 16 / 25 SH) in the mode the launch block asks for
 // (mnv_accel_march.hip); kUnsupportedBasis or a hipError_t
 int launch_march(const AccelLaunch &K, int basis, bool colourless, int n_blocks, size_t lds_bytes, hipStream_t stream);
-// the same for trees with bricks (K.A.bricks != NULL), plain / fast-colour / depth frames (mnv_accel_march_brick.hip)
+// the same for trees with brick records (K.A.recs != NULL), plain / fast-colour / depth frames (mnv_accel_march_brick.hip)
 int launch_march_brick(const AccelLaunch &K, int basis, bool colourless, int n_blocks, size_t lds_bytes, hipStream_t stream);
 // mnv_set_colour_math
 bool fast_colour_selected();

@@ -1,6 +1,7 @@
-// mnv_accel_march_brick.hip -- the instantiations of march_accel_kernel for trees with bricks (AccelView::bricks: the two levels below the
-// second lookup grid in one load): plain, fast-colour and depth frames, and the diagnostics instantiation of the SH9 kernel.  Tracker /
-// sample / fused frames of such trees walk the node words (mnv_accel_march.hip, mnv_accel_fused.hip): every lookup array stays valid.
+// mnv_accel_march_brick.hip -- the instantiations of march_accel_kernel for trees with brick records (AccelView::recs: the two levels below
+// the second lookup grid from one 64-byte record per chunk): plain, fast-colour and depth frames of the per-lane row formats (RGBA, SH1 / 4 /
+// 9), and the diagnostics instantiation of the SH9 kernel.  Tracker / sample / fused frames, SH16 / SH25 trees and frames with a negative
+// sigma_thresh walk the node words (mnv_accel_march.hip, mnv_accel_fused.hip): every other lookup array stays valid.
 #include "mnv_march_accel_kernel.h"
 
 namespace mnv {
@@ -36,8 +37,6 @@ int launch_march_brick(const AccelLaunch &K, int b, bool colourless, int n_block
         case 1: return launch_brick<1>(K, n_blocks, lds_bytes, stream);
         case 4: return launch_brick<4>(K, n_blocks, lds_bytes, stream);
         case 9: return launch_brick<9>(K, n_blocks, lds_bytes, stream);
-        case 16: return launch_brick<16>(K, n_blocks, lds_bytes, stream);
-        case 25: return launch_brick<25>(K, n_blocks, lds_bytes, stream);
         default: break;
     }
     return kUnsupportedBasis;

@@ -68,6 +68,7 @@ __global__ void accel_refresh_changed(const int32_t *changed_nodes, int32_t n, c
     nodes[v] = kLeafBit | (((uint32_t)depth[c] & 0x7fu) << 16) | (uint32_t)data[v * data_dim + data_dim - 1];
     for (int ch = 0; ch < 3; ++ch)
         for (int32_t k = 0; k < chan_halfs; ++k) rows[v * row_halfs + ch * chan_halfs + k] = k < per_chan ? data[v * data_dim + ch * per_chan + k] : (uint16_t)0;
+    rows[v * row_halfs + 3 * chan_halfs] = data[v * data_dim + data_dim - 1];  // sigma in the half behind the channel blocks (accel_pack_rows)
     if (depth[c] <= grid_depth) flags[2] = 1;
     atomicMin(&flags[3], depth[c]);
     if (items) items[i] = patch_items(depth[c], L2);
@@ -277,7 +278,7 @@ int accel_apply_prune(mnv_accel *a, const int32_t *parent, const uint16_t *data,
     a->view.nodes = a->nodes;
     a->view.rows = a->rows;
     a->view.capacity = old_capacity - n_deleted;  // max_depth stays an upper bound (the march only needs pos * 2^max_depth < 2^24)
-    a->view.bricks = nullptr;                      // stale (chunks renumbered): rebuilt by mnv_accel_rebuild
+    a->view.recs = nullptr;                        // stale (chunks renumbered): derived again by mnv_accel_rebuild
     return MNV_OK;
 }
 
@@ -364,7 +365,7 @@ int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity
     }
     a->view.max_depth = std::max(a->view.max_depth, h[1]);
     a->view.capacity = t->capacity;
-    a->view.bricks = nullptr;  // stale: plain frames walk the node words until mnv_accel_rebuild derives the bricks again
+    a->view.recs = nullptr;  // stale: plain frames walk the node words until mnv_accel_rebuild derives the brick records again
     return check_hip(hipGetLastError(), "accel refresh launch");
 }
 

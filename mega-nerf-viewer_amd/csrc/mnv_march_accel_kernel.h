@@ -30,11 +30,12 @@ namespace mnv {
 
 // Attribution of the L2 misses by array (tools/traffic_by_array.sh builds variants of the library with -DMNV_SHADOW_MASK=<bits>): every load
 // of the chosen array is repeated at the same index of a copy at other addresses -- results stay right, the miss counters grow by about
-// that array's share.  8 grid2 (its shadow is grid2_vox), 16 nodes, 32 rows, 64 bricks.  0 in every shipped build.
+// that array's share.  8 grid2 (its shadow is grid2_vox), 16 nodes, 32 rows, 64 brick records.  0 in every shipped build.
 #ifndef MNV_SHADOW_MASK
 #define MNV_SHADOW_MASK 0
 #endif
 constexpr int kShadow = MNV_SHADOW_MASK;
+
 
 // One step of the march on integer cell coordinates.  pos in [0, 1-1e-6] is scaled by 2^Lq
 // (Lq = deepest voxel depth of the tree, <= 23: the product is exact and < 2^24) and truncated;
@@ -42,7 +43,7 @@ constexpr int kShadow = MNV_SHADOW_MASK;
 // lookup grids are plain shifts.  The in-leaf coordinates are fract(pos * 2^depth), which equals the
 // reference's iterated x*2 - floor(x*2) bit for bit (all three operations are exact in binary32).
 template <int BASIS, int BLOCK, int MODE /* 0 plain, 1 statistics, 2 refinement trackers, 3 trackers + emitted samples instead of colour, 4 plain with fast colour math, 5 depth image (render_depth) */,
-          bool BRICK = false /* the two levels below the second lookup grid come from A.bricks (one 8-byte load) instead of two node loads */>
+          bool BRICK = false /* the two levels below the second lookup grid come from the brick records (A.recs) instead of two node loads */>
 // A/B knobs (tools/build_variant.sh): explicit register budgets on top of the launch bounds
 #if defined(MNV_NUM_VGPR) && defined(MNV_NUM_SGPR)
 #define MNV_EXTRA_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(MNV_NUM_VGPR), amdgpu_num_sgpr(MNV_NUM_SGPR)))
@@ -334,6 +335,8 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
         }
         // ---- one march step (rt_core.cuh:220-323) for every live lane
         bool dense = false;
+        [[maybe_unused]] bool cand = false;  // BRICK: the leaf came out of a brick record with code 3 (sigma not known yet)
+        [[maybe_unused]] float sigma_held = 0.f;  // BRICK: sigma of a dense leaf that did not come out of a record
         float delta_t = 0.f, weight = 0.f, att = 1.f;
         uint32_t vox = 0;
         ph_mark = phase_clock();
@@ -377,21 +380,27 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                             asm volatile("" ::"v"(w2));
                         }
                         if constexpr (BRICK) {
-                            // two levels in one load: cell (x2, y2, z2) of the brick of the chunk the grid cell names
+                            // the two levels below the grid cell from the 64-byte record of the chunk it names: ONE 8-byte load -- entry s1 = {child
+                            // chunk of voxel s1, 2-bit codes of its eight sub-cells}; empty leaves of either level end here
                             if (!(word & kLeafBit)) {
                                 stat(6, true);
-                                sh -= 2;
-                                uint32_t c = (word << 2) | __builtin_amdgcn_ubfe(q[0], (uint32_t)sh, 2u);
-                                c = (c << 2) | __builtin_amdgcn_ubfe(q[1], (uint32_t)sh, 2u);
-                                c = (c << 2) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh, 2u);
-                                const uint2 bw = A.bricks[c];
-                                word = bw.x;
-                                vox = bw.y;
-                                src = 2;
+                                uint32_t s1 = __builtin_amdgcn_ubfe(q[0], (uint32_t)(sh2 - 1), 1u), s2 = __builtin_amdgcn_ubfe(q[0], (uint32_t)(sh2 - 2), 1u);
+                                s1 = (s1 << 1) | __builtin_amdgcn_ubfe(q[1], (uint32_t)(sh2 - 1), 1u);
+                                s2 = (s2 << 1) | __builtin_amdgcn_ubfe(q[1], (uint32_t)(sh2 - 2), 1u);
+                                s1 = (s1 << 1) | __builtin_amdgcn_ubfe(q[2], (uint32_t)(sh2 - 1), 1u);
+                                s2 = (s2 << 1) | __builtin_amdgcn_ubfe(q[2], (uint32_t)(sh2 - 2), 1u);
+                                const uint2 e = A.recs[(int64_t)word * 8 + s1];
                                 if constexpr ((kShadow & 64) != 0) {
-                                    const uint2 b2 = K.shadow_bricks[c];
-                                    asm volatile("" ::"v"(b2.x));
+                                    const uint2 e2 = K.shadow_recs[(int64_t)word * 8 + s1];
+                                    asm volatile("" ::"v"(e2.x));
                                 }
+                                const uint32_t code = __builtin_amdgcn_ubfe(e.y, s2 << 1, 2u);
+                                // 0: walk on from the chunk (word stays); 1 / 2: an empty leaf of depth L2 + 1 / L2 + 2; 3: a leaf of depth L2 + 2
+                                // with sigma != 0 -- its voxel through the entry's child word, its sigma with its colour row (cand)
+                                vox = (e.x << 3) | s2;
+                                cand = code == 3u;
+                                word = code != 0u ? (kLeafBit | ((uint32_t)(L2 + 2 - (code == 1u ? 1 : 0)) << 16)) : word;
+                                src = 2;
                             }
                         }
                     }
@@ -443,7 +452,11 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                     // the mark only ever goes 0 -> 1: load + conditional plain store (mnv_march_ref_layout.hip does the same per level)
                     if (K.visited && __hip_atomic_load(&K.visited[vox >> 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) K.visited[vox >> 3] = 1;
                 }
-                if (is_dense) {
+                if constexpr (BRICK) {
+                    // the opacity of every dense sample is worked out in the colour block (settle): a candidate's sigma arrives there with its row
+                    dense = (is_dense || cand) && !ablate(2);
+                    sigma_held = sigma;
+                } else if (is_dense) {
                     // opacity of a dense sample, rt_core.cuh:233-235
                     dense = true;
                     att = exact_expf(-delta_t * my_ray[NB * BLOCK] * sigma, s_exp);
@@ -509,11 +522,29 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
         const uint64_t dense_mask = __ballot(dense);
         if (dense_mask != 0) {
             stat(8, dense);
+            // BRICK: whether a sample is dense at all (rt_core.cuh:233) and its opacity (:234-235) are settled here, in one place -- a
+            // candidate (leaf with sigma != 0 out of a brick record) learns its sigma from its row, the half behind the three channel blocks
+            [[maybe_unused]] auto settle = [&](uint32_t row_sigma_bits) {
+                const float sg = cand ? half_bits_to_float((uint16_t)row_sigma_bits) : sigma_held;
+                if (sg > P.sigma_thresh) {
+                    att = exact_expf(-delta_t * my_ray[NB * BLOCK] * sg, s_exp);
+                    weight = T * (1.f - att);
+                } else {
+                    dense = false;
+                }
+            };
+            [[maybe_unused]] auto settle_from_memory = [&]() {  // frames that read no colour row: the sigma half alone
+                if constexpr (BRICK) {
+                    if (dense) settle(cand ? (uint32_t)*reinterpret_cast<const uint16_t *>(A.rows + (int64_t)vox * A.row_bytes + A.sigma_off) : 0u);
+                }
+            };
             if constexpr (MODE == 3) {
                 // no colour: the networks supply it (render_nerf_results)
             } else if (depth_mode()) {
+                settle_from_memory();
                 if (dense) o0 += weight * t;
             } else if (ablate(1)) {
+                settle_from_memory();
             } else if constexpr (BASIS >= 16) {
                 // SH16 / SH25 (a row is 96 / 150 bytes: per-lane rows would need 24 / 39 registers and spill -- 6234 against 8687 Mrays/s for
                 // SH16, 2453 against 4062 for SH25): the wavefront evaluates the samples cooperatively, one lane per (sample, channel):
@@ -584,7 +615,9 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                     }
                     const ChanWords<NW> c0 = *reinterpret_cast<const ChanWords<NW> *>(row);
                     const ChanWords<NW> c1 = *reinterpret_cast<const ChanWords<NW> *>(row + CHAN_BYTES);
-                    const ChanWords<NW> c2 = *reinterpret_cast<const ChanWords<NW> *>(row + 2 * CHAN_BYTES);
+                    // (BRICK: the third block is read one dword longer -- the row's sigma half sits right behind it, accel_pack_rows)
+                    constexpr int NW2 = NW + (BRICK ? 1 : 0);
+                    const ChanWords<NW2> c2 = *reinterpret_cast<const ChanWords<NW2> *>(row + 2 * CHAN_BYTES);
                     if constexpr (MODE == 1) {
                         if (K.count_stats == 2) {
                             const unsigned long long now = phase_clock();   // the rows have arrived
@@ -592,10 +625,11 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                             ph_mark = now;
                         }
                     }
+                    if constexpr (BRICK) settle(c2.w[NW] & 0xffffu);
                     float b[NB];
 #pragma unroll
                     for (int k = 0; k < NB; ++k) b[k] = my_ray[k * BLOCK];
-                    auto chan = [&](const ChanWords<NW> &cw) -> float {
+                    auto chan = [&](const auto &cw) -> float {
                         auto coef = [&](int k) -> float {
                             const uint32_t wd = cw.w[k >> 1];
                             return half_bits_to_float((uint16_t)((k & 1) ? (wd >> 16) : (wd & 0xffffu)));
@@ -610,17 +644,22 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                             return weight / (1.f + exact_expf(-tmp, s_exp));
                         }
                     };
-                    o0 += chan(c0);
-                    o1 += chan(c1);
-                    o2 += chan(c2);
+                    if (dense) {  // (a candidate may have turned out not to be dense)
+                        o0 += chan(c0);
+                        o1 += chan(c1);
+                        o2 += chan(c2);
+                    }
                 }
             } else {
-                // RGBA rows (rt_core.cuh:285-290): three halfs per voxel, per-lane
+                // RGBA rows (rt_core.cuh:285-290): three halfs per voxel (the fourth half of the row is the voxel's sigma), per-lane
                 if (dense) {
                     const uint2 qd = *reinterpret_cast<const uint2 *>(A.rows + (int64_t)vox * ROW_BYTES);
-                    o0 += half_bits_to_float((uint16_t)(qd.x & 0xffffu)) * weight;
-                    o1 += half_bits_to_float((uint16_t)(qd.x >> 16)) * weight;
-                    o2 += half_bits_to_float((uint16_t)(qd.y & 0xffffu)) * weight;
+                    if constexpr (BRICK) settle(qd.y >> 16);
+                    if (dense) {
+                        o0 += half_bits_to_float((uint16_t)(qd.x & 0xffffu)) * weight;
+                        o1 += half_bits_to_float((uint16_t)(qd.x >> 16)) * weight;
+                        o2 += half_bits_to_float((uint16_t)(qd.y & 0xffffu)) * weight;
+                    }
                 }
             }
             if (dense) {

@@ -10,3 +10,21 @@ d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$wl bricks $B:', d['value'], 'Mrays/s', d['roofline']['avg_launch_ms'], 'ms per launch')"
   done
 done
+# L2 misses of the same launches
+export TMPDIR=/tmp
+for wl in ${@:-cfg3 cfg4}; do
+  for B in 2 0; do
+    OUT=$PWD/gpurun_out/ab_bricks/pmc_${wl}_$B; mkdir -p $PWD/gpurun_out/ab_bricks
+    MNV_BRICK_LEVELS=$B timeout 300 rocprofv3 --pmc TCC_MISS_sum TCC_HIT_sum --output-format csv -d "$OUT" -- python3 bench.py --workload $wl --laps 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --frame-streams 0 > "$OUT.log" 2>&1
+    python3 - "$OUT" "$wl bricks $B" <<'PY'
+import csv, glob, os, sys
+from collections import defaultdict
+agg = defaultdict(list)
+for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        if "march" in row.get("Kernel_Name", ""):
+            agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
+print(sys.argv[2], {k: round(sum(v) / len(v)) for k, v in sorted(agg.items())})
+PY
+  done
+done
