@@ -16,6 +16,11 @@
 //   grid2 / grid2_vox [2^L2]^3 u32   the same two arrays at level L2 <= min(max_depth-1, 9), in
 //                            4x4x4-cell brick order; a step below the LDS grid costs one load
 //                            here plus one node load per level below L2
+//   grid2i [2^L2]^3 u32      grid2 with the LAST level folded into the cell word (plain frames read it instead of grid2; dropped by a tree
+//                            edit like the records): a non-leaf cell whose chunk holds eight LEAVES (and has a number below 2^22) reads
+//                              0 | 1 << 30 | (voxel s1 has sigma bits != 0) << (22 + s1) | chunk
+//                            so a step into an empty leaf one level below the grid costs no load beyond the grid cell, and a dense one goes
+//                            straight to its colour row (sigma is in the row).  cfg2 (depth 10, L2 = 9): every deep step; no node word is read.
 //   recs [capacity][8] {u32 child, u32 codes}   brick records (trees with leaves two or more levels below L2 only; dropped by a tree edit,
 //                            derived again by mnv_accel_rebuild): record c belongs to chunk c of depth L2 + 1 -- the chunk a non-leaf grid2
 //                            cell names -- and describes the 4x4x4 cells of level L2 + 2 under it in 64 bytes.  Entry s1 (one 8-byte load):
@@ -51,6 +56,8 @@ constexpr int kNumQueues = 8;     // one ray queue per XCD
 constexpr int kSlots = 64;        // per-launch parameter slots in flight
 constexpr size_t kSlotBytes = (size_t)MNV_MAX_BATCH * (kNumQueues * 64 + sizeof(mnv::CamBlock));
 constexpr int kMaxGrid2Level = 9;  // 8^9 * 4 B = 512 MiB per array
+constexpr uint32_t kInlineBit = 0x40000000u;  // grid2i: the cell's eight children are leaves, described by the word itself
+constexpr int kInlineMaskShift = 22;           // ... bit (22 + s1): child s1 has sigma bits != 0; bits 0..21: the chunk
 constexpr int kRecWords = 16;      // a brick record: 8 entries {child chunk, 8 two-bit sub-cell codes} = 64 B
 
 // Interleaved macro-tile partition (mnv_partition in include/mnv.h).  Tiles are dealt in rounds of `world`; with a root period
@@ -103,6 +110,7 @@ struct AccelView {
     const uint32_t *grid2;      // [2^L2]^3 brick-ordered second lookup grid (NULL when grid2_level == 0)
     const uint32_t *grid2_vox;
     int32_t grid2_level;
+    const uint32_t *grid2i;     // grid2 with inline last-level words (NULL: none / stale; plain frames then read grid2 and walk the node words)
     const uint2 *recs;          // [capacity][8] brick records of levels grid2_level + 1 and + 2 (NULL: none, the node words are walked)
     int32_t sigma_off;          // byte offset of the sigma half inside a colour row
     int32_t max_depth;          // deepest voxel depth of the tree (<= 23)
@@ -121,6 +129,7 @@ struct mnv_accel {
     uint32_t *grid_vox = nullptr;
     uint32_t *grid2 = nullptr;
     uint32_t *grid2_vox = nullptr;
+    uint32_t *grid2i = nullptr;           // [2^L2]^3; view.grid2i is NULL while it is stale
     uint2 *recs = nullptr;                // [reserved][8]; view.recs is NULL while they are stale (after mnv_accel_refresh / a prune)
     uint32_t *shadow_nodes = nullptr;     // MNV_ABLATE shadow loads (test-hook build, diagnostics instantiation): copies of nodes / rows at other
     uint8_t *shadow_rows = nullptr;       // addresses, read with the same access pattern to attribute the HBM traffic by array

@@ -103,6 +103,25 @@ __global__ void accel_build_grid2(const uint32_t *nodes, uint32_t *grid2, uint32
 
 // (Re)build every derived array of `a` from the tree: chunk depths, node words, colour rows, lookup grids.  The big arrays
 // (nodes, rows, depth) are sized for a->reserved chunks and kept; the grids are reallocated only when their level changes.
+// grid2i = grid2 with the last level folded into the words of the cells whose chunk holds eight leaves (mnv_accel.h); one thread per cell
+__global__ void accel_build_grid2i(const uint32_t *nodes, const uint32_t *grid2, uint32_t *grid2i, int64_t cells) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    uint32_t word = grid2[i];
+    if (!(word & kLeafBit) && word < (1u << kInlineMaskShift)) {
+        const uint4 lo = *reinterpret_cast<const uint4 *>(nodes + (int64_t)word * 8), hi = *reinterpret_cast<const uint4 *>(nodes + (int64_t)word * 8 + 4);
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        bool leaves = true;
+        uint32_t mask = 0u;
+        for (int s = 0; s < 8; ++s) {
+            leaves = leaves && (w[s] & kLeafBit) != 0u;
+            mask |= ((w[s] & 0xffffu) != 0u ? 1u : 0u) << s;
+        }
+        if (leaves) word |= kInlineBit | (mask << kInlineMaskShift);
+    }
+    grid2i[i] = word;
+}
+
 // brick record of every chunk c of depth L2 + 1 (layout: mnv_accel.h); one thread per (chunk, voxel s1)
 __global__ void accel_build_recs(const uint32_t *nodes, const int32_t *depth, uint2 *recs, int32_t capacity, int32_t L2) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,6 +211,8 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
         (void)hipFree(a->grid2);
         (void)hipFree(a->grid2_vox);
         a->grid2 = a->grid2_vox = nullptr;
+        if (a->grid2i) (void)hipFree(a->grid2i);
+        a->grid2i = nullptr;
     }
     if (L2 > 0) {
         g2cells = (int64_t)1 << (3 * L2);
@@ -201,11 +222,20 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
         }
         hipLaunchKernelGGL(accel_build_grid2, dim3((unsigned)((g2cells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid2, a->grid2_vox, L2);
     }
-    // brick records: the two levels below the second grid from one 64-byte record per depth-(L2 + 1) chunk, for trees that have two such
-    // levels (depth >= L2 + 2).  A depth-11 tree (cfg3) then takes LDS grid -> grid2 -> record [-> row] instead of LDS grid -> grid2 ->
-    // node -> node [-> row]; a depth-10 tree (cfg2) has one level below L2 = 9 and keeps its single node load.
-    static const int env_bricks = knob_int(KNOB_BRICK_LEVELS, 2);
-    const bool want_recs = env_bricks >= 2 && L2 > 0 && max_depth >= L2 + 2;
+    // What plain frames read instead of node words (derived data that a tree edit drops and mnv_accel_rebuild derives again):
+    //  * grid2i: grid2 with the last level folded into the words of the cells whose chunk holds eight leaves -- a depth-10 tree (cfg2, L2 = 9)
+    //    then never reads a node word: LDS grid -> grid2i [-> row];
+    //  * brick records: the two levels below the grid from one 64-byte record per depth-(L2 + 1) chunk, for trees that have two such levels
+    //    (depth >= L2 + 2; cfg3): LDS grid -> grid2i -> record [-> row] instead of LDS grid -> grid2 -> node -> node [-> row].
+    static const int env_bricks = knob_int(KNOB_BRICK_LEVELS, 3);  // bit 0: inline cell words, bit 1: records
+    const bool want_inline = (env_bricks & 1) && L2 > 0, want_recs = (env_bricks & 2) && want_inline && max_depth >= L2 + 2;
+    if (want_inline) {
+        if (!a->grid2i && (rc = check_hip(hipMalloc((void **)&a->grid2i, g2cells * 4), "hipMalloc(grid2i)"))) return fail(rc);
+        hipLaunchKernelGGL(accel_build_grid2i, dim3((unsigned)((g2cells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid2, a->grid2i, g2cells);
+    } else if (a->grid2i) {
+        (void)hipFree(a->grid2i);
+        a->grid2i = nullptr;
+    }
     if (want_recs) {
         if (!a->recs && (rc = check_hip(hipMalloc((void **)&a->recs, (size_t)max_capacity * kRecWords * 4), "hipMalloc(brick records)"))) return fail(rc);
         launch_build_recs(a->nodes, depth, a->recs, t->capacity, L2, stream);
@@ -215,6 +245,7 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
     }
     if ((rc = check_hip(hipGetLastError(), "accel build launch"))) return fail(rc);
     if ((rc = check_hip(hipStreamSynchronize(stream), "accel build"))) return fail(rc);
+    a->view.grid2i = want_inline ? a->grid2i : nullptr;
     a->view.recs = want_recs ? a->recs : nullptr;
 
     a->view.nodes = a->nodes;
@@ -236,7 +267,7 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
     a->view.basis_dim = t->basis_dim;
     a->view.format = t->format;
     a->view.capacity = t->capacity;
-    a->bytes = (size_t)(nvox * 4 + nvox * row_bytes + gcells * 8 + g2cells * 8) + (a->recs ? (size_t)max_capacity * kRecWords * 4 : 0);
+    a->bytes = (size_t)(nvox * 4 + nvox * row_bytes + gcells * 8 + g2cells * 8) + (a->recs ? (size_t)max_capacity * kRecWords * 4 : 0) + (a->grid2i ? (size_t)g2cells * 4 : 0);
     return MNV_OK;
 }
 
@@ -340,6 +371,7 @@ void mnv_accel_destroy(mnv_accel *a) {
     }
     if (a->timeline) (void)hipFree(a->timeline);
     if (a->recs) (void)hipFree(a->recs);
+    if (a->grid2i) (void)hipFree(a->grid2i);
     if (a->shadow_nodes) (void)hipFree(a->shadow_nodes);
     if (a->shadow_rows) (void)hipFree(a->shadow_rows);
     if (a->nodes_spare) (void)hipFree(a->nodes_spare);
@@ -366,7 +398,7 @@ void mnv_accel_destroy(mnv_accel *a) {
 
 size_t mnv_accel_device_bytes(const mnv_accel *a) { return a ? a->bytes : 0; }
 int32_t mnv_accel_grid2_level(const mnv_accel *a) { return a ? a->view.grid2_level : -1; }
-int32_t mnv_accel_brick_levels(const mnv_accel *a) { return a ? (a->view.recs ? 2 : 0) : -1; }
+int32_t mnv_accel_brick_levels(const mnv_accel *a) { return a ? (a->view.recs ? 2 : a->view.grid2i ? 1 : 0) : -1; }
 
 int mnv_accel_set_cu_budget(mnv_accel *a, int32_t num_cus) {
     if (!a) return set_error(MNV_E_INVALID, "accel is null");

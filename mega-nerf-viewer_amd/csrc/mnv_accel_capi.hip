@@ -233,8 +233,8 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     const int b = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim >= 0) ? accel->view.basis_dim : -1;
     if (track && track->fused) {
         rc = launch_fused(accel, K, *track->fused, b, lds_level, n_waves_needed, stream);
-    } else if (K.A.recs && !K.split_track && !K.sample_track && !K.visited && !K.samples && !(P.sigma_thresh < 0.f) && b < 16) {
-        // (a record calls a leaf whose sigma bits are 0 "not dense" without reading it: true for every sigma_thresh >= 0; SH16 / SH25 rows are
+    } else if (K.A.grid2i && !K.split_track && !K.sample_track && !K.visited && !K.samples && !(P.sigma_thresh < 0.f) && b < 16) {
+        // (an inline cell word / a brick record calls a leaf whose sigma bits are 0 "not dense" without reading it: true for every sigma_thresh >= 0; SH16 / SH25 rows are
         // evaluated by the cooperative pass, which has no brick variant)
         rc = launch_march_brick(K, b, colourless, n_blocks, lds_bytes, stream);
     } else {

@@ -279,6 +279,7 @@ int accel_apply_prune(mnv_accel *a, const int32_t *parent, const uint16_t *data,
     a->view.rows = a->rows;
     a->view.capacity = old_capacity - n_deleted;  // max_depth stays an upper bound (the march only needs pos * 2^max_depth < 2^24)
     a->view.recs = nullptr;                        // stale (chunks renumbered): derived again by mnv_accel_rebuild
+    a->view.grid2i = nullptr;
     return MNV_OK;
 }
 
@@ -365,7 +366,8 @@ int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity
     }
     a->view.max_depth = std::max(a->view.max_depth, h[1]);
     a->view.capacity = t->capacity;
-    a->view.recs = nullptr;  // stale: plain frames walk the node words until mnv_accel_rebuild derives the brick records again
+    a->view.recs = nullptr;  // stale: plain frames walk the node words until mnv_accel_rebuild derives the inline words and brick records again
+    a->view.grid2i = nullptr;
     return check_hip(hipGetLastError(), "accel refresh launch");
 }
 

@@ -43,7 +43,7 @@ constexpr int kShadow = MNV_SHADOW_MASK;
 // lookup grids are plain shifts.  The in-leaf coordinates are fract(pos * 2^depth), which equals the
 // reference's iterated x*2 - floor(x*2) bit for bit (all three operations are exact in binary32).
 template <int BASIS, int BLOCK, int MODE /* 0 plain, 1 statistics, 2 refinement trackers, 3 trackers + emitted samples instead of colour, 4 plain with fast colour math, 5 depth image (render_depth) */,
-          bool BRICK = false /* the two levels below the second lookup grid come from the brick records (A.recs) instead of two node loads */>
+          bool BRICK = false /* the levels below the second lookup grid come from inline cell words (A.grid2i) and brick records (A.recs) instead of node loads */>
 // A/B knobs (tools/build_variant.sh): explicit register budgets on top of the launch bounds
 #if defined(MNV_NUM_VGPR) && defined(MNV_NUM_SGPR)
 #define MNV_EXTRA_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(MNV_NUM_VGPR), amdgpu_num_sgpr(MNV_NUM_SGPR)))
@@ -372,7 +372,8 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                         g = (g << 2) | __builtin_amdgcn_ubfe(q[0], (uint32_t)sh2, 2u);
                         g = (g << 2) | __builtin_amdgcn_ubfe(q[1], (uint32_t)sh2, 2u);
                         vox = (g << 2) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh2, 2u);
-                        word = A.grid2[vox];
+                        if constexpr (BRICK) word = A.grid2i[vox];
+                        else word = A.grid2[vox];
                         src = 1;
                         sh = sh2;
                         if constexpr ((kShadow & 8) != 0) {  // shadow load: the same cell of grid2_vox (same size, same order, other addresses)
@@ -383,6 +384,19 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                             // the two levels below the grid cell from the 64-byte record of the chunk it names: ONE 8-byte load -- entry s1 = {child
                             // chunk of voxel s1, 2-bit codes of its eight sub-cells}; empty leaves of either level end here
                             if (!(word & kLeafBit)) {
+                                uint32_t s1 = __builtin_amdgcn_ubfe(q[0], (uint32_t)(sh2 - 1), 1u);
+                                s1 = (s1 << 1) | __builtin_amdgcn_ubfe(q[1], (uint32_t)(sh2 - 1), 1u);
+                                s1 = (s1 << 1) | __builtin_amdgcn_ubfe(q[2], (uint32_t)(sh2 - 1), 1u);
+                                if (word & kInlineBit) {
+                                    // the cell's eight children are leaves and the word says which of them are empty: no load at all for an
+                                    // empty one, and a non-empty one is a candidate whose sigma arrives with its colour row
+                                    vox = ((word & ((1u << kInlineMaskShift) - 1u)) << 3) | s1;
+                                    cand = ((word >> (kInlineMaskShift + s1)) & 1u) != 0u;
+                                    word = kLeafBit | ((uint32_t)(L2 + 1) << 16);
+                                    src = 2;
+                                }
+                            }
+                            if (!(word & kLeafBit) && A.recs != nullptr) {
                                 stat(6, true);
                                 uint32_t s1 = __builtin_amdgcn_ubfe(q[0], (uint32_t)(sh2 - 1), 1u), s2 = __builtin_amdgcn_ubfe(q[0], (uint32_t)(sh2 - 2), 1u);
                                 s1 = (s1 << 1) | __builtin_amdgcn_ubfe(q[1], (uint32_t)(sh2 - 1), 1u);

@@ -1,10 +1,10 @@
 #!/bin/bash
-# A/B of the bricks below the second lookup grid (AccelView::bricks) on the deep-tree workloads: MNV_BRICK_LEVELS=0 builds the accel without them.
+# A/B of the bricks below the second lookup grid (AccelView::bricks) on the deep-tree workloads: MNV_BRICK_LEVELS=0 builds the accel without them (3: inline cell words + records, 1: inline words only).
 # The knob exists in the test-hook build of the library only (csrc/mnv_knobs.h).   usage (via gpurun): bash tools/ab_bricks.sh [workloads...]
 export MNV_LIB_PATH=${MNV_LIB_PATH:-$(cd "$(dirname "$0")/.." && pwd)/mega-nerf-viewer_amd/testhooks/libmnv.so}
 for wl in ${@:-cfg3 cfg4}; do
-  for B in 2 0; do
-    MNV_BRICK_LEVELS=$B timeout 900 python3 bench.py --workload $wl --laps 1 --steps 5 --warmup 2 --no-cpu-baseline --no-extras --frame-streams 0 2>/dev/null | python3 -c "
+  for B in 3 0; do
+    MNV_BRICK_LEVELS=$B timeout 900 python3 bench.py --workload $wl $( [ $wl = cfg2 ] && echo --laps 4 || echo --laps 1 ) --steps 5 --warmup 2 --no-cpu-baseline --no-extras --frame-streams 0 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('$wl bricks $B:', d['value'], 'Mrays/s', d['roofline']['avg_launch_ms'], 'ms per launch')"
@@ -13,9 +13,9 @@ done
 # L2 misses of the same launches
 export TMPDIR=/tmp
 for wl in ${@:-cfg3 cfg4}; do
-  for B in 2 0; do
+  for B in 3 0; do
     OUT=$PWD/gpurun_out/ab_bricks/pmc_${wl}_$B; mkdir -p $PWD/gpurun_out/ab_bricks
-    MNV_BRICK_LEVELS=$B timeout 300 rocprofv3 --pmc TCC_MISS_sum TCC_HIT_sum --output-format csv -d "$OUT" -- python3 bench.py --workload $wl --laps 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras --frame-streams 0 > "$OUT.log" 2>&1
+    MNV_BRICK_LEVELS=$B timeout 300 rocprofv3 --pmc TCC_MISS_sum TCC_HIT_sum --output-format csv -d "$OUT" -- python3 bench.py --workload $wl $( [ $wl = cfg2 ] && echo --laps 4 || echo --laps 1 ) --steps 3 --warmup 1 --no-cpu-baseline --no-extras --frame-streams 0 > "$OUT.log" 2>&1
     python3 - "$OUT" "$wl bricks $B" <<'PY'
 import csv, glob, os, sys
 from collections import defaultdict
