@@ -184,7 +184,7 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
     if (max_depth > 23) return fail(set_error(MNV_E_UNSUPPORTED, "accel supports trees up to depth 23; use mnv_render_voxels"));
     hipLaunchKernelGGL(accel_pack_nodes, dim3(nb), dim3(256), 0, stream, t->child, t->data, depth, a->nodes, t->capacity, t->data_dim);
     hipLaunchKernelGGL(accel_pack_rows, dim3((unsigned)((nvox * 3 + 255) / 256)), dim3(256), 0, stream, t->data,
-                       reinterpret_cast<uint16_t *>(a->rows), nvox, t->data_dim, b > 0 ? b : 1, b > 0 ? chan_bytes_for(b) / 2 : 1,
+                       reinterpret_cast<uint16_t *>(a->rows), nvox, t->data_dim, b > 0 ? b : 1, chan_bytes_for(b) / 2,
                        row_bytes / 2);
     int L = max_depth < kMaxGridLevel ? max_depth : kMaxGridLevel;
     const int64_t gcells = (int64_t)1 << (3 * L);
@@ -258,7 +258,7 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
     a->view.grid2_level = L2;
     a->view.max_depth = max_depth;
     a->view.row_bytes = row_bytes;
-    a->view.sigma_off = 3 * (b > 0 ? chan_bytes_for(b) : 2);
+    a->view.sigma_off = 3 * chan_bytes_for(b);
     for (int i = 0; i < 3; ++i) {
         a->view.offset[i] = t->offset[i];
         a->view.scale[i] = t->scale[i];

@@ -90,14 +90,16 @@ __device__ __forceinline__ uint32_t lane_read(uint32_t v, int src_lane) {
     return (uint32_t)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
 }
 
-// bytes of one colour channel block of a packed row: basis_dim halfs padded to a whole dword
-__host__ __device__ constexpr int chan_bytes_for(int basis) { return basis > 0 ? ((2 * basis + 3) / 4) * 4 : 4; }
-// bytes of a packed row: three channel blocks rounded up to a power of two (16 ... 256), so that a
-// row never straddles a 128-B cache line (SH9: 3 * 20 = 60 -> 64 B)
+// A packed colour row.  Formats whose rows a lane evaluates by itself (RGBA, SH1 / 4 / 9): the reference's row as it is -- the three channels'
+// coefficients back to back, then the voxel's sigma -- padded to a power of two (SH9: 28 halfs = 56 -> 64 B), read with 16-byte loads.
+// SH16 / SH25 (the cooperative colour pass, one lane per (sample, channel)): every channel block padded to whole dwords, sigma behind them.
+// bytes of one colour channel block:
+__host__ __device__ constexpr int chan_bytes_for(int basis) { return basis <= 0 ? 2 : basis < 16 ? 2 * basis : ((2 * basis + 3) / 4) * 4; }
+// bytes of a packed row: three channel blocks + the sigma half, rounded up to a power of two (8 ... 256), so that a row never straddles
+// a 128-B cache line
 __host__ __device__ constexpr int row_bytes_pow2(int basis) {
-    if (basis <= 0) return 8;
-    int r = 16;
-    while (r < 3 * chan_bytes_for(basis)) r *= 2;
+    int r = 8;
+    while (r < 3 * chan_bytes_for(basis) + 2) r *= 2;
     return r;
 }
 // channel block as dwords with 4-byte alignment (the compiler picks the widest legal loads)

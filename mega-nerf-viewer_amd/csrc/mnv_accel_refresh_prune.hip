@@ -303,7 +303,7 @@ int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity
     hipStream_t stream = (hipStream_t)hip_stream;
     int rc;
     const int b = (t->format == MNV_FORMAT_SH && t->basis_dim >= 0) ? t->basis_dim : -1;
-    const int per_chan = b > 0 ? b : 1, chan_halfs = b > 0 ? chan_bytes_for(b) / 2 : 1, row_halfs = a->view.row_bytes / 2;
+    const int per_chan = b > 0 ? b : 1, chan_halfs = chan_bytes_for(b) / 2, row_halfs = a->view.row_bytes / 2;
     const int grid_depth = a->view.grid_level;  // leaves this shallow sit in the small (LDS-staged) lookup grid
     // [1] deepest depth, [2] the small lookup grid is affected, [3] shallowest affected voxel, [4] / [5] patch items of the appended / changed voxels
     int32_t h[8] = {0, a->view.max_depth, 0, 127, 0, 0, 0, 0};

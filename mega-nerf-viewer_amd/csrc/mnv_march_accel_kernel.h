@@ -627,11 +627,24 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                         const uint32_t w2 = *reinterpret_cast<const uint32_t *>(K.shadow_rows + (int64_t)vx * ROW_BYTES);
                         asm volatile("" ::"v"(w2));
                     }
-                    const ChanWords<NW> c0 = *reinterpret_cast<const ChanWords<NW> *>(row);
-                    const ChanWords<NW> c1 = *reinterpret_cast<const ChanWords<NW> *>(row + CHAN_BYTES);
-                    // (BRICK: the third block is read one dword longer -- the row's sigma half sits right behind it, accel_pack_rows)
-                    constexpr int NW2 = NW + (BRICK ? 1 : 0);
-                    const ChanWords<NW2> c2 = *reinterpret_cast<const ChanWords<NW2> *>(row + 2 * CHAN_BYTES);
+                    // the whole row -- 3 * BASIS coefficient halfs, then sigma -- with 16-byte loads (SH9: four; until round 5 three channel
+                    // blocks of 20 bytes each took six load instructions)
+                    constexpr int RW = ROW_BYTES / 4;
+                    uint32_t rw[RW];
+                    if constexpr (RW >= 4) {
+#pragma unroll
+                        for (int u = 0; u < RW / 4; ++u) {
+                            const uint4 x = reinterpret_cast<const uint4 *>(row)[u];
+                            rw[4 * u] = x.x;
+                            rw[4 * u + 1] = x.y;
+                            rw[4 * u + 2] = x.z;
+                            rw[4 * u + 3] = x.w;
+                        }
+                    } else {
+                        const uint2 x = *reinterpret_cast<const uint2 *>(row);
+                        rw[0] = x.x;
+                        rw[1] = x.y;
+                    }
                     if constexpr (MODE == 1) {
                         if (K.count_stats == 2) {
                             const unsigned long long now = phase_clock();   // the rows have arrived
@@ -639,16 +652,14 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                             ph_mark = now;
                         }
                     }
-                    if constexpr (BRICK) settle(c2.w[NW] & 0xffffu);
+                    auto half_at = [&](int hidx) -> uint32_t { return (hidx & 1) ? (rw[hidx >> 1] >> 16) : (rw[hidx >> 1] & 0xffffu); };
+                    if constexpr (BRICK) settle(half_at(3 * BASIS));
                     float b[NB];
 #pragma unroll
                     for (int k = 0; k < NB; ++k) b[k] = my_ray[k * BLOCK];
-                    auto chan = [&](const auto &cw) -> float {
-                        auto coef = [&](int k) -> float {
-                            const uint32_t wd = cw.w[k >> 1];
-                            return half_bits_to_float((uint16_t)((k & 1) ? (wd >> 16) : (wd & 0xffffu)));
-                        };
-                        const float tmp = sh_channel<BASIS>(b, coef, 0);
+                    auto chan = [&](int c) -> float {
+                        auto coef = [&](int k) -> float { return half_bits_to_float((uint16_t)half_at(k)); };
+                        const float tmp = sh_channel<BASIS>(b, coef, c * BASIS);
                         if constexpr (MODE == 4) {
                             // colour-only arithmetic: it feeds no branch (opacity, transmittance and the step sequence stay exact),
                             // so hardware exp2 / rcp (about 1 ulp each) move a colour by ~1e-7 and nothing else
@@ -659,9 +670,9 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                         }
                     };
                     if (dense) {  // (a candidate may have turned out not to be dense)
-                        o0 += chan(c0);
-                        o1 += chan(c1);
-                        o2 += chan(c2);
+                        o0 += chan(0);
+                        o1 += chan(1);
+                        o2 += chan(2);
                     }
                 }
             } else {
