@@ -85,12 +85,12 @@ def roofline_fractions(achieved_gbs, traffic, avg_ms):
 
 def load_counters(workload="cfg2"):
     """Per-pose integer work counters of the CPU restatement, committed with the fixtures."""
-    path = COUNTERS_JSON if workload == "cfg2" else COUNTERS3_JSON
+    path = COUNTERS_JSON if workload == "cfg2" else os.path.join(ROOT, "tests", "golden", "fog_counters.json") if workload == "fog" else COUNTERS3_JSON
     if not os.path.exists(path):
         return None
     with open(path) as f:
         d = json.load(f)
-    return d if workload == "cfg2" else d.get(workload)
+    return d if workload in ("cfg2", "fog") else d.get(workload)
 
 
 def kernel_source_sha():
@@ -256,7 +256,7 @@ def extras_cfg3_cfg4(mnv, cases, orc, torch, dev, opt, steps):
         traffic, traffic_source = committed_traffic("cfg3" if name == "cfg3" else "cfg4", N_POSES)
         rl = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
         rl.update(roofline_fractions(achieved, traffic, avg_ms))
-        rl.update({"traffic": traffic, "traffic_source": traffic_source, "kernel": "march_accel_kernel<9,256,0>", "avg_launch_ms": round(avg_ms, 5), "launches": launches,
+        rl.update({"traffic": traffic, "traffic_source": traffic_source, "kernel": "march_accel_kernel<9,256,0,true>", "avg_launch_ms": round(avg_ms, 5), "launches": launches,
                    "algorithmic_bytes_per_launch": int(per_launch), "counter_poses": N_POSES if committed else list(chk), "counters_rechecked_poses": list(chk) if committed else []})
         out[name] = {"value": round(N_POSES * w * h * steps / el / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
                      "resolution": f"{w}x{h}", "frames_per_launch": N_POSES, "roofline": rl,
@@ -268,6 +268,66 @@ def extras_cfg3_cfg4(mnv, cases, orc, torch, dev, opt, steps):
         v["workload"] = workload
     out["cfg3"]["setup_s"] = round(setup_s, 2)
     del tree
+    torch.cuda.empty_cache()
+    return out
+
+
+FOG_COUNTERS_JSON = os.path.join(ROOT, "tests", "golden", "fog_counters.json")
+
+
+def extras_fog(mnv, cases, orc, torch, dev, opt, steps):
+    """A second distribution for the headline's kernel (long dense runs): cases.FOG_TREE -- the cfg2 generator with a thick shell of thin
+    density, 33 dense samples in 44 steps per ray against cfg2's 4.5 in 21 -- under the cfg2 cameras at 1920x1080, 16 poses per launch.
+    Its own roofline (numerator: the committed 16-pose counters, one pose re-derived here) and its own bit-exact frame."""
+    t_setup = time.time()
+    tree = cases.make_tree(mnv, cases.FOG_TREE)
+    ot = orc.tree_from_view(tree.host_view())
+    tree.move_to_device()
+    info = mnv.accel_info(tree.accel)
+    setup_s = time.time() - t_setup
+    w, h = W, H
+    cams = [cases.cfg2_camera(mnv, pose, w, h, FX) for pose in range(N_POSES)]
+    frames = torch.empty((N_POSES, h, w, 4), dtype=torch.float32, device=dev)
+    for _ in range(2):
+        mnv.render_voxels_accel_batch(tree.accel, cams, opt, rgba=frames)
+    torch.cuda.synchronize(dev)
+    mnv.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        mnv.render_voxels_accel_batch(tree.accel, cams, opt, rgba=frames)
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    kern_ms, launches = mnv.take_timing()
+    mnv.set_timing(False)
+    committed = json.load(open(FOG_COUNTERS_JSON)) if os.path.exists(FOG_COUNTERS_JSON) else None
+    pose = 3
+    r = orc.render(ot, cams[pose].c, opt)
+    c = r["counters"].as_dict()
+    if committed and any(committed["poses"].get(str(pose), {}).get(k) != x for k, x in c.items()):
+        raise SystemExit(f"bench.py: tests/golden/fog_counters.json disagrees with the oracle's counters for pose {pose}")
+    gpu = frames[pose].cpu().numpy()
+    n_bad = int((gpu.view(np.uint32) != r["rgba"].view(np.uint32)).any(axis=-1).sum())
+    max_d = float(np.abs(gpu - r["rgba"]).max())
+    have_all = bool(committed) and len(committed["poses"]) == N_POSES
+    per_launch = float(np.sum([alg_bytes(p) for p in committed["poses"].values()])) if have_all else float(alg_bytes(c)) * N_POSES
+    dense_per_ray = (sum(p["hits"] for p in committed["poses"].values()) / sum(p["rays"] for p in committed["poses"].values())) if have_all else c["hits"] / c["rays"]
+    steps_per_ray = (sum(p["steps"] for p in committed["poses"].values()) / sum(p["rays"] for p in committed["poses"].values())) if have_all else c["steps"] / c["rays"]
+    avg_ms = kern_ms / max(1, launches)
+    achieved = per_launch / (avg_ms * 1e-3) / 1e9
+    traffic, traffic_source = committed_traffic("fog", N_POSES)
+    rl = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    rl.update(roofline_fractions(achieved, traffic, avg_ms))
+    rl.update({"traffic": traffic, "traffic_source": traffic_source, "kernel": "march_accel_kernel<9,256,0,true>", "avg_launch_ms": round(avg_ms, 5), "launches": launches,
+               "algorithmic_bytes_per_launch": int(per_launch), "counter_poses": N_POSES if have_all else [pose], "counters_rechecked_poses": [pose] if committed else []})
+    value = N_POSES * w * h * steps / el / 1e6
+    out = {"value": round(value, 2), "unit": "Mrays/s", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps, "resolution": f"{w}x{h}", "frames_per_launch": N_POSES,
+           "dense_samples_per_ray": round(dense_per_ray, 2), "steps_per_ray": round(steps_per_ray, 2),
+           "dense_samples_per_s": round(value * 1e6 * dense_per_ray, 0), "roofline": rl,
+           "parity": {"frames_checked": 1, "pixels_not_bit_identical": n_bad, "max_abs_drgba_vs_oracle": max_d},
+           "workload": (f"fog: depth-9 SH9 thick shell N3Tree ({tree.capacity:,} chunks, {tree.capacity * 8 * 28 * 2 / 1e9:.2f} GB of voxel rows; half-thickness 0.06, sigma U(5,40)), "
+                        f"packed accel {info['device_bytes'] / 1e9:.2f} GB with a level-{info['grid2_level']} lookup grid, the cfg2 orbit, 16 poses per launch"),
+           "setup_s": round(setup_s, 2)}
+    del frames, tree
     torch.cuda.empty_cache()
     return out
 
@@ -422,7 +482,7 @@ def main():
     ap.add_argument("--kernel", choices=["accel", "ref_layout"], default="accel")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend for N > 1; gloo (host-staged gather, all ranks may share one GPU) is the single-GPU rehearsal of the multi-GPU path")
-    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4"], default="cfg2",
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "cfg4", "fog"], default="cfg2",
                     help="cfg2 = BASELINE.json's headline config (default); cfg3 = merged-Mega-NeRF stand-in (anisotropic terrain, 7.2 M chunks); "
                          "cfg4 = cfg3 at 3840x2160 (configs[3], meant for --gpus 8)")
     ap.add_argument("--per-frame", action="store_true", help="one launch per pose instead of one batched launch per step")
@@ -493,6 +553,10 @@ def main():
         tree = cases.make_tree(mnv, cases.CFG2_TREE)
         cams = [cases.cfg2_camera(mnv, pose % N_POSES, W, H, FX) for pose in range(N_FRAMES)]
         workload = "cfg2: depth-10 SH9 shell N3Tree (1,499,569 chunks), 1920x1080, 16-pose orbit per step" + (f" x {args.laps} laps" if args.laps > 1 else "")
+    elif args.workload == "fog":
+        tree = cases.make_tree(mnv, cases.FOG_TREE)
+        cams = [cases.cfg2_camera(mnv, pose % N_POSES, W, H, FX) for pose in range(N_FRAMES)]
+        workload = f"fog: depth-9 SH9 thick shell N3Tree ({tree.capacity:,} chunks; half-thickness 0.06, sigma U(5,40)), {W}x{H}, the cfg2 orbit, 16 poses per step"
     else:
         tree = cases.make_tree(mnv, cases.CFG3_FULL)
         cams = [cases.cfg3_camera(mnv, pose % N_POSES, W, H, fx=1400.0 * W / 1920) for pose in range(N_FRAMES)]
@@ -760,7 +824,7 @@ def main():
             # the committed counters (the roofline's numerator) must be the ones this tree and these cameras produce today
             stale = [k for k, v in fresh.items() if any(counters["poses"].get(k, {}).get(n) != x for n, x in v.items())]
             if stale:
-                raise SystemExit(f"bench.py: tests/golden/{'cfg2' if args.workload == 'cfg2' else 'cfg3'}_counters.json disagrees with the oracle's counters for poses {stale}: "
+                raise SystemExit(f"bench.py: tests/golden/{args.workload if args.workload in ('cfg2', 'fog') else 'cfg3'}_counters.json disagrees with the oracle's counters for poses {stale}: "
                                  f"e.g. committed {counters['poses'].get(stale[0])} vs fresh {fresh[stale[0]]}")
             counters_checked = len(fresh)
     if rank == 0 and multi and not args.no_cpu_baseline:
@@ -799,7 +863,7 @@ def main():
         roofline.update(roofline_fractions(achieved, traffic, avg_ms))
         roofline.update({"traffic": traffic, "traffic_source": traffic_source,
                     "counters_rechecked_poses": counters_checked,
-                    "kernel": "march_accel_kernel<9,256,0>" if args.kernel == "accel" else "march_ref_layout_kernel<9>",
+                    "kernel": "march_accel_kernel<9,256,0,true>" if args.kernel == "accel" else "march_ref_layout_kernel<9>",
                     "frames_per_launch": frames_per_launch,
                     "avg_launch_ms": round(avg_ms, 5), "launches": launches,
                     "algorithmic_bytes_per_launch": int(per_launch)})
@@ -823,6 +887,10 @@ def main():
             cfg345.update(extras_cfg3_cfg4(mnv, cases, orc, torch, dev, opt, max(1, min(args.steps, 5))))
         except Exception as e:
             cfg345["cfg3"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            cfg345["fog"] = extras_fog(mnv, cases, orc, torch, dev, opt, max(1, min(args.steps, 5)))
+        except Exception as e:
+            cfg345["fog"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         line = {
             "metric": "Mrays/sec at 1920x1080 on depth-10 SH-9 N3Tree; max|dRGBA| vs ref",

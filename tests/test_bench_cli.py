@@ -60,7 +60,7 @@ def test_committed_counters_cover_all_poses_of_every_bench_workload():
     sys.path.insert(0, ROOT)
     import bench
 
-    for wl, rays in (("cfg2", 1920 * 1080), ("cfg3", 1920 * 1080), ("cfg4", 3840 * 2160)):
+    for wl, rays in (("cfg2", 1920 * 1080), ("cfg3", 1920 * 1080), ("cfg4", 3840 * 2160), ("fog", 1920 * 1080)):
         c = bench.load_counters(wl)
         assert c is not None and sorted(c["poses"], key=int) == [str(i) for i in range(16)], wl
         for p in c["poses"].values():
@@ -68,6 +68,9 @@ def test_committed_counters_cover_all_poses_of_every_bench_workload():
     # cfg3's rays are 1.8 x as long as cfg2's: what puts it at 0.54 x the headline's ray rate at the same efficiency per step
     steps = {wl: sum(p["steps"] for p in bench.load_counters(wl)["poses"].values()) / (16 * 1920 * 1080) for wl in ("cfg2", "cfg3")}
     assert 1.7 < steps["cfg3"] / steps["cfg2"] < 2.0
+    # fog: long dense runs -- more than 30 dense samples per ray (cfg2: 4.5)
+    fog = bench.load_counters("fog")["poses"].values()
+    assert sum(p["hits"] for p in fog) / (16 * 1920 * 1080) > 30
 
 
 def test_committed_traffic_belongs_to_one_kernel_source_and_launch_shape(tmp_path, monkeypatch):

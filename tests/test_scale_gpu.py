@@ -366,3 +366,47 @@ def test_8k_frame_and_odd_sizes_beyond_the_configs(mnv, orc, torch_gpu):
             torch.cuda.synchronize()
             assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref["rgba"])), (w, h, which)
             assert np.array_equal(out8.cpu().numpy(), ref["rgba8"]), (w, h, which)
+
+
+def test_fog_workload_full_size_against_the_oracle(mnv, orc, torch_gpu):
+    """bench.py's second distribution for the headline kernel (cases.FOG_TREE: 3.8 M chunks, 33 dense samples in 44 steps per ray -- long
+    dense runs through inline cell words, sigma read with the colour row): two poses at 1920x1080 on the tuned kernel, float and RGBA8, bit
+    for bit against the oracle; the oracle's counters of those poses equal the committed ones (tests/golden/fog_counters.json: the
+    numerator of the fog roofline); the reference-layout kernel agrees; and a frame with a per-pixel depth limit and an image under it
+    (the reference's offscreen == false call shape) as well."""
+    import json
+    import os
+
+    torch = torch_gpu
+    tree = cases.make_tree(mnv, cases.FOG_TREE)
+    assert 3_000_000 < tree.capacity < 5_000_000
+    ot = orc.tree_from_view(tree.host_view())
+    tree.move_to_device()
+    assert mnv.accel_info(tree.accel)["brick_levels"] >= 1
+    opt = mnv.RenderOptions.cli_defaults()
+    committed = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fog_counters.json")))
+    assert committed["capacity"] == tree.capacity and len(committed["poses"]) == 16
+    w, h = 1920, 1080
+    for pose in (3, 12):
+        cam = cases.cfg2_camera(mnv, pose)
+        ref = orc.render(ot, cam.c, opt, want_rgba8=True)
+        c = ref["counters"].as_dict()
+        assert all(committed["poses"][str(pose)][k] == x for k, x in c.items()), pose
+        assert c["hits"] > 25 * c["rays"] and c["steps"] > 35 * c["rays"]
+        out = torch.full((h, w, 4), float("nan"), dtype=torch.float32, device="cuda")
+        out8 = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        mnv.render_voxels_accel(tree.accel, cam, opt, rgba=out, rgba8=out8)
+        torch.cuda.synchronize()
+        assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref["rgba"])), pose
+        assert np.array_equal(out8.cpu().numpy(), ref["rgba8"])
+        if pose == 3:
+            mnv.render_voxels(tree.device_view(), cam, opt, rgba=out)
+            torch.cuda.synchronize()
+            assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref["rgba"]))
+            rng = np.random.default_rng(5)
+            tmax = (2.6 * rng.uniform(0.8, 1.2, size=(h, w))).astype(np.float32)
+            image = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+            want = orc.render(ot, cam.c, opt, tmax_px=tmax, rgba8_init=image)["rgba"]
+            mnv.render_voxels_accel(tree.accel, cam, opt, rgba=out, tmax_px=torch.from_numpy(tmax).cuda(), rgba8_init=torch.from_numpy(image).cuda())
+            torch.cuda.synchronize()
+            assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(want))

@@ -23,7 +23,7 @@ fetch, write, miss = avg("FETCH_SIZE"), avg("WRITE_SIZE"), avg("TCC_MISS_sum")
 import bench  # noqa: E402  (kernel_source_sha: the profile is only valid for the kernel sources it was taken with)
 
 out = {"kernel_source_sha": bench.kernel_source_sha(), "source": f"{sys.argv[1]} (rocprofv3 --pmc, separate passes, bench.py {extra})".replace(" )", ")"),
-       "kernel": "march_accel_kernel<9,256,0>", "frames_per_launch": frames, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "TCC_MISS": miss,
+       "kernel": "march_accel_kernel<9,256,0,true>", "frames_per_launch": frames, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "TCC_MISS": miss,
        "hbm_bytes_per_launch": int(2 * fetch * 1024 + write * 1024)}
 r128, r64, rall = avg("TCC_EA0_RDREQ_128B_sum"), avg("TCC_EA0_RDREQ_64B_sum"), avg("TCC_EA0_RDREQ_sum")
 if r128 is not None and rall is not None:
