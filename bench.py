@@ -27,6 +27,10 @@ import os
 import sys
 import time
 
+# the CPU baseline's OpenMP threads: one per physical core, pinned and spread (must be in the environment before an OpenMP runtime loads)
+os.environ.setdefault("OMP_PROC_BIND", "spread")
+os.environ.setdefault("OMP_PLACES", "cores")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -795,11 +799,16 @@ def main():
         n_cpu = max(1, min(args.cpu_poses, N_POSES))
         t_cpu, max_diff, n_bad, n_alpha = 0.0, 0.0, 0, 0
         fresh = {}
-        phys, hw_threads = orc.physical_cores()
-        n_thr = phys or hw_threads   # one thread per physical core (SMT siblings share the core's ports: no gain for this pointer chase)
+        # one thread per physical core this process can run: SMT siblings share the core's ports (no gain for this pointer chase), and a
+        # cgroup CPU quota below the core count throttles whatever is started beyond it (tools/cpu_ladder.py: 128 threads under a quota of
+        # 16 CPUs run at 8 Mrays/s, 16 threads at 9.4)
+        n_thr, phys, hw_threads, quota = orc.baseline_threads()
+        # the tree was built by one thread (all its pages on that thread's NUMA node): the baseline marches a copy whose pages its own
+        # threads touched first, spread over the nodes
+        ot_cpu = orc.copy_first_touch(ot, n_thr)
         for i in range(n_cpu):
             tc = time.perf_counter()
-            r = orc.render(ot, cams[i].c, opt, n_threads=n_thr)
+            r = orc.render(ot_cpu, cams[i].c, opt, n_threads=n_thr)
             t_cpu += time.perf_counter() - tc
             fresh[str(i)] = r["counters"].as_dict()
             scratch = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
@@ -812,10 +821,22 @@ def main():
             max_diff = max(max_diff, float(d.max()))
             n_bad += int((gpu.view(np.uint32) != r["rgba"].view(np.uint32)).any(axis=-1).sum())
             n_alpha += int((gpu[..., 3].view(np.uint32) != r["rgba"][..., 3].view(np.uint32)).sum())
-        cpu_baseline = {"value": round(n_cpu * W * H / t_cpu / 1e6, 4), "unit": "Mrays/s", "cores": n_thr, "hardware_threads": hw_threads,
-                        "per_core": round(n_cpu * W * H / t_cpu / 1e6 / n_thr, 4),
-                        "kind": "port", "sample": f"poses 0..{n_cpu - 1} of the 16-pose orbit, full 1920x1080 frames; gcc -O3, OpenMP, 16x16-pixel tiles handed out one at a time, "
-                                                  "one thread per physical core"}
+        # a second, untimed-for-parity pass over the same poses: the run-to-run spread of the baseline itself
+        t_again = 0.0
+        for i in range(n_cpu):
+            tc = time.perf_counter()
+            orc.render(ot_cpu, cams[i].c, opt, n_threads=n_thr)
+            t_again += time.perf_counter() - tc
+        orc.free_copy(ot_cpu)
+        rates = [n_cpu * W * H / t / 1e6 for t in (t_cpu, t_again)]
+        cpu_value = sum(rates) / 2
+        cpu_baseline = {"value": round(cpu_value, 4), "unit": "Mrays/s", "cores": n_thr, "host_physical_cores": phys, "hardware_threads": hw_threads,
+                        "cgroup_cpu_quota": quota,
+                        "per_core": round(cpu_value / n_thr, 4), "passes": [round(x, 4) for x in rates],
+                        "spread": round(abs(rates[0] - rates[1]) / cpu_value, 4),
+                        "kind": "port", "sample": f"poses 0..{n_cpu - 1} of the 16-pose orbit, full 1920x1080 frames, twice; gcc -O3, OpenMP (OMP_PROC_BIND=spread, OMP_PLACES=cores), "
+                                                  "16x16-pixel tiles handed out one at a time, one thread per physical core the process may run (cgroup CPU quota respected), "
+                                                  "tree pages first touched by the marching threads"}
         parity = {"max_abs_drgba_vs_oracle": max_diff, "pixels_not_bit_identical": n_bad, "frames_checked": n_cpu,
                   "alpha_not_bit_identical": n_alpha, "colour_math": "fast" if args.fast_colour else "exact"}
         if counters is None:

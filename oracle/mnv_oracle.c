@@ -11,6 +11,7 @@
 #include "mnv_oracle.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -456,6 +457,51 @@ static void trace_ray(const orc_tree *tree, int32_t *visited, float dir[3], cons
 /* analysis hook, not part of any parity check: hist[0][d] += 1 per march step that lands in an empty leaf of depth d (sigma <= sigma_thresh),
  * hist[1][d] per dense step; NULL switches it off */
 void orc_set_depth_histogram(uint64_t *hist_2x32) { g_depth_hist = hist_2x32; }
+
+/* CPU-baseline fairness (bench.py's cpu_baseline leg, tools/cpu_ladder.py): a copy of the tree's arrays whose pages are first touched by
+ * the threads that will march them -- schedule(static) over 2 MiB blocks, so the pages end up spread over the NUMA nodes of a big host
+ * instead of on the node of the one thread that built the tree.  Free with orc_tree_free_copy. */
+int orc_tree_copy_first_touch(const orc_tree *src, orc_tree *dst, int n_threads) {
+    if (!src || !dst || !src->data || !src->child) return -1;
+    const int64_t n3 = (int64_t)src->N * src->N * src->N;
+    const size_t data_bytes = (size_t)src->capacity * n3 * src->data_dim * 2, child_bytes = (size_t)src->capacity * n3 * 4;
+    *dst = *src;
+    uint8_t *d = (uint8_t *)malloc(data_bytes), *c = (uint8_t *)malloc(child_bytes); /* large: mmap'd, untouched until written */
+    if (!d || !c) {
+        free(d);
+        free(c);
+        return -2;
+    }
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+    n_threads = 1;
+#endif
+    (void)n_threads;
+    const size_t blk = (size_t)2 << 20;
+    const int64_t nd = (int64_t)((data_bytes + blk - 1) / blk), nc = (int64_t)((child_bytes + blk - 1) / blk);
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+    for (int64_t i = 0; i < nd; ++i) {
+        const size_t o = (size_t)i * blk, n = o + blk <= data_bytes ? blk : data_bytes - o;
+        memcpy(d + o, (const uint8_t *)src->data + o, n);
+    }
+#pragma omp parallel for schedule(static) num_threads(n_threads)
+    for (int64_t i = 0; i < nc; ++i) {
+        const size_t o = (size_t)i * blk, n = o + blk <= child_bytes ? blk : child_bytes - o;
+        memcpy(c + o, (const uint8_t *)src->child + o, n);
+    }
+    dst->data = (const uint16_t *)d;
+    dst->child = (const int32_t *)c;
+    return 0;
+}
+
+void orc_tree_free_copy(orc_tree *t) {
+    if (!t) return;
+    free((void *)t->data);
+    free((void *)t->child);
+    t->data = NULL;
+    t->child = NULL;
+}
 
 static inline uint8_t pack_u8(float v) {
     /* renderer_kernel.cu:237 uint8_t(v * 255): truncation; the CUDA float->u8

@@ -205,6 +205,11 @@ int orc_mlp_forward(const orc_mlp_desc *desc, const uint16_t *params, const int1
 
 int orc_num_threads(void);
 
+/* CPU-baseline fairness: a copy of data / child whose pages are first touched in parallel (spread over the NUMA nodes of a many-socket
+ * host); the copy renders exactly like the original.  orc_tree_free_copy releases the two arrays of such a copy. */
+int orc_tree_copy_first_touch(const orc_tree *src, orc_tree *dst, int n_threads);
+void orc_tree_free_copy(orc_tree *t);
+
 /* Analysis hook (no parity test depends on it): while `hist_2x32` is non-NULL every march step of orc_render_voxels adds 1 to
  * hist[dense][leaf depth] (dense = sigma > sigma_thresh).  tools/step_depths.py uses it to say where a workload's steps land. */
 void orc_set_depth_histogram(uint64_t *hist_2x32);

@@ -77,6 +77,10 @@ def lib():
                                            C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_void_p, C.POINTER(OrcCounters), C.c_int]
+        h.orc_tree_copy_first_touch.restype = C.c_int
+        h.orc_tree_copy_first_touch.argtypes = [C.POINTER(OrcTree), C.POINTER(OrcTree), C.c_int]
+        h.orc_tree_free_copy.restype = None
+        h.orc_tree_free_copy.argtypes = [C.POINTER(OrcTree)]
         h.orc_get_samples_from_voxels.restype = C.c_int
         h.orc_get_samples_from_voxels.argtypes = [C.POINTER(OrcTree), C.POINTER(OrcCamera), C.POINTER(OrcOptions), C.c_void_p, C.c_void_p,
                                                   C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
@@ -107,6 +111,78 @@ def tree_from_view(view, sample_counts=None) -> OrcTree:
         t.offset[i], t.scale[i] = view.offset[i], view.scale[i]
     t.N, t.data_dim, t.format, t.basis_dim, t.capacity = view.N, view.data_dim, view.format, view.basis_dim, view.capacity
     return t
+
+
+_default_threads = None
+
+
+def _threads(n_threads):
+    """n_threads <= 0: every hardware thread this process can really run -- under a cgroup CPU quota not the visible ones (256 threads
+    under a quota of 16 CPUs are throttled in turn and finish later than 16)."""
+    global _default_threads
+    if n_threads and n_threads > 0:
+        return n_threads
+    if _default_threads is None:
+        import math
+        import os
+
+        n = os.cpu_count() or 1
+        try:
+            n = min(n, len(os.sched_getaffinity(0)))
+        except (AttributeError, OSError):
+            pass
+        q = cpu_quota()
+        if q is not None:
+            n = min(n, max(1, int(math.ceil(q))))
+        _default_threads = max(1, n)
+    return _default_threads
+
+
+def copy_first_touch(tree: OrcTree, n_threads=0) -> OrcTree:
+    """A copy of the tree whose pages the marching threads touched first (NUMA spread on a big host); release with free_copy."""
+    out = OrcTree()
+    if lib().orc_tree_copy_first_touch(C.byref(tree), C.byref(out), _threads(n_threads)) != 0:
+        raise MemoryError("orc_tree_copy_first_touch")
+    return out
+
+
+def free_copy(tree: OrcTree) -> None:
+    lib().orc_tree_free_copy(C.byref(tree))
+
+
+def cpu_quota():
+    """CPUs' worth of time this process may use: the cgroup CPU quota (v2 cpu.max, v1 cfs_quota_us / cfs_period_us) or None when there
+    is none.  A container with 256 visible hardware threads and a quota of 16 CPUs runs 128 threads no faster than 16 -- slower: they
+    are throttled in turn."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+def baseline_threads():
+    """(threads for the CPU baseline, physical cores, hardware threads, quota): one thread per physical core this process can actually run --
+    the smaller of the physical cores, the scheduler affinity and the cgroup CPU quota."""
+    import math
+    import os
+
+    phys, hw = physical_cores()
+    n = phys or hw
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = cpu_quota()
+    if quota is not None:
+        n = min(n, max(1, int(math.floor(quota + 1e-9))))
+    return max(1, n), phys, hw, quota
 
 
 def physical_cores():
@@ -147,7 +223,7 @@ def render(tree: OrcTree, cam_struct, opt_struct, tile=None, *, want_rgba8=False
         rgba8_init = np.ascontiguousarray(rgba8_init, np.uint8)
         assert rgba8_init.size == w * h * 4
     rc = lib().orc_render_voxels_ex(C.byref(tree), C.byref(cam), C.byref(opt), x0, y0, w, h, p(tmax_px), p(rgba8_init), p(rgba), p(rgba8),
-                                    p(split), p(sample), p(visited), int(track_visit), p(steps), C.byref(ctr), n_threads)
+                                    p(split), p(sample), p(visited), int(track_visit), p(steps), C.byref(ctr), _threads(n_threads))
     if rc != 0:
         raise RuntimeError("orc_render_voxels: invalid arguments")
     return dict(rgba=rgba, rgba8=rgba8, split=split, sample=sample, steps=steps, counters=ctr)
@@ -171,7 +247,7 @@ def get_samples(tree: OrcTree, cam_struct, opt_struct, grid_struct, samples_dim,
     sample = np.full((n, 3), -1, np.float32)
     rc = lib().orc_get_samples_from_voxels(C.byref(tree), C.byref(cam), C.byref(opt), split.ctypes.data, sample.ctypes.data,
                                            visited.ctypes.data if visited is not None else None, int(track_visit), num.ctypes.data,
-                                           samples.ctypes.data, samples_dim, clusters.ctypes.data, C.byref(grid), n_threads)
+                                           samples.ctypes.data, samples_dim, clusters.ctypes.data, C.byref(grid), _threads(n_threads))
     if rc != 0:
         raise RuntimeError("orc_get_samples_from_voxels: invalid arguments")
     return dict(num_samples=num, samples=samples, cluster_indices=clusters, split=split, sample=sample)
@@ -187,7 +263,7 @@ def render_nerf_results(tree: OrcTree, cam_struct, opt_struct, sample_values, z_
     rgba8 = np.empty((cam.height, cam.width, 4), np.uint8) if want_rgba8 else None
     rc = lib().orc_render_nerf_results(C.byref(tree), C.byref(cam), C.byref(opt), sample_values.ctypes.data, sample_values.shape[-1],
                                        z_vals.ctypes.data, offsets.ctypes.data, rgba.ctypes.data,
-                                       rgba8.ctypes.data if want_rgba8 else None, n_threads)
+                                       rgba8.ctypes.data if want_rgba8 else None, _threads(n_threads))
     if rc != 0:
         raise RuntimeError("orc_render_nerf_results: invalid arguments")
     return dict(rgba=rgba, rgba8=rgba8)
