@@ -530,10 +530,11 @@ void VolumeRenderer::render() {
                       (!track_visit || tree.device.parent) && !options.render_depth && I.mlp_desc.hidden_width == 64 && I.fused_inputs_ok &&
                       (tree.data_format.format != DataFormat::SH || tree.data_format.basis_dim == 1 || tree.data_format.basis_dim == 4 ||
                        tree.data_format.basis_dim == 9 || tree.data_format.basis_dim == 16);
-    if (split && !fuse) {
-        // cuda_renderer.cpp:97-98.  (The fused kernel writes all three words of both rows for every pixel of the frame it renders -- the
-        // rows of a ray without a candidate are (max + 1, -1, -1), what the fill and the reference's kernel leave -- so the 2 x 25 MB fill
-        // is skipped there: 50 us of a 3 ms configs[4] frame.)
+    if (split) {
+        // cuda_renderer.cpp:97-98.  The fused kernel writes all three words of both rows for every pixel it renders, so a healthy fused
+        // frame does not need the fill (50 us of a 3 ms configs[4] frame) -- but a wavefront that its watchdog abandoned (MNV_E_FAULT, reported
+        // by the NEXT fused call) leaves its pixels' rows unwritten, and refine_after_frame edits the tree from these rows in this same
+        // frame: stale (chunk, child) pairs of an earlier frame may name chunks a prune has renumbered since.  -1 rows name nothing.
         I.fill_f32(split, n_px * 3, -1.f);
         I.fill_f32(sample, n_px * 3, -1.f);
     }
