@@ -138,8 +138,8 @@ def gpu_count_without_hip():
 def self_launch(n, backend, timeout_s):
     """One process per GPU via torch.distributed.run, started from a parent that never initialises HIP.  The ranks run in their own
     process group under a watchdog: a run that exceeds `timeout_s` (a wedged collective) is killed -- that group, by id -- and, like a run
-    that failed, repeated once in the conservative configuration (--gather-via torch --one-march-stream: torch.distributed's gather
-    instead of mnv_gather_tiles, one march stream); the line then says so in `launch`."""
+    that failed, repeated down a short ladder of more conservative configurations (no CU reservation; float tiles; torch.distributed's
+    gather instead of mnv_gather_tiles); the line then carries what failed and what it ran with in `launch`."""
     import signal
     import socket
     import subprocess
@@ -192,12 +192,25 @@ def self_launch(n, backend, timeout_s):
                 print(ln, file=sys.stderr)
         return rc, lines
 
-    rc, lines = attempt([])
+    # The ladder: every rung changes ONE thing a first contact with an N-GPU node can trip over, the last rung leaves libmnv's gather altogether.
+    # A rung is skipped when the command line already pins the option it would change.
+    ladder = [([], "as asked"),
+              (["--reserve-cus", "0", "--one-march-stream"], "no compute units reserved for RCCL, one march stream"),
+              (["--gather", "f32", "--reserve-cus", "0", "--one-march-stream"], "float RGBA tiles instead of RGBA8, no reservation, one march stream"),
+              (["--gather-via", "torch", "--one-march-stream"], "torch.distributed's gather instead of mnv_gather_tiles, one march stream")]
+    failed = []
+    rc, lines = 4, []
+    for extra, what in ladder:
+        if extra and any(o in sys.argv for o in extra if o.startswith("--") and o != "--one-march-stream"):
+            continue
+        rc, lines = attempt(extra)
+        if rc == 0 and lines:
+            break
+        failed.append(f"[{' '.join(extra) or 'default'}] ended with code {rc}")
+        print(f"bench.py: attempt {len(failed)} ({what}) {failed[-1]}", file=sys.stderr)
     note = None
-    if (rc != 0 or not lines) and "--gather-via" not in sys.argv:
-        note = f"first attempt ended with code {rc}; repeated with --gather-via torch --one-march-stream"
-        print(f"bench.py: {note}", file=sys.stderr)
-        rc, lines = attempt(["--gather-via", "torch", "--one-march-stream"])
+    if failed and rc == 0 and lines:
+        note = "; ".join(failed) + f"; this line: repeated with {' '.join(extra)} ({what})"
     if rc == 0 and lines:
         d = json.loads(lines[-1])
         if d.get("n_gpus") != n:
@@ -574,6 +587,10 @@ def main():
 
     RING = 2
     reserve = args.reserve_cus if args.reserve_cus >= 0 else (32 if multi else 0)
+    if multi and reserve > 0 and os.environ.get("MNV_BENCH_TEST_FAIL_RESERVED"):
+        # test hook (tests/test_bench_multirank_gpu.py): stands in for a node on which the CU-masked stream does not work
+        print("bench.py: MNV_BENCH_TEST_FAIL_RESERVED is set: failing the run with reserved compute units", file=sys.stderr)
+        sys.exit(7)
     n_march_streams = RING if multi and not args.one_march_stream else 1
     march_streams = None
     enabled_cus = None   # compute units the march stream may use (None: an ordinary stream, all of them)

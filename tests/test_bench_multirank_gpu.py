@@ -51,20 +51,29 @@ def test_bench_starts_its_own_ranks(torch_gpu):
     assert d["n_gpus"] == 2 and d["parity"]["pixels_not_bit_identical"] == 0 and d["parity"]["frames_checked"] >= 3
 
 
-def test_bench_launcher_repeats_a_failed_run_conservatively_and_kills_a_wedged_one(torch_gpu):
-    """The launcher inside bench.py: (i) ranks that fail (here: the C-ABI gather cannot bind its library) are started once more with
-    torch.distributed's gather, and the line says so; (ii) ranks that do not finish within --launch-timeout are killed -- their process
-    group, nothing else -- and the exit code is not 0."""
+def test_bench_launcher_repeats_a_failed_run_conservatively_and_kills_a_wedged_one(torch_gpu, fake_rccl):
+    """The launcher inside bench.py walks a ladder: (i) ranks that fail with reserved compute units (test hook) are started again
+    WITHOUT the reservation and the C-ABI gather then works -- the second rung; (ii) ranks whose C-ABI gather cannot bind its library
+    at all fall through the abi rungs to torch.distributed's gather -- the last rung; the line names every failed attempt; (iii) ranks
+    that do not finish within --launch-timeout are killed -- their process group, nothing else -- and the exit code is not 0."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env["MNV_RCCL_LIBRARY"] = "/nonexistent/librccl.so"
     env["MNV_LIB_PATH"] = hooks.HOOKS_LIB
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--laps", "1"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    # (i) the two-step ladder over the stand-in
+    e1 = dict(env, MNV_RCCL_LIBRARY=fake_rccl, MNV_BENCH_TEST_FAIL_RESERVED="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=e1)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["n_gpus"] == 2 and "repeated with --gather-via torch" in d["launch"] and "gloo" in d["config"]["partition"]
+    assert d["n_gpus"] == 2 and "[default] ended with code" in d["launch"] and "repeated with --reserve-cus 0 --one-march-stream" in d["launch"]
+    assert "mnv_gather_tiles" in d["config"]["partition"] and d["config"]["reserved_cus"] == 0 and d["parity"]["pixels_not_bit_identical"] == 0
+    # (ii) down to the last rung
+    e2 = dict(env, MNV_RCCL_LIBRARY="/nonexistent/librccl.so")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=e2)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["launch"].count("ended with code") == 3 and "repeated with --gather-via torch" in d["launch"] and "gloo" in d["config"]["partition"]
     assert d["parity"]["pixels_not_bit_identical"] == 0
-    del env["MNV_RCCL_LIBRARY"]
+    # (iii) the watchdog
     r = subprocess.run(cmd + ["--launch-timeout", "8"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode != 0 and "was killed" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
