@@ -148,9 +148,15 @@ __global__ __launch_bounds__(256) void mlp_scatter(const int16_t *__restrict__ c
 // per CU is all that fits: eight wavefronts with two column tiles each share the weights (two per SIMD, 64 accumulator + 32 operand
 // registers) instead of four wavefronts that hold 128 + 64 and leave every SIMD with one wavefront and nothing to overlap its
 // LDS and matrix-pipe latencies with.
+// <8, 4, 8> (round 5): the 128-wide network with 64 columns per wavefront -- every weight fragment read from LDS (1 KB, 8 cycles of the CU's LDS
+// port) feeds FOUR 16-cycle MFMAs instead of two, so the port is busy half as long as the matrix pipes instead of as long; 128 accumulator
+// + 64 operand registers at two wavefronts per SIMD (256-register budget), 512 rows per pass.  Its encode tiles hold HALF a K tile (16
+// features: 2 KB per wavefront, written and read twice per K tile) -- with whole tiles the 131 KB of weights + 32 KB would not fit a CU.
 template <int MT, int NT, int WAVES>  // hidden width = 16 * MT
-__global__ __launch_bounds__(64 * WAVES, 2) void mlp_forward_kernel(const MlpLaunch L) {
-    static_assert(WAVES * 16 * NT == kRowsPerPass, "a pass is 256 rows");
+__global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forward_kernel(const MlpLaunch L) {
+    constexpr int ROWS = WAVES * 16 * NT;  // rows of one pass of the workgroup
+    constexpr bool HALF = NT * 16 == 64 && WAVES == 8;  // half-K-tile encode tiles
+    static_assert(ROWS % kRowsPerPass == 0, "a pass is a multiple of 256 rows");
     constexpr int COLS = 16 * NT;  // samples (MFMA columns) of one wavefront
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const MlpShape &S = L.S;
@@ -183,11 +189,12 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_forward_kernel(const MlpLau
     // the wavefront's encode tile: one K tile (32 features) of its COLS samples, a sample's 64 bytes in operand order (the 8 halfs of
     // lane group gg at byte 16 gg: features 4 gg .. 4 gg + 3 and 16 + 4 gg .. 16 + 4 gg + 3): written as four 16-byte stores by the
     // lane that owns the sample, read as one 16-byte load per column tile by the lane that feeds the matrix pipe
-    uint4 *s_enc = reinterpret_cast<uint4 *>(lds + (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4) + wave * (COLS * 4);
+    uint4 *s_enc = reinterpret_cast<uint4 *>(lds + (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4) + wave * (COLS * (HALF ? 2 : 4));
+    [[maybe_unused]] uint2 *s_enc2 = reinterpret_cast<uint2 *>(s_enc);  // HALF: a sample's 32 bytes = four lane groups x 8 bytes (features 4 gg .. 4 gg + 3 of the half)
     const int emb_base = S.n_pos + S.n_dir;
 
-    for (int pass_first = 0; pass_first < block_rows; pass_first += kRowsPerPass) {
-        const int first = block_first + pass_first, rows = min(kRowsPerPass, block_rows - pass_first);
+    for (int pass_first = 0; pass_first < block_rows; pass_first += ROWS) {
+        const int first = block_first + pass_first, rows = min(ROWS, block_rows - pass_first);
         // Two roles per lane.  Encoding: lane j < COLS owns sample j of the wavefront.  Matrix operand / output: lane (g, col) serves the
         // samples col + 16 nt.
         int32_t src_row[NT];
@@ -273,6 +280,48 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_forward_kernel(const MlpLau
             __builtin_amdgcn_wave_barrier();  // LDS executes a wavefront's accesses in order; this only pins the compiler's order
         };
 
+        // HALF: the same features, one half of the K tile (16 features) at a time into a tile half the size
+        [[maybe_unused]] auto fast_half_group = [&](auto kk_tag, auto h_tag, auto gg_tag) __attribute__((always_inline)) {
+            constexpr int kk = decltype(kk_tag)::value, h = decltype(h_tag)::value, gg = decltype(gg_tag)::value, f0 = 32 * kk + 16 * h + 4 * gg;
+            s_enc2[lane * 4 + gg] = make_uint2(pair(std::integral_constant<int, f0>{}), pair(std::integral_constant<int, f0 + 2>{}));
+        };
+        [[maybe_unused]] auto fast_half = [&](auto kk_tag, auto h_tag) __attribute__((always_inline)) {
+            fast_half_group(kk_tag, h_tag, std::integral_constant<int, 0>{});
+            fast_half_group(kk_tag, h_tag, std::integral_constant<int, 1>{});
+            fast_half_group(kk_tag, h_tag, std::integral_constant<int, 2>{});
+            fast_half_group(kk_tag, h_tag, std::integral_constant<int, 3>{});
+        };
+        [[maybe_unused]] auto encode_half = [&](int kk, auto h_tag) __attribute__((always_inline)) {  // kk is wave-uniform
+            constexpr int h = decltype(h_tag)::value;
+            if (lane < COLS) {
+                int f_lo;
+                if (kk == 0) {
+                    fast_half(std::integral_constant<int, 0>{}, h_tag);
+                    f_lo = S.n_pos;
+                } else if (kk == 1) {
+                    fast_half(std::integral_constant<int, 1>{}, h_tag);
+                    f_lo = S.n_pos;
+                } else if (kk == 2) {
+                    fast_half(std::integral_constant<int, 2>{}, h_tag);
+                    f_lo = S.n_pos;
+                } else {
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) s_enc2[lane * 4 + gg] = make_uint2(0u, 0u);
+                    f_lo = 32 * kk;
+                }
+                const int h_lo = 32 * kk + 16 * h, h_hi = h_lo + 16;
+                f_lo = f_lo > h_lo ? f_lo : h_lo;
+                const int f_hi = S.in_dim < h_hi ? S.in_dim : h_hi;
+                _Float16 *tile_h = reinterpret_cast<_Float16 *>(s_enc2);
+                for (int f = f_lo; f < f_hi; ++f) {  // wave-uniform bounds
+                    const float v = (f >= emb_base) ? half_bits_to_float(emb[f - emb_base]) : encode_feature(S, f, p, d);
+                    const int r = f & 15;
+                    tile_h[lane * 16 + (r >> 2) * 4 + (r & 3)] = (_Float16)v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+
         f32x4 acc[MT][NT];
         const half8 *w = s_frag;
         const float *b = s_bias;
@@ -281,11 +330,26 @@ __global__ __launch_bounds__(64 * WAVES, 2) void mlp_forward_kernel(const MlpLau
         // ---- layer 0: B fragments are computed from the raw sample on the fly, one K tile at a time; the bias enters as the C operand
         //      of the first K tile's MFMAs, and the next M tile's fragment travels under the current one's MFMAs
         for (int kk = 0; kk < S.nkk0; ++kk) {
-            encode_tile(kk);
             half8 bf[NT];
+            if constexpr (HALF) {
+                uint2 lo2[NT];
+                encode_half(kk, std::integral_constant<int, 0>{});
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bf[nt] = __builtin_bit_cast(half8, s_enc[(nt * 16 + col) * 4 + g]);
-            __builtin_amdgcn_wave_barrier();
+                for (int nt = 0; nt < NT; ++nt) lo2[nt] = s_enc2[(nt * 16 + col) * 4 + g];
+                __builtin_amdgcn_wave_barrier();
+                encode_half(kk, std::integral_constant<int, 1>{});
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const uint2 hi2 = s_enc2[(nt * 16 + col) * 4 + g];
+                    bf[nt] = __builtin_bit_cast(half8, make_uint4(lo2[nt].x, lo2[nt].y, hi2.x, hi2.y));
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+                encode_tile(kk);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bf[nt] = __builtin_bit_cast(half8, s_enc[(nt * 16 + col) * 4 + g]);
+                __builtin_amdgcn_wave_barrier();
+            }
             half8 a = w[kk * 64 + lane];
             if (kk == 0) {
 #pragma unroll
@@ -522,9 +586,10 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
     // refinement step's 4096 splits: 134 workgroups of 2048 rows on 256 CUs, 51 us) takes fewer passes per workgroup, so that the device
     // holds about four workgroups per CU.
     const int64_t cus = m->num_cus > 0 ? m->num_cus : 256;
-    int passes = kPasses;
-    while (passes > 1 && n / ((int64_t)kRowsPerPass * passes) < cus * 4) passes >>= 1;
-    const int32_t rows_per_block = kRowsPerPass * passes;
+    const int rows_per_pass = S.hidden_width == 64 ? kRowsPerPass : 2 * kRowsPerPass;  // <4, 4, 4>: 4 x 64 rows; <8, 4, 8>: 8 x 64 rows
+    int passes = kRowsPerBlock / rows_per_pass;
+    while (passes > 1 && n / ((int64_t)rows_per_pass * passes) < cus * 4) passes >>= 1;
+    const int32_t rows_per_block = rows_per_pass * passes;
     const int64_t max_tiles = n / rows_per_block + S.n_clusters + 1;
     const size_t table = (size_t)(kMaxClusters + 64) * 4;
     const size_t o_counts = 0, o_start = o_counts + table, o_cursor = o_start + table, o_tiles = o_cursor + table, o_order = o_tiles + table;
@@ -569,7 +634,7 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
         if ((rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "lds attr"))) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)max_tiles), dim3(256), lds_bytes, stream, L);
     } else {
-        auto kern = mlp_forward_kernel<8, 2, 8>;
+        auto kern = mlp_forward_kernel<8, 4, 8>;  // (until round 5 <8, 2, 8>: 32 columns per wavefront, two MFMAs per fragment read)
         if ((rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "lds attr"))) return rc;
         hipLaunchKernelGGL(kern, dim3((unsigned)max_tiles), dim3(512), lds_bytes, stream, L);
     }
