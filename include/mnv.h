@@ -123,6 +123,11 @@ void mnv_cli_render_options(mnv_render_options *opt);
 void mnv_camera_init(mnv_camera *cam, int32_t width, int32_t height, float fx, float fy, float cx, float cy);
 void mnv_camera_set_pose(mnv_camera *cam, const float center[3], const float v_back[3],
                          const float v_world_up[3]);
+/* Camera's drag helpers (include/camera.hpp:22-25, src/camera.cpp:132-187) as one stateless call for hosts without the C++ struct: the
+ * pose (center, v_back, origin; updated in place) after begin_drag(x0, y0, is_pan, about_origin); drag_update(x1, y1); end_drag(); and the
+ * _update() of the next frame; cam->c2w receives the new matrix.  The C++ host model (host/camera.hpp) has the four members themselves. */
+void mnv_camera_drag(mnv_camera *cam, float center[3], float v_back[3], const float v_world_up[3], float origin[3], float movement_speed,
+                     int is_pan, int about_origin, float x0, float y0, float x1, float y1);
 
 /* ------------------------------------------------- the hot path (device) */
 

@@ -193,6 +193,8 @@ _SIGNATURES = {
     "mnv_cli_render_options": (None, [C.POINTER(RenderOptions)]),
     "mnv_camera_init": (None, [C.POINTER(CameraStruct), C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float]),
     "mnv_camera_set_pose": (None, [C.POINTER(CameraStruct), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "mnv_camera_drag": (None, [C.POINTER(CameraStruct), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_float,
+                               C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]),
     "mnv_render_voxels": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "mnv_render_voxels_ex": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.POINTER(FrameInputs),
@@ -409,6 +411,14 @@ class Camera:
     @property
     def c2w(self) -> np.ndarray:
         return np.array(list(self.c.c2w), dtype=np.float32)
+
+
+def camera_drag(cam: "Camera", center, v_back, v_world_up, origin, movement_speed, is_pan, about_origin, start_xy, end_xy):
+    """Camera::begin_drag / drag_update / end_drag (+ the next frame's _update) on a camera at the given pose: -> (center, v_back, origin, c2w[12])."""
+    c, b, u, o = _f3(center), _f3(v_back), _f3(v_world_up), _f3(origin)
+    lib().mnv_camera_drag(C.byref(cam.c), c, b, u, o, float(movement_speed), int(is_pan), int(about_origin), float(start_xy[0]), float(start_xy[1]),
+                          float(end_xy[0]), float(end_xy[1]))
+    return np.float32(list(c)), np.float32(list(b)), np.float32(list(o)), np.float32(list(cam.c.c2w))
 
 
 def orbit_camera(width, height, fx, radius, azimuth_deg, elevation_deg, fy=-1.0) -> Camera:

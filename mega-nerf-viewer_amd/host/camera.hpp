@@ -6,7 +6,8 @@
 // move() and the has_changed() latch.  Changed on purpose: there is no device copy
 // of the transform -- the 12 floats travel by value inside mnv_camera, which removes
 // the reference's hidden default-stream cudaMemcpyAsync (camera.cpp:113-123).
-// Dropped: the mouse-drag state machine (interactive window is out of scope).
+// The drag helpers (camera.hpp:22-25) are kept for API compatibility -- they feed only the interactive window, which is out of scope,
+// but a host that scripts a camera path with them gets the reference's poses (tests/golden/ref_camera_drag.npz).
 #pragma once
 
 #include "../../include/mnv.h"
@@ -23,7 +24,13 @@ struct Camera {
     Camera(int width = 256, int height = 256, float fx = 1111.f, float fy = -1.f, float cx = -1.f,
            float cy = -1.f);
 
-    /** Move center by += xyz * movement_speed **/
+    /** Drag helpers (camera.hpp:22-25, camera.cpp:132-187): screen-space drag from (x, y) of begin_drag to (x, y) of drag_update --
+        a pan along v_right / v_up, or a rotation about v_world_up and the start's v_right (about the camera, or about `origin`) **/
+    void begin_drag(float x, float y, bool is_pan, bool about_origin);
+    void drag_update(float x, float y);
+    void end_drag();
+    bool is_dragging() const;
+    /** Move center by += xyz * movement_speed, correctly handling drag **/
     void move(const vec3 &xyz);
     bool has_changed();
 
@@ -49,6 +56,11 @@ struct Camera {
     mnv_camera c_abi() const;
 
 private:
+    struct DragState {
+        bool is_dragging = false, is_panning = false, about_origin = false;
+        float start_x = 0.f, start_y = 0.f;
+        vec3 start_back, start_right, start_up, start_center, start_origin;
+    } drag_;
     bool has_changed_ = true;
     bool transform_changed_ = false;
     float last_fx = 0.f, last_fy = 0.f;

@@ -73,6 +73,27 @@ void mnv_camera_set_pose(mnv_camera *cam, const float center[3], const float v_b
     std::memcpy(cam->c2w, c.transform, sizeof(cam->c2w));
 }
 
+void mnv_camera_drag(mnv_camera *cam, float center[3], float v_back[3], const float v_world_up[3], float origin[3], float movement_speed,
+                     int is_pan, int about_origin, float x0, float y0, float x1, float y1) {
+    viewer::Camera c(cam->width, cam->height, cam->fx, cam->fy, cam->cx, cam->cy);
+    c.center = {center[0], center[1], center[2]};
+    c.v_back = {v_back[0], v_back[1], v_back[2]};
+    c.v_world_up = {v_world_up[0], v_world_up[1], v_world_up[2]};
+    c.origin = {origin[0], origin[1], origin[2]};
+    c.movement_speed = movement_speed;
+    c._update();
+    c.begin_drag(x0, y0, is_pan != 0, about_origin != 0);
+    c.drag_update(x1, y1);
+    c.end_drag();
+    c._update();  // what the next frame does (VolumeRenderer::render -> camera._update)
+    for (int i = 0; i < 3; ++i) {
+        center[i] = c.center[i];
+        v_back[i] = c.v_back[i];
+        origin[i] = c.origin[i];
+    }
+    std::memcpy(cam->c2w, c.transform, sizeof(cam->c2w));
+}
+
 int mnv_n3tree_open(const char *npz_path, mnv_n3tree **out) {
     if (!npz_path || !out) return mnv::set_error(MNV_E_INVALID, "null argument");
     return guarded([&] {

@@ -214,6 +214,21 @@ def camera_pose(width, height, fx, fy, cx, cy, center, back, up, updates=1):
     return np.array(list(out), np.float32), tuple(float(x) for x in intr)
 
 
+def camera_drag(width, height, fx, center, back, up, origin, movement_speed, is_pan, about_origin, start_xy, end_xy):
+    """The reference's Camera drag helpers: -> (center, v_back, origin, c2w[12]) after the drag and the next _update."""
+    h = lib()
+    h.ref_camera_drag.restype = C.c_int
+    pose = (C.c_float * 9)(*[float(x) for x in list(center) + list(back) + list(origin)])
+    out = (C.c_float * 12)()
+    rc = h.ref_camera_drag(C.c_int(width), C.c_int(height), C.c_float(fx), (C.c_float * 3)(*[float(x) for x in up]), C.c_float(movement_speed),
+                           C.c_int(int(is_pan)), C.c_int(int(about_origin)), C.c_float(start_xy[0]), C.c_float(start_xy[1]), C.c_float(end_xy[0]),
+                           C.c_float(end_xy[1]), pose, out)
+    if rc != 0:
+        raise RuntimeError(f"ref_camera_drag failed with {rc}")
+    p = np.array(list(pose), np.float32)
+    return p[0:3], p[3:6], p[6:9], np.array(list(out), np.float32)
+
+
 def dropin_render_npz(npz_path, cam_spec, opt_struct, capacity, path=0, want_trackers=False):
     """The reference's loader / N3Tree / Camera feeding libmnv.so through include/mnv_reference_binding.hpp.
     cam_spec: dict(width, height, fx, fy, cx, cy, center, back, up).  path 0 = mnv_render_voxels, 1 = packed accel."""

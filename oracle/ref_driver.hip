@@ -422,6 +422,37 @@ int ref_camera_pose(int width, int height, float fx, float fy, float cx, float c
     return 0;
 }
 
+// The reference's Camera drag helpers (camera.hpp:22-25, camera.cpp:132-187): pose after begin_drag(x0, y0) .. drag_update(x1, y1) ..
+// end_drag() and the next frame's _update().  pose9 = center, v_back, origin (in / out); c2w12_out = the new matrix.
+int ref_camera_drag(int width, int height, float fx, const float *up3, float movement_speed, int is_pan, int about_origin, float x0, float y0,
+                    float x1, float y1, float *pose9, float *c2w12_out) {
+    using namespace viewer;
+    try {
+        Camera cam(width, height, fx);
+        cam.center = glm::vec3(pose9[0], pose9[1], pose9[2]);
+        cam.v_back = glm::vec3(pose9[3], pose9[4], pose9[5]);
+        cam.origin = glm::vec3(pose9[6], pose9[7], pose9[8]);
+        cam.v_world_up = glm::vec3(up3[0], up3[1], up3[2]);
+        cam.movement_speed = movement_speed;
+        cam._update();
+        cam.begin_drag(x0, y0, is_pan != 0, about_origin != 0);
+        cam.drag_update(x1, y1);
+        cam.end_drag();
+        cam._update();
+        (void)hipDeviceSynchronize();
+        for (int i = 0; i < 3; ++i) {
+            pose9[i] = cam.center[i];
+            pose9[3 + i] = cam.v_back[i];
+            pose9[6 + i] = cam.origin[i];
+        }
+        memcpy(c2w12_out, glm::value_ptr(cam.transform), 12 * sizeof(float));
+    } catch (const std::exception &e) {
+        fprintf(stderr, "ref_camera_drag: %s\n", e.what());
+        return -1;
+    }
+    return 0;
+}
+
 // Drop-in demonstration: the reference's own loader, N3Tree (libtorch tensors on the device) and Camera (glm) feed libmnv.so
 // through include/mnv_reference_binding.hpp -- what a ROCm build of the viewer would do per frame.  path: 0 = mnv_render_voxels on
 // the reference's arrays (with trackers / visit marks), 1 = the packed accel.  Trackers / visited may be NULL.

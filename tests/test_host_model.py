@@ -213,3 +213,42 @@ def test_npz_reader_rejects_malformed_files_without_hanging(mnv, tmp_path):
     bad.write_bytes(bytes(b))
     with pytest.raises(mnv.MnvError):
         mnv.N3Tree.open(str(bad))
+
+
+def test_camera_drag_matches_reference_camera(mnv):
+    """Camera::begin_drag / drag_update / end_drag (include/camera.hpp:22-25, src/camera.cpp:132-187): 64 drags -- rotations about the camera
+    and about the origin, pans, drags that wrap the azimuth or run into the pole guard -- against the poses the reference's own Camera (glm)
+    produced (tests/golden/make_camera_drag_goldens.py, run inside oracle/_ref on the GPU box).  Kept for API compatibility; the window
+    that used them is out of scope."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_camera_drag.npz"))
+    kinds = set()
+    n_exact = 0
+    for d, want in zip(g["inputs"], g["outputs"]):
+        cam = mnv.Camera(int(d[0]), int(d[1]), float(np.float32(d[2])))
+        c, b, o, m = mnv.camera_drag(cam, np.float32(d[3:6]), np.float32(d[6:9]), np.float32(d[9:12]), np.float32(d[12:15]), np.float32(d[15]), bool(d[16]),
+                                     bool(d[17]), (np.float32(d[18]), np.float32(d[19])), (np.float32(d[20]), np.float32(d[21])))
+        got = np.concatenate([c, b, o, m])
+        assert np.allclose(got, want, rtol=0, atol=2e-6), (d, got, want)
+        n_exact += int(np.array_equal(got.view(np.uint32), want.view(np.uint32)))
+        kinds.add((bool(d[16]), bool(d[17])))
+    assert kinds == {(False, False), (True, False), (False, True)} and n_exact >= 48   # (cosf / sinf of glibc on both sides: mostly bit-identical)
+
+
+def test_camera_drag_properties(mnv):
+    """What the drag does, without the goldens: a pan slides center (and origin with about_origin) along the start's right / up vectors by
+    -2 * speed / max(w, h) per pixel; a rotation keeps |v_back| = 1 and, about the origin, the distance centre-origin; a tilt over the pole
+    is refused; a drag of zero pixels changes nothing."""
+    cam = mnv.Camera(800, 600, 700.0)
+    c0, b0, up, org = np.float32([-3.55, 0.0, 3.55]), np.float32([-0.7071068, 0.0, 0.7071068]), (0.0, 0.0, 1.0), np.float32([0.3, -0.2, 0.1])
+    c, b, o, m = mnv.camera_drag(cam, c0, b0, up, org, 1.0, False, False, (10, 10), (10, 10))
+    assert np.allclose(c, c0) and np.allclose(b, b0, atol=1e-7) and np.allclose(o, org)
+    c, b, o, m = mnv.camera_drag(cam, c0, b0, up, org, 2.0, True, True, (100, 100), (300, 180))
+    right, upv = np.float32([0.0, -1.0, 0.0]), np.float32([0.7071068, 0.0, 0.7071068])
+    k = -2.0 * 2.0 / 800
+    assert np.allclose(c, c0 + 200 * k * right - 80 * k * upv, atol=1e-5) and np.allclose(o - org, c - c0, atol=1e-6)
+    c, b, o, m = mnv.camera_drag(cam, c0, b0, up, org, 1.0, False, True, (100, 100), (260, 40))
+    assert abs(np.linalg.norm(b) - 1) < 1e-6 and abs(np.linalg.norm(c - org) - np.linalg.norm(c0 - org)) < 1e-5 and not np.allclose(c, c0)
+    c, b, o, m = mnv.camera_drag(cam, c0, b0, up, org, 1.0, False, False, (100, 100), (100, 100 + 1000))   # 2.5 rad of tilt from 45 degrees: over the pole
+    assert np.allclose(b, b0, atol=1e-7)

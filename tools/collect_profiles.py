@@ -6,7 +6,7 @@ import re
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = os.environ.get("ROUND", "r04")
+R = os.environ.get("ROUND", "r05")
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
 
@@ -29,13 +29,13 @@ s += "         -> %.0f L1 misses in flight per compute unit on average; TA busy 
     lat * req, 100 * avg(mem, "TA_BUSY_avr") / cyc, 100 * avg(mem, "TCP_PENDING_STALL_CYCLES_sum") / 256 / cyc)
 open(os.path.join(P, R + "_rocprofv3_summary.txt"), "w").write(s)
 shutil.copy(os.path.join(G, R + "_batch", "traffic.json"), os.path.join(P, R + "_traffic.json"))
-for t in ("per_frame", "per_frame_1stream", "ref_layout", "cfg3", "cfg4"):
+for t in ("per_frame", "per_frame_1stream", "ref_layout", "cfg3", "cfg4", "fog"):
     shutil.copy(os.path.join(G, "%s_%s" % (R, t), "summary.txt"), os.path.join(P, "%s_rocprofv3_summary_%s.txt" % (R, t)))
-for wl in ("cfg3", "cfg4"):   # HBM bytes per launch of the 7.2 M-chunk tree's launches (bench.py: cfg3 / cfg4_n1 rooflines)
+for wl in ("cfg3", "cfg4", "fog"):   # HBM bytes per launch of the 7.2 M-chunk tree's launches (bench.py: cfg3 / cfg4_n1 rooflines)
     shutil.copy(os.path.join(G, "%s_%s" % (R, wl), "traffic.json"), os.path.join(P, "%s_traffic_%s.json" % (R, wl)))
 shutil.copy(os.path.join(G, R + "_guided", "summary.txt"), os.path.join(P, R + "_rocprofv3_summary_guided_fused.txt"))
 d = json.load(open(os.path.join(G, R + "_bench_n1.json")))
 json.dump(d, open(os.path.join(P, R + "_bench_n1.json"), "w"))
 print("value", d["value"], "frac", d["roofline"]["frac"], "traffic", d["roofline"]["traffic"], "per_frame", d["per_frame"]["value"])
-for k in ("cfg3", "cfg4_n1"):
+for k in ("cfg3", "cfg4_n1", "fog"):
     print(k, d[k]["value"], {x: d[k]["roofline"][x] for x in ("frac", "algorithmic_over_peak", "frac_real_hbm", "traffic")})

@@ -4,7 +4,7 @@ set -u
 TAG=${1:-mem}; export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/$TAG; mkdir -p "$OUT"
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --frame-streams 0"
-pmc() { local name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 bench.py $ARGS > "$OUT/pmc_$name.log" 2>&1; }
+pmc() { local name=$1; shift; timeout 400 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 bench.py $ARGS > "$OUT/pmc_$name.log" 2>&1; }
 pmc ta TA_TA_BUSY_sum TA_BUSY_avr TA_BUSY_max GRBM_GUI_ACTIVE
 pmc lat TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum
 pmc stall TCP_PENDING_STALL_CYCLES_sum TCP_TCR_RDRET_STALL_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum

@@ -8,8 +8,8 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extras --frame-streams 0 $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/trace.log" 2>&1
-pmc() { local name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 bench.py $ARGS > "$OUT/pmc_$name.log" 2>&1; }
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/trace.log" 2>&1
+pmc() { local name=$1; shift; timeout 400 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -- python3 bench.py $ARGS > "$OUT/pmc_$name.log" 2>&1; }
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 pmc rdreq TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum
