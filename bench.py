@@ -27,7 +27,11 @@ import os
 import sys
 import time
 
-# the CPU baseline's OpenMP threads: one per physical core, pinned and spread (must be in the environment before an OpenMP runtime loads)
+# the CPU baseline's OpenMP threads: one per physical core, pinned and spread (must be in the environment before an OpenMP runtime loads).
+# Once a runtime has loaded, the main thread is bound to ITS place and sched_getaffinity no longer tells how many CPUs the process may use:
+# the count is taken here and handed to the oracle's thread-count logic (oracle/mnv_oracle.py).
+if hasattr(os, "sched_getaffinity"):
+    os.environ.setdefault("MNV_ORACLE_CPUS", str(len(os.sched_getaffinity(0))))
 os.environ.setdefault("OMP_PROC_BIND", "spread")
 os.environ.setdefault("OMP_PLACES", "cores")
 

@@ -126,11 +126,7 @@ def _threads(n_threads):
         import math
         import os
 
-        n = os.cpu_count() or 1
-        try:
-            n = min(n, len(os.sched_getaffinity(0)))
-        except (AttributeError, OSError):
-            pass
+        n = min(os.cpu_count() or 1, _usable_cpus())
         q = cpu_quota()
         if q is not None:
             n = min(n, max(1, int(math.ceil(q))))
@@ -148,6 +144,22 @@ def copy_first_touch(tree: OrcTree, n_threads=0) -> OrcTree:
 
 def free_copy(tree: OrcTree) -> None:
     lib().orc_tree_free_copy(C.byref(tree))
+
+
+def _usable_cpus():
+    """CPUs in the process's scheduler affinity.  A host program that pins OpenMP threads (OMP_PROC_BIND) must count them BEFORE an OpenMP
+    runtime loads -- afterwards the main thread is bound to one place and its own mask says 1 or 2 -- and hand the count over in
+    MNV_ORACLE_CPUS (bench.py, tools/cpu_ladder.py)."""
+    import os
+
+    try:
+        return max(1, int(os.environ["MNV_ORACLE_CPUS"]))
+    except (KeyError, ValueError):
+        pass
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
 
 
 def cpu_quota():
@@ -174,11 +186,7 @@ def baseline_threads():
     import os
 
     phys, hw = physical_cores()
-    n = phys or hw
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except (AttributeError, OSError):
-        pass
+    n = min(phys or hw, _usable_cpus())
     quota = cpu_quota()
     if quota is not None:
         n = min(n, max(1, int(math.floor(quota + 1e-9))))

@@ -6,6 +6,8 @@ import os
 import sys
 import time
 
+if hasattr(os, "sched_getaffinity"):
+    os.environ.setdefault("MNV_ORACLE_CPUS", str(len(os.sched_getaffinity(0))))   # before an OpenMP runtime binds the main thread to one place
 os.environ.setdefault("OMP_PROC_BIND", "spread")
 os.environ.setdefault("OMP_PLACES", "cores")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
