@@ -533,6 +533,14 @@ def test_bricks_below_the_second_grid_bit_exact(mnv, orc, torch_gpu, depth, basi
         want_d = orc.render(t, cam.c, opt_d)["rgba"]
         got_d, _ = _render_gpu(mnv, torch, tree, cam, opt_d, "accel")
         assert np.array_equal(cases.bits(got_d), cases.bits(want_d))
+    # a negative sigma_thresh makes EMPTY leaves dense samples (0 > thresh: weight 0, the colour row is still read) -- the inline words and
+    # records cannot answer that, the launch falls back to the node words
+    opt_n = mnv.RenderOptions.cli_defaults()
+    opt_n.sigma_thresh = -0.5
+    want_n = orc.render(t, cam.c, opt_n)
+    assert want_n["counters"].hits > 3 * ref["counters"].hits
+    got_n, _ = _render_gpu(mnv, torch, tree, cam, opt_n, "accel")
+    assert np.array_equal(cases.bits(got_n), cases.bits(want_n["rgba"]))
     # a sub-rectangle and a batch of two cameras through the same kernel
     cam2 = mnv.Camera(200, 144, 500.0).set_pose((2.2, -1.9, 1.1), (0.7, -0.6, 0.39))
     ref2 = orc.render(t, cam2.c, opt)["rgba"]
