@@ -245,6 +245,9 @@ int mnv_render_voxels_accel_part(const mnv_accel *accel, const mnv_camera *cam, 
  * Trackers, sample emission, depth mode and RGBA-format trees are unaffected.
  */
 void mnv_set_colour_math(int fast);
+/* The same choice for ONE accel: mode 0 exact, 1 fast, a negative value = follow the process-wide switch again (the default).  Two renderers
+ * of one process can thus differ; launches already queued keep the mode they were launched with. */
+int mnv_accel_set_colour_math(mnv_accel *accel, int mode);
 
 /*
  * mnv_render_voxels builds, in front of every launch of at least `min_rays` rays, a dense level-7 lookup table of the tree on the
@@ -586,6 +589,8 @@ int mnv_render_guided_fused(const mnv_accel *accel, const mnv_camera *cam, const
  * 1 = the one-role kernel (every wavefront marches and evaluates), 2 = producer / consumer wavefronts wherever the rings, the
  * rays' constants and the weights of enough sub-modules fit a workgroup's LDS (the one-role kernel otherwise). */
 void mnv_set_fused_kernel(int version);
+/* ... and for ONE accel (a negative value = follow the process-wide choice again, the default) */
+int mnv_accel_set_fused_kernel(mnv_accel *accel, int version);
 /* Diagnostics of the fused kernels (process-wide): `words32` = NULL (default, none) or a device buffer of 32 64-bit words the
  * kernels add run counts and per-phase times to (tools/guided_bench.py names them).  Costs a few per cent while set.  The library keeps
  * only the address: the buffer must outlive every launch made while it is set (pass NULL before freeing it). */

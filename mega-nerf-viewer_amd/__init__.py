@@ -218,6 +218,8 @@ _SIGNATURES = {
     "mnv_render_voxels_accel_part": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, Partition,
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_set_colour_math": (None, [C.c_int]),
+    "mnv_accel_set_colour_math": (C.c_int, [C.c_void_p, C.c_int]),
+    "mnv_accel_set_fused_kernel": (C.c_int, [C.c_void_p, C.c_int]),
     "mnv_set_fused_kernel": (None, [C.c_int]),
     "mnv_set_fused_diag": (None, [C.c_void_p]),
     "mnv_accel_fused_faults": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
@@ -683,6 +685,16 @@ def get_samples_from_voxels_accel_visit(accel: int, cam: Camera, opt: RenderOpti
 def set_colour_math(fast: bool) -> None:
     """False (default): bit-identical to the oracle.  True: hardware exp2 / rcp in the colour sigmoid (colours move ~1e-7)."""
     lib().mnv_set_colour_math(int(bool(fast)))
+
+
+def accel_set_colour_math(accel: int, mode: int) -> None:
+    """Colour math of ONE accel: 0 exact, 1 fast colour sigmoid, negative = follow set_colour_math (the default)."""
+    _check(lib().mnv_accel_set_colour_math(C.c_void_p(accel), int(mode)))
+
+
+def accel_set_fused_kernel(accel: int, version: int) -> None:
+    """Fused guided-sampling kernel of ONE accel: 0 / 1 / 2 as set_fused_kernel, negative = follow it (the default)."""
+    _check(lib().mnv_accel_set_fused_kernel(C.c_void_p(accel), int(version)))
 
 
 def set_fused_kernel(version: int) -> None:

@@ -154,6 +154,8 @@ struct mnv_accel {
     std::atomic<uint32_t> slot_counter{0};
     hipEvent_t slot_done[mnv::kSlots] = {};  // recorded after the launch that used the slot
     bool slot_used[mnv::kSlots] = {};
+    std::atomic<int> colour_math{-1};     // mnv_accel_set_colour_math: -1 follow the process-wide switch, 0 exact, 1 fast colour sigmoid
+    std::atomic<int> fused_kernel{-1};    // mnv_accel_set_fused_kernel: -1 follow the process-wide switch, 0 / 1 / 2 as mnv_set_fused_kernel
     size_t bytes = 0;
     int device = 0;
     int num_cus = 0;     // units the persistent launch fills (mnv_accel_set_cu_budget)

@@ -97,6 +97,10 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
         }
     }
     K.A = accel->view;
+    {   // colour math: the accel's own setting, else the process-wide switch (two renderers of one process may differ)
+        const int own = accel->colour_math.load(std::memory_order_relaxed);
+        K.fast_colour = own >= 0 ? own : (fast_colour_selected() ? 1 : 0);
+    }
     K.part_rank = part.rank;
     K.part_world = is_partitioned(part) ? part.world : 0;
     K.part_period = root_period_of(part);
@@ -261,6 +265,18 @@ using namespace mnv;
 extern "C" {
 
 int32_t mnv_partition_local_tiles(mnv_rect tile, mnv_partition part) { return partition_local_tiles(tile, part); }
+
+int mnv_accel_set_colour_math(mnv_accel *accel, int mode) {
+    if (!accel) return set_error(MNV_E_INVALID, "accel is null");
+    accel->colour_math.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed);
+    return MNV_OK;
+}
+
+int mnv_accel_set_fused_kernel(mnv_accel *accel, int version) {
+    if (!accel) return set_error(MNV_E_INVALID, "accel is null");
+    accel->fused_kernel.store(version < 0 ? -1 : (version == 1 || version == 2 ? version : 0), std::memory_order_relaxed);
+    return MNV_OK;
+}
 
 int mnv_accel_fused_faults(const mnv_accel *accel, uint32_t *count_out) {
     if (!accel || !count_out) return set_error(MNV_E_INVALID, "null argument");

@@ -27,7 +27,8 @@ int launch_fused(const mnv_accel *accel, const AccelLaunch &K, const FusedGuided
     while (slots > 1 && (size_t)f2_layout(nb, lds_level, F.S, slots).total * 4 > (size_t)160 * 1024 / f2_per_cu) --slots;
     F.weight_slots = slots;
     const size_t f2_bytes = (size_t)f2_layout(nb, lds_level, F.S, slots).total * 4;
-    const int version = g_fused_kernel.load(std::memory_order_relaxed);
+    const int own = accel->fused_kernel.load(std::memory_order_relaxed);
+    const int version = own >= 0 ? own : g_fused_kernel.load(std::memory_order_relaxed);
     const bool fits2 = f2_bytes <= (size_t)160 * 1024 / f2_per_cu && slots >= (kF2NS < 2 ? kF2NS : 2) && F.S.bias_floats <= 256;  // (a consumer refills a sub-module's biases with four loads per lane)
     if (fits2 && (version == 2 || (version == 0 && kF2Default))) {
         int per_cu = (int)((size_t)160 * 1024 / f2_bytes);

@@ -48,6 +48,7 @@ struct AccelLaunch {
     int32_t max_depth, max_sample_count;
     int32_t *visited;                     // MODE 2 / 3 only: visit marks [capacity]; the march marks the chunk of every leaf it steps through,
                                           // close_visit_marks adds the ancestors (= every chunk of every descent, rt_core.cuh:132-134)
+    int32_t fast_colour;                  // host side only: the colour-math mode this launch resolved to (the accel's own, else the process-wide one)
     int32_t ablate;                       // diagnostics only (breaks results): 1 no colour, 2 no dense samples, 4 cached rows
     const uint32_t *shadow_nodes;         // -DMNV_SHADOW_MASK variants only: copies of nodes / rows / brick records for the shadow loads
     const uint8_t *shadow_rows;

@@ -33,7 +33,7 @@ static int launch_variant(const AccelLaunch &K, int n_blocks, size_t lds_bytes, 
         if (K.P.render_depth) return launch_variant2<BASIS, 5>(K, n_blocks, lds_bytes, stream);
     }
     if constexpr (BASIS >= 1) {
-        if (g_fast_colour.load(std::memory_order_relaxed)) return launch_variant2<BASIS, 4>(K, n_blocks, lds_bytes, stream);
+        if (K.fast_colour) return launch_variant2<BASIS, 4>(K, n_blocks, lds_bytes, stream);
     }
     return launch_variant2<BASIS, 0>(K, n_blocks, lds_bytes, stream);
 }

@@ -25,7 +25,7 @@ static int launch_brick(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hi
         if (K.P.render_depth) return launch_brick2<BASIS, 5>(K, n_blocks, lds_bytes, stream);
     }
     if constexpr (BASIS >= 1) {
-        if (fast_colour_selected()) return launch_brick2<BASIS, 4>(K, n_blocks, lds_bytes, stream);
+        if (K.fast_colour) return launch_brick2<BASIS, 4>(K, n_blocks, lds_bytes, stream);
     }
     return launch_brick2<BASIS, 0>(K, n_blocks, lds_bytes, stream);
 }

@@ -19,6 +19,7 @@ def fused_kernel(request, mnv, torch_gpu):
     (csrc/mnv_guided_fused.h).  The diagnostics buffer is on so that a spin-wait abandoned by the watchdog fails the test."""
     diag = torch_gpu.zeros(32, dtype=torch_gpu.int64, device="cuda")
     mnv.set_fused_kernel(request.param)
+    _FUSED_CHOICE[0] = request.param
     mnv.set_fused_diag(diag if request.param == 2 else None)
     yield request.param
     torch_gpu.cuda.synchronize()
@@ -85,6 +86,21 @@ def test_fused_frame_equals_the_four_step_path(mnv, torch_gpu, case, need_viewdi
     assert int(counter.item()) == total
     assert np.array_equal(cases.bits(got), cases.bits(ref)), float(np.nanmax(np.abs(got - ref)))
     assert np.array_equal(out8.cpu().numpy(), ref8)
+    # the OTHER kernel for this accel alone (mnv_accel_set_fused_kernel overrides the process-wide choice of the fixture): the same frame
+    mnv.accel_set_fused_kernel(tree.accel, 1 if fused_kernel_choice(mnv) == 2 else 2)
+    out.fill_(float("nan"))
+    mnv.render_guided_fused(tree.accel, cam, opt, mlp, grid, rgba=out)
+    torch.cuda.synchronize()
+    assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref))
+    mnv.accel_set_fused_kernel(tree.accel, -1)
+
+
+def fused_kernel_choice(mnv):
+    """The process-wide choice the module's fixture made for the running test."""
+    return _FUSED_CHOICE[0]
+
+
+_FUSED_CHOICE = [0]
 
 
 def test_fused_frame_at_cfg2_size(mnv, torch_gpu):

@@ -648,6 +648,42 @@ def test_fast_colour_math_keeps_alpha_and_control_flow_exact(mnv, orc, torch_gpu
     assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref))
 
 
+def test_two_accels_of_one_process_can_differ_in_colour_math(mnv, orc, torch_gpu):
+    """mnv_accel_set_colour_math: the process-wide switch is only the default -- one accel renders with the hardware exp2 / rcp colour
+    sigmoid (alpha bit-identical, colours within 2e-6) while another accel of the same process stays exact, and -1 hands an accel back to
+    the process-wide switch."""
+    torch = torch_gpu
+    spec = cases.CASES["shell_d7_sh9"]
+    cam, opt = cases.make_camera(mnv, spec["camera"]), cases.make_options(mnv, spec["options"])
+    ta, tb = cases.make_tree(mnv, spec["tree"]), cases.make_tree(mnv, spec["tree"])
+    ref = orc.render(orc.tree_from_view(ta.host_view()), cam.c, opt)["rgba"]
+    ta.move_to_device()
+    tb.move_to_device()
+    out_a = torch.empty((cam.height, cam.width, 4), dtype=torch.float32, device="cuda")
+    out_b = torch.empty_like(out_a)
+    mnv.accel_set_colour_math(ta.accel, 1)
+    try:
+        mnv.render_voxels_accel(ta.accel, cam, opt, rgba=out_a)
+        mnv.render_voxels_accel(tb.accel, cam, opt, rgba=out_b)
+        torch.cuda.synchronize()
+        a, b = out_a.cpu().numpy(), out_b.cpu().numpy()
+        assert np.array_equal(cases.bits(b), cases.bits(ref))
+        assert np.array_equal(cases.bits(a[..., 3]), cases.bits(ref[..., 3])) and not np.array_equal(cases.bits(a), cases.bits(ref))
+        assert np.abs(a - ref).max() < 2e-6
+        mnv.accel_set_colour_math(ta.accel, -1)   # follow the process-wide switch (exact) again
+        mnv.render_voxels_accel(ta.accel, cam, opt, rgba=out_a)
+        torch.cuda.synchronize()
+        assert np.array_equal(cases.bits(out_a.cpu().numpy()), cases.bits(ref))
+        mnv.set_colour_math(True)                  # process-wide fast, this accel pinned to exact
+        mnv.accel_set_colour_math(tb.accel, 0)
+        mnv.render_voxels_accel(tb.accel, cam, opt, rgba=out_b)
+        mnv.render_voxels_accel(ta.accel, cam, opt, rgba=out_a)
+        torch.cuda.synchronize()
+        assert np.array_equal(cases.bits(out_b.cpu().numpy()), cases.bits(ref)) and not np.array_equal(cases.bits(out_a.cpu().numpy()), cases.bits(ref))
+    finally:
+        mnv.set_colour_math(False)
+
+
 @pytest.mark.parametrize("name", ["sh4_d6", "sh9_d7_aniso", "rgba_d5", "terrain_d7_aniso"])
 def test_reference_binding_is_a_drop_in(mnv, orc, torch_gpu, tmp_path, name):
     """include/mnv_reference_binding.hpp compiled inside a build of the reference (oracle/Makefile.ref): the reference's OWN loader,
