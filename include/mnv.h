@@ -198,8 +198,9 @@ size_t mnv_accel_device_bytes(const mnv_accel *accel);
 int32_t mnv_accel_grid2_level(const mnv_accel *accel);
 /* levels below that grid which plain frames currently resolve WITHOUT node words: 1 = the last level is folded into the grid's cell words
  * (a depth-10 tree under a level-9 grid reads no node word at all), 2 = the next two levels also come from 64-byte brick records (trees with
- * leaves two or more levels below the grid), 0 = neither -- always 0 after mnv_accel_refresh / a prune until mnv_accel_rebuild (derived data
- * that tree edits do not patch; frames are bit-identical either way) */
+ * leaves two or more levels below the grid), 0 = neither -- 0 after mnv_accel_refresh / a prune (derived data that tree edits do not patch)
+ * until mnv_accel_rebuild, or until 16 plain frames in a row have been launched without another edit: the sixteenth derives them again on
+ * its stream (about 0.3 ms for a level-9 grid).  Frames are bit-identical either way. */
 int32_t mnv_accel_brick_levels(const mnv_accel *accel);
 /* Compute units the tuned kernel may fill with its persistent workgroups (8 per unit).  Default (and num_cus <= 0): every unit
  * of the device.  A caller that launches on a stream created with hipExtStreamCreateWithCUMask -- to leave units free for

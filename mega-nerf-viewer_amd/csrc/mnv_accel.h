@@ -58,6 +58,7 @@ constexpr size_t kSlotBytes = (size_t)MNV_MAX_BATCH * (kNumQueues * 64 + sizeof(
 constexpr int kMaxGrid2Level = 9;  // 8^9 * 4 B = 512 MiB per array
 constexpr uint32_t kInlineBit = 0x40000000u;  // grid2i: the cell's eight children are leaves, described by the word itself
 constexpr int kInlineMaskShift = 22;           // ... bit (22 + s1): child s1 has sigma bits != 0; bits 0..21: the chunk
+constexpr int kRederiveAfter = 16;  // plain launches without a tree edit after which stale inline words / brick records are derived again
 constexpr int kRecWords = 16;      // a brick record: 8 entries {child chunk, 8 two-bit sub-cell codes} = 64 B
 
 // Interleaved macro-tile partition (mnv_partition in include/mnv.h).  Tiles are dealt in rounds of `world`; with a root period
@@ -154,6 +155,14 @@ struct mnv_accel {
     std::atomic<uint32_t> slot_counter{0};
     hipEvent_t slot_done[mnv::kSlots] = {};  // recorded after the launch that used the slot
     bool slot_used[mnv::kSlots] = {};
+    // grid2i / recs after a tree edit: stale until mnv_accel_rebuild -- or until kRederiveAfter plain frames in a row have been launched
+    // without another edit, when launch_accel derives them again on the launch stream (0.3 ms for a level-9 grid: more than a handful of
+    // frames lose without them, so a caller that alternates edits and plain frames never pays it)
+    bool derived_stale = false;
+    int plain_since_edit = 0;
+    bool derived_pending = false;         // the re-derivation's kernels may still run on derived_stream: other streams wait for derived_ready
+    hipStream_t derived_stream = nullptr;
+    hipEvent_t derived_ready = nullptr;
     std::atomic<int> colour_math{-1};     // mnv_accel_set_colour_math: -1 follow the process-wide switch, 0 exact, 1 fast colour sigmoid
     std::atomic<int> fused_kernel{-1};    // mnv_accel_set_fused_kernel: -1 follow the process-wide switch, 0 / 1 / 2 as mnv_set_fused_kernel
     size_t bytes = 0;

@@ -159,6 +159,30 @@ void launch_build_grid2(const uint32_t *nodes, uint32_t *grid2, uint32_t *grid2_
     hipLaunchKernelGGL(accel_build_grid2, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, nodes, grid2, grid2_vox, L2);
 }
 
+int accel_rederive(mnv_accel *a, hipStream_t stream) {
+    static const int env_bricks = knob_int(KNOB_BRICK_LEVELS, 3);
+    const int L2 = a->view.grid2_level;
+    const bool want_inline = (env_bricks & 1) && L2 > 0 && a->grid2 != nullptr, want_recs = (env_bricks & 2) && want_inline && a->view.max_depth >= L2 + 2;
+    a->derived_stale = false;
+    if (!want_inline) return MNV_OK;
+    int rc;
+    const int64_t g2cells = (int64_t)1 << (3 * L2);
+    if (!a->grid2i && (rc = check_hip(hipMalloc((void **)&a->grid2i, g2cells * 4), "hipMalloc(grid2i)"))) return rc;
+    hipLaunchKernelGGL(accel_build_grid2i, dim3((unsigned)((g2cells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid2, a->grid2i, g2cells);
+    if (want_recs) {
+        if (!a->recs && (rc = check_hip(hipMalloc((void **)&a->recs, (size_t)a->reserved * kRecWords * 4), "hipMalloc(brick records)"))) return rc;
+        launch_build_recs(a->nodes, a->depth, a->recs, a->view.capacity, L2, stream);
+    }
+    if ((rc = check_hip(hipGetLastError(), "accel rederive launch"))) return rc;
+    if (!a->derived_ready && (rc = check_hip(hipEventCreateWithFlags(&a->derived_ready, hipEventDisableTiming), "hipEventCreate(derived)"))) return rc;
+    if ((rc = check_hip(hipEventRecord(a->derived_ready, stream), "record derived"))) return rc;
+    a->derived_stream = stream;
+    a->derived_pending = true;
+    a->view.grid2i = a->grid2i;
+    a->view.recs = want_recs ? a->recs : nullptr;
+    return MNV_OK;
+}
+
 int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
     int rc = MNV_OK;
     const int b = (t->format == MNV_FORMAT_SH && t->basis_dim >= 0) ? t->basis_dim : -1;
@@ -212,6 +236,7 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
         (void)hipFree(a->grid2_vox);
         a->grid2 = a->grid2_vox = nullptr;
         if (a->grid2i) (void)hipFree(a->grid2i);
+    if (a->derived_ready) (void)hipEventDestroy(a->derived_ready);
         a->grid2i = nullptr;
     }
     if (L2 > 0) {
@@ -247,6 +272,9 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
     if ((rc = check_hip(hipStreamSynchronize(stream), "accel build"))) return fail(rc);
     a->view.grid2i = want_inline ? a->grid2i : nullptr;
     a->view.recs = want_recs ? a->recs : nullptr;
+    a->derived_stale = false;   // (the stream was synchronised above: nothing pending)
+    a->derived_pending = false;
+    a->plain_since_edit = 0;
 
     a->view.nodes = a->nodes;
     a->view.rows = a->rows;

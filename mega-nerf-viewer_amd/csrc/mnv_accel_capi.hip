@@ -148,6 +148,19 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     // (or one thread feeding several streams) serialise here from the slot's acquisition to the record of its event.
     mnv_accel *mut = const_cast<mnv_accel *>(accel);
     std::lock_guard<std::mutex> launch_lock(mut->launch_mutex);
+    if (!track) {
+        // plain frame: stale inline words / brick records come back once enough plain frames in a row say the editing is over
+        if (mut->derived_stale && ++mut->plain_since_edit >= kRederiveAfter) {
+            const int rd = accel_rederive(mut, stream);
+            if (rd) return (int)hipErrorUnknown;
+        }
+        if (mut->derived_pending) {
+            if (hipEventQuery(mut->derived_ready) == hipSuccess) mut->derived_pending = false;
+            else if (mut->derived_stream != stream && hipStreamWaitEvent(stream, mut->derived_ready, 0) != hipSuccess) return (int)hipErrorUnknown;
+        }
+        K.A.grid2i = mut->view.grid2i;
+        K.A.recs = mut->view.recs;
+    }
     const uint32_t slot = mut->slot_counter.fetch_add(1) % kSlots;
     // a caller that runs more than kSlots launches ahead of the device waits here for the launch that last used the slot
     if (mut->slot_used[slot]) {

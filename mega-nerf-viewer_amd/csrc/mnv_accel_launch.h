@@ -164,6 +164,9 @@ struct AccelTrack {
 
 constexpr int kUnsupportedBasis = -1000;  // not a hipError_t
 
+// grid2i and the brick records again from the accel's own (patched) node words and grid2, asynchronously on `stream` (mnv_accel_build.hip);
+// sets view.grid2i / view.recs and records derived_ready
+int accel_rederive(mnv_accel *a, hipStream_t stream);
 // (Re)build every derived array of `a` from the tree (mnv_accel_build.hip)
 int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream);
 // the two lookup grids, whole, from the node words (mnv_accel_build.hip; the refresh rebuilds the small one, or both without a parent array)

@@ -278,8 +278,10 @@ int accel_apply_prune(mnv_accel *a, const int32_t *parent, const uint16_t *data,
     a->view.nodes = a->nodes;
     a->view.rows = a->rows;
     a->view.capacity = old_capacity - n_deleted;  // max_depth stays an upper bound (the march only needs pos * 2^max_depth < 2^24)
-    a->view.recs = nullptr;                        // stale (chunks renumbered): derived again by mnv_accel_rebuild
+    a->view.recs = nullptr;                        // stale (chunks renumbered): derived again by mnv_accel_rebuild, or after kRederiveAfter plain frames
     a->view.grid2i = nullptr;
+    a->derived_stale = true;
+    a->plain_since_edit = 0;
     return MNV_OK;
 }
 
@@ -366,8 +368,10 @@ int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity
     }
     a->view.max_depth = std::max(a->view.max_depth, h[1]);
     a->view.capacity = t->capacity;
-    a->view.recs = nullptr;  // stale: plain frames walk the node words until mnv_accel_rebuild derives the inline words and brick records again
+    a->view.recs = nullptr;  // stale: plain frames walk the node words until mnv_accel_rebuild -- or kRederiveAfter plain frames in a row -- derive them again
     a->view.grid2i = nullptr;
+    a->derived_stale = true;
+    a->plain_since_edit = 0;
     return check_hip(hipGetLastError(), "accel refresh launch");
 }
 

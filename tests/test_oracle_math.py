@@ -203,3 +203,28 @@ def test_mlp_restatement_against_numpy(mnv, orc):
             if li < 2:
                 h = f16(np.maximum(h, 0))
         assert np.allclose(got[row], h, rtol=2e-3, atol=2e-3)
+
+
+def test_oracle_onscreen_inputs_reduce_to_the_offscreen_call(mnv, orc):
+    """orc_render_voxels_ex (the reference's offscreen == false call shape, renderer_kernel.cu:230-234,277-280): a depth image of 1e9f
+    everywhere is the offscreen t_max, a white image under the volume is background_brightness 1, and a depth image of zeros leaves the
+    image as it was."""
+    import cases
+
+    spec = cases.CASES["sh4_d6"]
+    tree = cases.make_tree(mnv, spec["tree"])
+    cam, opt = cases.make_camera(mnv, spec["camera"]), cases.make_options(mnv, spec["options"])
+    t = orc.tree_from_view(tree.host_view())
+    h, w = cam.height, cam.width
+    plain = orc.render(t, cam.c, opt, want_rgba8=True)
+    far = orc.render(t, cam.c, opt, want_rgba8=True, tmax_px=np.full((h, w), 1e9, np.float32))
+    assert np.array_equal(plain["rgba"].view(np.uint32), far["rgba"].view(np.uint32)) and np.array_equal(plain["rgba8"], far["rgba8"])
+    opt.background_brightness = 1.0
+    white = np.full((h, w, 4), 255, np.uint8)
+    a = orc.render(t, cam.c, opt)["rgba"]
+    b = orc.render(t, cam.c, opt, rgba8_init=white)["rgba"]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    rng = np.random.default_rng(3)
+    image = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    shut = orc.render(t, cam.c, opt, want_rgba8=True, tmax_px=np.zeros((h, w), np.float32), rgba8_init=image)
+    assert np.all(shut["rgba"][..., 3] == 0.0) and np.array_equal(shut["rgba8"][..., :3], image[..., :3]) and np.all(shut["rgba8"][..., 3] == 255)

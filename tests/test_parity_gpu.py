@@ -559,6 +559,20 @@ def test_bricks_below_the_second_grid_bit_exact(mnv, orc, torch_gpu, depth, basi
     assert mnv.accel_info(tree.accel)["brick_levels"] == 2
     got, _ = _render_gpu(mnv, torch, tree, cam, opt, "accel")
     assert np.array_equal(cases.bits(got), cases.bits(ref["rgba"]))
+    # ... or by themselves, once 16 plain frames in a row have followed the last edit (derived on the launch stream of the sixteenth; a
+    # frame on another stream right behind it waits for that)
+    mnv.accel_refresh(tree.accel, dv, dv.capacity, changed_nodes=changed)
+    side = torch.cuda.Stream()
+    for k in range(18):
+        if k == 5:   # a tracker frame in between does not count and does not disturb
+            split = torch.full((cam.height, cam.width, 3), -1.0, dtype=torch.float32, device="cuda")
+            mnv.render_voxels_accel_track(tree.accel, cam, opt, rgba=torch.empty((cam.height, cam.width, 4), dtype=torch.float32, device="cuda"), split_track=split)
+        out1 = torch.full((cam.height, cam.width, 4), float("nan"), dtype=torch.float32, device="cuda")
+        mnv.render_voxels_accel(tree.accel, cam, opt, rgba=out1, stream=side.cuda_stream if k == 16 else 0)
+        levels = mnv.accel_info(tree.accel)["brick_levels"]
+        assert levels == (0 if k < 15 else 2), (k, levels)
+        torch.cuda.synchronize()
+        assert np.array_equal(cases.bits(out1.cpu().numpy()), cases.bits(ref["rgba"])), k
 
 
 @pytest.mark.parametrize("step", [1e-4, 1.5e-3, 3e-3, 5e-2])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of the bricks below the second lookup grid (AccelView::bricks) on the deep-tree workloads: MNV_BRICK_LEVELS=0 builds the accel without them (3: inline cell words + records, 1: inline words only).
+# A/B of the inline cell words and brick records below the second lookup grid (AccelView::grid2i, ::recs): MNV_BRICK_LEVELS=0 builds the accel without them (3: inline cell words + records, 1: inline words only).
 # The knob exists in the test-hook build of the library only (csrc/mnv_knobs.h).   usage (via gpurun): bash tools/ab_bricks.sh [workloads...]
 export MNV_LIB_PATH=${MNV_LIB_PATH:-$(cd "$(dirname "$0")/.." && pwd)/mega-nerf-viewer_amd/testhooks/libmnv.so}
 for wl in ${@:-cfg3 cfg4}; do
