@@ -108,6 +108,30 @@ def test_random_scene_bit_exact(mnv, orc, torch_gpu, seed):
     mnv.render_voxels_accel(tree.accel, cam, opt, rgba=rgba, rgba8=rgba8)
     torch.cuda.synchronize()
     same_frame(rgba, rgba8, "march_accel_kernel")
+    if seed % 4 == 2:
+        # the reference's live call shape on a scene nobody chose: a depth image scattered around the camera-to-box distance (some pixels "no
+        # mesh", some "mesh at the lens") and / or a random image under the volume, both kernels
+        kind = (seed // 4) % 3
+        dist = float(np.linalg.norm(np.float64(spec["camera"]["center"])) + 1e-3)
+        tmax = (dist * rng.uniform(0.0, 2.0, size=(h, w))).astype(np.float32) if kind != 1 else None
+        if tmax is not None:
+            u = rng.uniform(size=(h, w))
+            tmax[u < 0.2] = np.float32(1e9)
+            tmax[u > 0.93] = np.float32(0.0)
+        image = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8) if kind != 0 else None
+        want = orc.render(orc.tree_from_view(v, sample_counts=sc), cam.c, opt, want_rgba8=True, tmax_px=tmax, rgba8_init=image)
+        t_dev = None if tmax is None else torch.from_numpy(tmax).cuda()
+        i_dev = None if image is None else torch.from_numpy(image).cuda()
+        for who in ("ref_layout", "accel"):
+            rgba, rgba8 = fresh()
+            if who == "accel":
+                mnv.render_voxels_accel(tree.accel, cam, opt, rgba=rgba, rgba8=rgba8, tmax_px=t_dev, rgba8_init=i_dev)
+            else:
+                mnv.render_voxels(tree.device_view(), cam, opt, rgba=rgba, rgba8=rgba8, tmax_px=t_dev, rgba8_init=i_dev)
+            torch.cuda.synchronize()
+            got = rgba.cpu().numpy()
+            assert np.array_equal(cases.bits(got), cases.bits(want["rgba"])), f"{who} with on-screen inputs (kind {kind}): {int((cases.bits(got) != cases.bits(want['rgba'])).any(axis=-1).sum())} pixels differ; {what}"
+            assert np.array_equal(rgba8.cpu().numpy(), want["rgba8"]), f"{who} with on-screen inputs: RGBA8; {what}"
     if not with_trackers:
         return
     sc_dev = torch.from_numpy(sc).cuda()
