@@ -356,9 +356,9 @@ def shipped_source_sha() -> str:
 
     here = os.path.dirname(os.path.abspath(__file__))
     names = []
-    for pat in ("csrc/*.hip", "csrc/*.h", "host/*.cpp", "host/*.hpp", "../include/*.h", "csrc/mnv_comm.cpp"):
+    for pat in ("csrc/*.hip", "csrc/*.h", "csrc/*.cpp", "host/*.cpp", "host/*.hpp", "../include/*.h"):
         names += [os.path.relpath(f, here) for f in glob.glob(os.path.join(here, pat))]
-    names = sorted(set(names))
+    names = sorted(set(names) - {os.path.join("csrc", "mnv_build_info.cpp")})   # (the unit the hash is compiled INTO is not part of it)
     h = hashlib.sha256()
     for n in names:
         with open(os.path.join(here, n), "rb") as f:

@@ -119,3 +119,11 @@ def test_no_packed_fp32_instructions_in_the_code_objects(mnv):
             n_insts += dis.count("\n")
             hits += re.findall(r"\bv_pk_(?:add|mul|fma|mov)_[fb]32\b[^\n]*", dis)
     assert n_insts > 100_000 and not hits, hits[:5]
+
+
+def test_the_library_was_built_from_the_sources_in_this_tree(mnv):
+    """mnv_source_sha (compiled in by the Makefile over its source lists) == the same hash taken over the tree by the Python side
+    (shipped_source_sha): a source file the Makefile compiles but the Python mirror does not list (or the other way round) would make
+    smoke() call every library stale -- as happened when csrc/mnv_knobs.cpp was added -- and an edited source without a rebuild fails here
+    instead of passing tests with old code."""
+    assert mnv.built_source_sha() == mnv.shipped_source_sha(), "libmnv.so is stale (run make) or the two source lists differ"
