@@ -334,13 +334,7 @@ int mnv_accel_create_reserved(const mnv_tree_view *t, int64_t max_capacity, void
     const int row_bytes = row_bytes_for(b);
     a->reserved = max_capacity;
     if ((rc = check_hip(hipMalloc((void **)&a->nodes, max_capacity * 8 * 4), "hipMalloc(nodes)"))) return fail(rc);
-    {
-        static const int rows_mem = knob_int(KNOB_ROWS_MEM, 0);  // measurement: does the L2 fetch less than a 128-byte line for rows it does not cache?
-        const size_t bytes = (size_t)max_capacity * 8 * row_bytes;
-        const hipError_t e = rows_mem == 0 ? hipMalloc((void **)&a->rows, bytes)
-                                           : hipExtMallocWithFlags((void **)&a->rows, bytes, rows_mem == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
-        if ((rc = check_hip(e, "hipMalloc(rows)"))) return fail(rc);
-    }
+    if ((rc = check_hip(hipMalloc((void **)&a->rows, max_capacity * 8 * row_bytes), "hipMalloc(rows)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&a->depth, max_capacity * 4), "hipMalloc(depth)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&a->flags, 32), "hipMalloc(flag)"))) return fail(rc);
     if ((rc = check_hip(hipMalloc((void **)&a->fault_dev, 4), "hipMalloc(fault)"))) return fail(rc);

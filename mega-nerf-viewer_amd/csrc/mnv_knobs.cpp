@@ -12,7 +12,6 @@ static const char *const kKnobNames[KNOB_COUNT] = {
     "MNV_TILE_WLOG",      "MNV_QUEUES",           "MNV_LDS_LEVEL",      "MNV_BLOCKS_PER_CU",   "MNV_REFILL_MIN",     "MNV_ABLATE",
     "MNV_STATS",          "MNV_TIMELINE",         "MNV_GRID2_LEVEL",    "MNV_BRICK_LEVELS",    "MNV_F2_BLOCKS_PER_CU", "MNV_F2_SWITCH_MIN",
     "MNV_FUSED_BATCH_MIN", "MNV_VOTE_WIDE_KEYS",  "MNV_VOTE_FULL_SORT", "MNV_ASSEMBLE_NARROW", "MNV_REFRESH_DEBUG",  "MNV_SYNTH_TIMING",
-    "MNV_ROWS_MEM",
     "MNV_SHADOW",
 };
 const char *knob_str(Knob k) { return k >= 0 && k < KNOB_COUNT ? std::getenv(kKnobNames[k]) : nullptr; }

@@ -25,7 +25,6 @@ enum Knob {
     KNOB_ASSEMBLE_NARROW,  // one RGBA8 pixel per thread in mnv_assemble_tiles
     KNOB_REFRESH_DEBUG,    // mnv_accel_refresh prints what it patched
     KNOB_SYNTH_TIMING,     // the synthetic-tree generators print their phases
-    KNOB_ROWS_MEM,         // memory type of the colour rows: 0 default, 1 uncached (hipDeviceMallocUncached), 2 fine-grained
     KNOB_SHADOW,           // allocate the copies the -DMNV_SHADOW_MASK variants of the march read (16 nodes, 32 rows, 64 bricks)
     KNOB_COUNT
 };

@@ -12,9 +12,12 @@
 //   * the top `grid_level` levels of the octree are a dense grid staged in LDS (up to
 //     128 KiB of the CU's 160 KiB): a step in coarse empty space costs one ds_read and no
 //     global load, and deep descents start at level grid_level + 1;
-//   * one 32-bit node word per voxel carries either the child link or the leaf's sigma,
-//     so the dependent sigma load of the reference disappears; colour rows are fetched
-//     (16-B vector loads from a 64-B padded row) only for dense samples;
+//   * below it one load from a dense brick-ordered level-L2 grid (L2 <= 9), then -- tracker / sample frames -- one 32-bit node
+//     word per level: the child link or the leaf's depth and sigma, so the dependent sigma load of the reference disappears;
+//   * plain frames (BRICK = true) do not read node words at all when the tree allows it: the grid's cell word carries the last
+//     level inline (which of the chunk's eight leaves are non-empty), two more levels come from one 8-byte entry of a 64-byte
+//     brick record, and a non-empty leaf's sigma is read WITH its colour row (the reference's row: coefficients, then sigma);
+//   * colour rows are fetched (16-B vector loads from a 64-B padded row) only for dense samples;
 //   * rays are queued in 8x8-pixel tile order and the tile range is split into 8
 //     contiguous bands, one per XCD (workgroup b runs on XCD b % 8), so that each XCD's
 //     4 MiB L2 holds the sub-trees of its own screen region; empty queues steal.
