@@ -30,10 +30,26 @@ import time
 # the CPU baseline's OpenMP threads: one per physical core, pinned and spread (must be in the environment before an OpenMP runtime loads).
 # Once a runtime has loaded, the main thread is bound to ITS place and sched_getaffinity no longer tells how many CPUs the process may use:
 # the count is taken here and handed to the oracle's thread-count logic (oracle/mnv_oracle.py).
-if hasattr(os, "sched_getaffinity"):
-    os.environ.setdefault("MNV_ORACLE_CPUS", str(len(os.sched_getaffinity(0))))
-os.environ.setdefault("OMP_PROC_BIND", "spread")
-os.environ.setdefault("OMP_PLACES", "cores")
+# ONLY in a one-rank run: with proc-bind every process's main thread -- the one that issues the launches -- is bound to the FIRST place, and N
+# ranks of a multi-GPU run would share one core.
+
+
+def _single_rank_run():
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        return False
+    for i, a in enumerate(sys.argv):
+        if a == "--gpus" and i + 1 < len(sys.argv):
+            return sys.argv[i + 1] == "1"
+        if a.startswith("--gpus="):
+            return a.split("=", 1)[1] == "1"
+    return True
+
+
+if _single_rank_run():
+    if hasattr(os, "sched_getaffinity"):
+        os.environ.setdefault("MNV_ORACLE_CPUS", str(len(os.sched_getaffinity(0))))
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
