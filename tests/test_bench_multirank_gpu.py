@@ -74,7 +74,7 @@ def test_bench_launcher_repeats_a_failed_run_conservatively_and_kills_a_wedged_o
     assert d["n_gpus"] == 2 and d["launch"].count("ended with code") == 3 and "repeated with --gather-via torch" in d["launch"] and "gloo" in d["config"]["partition"]
     assert d["parity"]["pixels_not_bit_identical"] == 0
     # (iii) the watchdog
-    r = subprocess.run(cmd + ["--launch-timeout", "8"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    r = subprocess.run(cmd + ["--launch-timeout", "3"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)   # (no rung can finish in 3 s)
     assert r.returncode != 0 and "was killed" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
