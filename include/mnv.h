@@ -264,7 +264,8 @@ void mnv_set_ref_table_min_rays(int64_t min_rays);
  * the packed re-layout).  mnv_set_tree_cache(1) (process-wide, default 0) lets it keep, per tree -- identified by the addresses of
  * `child` and `data`, `capacity` and the row format; up to four trees, least recently used out -- the packed re-layout of
  * mnv_accel_create, built on the caller's stream at the first call (tens of milliseconds, once) and used for every later plain frame
- * (no trackers, no visit marks: those always walk the arrays).  Frames are bit-identical either way.
+ * -- with the refinement trackers as well (the reference passes both tensors with every call, cuda_renderer.cpp:141-142; sample counts from
+ * the call's view); only frames that ask for visit marks walk the arrays.  Frames and tracker rows are bit-identical either way.
  *   THE RULE: after changing the contents of a cached tree's arrays in place, call mnv_tree_invalidate(child) (NULL: every tree) before the
  *   next frame; a tree that moved or grew (other addresses, other capacity) is a new tree by itself.  Both calls wait for the device.
  *   FREEING a cached tree's arrays counts as changing them: an allocator that hands the same addresses to the next tree of the same

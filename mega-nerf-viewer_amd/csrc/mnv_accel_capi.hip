@@ -585,11 +585,21 @@ static int guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv
 
 namespace mnv {
 int render_accel_for_tree(const mnv_accel *accel, const mnv_tree_view *tree, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
-                          const mnv_frame_inputs *inputs, float *rgba_out, uint8_t *rgba8_out, hipStream_t stream) {
+                          const mnv_frame_inputs *inputs, float *rgba_out, uint8_t *rgba8_out, float *split_track, float *sample_track,
+                          hipStream_t stream) {
     float xform[6];
     std::memcpy(xform, tree->offset, sizeof(tree->offset));
     std::memcpy(xform + 3, tree->scale, sizeof(tree->scale));
     const mnv_partition whole = {0, 1, 0, 0, 0};
-    return render_accel(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, nullptr, (void *)stream, inputs, xform);
+    if (!split_track && !sample_track) return render_accel(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, nullptr, (void *)stream, inputs, xform);
+    // with the refinement trackers (the reference passes them with every call, cuda_renderer.cpp:141-142): the tracker instantiation of the
+    // tuned kernel, the voxels' sample counts from the CALL's view
+    AccelTrack track = {};
+    track.split_track = split_track;
+    track.sample_track = sample_track;
+    track.sample_counts = tree->sample_counts;
+    track.max_depth = opt->max_depth;
+    track.max_sample_count = opt->max_sample_count;
+    return render_accel(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, &track, (void *)stream, inputs, xform);
 }
 }  // namespace mnv

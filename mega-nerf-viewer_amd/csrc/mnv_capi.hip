@@ -318,10 +318,12 @@ int mnv_render_voxels_ex(const mnv_tree_view *tree, const mnv_camera *cam, const
     if (rc) return rc;
     if (track_visit && !visited) return set_error(MNV_E_INVALID, "track_visit set but visited is null");
     hipStream_t stream = (hipStream_t)hip_stream;
-    if (g_cache_on.load(std::memory_order_relaxed) && tree->N == 2 && !split_track && !sample_track && !track_visit) {
-        // plain frames of a tree this process has seen before run on the packed re-layout kept from that call (mnv_set_tree_cache)
+    if (g_cache_on.load(std::memory_order_relaxed) && tree->N == 2 && !track_visit) {
+        // frames of a tree this process has seen before run on the packed re-layout kept from that call (mnv_set_tree_cache) -- with the
+        // refinement trackers as well (the reference passes them with every call); visit marks need the parent array and walk the arrays
         std::lock_guard<std::mutex> lk(g_cache_mu);
-        if (const mnv_accel *a = cached_accel(tree, stream)) return render_accel_for_tree(a, tree, cam, opt, tile, inputs, rgba_out, rgba8_out, stream);
+        if (const mnv_accel *a = cached_accel(tree, stream))
+            return render_accel_for_tree(a, tree, cam, opt, tile, inputs, rgba_out, rgba8_out, split_track, sample_track, stream);
     }
     P.max_depth = opt->max_depth;
     P.max_sample_count = opt->max_sample_count;

@@ -26,9 +26,10 @@ int launch_background(const FrameParams &P, hipStream_t stream);
 int accel_apply_prune(mnv_accel *a, const int32_t *parent, const uint16_t *data, int32_t data_dim, const uint8_t *to_delete, const int32_t *shifts,
                       int32_t old_capacity, int32_t n_deleted, hipStream_t stream);
 
-// a plain frame on `accel` with the offset / scale of the caller's tree view (the accel's arrays are what was cached; the transform is the call's)
+// a frame (plain, or with the refinement trackers) on `accel` with the offset / scale of the caller's tree view (the accel's arrays are what was cached; the transform is the call's)
 int render_accel_for_tree(const mnv_accel *accel, const mnv_tree_view *tree, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
-                          const mnv_frame_inputs *inputs, float *rgba_out, uint8_t *rgba8_out, hipStream_t stream);
+                          const mnv_frame_inputs *inputs, float *rgba_out, uint8_t *rgba8_out, float *split_track, float *sample_track,
+                          hipStream_t stream);
 
 // event-based timing of the render launches (mnv_set_timing / mnv_take_timing)
 struct LaunchTimer {

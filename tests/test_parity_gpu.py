@@ -813,7 +813,7 @@ def test_tree_cache_of_the_stateless_entry_point(mnv, orc, torch_gpu):
     """mnv_set_tree_cache(1): mnv_render_voxels -- the literal replacement of viewer::render_voxels (renderer_kernel.hpp:23-34), arrays
     handed over with every call -- keeps the packed re-layout of the trees it has seen.  Frames are bit-identical to the stateless
     path and to the oracle; an in-place edit of the arrays shows up after mnv_tree_invalidate (and, by the rule in include/mnv.h, not
-    before); frames with trackers still walk the arrays; five trees through four cache entries."""
+    before); frames with trackers run on the re-layout too, frames with visit marks walk the arrays; five trees through four cache entries."""
     torch = torch_gpu
     names = ["sh9_d7_aniso", "rgba_d5", "sh4_d6", "shell_d7_sh9", "cfg1_sh1_d4"]
     trees, views, cams, opts, refs = [], [], [], [], []
@@ -833,11 +833,20 @@ def test_tree_cache_of_the_stateless_entry_point(mnv, orc, torch_gpu):
                 torch.cuda.synchronize()
                 assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(refs[i])), (names[i], rnd)
         out = torch.empty((cams[0].height, cams[0].width, 4), dtype=torch.float32, device="cuda")
-        # frames with trackers take the walking kernel whatever the switch says
+        # frames with trackers run on the kept re-layout as well (its tracker instantiation): rows equal to the oracle's; visit marks walk
         split = torch.full((cams[0].height, cams[0].width, 3), -1.0, dtype=torch.float32, device="cuda")
-        mnv.render_voxels(views[0], cams[0], opts[0], rgba=out, split_track=split)
+        sample = torch.full((cams[0].height, cams[0].width, 3), -1.0, dtype=torch.float32, device="cuda")
+        opts[0].max_depth, opts[0].max_sample_count = 5, 9
+        want_t = orc.render(orc.tree_from_view(trees[0].host_view()), cams[0].c, opts[0], want_trackers=True)
+        mnv.render_voxels(views[0], cams[0], opts[0], rgba=out, split_track=split, sample_track=sample)
         torch.cuda.synchronize()
         assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(refs[0])) and bool((split[..., 1] >= 0).any())
+        assert np.array_equal(split.cpu().numpy(), want_t["split"]) and np.array_equal(sample.cpu().numpy(), want_t["sample"])
+        visited = torch.zeros(views[0].capacity, dtype=torch.int32, device="cuda")
+        split.fill_(-1.0)
+        mnv.render_voxels(views[0], cams[0], opts[0], rgba=out, split_track=split, visited=visited, track_visit=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(split.cpu().numpy(), want_t["split"]) and int(visited.sum().item()) > 0
         # an in-place edit of the arrays (the caller's own device copies here): every sigma set to zero -> an empty picture, but only
         # once the cache has been told (include/mnv.h: THE RULE)
         h_data, h_child, _ = trees[0].host_arrays()
