@@ -151,6 +151,61 @@ def test_random_scene_bit_exact(mnv, orc, torch_gpu, seed):
         assert np.array_equal(sample.cpu().numpy().reshape(-1, 3), ref["sample"].reshape(-1, 3)), f"{who}: sample tracker; {what}"
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_deep_scene_bit_exact(mnv, orc, torch_gpu, seed):
+    """Random trees DEEP enough to carry brick records (depth 10 - 12 under a level-8 grid: leaves two to four levels below it, node words
+    below the records) and mostly empty, so that rays reach those levels -- random row formats, cameras, options, a negative sigma_thresh
+    now and then (the launch then takes the node words), on-screen inputs on every third: the tuned kernel against the oracle bit for bit."""
+    torch = torch_gpu
+    spec, rng = _scene(7000 + seed)
+    basis = int(rng.choice([-1, 1, 4, 9]))
+    spec["tree"].update(depth=int(rng.integers(10, 13)), basis_dim=basis, refine_prob=float(rng.uniform(0.38, 0.43)), empty_prob=float(rng.uniform(0.88, 0.95)),
+                        sigma_max=float(10 ** rng.uniform(1.0, 2.0)))
+    spec["tree"].pop("fmt", None)
+    if basis == -1:
+        spec["tree"]["fmt"] = 0
+    spec["options"].pop("rot_dirs", None)
+    spec["options"].pop("render_bbox", None)
+    spec["options"].update(basis_minmax=(0, max(basis - 1, 0)), step_size=float(10 ** rng.uniform(-5, -3.5)), stop_thresh=float(10 ** rng.uniform(-4, -2)),
+                           sigma_thresh=-0.25 if seed % 4 == 3 else float(10 ** rng.uniform(-3, -1)))
+    # a camera that looks AT the box from just outside it or from inside: the rays cross the levels the records cover
+    sc, off = np.float32(spec["tree"].get("scale", (0.5, 0.5, 0.5))), np.float32(spec["tree"].get("offset", (0.5, 0.5, 0.5)))
+    box_c, box_r = (0.5 - off) / sc, 0.5 / sc
+    d = rng.normal(size=3)
+    d /= np.linalg.norm(d)
+    center = box_c + d * box_r * float(rng.choice([0.3, 1.2, 2.0]))
+    back = center - (box_c + rng.uniform(-0.2, 0.2, 3) * box_r)
+    w, h = int(rng.integers(96, 256)), int(rng.integers(64, 192))
+    spec["camera"] = dict(width=w, height=h, fx=float(0.5 * w / np.tan(0.5 * np.deg2rad(rng.uniform(40.0, 90.0)))), center=tuple(map(float, center)),
+                          back=tuple(map(float, back / np.linalg.norm(back))), up=spec["camera"]["up"])
+    tree = cases.make_tree(mnv, spec["tree"])
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    v = tree.host_view()
+    h, w = cam.height, cam.width
+    tmax = image = None
+    if seed % 3 == 0:
+        dist = float(np.linalg.norm(np.float64(spec["camera"]["center"])) + 1e-3)
+        tmax = (dist * rng.uniform(0.0, 2.0, size=(h, w))).astype(np.float32)
+        tmax[rng.uniform(size=(h, w)) < 0.25] = np.float32(1e9)
+        image = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    want = orc.render(orc.tree_from_view(v), cam.c, opt, want_rgba8=True, tmax_px=tmax, rgba8_init=image)
+    what = f"deep scene {seed}: {spec}, {v.capacity} chunks, steps/ray {want['counters'].steps / max(1, want['counters'].rays):.1f}, levels/step {want['counters'].levels / max(1, want['counters'].steps):.1f}"
+    tree.move_to_device()
+    info = mnv.accel_info(tree.accel)
+    assert info["brick_levels"] == 2, (info, spec["tree"])
+    assert want["counters"].steps > 2 * want["counters"].rays and want["counters"].levels > 1.5 * want["counters"].steps, what
+    rgba = torch.full((h, w, 4), float("nan"), dtype=torch.float32, device="cuda")
+    rgba8 = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    mnv.render_voxels_accel(tree.accel, cam, opt, rgba=rgba, rgba8=rgba8, tmax_px=None if tmax is None else torch.from_numpy(tmax).cuda(),
+                            rgba8_init=None if image is None else torch.from_numpy(image).cuda())
+    torch.cuda.synchronize()
+    got = rgba.cpu().numpy()
+    assert not np.isnan(got).any(), what
+    assert np.array_equal(cases.bits(got), cases.bits(want["rgba"])), f"{int((cases.bits(got) != cases.bits(want['rgba'])).any(axis=-1).sum())} pixels differ; {what}"
+    assert np.array_equal(rgba8.cpu().numpy(), want["rgba8"]), what
+
+
 @pytest.mark.parametrize("seed", range(80))
 def test_random_scene_guided_samples_bit_exact(mnv, orc, torch_gpu, seed):
     """The sample-emitting march (rt_core.cuh:418-576) of both kernels on the same kind of scene: counts, sample rows (z, world position,
