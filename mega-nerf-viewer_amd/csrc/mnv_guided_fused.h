@@ -442,11 +442,13 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                         }
                     };
                     octaves(0, S.pos_octaves, p);
-                    if (S.need_viewdir) octaves(S.n_pos, S.dir_octaves, d);
-                    const int emb_base = S.n_pos + S.n_dir;
+                    if (S.need_viewdir) octaves(S.dir_base, S.dir_octaves, d);  // (every block starts at a multiple of 16 slots: mnv_mlp.h)
                     if (part == 0) {
-                        for (int j = 0; j < S.embedding_dim; ++j) put(emb_base + j, half_bits_to_float(emb[j]));
-                        for (int f = S.in_dim; f < 32 * NKK0; ++f) put(f, 0.f);  // padding features: finite (their weights are zero)
+                        for (int j = 0; j < S.embedding_dim; ++j) put(S.emb_base + j, half_bits_to_float(emb[j]));
+                        // gaps and padding: finite (their weights are zero)
+                        for (int f = S.n_pos; f < S.dir_base; ++f) put(f, 0.f);
+                        for (int f = S.dir_base + S.n_dir; f < S.emb_base; ++f) put(f, 0.f);
+                        for (int f = S.k_slots; f < 32 * NKK0; ++f) put(f, 0.f);
                     }
                     __builtin_amdgcn_wave_barrier();
                 }

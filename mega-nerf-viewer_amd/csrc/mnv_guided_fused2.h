@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                             if (lane < kF2Cols) tile_h[(f >> 5) * (32 * kF2Cols) + lane * 32 + ((r & 15) >> 2) * 8 + (r >> 4) * 4 + (r & 3)] = (_Float16)v;
                         };
                         if (S.need_viewdir) {
-                            const int base = S.n_pos;
+                            const int base = S.dir_base;  // (every block starts at a multiple of 16 slots: mnv_mlp.h)
 #pragma unroll
                             for (int i = 0; i < 3; ++i) put(base + i, d[i]);
                             for (int k = 0; k < S.dir_octaves; ++k) {
@@ -1084,8 +1084,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                             int idx = (int)(float)F.appearance_embedding;
                             idx = idx < 0 ? 0 : (idx >= S.n_embeddings ? S.n_embeddings - 1 : idx);
                             const uint16_t *emb = F.embeddings + ((size_t)c_star * S.n_embeddings + idx) * S.embedding_dim;
-                            const int emb_base = S.n_pos + S.n_dir;
-                            for (int j = 0; j < S.embedding_dim; ++j) put(emb_base + j, half_bits_to_float(emb[j]));
+                            for (int j = 0; j < S.embedding_dim; ++j) put(S.emb_base + j, half_bits_to_float(emb[j]));
                         }
                     }
                     __builtin_amdgcn_wave_barrier();

@@ -16,7 +16,7 @@ using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kRowsPerPass = 256;   // 4 wavefronts x 64 rows
-constexpr int kPasses = 8;          // passes of one workgroup over rows of the same cluster: the weights are staged once per 2048 rows
+constexpr int kPasses = 32;         // passes of 256 rows of one workgroup over rows of the same cluster: the weights are staged once per 8192 rows at most
 constexpr int kRowsPerBlock = kRowsPerPass * kPasses;
 constexpr int kNT = 4;              // 16-row MFMA column tiles per wavefront
 constexpr int kMaxClusters = 1024;
@@ -25,7 +25,11 @@ struct MlpShape {
     int32_t n_clusters, pos_octaves, dir_octaves, need_viewdir, n_embeddings, embedding_dim;
     int32_t hidden_width, hidden_layers, out_dim;
     int32_t in_dim, n_pos, n_dir;   // encoded widths
-    int32_t nkk0;                   // K tiles (32) of the first layer
+    // K slots of the first layer (round 5): the position block, the direction block and the embedding each START at a multiple of 16 -- a half K
+    // tile never mixes blocks, so that every block's features sit at compile-time places of its half tiles (slot_of_feature / feature_of_slot;
+    // the gaps carry zero weights).  The parameter blob keeps the plain feature order.
+    int32_t dir_base, emb_base, k_slots;
+    int32_t nkk0;                   // K tiles (32) of the first layer: ceil(k_slots / 32)
     int32_t mt_hidden, mt_out;      // M tiles (16) of hidden / output layers
     int32_t frag_halfs;             // per cluster: all weight fragments
     int32_t bias_floats;            // per cluster: all biases, padded per layer
@@ -46,8 +50,14 @@ struct mnv_mlp {
 
 namespace mnv {
 
-// input feature handled by K slot e of lane group g in K tile kk (see the header comment)
+// K slot of the first layer handled by element e of lane group g in K tile kk (see the header comment)
 __host__ __device__ inline int slot_feature(int kk, int g, int e) { return 32 * kk + 16 * (e >> 2) + 4 * g + (e & 3); }
+// ... and the input feature that lives in K slot s of the first layer (-1: a gap or padding -- zero weights)
+__host__ __device__ inline int feature_of_slot(const MlpShape &S, int s) {
+    if (s < S.dir_base) return s < S.n_pos ? s : -1;
+    if (s < S.emb_base) return s - S.dir_base < S.n_dir ? S.n_pos + (s - S.dir_base) : -1;
+    return s - S.emb_base < S.embedding_dim ? S.n_pos + S.n_dir + (s - S.emb_base) : -1;
+}
 
 __host__ __device__ inline float tri_wave(float t) {
     const float r = t - floorf(t + 0.5f);

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cstring>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "mnv_internal.h"
@@ -44,7 +45,24 @@ struct MlpLaunch {
     const int32_t *seg_start;   // [n_clusters + 1]: first position of each cluster in `order`
     const int32_t *tile_start;  // [n_clusters + 1]: first tile (workgroup) of each cluster; [n_clusters] = number of tiles
     int32_t rows_per_block;     // rows of one cluster a workgroup takes (a multiple of kRowsPerPass, at most kRowsPerBlock)
+#ifdef MNV_MLP_CLOCKS
+    unsigned long long *clocks;  // measurement variant (tools/mlp_clocks.sh): summed s_memtime per phase of wavefront 0 of every workgroup
+#endif
 };
+
+// Phase clocks of the measurement variant; nothing in the shipped build.
+#ifdef MNV_MLP_CLOCKS
+#define MLP_CLOCK(i)                                                    \
+    do {                                                                \
+        const unsigned long long now_ = __builtin_readcyclecounter();   \
+        clk_[i] += now_ - clk_t_;                                       \
+        clk_t_ = now_;                                                  \
+    } while (0)
+#else
+#define MLP_CLOCK(i) \
+    do {             \
+    } while (0)
+#endif
 
 // ---------------------------------------------------------------- counting sort by cluster
 
@@ -52,25 +70,12 @@ struct MlpLaunch {
 constexpr int kSortItems = 8;
 constexpr int kSortRows = 256 * kSortItems;
 
-// Wavefront-aggregated add of 1 to s_bins[c] for every active lane: one LDS atomic per distinct bin in the
-// wavefront instead of one per lane (neighbouring samples mostly share a cluster).  Returns the lane's rank
-// among the block's rows of its bin.
-__device__ inline int aggregated_rank(int32_t *s_bins, int c, bool valid) {
-    int rank = 0;
-    unsigned long long todo = __ballot(valid);
-    const unsigned lane = threadIdx.x & 63;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int c0 = __shfl(c, leader);
-        const unsigned long long same = __ballot(valid && c == c0);
-        int base = 0;
-        if ((int)lane == leader) base = atomicAdd(&s_bins[c0], __popcll(same));
-        base = __shfl(base, leader);
-        if (valid && c == c0) rank = base + __popcll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
-    }
-    return rank;
-}
+// Rank of every row among the block's rows of its bin: one LDS atomic per row.  (Until round 5 a wavefront-aggregated form -- one atomic per
+// distinct bin of the wavefront, found by a ballot / shuffle loop: cheaper when neighbouring rows share a bin, but the loop runs once per
+// distinct bin, and on incoherent rows -- the profile's 8 random clusters -- that was eight trips of ten instructions per row against one
+// ds_add_rtn whose same-address lanes the LDS serialises by itself.)  The order of rows within a bin is whatever the LDS makes it: rows are
+// independent columns of the matrix products, their results do not depend on their place.
+__device__ inline int rank_in_bin(int32_t *s_bins, int c, bool valid) { return valid ? atomicAdd(&s_bins[c], 1) : 0; }
 
 __global__ __launch_bounds__(256) void mlp_histogram(const int16_t *__restrict__ cluster, int64_t n, int32_t n_clusters,
                                                      int32_t *__restrict__ counts, float *__restrict__ results, int32_t result_stride,
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(256) void mlp_histogram(const int16_t *__restrict__
         const int64_t i = base + k * 256 + threadIdx.x;
         const int c = i < n ? cluster[i] : -1;
         const bool valid = c >= 0 && c < n_clusters;
-        (void)aggregated_rank(s_bins, c, valid);
+        if (valid) atomicAdd(&s_bins[c], 1);
         if (i < n && !valid)
             for (int o = 0; o < out_dim; ++o) results[i * result_stride + o] = 0.f;  // no sub-module: zeros
     }
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void mlp_scatter(const int16_t *__restrict__ c
         const int c = i < n ? cluster[i] : -1;
         const bool valid = c >= 0 && c < n_clusters;
         bin[k] = valid ? c : -1;
-        rank[k] = aggregated_rank(s_bins, c, valid);
+        rank[k] = rank_in_bin(s_bins, c, valid);
     }
     __syncthreads();
     // one global reservation per bin and block; s_bins becomes the block's base position
@@ -152,11 +157,20 @@ __global__ __launch_bounds__(256) void mlp_scatter(const int16_t *__restrict__ c
 // port) feeds FOUR 16-cycle MFMAs instead of two, so the port is busy half as long as the matrix pipes instead of as long; 128 accumulator
 // + 64 operand registers at two wavefronts per SIMD (256-register budget), 512 rows per pass.  Its encode tiles hold HALF a K tile (16
 // features: 2 KB per wavefront, written and read twice per K tile) -- with whole tiles the 131 KB of weights + 32 KB would not fit a CU.
-template <int MT, int NT, int WAVES>  // hidden width = 16 * MT
+template <int... I, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {  // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+template <int MT, int NT, int WAVES, int NKK0>  // hidden width = 16 * MT; NKK0: K tiles of the first layer, 1 .. 4, or 0 for "S.nkk0, any"
 __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forward_kernel(const MlpLaunch L) {
     constexpr int ROWS = WAVES * 16 * NT;  // rows of one pass of the workgroup
-    constexpr bool HALF = NT * 16 == 64 && WAVES == 8;  // half-K-tile encode tiles
-    static_assert(ROWS % kRowsPerPass == 0, "a pass is a multiple of 256 rows");
+    constexpr int OWN = (16 * NT + 63) / 64;  // samples a lane encodes: lane + 64 o
+    static_assert(ROWS % kRowsPerPass == 0 && (16 * NT) % 64 == 0, "a pass is a multiple of 256 rows, a wavefront's columns a multiple of its lanes");
     constexpr int COLS = 16 * NT;  // samples (MFMA columns) of one wavefront
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const MlpShape &S = L.S;
@@ -169,6 +183,9 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
         else hi = mid;
     }
     const int cluster = lo;
+#ifdef MNV_MLP_CLOCKS
+    unsigned long long clk_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, clk_t_ = __builtin_readcyclecounter();
+#endif
     const int block_first = L.seg_start[cluster] + ((int)blockIdx.x - L.tile_start[cluster]) * L.rows_per_block;
     const int block_rows = min(L.rows_per_block, L.seg_start[cluster + 1] - block_first);
 
@@ -176,247 +193,368 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
     const half8 *s_frag = reinterpret_cast<const half8 *>(lds);
     const float *s_bias = reinterpret_cast<const float *>(lds + (size_t)S.frag_halfs * 2);
     {
+        // (eight 16-byte loads in flight per thread: one load per trip of a plain copy loop costs a trip to the L2 each -- 18 trips for 147 KB)
         const uint4 *src = reinterpret_cast<const uint4 *>(L.frags + (size_t)cluster * S.frag_halfs);
         uint4 *dst = reinterpret_cast<uint4 *>(lds);
-        for (int i = threadIdx.x; i < S.frag_halfs / 8; i += blockDim.x) dst[i] = src[i];
+        const int n16 = S.frag_halfs / 8;
+        int i0 = threadIdx.x;
+        for (; i0 + 7 * 64 * WAVES < n16; i0 += 8 * 64 * WAVES) {
+            uint4 t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = src[i0 + k * 64 * WAVES];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dst[i0 + k * 64 * WAVES] = t[k];
+        }
+        for (; i0 < n16; i0 += 64 * WAVES) dst[i0] = src[i0];
         const float *bsrc = L.biases + (size_t)cluster * S.bias_floats;
         float *bdst = reinterpret_cast<float *>(lds + (size_t)S.frag_halfs * 2);
         for (int i = threadIdx.x; i < S.bias_floats; i += blockDim.x) bdst[i] = bsrc[i];
     }
     __syncthreads();
+    MLP_CLOCK(0);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, col = lane & 15;
-    // the wavefront's encode tile: one K tile (32 features) of its COLS samples, a sample's 64 bytes in operand order (the 8 halfs of
-    // lane group gg at byte 16 gg: features 4 gg .. 4 gg + 3 and 16 + 4 gg .. 16 + 4 gg + 3): written as four 16-byte stores by the
-    // lane that owns the sample, read as one 16-byte load per column tile by the lane that feeds the matrix pipe
-    uint4 *s_enc = reinterpret_cast<uint4 *>(lds + (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4) + wave * (COLS * (HALF ? 2 : 4));
-    [[maybe_unused]] uint2 *s_enc2 = reinterpret_cast<uint2 *>(s_enc);  // HALF: a sample's 32 bytes = four lane groups x 8 bytes (features 4 gg .. 4 gg + 3 of the half)
-    const int emb_base = S.n_pos + S.n_dir;
+    // the wavefront's encode tile: HALF a K tile (16 features) of its COLS samples, a sample's 32 bytes = four lane groups x 8 bytes (features
+    // 4 gg .. 4 gg + 3 of the half): written as four 8-byte stores by the lane that owns the sample, read as one 8-byte load per column tile
+    // and half by the lane that feeds the matrix pipe (whole K tiles of the 512-row kernels would not fit a CU beside 131 KB of weights)
+    uint2 *s_enc2 = reinterpret_cast<uint2 *>(lds + (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4) + wave * (COLS * 4);
 
-    for (int pass_first = 0; pass_first < block_rows; pass_first += ROWS) {
+    // Rows and samples of a pass are fetched DURING the pass before it (a row index from `order`, then that row's three to seven floats: two trips
+    // to memory in a row, 17 % of a wavefront's time when they opened each pass): the indices while the pass encodes, the floats while its
+    // layers run.  Two roles per lane.  Encoding: lane j owns sample j of the wavefront.  Matrix operand / output: lane (g, col) serves the
+    // samples col + 16 nt.  The store: lane l writes 16 bytes (features 4 (l & 3) .. + 3 of an M tile) of sample (l >> 2) + 16 nt -- four
+    // neighbouring lanes cover 64 contiguous bytes of one result row (the accumulators' own layout would send 64 separate 4-byte writes
+    // per instruction).
+    int32_t dst_row_next[NT], own_next[OWN];
+    float x_next[OWN][7];
+    auto fetch_rows = [&](int pass_first) __attribute__((always_inline)) {
         const int first = block_first + pass_first, rows = min(ROWS, block_rows - pass_first);
-        // Two roles per lane.  Encoding: lane j < COLS owns sample j of the wavefront.  Matrix operand / output: lane (g, col) serves the
-        // samples col + 16 nt.
-        int32_t src_row[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int local = wave * COLS + nt * 16 + col;
-            src_row[nt] = local < rows ? L.order[first + local] : -1;
+            const int local = wave * COLS + nt * 16 + (lane >> 2);
+            dst_row_next[nt] = local < rows ? L.order[first + local] : -1;
         }
-        float p[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, 0.f};
-        const uint16_t *emb = nullptr;
-        if (lane < COLS) {
-            const int local = wave * COLS + lane;
-            const float *x = L.samples + (int64_t)L.order[first + (local < rows ? local : 0)] * L.samples_stride;
+#pragma unroll
+        for (int o = 0; o < OWN; ++o) {
+            const int local = wave * COLS + 64 * o + lane;
+            own_next[o] = L.order[first + (local < rows ? local : 0)];
+        }
+    };
+    auto fetch_samples = [&]() __attribute__((always_inline)) {
+        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+        typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+#pragma unroll
+        for (int o = 0; o < OWN; ++o) {
+            const float *x = L.samples + (int64_t)own_next[o] * L.samples_stride;
+            if (S.need_viewdir) {  // six floats of one row: a 16-byte and an 8-byte load (rows are 4-byte aligned)
+                const f4u a = *reinterpret_cast<const f4u *>(x);
+                const f2u c = *reinterpret_cast<const f2u *>(x + 4);
+                x_next[o][0] = a[0], x_next[o][1] = a[1], x_next[o][2] = a[2], x_next[o][3] = a[3], x_next[o][4] = c[0], x_next[o][5] = c[1];
+            } else {
+                const f2u a = *reinterpret_cast<const f2u *>(x);
+                x_next[o][0] = a[0], x_next[o][1] = a[1], x_next[o][2] = x[2];
+                x_next[o][3] = x_next[o][4] = x_next[o][5] = 0.f;
+            }
+            x_next[o][6] = S.n_embeddings > 0 ? x[S.need_viewdir ? 6 : 3] : 0.f;
+        }
+    };
+    fetch_rows(0);
+    fetch_samples();
+
+    for (int pass_first = 0; pass_first < block_rows; pass_first += ROWS) {
+        int32_t dst_row[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) dst_row[nt] = dst_row_next[nt];
+        float p[OWN][3], d[OWN][3];
+        const uint16_t *emb[OWN];
+#pragma unroll
+        for (int o = 0; o < OWN; ++o) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                p[i] = (x[i] - S.center[i]) * S.inv_extent[i];
-                d[i] = S.need_viewdir ? x[3 + i] : 0.f;
+                p[o][i] = (x_next[o][i] - S.center[i]) * S.inv_extent[i];
+                d[o][i] = x_next[o][3 + i];
             }
+            emb[o] = nullptr;
             if (S.n_embeddings > 0) {
-                int idx = (int)x[S.need_viewdir ? 6 : 3];
+                int idx = (int)x_next[o][6];
                 idx = idx < 0 ? 0 : (idx >= S.n_embeddings ? S.n_embeddings - 1 : idx);
-                emb = L.embeddings + ((size_t)cluster * S.n_embeddings + idx) * S.embedding_dim;
+                emb[o] = L.embeddings + ((size_t)cluster * S.n_embeddings + idx) * S.embedding_dim;
             }
         }
-        // Encoding of K tile kk (32 features) of this lane's sample.  Position features -- the bulk -- have compile-time places in the first
-        // three K tiles (coordinate, then per octave three phase-0 and three phase-1/4 triangle waves), guarded per octave by the
-        // network's octave count (wave-uniform) and stored as four 16-byte words; whatever else the tile holds (view direction,
-        // embedding, position features past the 96th) is decoded at run time and stored half by half over the zeros.
+        const bool more = pass_first + ROWS < block_rows;
+        if (more) fetch_rows(pass_first + ROWS);
+        // Encoding of one HALF of a K tile (16 K slots) of this lane's samples into the wavefront's tile.  The position block, the direction
+        // block and the embedding each start at a multiple of 16 slots (mnv_mlp.h), so a half tile holds features of ONE block at
+        // compile-time places: octave, axis and phase of every feature are constants of the code -- seven or eight instructions per feature,
+        // no scalar decoding and no branch (until round 5 the direction block started right behind the position block, at a run-time
+        // slot, and its features went through a decoding loop with a branch each: 40 % of a wavefront's time; a branch-free decoder was
+        // 41 instructions per feature, and at two wavefronts per SIMD every instruction, scalar or not, is four cycles of the wavefront).
+        // The half that holds a block's END masks what lies past it (scalar masks).
         typedef _Float16 half2v __attribute__((ext_vector_type(2)));
         typedef float float2v __attribute__((ext_vector_type(2)));
-        auto pos_feature = [&](auto f_tag) __attribute__((always_inline)) -> float {
-            constexpr int f = decltype(f_tag)::value;
-            if constexpr (f < 3) {
-                return p[f];
-            } else {
-                constexpr int k = (f - 3) / 6, r = (f - 3) % 6, i = r % 3;
-                const float scale = __uint_as_float((uint32_t)(127 + k) << 23);
-                return k < S.pos_octaves ? tri_wave(p[i] * scale + (r >= 3 ? 0.25f : 0.f)) : 0.f;
-            }
-        };
-        auto pair = [&](auto f_tag) __attribute__((always_inline)) -> uint32_t {
-            constexpr int f = decltype(f_tag)::value;
-            const float2v pr = {pos_feature(std::integral_constant<int, f>{}), pos_feature(std::integral_constant<int, f + 1>{})};
+        auto pack2 = [](float x0, float x1) __attribute__((always_inline)) -> uint32_t {
+            const float2v pr = {x0, x1};
             return __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, half2v));
         };
-        auto fast_group = [&](auto kk_tag, auto gg_tag) __attribute__((always_inline)) {
-            constexpr int kk = decltype(kk_tag)::value, gg = decltype(gg_tag)::value, f0 = 32 * kk + 4 * gg;
-            s_enc[lane * 4 + gg] = make_uint4(pair(std::integral_constant<int, f0>{}), pair(std::integral_constant<int, f0 + 2>{}),
-                                              pair(std::integral_constant<int, f0 + 16>{}), pair(std::integral_constant<int, f0 + 18>{}));
+        // feature j of a block over the coordinates x: j < 3 the coordinate, then per octave k three phase-0 and three phase-1/4 triangle waves
+        auto block_feature = [&](const float (&x)[3], auto j_tag) __attribute__((always_inline)) -> float {
+            constexpr int j = decltype(j_tag)::value;
+            if constexpr (j < 3) {
+                return x[j];
+            } else {
+                constexpr int k = (j - 3) / 6, r = (j - 3) % 6, i = r % 3;
+                const float scale = __uint_as_float((uint32_t)(127 + k) << 23);
+                return tri_wave(x[i] * scale + (r >= 3 ? 0.25f : 0.f));
+            }
         };
-        auto fast_tile = [&](auto kk_tag) __attribute__((always_inline)) {
-            fast_group(kk_tag, std::integral_constant<int, 0>{});
-            fast_group(kk_tag, std::integral_constant<int, 1>{});
-            fast_group(kk_tag, std::integral_constant<int, 2>{});
-            fast_group(kk_tag, std::integral_constant<int, 3>{});
+        // features j0 .. j0 + 3 of a block -> 8 bytes of the tile; `masked`: features from n on are zeros (n is wave-uniform)
+        auto block_group = [&](int o, const float (&x)[3], auto j0_tag, int gg, auto masked_tag, int n) __attribute__((always_inline)) {
+            constexpr int j0 = decltype(j0_tag)::value;
+            constexpr bool masked = decltype(masked_tag)::value;
+            uint32_t lo = pack2(block_feature(x, std::integral_constant<int, j0>{}), block_feature(x, std::integral_constant<int, j0 + 1>{}));
+            uint32_t hi = pack2(block_feature(x, std::integral_constant<int, j0 + 2>{}), block_feature(x, std::integral_constant<int, j0 + 3>{}));
+            if constexpr (masked) {
+                lo &= (j0 < n ? 0xffffu : 0u) | (j0 + 1 < n ? 0xffff0000u : 0u);
+                hi &= (j0 + 2 < n ? 0xffffu : 0u) | (j0 + 3 < n ? 0xffff0000u : 0u);
+            }
+            s_enc2[(64 * o + lane) * 4 + gg] = make_uint2(lo, hi);
         };
-        auto encode_tile = [&](int kk) __attribute__((always_inline)) {  // kk is wave-uniform
-            if (lane < COLS) {
-                int f_lo;  // the first feature of the tile the wide stores did not produce
-                if (kk == 0) {
-                    fast_tile(std::integral_constant<int, 0>{});
-                    f_lo = S.n_pos;
-                } else if (kk == 1) {
-                    fast_tile(std::integral_constant<int, 1>{});
-                    f_lo = S.n_pos;
-                } else if (kk == 2) {
-                    fast_tile(std::integral_constant<int, 2>{});
-                    f_lo = S.n_pos;
-                } else {
+        auto block_half = [&](int o, const float (&x)[3], auto m_tag, int n) __attribute__((always_inline)) {  // features 16 m .. 16 m + 15 of a block of n
+            constexpr int m = decltype(m_tag)::value;
+            if (16 * m + 16 <= n) {
+                block_group(o, x, std::integral_constant<int, 16 * m>{}, 0, std::false_type{}, n);
+                block_group(o, x, std::integral_constant<int, 16 * m + 4>{}, 1, std::false_type{}, n);
+                block_group(o, x, std::integral_constant<int, 16 * m + 8>{}, 2, std::false_type{}, n);
+                block_group(o, x, std::integral_constant<int, 16 * m + 12>{}, 3, std::false_type{}, n);
+            } else {
+                block_group(o, x, std::integral_constant<int, 16 * m>{}, 0, std::true_type{}, n);
+                block_group(o, x, std::integral_constant<int, 16 * m + 4>{}, 1, std::true_type{}, n);
+                block_group(o, x, std::integral_constant<int, 16 * m + 8>{}, 2, std::true_type{}, n);
+                block_group(o, x, std::integral_constant<int, 16 * m + 12>{}, 3, std::true_type{}, n);
+            }
+        };
+        // half m of a block, m wave-uniform and at most `last` (a block of 16 octaves is 99 features: seven halves)
+        auto block_half_of = [&](int o, const float (&x)[3], int m, auto last_tag, int n) __attribute__((always_inline)) {
+            constexpr int last = decltype(last_tag)::value < 6 ? decltype(last_tag)::value : 6;
+            if (m == 0 || last == 0) {
+                block_half(o, x, std::integral_constant<int, 0>{}, n);
+            } else if (m == 1 || last == 1) {
+                if constexpr (last >= 1) block_half(o, x, std::integral_constant<int, 1>{}, n);
+            } else if (m == 2 || last == 2) {
+                if constexpr (last >= 2) block_half(o, x, std::integral_constant<int, 2>{}, n);
+            } else if (m == 3 || last == 3) {
+                if constexpr (last >= 3) block_half(o, x, std::integral_constant<int, 3>{}, n);
+            } else if (m == 4 || last == 4) {
+                if constexpr (last >= 4) block_half(o, x, std::integral_constant<int, 4>{}, n);
+            } else if (m == 5 || last == 5) {
+                if constexpr (last >= 5) block_half(o, x, std::integral_constant<int, 5>{}, n);
+            } else {
+                if constexpr (last >= 6) block_half(o, x, std::integral_constant<int, 6>{}, n);
+            }
+        };
+        // one half tile; static_tag: the half tile as a compile-time constant, or -1 (the K-outer loop of the kernels without a compile-time
+        // tile count: p and d then pass through an empty statement per trip -- as invariants of that loop every feature, a function of p or
+        // d alone, would be computed before it and held in registers)
+        auto encode_half = [&](int half_tile, auto static_tag) __attribute__((always_inline)) {
+            constexpr int T = decltype(static_tag)::value;
+            const int pos_halves = S.dir_base >> 4, dir_halves = (S.emb_base - S.dir_base) >> 4;
 #pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) s_enc[lane * 4 + gg] = make_uint4(0u, 0u, 0u, 0u);
-                    f_lo = 32 * kk;
-                }
-                f_lo = f_lo > 32 * kk ? f_lo : 32 * kk;
-                const int f_hi = S.in_dim < 32 * kk + 32 ? S.in_dim : 32 * kk + 32;
-                _Float16 *tile_h = reinterpret_cast<_Float16 *>(s_enc);
-                for (int f = f_lo; f < f_hi; ++f) {  // wave-uniform bounds
-                    const float v = (f >= emb_base) ? half_bits_to_float(emb[f - emb_base]) : encode_feature(S, f, p, d);
-                    const int r = f & 31;
-                    tile_h[lane * 32 + ((r & 15) >> 2) * 8 + (r >> 4) * 4 + (r & 3)] = (_Float16)v;
+            for (int o = 0; o < OWN; ++o) {
+                float xp[3] = {p[o][0], p[o][1], p[o][2]}, xd[3] = {d[o][0], d[o][1], d[o][2]};
+                if constexpr (T < 0) asm volatile("" : "+v"(xp[0]), "+v"(xp[1]), "+v"(xp[2]), "+v"(xd[0]), "+v"(xd[1]), "+v"(xd[2]));
+                if (half_tile < pos_halves) {
+                    if constexpr (T >= 0 && T <= 6) block_half(o, xp, std::integral_constant<int, (T >= 0 && T <= 6) ? T : 0>{}, S.n_pos);
+                    else if constexpr (T < 0) block_half_of(o, xp, half_tile, std::integral_constant<int, 6>{}, S.n_pos);
+                } else if (half_tile - pos_halves < dir_halves) {
+                    block_half_of(o, xd, half_tile - pos_halves, std::integral_constant<int, T < 0 ? 6 : T>{}, S.n_dir);
+                } else {  // the embedding (copied slot by slot) and the padding behind it
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) s_enc2[(64 * o + lane) * 4 + gg] = make_uint2(0u, 0u);
+                    _Float16 *tile_h = reinterpret_cast<_Float16 *>(s_enc2);
+                    const int e_lo = 16 * half_tile - S.emb_base, e_hi = S.embedding_dim < e_lo + 16 ? S.embedding_dim : e_lo + 16;
+                    for (int e = e_lo; e < e_hi; ++e) tile_h[(64 * o + lane) * 16 + (e & 15)] = (_Float16)half_bits_to_float(emb[o][e]);
                 }
             }
             __builtin_amdgcn_wave_barrier();  // LDS executes a wavefront's accesses in order; this only pins the compiler's order
         };
 
-        // HALF: the same features, one half of the K tile (16 features) at a time into a tile half the size
-        [[maybe_unused]] auto fast_half_group = [&](auto kk_tag, auto h_tag, auto gg_tag) __attribute__((always_inline)) {
-            constexpr int kk = decltype(kk_tag)::value, h = decltype(h_tag)::value, gg = decltype(gg_tag)::value, f0 = 32 * kk + 16 * h + 4 * gg;
-            s_enc2[lane * 4 + gg] = make_uint2(pair(std::integral_constant<int, f0>{}), pair(std::integral_constant<int, f0 + 2>{}));
-        };
-        [[maybe_unused]] auto fast_half = [&](auto kk_tag, auto h_tag) __attribute__((always_inline)) {
-            fast_half_group(kk_tag, h_tag, std::integral_constant<int, 0>{});
-            fast_half_group(kk_tag, h_tag, std::integral_constant<int, 1>{});
-            fast_half_group(kk_tag, h_tag, std::integral_constant<int, 2>{});
-            fast_half_group(kk_tag, h_tag, std::integral_constant<int, 3>{});
-        };
-        [[maybe_unused]] auto encode_half = [&](int kk, auto h_tag) __attribute__((always_inline)) {  // kk is wave-uniform
-            constexpr int h = decltype(h_tag)::value;
-            if (lane < COLS) {
-                int f_lo;
-                if (kk == 0) {
-                    fast_half(std::integral_constant<int, 0>{}, h_tag);
-                    f_lo = S.n_pos;
-                } else if (kk == 1) {
-                    fast_half(std::integral_constant<int, 1>{}, h_tag);
-                    f_lo = S.n_pos;
-                } else if (kk == 2) {
-                    fast_half(std::integral_constant<int, 2>{}, h_tag);
-                    f_lo = S.n_pos;
-                } else {
-#pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) s_enc2[lane * 4 + gg] = make_uint2(0u, 0u);
-                    f_lo = 32 * kk;
-                }
-                const int h_lo = 32 * kk + 16 * h, h_hi = h_lo + 16;
-                f_lo = f_lo > h_lo ? f_lo : h_lo;
-                const int f_hi = S.in_dim < h_hi ? S.in_dim : h_hi;
-                _Float16 *tile_h = reinterpret_cast<_Float16 *>(s_enc2);
-                for (int f = f_lo; f < f_hi; ++f) {  // wave-uniform bounds
-                    const float v = (f >= emb_base) ? half_bits_to_float(emb[f - emb_base]) : encode_feature(S, f, p, d);
-                    const int r = f & 15;
-                    tile_h[lane * 16 + (r >> 2) * 4 + (r & 3)] = (_Float16)v;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        };
-
-        f32x4 acc[MT][NT];
-        const half8 *w = s_frag;
-        const float *b = s_bias;
+        // (the weights in LDS do not change between passes and the compiler knows: it would read the first layer's fragments and biases once,
+        // before the pass loop, and hold them in 64 registers the hidden layers need -- the empty statement hides that the offset is the same;
+        // an offset, not the pointers: hidden themselves they would stop being LDS pointers, and their loads become flat loads)
+        int same_place = 0;
+        asm volatile("" : "+s"(same_place));
+        const half8 *w = s_frag + same_place;
+        const float *b = s_bias + same_place;
         auto bias_tile = [&](int mt) __attribute__((always_inline)) -> f32x4 { return *reinterpret_cast<const f32x4 *>(b + 16 * mt + 4 * g); };
 
-        // ---- layer 0: B fragments are computed from the raw sample on the fly, one K tile at a time; the bias enters as the C operand
-        //      of the first K tile's MFMAs, and the next M tile's fragment travels under the current one's MFMAs
-        for (int kk = 0; kk < S.nkk0; ++kk) {
-            half8 bf[NT];
-            if constexpr (HALF) {
-                uint2 lo2[NT];
-                encode_half(kk, std::integral_constant<int, 0>{});
+        // A layer with ReLU: the B fragments `bin` (KTIN K tiles x NT column tiles) in, the next layer's B fragments `nb` out.  One M tile (16
+        // output features x COLS samples) at a time over the layer's K tiles, bias as the first MFMA's C operand; a finished PAIR of M tiles
+        // is rounded and packed into the next layer's B fragment straight away (the C layout of two M tiles is the B layout of one K tile:
+        // the permutation is in the weights), so that two accumulator tiles are live instead of MT, and the next M tile's weight fragments
+        // and bias are read while the current one's MFMAs run.
+        constexpr int KT = MT / 2;  // K tiles of a hidden layer
+        auto dense_relu = [&](auto ktin_tag, const auto &bin, half8 (&nb)[KT][NT]) __attribute__((always_inline)) {
+            constexpr int KTIN = decltype(ktin_tag)::value;
+            half8 a[KTIN];
+            f32x4 prev[NT], bv = bias_tile(0);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) lo2[nt] = s_enc2[(nt * 16 + col) * 4 + g];
-                __builtin_amdgcn_wave_barrier();
-                encode_half(kk, std::integral_constant<int, 1>{});
+            for (int kk = 0; kk < KTIN; ++kk) a[kk] = w[kk * 64 + lane];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                half8 an[KTIN];
+                f32x4 bvn = bv;
+                if (mt + 1 < MT) {
+#pragma unroll
+                    for (int kk = 0; kk < KTIN; ++kk) an[kk] = w[((mt + 1) * KTIN + kk) * 64 + lane];
+                    bvn = bias_tile(mt + 1);
+                }
+                f32x4 cur[NT];
+#pragma unroll
+                for (int kk = 0; kk < KTIN; ++kk)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) cur[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk], bin[kk][nt], kk == 0 ? bv : cur[nt], 0, 0, 0);
+                if (mt & 1) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) nb[mt >> 1][nt] = relu_pack(prev[nt], cur[nt]);
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) prev[nt] = cur[nt];
+                }
+                if (mt + 1 < MT) {
+#pragma unroll
+                    for (int kk = 0; kk < KTIN; ++kk) a[kk] = an[kk];
+                    bv = bvn;
+                }
+            }
+            w += MT * KTIN * 64;
+            b += 16 * MT;
+        };
+
+#ifdef MNV_MLP_CLOCKS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        MLP_CLOCK(1);
+        half8 bf[KT][NT];
+        if constexpr (NKK0 > 0) {
+            // ---- layer 0, the first layer's K tiles counted at compile time: ALL its B fragments are encoded first, half a K tile at a time through
+            //      the tile (no accumulator is live yet: the encoding has the registers to itself), then it runs like any other layer
+            half8 bf0[NKK0][NT];
+            uint2 lo2[NT];
+            static_for<2 * NKK0>([&](auto t_tag) __attribute__((always_inline)) {
+                constexpr int T = decltype(t_tag)::value;
+                encode_half(T, t_tag);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const uint2 hi2 = s_enc2[(nt * 16 + col) * 4 + g];
-                    bf[nt] = __builtin_bit_cast(half8, make_uint4(lo2[nt].x, lo2[nt].y, hi2.x, hi2.y));
+                    const uint2 part = s_enc2[(nt * 16 + col) * 4 + g];
+                    if constexpr (T & 1) bf0[T >> 1][nt] = __builtin_bit_cast(half8, make_uint4(lo2[nt].x, lo2[nt].y, part.x, part.y));
+                    else lo2[nt] = part;
                 }
                 __builtin_amdgcn_wave_barrier();
-            } else {
-                encode_tile(kk);
+            });
+            MLP_CLOCK(2);
+            if (more) fetch_samples();
+            dense_relu(std::integral_constant<int, NKK0>{}, bf0, bf);
+            MLP_CLOCK(3);
+        } else {
+            // ---- layer 0 with any number of K tiles (more than four: large embeddings): K tile by K tile into ALL the layer's accumulators, the
+            //      tile's MT weight fragments read before its encoding.  (Registers: the accumulators alone are half the budget of <8, 4, 8>,
+            //      and its encoding spills around them -- the price of the rare shape.)
+            f32x4 acc[MT][NT];
+            half8 a8[MT];
+            uint2 lo2[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bf[nt] = __builtin_bit_cast(half8, s_enc[(nt * 16 + col) * 4 + g]);
-                __builtin_amdgcn_wave_barrier();
+            for (int mt = 0; mt < MT; ++mt) {  // the accumulators start as the bias (as a C operand of the first K tile's MFMAs it would make them
+                const f32x4 bv = bias_tile(mt);  // conditionally defined inside the loop: live, and spilled, from one pass to the next)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bv;
             }
-            half8 a = w[kk * 64 + lane];
-            if (kk == 0) {
+#pragma unroll 1
+            for (int half_tile = 0; half_tile < 2 * S.nkk0; ++half_tile) {
+                if (!(half_tile & 1)) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const half8 a_now = a;
-                    if (mt + 1 < MT) a = w[((mt + 1) * S.nkk0 + kk) * 64 + lane];
-                    const f32x4 bv = bias_tile(mt);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_now, bf[nt], bv, 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt) a8[mt] = w[(mt * S.nkk0 + (half_tile >> 1)) * 64 + lane];
                 }
-            } else {
+                encode_half(half_tile, std::integral_constant<int, -1>{});
+                if (!(half_tile & 1)) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const half8 a_now = a;
-                    if (mt + 1 < MT) a = w[((mt + 1) * S.nkk0 + kk) * 64 + lane];
+                    for (int nt = 0; nt < NT; ++nt) lo2[nt] = s_enc2[(nt * 16 + col) * 4 + g];
+                    __builtin_amdgcn_wave_barrier();
+                } else {
+                    half8 bt[NT];
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_now, bf[nt], acc[mt][nt], 0, 0, 0);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const uint2 hi2 = s_enc2[(nt * 16 + col) * 4 + g];
+                        bt[nt] = __builtin_bit_cast(half8, make_uint4(lo2[nt].x, lo2[nt].y, hi2.x, hi2.y));
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8[mt], bt[nt], acc[mt][nt], 0, 0, 0);
                 }
             }
-        }
-        w += MT * S.nkk0 * 64;
-        b += 16 * MT;
-
-        // ---- hidden layers 1 .. hidden_layers-1 and the output layer: B fragments are the previous accumulators
-        for (int layer = 1; layer <= S.hidden_layers; ++layer) {
-            const int n_mt = layer < S.hidden_layers ? MT : S.mt_out;
-            half8 bf[MT / 2][NT];
+            MLP_CLOCK(2);
+            if (more) fetch_samples();
 #pragma unroll
-            for (int kk = 0; kk < MT / 2; ++kk)
+            for (int kk = 0; kk < KT; ++kk)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bf[kk][nt] = relu_pack(acc[2 * kk][nt], acc[2 * kk + 1][nt]);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (mt < n_mt) {
-                    half8 a = w[(mt * (MT / 2)) * 64 + lane];
-#pragma unroll
-                    for (int kk = 0; kk < MT / 2; ++kk) {
-                        const half8 a_now = a;
-                        if (kk + 1 < MT / 2) a = w[(mt * (MT / 2) + kk + 1) * 64 + lane];
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
-                            if (kk == 0) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_now, bf[0][nt], bias_tile(mt), 0, 0, 0);
-                            else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_now, bf[kk][nt], acc[mt][nt], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-            w += n_mt * (MT / 2) * 64;
-            b += 16 * n_mt;
+            w += MT * S.nkk0 * 64;
+            b += 16 * MT;
+            MLP_CLOCK(3);
         }
 
-        // ---- store: lane holds features 16 mt + 4 g + r of row src_row[nt]
+        // ---- hidden layers 1 .. hidden_layers - 1
+        for (int layer = 1; layer < S.hidden_layers; ++layer) {
+            half8 nb[KT][NT];
+            dense_relu(std::integral_constant<int, KT>{}, bf, nb);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            if (src_row[nt] < 0) continue;
-            float *out = L.results + (int64_t)src_row[nt] * L.result_stride;
+            for (int kk = 0; kk < KT; ++kk)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (mt >= S.mt_out) break;
+                for (int nt = 0; nt < NT; ++nt) bf[kk][nt] = nb[kk][nt];
+        }
+
+        MLP_CLOCK(4);
+        // ---- the output layer: lane (g, col) holds features 16 mt + 4 g + r of sample col + 16 nt; a 1 KB tile in LDS (the encode tile's
+        //      place) turns that into the store's lane order, 16-byte slots swizzled so that neither side meets a bank twice
+        f32x4 *s_out = reinterpret_cast<f32x4 *>(s_enc2);
+        const int slot_w = col * 4 + (g ^ (col >> 2)), slot_r = (lane & ~3) | ((lane & 3) ^ ((lane >> 4) & 3));
+#pragma unroll 1
+        for (int mt = 0; mt < S.mt_out; ++mt) {
+            half8 a[KT];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int f = 16 * mt + 4 * g + r;
-                    if (f < S.out_dim) out[f] = acc[mt][nt][r];
+            for (int kk = 0; kk < KT; ++kk) a[kk] = w[(mt * KT + kk) * 64 + lane];
+            const f32x4 bv = bias_tile(mt);
+            f32x4 cur[NT];
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) cur[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk], bf[kk][nt], kk == 0 ? bv : cur[nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                s_out[slot_w] = cur[nt];
+                __builtin_amdgcn_wave_barrier();
+                const f32x4 v = s_out[slot_r];
+                __builtin_amdgcn_wave_barrier();
+                const int f0 = 16 * mt + 4 * (lane & 3);
+                if (dst_row[nt] < 0 || f0 >= S.out_dim) continue;
+                float *out = L.results + (int64_t)dst_row[nt] * L.result_stride + f0;
+                if (f0 + 3 < S.out_dim) {
+                    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                    *reinterpret_cast<f4u *>(out) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+                        if (f0 + r < S.out_dim) out[r] = v[r];
                 }
             }
         }
+        MLP_CLOCK(5);
     }
+#ifdef MNV_MLP_CLOCKS
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 16; ++i) atomicAdd(&L.clocks[i], clk_[i]);
+#endif
 }
 
 // ---------------------------------------------------------------- host side
@@ -444,7 +582,10 @@ static int fill_shape(MlpShape &S, const mnv_mlp_desc *d) {
     S.n_pos = 3 + 6 * S.pos_octaves;
     S.n_dir = S.need_viewdir ? 3 + 6 * S.dir_octaves : 0;
     S.in_dim = S.n_pos + S.n_dir + S.embedding_dim;
-    S.nkk0 = (S.in_dim + 31) / 32;
+    S.dir_base = (S.n_pos + 15) & ~15;
+    S.emb_base = S.dir_base + ((S.n_dir + 15) & ~15);
+    S.k_slots = S.emb_base + S.embedding_dim;
+    S.nkk0 = (S.k_slots + 31) / 32;
     S.mt_hidden = S.hidden_width / 16;
     S.mt_out = (S.out_dim + 15) / 16;
     const int nkk_h = S.hidden_width / 32;
@@ -529,8 +670,9 @@ int mnv_mlp_create(const mnv_mlp_desc *desc, const uint16_t *params, size_t n_ha
                 for (int kk = 0; kk < nkk; ++kk)
                     for (int lane = 0; lane < 64; ++lane)
                         for (int e = 0; e < 8; ++e) {
-                            const int row = 16 * mt + (lane & 15), k = slot_feature(kk, lane >> 4, e);
-                            f[((size_t)(mt * nkk + kk) * 64 + lane) * 8 + e] = (row < outd && k < in) ? src[(size_t)row * in + k] : 0;
+                            const int row = 16 * mt + (lane & 15), slot = slot_feature(kk, lane >> 4, e);
+                            const int k = layer == 0 ? feature_of_slot(S, slot) : (slot < in ? slot : -1);  // hidden layers: slot = feature
+                            f[((size_t)(mt * nkk + kk) * 64 + lane) * 8 + e] = (row < outd && k >= 0) ? src[(size_t)row * in + k] : 0;
                         }
             for (int i = 0; i < outd; ++i) b[i] = half_to_float_host(src[(size_t)outd * in + i]);
             f += (size_t)n_mt * nkk * 512;
@@ -628,16 +770,49 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
     L.seg_start = seg_start;
     L.tile_start = tile_start;
     L.rows_per_block = rows_per_block;
+#ifdef MNV_MLP_CLOCKS
+    static unsigned long long *clocks = nullptr;
+    if (!clocks) (void)hipMalloc((void **)&clocks, 128);
+    (void)hipMemsetAsync(clocks, 0, 128, stream);
+    L.clocks = clocks;
+#endif
     const size_t lds_bytes = (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4 + 4 * 16 * 64 * 4;  // + the encode tiles: 256 samples x 64 bytes
+    // one kernel per width and per number of K tiles of the first layer (1 .. 4 at compile time; 0: any number -- the large embeddings)
+    auto launch = [&](auto kern, unsigned threads) -> int {
+        int rc2 = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "lds attr");
+        if (rc2) return rc2;
+        hipLaunchKernelGGL(kern, dim3((unsigned)max_tiles), dim3(threads), lds_bytes, stream, L);
+        return MNV_OK;
+    };
     if (S.hidden_width == 64) {
-        auto kern = mlp_forward_kernel<4, 4, 4>;
-        if ((rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "lds attr"))) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)max_tiles), dim3(256), lds_bytes, stream, L);
-    } else {
-        auto kern = mlp_forward_kernel<8, 4, 8>;  // (until round 5 <8, 2, 8>: 32 columns per wavefront, two MFMAs per fragment read)
-        if ((rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "lds attr"))) return rc;
-        hipLaunchKernelGGL(kern, dim3((unsigned)max_tiles), dim3(512), lds_bytes, stream, L);
+        switch (S.nkk0) {
+            case 1: rc = launch(mlp_forward_kernel<4, 4, 4, 1>, 256); break;
+            case 2: rc = launch(mlp_forward_kernel<4, 4, 4, 2>, 256); break;
+            case 3: rc = launch(mlp_forward_kernel<4, 4, 4, 3>, 256); break;
+            case 4: rc = launch(mlp_forward_kernel<4, 4, 4, 4>, 256); break;
+            default: rc = launch(mlp_forward_kernel<4, 4, 4, 0>, 256); break;
+        }
+    } else {  // (until round 5 <8, 2, 8>: 32 columns per wavefront, two MFMAs per fragment read)
+        switch (S.nkk0) {
+            case 1: rc = launch(mlp_forward_kernel<8, 4, 8, 1>, 512); break;
+            case 2: rc = launch(mlp_forward_kernel<8, 4, 8, 2>, 512); break;
+            case 3: rc = launch(mlp_forward_kernel<8, 4, 8, 3>, 512); break;
+            case 4: rc = launch(mlp_forward_kernel<8, 4, 8, 4>, 512); break;
+            default: rc = launch(mlp_forward_kernel<8, 4, 8, 0>, 512); break;
+        }
     }
+    if (rc) return rc;
+#ifdef MNV_MLP_CLOCKS
+    {
+        unsigned long long h[16];
+        (void)hipMemcpyAsync(h, clocks, 128, hipMemcpyDeviceToHost, stream);
+        (void)hipStreamSynchronize(stream);
+        unsigned long long sum = 0;
+        for (int i = 0; i < 16; ++i) sum += h[i];
+        static const char *const names[6] = {"stage weights", "rows + samples", "layer 0: fragment reads + encode", "layer 0: read back + MFMAs", "hidden layers", "output layer + stores"};
+        for (int i = 0; i < 6; ++i) fprintf(stderr, "mlp clocks: %-28s %5.1f %%\n", names[i], 100.0 * (double)h[i] / (double)sum);
+    }
+#endif
     return check_hip(hipGetLastError(), "mlp_forward_kernel");
 }
 

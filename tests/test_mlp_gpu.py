@@ -20,6 +20,16 @@ CONFIGS = {
     "w128_l3_dir_sh16": dict(n_clusters=5, pos_octaves=12, dir_octaves=4, need_viewdir=True, hidden_width=128, hidden_layers=3, out_dim=50),
     "w128_l4_dir_sh9": dict(n_clusters=3, pos_octaves=10, dir_octaves=4, need_viewdir=True, hidden_width=128, hidden_layers=4, out_dim=29),
     "w128_l2_out128": dict(n_clusters=2, pos_octaves=2, hidden_width=128, hidden_layers=2, out_dim=128),
+    # the K-slot layout of the first layer (every block starts at a multiple of 16 slots) at its corners: a direction block right behind three
+    # position features; blocks of 16 octaves (99 features: seven half tiles, the last one masked); embeddings that push the first layer past
+    # four K tiles (the kernels without a compile-time tile count); two and one K tiles of a 128-wide network
+    "w64_l2_dir_only_coords": dict(n_clusters=2, pos_octaves=0, dir_octaves=0, need_viewdir=True, hidden_width=64, hidden_layers=2, out_dim=4),
+    "w64_l2_oct16": dict(n_clusters=2, pos_octaves=16, dir_octaves=16, need_viewdir=True, hidden_width=64, hidden_layers=2, out_dim=7),
+    "w128_l2_oct16_emb": dict(n_clusters=2, pos_octaves=16, dir_octaves=3, need_viewdir=True, n_embeddings=5, embedding_dim=33, hidden_width=128, hidden_layers=2,
+                              out_dim=9),
+    "w64_l2_emb64": dict(n_clusters=3, pos_octaves=10, dir_octaves=4, need_viewdir=True, n_embeddings=7, embedding_dim=64, hidden_width=64, hidden_layers=2, out_dim=5),
+    "w128_l3_two_tiles": dict(n_clusters=2, pos_octaves=5, dir_octaves=1, need_viewdir=True, hidden_width=128, hidden_layers=3, out_dim=16),
+    "w128_l1_one_tile": dict(n_clusters=2, pos_octaves=1, dir_octaves=1, need_viewdir=True, hidden_width=128, hidden_layers=1, out_dim=3),
 }
 
 
