@@ -157,6 +157,15 @@ __global__ __launch_bounds__(256) void mlp_scatter(const int16_t *__restrict__ c
 // port) feeds FOUR 16-cycle MFMAs instead of two, so the port is busy half as long as the matrix pipes instead of as long; 128 accumulator
 // + 64 operand registers at two wavefronts per SIMD (256-register budget), 512 rows per pass.  Its encode tiles hold HALF a K tile (16
 // features: 2 KB per wavefront, written and read twice per K tile) -- with whole tiles the 131 KB of weights + 32 KB would not fit a CU.
+// tri_wave(x * scale + phase) (mnv_mlp.h) in five instructions instead of seven, bit for bit: scale is a power of two, so x * scale is exact and
+// one fused multiply-add rounds exactly where the sum rounds; 4 |r| is exact, so the closing fused multiply-add rounds where the subtraction
+// rounds; and the "+ 0.f" of the phase-0 features changes no result (t = -0 gives r = -0, |r| = 0, as t = +0 does).
+__device__ __forceinline__ float tri_of(float x, float scale, bool quarter_phase) {
+    const float t = quarter_phase ? __builtin_fmaf(x, scale, 0.25f) : x * scale;
+    const float r = t - floorf(t + 0.5f);
+    return __builtin_fmaf(4.f, fabsf(r), -1.f);
+}
+
 template <int... I, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -218,6 +227,10 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
     // 4 gg .. 4 gg + 3 of the half): written as four 8-byte stores by the lane that owns the sample, read as one 8-byte load per column tile
     // and half by the lane that feeds the matrix pipe (whole K tiles of the 512-row kernels would not fit a CU beside 131 KB of weights)
     uint2 *s_enc2 = reinterpret_cast<uint2 *>(lds + (size_t)S.frag_halfs * 2 + (size_t)S.bias_floats * 4) + wave * (COLS * 4);
+    // (a sample's four 8-byte groups are stored rotated by two bits of its index -- samples 8 apart would meet on the same banks, on the
+    // writing side, lane = sample, and on the reading side, lane (g, col) reads group g of sample col + 16 nt: four-way conflicts both)
+    const int own_swz = ((lane >> 3) & 1) * 2 + ((lane >> 4) & 1);  // of sample `lane` (and of lane + 64: bits 3 and 4 are the same)
+    auto read_swz = [&](int nt) { return ((col >> 3) & 1) * 2 + (nt & 1); };  // of sample col + 16 nt
 
     // Rows and samples of a pass are fetched DURING the pass before it (a row index from `order`, then that row's three to seven floats: two trips
     // to memory in a row, 17 % of a wavefront's time when they opened each pass): the indices while the pass encodes, the floats while its
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
             } else {
                 constexpr int k = (j - 3) / 6, r = (j - 3) % 6, i = r % 3;
                 const float scale = __uint_as_float((uint32_t)(127 + k) << 23);
-                return tri_wave(x[i] * scale + (r >= 3 ? 0.25f : 0.f));
+                return tri_of(x[i], scale, r >= 3);
             }
         };
         // features j0 .. j0 + 3 of a block -> 8 bytes of the tile; `masked`: features from n on are zeros (n is wave-uniform)
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
                 lo &= (j0 < n ? 0xffffu : 0u) | (j0 + 1 < n ? 0xffff0000u : 0u);
                 hi &= (j0 + 2 < n ? 0xffffu : 0u) | (j0 + 3 < n ? 0xffff0000u : 0u);
             }
-            s_enc2[(64 * o + lane) * 4 + gg] = make_uint2(lo, hi);
+            s_enc2[(64 * o + lane) * 4 + (gg ^ own_swz)] = make_uint2(lo, hi);
         };
         auto block_half = [&](int o, const float (&x)[3], auto m_tag, int n) __attribute__((always_inline)) {  // features 16 m .. 16 m + 15 of a block of n
             constexpr int m = decltype(m_tag)::value;
@@ -372,7 +385,8 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
                     for (int gg = 0; gg < 4; ++gg) s_enc2[(64 * o + lane) * 4 + gg] = make_uint2(0u, 0u);
                     _Float16 *tile_h = reinterpret_cast<_Float16 *>(s_enc2);
                     const int e_lo = 16 * half_tile - S.emb_base, e_hi = S.embedding_dim < e_lo + 16 ? S.embedding_dim : e_lo + 16;
-                    for (int e = e_lo; e < e_hi; ++e) tile_h[(64 * o + lane) * 16 + (e & 15)] = (_Float16)half_bits_to_float(emb[o][e]);
+                    for (int e = e_lo; e < e_hi; ++e)
+                        tile_h[(64 * o + lane) * 16 + ((((e & 15) >> 2) ^ own_swz) << 2) + (e & 3)] = (_Float16)half_bits_to_float(emb[o][e]);
                 }
             }
             __builtin_amdgcn_wave_barrier();  // LDS executes a wavefront's accesses in order; this only pins the compiler's order
@@ -445,7 +459,7 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
                 encode_half(T, t_tag);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const uint2 part = s_enc2[(nt * 16 + col) * 4 + g];
+                    const uint2 part = s_enc2[(nt * 16 + col) * 4 + (g ^ read_swz(nt))];
                     if constexpr (T & 1) bf0[T >> 1][nt] = __builtin_bit_cast(half8, make_uint4(lo2[nt].x, lo2[nt].y, part.x, part.y));
                     else lo2[nt] = part;
                 }
@@ -477,13 +491,13 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
                 encode_half(half_tile, std::integral_constant<int, -1>{});
                 if (!(half_tile & 1)) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) lo2[nt] = s_enc2[(nt * 16 + col) * 4 + g];
+                    for (int nt = 0; nt < NT; ++nt) lo2[nt] = s_enc2[(nt * 16 + col) * 4 + (g ^ read_swz(nt))];
                     __builtin_amdgcn_wave_barrier();
                 } else {
                     half8 bt[NT];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const uint2 hi2 = s_enc2[(nt * 16 + col) * 4 + g];
+                        const uint2 hi2 = s_enc2[(nt * 16 + col) * 4 + (g ^ read_swz(nt))];
                         bt[nt] = __builtin_bit_cast(half8, make_uint4(lo2[nt].x, lo2[nt].y, hi2.x, hi2.y));
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -505,13 +519,21 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
         }
 
         // ---- hidden layers 1 .. hidden_layers - 1
-        for (int layer = 1; layer < S.hidden_layers; ++layer) {
+        //      (two per trip, the B fragments going back and forth between two sets of registers: one per trip copied 64 registers a layer)
+        {
             half8 nb[KT][NT];
-            dense_relu(std::integral_constant<int, KT>{}, bf, nb);
+            int layer = 1;
+            for (; layer + 1 < S.hidden_layers; layer += 2) {
+                dense_relu(std::integral_constant<int, KT>{}, bf, nb);
+                dense_relu(std::integral_constant<int, KT>{}, nb, bf);
+            }
+            if (layer < S.hidden_layers) {
+                dense_relu(std::integral_constant<int, KT>{}, bf, nb);
 #pragma unroll
-            for (int kk = 0; kk < KT; ++kk)
+                for (int kk = 0; kk < KT; ++kk)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bf[kk][nt] = nb[kk][nt];
+                    for (int nt = 0; nt < NT; ++nt) bf[kk][nt] = nb[kk][nt];
+            }
         }
 
         MLP_CLOCK(4);
@@ -519,20 +541,10 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
         //      place) turns that into the store's lane order, 16-byte slots swizzled so that neither side meets a bank twice
         f32x4 *s_out = reinterpret_cast<f32x4 *>(s_enc2);
         const int slot_w = col * 4 + (g ^ (col >> 2)), slot_r = (lane & ~3) | ((lane & 3) ^ ((lane >> 4) & 3));
-#pragma unroll 1
-        for (int mt = 0; mt < S.mt_out; ++mt) {
-            half8 a[KT];
-#pragma unroll
-            for (int kk = 0; kk < KT; ++kk) a[kk] = w[(mt * KT + kk) * 64 + lane];
-            const f32x4 bv = bias_tile(mt);
-            f32x4 cur[NT];
-#pragma unroll
-            for (int kk = 0; kk < KT; ++kk)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) cur[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk], bf[kk][nt], kk == 0 ? bv : cur[nt], 0, 0, 0);
+        auto leave = [&](int mt, const f32x4 (&tile)[NT]) __attribute__((always_inline)) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                s_out[slot_w] = cur[nt];
+                s_out[slot_w] = tile[nt];
                 __builtin_amdgcn_wave_barrier();
                 const f32x4 v = s_out[slot_r];
                 __builtin_amdgcn_wave_barrier();
@@ -548,6 +560,30 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
                         if (f0 + r < S.out_dim) out[r] = v[r];
                 }
             }
+        };
+        {   // tile mt's MFMAs are issued, then tile mt - 1 goes through the tile and out while they run
+            f32x4 last[NT];
+            half8 a[KT];
+#pragma unroll
+            for (int kk = 0; kk < KT; ++kk) a[kk] = w[kk * 64 + lane];
+            f32x4 bv = bias_tile(0);
+#pragma unroll 1
+            for (int mt = 0; mt < S.mt_out; ++mt) {
+                f32x4 cur[NT];
+#pragma unroll
+                for (int kk = 0; kk < KT; ++kk)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) cur[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[kk], bf[kk][nt], kk == 0 ? bv : cur[nt], 0, 0, 0);
+                if (mt + 1 < S.mt_out) {
+#pragma unroll
+                    for (int kk = 0; kk < KT; ++kk) a[kk] = w[((mt + 1) * KT + kk) * 64 + lane];
+                    bv = bias_tile(mt + 1);
+                }
+                if (mt > 0) leave(mt - 1, last);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) last[nt] = cur[nt];
+            }
+            leave(S.mt_out - 1, last);
         }
         MLP_CLOCK(5);
     }
