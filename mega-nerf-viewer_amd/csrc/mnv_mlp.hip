@@ -66,32 +66,53 @@ struct MlpLaunch {
 
 // ---------------------------------------------------------------- counting sort by cluster
 
-// Rows per block of the two sort passes; each thread handles kSortItems rows.
+// Rows of one chunk of the two sort passes (each thread handles kSortItems rows of a chunk); a block takes `chunks` consecutive chunks and
+// talks to the global counters ONCE per bin -- with one chunk per block the 8 M rows of the profile were 3906 blocks x 8 bins = 31 k atomics on
+// eight addresses per pass, which the L2 serialises: 50 us for a pass that reads 16 MB.
 constexpr int kSortItems = 8;
 constexpr int kSortRows = 256 * kSortItems;
 
-// Rank of every row among the block's rows of its bin: one LDS atomic per row.  (Until round 5 a wavefront-aggregated form -- one atomic per
-// distinct bin of the wavefront, found by a ballot / shuffle loop: cheaper when neighbouring rows share a bin, but the loop runs once per
-// distinct bin, and on incoherent rows -- the profile's 8 random clusters -- that was eight trips of ten instructions per row against one
-// ds_add_rtn whose same-address lanes the LDS serialises by itself.)  The order of rows within a bin is whatever the LDS makes it: rows are
-// independent columns of the matrix products, their results do not depend on their place.
-__device__ inline int rank_in_bin(int32_t *s_bins, int c, bool valid) { return valid ? atomicAdd(&s_bins[c], 1) : 0; }
+// (Ranks within a bin: one LDS atomic per row.  Until round 5 a wavefront-aggregated form -- one atomic per distinct bin of the wavefront, found
+// by a ballot / shuffle loop: cheaper when neighbouring rows share a bin, but the loop runs once per distinct bin, and on incoherent rows --
+// the profile's 8 random clusters -- that was eight trips of ten instructions per row against one ds_add_rtn whose same-address lanes the
+// LDS serialises by itself.  The order of rows within a bin is whatever the LDS makes it: rows are independent columns of the matrix
+// products, their results do not depend on their place.)
+// The thread's eight CONSECUTIVE rows of a chunk (rows base + 8 t .. + 7): one 16-byte load when the chunk is whole and the array 16-byte
+// aligned, eight 2-byte loads otherwise; -1 past the end.
+__device__ inline void load_chunk_rows(const int16_t *__restrict__ cluster, int64_t n, int64_t base, bool aligned, int (&c)[kSortItems]) {
+    static_assert(kSortItems == 8, "eight 16-bit rows per 16-byte load");
+    const int64_t i0 = base + (int64_t)threadIdx.x * kSortItems;
+    if (aligned && base + kSortRows <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(cluster + i0);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < kSortItems; ++k) c[k] = (int)(int16_t)(w[k >> 1] >> (16 * (k & 1)));
+    } else {
+#pragma unroll
+        for (int k = 0; k < kSortItems; ++k) c[k] = i0 + k < n ? cluster[i0 + k] : -1;
+    }
+}
 
-__global__ __launch_bounds__(256) void mlp_histogram(const int16_t *__restrict__ cluster, int64_t n, int32_t n_clusters,
+__global__ __launch_bounds__(256) void mlp_histogram(const int16_t *__restrict__ cluster, int64_t n, int32_t n_clusters, int32_t chunks,
                                                      int32_t *__restrict__ counts, float *__restrict__ results, int32_t result_stride,
                                                      int32_t out_dim) {
     __shared__ int32_t s_bins[kMaxClusters];
     for (int c = threadIdx.x; c < n_clusters; c += 256) s_bins[c] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * kSortRows;
+    const bool aligned = (reinterpret_cast<uintptr_t>(cluster) & 15) == 0;
+    for (int ch = 0; ch < chunks; ++ch) {
+        const int64_t base = ((int64_t)blockIdx.x * chunks + ch) * kSortRows;
+        if (base >= n) break;
+        int c[kSortItems];
+        load_chunk_rows(cluster, n, base, aligned, c);
 #pragma unroll
-    for (int k = 0; k < kSortItems; ++k) {
-        const int64_t i = base + k * 256 + threadIdx.x;
-        const int c = i < n ? cluster[i] : -1;
-        const bool valid = c >= 0 && c < n_clusters;
-        if (valid) atomicAdd(&s_bins[c], 1);
-        if (i < n && !valid)
-            for (int o = 0; o < out_dim; ++o) results[i * result_stride + o] = 0.f;  // no sub-module: zeros
+        for (int k = 0; k < kSortItems; ++k) {
+            const int64_t i = base + (int64_t)threadIdx.x * kSortItems + k;
+            const bool valid = c[k] >= 0 && c[k] < n_clusters;
+            if (valid) atomicAdd(&s_bins[c[k]], 1);
+            if (i < n && !valid)
+                for (int o = 0; o < out_dim; ++o) results[i * result_stride + o] = 0.f;  // no sub-module: zeros
+        }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < n_clusters; c += 256)
@@ -121,29 +142,39 @@ __global__ void mlp_plan(const int32_t *__restrict__ counts, int32_t n_clusters,
     }
 }
 
-__global__ __launch_bounds__(256) void mlp_scatter(const int16_t *__restrict__ cluster, int64_t n, int32_t n_clusters,
+__global__ __launch_bounds__(256) void mlp_scatter(const int16_t *__restrict__ cluster, int64_t n, int32_t n_clusters, int32_t chunks,
                                                    int32_t *__restrict__ cursor, int32_t *__restrict__ order) {
-    __shared__ int32_t s_bins[kMaxClusters];
+    __shared__ int32_t s_bins[kMaxClusters], s_base[kMaxClusters];
     for (int c = threadIdx.x; c < n_clusters; c += 256) s_bins[c] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * kSortRows;
-    int rank[kSortItems], bin[kSortItems];
+    const bool aligned = (reinterpret_cast<uintptr_t>(cluster) & 15) == 0;
+    // the block's rows per bin (its chunks are read twice: 2 bytes a row, the second time from the L2) ...
+    for (int ch = 0; ch < chunks; ++ch) {
+        const int64_t base = ((int64_t)blockIdx.x * chunks + ch) * kSortRows;
+        if (base >= n) break;
+        int c[kSortItems];
+        load_chunk_rows(cluster, n, base, aligned, c);
 #pragma unroll
-    for (int k = 0; k < kSortItems; ++k) {
-        const int64_t i = base + k * 256 + threadIdx.x;
-        const int c = i < n ? cluster[i] : -1;
-        const bool valid = c >= 0 && c < n_clusters;
-        bin[k] = valid ? c : -1;
-        rank[k] = rank_in_bin(s_bins, c, valid);
+        for (int k = 0; k < kSortItems; ++k)
+            if (c[k] >= 0 && c[k] < n_clusters) atomicAdd(&s_bins[c[k]], 1);
     }
     __syncthreads();
-    // one global reservation per bin and block; s_bins becomes the block's base position
-    for (int c = threadIdx.x; c < n_clusters; c += 256)
-        if (s_bins[c]) s_bins[c] = atomicAdd(&cursor[c], s_bins[c]);
+    // ... one global reservation per bin and block ...
+    for (int c = threadIdx.x; c < n_clusters; c += 256) {
+        s_base[c] = s_bins[c] ? atomicAdd(&cursor[c], s_bins[c]) : 0;
+        s_bins[c] = 0;
+    }
     __syncthreads();
+    // ... and every row to its place
+    for (int ch = 0; ch < chunks; ++ch) {
+        const int64_t base = ((int64_t)blockIdx.x * chunks + ch) * kSortRows;
+        if (base >= n) break;
+        int c[kSortItems];
+        load_chunk_rows(cluster, n, base, aligned, c);
 #pragma unroll
-    for (int k = 0; k < kSortItems; ++k)
-        if (bin[k] >= 0) order[s_bins[bin[k]] + rank[k]] = (int32_t)(base + k * 256 + threadIdx.x);
+        for (int k = 0; k < kSortItems; ++k)
+            if (c[k] >= 0 && c[k] < n_clusters) order[s_base[c[k]] + atomicAdd(&s_bins[c[k]], 1)] = (int32_t)(base + (int64_t)threadIdx.x * kSortItems + k);
+    }
 }
 
 // ---------------------------------------------------------------- the network
@@ -788,10 +819,13 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
     int32_t *tile_start = reinterpret_cast<int32_t *>(m->scratch + o_tiles), *order = reinterpret_cast<int32_t *>(m->scratch + o_order);
 
     if ((rc = check_hip(hipMemsetAsync(counts, 0, kMaxClusters * 4, stream), "memset"))) return rc;
-    const unsigned nb = (unsigned)((n + kSortRows - 1) / kSortRows);
-    hipLaunchKernelGGL(mlp_histogram, dim3(nb), dim3(256), 0, stream, cluster_indices, n, S.n_clusters, counts, results, result_stride, S.out_dim);
+    // sort blocks: as many chunks of 2048 rows each as leaves about two blocks per compute unit (at most 16 chunks)
+    const int64_t n_chunks = (n + kSortRows - 1) / kSortRows;
+    const int32_t chunks = (int32_t)std::min<int64_t>(16, std::max<int64_t>(1, n_chunks / (2 * cus)));
+    const unsigned nb = (unsigned)((n_chunks + chunks - 1) / chunks);
+    hipLaunchKernelGGL(mlp_histogram, dim3(nb), dim3(256), 0, stream, cluster_indices, n, S.n_clusters, chunks, counts, results, result_stride, S.out_dim);
     hipLaunchKernelGGL(mlp_plan, dim3(1), dim3(256), 0, stream, counts, S.n_clusters, seg_start, cursor, tile_start, rows_per_block);
-    hipLaunchKernelGGL(mlp_scatter, dim3(nb), dim3(256), 0, stream, cluster_indices, n, S.n_clusters, cursor, order);
+    hipLaunchKernelGGL(mlp_scatter, dim3(nb), dim3(256), 0, stream, cluster_indices, n, S.n_clusters, chunks, cursor, order);
 
     MlpLaunch L;
     L.S = S;
