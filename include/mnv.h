@@ -376,6 +376,13 @@ int mnv_get_samples_from_voxels(const mnv_tree_view *tree, const mnv_camera *cam
                                 int track_visit, int16_t *num_samples, float *samples, int32_t samples_dim,
                                 int16_t *cluster_indices, const mnv_cluster_grid *grid, void *hip_stream);
 
+/* ... with the depth attachment of the reference's offscreen == false call (renderer_kernel.cu:354-357: `float t_max = surf2Dread(surf_obj_depth)`):
+ * inputs->tmax_px [tile.h][tile.w] limits every ray; inputs == NULL or tmax_px == NULL is the call above.  rgba8_init is not read (no image is written). */
+int mnv_get_samples_from_voxels_ex(const mnv_tree_view *tree, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                                   const mnv_frame_inputs *inputs, float *split_track, float *sample_track, int32_t *visited, int track_visit,
+                                   int16_t *num_samples, float *samples, int32_t samples_dim, int16_t *cluster_indices,
+                                   const mnv_cluster_grid *grid, void *hip_stream);
+
 /* The same march on the packed accel (visit marks: mnv_get_samples_from_voxels_accel_visit below); sample_counts is the tree's
  * live [capacity][8] array or NULL.  Bit-identical rows. */
 int mnv_get_samples_from_voxels_accel(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
@@ -397,6 +404,11 @@ int mnv_get_samples_from_voxels_accel_visit(const mnv_accel *accel, const mnv_ca
                                             float *split_track, float *sample_track, const int16_t *sample_counts, int32_t *visited,
                                             const int32_t *parent, int16_t *num_samples, float *samples, int32_t samples_dim,
                                             int16_t *cluster_indices, const mnv_cluster_grid *grid, void *hip_stream);
+/* ... and with the ray limits of offscreen == false (as mnv_get_samples_from_voxels_ex) */
+int mnv_get_samples_from_voxels_accel_visit_ex(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                                               const mnv_frame_inputs *inputs, float *split_track, float *sample_track, const int16_t *sample_counts,
+                                               int32_t *visited, const int32_t *parent, int16_t *num_samples, float *samples, int32_t samples_dim,
+                                               int16_t *cluster_indices, const mnv_cluster_grid *grid, void *hip_stream);
 /* The tracker frame of one rank of a multi-GPU run: pixels AND tracker rows of the macro tiles `part` assigns to the rank, both in the
  * compact tile-major order of mnv_render_voxels_accel_part (row p of a tracker belongs to pixel p of the rank's buffer); rows of tiles a
  * ragged partition leaves out are not written (pre-fill with -1 as for a frame).  `visited` receives the marks of this rank's rays. */
@@ -611,6 +623,14 @@ int mnv_render_guided_fused_track(const mnv_accel *accel, const mnv_camera *cam,
                                   const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, float *split_track, float *sample_track,
                                   const int16_t *sample_counts, int32_t *visited, const int32_t *parent, unsigned long long *sample_counter,
                                   void *hip_stream);
+/* The fused frame in the reference's LIVE call shape (offscreen == false in get_samples_from_voxels and render_nerf_results,
+ * cuda_renderer.cpp:111-113,135-136): every ray stops at inputs->tmax_px (renderer_kernel.cu:354-357).  inputs->rgba8_init is not read:
+ * render_nerf_results_kernel leaves out[3] at 1 (renderer_kernel.cu:316), so composite_and_write adds the image under the volume with
+ * weight 1 - 1 = 0 (:224-234) -- with or without it the frame is the same.  Tracker arguments may be NULL as in mnv_render_guided_fused. */
+int mnv_render_guided_fused_track_ex(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                                     const mnv_frame_inputs *inputs, const mnv_mlp *mlp, const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out,
+                                     float *split_track, float *sample_track, const int16_t *sample_counts, int32_t *visited, const int32_t *parent,
+                                     unsigned long long *sample_counter, void *hip_stream);
 /* The fused frame of one rank of a multi-GPU run: the macro tiles `part` assigns to the rank, written tile-major like
  * mnv_render_voxels_accel_part (guided sampling reads the tree only, so the ranks need no exchange but the usual tile gather). */
 int mnv_render_guided_fused_part(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, mnv_partition part,

@@ -86,6 +86,34 @@ inline void render_voxels(N3Tree &tree, const Camera &cam, const RenderOptions &
     if (rc != MNV_OK) throw std::runtime_error(mnv_last_error());
 }
 
+// Replacement body of viewer::get_samples_from_voxels (src/cuda/renderer_kernel.cu:439-485) with its ORIGINAL sixteen parameters
+// (include/cuda/renderer_kernel.hpp:36-52); depth_arr is the linear float depth image of render_voxels above, read when offscreen == false
+// (renderer_kernel.cu:354-357).  The three cluster-grid tensors are the model attributes of cuda_renderer.cpp:524-539 (host or device).
+inline void get_samples_from_voxels(N3Tree &tree, const Camera &cam, const RenderOptions &opt, float *&depth_arr /* was cudaArray_t& */,
+                                    hipStream_t &stream, const torch::Tensor &to_split, const torch::Tensor &to_sample, const torch::Tensor &visited,
+                                    const bool track_visit, const bool offscreen, const torch::Tensor &num_samples, const torch::Tensor &samples,
+                                    const torch::Tensor &cluster_indices, const torch::Tensor &grid_dim, const torch::Tensor &min_position,
+                                    const torch::Tensor &range) {
+    const mnv_tree_view tv = mnv_view(tree);
+    const mnv_camera cv = mnv_view(cam);
+    const mnv_rect full{0, 0, cam.width, cam.height};
+    const mnv_frame_inputs in{offscreen ? nullptr : depth_arr, nullptr};
+    mnv_cluster_grid grid;
+    const torch::Tensor gd = grid_dim.to(torch::kCPU, torch::kInt32), mp = min_position.to(torch::kCPU, torch::kFloat32), rg = range.to(torch::kCPU, torch::kFloat32);
+    for (int i = 0; i < 2; ++i) grid.grid_dim[i] = gd.data_ptr<int32_t>()[i];
+    for (int i = 0; i < 3; ++i) {
+        grid.min_position[i] = mp.data_ptr<float>()[i];
+        grid.range[i] = rg.data_ptr<float>()[i];
+    }
+    const int rc = mnv_get_samples_from_voxels_ex(&tv, &cv, reinterpret_cast<const mnv_render_options *>(&opt), full, &in,
+                                                  to_split.defined() ? to_split.data_ptr<float>() : nullptr,
+                                                  to_sample.defined() ? to_sample.data_ptr<float>() : nullptr,
+                                                  visited.defined() ? visited.data_ptr<int32_t>() : nullptr, track_visit ? 1 : 0,
+                                                  num_samples.data_ptr<int16_t>(), samples.data_ptr<float>(), (int32_t)samples.size(-1),
+                                                  cluster_indices.data_ptr<int16_t>(), &grid, (void *)stream);
+    if (rc != MNV_OK) throw std::runtime_error(mnv_last_error());
+}
+
 // The tuned path: build once where the reference calls tree->move_to_device (cuda_renderer.cpp:498-505) ...
 inline mnv_accel *make_accel(N3Tree &tree, long max_tree_capacity, void *stream) {
     const mnv_tree_view tv = mnv_view(tree);

@@ -248,6 +248,15 @@ _SIGNATURES = {
     "mnv_get_samples_from_voxels": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32,
                                               C.c_void_p, C.POINTER(ClusterGrid), C.c_void_p]),
+    "mnv_get_samples_from_voxels_ex": (C.c_int, [C.POINTER(TreeView), C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.POINTER(FrameInputs),
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int32,
+                                                 C.c_void_p, C.POINTER(ClusterGrid), C.c_void_p]),
+    "mnv_get_samples_from_voxels_accel_visit_ex": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.POINTER(FrameInputs),
+                                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                                             C.c_void_p, C.POINTER(ClusterGrid), C.c_void_p]),
+    "mnv_render_guided_fused_track_ex": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.POINTER(FrameInputs), C.c_void_p,
+                                                   C.POINTER(ClusterGrid), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p]),
     "mnv_get_samples_from_voxels_accel": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(ClusterGrid), C.c_void_p]),
     "mnv_render_voxels_accel_visit": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -674,9 +683,18 @@ def render_voxels_accel_visit(accel: int, cam: Camera, opt: RenderOptions, visit
 
 
 def get_samples_from_voxels_accel_visit(accel: int, cam: Camera, opt: RenderOptions, visited, parent, num_samples, samples, cluster_indices,
-                                        grid: ClusterGrid, split_track=None, sample_track=None, sample_counts=None, tile=None, stream: int = 0) -> None:
+                                        grid: ClusterGrid, split_track=None, sample_track=None, sample_counts=None, tile=None, stream: int = 0,
+                                        tmax_px=None) -> None:
+    """tmax_px: the depth attachment of the reference's offscreen == false call (every ray stops there), indexed like the pixels."""
     if tile is None:
         tile = (0, 0, cam.width, cam.height)
+    inputs = _frame_inputs(tmax_px, None, tile[2] * tile[3])
+    if inputs is not None:
+        _check(lib().mnv_get_samples_from_voxels_accel_visit_ex(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), C.byref(inputs),
+                                                                _ptr(split_track), _ptr(sample_track), _ptr(sample_counts), _ptr(visited), _ptr(parent),
+                                                                _ptr(num_samples), _ptr(samples), int(samples.shape[-1]), _ptr(cluster_indices),
+                                                                C.byref(grid), C.c_void_p(stream)))
+        return
     _check(lib().mnv_get_samples_from_voxels_accel_visit(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(split_track), _ptr(sample_track),
                                                          _ptr(sample_counts), _ptr(visited), _ptr(parent), _ptr(num_samples), _ptr(samples),
                                                          int(samples.shape[-1]), _ptr(cluster_indices), C.byref(grid), C.c_void_p(stream)))
@@ -771,20 +789,31 @@ def render_voxels_accel_part(accel: int, cam: Camera, opt: RenderOptions, rank: 
 
 def get_samples_from_voxels(tree_view: TreeView, cam: Camera, opt: RenderOptions, num_samples, samples, cluster_indices,
                             grid: ClusterGrid, split_track=None, sample_track=None, visited=None, track_visit=False,
-                            tile=None, stream: int = 0) -> None:
-    """viewer::get_samples_from_voxels (reference include/cuda/renderer_kernel.hpp:36-52)."""
+                            tile=None, stream: int = 0, tmax_px=None) -> None:
+    """viewer::get_samples_from_voxels (reference include/cuda/renderer_kernel.hpp:36-52).  tmax_px: the depth attachment of its
+    offscreen == false call (renderer_kernel.cu:354-357), a float32 device tensor indexed like the pixels."""
     if tile is None:
         tile = (0, 0, cam.width, cam.height)
+    inputs = _frame_inputs(tmax_px, None, tile[2] * tile[3])
+    if inputs is not None:
+        _check(lib().mnv_get_samples_from_voxels_ex(C.byref(tree_view), C.byref(cam.c), C.byref(opt), Rect(*tile), C.byref(inputs), _ptr(split_track),
+                                                    _ptr(sample_track), _ptr(visited), int(track_visit), _ptr(num_samples), _ptr(samples),
+                                                    int(samples.shape[-1]), _ptr(cluster_indices), C.byref(grid), C.c_void_p(stream)))
+        return
     _check(lib().mnv_get_samples_from_voxels(C.byref(tree_view), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(split_track),
                                              _ptr(sample_track), _ptr(visited), int(track_visit), _ptr(num_samples), _ptr(samples),
                                              int(samples.shape[-1]), _ptr(cluster_indices), C.byref(grid), C.c_void_p(stream)))
 
 
 def get_samples_from_voxels_accel(accel: int, cam: Camera, opt: RenderOptions, num_samples, samples, cluster_indices, grid: ClusterGrid,
-                                  split_track=None, sample_track=None, sample_counts=None, tile=None, stream: int = 0) -> None:
+                                  split_track=None, sample_track=None, sample_counts=None, tile=None, stream: int = 0, tmax_px=None) -> None:
     """get_samples_from_voxels on the packed accel (no visit marks)."""
     if tile is None:
         tile = (0, 0, cam.width, cam.height)
+    if tmax_px is not None:
+        get_samples_from_voxels_accel_visit(accel, cam, opt, None, None, num_samples, samples, cluster_indices, grid, split_track, sample_track,
+                                            sample_counts, tile, stream, tmax_px)
+        return
     _check(lib().mnv_get_samples_from_voxels_accel(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(split_track),
                                                    _ptr(sample_track), _ptr(sample_counts), _ptr(num_samples), _ptr(samples),
                                                    int(samples.shape[-1]), _ptr(cluster_indices), C.byref(grid), C.c_void_p(stream)))
@@ -802,11 +831,18 @@ def render_nerf_results(tree_view: TreeView, cam: Camera, opt: RenderOptions, sa
 
 def render_guided_fused(accel: int, cam: Camera, opt: RenderOptions, mlp: "Mlp", grid: ClusterGrid, tile=None, rgba=None, rgba8=None,
                         sample_counter=None, split_track=None, sample_track=None, sample_counts=None, visited=None, parent=None,
-                        stream: int = 0) -> None:
+                        stream: int = 0, tmax_px=None) -> None:
     """The guided-sampling frame as one kernel (mnv_render_guided_fused[_track]).  `sample_counter`: optional device int64 tensor,
-    incremented by the number of network evaluations; trackers / visit marks as in render_voxels_accel_visit."""
+    incremented by the number of network evaluations; trackers / visit marks as in render_voxels_accel_visit.  tmax_px: the depth
+    attachment of the reference's offscreen == false frame (the image under the volume has weight 0 in that frame: not an input)."""
     if tile is None:
         tile = (0, 0, cam.width, cam.height)
+    inputs = _frame_inputs(tmax_px, None, tile[2] * tile[3])
+    if inputs is not None:
+        _check(lib().mnv_render_guided_fused_track_ex(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), C.byref(inputs), mlp._h, C.byref(grid),
+                                                      _ptr(rgba), _ptr(rgba8), _ptr(split_track), _ptr(sample_track), _ptr(sample_counts), _ptr(visited),
+                                                      _ptr(parent), _ptr(sample_counter), C.c_void_p(stream)))
+        return
     _check(lib().mnv_render_guided_fused_track(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), mlp._h, C.byref(grid), _ptr(rgba),
                                                _ptr(rgba8), _ptr(split_track), _ptr(sample_track), _ptr(sample_counts), _ptr(visited), _ptr(parent),
                                                _ptr(sample_counter), C.c_void_p(stream)))

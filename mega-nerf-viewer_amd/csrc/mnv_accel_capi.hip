@@ -459,6 +459,14 @@ int mnv_get_samples_from_voxels_accel_visit(const mnv_accel *accel, const mnv_ca
                                             float *split_track, float *sample_track, const int16_t *sample_counts, int32_t *visited,
                                             const int32_t *parent, int16_t *num_samples, float *samples, int32_t samples_dim,
                                             int16_t *cluster_indices, const mnv_cluster_grid *grid, void *hip_stream) {
+    return mnv_get_samples_from_voxels_accel_visit_ex(accel, cam, opt, tile, nullptr, split_track, sample_track, sample_counts, visited, parent, num_samples,
+                                                      samples, samples_dim, cluster_indices, grid, hip_stream);
+}
+
+int mnv_get_samples_from_voxels_accel_visit_ex(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                                               const mnv_frame_inputs *inputs, float *split_track, float *sample_track, const int16_t *sample_counts,
+                                               int32_t *visited, const int32_t *parent, int16_t *num_samples, float *samples, int32_t samples_dim,
+                                               int16_t *cluster_indices, const mnv_cluster_grid *grid, void *hip_stream) {
     if (visited && !parent) return set_error(MNV_E_INVALID, "visit marks on the packed layout need the parent array (the ancestors of the marked chunks)");
     if (!opt || !num_samples || !samples || !cluster_indices || !grid) return set_error(MNV_E_INVALID, "null argument");
     const int need = 4 + (opt->need_viewdir ? 3 : 0) + (opt->appearance_embedding != -1 ? 1 : 0);
@@ -481,7 +489,8 @@ int mnv_get_samples_from_voxels_accel_visit(const mnv_accel *accel, const mnv_ca
     track.visited = visited;
     track.parent = parent;
     const mnv_partition whole = {0, 1, 0, 0, 0};
-    return render_accel(accel, cam, 1, opt, tile, whole, nullptr, nullptr, &track, hip_stream);
+    const mnv_frame_inputs limit_only = {inputs ? inputs->tmax_px : nullptr, nullptr};  // (this call writes no image: rgba8_init has no role)
+    return render_accel(accel, cam, 1, opt, tile, whole, nullptr, nullptr, &track, hip_stream, &limit_only);
 }
 
 int mnv_render_guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, const mnv_mlp *mlp,
@@ -494,7 +503,16 @@ int mnv_render_guided_fused(const mnv_accel *accel, const mnv_camera *cam, const
 static int guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, mnv_partition part,
                         const mnv_mlp *mlp, const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, float *split_track,
                         float *sample_track, const int16_t *sample_counts, int32_t *visited, const int32_t *parent,
-                        unsigned long long *sample_counter, void *hip_stream);
+                        unsigned long long *sample_counter, void *hip_stream, const mnv_frame_inputs *inputs = nullptr);
+
+int mnv_render_guided_fused_track_ex(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                                     const mnv_frame_inputs *inputs, const mnv_mlp *mlp, const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out,
+                                     float *split_track, float *sample_track, const int16_t *sample_counts, int32_t *visited, const int32_t *parent,
+                                     unsigned long long *sample_counter, void *hip_stream) {
+    const mnv_partition whole = {0, 1, 0, 0, 0};
+    return guided_fused(accel, cam, opt, tile, whole, mlp, grid, rgba_out, rgba8_out, split_track, sample_track, sample_counts, visited, parent,
+                        sample_counter, hip_stream, inputs);
+}
 
 int mnv_render_guided_fused_track(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, const mnv_mlp *mlp,
                                   const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, float *split_track, float *sample_track,
@@ -523,7 +541,7 @@ int mnv_render_guided_fused_track_part(const mnv_accel *accel, const mnv_camera 
 static int guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, mnv_partition part,
                         const mnv_mlp *mlp, const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, float *split_track,
                         float *sample_track, const int16_t *sample_counts, int32_t *visited, const int32_t *parent,
-                        unsigned long long *sample_counter, void *hip_stream) {
+                        unsigned long long *sample_counter, void *hip_stream, const mnv_frame_inputs *inputs) {
     if (!accel || !cam || !opt || !mlp || !grid) return set_error(MNV_E_INVALID, "null argument");
     {
         // A spin-wait that the watchdog of guided_fused2_kernel abandoned leaves wrong pixels behind.  The launches are asynchronous, so the
@@ -578,7 +596,11 @@ static int guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv
     track.max_sample_count = opt->max_sample_count;
     track.visited = visited;
     track.parent = parent;
-    return render_accel(accel, cam, 1, opt, tile, part, rgba_out, rgba8_out, &track, hip_stream);
+    // offscreen == false: the march stops at the pixel's t_max (get_samples_from_voxels_kernel, renderer_kernel.cu:354-357); the composite of the
+    // network's results adds the image under the volume with weight 1 - out[3] = 0 (render_nerf_results_kernel leaves out[3] at 1, :316,
+    // composite_and_write :224-234): rgba8_init changes no pixel and is not read
+    const mnv_frame_inputs limit_only = {inputs ? inputs->tmax_px : nullptr, nullptr};
+    return render_accel(accel, cam, 1, opt, tile, part, rgba_out, rgba8_out, &track, hip_stream, &limit_only);
 }
 
 }  // extern "C"

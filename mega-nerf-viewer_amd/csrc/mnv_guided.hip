@@ -345,6 +345,14 @@ int mnv_get_samples_from_voxels(const mnv_tree_view *tree, const mnv_camera *cam
                                 float *split_track, float *sample_track, int32_t *visited, int track_visit,
                                 int16_t *num_samples, float *samples, int32_t samples_dim, int16_t *cluster_indices,
                                 const mnv_cluster_grid *grid, void *hip_stream) {
+    return mnv_get_samples_from_voxels_ex(tree, cam, opt, tile, nullptr, split_track, sample_track, visited, track_visit, num_samples, samples, samples_dim,
+                                          cluster_indices, grid, hip_stream);
+}
+
+int mnv_get_samples_from_voxels_ex(const mnv_tree_view *tree, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                                   const mnv_frame_inputs *inputs, float *split_track, float *sample_track, int32_t *visited, int track_visit,
+                                   int16_t *num_samples, float *samples, int32_t samples_dim, int16_t *cluster_indices,
+                                   const mnv_cluster_grid *grid, void *hip_stream) {
     if (!num_samples || !samples || !cluster_indices || !grid || !opt) return set_error(MNV_E_INVALID, "null argument");
     if (!tree || tree->N <= 0) return set_error(MNV_E_INVALID, "get_samples needs a non-empty tree");
     const int need = 4 + (opt->need_viewdir ? 3 : 0) + (opt->appearance_embedding != -1 ? 1 : 0);
@@ -360,6 +368,7 @@ int mnv_get_samples_from_voxels(const mnv_tree_view *tree, const mnv_camera *cam
         return set_error(MNV_E_UNSUPPORTED, "the sample march supports N == 2 trees (generate_samples is written for N == 2 in the reference as well, renderer_kernel.cu:88-168)");
     S.M.max_depth = opt->max_depth;
     S.M.max_sample_count = opt->max_sample_count;
+    if (inputs) S.M.tmax_px = inputs->tmax_px;  // offscreen == false: the ray limit of every pixel (renderer_kernel.cu:354-357)
     S.M.split_track = split_track;
     S.M.sample_track = sample_track;
     S.M.visited = visited;

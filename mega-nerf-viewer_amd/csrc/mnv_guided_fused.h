@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                     sp_vox = sa_vox = -1;
                 }
                 RaySetup<NB> r;
-                setup_ray<(BASIS > 0 ? BASIS : 0)>(P, *Cp, P.x0 + bx, P.y0 + by, r);
+                setup_ray<(BASIS > 0 ? BASIS : 0)>(P, *Cp, P.x0 + bx, P.y0 + by, r, frame_tmax(P, p));
                 if constexpr (BASIS == 0) r.basis[0] = (0 < P.basis_min || 0 > P.basis_max) ? 0.f : (float)0.28209479177387814;
                 float true_dir[3], vdir[3];
                 world_ray_dirs(P, *Cp, P.x0 + bx, P.y0 + by, true_dir, vdir);

@@ -645,6 +645,15 @@ int orc_get_samples_from_voxels(const orc_tree *tree, const orc_camera *cam, con
                                 float *split_track, float *sample_track, int32_t *visited, int track_visit,
                                 int16_t *num_samples, float *samples, int32_t samples_dim,
                                 int16_t *cluster_indices, const orc_cluster_grid *grid, int n_threads) {
+    return orc_get_samples_from_voxels_ex(tree, cam, opt, NULL, split_track, sample_track, visited, track_visit, num_samples, samples, samples_dim,
+                                          cluster_indices, grid, n_threads);
+}
+
+/* ... with the depth attachment of offscreen == false: t_max of every pixel (renderer_kernel.cu:354-357), NULL = 1e9f */
+int orc_get_samples_from_voxels_ex(const orc_tree *tree, const orc_camera *cam, const orc_options *opt, const float *tmax_px,
+                                   float *split_track, float *sample_track, int32_t *visited, int track_visit,
+                                   int16_t *num_samples, float *samples, int32_t samples_dim,
+                                   int16_t *cluster_indices, const orc_cluster_grid *grid, int n_threads) {
     if (!tree || !cam || !opt || !num_samples || !samples || !cluster_indices || !grid || tree->N <= 0) return -1;
     const int need = 4 + (opt->need_viewdir ? 3 : 0) + (opt->appearance_embedding != -1 ? 1 : 0);
     if (samples_dim < need) return -1;
@@ -676,7 +685,7 @@ int orc_get_samples_from_voxels(const orc_tree *tree, const orc_camera *cam, con
             dir[0] *= delta_scale;
             dir[1] *= delta_scale;
             dir[2] *= delta_scale;
-            float tmax_bg = 1e9f;
+            float tmax_bg = tmax_px ? tmax_px[idx] : 1e9f; /* renderer_kernel.cu:354-357 */
             tmax_bg /= delta_scale;
             float invdir[3];
             for (int i = 0; i < 3; ++i) invdir[i] = (float)(1.0 / ((double)dir[i] + 1e-9));

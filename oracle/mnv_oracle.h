@@ -160,6 +160,12 @@ int orc_get_samples_from_voxels(const orc_tree *tree, const orc_camera *cam, con
                                 float *split_track, float *sample_track, int32_t *visited, int track_visit,
                                 int16_t *num_samples, float *samples, int32_t samples_dim,
                                 int16_t *cluster_indices, const orc_cluster_grid *grid, int n_threads);
+/* the same with the reference's offscreen == false input: tmax_px [h][w], the ray limit read from the depth attachment
+ * (renderer_kernel.cu:354-357); NULL = 1e9f everywhere = the function above */
+int orc_get_samples_from_voxels_ex(const orc_tree *tree, const orc_camera *cam, const orc_options *opt, const float *tmax_px,
+                                   float *split_track, float *sample_track, int32_t *visited, int track_visit,
+                                   int16_t *num_samples, float *samples, int32_t samples_dim,
+                                   int16_t *cluster_indices, const orc_cluster_grid *grid, int n_threads);
 
 /*
  * render_nerf_results_kernel + composite_nerf_results (renderer_kernel.cu:294-327, rt_core.cuh:334-416),

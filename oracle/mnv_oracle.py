@@ -241,9 +241,9 @@ def algorithmic_bytes(ctr: OrcCounters, fmt: int, basis_dim: int) -> int:
     return int(lib().orc_algorithmic_bytes(C.byref(ctr), fmt, basis_dim))
 
 
-def get_samples(tree: OrcTree, cam_struct, opt_struct, grid_struct, samples_dim, visited=None, track_visit=False, n_threads=0):
-    """orc_get_samples_from_voxels on a full frame.  Buffers are initialised the way the reference's
-    host code does (num_samples = 0, samples column 0 = -1, trackers = -1)."""
+def get_samples(tree: OrcTree, cam_struct, opt_struct, grid_struct, samples_dim, visited=None, track_visit=False, n_threads=0, tmax_px=None):
+    """orc_get_samples_from_voxels(_ex) on a full frame.  Buffers are initialised the way the reference's
+    host code does (num_samples = 0, samples column 0 = -1, trackers = -1).  tmax_px [h][w]: the depth attachment of offscreen == false."""
     cam = _copy_struct(OrcCamera(), cam_struct)
     opt = _copy_struct(OrcOptions(), opt_struct)
     grid = _copy_struct(OrcClusterGrid(), grid_struct)
@@ -253,9 +253,13 @@ def get_samples(tree: OrcTree, cam_struct, opt_struct, grid_struct, samples_dim,
     clusters = np.full((n, mg), -1, np.int16)
     split = np.full((n, 3), -1, np.float32)
     sample = np.full((n, 3), -1, np.float32)
-    rc = lib().orc_get_samples_from_voxels(C.byref(tree), C.byref(cam), C.byref(opt), split.ctypes.data, sample.ctypes.data,
-                                           visited.ctypes.data if visited is not None else None, int(track_visit), num.ctypes.data,
-                                           samples.ctypes.data, samples_dim, clusters.ctypes.data, C.byref(grid), _threads(n_threads))
+    if tmax_px is not None:
+        tmax_px = np.ascontiguousarray(tmax_px, np.float32)
+        assert tmax_px.shape == (cam.height, cam.width)
+    rc = lib().orc_get_samples_from_voxels_ex(C.byref(tree), C.byref(cam), C.byref(opt), C.c_void_p(tmax_px.ctypes.data if tmax_px is not None else 0),
+                                              C.c_void_p(split.ctypes.data), C.c_void_p(sample.ctypes.data),
+                                              C.c_void_p(visited.ctypes.data if visited is not None else 0), int(track_visit), C.c_void_p(num.ctypes.data),
+                                              C.c_void_p(samples.ctypes.data), samples_dim, C.c_void_p(clusters.ctypes.data), C.byref(grid), _threads(n_threads))
     if rc != 0:
         raise RuntimeError("orc_get_samples_from_voxels: invalid arguments")
     return dict(num_samples=num, samples=samples, cluster_indices=clusters, split=split, sample=sample)

@@ -112,22 +112,30 @@ def _cam_args(cam_struct):
             (C.c_float * 12)(*list(cam_struct.c2w)))
 
 
-def get_samples_npz(npz_path, cam_struct, opt_struct, grid_struct, samples_dim):
-    """The reference's get_samples_trace_ray (rt_core.cuh:418-576) on the device, full frame."""
+def get_samples_npz(npz_path, cam_struct, opt_struct, grid_struct, samples_dim, tmax_px=None, dropin=False):
+    """The reference's get_samples_trace_ray (rt_core.cuh:418-576) on the device, full frame; tmax_px [h][w]: the depth attachment the
+    kernel reads when offscreen == false (renderer_kernel.cu:354-357).  Also returns the two tracker arrays.  dropin: the same call served by
+    libmnv.so through the sixteen-parameter binding of include/mnv_reference_binding.hpp instead of the reference's device code."""
     h = lib()
-    h.ref_get_samples_npz.restype = C.c_int
+    h.ref_get_samples_onscreen_npz.restype = C.c_int
     n, mg = cam_struct.width * cam_struct.height, opt_struct.max_guided_samples
     num = np.zeros(n, np.int16)
     samples = np.empty((n, mg, samples_dim), np.float32)
     clusters = np.empty((n, mg), np.int16)
+    split, sample = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32)
+    if tmax_px is not None:
+        tmax_px = np.ascontiguousarray(tmax_px, np.float32)
+        assert tmax_px.shape == (cam_struct.height, cam_struct.width)
     w, ht, fx, fy, cx, cy, c2w = _cam_args(cam_struct)
-    rc = h.ref_get_samples_npz(os.fsencode(npz_path), C.c_int(w), C.c_int(ht), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), c2w,
-                               C.byref(opt_struct), C.c_int(C.sizeof(opt_struct)), (C.c_int32 * 2)(*list(grid_struct.grid_dim)),
-                               (C.c_float * 3)(*list(grid_struct.min_position)), (C.c_float * 3)(*list(grid_struct.range)),
-                               C.c_int(samples_dim), C.c_void_p(num.ctypes.data), C.c_void_p(samples.ctypes.data), C.c_void_p(clusters.ctypes.data))
+    rc = h.ref_get_samples_onscreen_npz(os.fsencode(npz_path), C.c_int(w), C.c_int(ht), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), c2w,
+                                        C.byref(opt_struct), C.c_int(C.sizeof(opt_struct)), (C.c_int32 * 2)(*list(grid_struct.grid_dim)),
+                                        (C.c_float * 3)(*list(grid_struct.min_position)), (C.c_float * 3)(*list(grid_struct.range)),
+                                        C.c_int(samples_dim), C.c_void_p(tmax_px.ctypes.data if tmax_px is not None else 0), C.c_void_p(num.ctypes.data),
+                                        C.c_void_p(samples.ctypes.data), C.c_void_p(clusters.ctypes.data), C.c_void_p(split.ctypes.data),
+                                        C.c_void_p(sample.ctypes.data), C.c_int(int(dropin)))
     if rc != 0:
-        raise RuntimeError(f"ref_get_samples_npz failed with {rc}")
-    return dict(num_samples=num, samples=samples, cluster_indices=clusters)
+        raise RuntimeError(f"ref_get_samples_onscreen_npz failed with {rc}")
+    return dict(num_samples=num, samples=samples, cluster_indices=clusters, split=split, sample=sample)
 
 
 def render_nerf_results_npz(npz_path, cam_struct, opt_struct, sample_values, z_vals, offsets):

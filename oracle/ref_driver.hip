@@ -96,8 +96,9 @@ __global__ void ref_render_voxels_kernel(const internal::TreeSpec tree, const Ca
     rgba[idx * 4 + 3] = out[3];
 }
 
-// restated wrapper of get_samples_from_voxels_kernel (renderer_kernel.cu:329-363), offscreen
-__global__ void ref_get_samples_kernel(internal::TreeSpec tree, const CameraSpec cam, const RenderOptions opt,
+// restated wrapper of get_samples_from_voxels_kernel (renderer_kernel.cu:329-363); tmax_px: what the kernel reads from the depth surface when
+// offscreen == false (:354-357), a linear [h][w] array here; nullptr = offscreen
+__global__ void ref_get_samples_kernel(internal::TreeSpec tree, const CameraSpec cam, const RenderOptions opt, const float *tmax_px,
                                        torch::PackedTensorAccessor32<float, 2, torch::RestrictPtrTraits> to_split,
                                        torch::PackedTensorAccessor32<float, 2, torch::RestrictPtrTraits> to_sample,
                                        torch::PackedTensorAccessor32<int32_t, 1, torch::RestrictPtrTraits> visited,
@@ -115,6 +116,7 @@ __global__ void ref_get_samples_kernel(internal::TreeSpec tree, const CameraSpec
     float aa[3] = {opt.rot_dirs[0], opt.rot_dirs[1], opt.rot_dirs[2]};
     rodrigues(aa, vdir);
     float t_max = 1e9f;
+    if (tmax_px) t_max = tmax_px[idx];
     device::get_samples_trace_ray(tree, visited, dir, vdir, cen, opt, t_max, &to_split[idx][1], &to_split[idx][2],
                                   &to_split[idx][0], &to_sample[idx][1], &to_sample[idx][2], &to_sample[idx][0], false,
                                   &num_samples[idx], samples, cluster_indices, idx, grid_dim, min_position, range);
@@ -550,11 +552,27 @@ int ref_dropin_onscreen_npz(const char *npz_path, int width, int height, float f
     return 0;
 }
 
+int ref_get_samples_onscreen_npz(const char *npz_path, int width, int height, float fx, float fy, float cx, float cy, const float *c2w12,
+                                 const void *opt_bytes, int opt_size, const int32_t *grid_dim2, const float *min_position3,
+                                 const float *range3, int samples_dim, const float *tmax_host, int16_t *num_samples_host, float *samples_host,
+                                 int16_t *cluster_host, float *split_host, float *sample_host, int dropin);
+
 // The reference's get_samples_trace_ray on the tree in `npz_path` (full frame, offscreen).
 int ref_get_samples_npz(const char *npz_path, int width, int height, float fx, float fy, float cx, float cy, const float *c2w12,
                         const void *opt_bytes, int opt_size, const int32_t *grid_dim2, const float *min_position3,
                         const float *range3, int samples_dim, int16_t *num_samples_host, float *samples_host,
                         int16_t *cluster_host) {
+    return ref_get_samples_onscreen_npz(npz_path, width, height, fx, fy, cx, cy, c2w12, opt_bytes, opt_size, grid_dim2, min_position3, range3, samples_dim,
+                                        nullptr, num_samples_host, samples_host, cluster_host, nullptr, nullptr, 0);
+}
+
+// ... with the depth attachment of offscreen == false (tmax_host [h][w], or NULL) and, when asked for, the two tracker arrays [h*w][3].
+// dropin != 0: not the reference's device code but libmnv.so through the sixteen-parameter binding of include/mnv_reference_binding.hpp
+// (viewer::get_samples_from_voxels on the reference's own N3Tree / Camera / tensors) -- the same arrays must come back.
+int ref_get_samples_onscreen_npz(const char *npz_path, int width, int height, float fx, float fy, float cx, float cy, const float *c2w12,
+                                 const void *opt_bytes, int opt_size, const int32_t *grid_dim2, const float *min_position3,
+                                 const float *range3, int samples_dim, const float *tmax_host, int16_t *num_samples_host, float *samples_host,
+                                 int16_t *cluster_host, float *split_host, float *sample_host, int dropin) {
     using namespace viewer;
     if (opt_size != (int)sizeof(RenderOptions)) return -2;
     RenderOptions opt;
@@ -578,8 +596,18 @@ int ref_get_samples_npz(const char *npz_path, int width, int height, float fx, f
         torch::Tensor gd = torch::from_blob((void *)grid_dim2, {2}, torch::kInt32).clone().to(dev);
         torch::Tensor mp = torch::from_blob((void *)min_position3, {3}, torch::kFloat32).clone().to(dev);
         torch::Tensor rg = torch::from_blob((void *)range3, {3}, torch::kFloat32).clone().to(dev);
+        torch::Tensor tmax_dev;
+        if (tmax_host) tmax_dev = torch::from_blob((void *)tmax_host, {n}, torch::kFloat32).clone().to(dev);
         const int threads = 512, blocks = N_BLOCKS_NEEDED(n, threads);
+        if (dropin) {
+            float *depth_arr = tmax_host ? tmax_dev.data_ptr<float>() : nullptr;
+            hipStream_t stream = nullptr;
+            if (hipDeviceSynchronize() != hipSuccess) return -4;
+            get_samples_from_voxels(tree, *camera, opt, depth_arr, stream, to_split, to_sample, visited, false, tmax_host == nullptr, num_samples, samples,
+                                    clusters, gd, mp, rg);
+        } else
         hipLaunchKernelGGL(ref_get_samples_kernel, dim3(blocks), dim3(threads), 0, 0, viewer::internal::TreeSpec(tree), cam, opt,
+                           tmax_host ? tmax_dev.data_ptr<float>() : (const float *)nullptr,
                            to_split.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
                            to_sample.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
                            visited.packed_accessor32<int32_t, 1, torch::RestrictPtrTraits>(),
@@ -593,6 +621,8 @@ int ref_get_samples_npz(const char *npz_path, int width, int height, float fx, f
         memcpy(num_samples_host, num_samples.cpu().data_ptr(), n * 2);
         memcpy(samples_host, samples.cpu().data_ptr(), n * opt.max_guided_samples * samples_dim * 4);
         memcpy(cluster_host, clusters.cpu().data_ptr(), n * opt.max_guided_samples * 2);
+        if (split_host) memcpy(split_host, to_split.cpu().data_ptr(), n * 3 * 4);
+        if (sample_host) memcpy(sample_host, to_sample.cpu().data_ptr(), n * 3 * 4);
     } catch (const std::exception &e) {
         fprintf(stderr, "ref_get_samples_npz: %s\n", e.what());
         return -1;

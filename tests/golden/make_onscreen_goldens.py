@@ -4,7 +4,7 @@ the reference's own march (rt_core.cuh, compiled for gfx950 by oracle/Makefile.r
 oracle/ref_driver.hip because the reference reads both through surface objects, which gfx950 does not have.
 
 Run on the GPU box:   python tests/golden/make_onscreen_goldens.py gpurun_out/goldens
-then copy gpurun_out/goldens/ref_onscreen_*.npz and ref_onscreen_stats.json into tests/golden/ and commit them.
+then copy gpurun_out/goldens/ref_onscreen_*.npz, ref_guided_get_samples_onscreen.npz and ref_onscreen_stats.json into tests/golden/ and commit them.
 Inputs are tests/cases.py::onscreen_inputs (seeded); only the reference's float RGBA frames are stored."""
 import json
 import os
@@ -53,6 +53,34 @@ def main(outdir):
         print(name, json.dumps(stats[name]), flush=True)
         np.savez_compressed(os.path.join(outdir, f"ref_{name}.npz"), rgba=ref)
         os.remove(path)
+    # ---- get_samples_from_voxels with offscreen == false: the depth attachment limits every ray (renderer_kernel.cu:354-357)
+    import guided_cases
+    tree, cam, opt, dim = guided_cases.get_samples_setup(mnv)
+    opt.max_depth, opt.max_sample_count = 5, 9
+    tmax = guided_cases.onscreen_tmax(cam)
+    path = os.path.join(tmp, "guided_onscreen.npz")
+    tree.save_npz(path)
+    grid = guided_cases.cluster_grid(mnv.ClusterGrid)
+    ref = mnv_ref.get_samples_npz(path, cam.c, opt, grid, dim, tmax_px=tmax)
+    plain = mnv_ref.get_samples_npz(path, cam.c, opt, grid, dim)
+    drop = mnv_ref.get_samples_npz(path, cam.c, opt, grid, dim, tmax_px=tmax, dropin=True)
+    counts = np.full((tree.host_view().capacity, 8), 8, np.int16)   # what the driver gives the reference's tree (ref_driver.hip: sample_counts.fill_(8))
+    o = orc.get_samples(orc.tree_from_view(tree.host_view(), sample_counts=counts), cam.c, opt, grid, dim, tmax_px=tmax)
+    k = np.arange(opt.max_guided_samples)[None, :] < ref["num_samples"][:, None]   # emitted rows only
+
+    def same(a):
+        return bool(np.array_equal(ref["num_samples"], a["num_samples"]) and np.array_equal(ref["cluster_indices"][k], a["cluster_indices"][k]) and
+                    np.array_equal(ref["samples"][k].view(np.uint32), a["samples"][k].view(np.uint32)) and
+                    np.array_equal(ref["split"].view(np.uint32), a["split"].view(np.uint32)) and np.array_equal(ref["sample"].view(np.uint32), a["sample"].view(np.uint32)))
+
+    stats["guided_get_samples_onscreen"] = {
+        "oracle_equals_ref": same(o), "binding_dropin_equals_ref": same(drop),
+        "rays_changed_by_the_depth_image": int((ref["num_samples"] != plain["num_samples"]).sum()),
+        "total_samples": int(ref["num_samples"].astype(np.int64).sum()), "total_samples_offscreen": int(plain["num_samples"].astype(np.int64).sum())}
+    print("guided_get_samples_onscreen", stats["guided_get_samples_onscreen"], flush=True)
+    np.savez_compressed(os.path.join(outdir, "ref_guided_get_samples_onscreen.npz"), num_samples=ref["num_samples"],
+                        samples=np.where(k[..., None], ref["samples"], np.float32(-1)), cluster_indices=np.where(k, ref["cluster_indices"], -1).astype(np.int16),
+                        split=ref["split"], sample=ref["sample"])
     with open(os.path.join(outdir, "ref_onscreen_stats.json"), "w") as f:
         json.dump(stats, f, indent=1)
 

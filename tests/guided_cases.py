@@ -22,6 +22,19 @@ def get_samples_setup(mnv):
     return tree, cam, opt, 8  # samples_dim = 4 + 3 + 1
 
 
+def onscreen_tmax(cam, seed=105):
+    """Stand-in for the GL depth attachment of the reference's offscreen == false call of get_samples_from_voxels (renderer_kernel.cu:354-357):
+    world-space ray limits scattered around the camera's distance to the scene centre, 15 % "no mesh" (1e9f), 5 % "mesh at the lens" (0)."""
+    rng = np.random.default_rng(seed)
+    h, w = cam.height, cam.width
+    dist = float(np.linalg.norm(np.array(list(cam.c.c2w), np.float64)[9:12]))
+    tmax = (dist * rng.uniform(0.55, 1.35, size=(h, w))).astype(np.float32)
+    u = rng.uniform(size=(h, w))
+    tmax[u < 0.15] = np.float32(1e9)
+    tmax[u > 0.95] = np.float32(0.0)
+    return tmax
+
+
 def nerf_results_setup(mnv, case):
     spec = cases.CASES[case]
     tree = cases.make_tree(mnv, spec["tree"])

@@ -80,6 +80,31 @@ def test_guided_get_samples_matches_reference_device_code(mnv, orc):
     assert np.array_equal(o["samples"][k].view(np.uint32), g["samples"][k].view(np.uint32))
 
 
+def test_guided_get_samples_onscreen_matches_reference_device_code(mnv, orc):
+    """The same with the reference's offscreen == false input -- a depth image that limits every ray (renderer_kernel.cu:354-357): counts,
+    cluster ids, sample rows and both tracker arrays bit-identical to the reference's device code (tests/golden/make_onscreen_goldens.py)."""
+    import guided_cases
+    g = np.load(os.path.join(GOLD, "ref_guided_get_samples_onscreen.npz"))
+    st = json.load(open(os.path.join(GOLD, "ref_onscreen_stats.json")))["guided_get_samples_onscreen"]
+    assert st["oracle_equals_ref"] and st["binding_dropin_equals_ref"] and st["rays_changed_by_the_depth_image"] > 1000
+    assert st["total_samples"] < st["total_samples_offscreen"]
+    tree, cam, opt, dim = guided_cases.get_samples_setup(mnv)
+    opt.max_depth, opt.max_sample_count = 5, 9
+    counts = np.full((tree.host_view().capacity, 8), 8, np.int16)   # what the golden's driver gave the reference's tree
+    o = orc.get_samples(orc.tree_from_view(tree.host_view(), sample_counts=counts), cam.c, opt, guided_cases.cluster_grid(mnv.ClusterGrid), dim,
+                        tmax_px=guided_cases.onscreen_tmax(cam))
+    assert np.array_equal(o["num_samples"], g["num_samples"])
+    k = np.arange(opt.max_guided_samples)[None, :] < g["num_samples"][:, None]
+    assert np.array_equal(o["cluster_indices"][k], g["cluster_indices"][k])
+    assert np.array_equal(o["samples"][k].view(np.uint32), g["samples"][k].view(np.uint32))
+    assert np.array_equal(o["split"].view(np.uint32), g["split"].view(np.uint32)) and np.array_equal(o["sample"].view(np.uint32), g["sample"].view(np.uint32))
+    # NULL limits are the offscreen call
+    a = orc.get_samples(orc.tree_from_view(tree.host_view()), cam.c, opt, guided_cases.cluster_grid(mnv.ClusterGrid), dim)
+    b = orc.get_samples(orc.tree_from_view(tree.host_view()), cam.c, opt, guided_cases.cluster_grid(mnv.ClusterGrid), dim,
+                        tmax_px=np.full((cam.height, cam.width), 1e9, np.float32))
+    assert np.array_equal(a["num_samples"], b["num_samples"]) and np.array_equal(a["samples"].view(np.uint32), b["samples"].view(np.uint32))
+
+
 @pytest.mark.parametrize("case", ["sh4_d6", "rgba_d5"])
 def test_guided_nerf_results_matches_reference_device_code(mnv, orc, case):
     """composite_nerf_results (rt_core.cuh:334-416); contract 1e-4, asserted 1e-6."""

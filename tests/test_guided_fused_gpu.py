@@ -28,13 +28,13 @@ def fused_kernel(request, mnv, torch_gpu):
     assert int(diag[15].item()) == 0, "a spin-wait of the producer / consumer kernel ran into its watchdog"
 
 
-def four_step_frame(mnv, torch, tree, cam, opt, mlp, grid, max_g, dim):
+def four_step_frame(mnv, torch, tree, cam, opt, mlp, grid, max_g, dim, tmax_px=None):
     n_px = cam.width * cam.height
     num = torch.zeros(n_px, dtype=torch.int16, device="cuda")
     guided = torch.zeros((n_px, max_g, dim), dtype=torch.float32, device="cuda")
     guided[:, :, 0] = -1
     clusters = torch.zeros((n_px, max_g), dtype=torch.int16, device="cuda")
-    mnv.get_samples_from_voxels_accel(tree.accel, cam, opt, num, guided, clusters, grid)
+    mnv.get_samples_from_voxels_accel(tree.accel, cam, opt, num, guided, clusters, grid, tmax_px=tmax_px)
     offsets = torch.cumsum(num, 0)
     flat = guided.view(-1, dim)
     mask = flat[:, 0] >= 0
@@ -93,6 +93,43 @@ def test_fused_frame_equals_the_four_step_path(mnv, torch_gpu, case, need_viewdi
     torch.cuda.synchronize()
     assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref))
     mnv.accel_set_fused_kernel(tree.accel, -1)
+
+
+@pytest.mark.parametrize("case,need_viewdir,max_g", [("sh9_d7_aniso", False, 64), ("sh4_d6", True, 8)])
+def test_fused_frame_with_the_depth_image_of_the_live_call(mnv, torch_gpu, case, need_viewdir, max_g):
+    """The reference's render loop calls get_samples_from_voxels and render_nerf_results with offscreen == false: every ray stops at the depth
+    attachment's t_max (renderer_kernel.cu:354-357); the image under the volume enters render_nerf_results with weight 0.  The fused
+    frame with the same limits (mnv_render_guided_fused_track_ex) equals the four-step path with them, bit for bit, and differs from the
+    offscreen frame; limits of 1e9 everywhere are the offscreen frame."""
+    import guided_cases
+    torch = torch_gpu
+    spec = cases.CASES[case]
+    tree = cases.make_tree(mnv, spec["tree"])
+    v = tree.host_view()
+    tree.move_to_device()
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    opt.basis_minmax[0], opt.basis_minmax[1] = 0, max(v.basis_dim - 1, 0)
+    opt.max_guided_samples, opt.need_viewdir, opt.appearance_embedding = max_g, need_viewdir, -1
+    desc = mnv.mlp_desc(n_clusters=6, pos_octaves=4, dir_octaves=2, need_viewdir=need_viewdir, hidden_width=64, hidden_layers=2, out_dim=v.data_dim + 1)
+    mlp = mnv.Mlp(desc, mlp_cases.make_params(mnv, desc, seed=21))
+    grid = make_grid(mnv)
+    dim = 4 + (3 if need_viewdir else 0)
+    tmax = torch.from_numpy(guided_cases.onscreen_tmax(cam)).cuda()
+    ref, ref8, total = four_step_frame(mnv, torch, tree, cam, opt, mlp, grid, max_g, dim, tmax_px=tmax)
+    off, _, total_off = four_step_frame(mnv, torch, tree, cam, opt, mlp, grid, max_g, dim)
+    assert 0 < total < total_off and int((cases.bits(ref) != cases.bits(off)).any(axis=-1).sum()) > 1000
+    out = torch.full((cam.height, cam.width, 4), float("nan"), dtype=torch.float32, device="cuda")
+    out8 = torch.zeros((cam.height, cam.width, 4), dtype=torch.uint8, device="cuda")
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+    mnv.render_guided_fused(tree.accel, cam, opt, mlp, grid, rgba=out, rgba8=out8, sample_counter=counter, tmax_px=tmax)
+    torch.cuda.synchronize()
+    assert int(counter.item()) == total
+    assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref)) and np.array_equal(out8.cpu().numpy(), ref8)
+    out.fill_(float("nan"))
+    mnv.render_guided_fused(tree.accel, cam, opt, mlp, grid, rgba=out, tmax_px=torch.full((cam.height, cam.width), 1e9, dtype=torch.float32, device="cuda"))
+    torch.cuda.synchronize()
+    assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(off))
 
 
 def fused_kernel_choice(mnv):

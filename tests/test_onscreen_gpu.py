@@ -150,3 +150,81 @@ def test_eleven_parameter_binding_is_a_drop_in(mnv, orc, torch_gpu, tmp_path, pa
     cam_spec = dict(width=cs["width"], height=cs["height"], fx=cs["fx"], center=cs["center"], back=cs["back"], up=cs.get("up", (0.0, 0.0, 1.0)))
     got = mnv_ref.dropin_onscreen_npz(path, cam_spec, opt, image, tmax, path=path_kind, offscreen=offscreen)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("need_viewdir,embedding", [(True, 7), (False, -1)])
+def test_guided_samples_with_the_depth_image_bit_exact_on_both_layouts(mnv, orc, torch_gpu, need_viewdir, embedding):
+    """get_samples_from_voxels with offscreen == false (renderer_kernel.cu:354-357: t_max from the depth attachment): the walking kernel on
+    the reference's arrays (mnv_get_samples_from_voxels_ex, with visit marks) and the tuned kernel on the packed accel
+    (mnv_get_samples_from_voxels_accel_visit_ex) against the oracle -- counts, rows, cluster ids, both trackers, marks."""
+    import guided_cases
+    torch = torch_gpu
+    tree, cam, opt, _ = guided_cases.get_samples_setup(mnv)
+    opt.need_viewdir, opt.appearance_embedding, opt.max_guided_samples = need_viewdir, embedding, 8
+    opt.max_depth, opt.max_sample_count = 5, 9
+    dim = 4 + (3 if need_viewdir else 0) + (1 if embedding != -1 else 0)
+    grid = guided_cases.cluster_grid(mnv.ClusterGrid)
+    tmax = guided_cases.onscreen_tmax(cam)
+    v = tree.host_view()
+    sc = np.random.default_rng(4).integers(0, 14, size=(v.capacity, 8)).astype(np.int16)
+    visited_ref = np.zeros(v.capacity, np.int32)
+    want = orc.get_samples(orc.tree_from_view(v, sample_counts=sc), cam.c, opt, grid, dim, visited=visited_ref, track_visit=True, tmax_px=tmax)
+    off = orc.get_samples(orc.tree_from_view(v, sample_counts=sc), cam.c, opt, grid, dim)
+    assert int((want["num_samples"] != off["num_samples"]).sum()) > 1000  # the limits do something
+    tree.move_to_device(need_parent=True, need_sample_counts=True)
+    dv = tree.device_view()
+    sc_dev = torch.from_numpy(sc).cuda()
+    dv.sample_counts = sc_dev.data_ptr()
+    d_tmax = torch.from_numpy(tmax).cuda()
+    n = cam.width * cam.height
+    k = np.arange(8)[None, :] < want["num_samples"][:, None]
+
+    def buffers():
+        return (torch.zeros(n, dtype=torch.int16, device="cuda"), torch.full((n, 8, dim), -1.0, dtype=torch.float32, device="cuda"),
+                torch.full((n, 8), -1, dtype=torch.int16, device="cuda"), torch.full((n, 3), -1.0, dtype=torch.float32, device="cuda"),
+                torch.full((n, 3), -1.0, dtype=torch.float32, device="cuda"), torch.zeros(v.capacity, dtype=torch.int32, device="cuda"))
+
+    def check(num, samples, clusters, split, sample, visited, who):
+        torch.cuda.synchronize()
+        assert np.array_equal(num.cpu().numpy(), want["num_samples"]), who
+        got_s, got_c = samples.cpu().numpy(), clusters.cpu().numpy()
+        assert np.array_equal(cases.bits(got_s[k]), cases.bits(want["samples"][k])) and np.all(got_s[~k][:, 0] == -1.0), who
+        assert np.array_equal(got_c[k], want["cluster_indices"][k]), who
+        assert np.array_equal(cases.bits(split.cpu().numpy()), cases.bits(want["split"])) and np.array_equal(cases.bits(sample.cpu().numpy()), cases.bits(want["sample"])), who
+        assert np.array_equal(visited.cpu().numpy(), visited_ref), who
+
+    num, samples, clusters, split, sample, visited = buffers()
+    mnv.get_samples_from_voxels(dv, cam, opt, num, samples, clusters, grid, split_track=split, sample_track=sample, visited=visited, track_visit=True,
+                                tmax_px=d_tmax)
+    check(num, samples, clusters, split, sample, visited, "mnv_get_samples_from_voxels_ex")
+    num, samples, clusters, split, sample, visited = buffers()
+    mnv.get_samples_from_voxels_accel_visit(tree.accel, cam, opt, visited, dv.parent, num, samples, clusters, grid, split_track=split, sample_track=sample,
+                                            sample_counts=sc_dev, tmax_px=d_tmax)
+    check(num, samples, clusters, split, sample, visited, "mnv_get_samples_from_voxels_accel_visit_ex")
+
+
+def test_guided_samples_with_the_depth_image_against_the_live_reference_and_through_the_binding(mnv, orc, torch_gpu, tmp_path):
+    """The reference's own get_samples_trace_ray with t_max from a depth image, run here (oracle/_ref), reproduces the committed golden; and
+    viewer::get_samples_from_voxels with its sixteen original parameters (include/mnv_reference_binding.hpp, offscreen == false), served by
+    libmnv.so on the reference's N3Tree / Camera / tensors, returns the same arrays."""
+    import guided_cases
+    mnv_ref = require_live_reference()
+    g = np.load(os.path.join(GOLD, "ref_guided_get_samples_onscreen.npz"))
+    tree, cam, opt, dim = guided_cases.get_samples_setup(mnv)
+    opt.max_depth, opt.max_sample_count = 5, 9
+    grid = guided_cases.cluster_grid(mnv.ClusterGrid)
+    tmax = guided_cases.onscreen_tmax(cam)
+    path = str(tmp_path / "t.npz")
+    tree.save_npz(path)
+    k = np.arange(opt.max_guided_samples)[None, :] < g["num_samples"][:, None]
+    for dropin in (False, True):
+        got = mnv_ref.get_samples_npz(path, cam.c, opt, grid, dim, tmax_px=tmax, dropin=dropin)
+        assert np.array_equal(got["num_samples"], g["num_samples"]), dropin
+        assert np.array_equal(got["cluster_indices"][k], g["cluster_indices"][k]) and np.array_equal(cases.bits(got["samples"][k]), cases.bits(g["samples"][k])), dropin
+        assert np.array_equal(cases.bits(got["split"]), cases.bits(g["split"])) and np.array_equal(cases.bits(got["sample"]), cases.bits(g["sample"])), dropin
+    # offscreen == true through the binding: the offscreen golden
+    g0 = np.load(os.path.join(GOLD, "ref_guided_get_samples.npz"))
+    tree, cam, opt, dim = guided_cases.get_samples_setup(mnv)
+    got = mnv_ref.get_samples_npz(path, cam.c, opt, grid, dim, dropin=True)
+    k0 = np.arange(opt.max_guided_samples)[None, :] < g0["num_samples"][:, None]
+    assert np.array_equal(got["num_samples"], g0["num_samples"]) and np.array_equal(cases.bits(got["samples"][k0]), cases.bits(g0["samples"][k0]))
