@@ -230,11 +230,20 @@ def test_random_scene_guided_samples_bit_exact(mnv, orc, torch_gpu, seed):
         grid.range[i] = float(rng.uniform(0.5, 1.1) * ext_w[i])
     v = tree.host_view()
     sc = rng.integers(0, 14, size=(v.capacity, 8)).astype(np.int16)
-    ref = orc.get_samples(orc.tree_from_view(v, sample_counts=sc), cam.c, opt, grid, dim)
+    # every third scene in the reference's live call shape: a depth image scattered around the camera-to-box distance limits the rays
+    tmax = None
+    if seed % 3 == 1:
+        dist = float(np.linalg.norm(np.float64(spec["camera"]["center"])) + 1e-3)
+        tmax = (dist * rng.uniform(0.0, 2.0, size=(cam.height, cam.width))).astype(np.float32)
+        u = rng.uniform(size=(cam.height, cam.width))
+        tmax[u < 0.2] = np.float32(1e9)
+        tmax[u > 0.93] = np.float32(0.0)
+    ref = orc.get_samples(orc.tree_from_view(v, sample_counts=sc), cam.c, opt, grid, dim, tmax_px=tmax)
     tree.move_to_device(need_sample_counts=True)
     sc_dev = torch.from_numpy(sc).cuda()
+    d_tmax = None if tmax is None else torch.from_numpy(tmax).cuda()
     n = cam.width * cam.height
-    what = f"scene {500 + seed}: {spec}, viewdir {need_viewdir}, embedding {embedding}, quota {quota}"
+    what = f"scene {500 + seed}: {spec}, viewdir {need_viewdir}, embedding {embedding}, quota {quota}, depth image {tmax is not None}"
     k = np.arange(quota)[None, :] < ref["num_samples"][:, None]  # emitted rows; the rest keep the caller's fill on both sides
     for who in ("ref_layout", "accel"):
         num = torch.zeros(n, dtype=torch.int16, device="cuda")
@@ -243,11 +252,12 @@ def test_random_scene_guided_samples_bit_exact(mnv, orc, torch_gpu, seed):
         split = torch.full((n, 3), -1.0, dtype=torch.float32, device="cuda")
         sample = torch.full((n, 3), -1.0, dtype=torch.float32, device="cuda")
         if who == "accel":
-            mnv.get_samples_from_voxels_accel(tree.accel, cam, opt, num, samples, clusters, grid, split_track=split, sample_track=sample, sample_counts=sc_dev)
+            mnv.get_samples_from_voxels_accel(tree.accel, cam, opt, num, samples, clusters, grid, split_track=split, sample_track=sample, sample_counts=sc_dev,
+                                              tmax_px=d_tmax)
         else:
             dv = tree.device_view()
             dv.sample_counts = sc_dev.data_ptr()
-            mnv.get_samples_from_voxels(dv, cam, opt, num, samples, clusters, grid, split_track=split, sample_track=sample)
+            mnv.get_samples_from_voxels(dv, cam, opt, num, samples, clusters, grid, split_track=split, sample_track=sample, tmax_px=d_tmax)
         torch.cuda.synchronize()
         assert np.array_equal(num.cpu().numpy(), ref["num_samples"]), f"{who}: counts; {what}"
         got_s, got_c = samples.cpu().numpy(), clusters.cpu().numpy()
