@@ -400,6 +400,11 @@ int mnv_get_samples_from_voxels_accel(const mnv_accel *accel, const mnv_camera *
 int mnv_render_voxels_accel_visit(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, float *rgba_out,
                                   uint8_t *rgba8_out, float *split_track, float *sample_track, const int16_t *sample_counts, int32_t *visited,
                                   const int32_t *parent, void *hip_stream);
+/* ... in the reference's LIVE call shape (mnv_frame_inputs, offscreen == false: the tracker frame of cuda_renderer.cpp:141-142 with its depth
+ * image and the image under the volume); trackers and `visited` may be NULL (then mnv_render_voxels_accel_ex) */
+int mnv_render_voxels_accel_visit_ex(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                                     const mnv_frame_inputs *inputs, float *rgba_out, uint8_t *rgba8_out, float *split_track, float *sample_track,
+                                     const int16_t *sample_counts, int32_t *visited, const int32_t *parent, void *hip_stream);
 int mnv_get_samples_from_voxels_accel_visit(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
                                             float *split_track, float *sample_track, const int16_t *sample_counts, int32_t *visited,
                                             const int32_t *parent, int16_t *num_samples, float *samples, int32_t samples_dim,
@@ -735,6 +740,11 @@ int mnv_renderer_slot_guided_samples(mnv_renderer *r, int32_t slot, int64_t *cou
 /* VolumeRenderer::use_fused_guided (default on): guided-sampling frames that need nothing but the picture run as one kernel;
  * off = always the four steps of cuda_renderer.cpp:107-139 (sample march, compaction, networks, composite) */
 int mnv_renderer_set_fused_guided(mnv_renderer *r, int enable);
+/* The reference's render loop passes offscreen == false to all three launchers (cuda_renderer.cpp:111-113,135-136,141-142): the frame is limited by
+ * the GL pass's depth attachment and composited over its image.  tmax_px [height][width] float / rgba8_init [height][width][4] uint8: device
+ * arrays of the caller that stay valid while frames are rendered (either may be NULL; both NULL = the offline renderer again, the default).
+ * Single-rank rendering only. */
+int mnv_renderer_set_frame_inputs(mnv_renderer *r, const float *tmax_px, const uint8_t *rgba8_init);
 /* VolumeRenderer::set_ranks: several ranks (one process per GPU, each with its own renderer over the same scene and networks) render and
  * refine in lock step -- this rank marches its macro tiles, tracker rows and visit marks are all-gathered, the same refinement runs on
  * every replica, rank 0's frame is the whole picture.  comm NULL = back to one rank.  The communicator stays the caller's. */

@@ -309,6 +309,9 @@ _SIGNATURES = {
     "mnv_renderer_slot_guided_samples": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "mnv_renderer_last_slot": (C.c_int32, [C.c_void_p]),
     "mnv_renderer_set_fused_guided": (C.c_int, [C.c_void_p, C.c_int]),
+    "mnv_renderer_set_frame_inputs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mnv_render_voxels_accel_visit_ex": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, C.POINTER(FrameInputs), C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_renderer_set_ranks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "mnv_renderer_download_slot": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "mnv_set_timing": (None, [C.c_int]),
@@ -665,11 +668,20 @@ def render_voxels_accel_track(accel: int, cam: Camera, opt: RenderOptions, tile=
 
 
 def render_voxels_accel_visit(accel: int, cam: Camera, opt: RenderOptions, visited, parent, tile=None, rgba=None, rgba8=None, split_track=None,
-                              sample_track=None, sample_counts=None, stream: int = 0, part=None) -> None:
+                              sample_track=None, sample_counts=None, stream: int = 0, part=None, tmax_px=None, rgba8_init=None) -> None:
     """Tracker march on the packed accel that also leaves the reference's visit marks (march marks leaf chunks, closure adds ancestors).
-    part = (rank, world, tile_w, tile_h[, root_period]): only that rank's macro tiles, pixels and tracker rows in compact tile order."""
+    part = (rank, world, tile_w, tile_h[, root_period]): only that rank's macro tiles, pixels and tracker rows in compact tile order.
+    tmax_px / rgba8_init: the reference's offscreen == false inputs (whole-frame launches only)."""
     if tile is None:
         tile = (0, 0, cam.width, cam.height)
+    inputs = _frame_inputs(tmax_px, rgba8_init, tile[2] * tile[3])
+    if inputs is not None:
+        if part is not None:
+            raise MnvError(MNV_E_INVALID, "frame inputs are for whole-frame launches")
+        _check(lib().mnv_render_voxels_accel_visit_ex(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), C.byref(inputs), _ptr(rgba), _ptr(rgba8),
+                                                      _ptr(split_track), _ptr(sample_track), _ptr(sample_counts), _ptr(visited), _ptr(parent),
+                                                      C.c_void_p(stream)))
+        return
     if part is not None:
         px = _pixels(tile, 1, part)
         _check_out("rgba", rgba, px, "f32")
@@ -1049,6 +1061,15 @@ class Renderer:
 
     def set_fused_guided(self, enable: bool) -> None:
         _check(lib().mnv_renderer_set_fused_guided(self._h, int(enable)))
+
+    def set_frame_inputs(self, tmax_px=None, rgba8_init=None) -> None:
+        """The depth image ([height][width] float32) and the image under the volume ([height][width][4] uint8) of the reference's
+        offscreen == false frames: device tensors the caller keeps alive while frames are rendered; None, None = the offline renderer."""
+        px = self.width * self.height
+        inputs = _frame_inputs(tmax_px, rgba8_init, px)
+        self._inputs = (tmax_px, rgba8_init)  # keep the tensors alive
+        _check(lib().mnv_renderer_set_frame_inputs(self._h, C.c_void_p(inputs.tmax_px if inputs is not None else None),
+                                                   C.c_void_p(inputs.rgba8_init if inputs is not None else None)))
 
     def set_ranks(self, comm, tile_w: int = 64, tile_h: int = 24) -> None:
         """Several ranks refine one scene in lock step (VolumeRenderer::set_ranks); comm: mnv.Comm or None."""

@@ -430,6 +430,24 @@ int mnv_render_voxels_accel_visit(const mnv_accel *accel, const mnv_camera *cam,
     return render_accel(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, &track, hip_stream);
 }
 
+int mnv_render_voxels_accel_visit_ex(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile,
+                                     const mnv_frame_inputs *inputs, float *rgba_out, uint8_t *rgba8_out, float *split_track, float *sample_track,
+                                     const int16_t *sample_counts, int32_t *visited, const int32_t *parent, void *hip_stream) {
+    if (!opt) return set_error(MNV_E_INVALID, "options are null");
+    if (!split_track && !sample_track && !visited) return mnv_render_voxels_accel_ex(accel, cam, opt, tile, inputs, rgba_out, rgba8_out, hip_stream);
+    if (visited && !parent) return set_error(MNV_E_INVALID, "visit marks on the packed layout need the parent array (the ancestors of the marked chunks)");
+    const mnv_partition whole = {0, 1, 0, 0, 0};
+    AccelTrack track = {};
+    track.split_track = split_track;
+    track.sample_track = sample_track;
+    track.sample_counts = sample_counts;
+    track.max_depth = opt->max_depth;
+    track.max_sample_count = opt->max_sample_count;
+    track.visited = visited;
+    track.parent = parent;
+    return render_accel(accel, cam, 1, opt, tile, whole, rgba_out, rgba8_out, &track, hip_stream, inputs);
+}
+
 int mnv_render_voxels_accel_visit_part(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, mnv_partition part,
                                        float *rgba_out, uint8_t *rgba8_out, float *split_track, float *sample_track, const int16_t *sample_counts,
                                        int32_t *visited, const int32_t *parent, void *hip_stream) {

@@ -354,6 +354,14 @@ int mnv_renderer_set_fused_guided(mnv_renderer *r, int enable) {
     return MNV_OK;
 }
 
+int mnv_renderer_set_frame_inputs(mnv_renderer *r, const float *tmax_px, const uint8_t *rgba8_init) {
+    if (!r) return mnv::set_error(MNV_E_INVALID, "null argument");
+    return guarded([&] {
+        r->rend.set_frame_inputs(tmax_px, rgba8_init);
+        return MNV_OK;
+    });
+}
+
 int mnv_renderer_set_ranks(mnv_renderer *r, mnv_comm *comm, int32_t tile_w, int32_t tile_h) {
     if (!r) return mnv::set_error(MNV_E_INVALID, "null argument");
     if (comm && (tile_w < 8 || tile_h < 8 || tile_w % 8 || tile_h % 8)) return mnv::set_error(MNV_E_INVALID, "macro tiles are multiples of 8 pixels");

@@ -46,6 +46,8 @@ struct DeviceBuffer {
 struct VolumeRenderer::Impl {
     N3Tree *tree = nullptr;
     long max_tree_capacity = 0;
+    mnv_frame_inputs inputs = {nullptr, nullptr};  // offscreen == false: the caller's depth image and image (set_frame_inputs); the _ex entry
+                                                   // points take a block of two nulls as offscreen == true
     // Frames in flight.  The reference calls render_voxels once per frame on one stream (cuda_renderer.cpp:141-142); a single
     // 1080p launch of the march ends in a tail of a few wavefronts finishing the longest rays (a third of the wave slots idle
     // on average), so plain frames rotate over `slots` -- each with its own stream and frame buffers -- and the tail of frame k
@@ -407,8 +409,18 @@ void VolumeRenderer::clear() { impl_->tree = nullptr; }
 const mnv_mlp *VolumeRenderer::model() const { return impl_->mlp; }
 const mnv_cluster_grid &VolumeRenderer::cluster_grid() const { return impl_->grid; }
 
+void VolumeRenderer::set_frame_inputs(const float *tmax_px_device, const uint8_t *rgba8_init_device) {
+    Impl &I = *impl_;
+    if (I.comm && (tmax_px_device || rgba8_init_device)) throw std::runtime_error("frame inputs (offscreen == false) are for one rank");
+    I.sync_all();
+    I.inputs.tmax_px = tmax_px_device;
+    I.inputs.rgba8_init = rgba8_init_device;
+    I.can_reuse_results = false;  // the samples of the last guided frame were limited by the previous depth image
+}
+
 void VolumeRenderer::set_ranks(mnv_comm *comm, int tile_w, int tile_h) {
     Impl &I = *impl_;
+    if (comm && (I.inputs.tmax_px || I.inputs.rgba8_init)) throw std::runtime_error("frame inputs (offscreen == false) are for one rank");
     I.sync_all();
     I.comm = comm;
     if (!comm) {
@@ -468,8 +480,9 @@ void VolumeRenderer::render() {
                     hip_check(hipHostMalloc((void **)&S.count_host, sizeof(unsigned long long), hipHostMallocDefault), "hipHostMalloc(sample count)");
                 }
                 hip_check(hipMemsetAsync(S.count_dev, 0, sizeof(unsigned long long), S.stream), "clear sample counter");
-                mnv_check(mnv_render_guided_fused(I.tree->device.accel, &cv, options.c_abi(), full, I.mlp, &I.grid, I.rgba, I.rgba8, S.count_dev, S.stream),
-                          "mnv_render_guided_fused");
+                mnv_check(mnv_render_guided_fused_track_ex(I.tree->device.accel, &cv, options.c_abi(), full, &I.inputs, I.mlp, &I.grid, I.rgba, I.rgba8, nullptr,
+                                                           nullptr, nullptr, nullptr, nullptr, S.count_dev, S.stream),
+                          "mnv_render_guided_fused_track_ex");
                 hip_check(hipMemcpyAsync(S.count_host, S.count_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, S.stream), "read sample counter");
                 S.counted = true;
                 stats.fused = true;
@@ -477,7 +490,8 @@ void VolumeRenderer::render() {
                 ++I.quiet_frames;           // (what refine_after_frame does for a frame without splitting)
             } else {
                 S.counted = false;
-                mnv_check(mnv_render_voxels_accel(I.tree->device.accel, &cv, options.c_abi(), full, I.rgba, I.rgba8, S.stream), "mnv_render_voxels_accel");
+                mnv_check(mnv_render_voxels_accel_ex(I.tree->device.accel, &cv, options.c_abi(), full, &I.inputs, I.rgba, I.rgba8, S.stream),
+                          "mnv_render_voxels_accel_ex");
             }
             stats.used_accel = true;
             stats.capacity = I.tree->capacity;
@@ -495,7 +509,8 @@ void VolumeRenderer::render() {
     }
     if (I.tree == nullptr || I.tree->N <= 0) {
         mnv_tree_view empty = {};  // N == 0: background only (renderer_kernel.cu:266)
-        mnv_check(mnv_render_voxels(&empty, &cv, options.c_abi(), full, I.rgba, I.rgba8, nullptr, nullptr, nullptr, 0, I.stream), "mnv_render_voxels");
+        mnv_check(mnv_render_voxels_ex(&empty, &cv, options.c_abi(), full, &I.inputs, I.rgba, I.rgba8, nullptr, nullptr, nullptr, 0, I.stream),
+                  "mnv_render_voxels_ex");
         return;
     }
     N3Tree &tree = *I.tree;
@@ -542,10 +557,10 @@ void VolumeRenderer::render() {
         unsigned long long *counter = I.fused_counter.get<unsigned long long>(1);
         hip_check(hipMemsetAsync(counter, 0, sizeof(unsigned long long), I.stream), "clear sample counter");
         // with refinement on as well (configs[4]) the same kernel also writes the trackers and the visit marks
-        mnv_check(mnv_render_guided_fused_track(tree.device.accel, &cv, options.c_abi(), full, I.mlp, &I.grid, I.rgba, I.rgba8, split, sample,
-                                                split ? tree.device.sample_counts : nullptr, track_visit ? visited : nullptr, tree.device.parent, counter,
-                                                I.stream),
-                  "mnv_render_guided_fused_track");
+        mnv_check(mnv_render_guided_fused_track_ex(tree.device.accel, &cv, options.c_abi(), full, &I.inputs, I.mlp, &I.grid, I.rgba, I.rgba8, split, sample,
+                                                   split ? tree.device.sample_counts : nullptr, track_visit ? visited : nullptr, tree.device.parent,
+                                                   counter, I.stream),
+                  "mnv_render_guided_fused_track_ex");
         I.read_count_later(counter);
         stats.used_accel = true;
         stats.fused = true;
@@ -562,14 +577,14 @@ void VolumeRenderer::render() {
             if (tree.device.accel && !I.accel_stale && (!track_visit || tree.device.parent)) {
                 // visit marks on the packed layout: the march marks leaf chunks, a closure pass adds their ancestors
                 stats.used_accel = true;
-                mnv_check(mnv_get_samples_from_voxels_accel_visit(tree.device.accel, &cv, options.c_abi(), full, split, sample, tree.device.sample_counts,
-                                                                  track_visit ? visited : nullptr, tree.device.parent, num, guided, samples_dim, clusters,
-                                                                  &I.grid, I.stream),
-                          "mnv_get_samples_from_voxels_accel_visit");
+                mnv_check(mnv_get_samples_from_voxels_accel_visit_ex(tree.device.accel, &cv, options.c_abi(), full, &I.inputs, split, sample,
+                                                                     tree.device.sample_counts, track_visit ? visited : nullptr, tree.device.parent, num, guided,
+                                                                     samples_dim, clusters, &I.grid, I.stream),
+                          "mnv_get_samples_from_voxels_accel_visit_ex");
             } else {
-                mnv_check(mnv_get_samples_from_voxels(&dv, &cv, options.c_abi(), full, split, sample, visited, track_visit, num, guided, samples_dim,
-                                                      clusters, &I.grid, I.stream),
-                          "mnv_get_samples_from_voxels");
+                mnv_check(mnv_get_samples_from_voxels_ex(&dv, &cv, options.c_abi(), full, &I.inputs, split, sample, visited, track_visit, num, guided,
+                                                         samples_dim, clusters, &I.grid, I.stream),
+                          "mnv_get_samples_from_voxels_ex");
             }
             // one call in the steady state: the packed buffers keep the size of the previous frames and grow when a frame
             // emits more (the call then reports the total it needs)
@@ -598,14 +613,12 @@ void VolumeRenderer::render() {
                   "mnv_render_nerf_results");
     } else if (tree.device.accel && !I.accel_stale && (!track_visit || tree.device.parent)) {
         stats.used_accel = true;
-        if (split || track_visit)
-            mnv_check(mnv_render_voxels_accel_visit(tree.device.accel, &cv, options.c_abi(), full, I.rgba, I.rgba8, split, sample,
-                                                    tree.device.sample_counts, track_visit ? visited : nullptr, tree.device.parent, I.stream),
-                      "mnv_render_voxels_accel_visit");
-        else
-            mnv_check(mnv_render_voxels_accel(tree.device.accel, &cv, options.c_abi(), full, I.rgba, I.rgba8, I.stream), "mnv_render_voxels_accel");
+        mnv_check(mnv_render_voxels_accel_visit_ex(tree.device.accel, &cv, options.c_abi(), full, &I.inputs, I.rgba, I.rgba8, split, sample,
+                                                   tree.device.sample_counts, track_visit ? visited : nullptr, tree.device.parent, I.stream),
+                  "mnv_render_voxels_accel_visit_ex");
     } else {
-        mnv_check(mnv_render_voxels(&dv, &cv, options.c_abi(), full, I.rgba, I.rgba8, split, sample, visited, track_visit, I.stream), "mnv_render_voxels");
+        mnv_check(mnv_render_voxels_ex(&dv, &cv, options.c_abi(), full, &I.inputs, I.rgba, I.rgba8, split, sample, visited, track_visit, I.stream),
+                  "mnv_render_voxels_ex");
     }
 
     if (refine) I.refine_after_frame(options, stats, seed, track_visit);

@@ -92,6 +92,11 @@ struct VolumeRenderer {
     //   * gathers the tiles to rank 0 (mnv_gather_tiles) and un-permutes them there: rank 0's frame is the whole picture.
     // Needs the packed accel; guided sampling needs a network the fused kernel covers.  `comm` stays the caller's.
     void set_ranks(mnv_comm *comm, int tile_w = 64, int tile_h = 24);
+    // The reference's render loop calls its three launchers with offscreen == false (cuda_renderer.cpp:111-113,135-136,141-142): rays stop at the
+    // depth attachment of the GL pass, the frame is composited over its image.  Here the two attachments are device arrays of the caller
+    // ([height][width] float, [height][width][4] uint8; either may be null) that stay valid while frames are rendered; both null (the default) is
+    // the offline renderer.  One rank only.
+    void set_frame_inputs(const float *tmax_px_device, const uint8_t *rgba8_init_device);
 
     // What the last render() did (the reference prints these to stdout).
     struct FrameStats {

@@ -228,3 +228,78 @@ def test_guided_samples_with_the_depth_image_against_the_live_reference_and_thro
     got = mnv_ref.get_samples_npz(path, cam.c, opt, grid, dim, dropin=True)
     k0 = np.arange(opt.max_guided_samples)[None, :] < g0["num_samples"][:, None]
     assert np.array_equal(got["num_samples"], g0["num_samples"]) and np.array_equal(cases.bits(got["samples"][k0]), cases.bits(g0["samples"][k0]))
+
+
+def test_host_renderer_renders_the_live_frame(mnv, orc, torch_gpu):
+    """VolumeRenderer with set_frame_inputs: the reference's render loop passes offscreen == false to every launcher (cuda_renderer.cpp:111-113,
+    135-136, 141-142).  A plain frame through the host renderer, with the depth image and the image under the volume, equals the oracle's
+    frame of the same inputs bit for bit (float and RGBA8); a guided-sampling frame equals the fused entry point called with the same depth
+    image, on the fused and on the four-step path of the renderer; without inputs it is the offline renderer again.
+    (One render() per renderer: Camera::_update normalises v_back on every call, as the reference's does (camera.cpp:54-82), and a
+    normalised vector normalised again may move by an ulp -- this case's camera alternates between two matrices from frame to frame.)"""
+    import ctypes as C
+
+    import mlp_cases
+    from test_renderer_refine_gpu import make_grid
+    torch = torch_gpu
+    name = "onscreen_both"
+    base = cases.ONSCREEN[name][0]
+    spec = cases.CASES[base]
+    tree = cases.make_tree(mnv, spec["tree"])
+    v = tree.host_view()
+    cs = spec["camera"]
+    cam = cases.make_camera(mnv, cs)
+    opt = cases.make_options(mnv, spec["options"])
+    opt.basis_minmax[0], opt.basis_minmax[1] = 0, max(v.basis_dim - 1, 0)
+    tmax, image = cases.onscreen_inputs(name, cam)
+    d_tmax, d_image = torch.from_numpy(tmax).cuda(), torch.from_numpy(image).cuda()
+    desc = mnv.mlp_desc(n_clusters=6, pos_octaves=4, dir_octaves=2, need_viewdir=False, hidden_width=64, hidden_layers=2, out_dim=v.data_dim + 1)
+    params = mlp_cases.make_params(mnv, desc, seed=21)
+    grid = make_grid(mnv)
+
+    def renderer(model=False, **over):
+        r = mnv.Renderer()
+        r.resize(cs["width"], cs["height"])
+        r.set(tree, v.capacity)
+        if model:
+            r.set_model(desc, params, grid)
+        r.set_camera(cs["center"], cs["back"], fx=cs["fx"], up=cs.get("up", (0.0, 0.0, 1.0)))
+        C.memmove(C.byref(r.options), C.byref(opt), C.sizeof(opt))  # every option of the case
+        for k, val in over.items():
+            setattr(r.options, k, val)
+        return r
+
+    t = orc.tree_from_view(v)
+    want = orc.render(t, cam.c, opt, want_rgba8=True, tmax_px=tmax, rgba8_init=image)
+    off = orc.render(t, cam.c, opt, want_rgba8=True)
+    assert int((cases.bits(want["rgba"]) != cases.bits(off["rgba"])).any(axis=-1).sum()) > 5000
+    r = renderer()
+    r.set_frame_inputs(d_tmax, d_image)
+    r.render()
+    f32, u8 = r.download(want_rgba8=True)
+    assert np.array_equal(cases.bits(f32), cases.bits(want["rgba"])) and np.array_equal(u8, want["rgba8"])
+    r = renderer()
+    r.set_frame_inputs(d_tmax, d_image)
+    r.set_frame_inputs(None, None)
+    r.render()
+    f32, u8 = r.download(want_rgba8=True)
+    assert np.array_equal(cases.bits(f32), cases.bits(off["rgba"])) and np.array_equal(u8, off["rgba8"])
+    # guided sampling: the renderer's frame against the fused entry point with the same depth image
+    opt2 = mnv.RenderOptions()
+    C.memmove(C.byref(opt2), C.byref(opt), C.sizeof(opt2))
+    opt2.use_guided_sampling, opt2.max_guided_samples = True, 16
+    tree.move_to_device()
+    out = torch.empty((cam.height, cam.width, 4), dtype=torch.float32, device="cuda")
+    mnv.render_guided_fused(tree.accel, cam, opt2, mnv.Mlp(desc, params), grid, rgba=out, tmax_px=d_tmax)
+    torch.cuda.synchronize()
+    direct = out.cpu().numpy()
+    mnv.render_guided_fused(tree.accel, cam, opt2, mnv.Mlp(desc, params), grid, rgba=out)
+    torch.cuda.synchronize()
+    assert int((cases.bits(out.cpu().numpy()) != cases.bits(direct)).any(axis=-1).sum()) > 1000  # the depth image matters
+    for fused in (True, False):
+        r = renderer(model=True, use_guided_sampling=True, max_guided_samples=16)
+        r.set_frame_inputs(d_tmax, d_image)
+        r.set_fused_guided(fused)
+        st = r.render()
+        assert bool(st["fused"]) == fused
+        assert np.array_equal(cases.bits(r.download()), cases.bits(direct)), f"renderer's guided frame (fused {fused})"
