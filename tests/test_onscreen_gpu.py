@@ -303,3 +303,49 @@ def test_host_renderer_renders_the_live_frame(mnv, orc, torch_gpu):
         st = r.render()
         assert bool(st["fused"]) == fused
         assert np.array_equal(cases.bits(r.download()), cases.bits(direct)), f"renderer's guided frame (fused {fused})"
+
+
+@pytest.mark.parametrize("name", ["onscreen_both", "onscreen_terrain"])
+def test_tracker_frame_of_the_live_call_on_both_layouts(mnv, orc, torch_gpu, name):
+    """The frame the reference's render loop actually launches (cuda_renderer.cpp:141-142): render_voxels with the refinement trackers, visit marks
+    AND offscreen == false.  mnv_render_voxels_ex on the reference's arrays and mnv_render_voxels_accel_visit_ex on the packed accel against the
+    oracle: float and RGBA8 frame, both tracker arrays, the marks."""
+    torch = torch_gpu
+    base = cases.ONSCREEN[name][0]
+    spec = cases.CASES[base]
+    tree = cases.make_tree(mnv, spec["tree"])
+    v = tree.host_view()
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    opt.basis_minmax[0], opt.basis_minmax[1] = 0, max(v.basis_dim - 1, 0)
+    opt.max_depth, opt.max_sample_count = 5, 9
+    tmax, image = cases.onscreen_inputs(name, cam)
+    sc = np.random.default_rng(7).integers(0, 14, size=(v.capacity, 8)).astype(np.int16)
+    visited_ref = np.zeros(v.capacity, np.int32)
+    want = orc.render(orc.tree_from_view(v, sample_counts=sc), cam.c, opt, want_rgba8=True, want_trackers=True, visited=visited_ref, track_visit=True,
+                      tmax_px=tmax, rgba8_init=image)
+    off = orc.render(orc.tree_from_view(v, sample_counts=sc), cam.c, opt, want_trackers=True)
+    assert int((cases.bits(want["split"]) != cases.bits(off["split"])).any(axis=-1).sum()) > 100  # the depth image changes what the trackers see
+    tree.move_to_device(need_parent=True, need_sample_counts=True)
+    dv = tree.device_view()
+    sc_dev = torch.from_numpy(sc).cuda()
+    dv.sample_counts = sc_dev.data_ptr()
+    d_tmax, d_image = torch.from_numpy(tmax).cuda(), torch.from_numpy(image).cuda()
+    n = cam.width * cam.height
+    for who in ("ref_layout", "accel"):
+        rgba = torch.full((cam.height, cam.width, 4), float("nan"), dtype=torch.float32, device="cuda")
+        rgba8 = torch.zeros((cam.height, cam.width, 4), dtype=torch.uint8, device="cuda")
+        split = torch.full((n, 3), -1.0, dtype=torch.float32, device="cuda")
+        sample = torch.full((n, 3), -1.0, dtype=torch.float32, device="cuda")
+        visited = torch.zeros(v.capacity, dtype=torch.int32, device="cuda")
+        if who == "accel":
+            mnv.render_voxels_accel_visit(tree.accel, cam, opt, visited, dv.parent, rgba=rgba, rgba8=rgba8, split_track=split, sample_track=sample,
+                                          sample_counts=sc_dev, tmax_px=d_tmax, rgba8_init=d_image)
+        else:
+            mnv.render_voxels(dv, cam, opt, rgba=rgba, rgba8=rgba8, split_track=split, sample_track=sample, visited=visited, track_visit=True,
+                              tmax_px=d_tmax, rgba8_init=d_image)
+        torch.cuda.synchronize()
+        assert np.array_equal(cases.bits(rgba.cpu().numpy()), cases.bits(want["rgba"])) and np.array_equal(rgba8.cpu().numpy(), want["rgba8"]), who
+        assert np.array_equal(cases.bits(split.cpu().numpy().reshape(want["split"].shape)), cases.bits(want["split"])), who
+        assert np.array_equal(cases.bits(sample.cpu().numpy().reshape(want["sample"].shape)), cases.bits(want["sample"])), who
+        assert np.array_equal(visited.cpu().numpy(), visited_ref), who
