@@ -88,20 +88,27 @@ def dropin_onscreen_npz(npz_path, cam_spec, opt_struct, image, depth, path=0, of
     return image
 
 
-def render_track_npz(npz_path, cam_struct, opt_struct, capacity, sample_counts=None, track_visit=True):
-    """The reference's march with its trackers: dict(rgba [h,w,4], split [h,w,3], sample [h,w,3], visited [capacity])."""
+def render_track_npz(npz_path, cam_struct, opt_struct, capacity, sample_counts=None, track_visit=True, tmax_px=None, rgba8_init=None):
+    """The reference's march with its trackers: dict(rgba [h,w,4], split [h,w,3], sample [h,w,3], visited [capacity]).  tmax_px / rgba8_init: the
+    two surfaces of the render loop's call (offscreen == false, cuda_renderer.cpp:141-142)."""
     h = lib()
     w, ht = cam_struct.width, cam_struct.height
     rgba = np.empty((ht, w, 4), np.float32)
     split, sample = np.empty((ht, w, 3), np.float32), np.empty((ht, w, 3), np.float32)
     visited = np.zeros(capacity, np.int32)
     sc = None if sample_counts is None else np.ascontiguousarray(sample_counts, np.int16)
-    h.ref_render_track_npz.restype = C.c_int
+    h.ref_render_track_onscreen_npz.restype = C.c_int
+    tm = None if tmax_px is None else np.ascontiguousarray(tmax_px, np.float32)
+    im = None if rgba8_init is None else np.ascontiguousarray(rgba8_init, np.uint8)
+    assert tm is None or tm.shape == (ht, w)
+    assert im is None or im.shape == (ht, w, 4)
     wd, hh, fx, fy, cx, cy, c2w = _cam_args(cam_struct)
-    rc = h.ref_render_track_npz(os.fsencode(npz_path), C.c_int(wd), C.c_int(hh), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), c2w,
-                                C.byref(opt_struct), C.c_int(C.sizeof(opt_struct)),
-                                C.c_void_p(sc.ctypes.data) if sc is not None else C.c_void_p(0), C.c_int(int(track_visit)), C.c_void_p(rgba.ctypes.data),
-                                C.c_void_p(split.ctypes.data), C.c_void_p(sample.ctypes.data), C.c_void_p(visited.ctypes.data))
+    rc = h.ref_render_track_onscreen_npz(os.fsencode(npz_path), C.c_int(wd), C.c_int(hh), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), c2w,
+                                         C.byref(opt_struct), C.c_int(C.sizeof(opt_struct)),
+                                         C.c_void_p(sc.ctypes.data) if sc is not None else C.c_void_p(0), C.c_int(int(track_visit)),
+                                         C.c_void_p(tm.ctypes.data if tm is not None else 0), C.c_void_p(im.ctypes.data if im is not None else 0),
+                                         C.c_void_p(rgba.ctypes.data), C.c_void_p(split.ctypes.data), C.c_void_p(sample.ctypes.data),
+                                         C.c_void_p(visited.ctypes.data))
     if rc != 0:
         raise RuntimeError(f"ref_render_track_npz failed with {rc}")
     return dict(rgba=rgba, split=split, sample=sample, visited=visited)

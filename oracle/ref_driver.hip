@@ -250,9 +250,22 @@ int ref_render_onscreen_npz(const char *npz_path, int width, int height, float f
 // The reference's render_voxels_trace_ray with its refinement trackers and visit marks (rt_core.cuh:132-134,179-180,237-252,
 // 308-321) returned to the host.  sample_counts_host: [capacity][8] int16 uploaded into the tree's device array, or NULL for
 // all 8 (the reference leaves the device array uninitialised, n3tree.cpp:235-241).
+int ref_render_track_onscreen_npz(const char *npz_path, int width, int height, float fx, float fy, float cx, float cy, const float *c2w12,
+                                  const void *opt_bytes, int opt_size, const int16_t *sample_counts_host, int track_visit, const float *tmax_host,
+                                  const uint8_t *image_host, float *rgba_host, float *split_host, float *sample_host, int32_t *visited_host);
+
 int ref_render_track_npz(const char *npz_path, int width, int height, float fx, float fy, float cx, float cy, const float *c2w12,
                          const void *opt_bytes, int opt_size, const int16_t *sample_counts_host, int track_visit, float *rgba_host,
                          float *split_host, float *sample_host, int32_t *visited_host) {
+    return ref_render_track_onscreen_npz(npz_path, width, height, fx, fy, cx, cy, c2w12, opt_bytes, opt_size, sample_counts_host, track_visit, nullptr,
+                                         nullptr, rgba_host, split_host, sample_host, visited_host);
+}
+
+// ... in the call shape of the render loop (cuda_renderer.cpp:141-142): trackers and marks AND offscreen == false -- tmax_host [h][w] and
+// image_host [h][w][4] stand for the two surfaces the kernel reads (either may be NULL)
+int ref_render_track_onscreen_npz(const char *npz_path, int width, int height, float fx, float fy, float cx, float cy, const float *c2w12,
+                                  const void *opt_bytes, int opt_size, const int16_t *sample_counts_host, int track_visit, const float *tmax_host,
+                                  const uint8_t *image_host, float *rgba_host, float *split_host, float *sample_host, int32_t *visited_host) {
     using namespace viewer;
     if (opt_size != (int)sizeof(RenderOptions)) return -2;
     RenderOptions opt;
@@ -275,10 +288,15 @@ int ref_render_track_npz(const char *npz_path, int width, int height, float fx, 
         torch::Tensor out = torch::zeros({n, 4}, fopt);
         torch::Tensor to_split = torch::full({n, 3}, -1.f, fopt), to_sample = torch::full({n, 3}, -1.f, fopt);  // cuda_renderer.cpp:97-98
         torch::Tensor visited = torch::zeros({tree.capacity}, torch::TensorOptions().device(torch::kCUDA).dtype(torch::kInt32));
+        torch::Tensor tmax, image;
+        if (tmax_host) tmax = torch::from_blob((void *)tmax_host, {n}, torch::kFloat32).clone().to(torch::kCUDA);
+        if (image_host) image = torch::from_blob((void *)image_host, {n, 4}, torch::kUInt8).clone().to(torch::kCUDA);
         const int threads = 512;
         const int blocks = N_BLOCKS_NEEDED(n, threads);
         hipLaunchKernelGGL(ref_render_voxels_kernel, dim3(blocks), dim3(threads), 0, 0, viewer::internal::TreeSpec(tree), cam, opt,
-                           out.data_ptr<float>(), (const float *)nullptr, (const uint8_t *)nullptr, to_split.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
+                           out.data_ptr<float>(), tmax_host ? (const float *)tmax.data_ptr<float>() : (const float *)nullptr,
+                           image_host ? (const uint8_t *)image.data_ptr<uint8_t>() : (const uint8_t *)nullptr,
+                           to_split.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
                            to_sample.packed_accessor32<float, 2, torch::RestrictPtrTraits>(),
                            visited.packed_accessor32<int32_t, 1, torch::RestrictPtrTraits>(), track_visit != 0);
         if (hipDeviceSynchronize() != hipSuccess) return -4;

@@ -4,7 +4,7 @@ the reference's own march (rt_core.cuh, compiled for gfx950 by oracle/Makefile.r
 oracle/ref_driver.hip because the reference reads both through surface objects, which gfx950 does not have.
 
 Run on the GPU box:   python tests/golden/make_onscreen_goldens.py gpurun_out/goldens
-then copy gpurun_out/goldens/ref_onscreen_*.npz, ref_guided_get_samples_onscreen.npz and ref_onscreen_stats.json into tests/golden/ and commit them.
+then copy gpurun_out/goldens/ref_onscreen_*.npz (incl. ref_onscreen_trackers_both.npz), ref_guided_get_samples_onscreen.npz and ref_onscreen_stats.json into tests/golden/ and commit them.
 Inputs are tests/cases.py::onscreen_inputs (seeded); only the reference's float RGBA frames are stored."""
 import json
 import os
@@ -81,6 +81,32 @@ def main(outdir):
     np.savez_compressed(os.path.join(outdir, "ref_guided_get_samples_onscreen.npz"), num_samples=ref["num_samples"],
                         samples=np.where(k[..., None], ref["samples"], np.float32(-1)), cluster_indices=np.where(k, ref["cluster_indices"], -1).astype(np.int16),
                         split=ref["split"], sample=ref["sample"])
+    # ---- the frame the render loop launches (cuda_renderer.cpp:141-142): trackers and visit marks AND offscreen == false
+    name = "onscreen_both"
+    spec = cases.CASES[cases.ONSCREEN[name][0]]
+    tree = cases.make_tree(mnv, spec["tree"])
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    opt.max_depth, opt.max_sample_count = 5, 9
+    tmax, image = cases.onscreen_inputs(name, cam)
+    v = tree.host_view()
+    counts = np.random.default_rng(7).integers(0, 14, size=(v.capacity, 8)).astype(np.int16)
+    path = os.path.join(tmp, "track_onscreen.npz")
+    tree.save_npz(path)
+    ref = mnv_ref.render_track_npz(path, cam.c, opt, v.capacity, sample_counts=counts, track_visit=True, tmax_px=tmax, rgba8_init=image)
+    plain = mnv_ref.render_track_npz(path, cam.c, opt, v.capacity, sample_counts=counts, track_visit=True)
+    marks = np.zeros(v.capacity, np.int32)
+    o = orc.render(orc.tree_from_view(v, sample_counts=counts), cam.c, opt, want_trackers=True, visited=marks, track_visit=True, tmax_px=tmax, rgba8_init=image)
+    stats["trackers_onscreen_both"] = {
+        "oracle_vs_ref": cmp(o["rgba"], ref["rgba"]),
+        "trackers_equal": bool(np.array_equal(o["split"].view(np.uint32), ref["split"].view(np.uint32)) and
+                               np.array_equal(o["sample"].view(np.uint32), ref["sample"].view(np.uint32))),
+        "marks_equal": bool(np.array_equal(marks, ref["visited"])),
+        "split_rows_changed_by_the_inputs": int((ref["split"] != plain["split"]).any(axis=-1).sum()),
+        "sample_rows_changed_by_the_inputs": int((ref["sample"] != plain["sample"]).any(axis=-1).sum()),
+        "marks_changed_by_the_inputs": int((ref["visited"] != plain["visited"]).sum())}
+    print("trackers_onscreen_both", json.dumps(stats["trackers_onscreen_both"]), flush=True)
+    np.savez_compressed(os.path.join(outdir, "ref_onscreen_trackers_both.npz"), rgba=ref["rgba"], split=ref["split"], sample=ref["sample"], visited=ref["visited"])
     with open(os.path.join(outdir, "ref_onscreen_stats.json"), "w") as f:
         json.dump(stats, f, indent=1)
 

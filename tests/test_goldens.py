@@ -105,6 +105,30 @@ def test_guided_get_samples_onscreen_matches_reference_device_code(mnv, orc):
     assert np.array_equal(a["num_samples"], b["num_samples"]) and np.array_equal(a["samples"].view(np.uint32), b["samples"].view(np.uint32))
 
 
+def test_tracker_frame_of_the_live_call_matches_reference_device_code(mnv, orc):
+    """The frame the reference's render loop launches (cuda_renderer.cpp:141-142): render_voxels with trackers, visit marks AND offscreen ==
+    false, from the reference's own device code (tests/golden/make_onscreen_goldens.py): the oracle's trackers and marks are equal, its
+    frame within the contract."""
+    g = np.load(os.path.join(GOLD, "ref_onscreen_trackers_both.npz"))
+    st = json.load(open(os.path.join(GOLD, "ref_onscreen_stats.json")))["trackers_onscreen_both"]
+    assert st["trackers_equal"] and st["marks_equal"] and st["oracle_vs_ref"]["px_gt_1e-4"] == 0
+    assert st["split_rows_changed_by_the_inputs"] > 1000 and st["sample_rows_changed_by_the_inputs"] > 1000
+    name = "onscreen_both"
+    spec = cases.CASES[cases.ONSCREEN[name][0]]
+    tree = cases.make_tree(mnv, spec["tree"])
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    opt.max_depth, opt.max_sample_count = 5, 9
+    tmax, image = cases.onscreen_inputs(name, cam)
+    v = tree.host_view()
+    counts = np.random.default_rng(7).integers(0, 14, size=(v.capacity, 8)).astype(np.int16)
+    marks = np.zeros(v.capacity, np.int32)
+    o = orc.render(orc.tree_from_view(v, sample_counts=counts), cam.c, opt, want_trackers=True, visited=marks, track_visit=True, tmax_px=tmax, rgba8_init=image)
+    assert np.array_equal(o["split"].view(np.uint32), g["split"].view(np.uint32)) and np.array_equal(o["sample"].view(np.uint32), g["sample"].view(np.uint32))
+    assert np.array_equal(marks, g["visited"])
+    assert np.abs(o["rgba"].astype(np.float64) - g["rgba"].astype(np.float64)).max() <= TOL
+
+
 @pytest.mark.parametrize("case", ["sh4_d6", "rgba_d5"])
 def test_guided_nerf_results_matches_reference_device_code(mnv, orc, case):
     """composite_nerf_results (rt_core.cuh:334-416); contract 1e-4, asserted 1e-6."""

@@ -349,3 +349,24 @@ def test_tracker_frame_of_the_live_call_on_both_layouts(mnv, orc, torch_gpu, nam
         assert np.array_equal(cases.bits(split.cpu().numpy().reshape(want["split"].shape)), cases.bits(want["split"])), who
         assert np.array_equal(cases.bits(sample.cpu().numpy().reshape(want["sample"].shape)), cases.bits(want["sample"])), who
         assert np.array_equal(visited.cpu().numpy(), visited_ref), who
+
+
+def test_live_reference_reproduces_the_tracker_frame_golden(mnv, tmp_path):
+    """oracle/_ref run here: the reference's render_voxels_trace_ray with trackers, marks, depth image and image gives the committed arrays."""
+    mnv_ref = require_live_reference()
+    g = np.load(os.path.join(GOLD, "ref_onscreen_trackers_both.npz"))
+    name = "onscreen_both"
+    spec = cases.CASES[cases.ONSCREEN[name][0]]
+    tree = cases.make_tree(mnv, spec["tree"])
+    cam = cases.make_camera(mnv, spec["camera"])
+    opt = cases.make_options(mnv, spec["options"])
+    opt.max_depth, opt.max_sample_count = 5, 9
+    tmax, image = cases.onscreen_inputs(name, cam)
+    v = tree.host_view()
+    counts = np.random.default_rng(7).integers(0, 14, size=(v.capacity, 8)).astype(np.int16)
+    path = str(tmp_path / "t.npz")
+    tree.save_npz(path)
+    live = mnv_ref.render_track_npz(path, cam.c, opt, v.capacity, sample_counts=counts, track_visit=True, tmax_px=tmax, rgba8_init=image)
+    for k in ("rgba", "split", "sample"):
+        assert np.array_equal(cases.bits(live[k]), cases.bits(g[k])), k
+    assert np.array_equal(live["visited"], g["visited"])
