@@ -14,12 +14,15 @@
 //                bit-identical on host and device; only the accumulation order inside the MFMA differs from
 //                the sequential CPU restatement (tests bound that).
 //
-// Execution: counting sort of the rows by cluster (histogram + scan + scatter), then one workgroup per 256 rows
-// of one cluster.  The whole network runs in registers: with the weights as the MFMA A operand and the samples
+// Execution: counting sort of the rows by cluster (histogram + scan + scatter), then one workgroup per up to 8192 rows of one
+// cluster, 256 or 512 rows per pass.  The whole network runs in registers: with the weights as the MFMA A operand and the samples
 // as the B operand (D^T = W X^T), the C layout of one layer (lane: sample l & 15, features 4 (l >> 4) + r) is
 // already a valid B layout for the next layer once the K index is permuted -- and the permutation is baked into
 // the weight fragments at upload time, so nothing moves between layers but a float -> half convert.
-// v_mfma_f32_16x16x32_f16, fragments staged in LDS once per workgroup.
+// v_mfma_f32_16x16x32_f16, fragments staged in LDS once per workgroup.  A pass: the first layer's B fragments are encoded (every
+// input block starts at a multiple of 16 K slots, mnv_mlp.h: all features at compile-time places), then every layer runs one M tile
+// at a time, a finished pair of M tiles packed into the next layer's B fragment at once; the results leave through a lane
+// permutation in LDS as 64-byte contiguous stores; the next pass's rows and samples are fetched meanwhile.
 
 #include <algorithm>
 #include <cstring>
@@ -179,15 +182,13 @@ __global__ __launch_bounds__(256) void mlp_scatter(const int16_t *__restrict__ c
 
 // ---------------------------------------------------------------- the network
 
-// One workgroup = WAVES wavefronts x (16 * NT) rows per pass = 256 rows.  <4, 4, 4>: 64-wide networks, four column tiles per
-// wavefront.  <8, 2, 8>: 128-wide networks -- their weights fill most of a CU's LDS (131 KB for 4 hidden layers), so one workgroup
-// per CU is all that fits: eight wavefronts with two column tiles each share the weights (two per SIMD, 64 accumulator + 32 operand
-// registers) instead of four wavefronts that hold 128 + 64 and leave every SIMD with one wavefront and nothing to overlap its
-// LDS and matrix-pipe latencies with.
-// <8, 4, 8> (round 5): the 128-wide network with 64 columns per wavefront -- every weight fragment read from LDS (1 KB, 8 cycles of the CU's LDS
-// port) feeds FOUR 16-cycle MFMAs instead of two, so the port is busy half as long as the matrix pipes instead of as long; 128 accumulator
-// + 64 operand registers at two wavefronts per SIMD (256-register budget), 512 rows per pass.  Its encode tiles hold HALF a K tile (16
-// features: 2 KB per wavefront, written and read twice per K tile) -- with whole tiles the 131 KB of weights + 32 KB would not fit a CU.
+// One workgroup = WAVES wavefronts x (16 * NT) rows per pass.  <4, 4, 4, .>: 64-wide networks, 256 rows per pass.  <8, 4, 8, .>: 128-wide networks --
+// their weights fill most of a CU's LDS (131 KB for 4 hidden layers), so one workgroup per CU is all that fits: eight wavefronts (two per SIMD, the
+// 256-register budget) of 64 columns each share the weights, 512 rows per pass; every weight fragment read from LDS (1 KB, 8 cycles of the CU's LDS
+// port) feeds four 16-cycle MFMAs.  (History: <8, 2, 8> with 32 columns per wavefront until round 4; 128 columns at one wavefront per SIMD,
+// <8, 8, 4>, measured 2.3 - 3.7 ms against 1.4 in round 5 and was dropped.)  The encode tiles hold HALF a K tile (16 features: 2 KB per
+// wavefront, written and read twice per K tile) -- with whole tiles the 131 KB of weights + 32 KB would not fit a CU.
+
 // tri_wave(x * scale + phase) (mnv_mlp.h) in five instructions instead of seven, bit for bit: scale is a power of two, so x * scale is exact and
 // one fused multiply-add rounds exactly where the sum rounds; 4 |r| is exact, so the closing fused multiply-add rounds where the subtraction
 // rounds; and the "+ 0.f" of the phase-0 features changes no result (t = -0 gives r = -0, |r| = 0, as t = +0 does).
