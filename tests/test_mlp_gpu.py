@@ -77,3 +77,26 @@ def test_mlp_rejects_bad_descriptions(mnv, torch_gpu):
     desc = mnv.mlp_desc(**big)
     with pytest.raises(mnv.MnvError, match="LDS"):
         mnv.Mlp(desc, np.zeros(mnv.Mlp.param_count(desc), np.float16))  # does not fit the CU's LDS
+
+
+@pytest.mark.parametrize("width", [64, 128])
+def test_mlp_ragged_batches_and_many_clusters(mnv, orc, torch_gpu, width):
+    """Batch sizes around the kernel's units (one row; one short of / one past a 512-row pass and an 8192-row workgroup; a sort chunk of 2048
+    rows) on a network with 1024 sub-modules -- most of them with no row at all, the rest with a handful: every workgroup is a partial pass."""
+    torch = torch_gpu
+    desc = mnv.mlp_desc(n_clusters=1024, pos_octaves=3, dir_octaves=1, need_viewdir=True, hidden_width=width, hidden_layers=2, out_dim=4)
+    params = mlp_cases.make_params(mnv, desc, seed=8)
+    mlp = mnv.Mlp(desc, params)
+    for n in (1, 2, 63, 511, 513, 2047, 2049, 8191, 8193):
+        x, cluster = mlp_cases.make_samples(desc, n, seed=100 + n)
+        if n >= 2047:
+            cluster[: n // 2] = 7  # one sub-module with a few thousand rows among a thousand with one or none
+        d_out = torch.full((n, desc.out_dim), 7.0, dtype=torch.float32, device="cuda")
+        mlp.query(torch.from_numpy(cluster).cuda(), torch.from_numpy(x).cuda(), d_out)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        want = orc.mlp_forward(desc, params, cluster, x)
+        err = np.abs(got - want) / (1.0 + np.abs(want))
+        assert np.isfinite(got).all() and err.max() < 4e-3, f"n = {n}: max rel err {err.max():.3e}"
+        valid = (cluster >= 0) & (cluster < desc.n_clusters)
+        assert np.all(got[~valid] == 0.0)
