@@ -16,13 +16,14 @@
 //   grid2 / grid2_vox [2^L2]^3 u32   the same two arrays at level L2 <= min(max_depth-1, 9), in
 //                            4x4x4-cell brick order; a step below the LDS grid costs one load
 //                            here plus one node load per level below L2
-//   grid2i [2^L2]^3 u32      grid2 with the LAST level folded into the cell word (plain frames read it instead of grid2; dropped by a tree
-//                            edit like the records): a non-leaf cell whose chunk holds eight LEAVES (and has a number below 2^22) reads
+//   grid2i [2^L2]^3 u32      grid2 with the LAST level folded into the cell word (every frame kind reads it instead of grid2; mnv_accel_refresh
+//                            patches it with the cells it rewrites, a prune derives it again): a non-leaf cell whose chunk holds eight LEAVES
+//                            (and has a number below 2^22) reads
 //                              0 | 1 << 30 | (voxel s1 has sigma bits != 0) << (22 + s1) | chunk
 //                            so a step into an empty leaf one level below the grid costs no load beyond the grid cell, and a dense one goes
 //                            straight to its colour row (sigma is in the row).  cfg2 (depth 10, L2 = 9): every deep step; no node word is read.
-//   recs [capacity][8] {u32 child, u32 codes}   brick records (trees with leaves two or more levels below L2 only; dropped by a tree edit,
-//                            derived again by mnv_accel_rebuild): record c belongs to chunk c of depth L2 + 1 -- the chunk a non-leaf grid2
+//   recs [capacity][8] {u32 child, u32 codes}   brick records (trees with leaves two or more levels below L2 only; kept current by
+//                            mnv_accel_refresh and the prune): record c belongs to chunk c of depth L2 + 1 -- the chunk a non-leaf grid2
 //                            cell names -- and describes the 4x4x4 cells of level L2 + 2 under it in 64 bytes.  Entry s1 (one 8-byte load):
 //                              child   chunk of the children of voxel s1 (0: that voxel is a leaf)
 //                              codes   two bits per sub-cell s2 (bits 2 * s2):
@@ -58,7 +59,6 @@ constexpr size_t kSlotBytes = (size_t)MNV_MAX_BATCH * (kNumQueues * 64 + sizeof(
 constexpr int kMaxGrid2Level = 9;  // 8^9 * 4 B = 512 MiB per array
 constexpr uint32_t kInlineBit = 0x40000000u;  // grid2i: the cell's eight children are leaves, described by the word itself
 constexpr int kInlineMaskShift = 22;           // ... bit (22 + s1): child s1 has sigma bits != 0; bits 0..21: the chunk
-constexpr int kRederiveAfter = 16;  // plain launches without a tree edit after which stale inline words / brick records are derived again
 constexpr int kRecWords = 16;      // a brick record: 8 entries {child chunk, 8 two-bit sub-cell codes} = 64 B
 
 // Interleaved macro-tile partition (mnv_partition in include/mnv.h).  Tiles are dealt in rounds of `world`; with a root period
@@ -111,7 +111,7 @@ struct AccelView {
     const uint32_t *grid2;      // [2^L2]^3 brick-ordered second lookup grid (NULL when grid2_level == 0)
     const uint32_t *grid2_vox;
     int32_t grid2_level;
-    const uint32_t *grid2i;     // grid2 with inline last-level words (NULL: none / stale; plain frames then read grid2 and walk the node words)
+    const uint32_t *grid2i;     // grid2 with inline last-level words (NULL: none; frames then read grid2 and walk the node words)
     const uint2 *recs;          // [capacity][8] brick records of levels grid2_level + 1 and + 2 (NULL: none, the node words are walked)
     int32_t sigma_off;          // byte offset of the sigma half inside a colour row
     int32_t max_depth;          // deepest voxel depth of the tree (<= 23)
@@ -130,8 +130,8 @@ struct mnv_accel {
     uint32_t *grid_vox = nullptr;
     uint32_t *grid2 = nullptr;
     uint32_t *grid2_vox = nullptr;
-    uint32_t *grid2i = nullptr;           // [2^L2]^3; view.grid2i is NULL while it is stale
-    uint2 *recs = nullptr;                // [reserved][8]; view.recs is NULL while they are stale (after mnv_accel_refresh / a prune)
+    uint32_t *grid2i = nullptr;           // [2^L2]^3
+    uint2 *recs = nullptr;                // [reserved][8]
     uint32_t *shadow_nodes = nullptr;     // MNV_ABLATE shadow loads (test-hook build, diagnostics instantiation): copies of nodes / rows at other
     uint8_t *shadow_rows = nullptr;       // addresses, read with the same access pattern to attribute the HBM traffic by array
     uint32_t *nodes_spare = nullptr;      // second set of nodes / rows / depth, allocated by the first prune (accel_apply_prune writes the
@@ -155,14 +155,6 @@ struct mnv_accel {
     std::atomic<uint32_t> slot_counter{0};
     hipEvent_t slot_done[mnv::kSlots] = {};  // recorded after the launch that used the slot
     bool slot_used[mnv::kSlots] = {};
-    // grid2i / recs after a tree edit: stale until mnv_accel_rebuild -- or until kRederiveAfter plain frames in a row have been launched
-    // without another edit, when launch_accel derives them again on the launch stream (0.3 ms for a level-9 grid: more than a handful of
-    // frames lose without them, so a caller that alternates edits and plain frames never pays it)
-    bool derived_stale = false;
-    int plain_since_edit = 0;
-    bool derived_pending = false;         // the re-derivation's kernels may still run on derived_stream: other streams wait for derived_ready
-    hipStream_t derived_stream = nullptr;
-    hipEvent_t derived_ready = nullptr;
     std::atomic<int> colour_math{-1};     // mnv_accel_set_colour_math: -1 follow the process-wide switch, 0 exact, 1 fast colour sigmoid
     std::atomic<int> fused_kernel{-1};    // mnv_accel_set_fused_kernel: -1 follow the process-wide switch, 0 / 1 / 2 as mnv_set_fused_kernel
     size_t bytes = 0;

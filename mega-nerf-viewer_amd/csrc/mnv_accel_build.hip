@@ -101,25 +101,11 @@ __global__ void accel_build_grid2(const uint32_t *nodes, uint32_t *grid2, uint32
     grid2_vox[o] = vox;
 }
 
-// (Re)build every derived array of `a` from the tree: chunk depths, node words, colour rows, lookup grids.  The big arrays
-// (nodes, rows, depth) are sized for a->reserved chunks and kept; the grids are reallocated only when their level changes.
 // grid2i = grid2 with the last level folded into the words of the cells whose chunk holds eight leaves (mnv_accel.h); one thread per cell
 __global__ void accel_build_grid2i(const uint32_t *nodes, const uint32_t *grid2, uint32_t *grid2i, int64_t cells) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cells) return;
-    uint32_t word = grid2[i];
-    if (!(word & kLeafBit) && word < (1u << kInlineMaskShift)) {
-        const uint4 lo = *reinterpret_cast<const uint4 *>(nodes + (int64_t)word * 8), hi = *reinterpret_cast<const uint4 *>(nodes + (int64_t)word * 8 + 4);
-        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        bool leaves = true;
-        uint32_t mask = 0u;
-        for (int s = 0; s < 8; ++s) {
-            leaves = leaves && (w[s] & kLeafBit) != 0u;
-            mask |= ((w[s] & 0xffffu) != 0u ? 1u : 0u) << s;
-        }
-        if (leaves) word |= kInlineBit | (mask << kInlineMaskShift);
-    }
-    grid2i[i] = word;
+    grid2i[i] = inline_cell_word(nodes, grid2[i]);
 }
 
 // brick record of every chunk c of depth L2 + 1 (layout: mnv_accel.h); one thread per (chunk, voxel s1)
@@ -127,23 +113,17 @@ __global__ void accel_build_recs(const uint32_t *nodes, const int32_t *depth, ui
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)capacity * 8) return;
     if (depth[i >> 3] != L2 + 1) return;
-    const uint32_t w1 = nodes[i];
-    uint32_t child = 0u, codes = 0u;
-    if (w1 & kLeafBit) {
-        if ((w1 & 0xffffu) == 0u) codes = 0x5555u;  // an empty leaf of depth L2 + 1: code 1 for its eight sub-cells
-    } else {
-        child = w1;
-        for (uint32_t s2 = 0; s2 < 8; ++s2) {
-            const uint32_t w2 = nodes[(int64_t)w1 * 8 + s2];
-            if (w2 & kLeafBit) codes |= ((w2 & 0xffffu) == 0u ? 2u : 3u) << (2 * s2);
-        }
-    }
-    recs[i] = make_uint2(child, codes);
+    recs[i] = brick_record_entry(nodes, i);
 }
 
 void launch_build_recs(const uint32_t *nodes, const int32_t *depth, uint2 *recs, int32_t capacity, int32_t L2, hipStream_t stream) {
     const int64_t n = (int64_t)capacity * 8;
     hipLaunchKernelGGL(accel_build_recs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, nodes, depth, recs, capacity, L2);
+}
+
+void launch_build_grid2i(const uint32_t *nodes, const uint32_t *grid2, uint32_t *grid2i, int32_t L2, hipStream_t stream) {
+    const int64_t cells = (int64_t)1 << (3 * L2);
+    hipLaunchKernelGGL(accel_build_grid2i, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, nodes, grid2, grid2i, cells);
 }
 
 void launch_pack_rows(const uint16_t *data, uint16_t *rows, int64_t nvox, int32_t data_dim, int32_t per_chan, int32_t chan_halfs, int32_t row_halfs,
@@ -159,30 +139,8 @@ void launch_build_grid2(const uint32_t *nodes, uint32_t *grid2, uint32_t *grid2_
     hipLaunchKernelGGL(accel_build_grid2, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, nodes, grid2, grid2_vox, L2);
 }
 
-int accel_rederive(mnv_accel *a, hipStream_t stream) {
-    static const int env_bricks = knob_int(KNOB_BRICK_LEVELS, 3);
-    const int L2 = a->view.grid2_level;
-    const bool want_inline = (env_bricks & 1) && L2 > 0 && a->grid2 != nullptr, want_recs = (env_bricks & 2) && want_inline && a->view.max_depth >= L2 + 2;
-    a->derived_stale = false;
-    if (!want_inline) return MNV_OK;
-    int rc;
-    const int64_t g2cells = (int64_t)1 << (3 * L2);
-    if (!a->grid2i && (rc = check_hip(hipMalloc((void **)&a->grid2i, g2cells * 4), "hipMalloc(grid2i)"))) return rc;
-    hipLaunchKernelGGL(accel_build_grid2i, dim3((unsigned)((g2cells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid2, a->grid2i, g2cells);
-    if (want_recs) {
-        if (!a->recs && (rc = check_hip(hipMalloc((void **)&a->recs, (size_t)a->reserved * kRecWords * 4), "hipMalloc(brick records)"))) return rc;
-        launch_build_recs(a->nodes, a->depth, a->recs, a->view.capacity, L2, stream);
-    }
-    if ((rc = check_hip(hipGetLastError(), "accel rederive launch"))) return rc;
-    if (!a->derived_ready && (rc = check_hip(hipEventCreateWithFlags(&a->derived_ready, hipEventDisableTiming), "hipEventCreate(derived)"))) return rc;
-    if ((rc = check_hip(hipEventRecord(a->derived_ready, stream), "record derived"))) return rc;
-    a->derived_stream = stream;
-    a->derived_pending = true;
-    a->view.grid2i = a->grid2i;
-    a->view.recs = want_recs ? a->recs : nullptr;
-    return MNV_OK;
-}
-
+// (Re)build every derived array of `a` from the tree: chunk depths, node words, colour rows, lookup grids.  The big arrays
+// (nodes, rows, depth) are sized for a->reserved chunks and kept; the grids are reallocated only when their level changes.
 int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
     int rc = MNV_OK;
     const int b = (t->format == MNV_FORMAT_SH && t->basis_dim >= 0) ? t->basis_dim : -1;
@@ -236,7 +194,6 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
         (void)hipFree(a->grid2_vox);
         a->grid2 = a->grid2_vox = nullptr;
         if (a->grid2i) (void)hipFree(a->grid2i);
-    if (a->derived_ready) (void)hipEventDestroy(a->derived_ready);
         a->grid2i = nullptr;
     }
     if (L2 > 0) {
@@ -247,7 +204,7 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
         }
         hipLaunchKernelGGL(accel_build_grid2, dim3((unsigned)((g2cells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid2, a->grid2_vox, L2);
     }
-    // What plain frames read instead of node words (derived data that a tree edit drops and mnv_accel_rebuild derives again):
+    // What frames read instead of node words (mnv_accel_refresh patches both with the tree edit, a prune derives them again):
     //  * grid2i: grid2 with the last level folded into the words of the cells whose chunk holds eight leaves -- a depth-10 tree (cfg2, L2 = 9)
     //    then never reads a node word: LDS grid -> grid2i [-> row];
     //  * brick records: the two levels below the grid from one 64-byte record per depth-(L2 + 1) chunk, for trees that have two such levels
@@ -256,7 +213,7 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
     const bool want_inline = (env_bricks & 1) && L2 > 0, want_recs = (env_bricks & 2) && want_inline && max_depth >= L2 + 2;
     if (want_inline) {
         if (!a->grid2i && (rc = check_hip(hipMalloc((void **)&a->grid2i, g2cells * 4), "hipMalloc(grid2i)"))) return fail(rc);
-        hipLaunchKernelGGL(accel_build_grid2i, dim3((unsigned)((g2cells + 255) / 256)), dim3(256), 0, stream, a->nodes, a->grid2, a->grid2i, g2cells);
+        launch_build_grid2i(a->nodes, a->grid2, a->grid2i, L2, stream);
     } else if (a->grid2i) {
         (void)hipFree(a->grid2i);
         a->grid2i = nullptr;
@@ -272,9 +229,6 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
     if ((rc = check_hip(hipStreamSynchronize(stream), "accel build"))) return fail(rc);
     a->view.grid2i = want_inline ? a->grid2i : nullptr;
     a->view.recs = want_recs ? a->recs : nullptr;
-    a->derived_stale = false;   // (the stream was synchronised above: nothing pending)
-    a->derived_pending = false;
-    a->plain_since_edit = 0;
 
     a->view.nodes = a->nodes;
     a->view.rows = a->rows;
@@ -359,6 +313,7 @@ int mnv_accel_rebuild(mnv_accel *a, const mnv_tree_view *t, void *hip_stream) {
         return set_error(MNV_E_INVALID, "invalid tree view, or the tree outgrew the reserved capacity");
     if (t->data_dim != a->view.data_dim || t->format != a->view.format || t->basis_dim != a->view.basis_dim)
         return set_error(MNV_E_INVALID, "tree view does not match the accel");
+    std::lock_guard<std::mutex> view_lock(a->launch_mutex);  // launch_accel copies the view under the same lock
     return accel_build(a, t, (hipStream_t)hip_stream);
 }
 

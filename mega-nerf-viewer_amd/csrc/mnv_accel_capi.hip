@@ -96,7 +96,6 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
             }
         }
     }
-    K.A = accel->view;
     {   // colour math: the accel's own setting, else the process-wide switch (two renderers of one process may differ)
         const int own = accel->colour_math.load(std::memory_order_relaxed);
         K.fast_colour = own >= 0 ? own : (fast_colour_selected() ? 1 : 0);
@@ -148,18 +147,13 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     // (or one thread feeding several streams) serialise here from the slot's acquisition to the record of its event.
     mnv_accel *mut = const_cast<mnv_accel *>(accel);
     std::lock_guard<std::mutex> launch_lock(mut->launch_mutex);
-    if (!track) {
-        // plain frame: stale inline words / brick records come back once enough plain frames in a row say the editing is over
-        if (mut->derived_stale && ++mut->plain_since_edit >= kRederiveAfter) {
-            const int rd = accel_rederive(mut, stream);
-            if (rd) return (int)hipErrorUnknown;
-        }
-        if (mut->derived_pending) {
-            if (hipEventQuery(mut->derived_ready) == hipSuccess) mut->derived_pending = false;
-            else if (mut->derived_stream != stream && hipStreamWaitEvent(stream, mut->derived_ready, 0) != hipSuccess) return (int)hipErrorUnknown;
-        }
-        K.A.grid2i = mut->view.grid2i;
-        K.A.recs = mut->view.recs;
+    K.A = accel->view;  // (under the lock: a launching thread never sees a half-written view)
+    const int b = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim >= 0) ? accel->view.basis_dim : -1;
+    // An inline cell word / a brick record calls a leaf whose sigma bits are 0 "not dense" without reading it: true for every
+    // sigma_thresh >= 0.  A frame with a negative threshold walks the node words (every other lookup array says the same).
+    if (P.sigma_thresh < 0.f) {
+        K.A.grid2i = nullptr;
+        K.A.recs = nullptr;
     }
     const uint32_t slot = mut->slot_counter.fetch_add(1) % kSlots;
     // a caller that runs more than kSlots launches ahead of the device waits here for the launch that last used the slot
@@ -247,14 +241,14 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
         K.timeline_tiles = (uint32_t)tiles;
     }
     int rc = kUnsupportedBasis;
-    const int b = (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim >= 0) ? accel->view.basis_dim : -1;
     if (track && track->fused) {
         rc = launch_fused(accel, K, *track->fused, b, lds_level, n_waves_needed, stream);
-    } else if (K.A.grid2i && !K.split_track && !K.sample_track && !K.visited && !K.samples && !(P.sigma_thresh < 0.f) && b < 16) {
-        // (an inline cell word / a brick record calls a leaf whose sigma bits are 0 "not dense" without reading it: true for every sigma_thresh >= 0; SH16 / SH25 rows are
-        // evaluated by the cooperative pass, which has no brick variant)
+    } else if (K.A.grid2i && (b < 16 || colourless)) {
+        // (SH16 / SH25 rows are evaluated by the cooperative pass, which has no brick variant)
         rc = launch_march_brick(K, b, colourless, n_blocks, lds_bytes, stream);
     } else {
+        K.A.grid2i = nullptr;
+        K.A.recs = nullptr;
         rc = launch_march(K, b, colourless, n_blocks, lds_bytes, stream);
     }
     if (rc == 0 && K.visited && track->parent) {

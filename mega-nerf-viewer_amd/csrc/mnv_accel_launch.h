@@ -21,6 +21,101 @@ __host__ __device__ __forceinline__ uint32_t grid2_index(uint32_t cx, uint32_t c
     return (brick << 6) | ((cx & 3u) << 4) | ((cy & 3u) << 2) | (cz & 3u);
 }
 
+// grid2i word of a level-L2 cell whose grid2 word is `word` (mnv_accel.h): a non-leaf cell whose chunk holds eight leaves carries their
+// sigma != 0 mask inline
+__device__ __forceinline__ uint32_t inline_cell_word(const uint32_t *__restrict__ nodes, uint32_t word) {
+    if (!(word & kLeafBit) && word < (1u << kInlineMaskShift)) {
+        const uint4 lo = *reinterpret_cast<const uint4 *>(nodes + (int64_t)word * 8), hi = *reinterpret_cast<const uint4 *>(nodes + (int64_t)word * 8 + 4);
+        const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        bool leaves = true;
+        uint32_t mask = 0u;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            leaves = leaves && (w[s] & kLeafBit) != 0u;
+            mask |= ((w[s] & 0xffffu) != 0u ? 1u : 0u) << s;
+        }
+        if (leaves) word |= kInlineBit | (mask << kInlineMaskShift);
+    }
+    return word;
+}
+
+// entry `vox` (= chunk * 8 + s1, the chunk of depth L2 + 1) of the brick records (mnv_accel.h) from the node words
+__device__ __forceinline__ uint2 brick_record_entry(const uint32_t *__restrict__ nodes, int64_t vox) {
+    const uint32_t w1 = nodes[vox];
+    uint32_t child = 0u, codes = 0u;
+    if (w1 & kLeafBit) {
+        if ((w1 & 0xffffu) == 0u) codes = 0x5555u;  // an empty leaf of depth L2 + 1: code 1 for its eight sub-cells
+    } else {
+        child = w1;
+        for (uint32_t s2 = 0; s2 < 8; ++s2) {
+            const uint32_t w2 = nodes[(int64_t)w1 * 8 + s2];
+            if (w2 & kLeafBit) codes |= ((w2 & 0xffffu) == 0u ? 2u : 3u) << (2 * s2);
+        }
+    }
+    return make_uint2(child, codes);
+}
+
+// The levels below the LDS grid for the kernels that need a leaf's sigma in the step itself and read no colour row (the sample march of the
+// fused guided kernels): the second lookup grid -- with inline cell words when A.grid2i is there -- then a brick record, then node words.  A
+// non-empty leaf found through an inline word or a record fetches its node word (depth + sigma); an empty one costs nothing more.
+// word: the LDS grid's (non-leaf) word in, the leaf word out.  src / vox as in march_accel_kernel: src 1 -- vox is the grid2 cell number (the
+// voxel is grid2_vox[vox]); src 2 -- vox is the voxel.  q: integer cell coordinates at level Lq; sh1 = Lq - LL, sh2 = Lq - L2.
+__device__ __forceinline__ uint32_t descend_to_leaf(const AccelView &A, const uint32_t (&q)[3], uint32_t word, int sh1, int sh2, int L2, int LL, int &src,
+                                                    uint32_t &vox) {
+    int sh = sh1;
+    if (L2 > LL) {
+        const int LB = L2 - 2;
+        uint32_t gi = q[0] >> (sh2 + 2);
+        gi = (gi << LB) | (q[1] >> (sh2 + 2));
+        gi = (gi << LB) | (q[2] >> (sh2 + 2));
+        gi = (gi << 2) | __builtin_amdgcn_ubfe(q[0], (uint32_t)sh2, 2u);
+        gi = (gi << 2) | __builtin_amdgcn_ubfe(q[1], (uint32_t)sh2, 2u);
+        gi = (gi << 2) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh2, 2u);
+        const uint32_t *__restrict__ g2 = A.grid2i ? A.grid2i : A.grid2;
+        word = g2[gi];
+        sh = sh2;
+        src = 1;
+        vox = gi;
+        if (!(word & kLeafBit) && A.grid2i) {
+            uint32_t s1 = __builtin_amdgcn_ubfe(q[0], (uint32_t)(sh2 - 1), 1u);
+            s1 = (s1 << 1) | __builtin_amdgcn_ubfe(q[1], (uint32_t)(sh2 - 1), 1u);
+            s1 = (s1 << 1) | __builtin_amdgcn_ubfe(q[2], (uint32_t)(sh2 - 1), 1u);
+            if (word & kInlineBit) {
+                vox = ((word & ((1u << kInlineMaskShift) - 1u)) << 3) | s1;
+                src = 2;
+                const bool filled = ((word >> (kInlineMaskShift + s1)) & 1u) != 0u;
+                return filled ? A.nodes[vox] : (kLeafBit | ((uint32_t)(L2 + 1) << 16));
+            }
+            if (A.recs != nullptr) {
+                uint32_t s2 = __builtin_amdgcn_ubfe(q[0], (uint32_t)(sh2 - 2), 1u);
+                s2 = (s2 << 1) | __builtin_amdgcn_ubfe(q[1], (uint32_t)(sh2 - 2), 1u);
+                s2 = (s2 << 1) | __builtin_amdgcn_ubfe(q[2], (uint32_t)(sh2 - 2), 1u);
+                const uint2 e = A.recs[(int64_t)word * 8 + s1];
+                const uint32_t code = __builtin_amdgcn_ubfe(e.y, s2 << 1, 2u);
+                if (code != 0u) {  // 1 / 2: an empty leaf of depth L2 + 1 / L2 + 2; 3: a leaf of depth L2 + 2 with sigma != 0
+                    vox = code == 1u ? ((word << 3) | s1) : ((e.x << 3) | s2);
+                    src = 2;
+                    return code == 3u ? A.nodes[vox] : (kLeafBit | ((uint32_t)(L2 + 2 - (code == 1u ? 1 : 0)) << 16));
+                }
+                if (e.x != 0u) {  // voxel s1 is an inner voxel and so is its child s2: the walk goes on below them
+                    word = e.x;
+                    sh = sh2 - 1;
+                }
+            }
+        }
+    }
+    while (!(word & kLeafBit)) {
+        --sh;
+        uint32_t v = (word << 1) | __builtin_amdgcn_ubfe(q[0], (uint32_t)sh, 1u);
+        v = (v << 1) | __builtin_amdgcn_ubfe(q[1], (uint32_t)sh, 1u);
+        v = (v << 1) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh, 1u);
+        word = A.nodes[v];
+        src = 2;
+        vox = v;
+    }
+    return word;
+}
+
 struct AccelLaunch {
     FrameParams P;   // tile, options, outputs (P.cam is unused: cameras come from `cams`)
     AccelView A;
@@ -164,9 +259,6 @@ struct AccelTrack {
 
 constexpr int kUnsupportedBasis = -1000;  // not a hipError_t
 
-// grid2i and the brick records again from the accel's own (patched) node words and grid2, asynchronously on `stream` (mnv_accel_build.hip);
-// sets view.grid2i / view.recs and records derived_ready
-int accel_rederive(mnv_accel *a, hipStream_t stream);
 // (Re)build every derived array of `a` from the tree (mnv_accel_build.hip)
 int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream);
 // the two lookup grids, whole, from the node words (mnv_accel_build.hip; the refresh rebuilds the small one, or both without a parent array)
@@ -174,12 +266,13 @@ void launch_pack_rows(const uint16_t *data, uint16_t *rows, int64_t nvox, int32_
                       hipStream_t stream);
 // brick records of the chunks of depth L2 + 1 (mnv_accel.h); one thread per chunk
 void launch_build_recs(const uint32_t *nodes, const int32_t *depth, uint2 *recs, int32_t capacity, int32_t L2, hipStream_t stream);
+void launch_build_grid2i(const uint32_t *nodes, const uint32_t *grid2, uint32_t *grid2i, int32_t L2, hipStream_t stream);
 void launch_build_grid(const uint32_t *nodes, uint32_t *grid, uint32_t *grid_vox, int32_t L, hipStream_t stream);
 void launch_build_grid2(const uint32_t *nodes, uint32_t *grid2, uint32_t *grid2_vox, int32_t L2, hipStream_t stream);
 // march_accel_kernel for the row format `basis` (-1 RGBA, 1 / 4 / 9 / 16 / 25 SH) in the mode the launch block asks for
 // (mnv_accel_march.hip); kUnsupportedBasis or a hipError_t
 int launch_march(const AccelLaunch &K, int basis, bool colourless, int n_blocks, size_t lds_bytes, hipStream_t stream);
-// the same for trees with brick records (K.A.recs != NULL), plain / fast-colour / depth frames (mnv_accel_march_brick.hip)
+// the same on inline cell words / brick records (K.A.grid2i != NULL), every frame kind of the per-lane row formats (mnv_accel_march_brick.hip)
 int launch_march_brick(const AccelLaunch &K, int basis, bool colourless, int n_blocks, size_t lds_bytes, hipStream_t stream);
 // mnv_set_colour_math
 bool fast_colour_selected();

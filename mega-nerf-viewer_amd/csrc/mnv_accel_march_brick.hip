@@ -1,7 +1,7 @@
-// mnv_accel_march_brick.hip -- the instantiations of march_accel_kernel for trees with brick records (AccelView::recs: the two levels below
-// the second lookup grid from one 64-byte record per chunk): plain, fast-colour and depth frames of the per-lane row formats (RGBA, SH1 / 4 /
-// 9), and the diagnostics instantiation of the SH9 kernel.  Tracker / sample / fused frames, SH16 / SH25 trees and frames with a negative
-// sigma_thresh walk the node words (mnv_accel_march.hip, mnv_accel_fused.hip): every other lookup array stays valid.
+// mnv_accel_march_brick.hip -- the instantiations of march_accel_kernel on inline cell words (AccelView::grid2i) and brick records
+// (AccelView::recs: the two levels below the second lookup grid from one 64-byte record per chunk): plain, fast-colour, depth, tracker and
+// sample frames of the per-lane row formats (RGBA, SH1 / 4 / 9), and the diagnostics instantiation of the SH9 kernel.  SH16 / SH25 trees
+// and frames with a negative sigma_thresh walk the node words (mnv_accel_march.hip): every other lookup array says the same.
 #include "mnv_march_accel_kernel.h"
 
 namespace mnv {
@@ -22,6 +22,10 @@ template <int BASIS>
 static int launch_brick(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
     if constexpr (BASIS == 9) {
         if (K.stats) return launch_brick2<BASIS, 1>(K, n_blocks, lds_bytes, stream);
+        if (K.samples) return launch_brick2<BASIS, 3>(K, n_blocks, lds_bytes, stream);  // (reads no colour rows: serves every row format)
+    }
+    if (K.split_track || K.sample_track || K.visited) return launch_brick2<BASIS, 2>(K, n_blocks, lds_bytes, stream);
+    if constexpr (BASIS == 9) {
         if (K.P.render_depth) return launch_brick2<BASIS, 5>(K, n_blocks, lds_bytes, stream);
     }
     if constexpr (BASIS >= 1) {

@@ -31,10 +31,11 @@ __global__ void accel_refresh_depth(const int32_t *parent, int32_t *depth, int32
 
 // node words of the appended chunks' voxels and the link word of the voxel each of them hangs under;
 // flags[2] = 1 when that voxel was shallow enough to be held by a lookup grid
-__device__ __forceinline__ uint32_t patch_items(int32_t d, int32_t L2);
+__device__ __forceinline__ uint32_t patch_items(int32_t d, int32_t L2, int32_t L2i);
 
 __global__ void accel_refresh_nodes(const int32_t *child, const int32_t *parent, const uint16_t *data, const int32_t *depth, uint32_t *nodes,
-                                    int32_t first, int32_t capacity, int32_t data_dim, int32_t grid_depth, int32_t *flags, uint32_t *items, int32_t L2) {
+                                    int32_t first, int32_t capacity, int32_t data_dim, int32_t grid_depth, int32_t *flags, uint32_t *items, int32_t L2,
+                                    int32_t L2i) {
     const int64_t v = (int64_t)first * 8 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= (int64_t)capacity * 8) return;
     const int32_t c = (int32_t)(v >> 3);
@@ -49,14 +50,14 @@ __global__ void accel_refresh_nodes(const int32_t *child, const int32_t *parent,
         nodes[pv] = (uint32_t)c;
         if (depth[pv >> 3] <= grid_depth) flags[2] = 1;
         atomicMin(&flags[3], depth[pv >> 3]);  // the shallowest voxel that stopped being a leaf
-        if (items) items[c - first] = patch_items(depth[pv >> 3], L2);  // (accel_patch_plan turns the counts into first items)
+        if (items) items[c - first] = patch_items(depth[pv >> 3], L2, L2i);  // (accel_patch_plan turns the counts into first items)
     }
 }
 
 // existing leaves whose data row was rewritten (mnv_apply_sample_results): sigma in the node word, colour row
 __global__ void accel_refresh_changed(const int32_t *changed_nodes, int32_t n, const int32_t *child, const uint16_t *data, const int32_t *depth,
                                       uint32_t *nodes, uint16_t *rows, int32_t data_dim, int32_t per_chan, int32_t chan_halfs,
-                                      int32_t row_halfs, int32_t grid_depth, int32_t *flags, uint32_t *items, int32_t L2) {
+                                      int32_t row_halfs, int32_t grid_depth, int32_t *flags, uint32_t *items, int32_t L2, int32_t L2i) {
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int32_t c = changed_nodes[2 * i];
@@ -71,7 +72,7 @@ __global__ void accel_refresh_changed(const int32_t *changed_nodes, int32_t n, c
     rows[v * row_halfs + 3 * chan_halfs] = data[v * data_dim + data_dim - 1];  // sigma in the half behind the channel blocks (accel_pack_rows)
     if (depth[c] <= grid_depth) flags[2] = 1;
     atomicMin(&flags[3], depth[c]);
-    if (items) items[i] = patch_items(depth[c], L2);
+    if (items) items[i] = patch_items(depth[c], L2, L2i);
 }
 
 // Rewrite the level-L2 lookup cells covered by voxels that stopped being (or changed as) leaves -- voxel b of the list is vox_list[b],
@@ -86,8 +87,11 @@ __device__ __forceinline__ int64_t patch_voxel(const int32_t *vox_pairs, int32_t
     return vox_pairs ? (int64_t)vox_pairs[2 * b] * 8 + vox_pairs[2 * b + 1] : (int64_t)parent[first_chunk + b];
 }
 
-__device__ __forceinline__ uint32_t patch_items(int32_t d, int32_t L2) {
-    return d >= 1 && d <= L2 ? (uint32_t)((((uint64_t)1 << (3 * (L2 - d))) + kPatchCells - 1) / kPatchCells) : 0u;
+// L2i = L2 + 1 when the grid carries inline cell words (grid2i): a voxel one level below the grid is described by the word of the ONE cell
+// above it (its chunk's eight-leaves flag and sigma mask), which is then an item too
+__device__ __forceinline__ uint32_t patch_items(int32_t d, int32_t L2, int32_t L2i) {
+    if (d >= 1 && d <= L2) return (uint32_t)((((uint64_t)1 << (3 * (L2 - d))) + kPatchCells - 1) / kPatchCells);
+    return d == L2 + 1 && L2i > L2 ? 1u : 0u;
 }
 
 // in: prefix[b] = items of voxel b (written by the refresh kernels); out: prefix[b] = items of voxels 0 .. b-1, prefix[n] = all of
@@ -124,7 +128,8 @@ __global__ __launch_bounds__(1024) void accel_patch_plan(int32_t n, uint32_t *pr
 
 // workgroup i: item i.  The voxel's integer coordinates come from the walk up the parent words.
 __global__ __launch_bounds__(256) void accel_patch_grid2(const int32_t *vox_pairs, int32_t first_chunk, int32_t n, const uint32_t *prefix, const int32_t *parent,
-                                                         const int32_t *depth, const uint32_t *nodes, uint32_t *grid2, uint32_t *grid2_vox, int32_t L2) {
+                                                         const int32_t *depth, const uint32_t *nodes, uint32_t *grid2, uint32_t *grid2_vox, uint32_t *grid2i,
+                                                         int32_t L2) {
     __shared__ uint32_t s_box[6];  // x, y, z at the voxel's own level; its depth; the voxel; the item's number among the voxel's items
     if (threadIdx.x == 0) {
         int32_t lo = 0, hi = n;  // the last voxel whose first item is <= this one (voxels without cells have no items and are never met)
@@ -133,9 +138,14 @@ __global__ __launch_bounds__(256) void accel_patch_grid2(const int32_t *vox_pair
             if (prefix[mid] <= blockIdx.x) lo = mid;
             else hi = mid;
         }
-        const int64_t pv = patch_voxel(vox_pairs, first_chunk, parent, lo);
+        int64_t pv = patch_voxel(vox_pairs, first_chunk, parent, lo);
         int32_t cur = (int32_t)(pv >> 3);
-        const int32_t d = depth[cur];
+        int32_t d = depth[cur];
+        if (d == L2 + 1) {  // a voxel one level below the grid (it has an item only when grid2i exists): the cell of the voxel above it
+            pv = (int64_t)parent[cur];
+            cur = (int32_t)(pv >> 3);
+            d = L2;
+        }
         uint32_t x = 0, y = 0, z = 0, slot = (uint32_t)(pv & 7);
         for (int k = 0; k < d; ++k) {
             x |= ((slot >> 2) & 1u) << k;
@@ -173,7 +183,94 @@ __global__ __launch_bounds__(256) void accel_patch_grid2(const int32_t *vox_pair
         const uint32_t o = grid2_index(ix, iy, iz, L2);
         grid2[o] = word;
         grid2_vox[o] = vox;
+        if (grid2i) grid2i[o] = inline_cell_word(nodes, word);
     }
+}
+
+// Brick records after a refinement step: entry v of the records describes voxel v of a depth-(L2 + 1) chunk and the eight voxels below it, so
+// an affected voxel of depth L2 + 1 rewrites its own entry, one of depth L2 + 2 the entry of the voxel above it, and a chunk appended at
+// depth L2 + 1 gets its eight entries.  One thread per affected voxel (vox_pairs, or the parent voxel of chunk first_chunk + b); threads
+// that meet in an entry write the same value (every node word is final when this runs).
+__global__ void accel_patch_recs(const int32_t *vox_pairs, int32_t first_chunk, int32_t n, const int32_t *parent, const int32_t *depth, const uint32_t *nodes,
+                                 uint2 *recs, int32_t L2) {
+    const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    const int64_t pv = patch_voxel(vox_pairs, first_chunk, parent, b);
+    const int32_t c = (int32_t)(pv >> 3);
+    if (!vox_pairs) {
+        const int32_t nc = first_chunk + b;
+        if (depth[nc] == L2 + 1)
+            for (int s = 0; s < 8; ++s) recs[(int64_t)nc * 8 + s] = brick_record_entry(nodes, (int64_t)nc * 8 + s);
+        if (depth[nc] == 0) return;  // not linked
+    }
+    const int32_t d = depth[c];
+    if (d == L2 + 1) {
+        recs[pv] = brick_record_entry(nodes, pv);
+    } else if (d == L2 + 2) {
+        const int64_t ppv = (int64_t)parent[c];
+        recs[ppv] = brick_record_entry(nodes, ppv);
+    }
+}
+
+// Test-hook builds (MNV_REFRESH_DEBUG=2): every lookup word the edits patched against a fresh derivation from the node words.
+// bad[0..4]: wrong grid2 words, grid2_vox words, grid2i words, record entries, small-grid words
+__global__ void accel_verify_lookup(const uint32_t *nodes, const int32_t *depth, const uint32_t *grid, const uint32_t *grid_vox, int32_t L,
+                                    const uint32_t *grid2, const uint32_t *grid2_vox, const uint32_t *grid2i, const uint2 *recs, int32_t L2,
+                                    int32_t capacity, int32_t *bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t cells2 = L2 > 0 ? (int64_t)1 << (3 * L2) : 0, cells1 = (int64_t)1 << (3 * L);
+    auto walk = [&](uint32_t ix, uint32_t iy, uint32_t iz, int32_t levels, uint32_t &word, uint32_t &vox) {
+        uint32_t chunk = 0;
+        word = vox = 0;
+        for (int32_t l = 1; l <= levels; ++l) {
+            const int32_t s = levels - l;
+            vox = chunk * 8u + ((((ix >> s) & 1u) << 2) | (((iy >> s) & 1u) << 1) | ((iz >> s) & 1u));
+            word = nodes[vox];
+            if (word & kLeafBit) break;
+            chunk = word;
+        }
+    };
+    if (i < cells2) {
+        const uint32_t G = 1u << L2, iz = (uint32_t)i & (G - 1), iy = ((uint32_t)i >> L2) & (G - 1), ix = (uint32_t)(i >> (2 * L2));
+        uint32_t word, vox;
+        walk(ix, iy, iz, L2, word, vox);
+        const uint32_t o = grid2_index(ix, iy, iz, L2);
+        if (grid2[o] != word) atomicAdd(&bad[0], 1);
+        if ((word & kLeafBit) && grid2_vox[o] != vox) atomicAdd(&bad[1], 1);
+        if (grid2i && grid2i[o] != inline_cell_word(nodes, word)) atomicAdd(&bad[2], 1);
+    }
+    if (i < cells1) {
+        const uint32_t G = 1u << L, iz = (uint32_t)i & (G - 1), iy = ((uint32_t)i >> L) & (G - 1), ix = (uint32_t)(i >> (2 * L));
+        uint32_t word, vox;
+        walk(ix, iy, iz, L, word, vox);
+        if (grid[i] != word || ((word & kLeafBit) && grid_vox[i] != vox)) atomicAdd(&bad[4], 1);
+    }
+    if (recs && i < (int64_t)capacity * 8 && depth[i >> 3] == L2 + 1) {
+        const uint2 want = brick_record_entry(nodes, i), got = recs[i];
+        if (want.x != got.x || want.y != got.y) atomicAdd(&bad[3], 1);
+    }
+}
+
+int verify_lookup(mnv_accel *a, hipStream_t stream, const char *where) {
+    int32_t *bad = nullptr, h[5] = {};
+    int rc;
+    if ((rc = check_hip(hipMalloc((void **)&bad, sizeof(h)), "hipMalloc(verify)"))) return rc;
+    (void)hipMemsetAsync(bad, 0, sizeof(h), stream);
+    const int L2 = a->view.grid2_level;
+    int64_t n = std::max<int64_t>((int64_t)1 << (3 * a->view.grid_level), (int64_t)a->view.capacity * 8);
+    if (L2 > 0) n = std::max<int64_t>(n, (int64_t)1 << (3 * L2));
+    hipLaunchKernelGGL(accel_verify_lookup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a->nodes, a->depth, a->grid, a->grid_vox, a->view.grid_level,
+                       a->grid2, a->grid2_vox, a->view.grid2i, a->view.recs, L2, a->view.capacity, bad);
+    rc = check_hip(hipMemcpyAsync(h, bad, sizeof(h), hipMemcpyDeviceToHost, stream), "verify read");
+    if (!rc) rc = check_hip(hipStreamSynchronize(stream), "verify");
+    (void)hipFree(bad);
+    if (rc) return rc;
+    if (h[0] | h[1] | h[2] | h[3] | h[4]) {
+        fprintf(stderr, "[mnv verify] %s: patched lookup words differ from a fresh derivation: grid2 %d, grid2_vox %d, grid2i %d, records %d, grid %d\n", where,
+                h[0], h[1], h[2], h[3], h[4]);
+        return set_error(MNV_E_FAULT, "patched lookup words differ from a fresh derivation (refresh-debug knob of the test-hook build)");
+    }
+    return MNV_OK;
 }
 
 // ---- the packed layout follows a prune (mnv_prune_tree_accel): chunk c survives as c - shifts[c] unless to_delete[c]; a voxel whose
@@ -246,6 +343,7 @@ __global__ void accel_prune_grid(uint32_t *grid, uint32_t *grid_vox, int64_t cel
 int accel_apply_prune(mnv_accel *a, const int32_t *parent, const uint16_t *data, int32_t data_dim, const uint8_t *to_delete, const int32_t *shifts,
                       int32_t old_capacity, int32_t n_deleted, hipStream_t stream) {
     if (!a || old_capacity != a->view.capacity) return set_error(MNV_E_INVALID, "the accel does not describe the tree that is being pruned");
+    std::lock_guard<std::mutex> view_lock(a->launch_mutex);  // launch_accel copies the view under the same lock
     int rc;
     const int64_t reserved = a->reserved;
     const int row_bytes = a->view.row_bytes;
@@ -278,10 +376,13 @@ int accel_apply_prune(mnv_accel *a, const int32_t *parent, const uint16_t *data,
     a->view.nodes = a->nodes;
     a->view.rows = a->rows;
     a->view.capacity = old_capacity - n_deleted;  // max_depth stays an upper bound (the march only needs pos * 2^max_depth < 2^24)
-    a->view.recs = nullptr;                        // stale (chunks renumbered): derived again by mnv_accel_rebuild, or after kRederiveAfter plain frames
-    a->view.grid2i = nullptr;
-    a->derived_stale = true;
-    a->plain_since_edit = 0;
+    // inline cell words and brick records: derived again from the renumbered node words and the patched grid, on the same stream (a pass over
+    // the grid like accel_prune_grid's own; prunes are rare)
+    if (a->view.grid2i) launch_build_grid2i(a->nodes, a->grid2, a->grid2i, a->view.grid2_level, stream);
+    if (a->view.recs) launch_build_recs(a->nodes, a->depth, a->recs, a->view.capacity, a->view.grid2_level, stream);
+    if ((rc = check_hip(hipGetLastError(), "accel prune launch"))) return rc;
+    static const int dbg = knob_int(KNOB_REFRESH_DEBUG, 0);
+    if (dbg >= 2) return verify_lookup(a, stream, "prune");
     return MNV_OK;
 }
 
@@ -302,6 +403,7 @@ int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity
     if (t->capacity > old_capacity && !t->parent) return set_error(MNV_E_INVALID, "appended chunks need the parent array");
     if (n_changed < 0 || (n_changed > 0 && !changed_nodes)) return set_error(MNV_E_INVALID, "invalid changed_nodes");
     if (t->capacity == old_capacity && n_changed == 0) return MNV_OK;
+    std::lock_guard<std::mutex> view_lock(a->launch_mutex);  // launch_accel copies the view under the same lock
     hipStream_t stream = (hipStream_t)hip_stream;
     int rc;
     const int b = (t->format == MNV_FORMAT_SH && t->basis_dim >= 0) ? t->basis_dim : -1;
@@ -313,6 +415,7 @@ int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity
     const int32_t n_new = t->capacity - old_capacity;
     // the level-L2 grid: only the cells the affected voxels cover, cut into items (accel_patch_grid2).  The refresh kernels count every
     // voxel's items, accel_patch_plan scans the counts, the totals come back with the flags.
+    const int32_t L2 = a->view.grid2_level, L2i = a->view.grid2i ? L2 + 1 : L2;
     const bool patch_changed = n_changed > 0 && t->parent != nullptr && a->view.grid2_level > 0;
     const bool patch_new = n_new > 0 && a->view.grid2_level > 0;
     uint32_t *prefix_new = nullptr, *prefix_changed = nullptr;
@@ -335,7 +438,7 @@ int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity
         hipLaunchKernelGGL(accel_refresh_depth, dim3((n_new + 255) / 256), dim3(256), 0, stream, t->parent, a->depth, old_capacity, t->capacity, a->flags);
         const int64_t nv = (int64_t)n_new * 8;
         hipLaunchKernelGGL(accel_refresh_nodes, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, t->child, t->parent, t->data, a->depth, a->nodes,
-                           old_capacity, t->capacity, t->data_dim, grid_depth, a->flags, prefix_new, a->view.grid2_level);
+                           old_capacity, t->capacity, t->data_dim, grid_depth, a->flags, prefix_new, L2, L2i);
         launch_pack_rows(t->data + (int64_t)old_capacity * 8 * t->data_dim, reinterpret_cast<uint16_t *>(a->rows) + (int64_t)old_capacity * 8 * row_halfs, nv,
                          t->data_dim, per_chan, chan_halfs, row_halfs, stream);
         if (patch_new) hipLaunchKernelGGL(accel_patch_plan, dim3(1), dim3(1024), 0, stream, n_new, prefix_new, a->flags + 4);
@@ -343,36 +446,63 @@ int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity
     if (n_changed > 0) {
         hipLaunchKernelGGL(accel_refresh_changed, dim3((n_changed + 255) / 256), dim3(256), 0, stream, changed_nodes, n_changed, t->child, t->data, a->depth,
                            a->nodes, reinterpret_cast<uint16_t *>(a->rows), t->data_dim, per_chan, chan_halfs, row_halfs, grid_depth, a->flags, prefix_changed,
-                           a->view.grid2_level);
+                           L2, L2i);
         if (patch_changed) hipLaunchKernelGGL(accel_patch_plan, dim3(1), dim3(1024), 0, stream, n_changed, prefix_changed, a->flags + 5);
     }
     if ((rc = check_hip(hipMemcpyAsync(h, a->flags, sizeof(h), hipMemcpyDeviceToHost, stream), "read flags"))) return rc;
     if ((rc = check_hip(hipStreamSynchronize(stream), "accel refresh"))) return rc;
-    if (h[1] > 23) return set_error(MNV_E_UNSUPPORTED, "accel supports trees up to depth 23; use mnv_render_voxels");
+    if (h[1] > 23) {
+        // nodes, rows and depths are patched, the lookup grids are not: no frame may read them as they are (mnv_accel_rebuild refuses the tree too)
+        a->view.grid2i = nullptr;
+        a->view.recs = nullptr;
+        a->view.capacity = t->capacity;
+        return set_error(MNV_E_UNSUPPORTED, "accel supports trees up to depth 23; use mnv_render_voxels");
+    }
     if (h[2]) {  // an affected voxel is held by the small lookup grid: 32^3 cells at most, rebuilt whole
         launch_build_grid(a->nodes, a->grid, a->grid_vox, a->view.grid_level, stream);
     }
     if (a->view.grid2_level > 0) {
-        static const bool dbg = knob_set(KNOB_REFRESH_DEBUG);
+        static const int dbg = knob_int(KNOB_REFRESH_DEBUG, 0);
         if (dbg)
             fprintf(stderr, "[mnv refresh] n_new %d n_changed %d shallowest %d grid2_level %d patch items %d + %d\n", n_new, n_changed, h[3], a->view.grid2_level, h[4], h[5]);
         if (h[4] > 0)
             hipLaunchKernelGGL(accel_patch_grid2, dim3((unsigned)h[4]), dim3(256), 0, stream, (const int32_t *)nullptr, old_capacity, n_new, prefix_new, t->parent,
-                               a->depth, a->nodes, a->grid2, a->grid2_vox, a->view.grid2_level);
+                               a->depth, a->nodes, a->grid2, a->grid2_vox, const_cast<uint32_t *>(a->view.grid2i), a->view.grid2_level);
         if (h[5] > 0)
             hipLaunchKernelGGL(accel_patch_grid2, dim3((unsigned)h[5]), dim3(256), 0, stream, changed_nodes, 0, n_changed, prefix_changed, t->parent, a->depth,
-                               a->nodes, a->grid2, a->grid2_vox, a->view.grid2_level);
-        if (n_changed > 0 && !t->parent && h[3] <= a->view.grid2_level) {  // no parent array to walk up: the whole grid
-            launch_build_grid2(a->nodes, a->grid2, a->grid2_vox, a->view.grid2_level, stream);
+                               a->nodes, a->grid2, a->grid2_vox, const_cast<uint32_t *>(a->view.grid2i), a->view.grid2_level);
+        if (n_changed > 0 && !t->parent && h[3] <= L2i) {  // no parent array to walk up: the whole grid
+            if (h[3] <= L2) launch_build_grid2(a->nodes, a->grid2, a->grid2_vox, a->view.grid2_level, stream);
+            if (a->view.grid2i) launch_build_grid2i(a->nodes, a->grid2, a->grid2i, a->view.grid2_level, stream);
         }
     }
     a->view.max_depth = std::max(a->view.max_depth, h[1]);
     a->view.capacity = t->capacity;
-    a->view.recs = nullptr;  // stale: plain frames walk the node words until mnv_accel_rebuild -- or kRederiveAfter plain frames in a row -- derive them again
-    a->view.grid2i = nullptr;
-    a->derived_stale = true;
-    a->plain_since_edit = 0;
-    return check_hip(hipGetLastError(), "accel refresh launch");
+    // brick records: the entries the edit touches -- or, for a tree that only now reaches two levels below the grid, all of them
+    static const int env_bricks = knob_int(KNOB_BRICK_LEVELS, 3);
+    if (a->view.grid2i && (env_bricks & 2) && a->view.max_depth >= L2 + 2) {
+        if (!a->view.recs) {
+            if (!a->recs) {
+                if ((rc = check_hip(hipMalloc((void **)&a->recs, (size_t)a->reserved * kRecWords * 4), "hipMalloc(brick records)"))) return rc;
+                a->bytes += (size_t)a->reserved * kRecWords * 4;
+            }
+            launch_build_recs(a->nodes, a->depth, a->recs, t->capacity, L2, stream);
+            a->view.recs = a->recs;
+        } else if (n_changed > 0 && !t->parent) {
+            launch_build_recs(a->nodes, a->depth, a->recs, t->capacity, L2, stream);
+        } else {
+            if (n_new > 0)
+                hipLaunchKernelGGL(accel_patch_recs, dim3((n_new + 255) / 256), dim3(256), 0, stream, (const int32_t *)nullptr, old_capacity, n_new, t->parent, a->depth,
+                                   a->nodes, a->recs, L2);
+            if (n_changed > 0)
+                hipLaunchKernelGGL(accel_patch_recs, dim3((n_changed + 255) / 256), dim3(256), 0, stream, changed_nodes, 0, n_changed, t->parent, a->depth, a->nodes,
+                                   a->recs, L2);
+        }
+    }
+    if ((rc = check_hip(hipGetLastError(), "accel refresh launch"))) return rc;
+    static const int dbg_verify = knob_int(KNOB_REFRESH_DEBUG, 0);
+    if (dbg_verify >= 2) return verify_lookup(a, stream, "refresh");
+    return MNV_OK;
 }
 
 }  // extern "C"

@@ -195,29 +195,7 @@ __global__ __launch_bounds__(256, MNV_FUSED_WAVES) void guided_fused_kernel(cons
                 int src = 0;       // TRACK: where the leaf word came from (0 LDS grid, 1 grid2, 2 node array) ...
                 uint32_t vox = 0;  // ... and the leaf's voxel index (grid cell number until it is looked up)
                 if (!(word & kLeafBit)) {
-                    int sh = sh1;
-                    if (L2 > LL) {
-                        const int LB = L2 - 2;
-                        uint32_t gi = q[0] >> (sh2 + 2);
-                        gi = (gi << LB) | (q[1] >> (sh2 + 2));
-                        gi = (gi << LB) | (q[2] >> (sh2 + 2));
-                        gi = (gi << 2) | __builtin_amdgcn_ubfe(q[0], (uint32_t)sh2, 2u);
-                        gi = (gi << 2) | __builtin_amdgcn_ubfe(q[1], (uint32_t)sh2, 2u);
-                        gi = (gi << 2) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh2, 2u);
-                        word = A.grid2[gi];
-                        sh = sh2;
-                        src = 1;
-                        vox = gi;
-                    }
-                    while (!(word & kLeafBit)) {
-                        --sh;
-                        uint32_t v = (word << 1) | __builtin_amdgcn_ubfe(q[0], (uint32_t)sh, 1u);
-                        v = (v << 1) | __builtin_amdgcn_ubfe(q[1], (uint32_t)sh, 1u);
-                        v = (v << 1) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh, 1u);
-                        word = A.nodes[v];
-                        src = 2;
-                        vox = v;
-                    }
+                    word = descend_to_leaf(A, q, word, sh1, sh2, L2, LL, src, vox);
                 }
                 const int depth = (int)((word >> 16) & 0x7fu);
                 const float sc = __uint_as_float((uint32_t)(127 + depth) << 23);

@@ -342,6 +342,29 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
         [[maybe_unused]] float sigma_held = 0.f;  // BRICK: sigma of a dense leaf that did not come out of a record
         float delta_t = 0.f, weight = 0.f, att = 1.f;
         uint32_t vox = 0;
+        [[maybe_unused]] bool track_leaf = false;  // MODE 2 / 3: this lane stepped into a leaf the trackers look at (vox is its voxel)
+        [[maybe_unused]] int track_depth = 0;
+        // rt_core.cuh:237-252 (dense leaf: best weight so far) and :308-321 (first leaf before any dense one); `dense` and `weight` final
+        [[maybe_unused]] auto track_update = [&]() {
+            if constexpr (MODE == 2 || MODE == 3) {
+                if (track_leaf) {
+                    const bool split_ok = track_depth < K.max_depth && (dense ? weight > max_weight : max_weight == -1.f);
+                    if (split_ok) {
+                        sp_vox = (int32_t)vox;
+                        sp_prio = (float)track_depth;
+                        if (dense) max_weight = weight;
+                    }
+                    if (K.sample_counts && (dense ? weight > max_sample_weight : max_sample_weight == -1.f)) {
+                        const int16_t sc = K.sample_counts[vox];
+                        if (sc < K.max_sample_count) {
+                            sa_vox = (int32_t)vox;
+                            sa_prio = (float)sc;
+                            if (dense) max_sample_weight = weight;
+                        }
+                    }
+                }
+            }
+        };
         ph_mark = phase_clock();
         if (alive) {
             if (!(t < tmax)) {
@@ -414,7 +437,8 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                                 const uint32_t code = __builtin_amdgcn_ubfe(e.y, s2 << 1, 2u);
                                 // 0: walk on from the chunk (word stays); 1 / 2: an empty leaf of depth L2 + 1 / L2 + 2; 3: a leaf of depth L2 + 2
                                 // with sigma != 0 -- its voxel through the entry's child word, its sigma with its colour row (cand)
-                                vox = (e.x << 3) | s2;
+                                // (the voxel of a code-1 leaf is voxel s1 of the cell's chunk; tracker frames name it)
+                                vox = code == 1u ? ((word << 3) | s1) : ((e.x << 3) | s2);
                                 cand = code == 3u;
                                 word = code != 0u ? (kLeafBit | ((uint32_t)(L2 + 2 - (code == 1u ? 1 : 0)) << 16)) : word;
                                 src = 2;
@@ -433,6 +457,14 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                             const uint32_t w2 = K.shadow_nodes[vox];
                             asm volatile("" ::"v"(w2));
                         }
+                    }
+                }
+                if constexpr (BRICK && MODE == 3) {
+                    // the sample march reads no colour row: a non-empty leaf found through an inline word / a record fetches its node word
+                    // (depth and sigma) -- the one load an empty leaf of the last levels no longer costs
+                    if (cand) {
+                        word = A.nodes[vox];
+                        cand = false;
                     }
                 }
                 if constexpr (MODE == 1) {
@@ -459,7 +491,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                 const float sigma = half_bits_to_float((uint16_t)word);
                 const bool is_dense = sigma > P.sigma_thresh && !ablate(2);
                 bool need_vox = is_dense;
-                if constexpr (MODE == 2 || MODE == 3) need_vox = is_dense || max_weight == -1.f || max_sample_weight == -1.f || K.visited != nullptr;
+                if constexpr (MODE == 2 || MODE == 3) need_vox = is_dense || cand || max_weight == -1.f || max_sample_weight == -1.f || K.visited != nullptr;
                 if (need_vox) {
                     // voxel index of a leaf that was answered by one of the lookup grids
                     if (src == 0) vox = A.grid_vox[((((q[0] >> shg) << A.grid_level) + (q[1] >> shg)) << A.grid_level) + (q[2] >> shg)];
@@ -469,7 +501,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                     // the mark only ever goes 0 -> 1: load + conditional plain store (mnv_march_ref_layout.hip does the same per level)
                     if (K.visited && __hip_atomic_load(&K.visited[vox >> 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) K.visited[vox >> 3] = 1;
                 }
-                if constexpr (BRICK) {
+                if constexpr (BRICK && MODE != 3) {
                     // the opacity of every dense sample is worked out in the colour block (settle): a candidate's sigma arrives there with its row
                     dense = (is_dense || cand) && !ablate(2);
                     sigma_held = sigma;
@@ -480,23 +512,10 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                     weight = T * (1.f - att);
                 }
                 if constexpr (MODE == 2 || MODE == 3) {
-                    // rt_core.cuh:237-252 (dense leaf: best weight so far) and :308-321 (first leaf before any dense one)
-                    if (need_vox) {
-                        const bool split_ok = depth < K.max_depth && (is_dense ? weight > max_weight : max_weight == -1.f);
-                        if (split_ok) {
-                            sp_vox = (int32_t)vox;
-                            sp_prio = (float)depth;
-                            if (is_dense) max_weight = weight;
-                        }
-                        if (K.sample_counts && (is_dense ? weight > max_sample_weight : max_sample_weight == -1.f)) {
-                            const int16_t sc = K.sample_counts[vox];
-                            if (sc < K.max_sample_count) {
-                                sa_vox = (int32_t)vox;
-                                sa_prio = (float)sc;
-                                if (is_dense) max_sample_weight = weight;
-                            }
-                        }
-                    }
+                    track_leaf = need_vox;
+                    track_depth = depth;
+                    // (BRICK tracker frames: whether the leaf is dense, and its weight, are known behind the colour block)
+                    if constexpr (!(BRICK && MODE == 2)) track_update();
                 }
                 if constexpr (MODE == 3) {
                     // rt_core.cuh:508-549: one row per dense step while there is room
@@ -622,7 +641,6 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                 // dense lanes waited for two or three passes' row misses one after the other -- LAB_NOTEBOOK.md.)
                 if (dense) {
                     stat(10, true);
-                    constexpr int NW = CHAN_BYTES / 4;
                     uint32_t vx = vox;
                     if (ablate(4)) vx &= 0xffffu;  // diagnostics: rows served from cache (wrong colours)
                     const uint8_t *row = A.rows + (int64_t)vx * ROW_BYTES;
@@ -690,6 +708,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                     }
                 }
             }
+            if constexpr (BRICK && MODE == 2) track_update();  // (lanes of an iteration without any dense sample: below)
             if (dense) {
                 T *= att;  // rt_core.cuh:293-307
                 if (T < P.stop_thresh) {
@@ -697,6 +716,9 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                     alive = false;
                 }
             }
+        }
+        if constexpr (BRICK && MODE == 2) {
+            if (dense_mask == 0) track_update();
         }
         t += delta_t;  // 0 for lanes that did not step
         if constexpr (MODE == 1) {

@@ -163,15 +163,35 @@ def render_nerf_results_npz(npz_path, cam_struct, opt_struct, sample_values, z_v
     return rgba
 
 
+def render_nerf_results_dropin_npz(npz_path, cam_struct, opt_struct, sample_values, z_vals, offsets, image=None, offscreen=True):
+    """libmnv.so through the nine-parameter viewer::render_nerf_results of include/mnv_reference_binding.hpp on the reference's own N3Tree / Camera /
+    tensors: the RGBA8 frame [h][w][4] its launcher writes through the image surface.  image: what the surface holds before the call."""
+    h = lib()
+    h.ref_render_nerf_results_dropin_npz.restype = C.c_int
+    sample_values = np.ascontiguousarray(sample_values, np.float32)
+    z_vals = np.ascontiguousarray(z_vals, np.float32)
+    offsets = np.ascontiguousarray(offsets, np.int64)
+    out = np.zeros((cam_struct.height, cam_struct.width, 4), np.uint8) if image is None else np.ascontiguousarray(image, np.uint8).copy()
+    w, ht, fx, fy, cx, cy, c2w = _cam_args(cam_struct)
+    rc = h.ref_render_nerf_results_dropin_npz(os.fsencode(npz_path), C.c_int(w), C.c_int(ht), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+                                              c2w, C.byref(opt_struct), C.c_int(C.sizeof(opt_struct)), C.c_void_p(sample_values.ctypes.data),
+                                              C.c_int64(sample_values.shape[0]), C.c_int(sample_values.shape[1]), C.c_void_p(z_vals.ctypes.data),
+                                              C.c_void_p(offsets.ctypes.data), C.c_int(int(offscreen)), C.c_void_p(out.ctypes.data))
+    if rc != 0:
+        raise RuntimeError(f"ref_render_nerf_results_dropin_npz failed with {rc}")
+    return out
+
+
 def _grid_args(grid_struct):
     return ((C.c_int32 * 2)(*list(grid_struct.grid_dim)), (C.c_float * 3)(*list(grid_struct.min_position)), (C.c_float * 3)(*list(grid_struct.range)))
 
 
-def add_children_npz(npz_path, opt_struct, max_capacity, parent_nodes, samples, visited, grid_struct):
+def add_children_npz(npz_path, opt_struct, max_capacity, parent_nodes, samples, visited, grid_struct, dropin=False):
     """The reference's add_children_and_generate_samples_kernel.  samples [n*8][spc][dim] uniform numbers in; returns
-    dict(samples, clusters, visited, child [max_capacity][8], parent [max_capacity])."""
+    dict(samples, clusters, visited, child [max_capacity][8], parent [max_capacity]).  dropin: the same call served by libmnv.so through the
+    nine-parameter viewer::add_children_and_generate_samples of include/mnv_reference_binding.hpp on the reference's own N3Tree and tensors."""
     h = lib()
-    h.ref_add_children_npz.restype = C.c_int
+    h.ref_add_children_dropin_npz.restype = C.c_int
     parent_nodes = np.ascontiguousarray(parent_nodes, np.int32)
     samples = np.ascontiguousarray(samples, np.float32).copy()
     visited = np.ascontiguousarray(visited, np.int32).copy()
@@ -179,38 +199,41 @@ def add_children_npz(npz_path, opt_struct, max_capacity, parent_nodes, samples, 
     clusters = np.empty(samples.shape[:2], np.int16)
     child, parent = np.empty((max_capacity, 8), np.int32), np.empty(max_capacity, np.int32)
     gd, mp, rg = _grid_args(grid_struct)
-    rc = h.ref_add_children_npz(os.fsencode(npz_path), C.byref(opt_struct), C.c_int(C.sizeof(opt_struct)), C.c_int(max_capacity),
-                                C.c_void_p(parent_nodes.ctypes.data), C.c_int(n), C.c_void_p(samples.ctypes.data), C.c_int(samples.shape[-1]),
-                                C.c_void_p(clusters.ctypes.data), C.c_void_p(visited.ctypes.data), gd, mp, rg, C.c_void_p(child.ctypes.data),
-                                C.c_void_p(parent.ctypes.data))
+    rc = h.ref_add_children_dropin_npz(os.fsencode(npz_path), C.byref(opt_struct), C.c_int(C.sizeof(opt_struct)), C.c_int(max_capacity),
+                                       C.c_void_p(parent_nodes.ctypes.data), C.c_int(n), C.c_void_p(samples.ctypes.data), C.c_int(samples.shape[-1]),
+                                       C.c_void_p(clusters.ctypes.data), C.c_void_p(visited.ctypes.data), gd, mp, rg, C.c_void_p(child.ctypes.data),
+                                       C.c_void_p(parent.ctypes.data), C.c_int(int(dropin)))
     if rc != 0:
         raise RuntimeError(f"ref_add_children_npz failed with {rc}")
     return dict(samples=samples, clusters=clusters, visited=visited, child=child, parent=parent)
 
 
-def generate_samples_npz(npz_path, opt_struct, nodes, samples, grid_struct):
+def generate_samples_npz(npz_path, opt_struct, nodes, samples, grid_struct, dropin=False):
+    """The reference's generate_samples_kernel; dropin: libmnv.so through the eight-parameter viewer::generate_samples binding."""
     h = lib()
-    h.ref_generate_samples_npz.restype = C.c_int
+    h.ref_generate_samples_dropin_npz.restype = C.c_int
     nodes = np.ascontiguousarray(nodes, np.int32)
     samples = np.ascontiguousarray(samples, np.float32).copy()
     clusters = np.empty(samples.shape[:2], np.int16)
     gd, mp, rg = _grid_args(grid_struct)
-    rc = h.ref_generate_samples_npz(os.fsencode(npz_path), C.byref(opt_struct), C.c_int(C.sizeof(opt_struct)), C.c_void_p(nodes.ctypes.data),
-                                    C.c_int(nodes.shape[0]), C.c_void_p(samples.ctypes.data), C.c_int(samples.shape[-1]),
-                                    C.c_void_p(clusters.ctypes.data), gd, mp, rg)
+    rc = h.ref_generate_samples_dropin_npz(os.fsencode(npz_path), C.byref(opt_struct), C.c_int(C.sizeof(opt_struct)), C.c_void_p(nodes.ctypes.data),
+                                           C.c_int(nodes.shape[0]), C.c_void_p(samples.ctypes.data), C.c_int(samples.shape[-1]),
+                                           C.c_void_p(clusters.ctypes.data), gd, mp, rg, C.c_int(int(dropin)))
     if rc != 0:
         raise RuntimeError(f"ref_generate_samples_npz failed with {rc}")
     return dict(samples=samples, clusters=clusters)
 
 
-def adjust_parents_npz(npz_path, capacity, first_shift_index, to_delete, index_shifts):
+def adjust_parents_npz(npz_path, capacity, first_shift_index, to_delete, index_shifts, dropin=False):
+    """The reference's adjust_parents_and_children_kernel; dropin: libmnv.so through the four-parameter viewer::adjust_parents_and_children binding."""
     h = lib()
-    h.ref_adjust_parents_npz.restype = C.c_int
+    h.ref_adjust_parents_dropin_npz.restype = C.c_int
     to_delete = np.ascontiguousarray(to_delete, np.uint8)
     index_shifts = np.ascontiguousarray(index_shifts, np.int32)
     child, parent = np.empty((capacity, 8), np.int32), np.empty(capacity, np.int32)
-    rc = h.ref_adjust_parents_npz(os.fsencode(npz_path), C.c_int(first_shift_index), C.c_void_p(to_delete.ctypes.data),
-                                  C.c_void_p(index_shifts.ctypes.data), C.c_void_p(child.ctypes.data), C.c_void_p(parent.ctypes.data))
+    rc = h.ref_adjust_parents_dropin_npz(os.fsencode(npz_path), C.c_int(first_shift_index), C.c_void_p(to_delete.ctypes.data),
+                                         C.c_void_p(index_shifts.ctypes.data), C.c_void_p(child.ctypes.data), C.c_void_p(parent.ctypes.data),
+                                         C.c_int(int(dropin)))
     if rc != 0:
         raise RuntimeError(f"ref_adjust_parents_npz failed with {rc}")
     return dict(child=child, parent=parent)

@@ -314,10 +314,23 @@ int ref_render_track_onscreen_npz(const char *npz_path, int width, int height, f
 // The reference's add_children_and_generate_samples_kernel (renderer_kernel.cu:170-198, launched as :487-510) on the tree in
 // `npz_path` moved to the device with room for max_capacity chunks.  samples: in = the caller's uniform numbers, out = sample
 // rows; child_out [max_capacity][8], parent_out [max_capacity], visited in/out [max_capacity].
+int ref_add_children_dropin_npz(const char *npz_path, const void *opt_bytes, int opt_size, int max_capacity, const int32_t *parent_nodes,
+                                int num_parents, float *samples, int samples_dim, int16_t *clusters, int32_t *visited, const int32_t *grid_dim2,
+                                const float *min_position3, const float *range3, int32_t *child_out, int32_t *parent_out, int dropin);
+
 int ref_add_children_npz(const char *npz_path, const void *opt_bytes, int opt_size, int max_capacity, const int32_t *parent_nodes,
                          int num_parents, float *samples, int samples_dim, int16_t *clusters, int32_t *visited,
                          const int32_t *grid_dim2, const float *min_position3, const float *range3, int32_t *child_out,
                          int32_t *parent_out) {
+    return ref_add_children_dropin_npz(npz_path, opt_bytes, opt_size, max_capacity, parent_nodes, num_parents, samples, samples_dim, clusters, visited,
+                                       grid_dim2, min_position3, range3, child_out, parent_out, 0);
+}
+
+// dropin != 0: not the reference's kernel but libmnv.so through the nine-parameter viewer::add_children_and_generate_samples of
+// include/mnv_reference_binding.hpp, on the reference's own N3Tree and the same tensors -- the same arrays must come back
+int ref_add_children_dropin_npz(const char *npz_path, const void *opt_bytes, int opt_size, int max_capacity, const int32_t *parent_nodes,
+                                int num_parents, float *samples, int samples_dim, int16_t *clusters, int32_t *visited, const int32_t *grid_dim2,
+                                const float *min_position3, const float *range3, int32_t *child_out, int32_t *parent_out, int dropin) {
     using namespace viewer;
     if (opt_size != (int)sizeof(RenderOptions)) return -2;
     RenderOptions opt;
@@ -337,6 +350,10 @@ int ref_add_children_npz(const char *npz_path, const void *opt_bytes, int opt_si
         torch::Tensor mp = torch::from_blob((void *)min_position3, {3}, torch::kFloat32).clone().to(dev);
         torch::Tensor rg = torch::from_blob((void *)range3, {3}, torch::kFloat32).clone().to(dev);
         const int threads = 512, blocks = N_BLOCKS_NEEDED(rows, threads);
+        if (dropin) {
+            if (hipDeviceSynchronize() != hipSuccess) return -4;
+            add_children_and_generate_samples(tree, opt, pn, smp, cl, vis, gd, mp, rg);
+        } else
         hipLaunchKernelGGL(add_children_and_generate_samples_kernel, dim3(blocks), dim3(threads), 0, 0, viewer::internal::TreeSpec(tree), opt,
                            pn.packed_accessor32<int32_t, 2, torch::RestrictPtrTraits>(), smp.packed_accessor32<float, 3, torch::RestrictPtrTraits>(),
                            cl.packed_accessor32<short, 2, torch::RestrictPtrTraits>(), vis.packed_accessor32<int32_t, 1, torch::RestrictPtrTraits>(),
@@ -356,8 +373,20 @@ int ref_add_children_npz(const char *npz_path, const void *opt_bytes, int opt_si
 }
 
 // The reference's generate_samples_kernel (renderer_kernel.cu:200-213, launched as :512-534) for existing voxels nodes[i] = (chunk, child).
+int ref_generate_samples_dropin_npz(const char *npz_path, const void *opt_bytes, int opt_size, const int32_t *nodes, int num_items, float *samples,
+                                    int samples_dim, int16_t *clusters, const int32_t *grid_dim2, const float *min_position3, const float *range3,
+                                    int dropin);
+
 int ref_generate_samples_npz(const char *npz_path, const void *opt_bytes, int opt_size, const int32_t *nodes, int num_items, float *samples,
                              int samples_dim, int16_t *clusters, const int32_t *grid_dim2, const float *min_position3, const float *range3) {
+    return ref_generate_samples_dropin_npz(npz_path, opt_bytes, opt_size, nodes, num_items, samples, samples_dim, clusters, grid_dim2, min_position3,
+                                           range3, 0);
+}
+
+// dropin != 0: libmnv.so through the eight-parameter viewer::generate_samples of include/mnv_reference_binding.hpp
+int ref_generate_samples_dropin_npz(const char *npz_path, const void *opt_bytes, int opt_size, const int32_t *nodes, int num_items, float *samples,
+                                    int samples_dim, int16_t *clusters, const int32_t *grid_dim2, const float *min_position3, const float *range3,
+                                    int dropin) {
     using namespace viewer;
     if (opt_size != (int)sizeof(RenderOptions)) return -2;
     RenderOptions opt;
@@ -376,6 +405,10 @@ int ref_generate_samples_npz(const char *npz_path, const void *opt_bytes, int op
         torch::Tensor mp = torch::from_blob((void *)min_position3, {3}, torch::kFloat32).clone().to(dev);
         torch::Tensor rg = torch::from_blob((void *)range3, {3}, torch::kFloat32).clone().to(dev);
         const int threads = 512, blocks = N_BLOCKS_NEEDED(rows, threads);
+        if (dropin) {
+            if (hipDeviceSynchronize() != hipSuccess) return -4;
+            generate_samples(tree, opt, nd, smp, cl, gd, mp, rg);
+        } else
         hipLaunchKernelGGL(generate_samples_kernel, dim3(blocks), dim3(threads), 0, 0, viewer::internal::TreeSpec(tree), opt,
                            nd.packed_accessor32<int32_t, 2, torch::RestrictPtrTraits>(), smp.packed_accessor32<float, 3, torch::RestrictPtrTraits>(),
                            cl.packed_accessor32<short, 2, torch::RestrictPtrTraits>(), gd.packed_accessor32<int32_t, 1, torch::RestrictPtrTraits>(),
@@ -392,8 +425,17 @@ int ref_generate_samples_npz(const char *npz_path, const void *opt_bytes, int op
 }
 
 // The reference's adjust_parents_and_children_kernel (renderer_kernel.cu:63-86, launched as :536-549).
+int ref_adjust_parents_dropin_npz(const char *npz_path, int first_shift_index, const uint8_t *to_delete, const int32_t *index_shifts,
+                                  int32_t *child_out, int32_t *parent_out, int dropin);
+
 int ref_adjust_parents_npz(const char *npz_path, int first_shift_index, const uint8_t *to_delete, const int32_t *index_shifts,
                            int32_t *child_out, int32_t *parent_out) {
+    return ref_adjust_parents_dropin_npz(npz_path, first_shift_index, to_delete, index_shifts, child_out, parent_out, 0);
+}
+
+// dropin != 0: libmnv.so through the four-parameter viewer::adjust_parents_and_children of include/mnv_reference_binding.hpp
+int ref_adjust_parents_dropin_npz(const char *npz_path, int first_shift_index, const uint8_t *to_delete, const int32_t *index_shifts,
+                                  int32_t *child_out, int32_t *parent_out, int dropin) {
     using namespace viewer;
     try {
         N3Tree tree;
@@ -405,6 +447,10 @@ int ref_adjust_parents_npz(const char *npz_path, int first_shift_index, const ui
         torch::Tensor td = torch::from_blob((void *)to_delete, {cap}, torch::kUInt8).clone().to(torch::kBool).to(dev);
         torch::Tensor sh = torch::from_blob((void *)index_shifts, {cap}, torch::kInt32).clone().to(dev);
         const int threads = 512, blocks = N_BLOCKS_NEEDED(cap - first_shift_index, threads);
+        if (dropin) {
+            if (hipDeviceSynchronize() != hipSuccess) return -4;
+            adjust_parents_and_children(tree, first_shift_index, td, sh);
+        } else
         hipLaunchKernelGGL(adjust_parents_and_children_kernel, dim3(blocks), dim3(threads), 0, 0, viewer::internal::TreeSpec(tree), first_shift_index,
                            td.packed_accessor32<bool, 1, torch::RestrictPtrTraits>(), sh.packed_accessor32<int32_t, 1, torch::RestrictPtrTraits>());
         if (hipDeviceSynchronize() != hipSuccess) return -4;
@@ -679,6 +725,41 @@ int ref_render_nerf_results_npz(const char *npz_path, int width, int height, flo
         memcpy(rgba_host, out.cpu().data_ptr(), n * 16);
     } catch (const std::exception &e) {
         fprintf(stderr, "ref_render_nerf_results_npz: %s\n", e.what());
+        return -1;
+    }
+    return 0;
+}
+
+// libmnv.so through the nine-parameter viewer::render_nerf_results of include/mnv_reference_binding.hpp on the reference's own N3Tree,
+// Camera and tensors: the RGBA8 image the reference's launcher writes through its surface (renderer_kernel.cu:237).  image_host [h][w][4]
+// is uploaded first (what is "under" the frame; the result must not depend on it, renderer_kernel.cu:316) and returned overwritten.
+int ref_render_nerf_results_dropin_npz(const char *npz_path, int width, int height, float fx, float fy, float cx, float cy, const float *c2w12,
+                                       const void *opt_bytes, int opt_size, const float *sample_values, int64_t n_samples, int value_stride,
+                                       const float *z_vals, const int64_t *offsets, int offscreen, uint8_t *image_host) {
+    using namespace viewer;
+    if (opt_size != (int)sizeof(RenderOptions)) return -2;
+    RenderOptions opt;
+    memcpy(&opt, opt_bytes, sizeof(opt));
+    try {
+        N3Tree tree;
+        tree.open(npz_path);
+        if (tree.N == 0) return -3;
+        tree.move_to_device(tree.capacity, true, true);
+        auto camera = make_camera(width, height, fx, fy, cx, cy, c2w12);
+        const int64_t n = (int64_t)width * height;
+        auto dev = torch::kCUDA;
+        torch::Tensor sv = torch::from_blob((void *)sample_values, {n_samples, (int64_t)value_stride}, torch::kFloat32).clone().to(dev);
+        torch::Tensor zv = torch::from_blob((void *)z_vals, {n_samples}, torch::kFloat32).clone().to(dev);
+        torch::Tensor of = torch::from_blob((void *)offsets, {n}, torch::kInt64).clone().to(dev);
+        torch::Tensor image = torch::from_blob((void *)image_host, {n, 4}, torch::kUInt8).clone().to(dev);
+        uint8_t *image_arr = image.data_ptr<uint8_t>();
+        hipStream_t stream = nullptr;
+        if (hipDeviceSynchronize() != hipSuccess) return -4;
+        render_nerf_results(tree, *camera, opt, image_arr, stream, sv, zv, of, offscreen != 0);
+        if (hipDeviceSynchronize() != hipSuccess) return -4;
+        memcpy(image_host, image.cpu().data_ptr<uint8_t>(), n * 4);
+    } catch (const std::exception &e) {
+        fprintf(stderr, "ref_render_nerf_results_dropin_npz: %s\n", e.what());
         return -1;
     }
     return 0;

@@ -1,0 +1,260 @@
+"""Tree edits and the lookup words that follow them.  mnv_accel_refresh patches -- besides node words, rows and the two lookup grids -- the
+inline cell words (grid2i) and the brick records of exactly the voxels an edit touches, and a prune derives both again, so that EVERY frame kind
+of the refinement loop (plain, trackers + visit marks, emitted samples, the fused guided frame) keeps reading them
+(csrc/mnv_accel_refresh_prune.hip; reference: the loop of src/renderer/cuda_renderer.cpp:98-156 edits tree.child / tree.data in place
+between frames, :205-381).
+
+Two kinds of evidence:
+  * frames -- after every round of random splits (at every depth around the second lookup grid, chained splits included) and row rewrites
+    (sigma going to and from zero), the patched accel's plain / tracker / sample frames equal the reference-layout kernel's on the same arrays
+    bit for bit, voxel numbers and visit marks included, and a freshly built accel's;
+  * words -- the same rounds (and the refinement-loop and prune tests) once more in a child process on the test-hook build with
+    MNV_REFRESH_DEBUG=2, where every refresh / prune ends with a kernel that holds EVERY patched lookup word (grid, grid2, grid2_vox, grid2i,
+    records) against a fresh derivation from the node words and fails the call on the first difference."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+import hooks
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def chunk_depths(parent, cap):
+    depth = np.zeros(cap, np.int32)
+    depth[0] = 1
+    pc = parent[:cap] >> 3
+    for _ in range(64):   # level by level, whatever order the chunks are numbered in
+        todo = (depth == 0) & (depth[pc] > 0)
+        todo[0] = False
+        if not todo.any():
+            break
+        depth[todo] = depth[pc[todo]] + 1
+    assert (depth > 0).all()
+    return depth
+
+
+class EditedTree:
+    """Host copy of the reference-layout arrays + their device twins at fixed addresses, edited the way the refinement loop edits them."""
+
+    def __init__(self, mnv, torch, spec, reserve):
+        self.mnv, self.torch = mnv, torch
+        tree = cases.make_tree(mnv, spec)
+        self.tree = tree
+        v = tree.host_view()
+        data, child, parent = tree.host_arrays()
+        self.cap, self.dd, self.max_cap = v.capacity, v.data_dim, v.capacity + reserve
+        self.data = np.zeros((self.max_cap, 8, self.dd), np.float16)
+        self.child = np.zeros((self.max_cap, 8), np.int32)
+        self.parent = np.zeros(self.max_cap, np.int32)
+        self.data[:self.cap], self.child[:self.cap], self.parent[:self.cap] = data.view(np.float16).reshape(self.cap, 8, self.dd), child, parent
+        self.depth = np.zeros(self.max_cap, np.int32)
+        self.depth[:self.cap] = chunk_depths(parent, self.cap)
+        self.counts = np.random.default_rng(99).integers(0, 13, (self.max_cap, 8)).astype(np.int16)
+        self.d = dict(data=torch.from_numpy(self.data.view(np.int16)).cuda(), child=torch.from_numpy(self.child).cuda(), parent=torch.from_numpy(self.parent).cuda(),
+                      counts=torch.from_numpy(self.counts).cuda())
+        tv = mnv.TreeView()
+        for f in ("offset", "scale", "N", "data_dim", "format", "basis_dim"):
+            setattr(tv, f, getattr(v, f))
+        tv.data, tv.child, tv.parent, tv.sample_counts = (self.d[k].data_ptr() for k in ("data", "child", "parent", "counts"))
+        tv.capacity = self.cap
+        self.tv = tv
+        self.accel = mnv.accel_create(tv, self.max_cap)
+
+    def close(self):
+        self.mnv.accel_destroy(self.accel)
+
+    def random_row(self, rng, empty_prob):
+        row = (rng.standard_normal(self.dd) * 0.7).astype(np.float16)
+        row[self.dd - 1] = np.float16(0.0) if rng.random() < empty_prob else np.float16(rng.uniform(0.02, 40.0))
+        return row
+
+    def edit(self, rng, n_split, n_change, depths_wanted, empty_prob=0.5):
+        """n_split leaves become inner voxels with eight new leaves each (a third of them under chunks appended in this very round),
+        n_change leaf rows are rewritten; then ONE mnv_accel_refresh, as the loop issues it."""
+        torch = self.torch
+        old_cap = self.cap
+        for k in range(n_split):
+            if self.cap >= self.max_cap:
+                break
+            lo = old_cap if (k % 3 == 2 and self.cap > old_cap) else 0    # chained: a leaf of a chunk that is new in this round
+            cand = np.argwhere(self.child[lo:self.cap] == 0)
+            cand[:, 0] += lo
+            want = depths_wanted[k % len(depths_wanted)]
+            at = cand[self.depth[cand[:, 0]] == want]
+            pick = at if len(at) else cand
+            c, s = pick[rng.integers(len(pick))]
+            if self.depth[c] >= 22:
+                continue
+            nc = self.cap
+            self.child[c, s] = nc - c
+            self.parent[nc] = c * 8 + s
+            self.child[nc] = 0
+            self.depth[nc] = self.depth[c] + 1
+            for j in range(8):
+                self.data[nc, j] = self.random_row(rng, empty_prob)
+            self.cap += 1
+        changed = []
+        leaves = np.argwhere(self.child[:old_cap] == 0)
+        for k in range(n_change):
+            want = depths_wanted[k % len(depths_wanted)]
+            at = leaves[self.depth[leaves[:, 0]] == want]
+            pick = at if len(at) else leaves
+            c, s = pick[rng.integers(len(pick))]
+            if self.child[c, s] != 0:
+                continue   # split in this round
+            self.data[c, s] = self.random_row(rng, empty_prob)
+            changed.append((c, s))
+        self.d["data"].copy_(torch.from_numpy(self.data.view(np.int16)))
+        self.d["child"].copy_(torch.from_numpy(self.child))
+        self.d["parent"].copy_(torch.from_numpy(self.parent))
+        self.tv.capacity = self.cap
+        ch = torch.from_numpy(np.asarray(changed, np.int32).reshape(-1, 2)).cuda() if changed else None
+        self.mnv.accel_refresh(self.accel, self.tv, old_cap, changed_nodes=ch)
+        return self.cap - old_cap, len(changed)
+
+
+def frames_of(mnv, torch, et, cam, opt, accel, grid):
+    """(plain, tracker + visit, sample) frames of `accel` (None: the reference-layout kernels on the arrays) as numpy."""
+    H, W = cam.height, cam.width
+    f32 = lambda *s: torch.full(s, float("nan"), dtype=torch.float32, device="cuda")  # noqa: E731
+    out = {}
+    rgba = f32(H, W, 4)
+    split, sample = torch.full((H, W, 3), -1.0, dtype=torch.float32, device="cuda"), torch.full((H, W, 3), -1.0, dtype=torch.float32, device="cuda")
+    visited = torch.zeros(et.max_cap, dtype=torch.int32, device="cuda")
+    if accel is None:
+        plain = f32(H, W, 4)
+        mnv.render_voxels(et.tv, cam, opt, rgba=plain)
+        mnv.render_voxels(et.tv, cam, opt, rgba=rgba, split_track=split, sample_track=sample, visited=visited, track_visit=True)
+    else:
+        plain = f32(H, W, 4)
+        mnv.render_voxels_accel(accel, cam, opt, rgba=plain)
+        mnv.render_voxels_accel_visit(accel, cam, opt, visited, et.d["parent"], rgba=rgba, split_track=split, sample_track=sample, sample_counts=et.d["counts"])
+    out.update(plain=plain, rgba=rgba, split=split, sample=sample, visited=visited)
+    mg = opt.max_guided_samples
+    num = torch.zeros(H * W, dtype=torch.int16, device="cuda")
+    smp = torch.full((H * W, mg, 4), -1.0, dtype=torch.float32, device="cuda")
+    cl = torch.full((H * W, mg), -1, dtype=torch.int16, device="cuda")
+    s2, a2 = torch.full((H, W, 3), -1.0, dtype=torch.float32, device="cuda"), torch.full((H, W, 3), -1.0, dtype=torch.float32, device="cuda")
+    v2 = torch.zeros(et.max_cap, dtype=torch.int32, device="cuda")
+    if accel is None:
+        mnv.get_samples_from_voxels(et.tv, cam, opt, num, smp, cl, grid, split_track=s2, sample_track=a2, visited=v2, track_visit=True)
+    else:
+        mnv.get_samples_from_voxels_accel_visit(accel, cam, opt, v2, et.d["parent"], num, smp, cl, grid, split_track=s2, sample_track=a2, sample_counts=et.d["counts"])
+    torch.cuda.synchronize()
+    k = (torch.arange(mg, device="cuda")[None, :] < num[:, None].to(torch.int64))
+    out.update(num=num, smp=torch.where(k[..., None], smp, torch.full_like(smp, -1.0)), cl=torch.where(k, cl, torch.full_like(cl, -1)), s2=s2, a2=a2, v2=v2)
+    return {k_: t.cpu().numpy() for k_, t in out.items()}
+
+
+def same_frames(a, b):
+    bad = []
+    for k in a:
+        x, y = a[k], b[k]
+        eq = np.array_equal(x.view(np.uint32), y.view(np.uint32)) if x.dtype == np.float32 else np.array_equal(x, y)
+        if not eq:
+            bad.append(k)
+    return bad
+
+
+def make_grid(mnv):
+    g = mnv.ClusterGrid()
+    g.grid_dim[0], g.grid_dim[1] = 3, 2
+    for i, (lo, rng) in enumerate([(-1.0, 2.0), (-1.1, 2.2), (-0.9, 1.8)]):
+        g.min_position[i], g.range[i] = lo, rng
+    return g
+
+
+EDIT_CASES = [
+    # depth, basis, fmt, refine_prob: trees whose second lookup grid sits at level 8 (the grid's memory budget) with one, two and three levels below it
+    (9, 9, {}, 0.40),
+    (10, 4, {}, 0.40),
+    (11, 9, {}, 0.36),
+    (11, -1, dict(fmt=0), 0.36),
+    (6, 4, {}, 0.5),     # shallow: the grid sits one level above the leaves; splits deepen the tree past it
+]
+
+
+def run_rounds(mnv, torch, depth, basis, fmt_kw, refine, seed, rounds=6, verbose=False):
+    spec = dict(kind="random", depth=depth, basis_dim=basis, refine_prob=refine, empty_prob=0.9, sigma_max=40.0, seed=500 + seed + depth, **fmt_kw)
+    et = EditedTree(mnv, torch, spec, reserve=rounds * 96)
+    try:
+        info = mnv.accel_info(et.accel)
+        L2 = info["grid2_level"]
+        grid = make_grid(mnv)
+        rng = np.random.default_rng(seed)
+        cams = [mnv.Camera(168, 120, 400.0).set_pose((-2.5, 1.4, 1.8), (-0.74, 0.4, 0.54)), mnv.Camera(168, 120, 400.0).set_pose((2.2, -1.9, 1.1), (0.7, -0.6, 0.39))]
+        opt = mnv.RenderOptions.cli_defaults()
+        opt.max_depth, opt.max_sample_count, opt.max_guided_samples = 12, 9, 16
+        levels_seen = set()
+        for r in range(rounds):
+            wanted = [L2 - 1, L2, L2 + 1, L2 + 2, L2 + 3, 2, L2 + 1, L2]
+            added, changed = et.edit(rng, 96, 64, wanted)
+            assert added > 0
+            info = mnv.accel_info(et.accel)
+            levels_seen.add(info["brick_levels"])
+            cam = cams[r % 2]
+            got = frames_of(mnv, torch, et, cam, opt, et.accel, grid)
+            want = frames_of(mnv, torch, et, cam, opt, None, grid)
+            bad = same_frames(got, want)
+            assert not bad, (depth, basis, r, bad, info)
+            if verbose:
+                print(f"round {r}: +{added} chunks, {changed} rows rewritten, capacity {et.cap}, {info}", flush=True)
+        fresh = mnv.accel_create(et.tv)
+        try:
+            for cam in cams:
+                a, b = frames_of(mnv, torch, et, cam, opt, et.accel, grid), frames_of(mnv, torch, et, cam, opt, fresh, grid)
+                assert not same_frames(a, b)
+        finally:
+            mnv.accel_destroy(fresh)
+        return levels_seen, L2
+    finally:
+        et.close()
+
+
+@pytest.mark.parametrize("depth,basis,fmt_kw,refine", EDIT_CASES)
+def test_every_frame_kind_follows_random_edits_through_inline_words_and_records(mnv, torch_gpu, depth, basis, fmt_kw, refine):
+    levels, L2 = run_rounds(mnv, torch_gpu, depth, basis, fmt_kw, refine, seed=7)
+    # the edits never drop the inline words / records (they used to: brick_levels fell to 0 until a rebuild)
+    assert 0 not in levels or L2 == 0, (levels, L2)
+    if depth >= L2 + 2 and L2 > 0:
+        assert 2 in levels
+
+
+def test_patched_lookup_words_equal_a_fresh_derivation_word_for_word(mnv, torch_gpu):
+    """The rounds above, the refinement loop of the host renderer and the prune, in a child process on the test-hook build with
+    MNV_REFRESH_DEBUG=2: every mnv_accel_refresh / prune then verifies every lookup word on the device and fails on a difference."""
+    if not os.path.exists(hooks.HOOKS_LIB):
+        pytest.fail("mega-nerf-viewer_amd/testhooks/libmnv.so is missing (make builds it)")
+    env = hooks.hooks_env(MNV_REFRESH_DEBUG="2")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "[mnv verify]" not in r.stderr
+    assert r.stdout.count("verified rounds ok") == len(EDIT_CASES)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_refine_gpu.py") + "::test_accel_follows_a_prune_in_place",
+                        os.path.join(ROOT, "tests", "test_renderer_refine_gpu.py") + "::test_refinement_run_keeps_a_valid_tree_and_the_accel_follows",
+                        os.path.join(ROOT, "tests", "test_renderer_refine_gpu.py") + "::test_prune_runs_inside_the_loop"],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "[mnv verify]" not in r.stderr and "[mnv refresh]" in r.stderr   # the knob was honoured: this was the hooks build
+
+
+if __name__ == "__main__":   # the child process of the word-for-word test
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+
+    import mega_nerf_viewer_amd as m
+
+    assert os.environ.get("MNV_LIB_PATH", "").endswith(os.path.join("testhooks", "libmnv.so"))
+    for depth, basis, fmt_kw, refine in EDIT_CASES:
+        run_rounds(m, torch, depth, basis, fmt_kw, refine, seed=11, verbose=True)
+        print("verified rounds ok", flush=True)

@@ -512,8 +512,8 @@ def test_tree_depth_extremes_bit_exact(mnv, orc, torch_gpu, depth, refine, basis
 @pytest.mark.parametrize("depth,basis,fmt_kw", [(10, 9, {}), (11, 4, {}), (12, 9, {}), (13, 1, {}), (11, -1, dict(fmt=0)), (11, 16, {})])
 def test_bricks_below_the_second_grid_bit_exact(mnv, orc, torch_gpu, depth, basis, fmt_kw):
     """Trees with leaves two or more levels below the second lookup grid carry bricks (the two levels below the grid in one 8-byte
-    load: AccelView::bricks): plain, fast-colour-off and depth frames read them and stay bit-identical to the oracle; a tree edit
-    (mnv_accel_refresh) drops them -- frames walk the node words, still right -- and mnv_accel_rebuild derives them again."""
+    load: AccelView::recs): plain, depth and tracker frames read them and stay bit-identical to the oracle, across a tree edit
+    (mnv_accel_refresh patches them) and a rebuild."""
     torch = torch_gpu
     spec = dict(kind="random", depth=depth, basis_dim=basis, refine_prob=0.42, empty_prob=0.93, sigma_max=40.0, seed=300 + depth + basis, **fmt_kw)
     tree = cases.make_tree(mnv, spec)
@@ -548,31 +548,32 @@ def test_bricks_below_the_second_grid_bit_exact(mnv, orc, torch_gpu, depth, basi
     mnv.render_voxels_accel_batch(tree.accel, [cam, cam2], opt, rgba=out)
     torch.cuda.synchronize()
     assert np.array_equal(cases.bits(out[0].cpu().numpy()), cases.bits(ref["rgba"])) and np.array_equal(cases.bits(out[1].cpu().numpy()), cases.bits(ref2))
-    # stale after a refresh (no change needed for the flag to drop: an empty edit list is a no-op, so rewrite one row in place)
+    # a tree edit (mnv_accel_refresh) keeps both: the refresh patches the words of the cells and records the edit touches (until round 5 it
+    # dropped them until a rebuild or sixteen plain frames in a row).  An edit that changes nothing -- one row rewritten with itself --
+    # leaves every frame kind as it was; tests/test_accel_edit_gpu.py holds real edits against the reference-layout kernel.
     dv = tree.device_view()
     changed = torch.tensor([[0, 0]], dtype=torch.int32, device="cuda")
     mnv.accel_refresh(tree.accel, dv, dv.capacity, changed_nodes=changed)
-    assert mnv.accel_info(tree.accel)["brick_levels"] == 0
+    assert mnv.accel_info(tree.accel)["brick_levels"] == 2
     got, _ = _render_gpu(mnv, torch, tree, cam, opt, "accel")
     assert np.array_equal(cases.bits(got), cases.bits(ref["rgba"]))
     mnv.accel_rebuild(tree.accel, dv)
     assert mnv.accel_info(tree.accel)["brick_levels"] == 2
     got, _ = _render_gpu(mnv, torch, tree, cam, opt, "accel")
     assert np.array_equal(cases.bits(got), cases.bits(ref["rgba"]))
-    # ... or by themselves, once 16 plain frames in a row have followed the last edit (derived on the launch stream of the sixteenth; a
-    # frame on another stream right behind it waits for that)
-    mnv.accel_refresh(tree.accel, dv, dv.capacity, changed_nodes=changed)
-    side = torch.cuda.Stream()
-    for k in range(18):
-        if k == 5:   # a tracker frame in between does not count and does not disturb
-            split = torch.full((cam.height, cam.width, 3), -1.0, dtype=torch.float32, device="cuda")
-            mnv.render_voxels_accel_track(tree.accel, cam, opt, rgba=torch.empty((cam.height, cam.width, 4), dtype=torch.float32, device="cuda"), split_track=split)
-        out1 = torch.full((cam.height, cam.width, 4), float("nan"), dtype=torch.float32, device="cuda")
-        mnv.render_voxels_accel(tree.accel, cam, opt, rgba=out1, stream=side.cuda_stream if k == 16 else 0)
-        levels = mnv.accel_info(tree.accel)["brick_levels"]
-        assert levels == (0 if k < 15 else 2), (k, levels)
-        torch.cuda.synchronize()
-        assert np.array_equal(cases.bits(out1.cpu().numpy()), cases.bits(ref["rgba"])), k
+    # tracker frames read the inline words and records too (SH16 rows go through the cooperative colour pass, which has no such variant):
+    # pixels, tracker rows (voxel numbers!) against the oracle
+    counts = np.full((tree.host_view().capacity, 8), 8, np.int16)
+    opt_t = mnv.RenderOptions.cli_defaults()
+    opt_t.max_depth, opt_t.max_sample_count = depth - 1, 9
+    want_t = orc.render(orc.tree_from_view(tree.host_view(), sample_counts=counts), cam.c, opt_t, want_trackers=True)
+    split = torch.full((cam.height, cam.width, 3), -1.0, dtype=torch.float32, device="cuda")
+    sample = torch.full((cam.height, cam.width, 3), -1.0, dtype=torch.float32, device="cuda")
+    out_t = torch.full((cam.height, cam.width, 4), float("nan"), dtype=torch.float32, device="cuda")
+    mnv.render_voxels_accel_track(tree.accel, cam, opt_t, rgba=out_t, split_track=split, sample_track=sample, sample_counts=torch.from_numpy(counts).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(cases.bits(out_t.cpu().numpy()), cases.bits(want_t["rgba"]))
+    assert np.array_equal(split.cpu().numpy(), want_t["split"]) and np.array_equal(sample.cpu().numpy(), want_t["sample"])
 
 
 @pytest.mark.parametrize("step", [1e-4, 1.5e-3, 3e-3, 5e-2])
