@@ -484,6 +484,92 @@ def extras_cfg5(mnv, cases, torch, dev, tree, frames_each=6):
     return res
 
 
+def extras_live_call(mnv, cases, orc, torch, dev, tree, cams, opt):
+    """The reference's LITERAL per-frame call (src/renderer/cuda_renderer.cpp:68-142 without the GL shell): the image attachment cleared to the
+    background and the depth attachment to 1e9 (:70-77), split_tracker.fill_(-1), sample_tracker.fill_(-1) (:97-98), then
+    render_voxels(tree, cam, opt, image, depth, stream, to_split, to_sample, visited, track_visit = false, offscreen = false) (:141-142) --
+    every frame passes the two tracker tensors, the depth image and the image, so what runs is the tracker instantiation of the march, not
+    the plain one the `per_frame` / `ref_layout` objects time.  Three servers of the same call: mnv_render_voxels_ex on the reference's arrays
+    (stateless), the same with mnv_set_tree_cache(1), and mnv_render_voxels_accel_visit_ex on the packed accel; each on one stream with a wait
+    per frame (the viewer's glFinish, main.cpp:614), on one stream back to back, and with three frames in flight (three sets of buffers)."""
+    import ctypes as C
+    v = tree.host_view()
+    cap = v.capacity
+    w, h = W, H
+    counts = torch.full((cap, 8), 8, dtype=torch.int16, device=dev)   # (the reference leaves this array uninitialised, n3tree.cpp:235-241)
+    dv = tree.device_view()
+    tv = mnv.TreeView()
+    C.memmove(C.byref(tv), C.byref(dv), C.sizeof(tv))
+    tv.sample_counts = counts.data_ptr()
+    o = mnv.RenderOptions()
+    C.memmove(C.byref(o), C.byref(opt), C.sizeof(o))
+    bg8 = int(o.background_brightness * 255)
+    clear_word = (255 << 24 | bg8 << 16 | bg8 << 8 | bg8) - (1 << 32)   # RGBA8 bytes (bg, bg, bg, 255) as one little-endian int32
+    K = 3
+    sets = [dict(image=torch.empty((h, w, 4), dtype=torch.uint8, device=dev), depth=torch.empty((h, w), dtype=torch.float32, device=dev),
+                 split=torch.empty((h * w, 3), dtype=torch.float32, device=dev), sample=torch.empty((h * w, 3), dtype=torch.float32, device=dev)) for _ in range(K)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(K)]
+
+    def frame(server, i, j, st):
+        b = sets[j]
+        with torch.cuda.stream(st):
+            b["image"].view(torch.int32).fill_(clear_word)   # glClearNamedFramebufferfv(..., GL_COLOR, 0, {bg, bg, bg, 1})
+            b["depth"].fill_(1e9)
+            b["split"].fill_(-1)
+            b["sample"].fill_(-1)
+        if server == "accel":
+            mnv.render_voxels_accel_visit(tree.accel, cams[i], o, None, None, rgba8=b["image"], split_track=b["split"], sample_track=b["sample"], sample_counts=counts,
+                                          stream=st.cuda_stream, tmax_px=b["depth"], rgba8_init=b["image"])
+        else:
+            mnv.render_voxels(tv, cams[i], o, rgba8=b["image"], split_track=b["split"], sample_track=b["sample"], stream=st.cuda_stream, tmax_px=b["depth"],
+                              rgba8_init=b["image"])
+
+    def timed(server, mode, laps=2):
+        def lap():
+            for i in range(N_POSES):
+                if mode == "wait_each":
+                    frame(server, i, 0, streams[0])
+                    streams[0].synchronize()
+                elif mode == "one_stream":
+                    frame(server, i, 0, streams[0])
+                else:
+                    frame(server, i, i % K, streams[i % K])
+        lap()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(laps):
+            lap()
+        torch.cuda.synchronize(dev)
+        ms = (time.perf_counter() - t0) / laps / N_POSES * 1e3
+        return {"ms_per_frame": round(ms, 4), "Mrays_per_s": round(w * h / ms / 1e3, 1)}
+
+    res = {}
+    for server in ("ref_arrays", "ref_arrays_tree_cache", "accel"):
+        mnv.set_tree_cache(server == "ref_arrays_tree_cache")
+        res[server] = {mode: timed(server, mode) for mode in ("wait_each", "one_stream", "three_in_flight")}
+    # one frame of every server against the oracle's tracker frame with the same two attachments: RGBA8 and both tracker arrays
+    pose = 5
+    counts_host = np.full((cap, 8), 8, np.int16)   # (kept alive: the oracle's tree view holds a pointer into it)
+    ot = orc.tree_from_view(v, sample_counts=counts_host)
+    want = orc.render(ot, cams[pose].c, o, want_rgba8=True, want_trackers=True, tmax_px=np.full((h, w), 1e9, np.float32),
+                      rgba8_init=np.tile(np.array([bg8, bg8, bg8, 255], np.uint8), (h, w, 1)))
+    bad = {}
+    for server in ("ref_arrays", "ref_arrays_tree_cache", "accel"):
+        mnv.set_tree_cache(server == "ref_arrays_tree_cache")
+        frame(server, pose, 0, streams[0])
+        torch.cuda.synchronize(dev)
+        b = sets[0]
+        bad[server] = {"rgba8_bytes_differing": int((b["image"].cpu().numpy() != want["rgba8"]).sum()),
+                       "tracker_values_differing": int((b["split"].cpu().numpy().reshape(h, w, 3) != want["split"]).sum() + (b["sample"].cpu().numpy().reshape(h, w, 3) != want["sample"]).sum())}
+    mnv.set_tree_cache(False)
+    res["checked_against_oracle"] = bad
+    res["what"] = ("the reference's per-frame call, literally (cuda_renderer.cpp:68-77,97-98,141-142): clear image + depth, fill_(-1) both tracker tensors, render_voxels(..., "
+                   "to_split, to_sample, visited, track_visit = false, offscreen = false) on the cfg2 tree at 1920x1080; ref_arrays = mnv_render_voxels_ex on the reference's own "
+                   "arrays, ref_arrays_tree_cache = the same after mnv_set_tree_cache(1), accel = mnv_render_voxels_accel_visit_ex; wait_each = one stream with a wait per frame "
+                   "(the viewer's glFinish), one_stream = back to back, three_in_flight = three sets of buffers on three streams; wall time incl. the four fills")
+    return res
+
+
 def predicted_step(world, root_period, n_frames, workload):
     """ms per step that the one-GPU emulation of one rank of `world` measured for this partition (the latest profiles/rNN_root_emulation.jsonl, tools/root_emulation.py: rank 0's
     march beside a device copy of the incoming tiles and the un-permute; 64 frames of cfg2 per step), so that the line of a real N-GPU run
@@ -934,6 +1020,10 @@ def main():
     cfg345 = {}
     if rank == 0 and not multi and args.kernel == "accel" and not args.per_frame and args.workload == "cfg2" and not args.no_extras and not args.no_cpu_baseline:
         import mnv_oracle as orc
+        try:
+            cfg345["live_call"] = extras_live_call(mnv, cases, orc, torch, dev, tree, cams, opt)
+        except Exception as e:  # a secondary number must not cost the headline line
+            cfg345["live_call"] = {"error": f"{type(e).__name__}: {e}"}
         try:
             cfg345["cfg5"] = extras_cfg5(mnv, cases, torch, dev, tree)
         except Exception as e:  # a secondary number must not cost the headline line

@@ -235,7 +235,7 @@ def test_patched_lookup_words_equal_a_fresh_derivation_word_for_word(mnv, torch_
     env = hooks.hooks_env(MNV_REFRESH_DEBUG="2")
     r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
-    assert "[mnv verify]" not in r.stderr
+    assert "[mnv verify]" not in r.stderr and "[mnv refresh]" in r.stderr   # (the knob was honoured: this was the hooks build)
     assert r.stdout.count("verified rounds ok") == len(EDIT_CASES)
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-s", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_refine_gpu.py") + "::test_accel_follows_a_prune_in_place",
@@ -243,7 +243,7 @@ def test_patched_lookup_words_equal_a_fresh_derivation_word_for_word(mnv, torch_
                         os.path.join(ROOT, "tests", "test_renderer_refine_gpu.py") + "::test_prune_runs_inside_the_loop"],
                        env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
-    assert "[mnv verify]" not in r.stderr and "[mnv refresh]" in r.stderr   # the knob was honoured: this was the hooks build
+    assert "[mnv verify]" not in r.stderr
 
 
 if __name__ == "__main__":   # the child process of the word-for-word test
