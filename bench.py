@@ -304,6 +304,10 @@ def extras_cfg3_cfg4(mnv, cases, orc, torch, dev, opt, steps):
     for v in out.values():
         v["workload"] = workload
     out["cfg3"]["setup_s"] = round(setup_s, 2)
+    try:
+        out["cfg5_cfg3"] = extras_cfg5_cfg3(mnv, cases, torch, dev, tree)
+    except Exception as e:  # a secondary number must not cost the line
+        out["cfg5_cfg3"] = {"error": f"{type(e).__name__}: {e}"}
     del tree
     torch.cuda.empty_cache()
     return out
@@ -480,6 +484,102 @@ def extras_cfg5(mnv, cases, torch, dev, tree, frames_each=6):
            "what": "cfg2 tree at 1920x1080: guided = mnv_render_guided_fused (one kernel per frame, 8 sub-modules, 64x2 network, quota 32), HIP events over 24 frames; "
                    "both = VolumeRenderer::render with use_splitting + use_guided_sampling (4096 splits x 8 corners x 8 samples per frame), wall time per frame"}
     del r, tree2
+    torch.cuda.empty_cache()
+    return res
+
+
+def extras_cfg5_cfg3(mnv, cases, torch, dev, tree):
+    """BASELINE.json configs[4] as SURVEY.md 8(d) defines it: cfg3's tree (the 7.2 M-chunk merged-octree stand-in) + the tiny MLP,
+    max_guided_samples 128, samples_per_corner 8, 1920x1080.  (The `cfg5` object is the same frame kinds on the cfg2 shell at quota 32.)
+    guided = mnv_render_guided_fused, one kernel per frame, eight sub-modules on the 4 x 2 grid over world y, z; checked bit for bit against the
+    four kernels it replaces; the producers' share of time spent waiting for ring space from the kernel's own clocks; both = both switches
+    through VolumeRenderer::render.  `tree` is moved to the device again with room to grow (it is not used afterwards)."""
+    import mlp_cases
+    w, h = W, H
+    v = tree.host_view()
+    opt = mnv.RenderOptions.cli_defaults()
+    opt.basis_minmax[1] = 8
+    opt.max_guided_samples = 128
+    desc = mnv.mlp_desc(n_clusters=8, pos_octaves=4, hidden_width=64, hidden_layers=2, out_dim=v.data_dim + 1)
+    params = mlp_cases.make_params(mnv, desc, seed=4)
+    mlp = mnv.Mlp(desc, params)
+    g = cases.cfg3_cluster_grid(mnv)
+    cams = [cases.cfg3_camera(mnv, p, w, h, fx=1400.0) for p in range(0, N_POSES, 2)]
+    out = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
+    counter = torch.zeros(1, dtype=torch.int64, device=dev)
+    for c in cams[:2]:
+        mnv.render_guided_fused(tree.accel, c, opt, mlp, g, rgba=out)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 2
+    e0.record()
+    for _ in range(reps):
+        for c in cams:
+            mnv.render_guided_fused(tree.accel, c, opt, mlp, g, rgba=out)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    guided_ms = e0.elapsed_time(e1) / (reps * len(cams))
+    # one frame through the four kernels the fused one replaces, bit for bit; the same frame with the kernel's clocks on
+    cam = cams[2]
+    n_px, dd = w * h, v.data_dim
+    num = torch.zeros(n_px, dtype=torch.int16, device=dev)
+    guided = torch.zeros((n_px, 128, 4), dtype=torch.float32, device=dev)
+    clusters = torch.zeros((n_px, 128), dtype=torch.int16, device=dev)
+    offsets = torch.empty(n_px, dtype=torch.int64, device=dev)
+    mnv.get_samples_from_voxels_accel(tree.accel, cam, opt, num, guided, clusters, g)
+    total_guess = int(num.to(torch.int64).sum().item())
+    z = torch.empty(total_guess + 1, dtype=torch.float32, device=dev)
+    rows = torch.empty((total_guess + 1, 3), dtype=torch.float32, device=dev)
+    rcl = torch.empty(total_guess + 1, dtype=torch.int16, device=dev)
+    values = torch.empty((total_guess + 1, dd + 1), dtype=torch.float32, device=dev)
+    ref = torch.empty((h, w, 4), dtype=torch.float32, device=dev)
+    total = mnv.compact_guided_samples(num, guided, clusters, offsets, z, rows, rcl)
+    mlp.query(rcl, rows, values, n=total)
+    mnv.render_nerf_results(tree.device_view(), cam, opt, values, z, offsets, rgba=ref)
+    at_quota = int((num >= 128).sum().item())
+    out.fill_(float("nan"))
+    mnv.render_guided_fused(tree.accel, cam, opt, mlp, g, rgba=out, sample_counter=counter)
+    torch.cuda.synchronize(dev)
+    n_bad = int((out.view(torch.int32) != ref.view(torch.int32)).any(dim=-1).sum().item())
+    evals = int(counter.item())
+    del num, guided, clusters, offsets, z, rows, rcl, values, ref
+    diag = torch.zeros(32, dtype=torch.int64, device=dev)
+    mnv.set_fused_diag(diag)
+    mnv.render_guided_fused(tree.accel, cam, opt, mlp, g, rgba=out)
+    torch.cuda.synchronize(dev)
+    mnv.set_fused_diag(None)
+    d = [int(x) for x in diag.tolist()]
+    faults = mnv.accel_fused_faults(tree.accel)
+    ring_wait = d[9] / max(1, d[8])        # F2Diag: kProdRingWait / kProdTotal (csrc/mnv_guided_fused2.h)
+    cons_busy = d[6] / max(1, d[7])        # kConsBusy / kConsTotal
+    # both switches through the renderer at the survey's parameters
+    r = mnv.Renderer()
+    r.resize(w, h)
+    cap0 = tree.capacity
+    r.set(tree, cap0 + 1_000_000)
+    r.set_model(desc, params, g)
+    r.set_seed(7)
+    o = r.options
+    o.use_splitting, o.use_guided_sampling, o.max_depth, o.split_batch_size, o.samples_per_corner, o.max_guided_samples = True, True, 13, 4096, 8, 128
+    ts, st = [], None
+    for f in range(10):
+        c = cases.cfg3_camera(mnv, f % N_POSES, w, h, fx=1400.0)
+        m = c.c2w
+        r.set_camera(tuple(m[9:12]), tuple(m[6:9]), up=(1.0, 0.0, 0.0), fx=1400.0)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        st = r.render()
+        torch.cuda.synchronize(dev)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    res = {"guided_ms_per_frame": round(guided_ms, 4), "guided_Mrays_per_s": round(w * h / guided_ms / 1e3, 1), "network_evals_per_frame": evals,
+           "rays_at_the_quota_of_128": at_quota, "pixels_not_bit_identical_vs_four_step": n_bad, "samples_equal_four_step": bool(evals == total), "watchdog_faults": int(faults),
+           "producer_ring_wait_share": round(ring_wait, 4), "consumer_busy_share": round(cons_busy, 4),
+           "both_ms_per_frame": round(float(np.median(ts[2:])), 4), "both_network_evals_per_frame": int(st["guided_samples"]), "both_added_per_frame": int(st["added"]),
+           "both_fused": int(st["fused"]),
+           "what": "SURVEY 8(d) cfg5: the cfg3 tree (7.2 M chunks, depth 11) at 1920x1080, eight 64x2 sub-modules on the 4 x 2 grid over world y, z, max_guided_samples 128, "
+                   "samples_per_corner 8, split_batch_size 4096; guided = mnv_render_guided_fused (HIP events over 16 frames, 8 oblique poses), both = VolumeRenderer::render with "
+                   "use_splitting + use_guided_sampling, wall time per frame; ring wait = share of the producers' time spent waiting for ring space (the kernel's own clocks)"}
+    del r
     torch.cuda.empty_cache()
     return res
 

@@ -105,6 +105,15 @@ def cfg3_camera(mnv, pose=0, width=1920, height=1080, fx=1400.0):
     return mnv.Camera(width, height, fx).set_pose(center, back.astype(_np.float32), (1.0, 0.0, 0.0))
 
 
+def cfg3_cluster_grid(mnv):
+    """The 4 x 2 sub-module grid over world y, z of the merged-octree stand-in (rt_core.cuh:541-549): one network per terrain brick."""
+    g = mnv.ClusterGrid()
+    g.grid_dim[0], g.grid_dim[1] = 4, 2
+    for i, (lo, rng) in enumerate([(-1.0, 2.0), (-4.0, 8.0), (-4.0, 8.0)]):
+        g.min_position[i], g.range[i] = lo, rng
+    return g
+
+
 # BASELINE.json configs[1]: depth-10 SH9 shell, 1920x1080, fx 1600, orbit radius 2.6, elevation 20
 CFG2_TREE = dict(kind="shell", depth=10, basis_dim=9, radius=0.35, half_thickness=1.5 / 1024, sigma_lo=50.0, sigma_hi=400.0, seed=0)
 

@@ -244,6 +244,92 @@ def test_cfg5_refinement_and_guided_sampling_together_at_scale(mnv, torch_gpu):
     assert torch.equal(a.view(torch.int32), b.view(torch.int32))
 
 
+def test_cfg5_on_the_merged_octree_at_the_survey_parameters(mnv, orc, torch_gpu):
+    """BASELINE.json configs[4] as SURVEY.md 8(d) defines it -- cfg3's tree (cases.CFG3_FULL, 7.2 M chunks, depth 11) + the tiny MLP,
+    max_guided_samples 128, samples_per_corner 8 -- at 1920x1080: the fused guided frame equals the four kernels it replaces bit for bit (long
+    oblique rays, a quota of 128: where the producers' rings fill), no spin-wait is abandoned, a sub-rectangle equals the crop of the frame, the
+    same pose at a quarter of the size equals the oracle's CPU chain (rt_core.cuh:418-576 -> compaction -> network -> rt_core.cuh:334-416), and
+    the renderer runs both switches on it: one fused kernel per frame, a valid tree, the packed accel follows."""
+    torch = torch_gpu
+    from test_guided_fused_gpu import four_step_frame, oracle_frames
+
+    tree = cases.make_tree(mnv, cases.CFG3_FULL)
+    v = tree.host_view()
+    assert 5_000_000 < v.capacity < 10_000_000
+    tree.move_to_device()
+    opt = mnv.RenderOptions.cli_defaults()
+    opt.basis_minmax[1] = 8
+    opt.max_guided_samples = 128
+    desc = mnv.mlp_desc(n_clusters=8, pos_octaves=4, hidden_width=64, hidden_layers=2, out_dim=v.data_dim + 1)
+    params = mlp_cases.make_params(mnv, desc, seed=4)
+    mlp = mnv.Mlp(desc, params)
+    grid = cases.cfg3_cluster_grid(mnv)
+    W, H = 1920, 1080
+    cam = cases.cfg3_camera(mnv, 5, W, H, fx=1400.0)
+    ref, ref8, total = four_step_frame(mnv, torch, tree, cam, opt, mlp, grid, 128, 4)
+    assert total > 5_000_000
+    for version in (2, 1):   # producer / consumer wavefronts (the default), then the one-role kernel
+        mnv.accel_set_fused_kernel(tree.accel, version)
+        out = torch.full((H, W, 4), float("nan"), dtype=torch.float32, device="cuda")
+        counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+        mnv.render_guided_fused(tree.accel, cam, opt, mlp, grid, rgba=out, sample_counter=counter)
+        torch.cuda.synchronize()
+        assert int(counter.item()) == total, version
+        assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(ref)), version
+    mnv.accel_set_fused_kernel(tree.accel, -1)
+    assert mnv.accel_fused_faults(tree.accel) == 0
+    # a sub-rectangle that is not aligned to the 8x8 ray tiles
+    x0, y0, w, h = 611, 203, 333, 251
+    sub = torch.full((h, w, 4), float("nan"), dtype=torch.float32, device="cuda")
+    mnv.render_guided_fused(tree.accel, cam, opt, mlp, grid, tile=(x0, y0, w, h), rgba=sub)
+    torch.cuda.synchronize()
+    assert np.array_equal(cases.bits(sub.cpu().numpy()), cases.bits(np.ascontiguousarray(ref[y0:y0 + h, x0:x0 + w])))
+    # the oracle's CPU chain on the same pose at 480x270 (1.4 M-sample class): march, sample order, delta z, clusters, composite bit for bit
+    small = cases.cfg3_camera(mnv, 5, 480, 270, fx=350.0)
+    all_cpu, hybrid, n_small = oracle_frames(mnv, orc, torch, tree, small, opt, mlp, desc, params, grid, 128, 4)
+    out = torch.full((270, 480, 4), float("nan"), dtype=torch.float32, device="cuda")
+    counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+    mnv.render_guided_fused(tree.accel, small, opt, mlp, grid, rgba=out, sample_counter=counter)
+    torch.cuda.synchronize()
+    assert int(counter.item()) == n_small and n_small > 300_000
+    assert np.array_equal(cases.bits(out.cpu().numpy()), cases.bits(hybrid))
+    assert float(np.abs(out.cpu().numpy() - all_cpu).max()) < 2e-2
+    assert mnv.accel_fused_faults(tree.accel) == 0
+    del mlp
+    # both switches through the host renderer at the survey's parameters
+    cap0 = v.capacity
+    r = mnv.Renderer()
+    r.resize(W, H)
+    r.set(tree, cap0 + 200_000)
+    r.set_model(desc, params, grid)
+    r.set_seed(7)
+    o = r.options
+    o.use_splitting, o.use_guided_sampling, o.max_depth, o.split_batch_size, o.samples_per_corner, o.max_guided_samples = True, True, 13, 4096, 8, 128
+    added = 0
+    for f in range(3):
+        c = cases.cfg3_camera(mnv, 3 + f, W, H, fx=1400.0)
+        m = c.c2w
+        r.set_camera(tuple(m[9:12]), tuple(m[6:9]), up=(1.0, 0.0, 0.0), fx=1400.0)
+        st = r.render()
+        added += st["added"]
+        assert st["fused"] == 1 and st["used_accel"] == 1 and st["guided_samples"] > 5_000_000 and st["pruned"] == 0
+        assert 0 < st["added"] <= 4096
+    frame = r.download()
+    assert np.isfinite(frame).all()
+    r.sync_tree()
+    data, child, parent = tree.host_arrays()
+    assert child.shape[0] == cap0 + added
+    check_tree_links(child, parent, cap0 + added)
+    ropt = mnv.RenderOptions()
+    C.memmove(C.byref(ropt), C.byref(r.options), C.sizeof(ropt))
+    a = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    mnv.render_voxels(tree.device_view(), cam, ropt, rgba=a)
+    mnv.render_voxels_accel(tree.accel, cam, ropt, rgba=b)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+
+
 def _cfg5_rank(rank, world, lib, idq, resq):
     """One rank of test_cfg5_on_several_ranks_at_scale (the ranks share cuda:0; the transport is tests/shim/fake_rccl.cpp)."""
     import hashlib
