@@ -94,17 +94,42 @@ def committed_traffic(workload, frames_per_launch):
     return None, None
 
 
-def roofline_fractions(achieved_gbs, traffic, avg_ms):
-    """Two fractions, each with ONE meaning in every object of the line:
-    `frac` = `achieved` / `peak` with `achieved` = the ALGORITHMIC bytes of SURVEY 8(d) / kernel time -- what the reference's algorithm
-    would have to move for these frames (every ray's loads counted, its root-restart child words included, no sharing between
-    neighbouring rays).  This kernel does not execute that algorithm's loads (lookup grids, inline cell words, brick records), so the
-    figure is a yardstick, not a bound: it can exceed 1, and `algorithmic_over_peak` repeats it under a name that says so.
-    `frac_real_hbm` = `traffic` (HBM bytes per launch from the committed PMC passes for these kernel sources) / kernel time / peak --
-    what the memory system delivered; null when no committed pass belongs to this source and launch shape."""
+def roofline_fractions(achieved_gbs, traffic, avg_ms, footprint=None):
+    """The fractions of a roofline object, each with ONE meaning in every object of the line (DESIGN.md section 7 says which is the bound):
+    `algorithmic_over_peak` = `achieved` / `peak` with `achieved` = the ALGORITHMIC bytes of SURVEY 8(d) / kernel time -- what the reference's
+    algorithm would have to move for these frames (every ray's loads counted, its root-restart child words included, no sharing between
+    neighbouring rays).  This kernel does not execute those loads (lookup grids, inline cell words, brick records): a yardstick against the
+    reference's algorithm, NOT a bound -- it can exceed 1.  `frac` repeats it where it is below 1 (the headline) and is null where it is not:
+    no field called a fraction of the roofline exceeds 1.
+    `frac_footprint` = `footprint_bytes` / kernel time / peak: the unique 128-byte lines the launch's loads touch (tools/footprint.py: one pass
+    of the diagnostics instantiation with a line bitmap) + its output.  Every such line has to arrive from memory at least once when the working
+    set is far beyond L2 + Infinity Cache, so this IS a floor under the HBM bytes and a bound: <= 1.
+    `frac_l2_fabric` = `traffic` / kernel time / peak with `traffic` = 2 x FETCH_SIZE + WRITE_SIZE of the committed PMC passes for these kernel
+    sources: requests the L2 sent to the fabric.  On gfx950 those include Infinity-Cache (MALL) hits, so this is an UPPER estimate of the DRAM
+    bytes, bracketed from below by the footprint; null when no committed pass belongs to this source and launch shape."""
     over = achieved_gbs / HBM_PEAK_GBS
-    real = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None
-    return {"frac": round(over, 5), "algorithmic_over_peak": round(over, 5), "frac_real_hbm": round(real, 5) if real is not None else None}
+    fabric = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None
+    out = {"frac": round(over, 5) if over <= 1.0 else None, "algorithmic_over_peak": round(over, 5),
+           "frac_l2_fabric": round(fabric, 5) if fabric is not None else None,
+           "traffic_is": "L2-to-fabric bytes (2 x FETCH_SIZE + WRITE_SIZE): includes Infinity-Cache hits, an upper estimate of DRAM bytes"}
+    if footprint:
+        fb = footprint["footprint_bytes"]
+        out.update({"footprint_bytes": int(fb), "frac_footprint": round(fb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "footprint_lines_by_array": {k[:-6]: v for k, v in footprint.items() if k.endswith("_lines")}})
+    else:
+        out.update({"footprint_bytes": None, "frac_footprint": None})
+    return out
+
+
+def measured_footprints(workloads):
+    """tools/footprint.py in a child process on the test-hook build (the shipped library has no diagnostics hook): {workload: dict} or {}."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import footprint as fp_tool
+        return fp_tool.measure(workloads)
+    except Exception as e:  # a diagnostic pass must not cost the line
+        print(f"bench.py: footprint pass skipped: {type(e).__name__}: {e}", file=sys.stderr)
+        return {}
 
 
 def load_counters(workload="cfg2"):
@@ -246,7 +271,7 @@ def self_launch(n, backend, timeout_s):
 MFMA_PEAK_TFLOPS = 2500.0           # MI355X_MICROARCH.md: dense f16 / bf16 matrix peak (no sparsity)
 
 
-def extras_cfg3_cfg4(mnv, cases, orc, torch, dev, opt, steps):
+def extras_cfg3_cfg4(mnv, cases, orc, torch, dev, opt, steps, footprints=None):
     """Secondary numbers of the default run: BASELINE.json configs[2] (merged-octree stand-in, 1920x1080) and configs[3] on ONE GPU
     (the same tree at 3840x2160) -- the 7.2 M-chunk terrain of SURVEY.md 8(d), 16 oblique poses per launch.  Each with its own roofline
     (algorithmic bytes from the oracle's counters of two poses rendered in this run) and a bit-exact check of those frames."""
@@ -292,7 +317,7 @@ def extras_cfg3_cfg4(mnv, cases, orc, torch, dev, opt, steps):
         achieved = per_launch / (avg_ms * 1e-3) / 1e9
         traffic, traffic_source = committed_traffic("cfg3" if name == "cfg3" else "cfg4", N_POSES)
         rl = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-        rl.update(roofline_fractions(achieved, traffic, avg_ms))
+        rl.update(roofline_fractions(achieved, traffic, avg_ms, (footprints or {}).get("cfg3" if name == "cfg3" else "cfg4")))
         rl.update({"traffic": traffic, "traffic_source": traffic_source, "kernel": "march_accel_kernel<9,256,0,true>", "avg_launch_ms": round(avg_ms, 5), "launches": launches,
                    "algorithmic_bytes_per_launch": int(per_launch), "counter_poses": N_POSES if committed else list(chk), "counters_rechecked_poses": list(chk) if committed else []})
         out[name] = {"value": round(N_POSES * w * h * steps / el / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(el / steps * 1e3, 4), "steps": steps,
@@ -316,7 +341,7 @@ def extras_cfg3_cfg4(mnv, cases, orc, torch, dev, opt, steps):
 FOG_COUNTERS_JSON = os.path.join(ROOT, "tests", "golden", "fog_counters.json")
 
 
-def extras_fog(mnv, cases, orc, torch, dev, opt, steps):
+def extras_fog(mnv, cases, orc, torch, dev, opt, steps, footprints=None):
     """A second distribution for the headline's kernel (long dense runs): cases.FOG_TREE -- the cfg2 generator with a thick shell of thin
     density, 33 dense samples in 44 steps per ray against cfg2's 4.5 in 21 -- under the cfg2 cameras at 1920x1080, 16 poses per launch.
     Its own roofline (numerator: the committed 16-pose counters, one pose re-derived here) and its own bit-exact frame."""
@@ -357,7 +382,7 @@ def extras_fog(mnv, cases, orc, torch, dev, opt, steps):
     achieved = per_launch / (avg_ms * 1e-3) / 1e9
     traffic, traffic_source = committed_traffic("fog", N_POSES)
     rl = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-    rl.update(roofline_fractions(achieved, traffic, avg_ms))
+    rl.update(roofline_fractions(achieved, traffic, avg_ms, (footprints or {}).get("fog")))
     rl.update({"traffic": traffic, "traffic_source": traffic_source, "kernel": "march_accel_kernel<9,256,0,true>", "avg_launch_ms": round(avg_ms, 5), "launches": launches,
                "algorithmic_bytes_per_launch": int(per_launch), "counter_poses": N_POSES if have_all else [pose], "counters_rechecked_poses": [pose] if committed else []})
     value = N_POSES * w * h * steps / el / 1e6
@@ -544,10 +569,10 @@ def extras_cfg5_cfg3(mnv, cases, torch, dev, tree):
     evals = int(counter.item())
     del num, guided, clusters, offsets, z, rows, rcl, values, ref
     diag = torch.zeros(32, dtype=torch.int64, device=dev)
-    mnv.set_fused_diag(diag)
+    mnv.accel_set_fused_diag(tree.accel, diag)
     mnv.render_guided_fused(tree.accel, cam, opt, mlp, g, rgba=out)
     torch.cuda.synchronize(dev)
-    mnv.set_fused_diag(None)
+    mnv.accel_set_fused_diag(tree.accel, None)
     d = [int(x) for x in diag.tolist()]
     faults = mnv.accel_fused_faults(tree.accel)
     ring_wait = d[9] / max(1, d[8])        # F2Diag: kProdRingWait / kProdTotal (csrc/mnv_guided_fused2.h)
@@ -712,7 +737,7 @@ def main():
     ap.add_argument("--frame-streams", type=int, default=3,
                     help="--per-frame: launches rotate over this many HIP streams (frames in flight; 1 = the frames of a step run back to back on one stream)")
     ap.add_argument("--fast-colour", action="store_true",
-                    help="mnv_set_colour_math(1): hardware exp2 / rcp in the colour sigmoid (alpha and control flow stay exact; colours move ~1e-7)")
+                    help="mnv_accel_set_colour_math(accel, 1): hardware exp2 / rcp in the colour sigmoid (alpha and control flow stay exact; colours move ~1e-7)")
     ap.add_argument("--reserve-cus", type=int, default=-1,
                     help="N > 1: compute units the march leaves free for the RCCL kernels of the tile gather (the march runs on a CU-masked "
                          "stream).  Default 32 when N > 1 (one unit per shader engine and XCD; measured cost of the march: 10 %%), 0 when N = 1. "
@@ -770,7 +795,6 @@ def main():
     import cases
 
     dev = torch.device("cuda", local_rank)
-    mnv.set_colour_math(args.fast_colour)
     t_setup = time.time()
     if args.workload == "cfg2":
         tree = cases.make_tree(mnv, cases.CFG2_TREE)
@@ -785,6 +809,8 @@ def main():
         cams = [cases.cfg3_camera(mnv, pose % N_POSES, W, H, fx=1400.0 * W / 1920) for pose in range(N_FRAMES)]
         workload = f"{args.workload}: depth-11 SH9 anisotropic 4x2-brick terrain N3Tree ({tree.capacity:,} chunks), {W}x{H}, 16 oblique poses per step"
     tree.move_to_device()
+    if args.fast_colour:
+        mnv.accel_set_colour_math(tree.accel, 1)
     if args.workload != "cfg2":
         info = mnv.accel_info(tree.accel)
         workload += f", packed accel {info['device_bytes'] / 1e9:.2f} GB with a level-{info['grid2_level']} lookup grid"
@@ -951,14 +977,14 @@ def main():
                      "launches": pf_steps * N_FRAMES, "frames_in_flight": k,
                      "what": "one mnv_render_voxels_accel call per 1920x1080 frame (the reference's call pattern, cuda_renderer.cpp:141-142), launches rotating over HIP streams"}
 
-    # second secondary number: the batched launch with mnv_set_colour_math(1) -- hardware exp2 / rcp in the colour sigmoid only; opacity,
+    # second secondary number: the batched launch with mnv_accel_set_colour_math(accel, 1) -- hardware exp2 / rcp in the colour sigmoid only; opacity,
     # transmittance, step sequence and every branch stay on the exact path.  Within the north star's 1e-4 (measured here against the exact
     # frames of the last timed step, which the parity leg below compares bit for bit with the oracle); the headline stays the exact mode.
     fast_colour = None
     if not multi and args.kernel == "accel" and not args.per_frame and not args.fast_colour and args.frame_streams >= 1:
         exact = frames[(counter[0] - 1) % RING]
         fc_out = pf_out
-        mnv.set_colour_math(True)
+        mnv.accel_set_colour_math(tree.accel, 1)
         mnv.render_voxels_accel_batch(tree.accel, cams, opt, rgba=fc_out, stream=stream)
         torch.cuda.synchronize(dev)
         fc_steps = max(1, min(args.steps, 5))
@@ -967,11 +993,11 @@ def main():
             mnv.render_voxels_accel_batch(tree.accel, cams, opt, rgba=fc_out, stream=stream)
         torch.cuda.synchronize(dev)
         fc_el = time.perf_counter() - t1
-        mnv.set_colour_math(False)
+        mnv.accel_set_colour_math(tree.accel, 0)
         d = (fc_out - exact).abs()
         fast_colour = {"value": round(rays_per_step * fc_steps / fc_el / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(fc_el / fc_steps * 1e3, 4),
                        "max_abs_drgba_vs_exact": float(d.max().item()), "alpha_not_bit_identical": int((fc_out[..., 3].view(torch.int32) != exact[..., 3].view(torch.int32)).sum().item()),
-                       "what": "mnv_set_colour_math(1): v_exp_f32 / v_rcp_f32 in the colour sigmoid, everything that feeds a branch exact"}
+                       "what": "mnv_accel_set_colour_math(accel, 1): v_exp_f32 / v_rcp_f32 in the colour sigmoid, everything that feeds a branch exact"}
         del d
 
     # third secondary number: mnv_render_voxels itself -- the literal drop-in on the reference's own arrays (no accel, nothing kept between
@@ -1090,6 +1116,11 @@ def main():
                 n_bad += int((gpu != r["rgba8"]).any(axis=-1).sum())
         parity = {"max_abs_drgba_vs_oracle": max_diff, "pixels_not_bit_identical": n_bad, "frames_checked": n_chk,
                   "frames": chk, "what": "frames assembled on rank 0 after the gather"}
+    footprints = {}
+    extras_on = rank == 0 and not multi and args.kernel == "accel" and not args.per_frame and args.workload == "cfg2" and not args.no_extras and not args.no_cpu_baseline
+    if extras_on and N_FRAMES == 64:
+        # one pass of the diagnostics instantiation per workload in a child process on the test-hook build: the unique 128-byte lines a launch touches
+        footprints = measured_footprints(["cfg2", "cfg3", "cfg4", "fog"])
     roofline = None
     if counters is not None and launches > 0:
         poses = counters["poses"]
@@ -1104,7 +1135,7 @@ def main():
             # launch shape; any other source or shape reports null
             traffic, traffic_source = committed_traffic(args.workload, frames_per_launch)
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s"}
-        roofline.update(roofline_fractions(achieved, traffic, avg_ms))
+        roofline.update(roofline_fractions(achieved, traffic, avg_ms, footprints.get("cfg2") if frames_per_launch == 64 else None))
         roofline.update({"traffic": traffic, "traffic_source": traffic_source,
                     "counters_rechecked_poses": counters_checked,
                     "kernel": "march_accel_kernel<9,256,0,true>" if args.kernel == "accel" else "march_ref_layout_kernel<9>",
@@ -1132,11 +1163,11 @@ def main():
         tree = None
         torch.cuda.empty_cache()
         try:
-            cfg345.update(extras_cfg3_cfg4(mnv, cases, orc, torch, dev, opt, max(1, min(args.steps, 5))))
+            cfg345.update(extras_cfg3_cfg4(mnv, cases, orc, torch, dev, opt, max(1, min(args.steps, 5)), footprints))
         except Exception as e:
             cfg345["cfg3"] = {"error": f"{type(e).__name__}: {e}"}
         try:
-            cfg345["fog"] = extras_fog(mnv, cases, orc, torch, dev, opt, max(1, min(args.steps, 5)))
+            cfg345["fog"] = extras_fog(mnv, cases, orc, torch, dev, opt, max(1, min(args.steps, 5)), footprints)
         except Exception as e:
             cfg345["fog"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:

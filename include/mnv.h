@@ -238,25 +238,23 @@ int mnv_render_voxels_accel_part(const mnv_accel *accel, const mnv_camera *cam, 
                                  void *hip_stream);
 
 /*
- * Colour arithmetic of the tuned SH march (process-wide, default 0).  0: every value is computed exactly as the arithmetic
+ * Colour arithmetic of the tuned SH march, per accel (default 0).  0: every value is computed exactly as the arithmetic
  * specification says and frames are bit-identical to the oracle.  1: the colour sigmoid
  * weight / (1 + exp(-dot)) uses the hardware exp2 and reciprocal (about 1 ulp each).  Opacity, transmittance, step sizes and
  * every branch stay exact -- SURVEY.md section 7: colour-only arithmetic is continuous and feeds no control flow -- so alpha and
  * the step sequence are unchanged and colours move by ~1e-7 (bound asserted in the tests: 2e-6; contract 1e-4).
  * Trackers, sample emission, depth mode and RGBA-format trees are unaffected.
  */
-void mnv_set_colour_math(int fast);
-/* The same choice for ONE accel: mode 0 exact, 1 fast, a negative value = follow the process-wide switch again (the default).  Two renderers
- * of one process can thus differ; launches already queued keep the mode they were launched with. */
+/* mode 0 exact, 1 fast.  Two renderers of one process can differ; launches already queued keep the mode they were launched with.  (There is no
+ * process-wide switch: no call's arithmetic depends on state outside its arguments.) */
 int mnv_accel_set_colour_math(mnv_accel *accel, int mode);
 
 /*
- * mnv_render_voxels builds, in front of every launch of at least `min_rays` rays, a dense level-7 lookup table of the tree on the
- * caller's stream (stream-ordered scratch memory, about 10 us, 16 MB; csrc/mnv_march_ref_layout.hip) -- the caller's arrays
- * may change between calls, so nothing is kept.  Smaller launches (tiles) derive a 512-cell table per workgroup instead.
- * Process-wide; default 65536; 0 = always, a negative value = never.  Frames are bit-identical either way.
+ * (mnv_render_voxels builds, in front of every launch of at least 65536 rays, a dense level-7 lookup table of the tree on the caller's stream --
+ * stream-ordered scratch memory, about 10 us, 16 MB; csrc/mnv_march_ref_layout.hip -- because the caller's arrays may change between calls and
+ * nothing is kept.  Smaller launches (tiles) derive a 512-cell table per workgroup instead.  Frames are bit-identical either way; the threshold
+ * is not a switch of this library -- the test-hook build alone can move it, so that the tests run either path at any size.)
  */
-void mnv_set_ref_table_min_rays(int64_t min_rays);
 /*
  * A memory for the stateless entry point.  viewer::render_voxels (renderer_kernel.hpp:23-34) takes the tree's arrays with every call
  * and keeps nothing, because its caller may edit them in between (the refinement of cuda_renderer.cpp:205-381 does); mnv_render_voxels
@@ -599,23 +597,21 @@ int mnv_query_submodules(mnv_mlp *mlp, const int16_t *cluster_indices, const flo
  * of one sub-module fit a workgroup's LDS beside the sample rings (every 64-wide network of up to about 6 layers), a workgroup
  * is three wavefronts that only march and push their samples into rings in LDS plus one wavefront that only evaluates the
  * network -- weights resident in LDS, results handed back through the rings, the owning lanes composite; otherwise every
- * wavefront does both jobs in turn (weights from L2).  mnv_set_fused_kernel selects one explicitly.
+ * wavefront does both jobs in turn (weights from L2).  mnv_accel_set_fused_kernel selects one explicitly.
  */
 int mnv_render_guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile, const mnv_mlp *mlp,
                             const mnv_cluster_grid *grid, float *rgba_out, uint8_t *rgba8_out, unsigned long long *sample_counter,
                             void *hip_stream);
-/* Which kernel the mnv_render_guided_fused* entry points launch (process-wide): 0 = choose by the network's size (default),
+/* Which kernel the mnv_render_guided_fused* entry points launch on THIS accel: 0 = choose by the network's size (default),
  * 1 = the one-role kernel (every wavefront marches and evaluates), 2 = producer / consumer wavefronts wherever the rings, the
  * rays' constants and the weights of enough sub-modules fit a workgroup's LDS (the one-role kernel otherwise). */
-void mnv_set_fused_kernel(int version);
-/* ... and for ONE accel (a negative value = follow the process-wide choice again, the default) */
 int mnv_accel_set_fused_kernel(mnv_accel *accel, int version);
-/* Diagnostics of the fused kernels (process-wide): `words32` = NULL (default, none) or a device buffer of 32 64-bit words the
+/* Diagnostics of the fused kernels on THIS accel: `words32` = NULL (default, none) or a device buffer of 32 64-bit words the
  * kernels add run counts and per-phase times to (tools/guided_bench.py names them).  Costs a few per cent while set.  The library keeps
  * only the address: the buffer must outlive every launch made while it is set (pass NULL before freeing it). */
-void mnv_set_fused_diag(unsigned long long *words32);
+int mnv_accel_set_fused_diag(mnv_accel *accel, unsigned long long *words32);
 /* The producer / consumer kernel waits with s_sleep polls under a watchdog (a bug ends in wrong pixels, never in a hung device).  A
- * wait the watchdog abandons is counted in a device word of the accel -- always, with or without mnv_set_fused_diag.  The frame's own
+ * wait the watchdog abandons is counted in a device word of the accel -- always, with or without mnv_accel_set_fused_diag.  The frame's own
  * call has long returned (the entry points are asynchronous), so: the NEXT mnv_render_guided_fused* call on this accel prints one line
  * on stderr and returns MNV_E_FAULT once per fault, and mnv_accel_fused_faults reads the count since mnv_accel_create (it waits for
  * the device).  No wait has ever been abandoned in a test or stress run; the count is 0 on a healthy build. */
@@ -658,11 +654,8 @@ int mnv_render_guided_fused_track_part(const mnv_accel *accel, const mnv_camera 
 int mnv_stream_create_reserved(int32_t reserve_cus, void **stream_out, int32_t *enabled_cus);
 int mnv_stream_destroy(void *stream);
 
-/* Average device time (ms) of the last `mnv_render_*` launches since the
- * previous call, measured with HIP events on the launch stream when
- * mnv_set_timing(1) is active; used by bench.py for roofline.achieved. */
-void mnv_set_timing(int enable);
-int mnv_take_timing(double *total_ms, int32_t *launches);
+/* (Device times: every entry point launches on the caller's stream and records nothing itself -- bracket the call with two HIP events on that
+ * stream, as bench.py does for roofline.achieved.) */
 
 /* ------------------------------------------ host-side data model (C++ core) */
 

@@ -217,13 +217,10 @@ _SIGNATURES = {
     "mnv_partition_local_tiles": (C.c_int32, [Rect, Partition]),
     "mnv_render_voxels_accel_part": (C.c_int, [C.c_void_p, C.POINTER(CameraStruct), C.POINTER(RenderOptions), Rect, Partition,
                                                C.c_void_p, C.c_void_p, C.c_void_p]),
-    "mnv_set_colour_math": (None, [C.c_int]),
     "mnv_accel_set_colour_math": (C.c_int, [C.c_void_p, C.c_int]),
     "mnv_accel_set_fused_kernel": (C.c_int, [C.c_void_p, C.c_int]),
-    "mnv_set_fused_kernel": (None, [C.c_int]),
-    "mnv_set_fused_diag": (None, [C.c_void_p]),
+    "mnv_accel_set_fused_diag": (C.c_int, [C.c_void_p, C.c_void_p]),
     "mnv_accel_fused_faults": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
-    "mnv_set_ref_table_min_rays": (None, [C.c_int64]),
     "mnv_set_tree_cache": (None, [C.c_int]),
     "mnv_tree_invalidate": (None, [C.c_void_p]),
     "mnv_assemble_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, Partition, C.c_int32, C.c_int32, C.c_void_p]),
@@ -314,8 +311,6 @@ _SIGNATURES = {
                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mnv_renderer_set_ranks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "mnv_renderer_download_slot": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
-    "mnv_set_timing": (None, [C.c_int]),
-    "mnv_take_timing": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "mnv_n3tree_open": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "mnv_n3tree_from_arrays": (C.c_int, [C.POINTER(TreeView), C.POINTER(C.c_void_p)]),
     "mnv_n3tree_free": (None, [C.c_void_p]),
@@ -356,6 +351,33 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_hooks_lib: Optional[C.CDLL] = None
+HOOKS_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "testhooks", "libmnv.so")
+
+
+def hooks_lib() -> C.CDLL:
+    """The test-hook build of the library (testhooks/libmnv.so: the same object code but for the knobs / transport units) as a SECOND binding in
+    this process -- for the one switch the shipped library does not have: mnv_hook_set_ref_table_min_rays, with which the tests run
+    mnv_render_voxels' per-launch lookup table at any frame size.  (When MNV_LIB_PATH already selects the hooks build it is that library.)"""
+    global _hooks_lib
+    if _hooks_lib is None:
+        lib()   # torch's HIP runtime first (see lib())
+        if os.path.abspath(LIB_PATH) == os.path.abspath(HOOKS_LIB_PATH):
+            h = lib()
+        else:
+            if not os.path.exists(HOOKS_LIB_PATH):
+                raise ImportError(f"{HOOKS_LIB_PATH} is missing (make builds it beside libmnv.so)")
+            h = C.CDLL(HOOKS_LIB_PATH)
+            for name, (res, args) in _SIGNATURES.items():
+                fn = getattr(h, name)
+                fn.restype = res
+                fn.argtypes = args
+        h.mnv_hook_set_ref_table_min_rays.restype = None
+        h.mnv_hook_set_ref_table_min_rays.argtypes = [C.c_longlong]
+        _hooks_lib = h
+    return _hooks_lib
+
+
 def built_source_sha() -> str:
     """Hash of the sources the loaded libmnv.so was built from (mnv_source_sha)."""
     return lib().mnv_source_sha().decode()
@@ -378,9 +400,9 @@ def shipped_source_sha() -> str:
     return h.hexdigest()[:16]
 
 
-def _check(rc: int) -> None:
+def _check(rc: int, h=None) -> None:
     if rc != 0:
-        raise MnvError(rc, lib().mnv_last_error().decode("utf-8", "replace"))
+        raise MnvError(rc, (h or lib()).mnv_last_error().decode("utf-8", "replace"))
 
 
 def device_count() -> int:
@@ -580,18 +602,30 @@ def _frame_inputs(tmax_px, rgba8_init, pixels: int):
 
 
 def render_voxels(tree_view: TreeView, cam: Camera, opt: RenderOptions, tile=None, rgba=None, rgba8=None,
-                  split_track=None, sample_track=None, visited=None, track_visit=False, stream: int = 0, tmax_px=None, rgba8_init=None) -> None:
+                  split_track=None, sample_track=None, visited=None, track_visit=False, stream: int = 0, tmax_px=None, rgba8_init=None,
+                  table_min_rays: Optional[int] = None) -> None:
     """viewer::render_voxels on reference-layout device arrays (asynchronous on `stream`).  tmax_px / rgba8_init: the depth attachment and
-    the image under the volume of the reference's offscreen == false call shape (indexed like the outputs; rgba8_init may be rgba8)."""
+    the image under the volume of the reference's offscreen == false call shape (indexed like the outputs; rgba8_init may be rgba8).
+    table_min_rays (tests only): run the call on the test-hook build with its per-launch lookup table forced on (0) / off (-1) / from that
+    many rays -- the shipped library has no such switch (65536 rays)."""
     if tile is None:
         tile = (0, 0, cam.width, cam.height)
+    h = lib()
+    if table_min_rays is not None:
+        h = hooks_lib()
+        h.mnv_hook_set_ref_table_min_rays(int(table_min_rays))
     inputs = _frame_inputs(tmax_px, rgba8_init, tile[2] * tile[3])
-    if inputs is not None:
-        _check(lib().mnv_render_voxels_ex(C.byref(tree_view), C.byref(cam.c), C.byref(opt), Rect(*tile), C.byref(inputs), _ptr(rgba), _ptr(rgba8),
-                                          _ptr(split_track), _ptr(sample_track), _ptr(visited), int(track_visit), C.c_void_p(stream)))
-        return
-    _check(lib().mnv_render_voxels(C.byref(tree_view), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba), _ptr(rgba8),
-                                   _ptr(split_track), _ptr(sample_track), _ptr(visited), int(track_visit), C.c_void_p(stream)))
+    try:
+        with _timed(stream):
+            if inputs is not None:
+                _check(h.mnv_render_voxels_ex(C.byref(tree_view), C.byref(cam.c), C.byref(opt), Rect(*tile), C.byref(inputs), _ptr(rgba), _ptr(rgba8),
+                                              _ptr(split_track), _ptr(sample_track), _ptr(visited), int(track_visit), C.c_void_p(stream)), h)
+            else:
+                _check(h.mnv_render_voxels(C.byref(tree_view), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba), _ptr(rgba8),
+                                           _ptr(split_track), _ptr(sample_track), _ptr(visited), int(track_visit), C.c_void_p(stream)), h)
+    finally:
+        if table_min_rays is not None:
+            h.mnv_hook_set_ref_table_min_rays(1 << 16)
 
 
 def accel_create(tree_view: TreeView, max_capacity: int = 0, stream: int = 0) -> int:
@@ -607,6 +641,7 @@ def accel_rebuild(accel: int, tree_view: TreeView, stream: int = 0) -> None:
 
 
 def accel_destroy(accel: int) -> None:
+    _pinned_fused_kernel.pop(accel, None)
     lib().mnv_accel_destroy(C.c_void_p(accel))
 
 
@@ -649,12 +684,13 @@ def render_voxels_accel(accel: int, cam: Camera, opt: RenderOptions, tile=None, 
     _check_out("rgba", rgba, tile[2] * tile[3], "f32")
     _check_out("rgba8", rgba8, tile[2] * tile[3], "u8")
     inputs = _frame_inputs(tmax_px, rgba8_init, tile[2] * tile[3])
-    if inputs is not None:
-        _check(lib().mnv_render_voxels_accel_ex(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), C.byref(inputs), _ptr(rgba),
-                                                _ptr(rgba8), C.c_void_p(stream)))
-        return
-    _check(lib().mnv_render_voxels_accel(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba), _ptr(rgba8),
-                                         C.c_void_p(stream)))
+    with _timed(stream):
+        if inputs is not None:
+            _check(lib().mnv_render_voxels_accel_ex(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), C.byref(inputs), _ptr(rgba),
+                                                    _ptr(rgba8), C.c_void_p(stream)))
+            return
+        _check(lib().mnv_render_voxels_accel(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba), _ptr(rgba8),
+                                             C.c_void_p(stream)))
 
 
 def render_voxels_accel_track(accel: int, cam: Camera, opt: RenderOptions, tile=None, rgba=None, rgba8=None,
@@ -662,9 +698,10 @@ def render_voxels_accel_track(accel: int, cam: Camera, opt: RenderOptions, tile=
     """The tuned march with the refinement trackers (rows as render_voxels writes them)."""
     if tile is None:
         tile = (0, 0, cam.width, cam.height)
-    _check(lib().mnv_render_voxels_accel_track(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba),
-                                               _ptr(rgba8), _ptr(split_track), _ptr(sample_track), _ptr(sample_counts),
-                                               C.c_void_p(stream)))
+    with _timed(stream):
+        _check(lib().mnv_render_voxels_accel_track(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), _ptr(rgba),
+                                                   _ptr(rgba8), _ptr(split_track), _ptr(sample_track), _ptr(sample_counts),
+                                                   C.c_void_p(stream)))
 
 
 def render_voxels_accel_visit(accel: int, cam: Camera, opt: RenderOptions, visited, parent, tile=None, rgba=None, rgba8=None, split_track=None,
@@ -712,38 +749,62 @@ def get_samples_from_voxels_accel_visit(accel: int, cam: Camera, opt: RenderOpti
                                                          int(samples.shape[-1]), _ptr(cluster_indices), C.byref(grid), C.c_void_p(stream)))
 
 
-def set_colour_math(fast: bool) -> None:
-    """False (default): bit-identical to the oracle.  True: hardware exp2 / rcp in the colour sigmoid (colours move ~1e-7)."""
-    lib().mnv_set_colour_math(int(bool(fast)))
-
-
 def accel_set_colour_math(accel: int, mode: int) -> None:
-    """Colour math of ONE accel: 0 exact, 1 fast colour sigmoid, negative = follow set_colour_math (the default)."""
+    """Colour math of ONE accel: 0 exact (bit-identical to the oracle, the default), 1 hardware exp2 / rcp in the colour sigmoid (colours move
+    ~1e-7).  There is no process-wide switch."""
     _check(lib().mnv_accel_set_colour_math(C.c_void_p(accel), int(mode)))
 
 
+# The C library holds the choice of the fused guided-sampling kernel and its diagnostics buffer PER ACCEL (mnv_accel_set_fused_kernel /
+# mnv_accel_set_fused_diag).  The two module-level setters below are a convenience of this harness for tests and tools whose trees are
+# created deep inside helpers: render_guided_fused* (and Renderer.render) hand the harness's current choice to the accel they launch on,
+# unless accel_set_fused_kernel pinned that accel.
+_harness_fused_kernel: Optional[int] = None
+_harness_fused_diag = None
+_harness_diag_used = False
+_pinned_fused_kernel: dict = {}
+
+
 def accel_set_fused_kernel(accel: int, version: int) -> None:
-    """Fused guided-sampling kernel of ONE accel: 0 / 1 / 2 as set_fused_kernel, negative = follow it (the default)."""
-    _check(lib().mnv_accel_set_fused_kernel(C.c_void_p(accel), int(version)))
+    """Fused guided-sampling kernel of ONE accel: 0 = by network size (default), 1 = one-role wavefronts, 2 = producer / consumer wavefronts;
+    negative = un-pin (the harness default of set_fused_kernel applies again)."""
+    if version < 0:
+        _pinned_fused_kernel.pop(accel, None)
+        _check(lib().mnv_accel_set_fused_kernel(C.c_void_p(accel), int(_harness_fused_kernel or 0)))
+    else:
+        _pinned_fused_kernel[accel] = int(version)
+        _check(lib().mnv_accel_set_fused_kernel(C.c_void_p(accel), int(version)))
+
+
+def accel_set_fused_diag(accel: int, words32=None) -> None:
+    """Diagnostics buffer of the fused kernels on ONE accel: a device int64 tensor of at least 32 words, or None.  The library keeps only the
+    address: the caller keeps the tensor alive while it is set."""
+    if words32 is not None and words32.numel() < 32:
+        raise ValueError("the diagnostics buffer holds 32 words")
+    _check(lib().mnv_accel_set_fused_diag(C.c_void_p(accel), _ptr(words32)))
 
 
 def set_fused_kernel(version: int) -> None:
-    """Kernel behind render_guided_fused*: 0 = by network size (default), 1 = one-role wavefronts, 2 = producer / consumer wavefronts."""
-    lib().mnv_set_fused_kernel(int(version))
-
-
-_fused_diag_keepalive = None
+    """Harness default for the accels render_guided_fused* launch on (see above): 0 = by network size, 1, 2."""
+    global _harness_fused_kernel
+    _harness_fused_kernel = int(version) if version in (1, 2) else None
 
 
 def set_fused_diag(words32=None) -> None:
-    """Diagnostics buffer of the fused kernels: a device int64 tensor of at least 32 words, or None (default: no diagnostics).
-    The library keeps only the device address: the tensor is held here until the next call, so that a caller that rebinds or drops
-    its own reference cannot leave the kernels adding into freed memory."""
-    global _fused_diag_keepalive
+    """Harness default: the diagnostics buffer handed to every accel render_guided_fused* launches on from now on (None: none).  The tensor
+    is held here, so that a caller that drops its own reference cannot leave the kernels adding into freed memory."""
+    global _harness_fused_diag, _harness_diag_used
     if words32 is not None and words32.numel() < 32:
         raise ValueError("the diagnostics buffer holds 32 words")
-    lib().mnv_set_fused_diag(_ptr(words32))
-    _fused_diag_keepalive = words32
+    _harness_fused_diag = words32
+    _harness_diag_used = True
+
+
+def _fused_defaults(accel: int) -> None:
+    if accel not in _pinned_fused_kernel and (_harness_fused_kernel is not None or _harness_diag_used):
+        _check(lib().mnv_accel_set_fused_kernel(C.c_void_p(accel), int(_harness_fused_kernel or 0)))
+    if _harness_diag_used:
+        _check(lib().mnv_accel_set_fused_diag(C.c_void_p(accel), _ptr(_harness_fused_diag)))
 
 
 def accel_fused_faults(accel: int) -> int:
@@ -768,12 +829,6 @@ def tree_invalidate(child=None) -> None:
         lib().mnv_tree_invalidate(C.c_void_p(child if isinstance(child, int) else child.data_ptr()))
 
 
-def set_ref_table_min_rays(min_rays: int) -> None:
-    """render_voxels (reference layout): launches of at least `min_rays` rays build the per-launch level-7 lookup table first
-    (default 65536; 0 = always, negative = never); bit-identical frames either way."""
-    lib().mnv_set_ref_table_min_rays(int(min_rays))
-
-
 def assemble_tiles(gathered, frames, width: int, height: int, world: int, tile_w: int, tile_h: int, n_frames: int = 1, stream: int = 0,
                    root_period: int = 0) -> None:
     """Rank 0's un-permute of the gathered tile buffers into frames (device tensors, RGBA8 or float RGBA)."""
@@ -795,8 +850,9 @@ def render_voxels_accel_part(accel: int, cam: Camera, opt: RenderOptions, rank: 
     n_local = partition_local_tiles(tile, rank, world, tile_w, tile_h, root_period)
     _check_out("rgba", rgba, n_local * tile_w * tile_h, "f32")
     _check_out("rgba8", rgba8, n_local * tile_w * tile_h, "u8")
-    _check(lib().mnv_render_voxels_accel_part(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile),
-                                              Partition(rank, world, tile_w, tile_h, root_period), _ptr(rgba), _ptr(rgba8), C.c_void_p(stream)))
+    with _timed(stream):
+        _check(lib().mnv_render_voxels_accel_part(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile),
+                                                  Partition(rank, world, tile_w, tile_h, root_period), _ptr(rgba), _ptr(rgba8), C.c_void_p(stream)))
 
 
 def get_samples_from_voxels(tree_view: TreeView, cam: Camera, opt: RenderOptions, num_samples, samples, cluster_indices,
@@ -849,6 +905,7 @@ def render_guided_fused(accel: int, cam: Camera, opt: RenderOptions, mlp: "Mlp",
     attachment of the reference's offscreen == false frame (the image under the volume has weight 0 in that frame: not an input)."""
     if tile is None:
         tile = (0, 0, cam.width, cam.height)
+    _fused_defaults(accel)
     inputs = _frame_inputs(tmax_px, None, tile[2] * tile[3])
     if inputs is not None:
         _check(lib().mnv_render_guided_fused_track_ex(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), C.byref(inputs), mlp._h, C.byref(grid),
@@ -870,6 +927,7 @@ def render_guided_fused_part(accel: int, cam: Camera, opt: RenderOptions, mlp: "
     px = _pixels(tile, 1, part)
     _check_out("rgba", rgba, px, "f32")
     _check_out("rgba8", rgba8, px, "u8")
+    _fused_defaults(accel)
     if split_track is not None or sample_track is not None or visited is not None:
         _check(lib().mnv_render_guided_fused_track_part(C.c_void_p(accel), C.byref(cam.c), C.byref(opt), Rect(*tile), Partition(*part), mlp._h, C.byref(grid),
                                                         _ptr(rgba), _ptr(rgba8), _ptr(split_track), _ptr(sample_track), _ptr(sample_counts), _ptr(visited),
@@ -1034,6 +1092,10 @@ class Renderer:
 
     def render(self) -> dict:
         st = RendererStats()
+        if self._tree is not None and (_harness_fused_kernel is not None or _harness_diag_used):
+            a = lib().mnv_n3tree_accel(self._tree._h)
+            if a:
+                _fused_defaults(a)
         _check(lib().mnv_renderer_render(self._h, C.byref(st)))
         return st.as_dict()
 
@@ -1103,8 +1165,9 @@ def render_voxels_accel_batch(accel: int, cams, opt: RenderOptions, tile=None, p
     px = _pixels(tile, n, part)
     _check_out("rgba", rgba, px, "f32")
     _check_out("rgba8", rgba8, px, "u8")
-    _check(lib().mnv_render_voxels_accel_batch(C.c_void_p(accel), arr, n, C.byref(opt), Rect(*tile), p, _ptr(rgba), _ptr(rgba8),
-                                               C.c_void_p(stream)))
+    with _timed(stream):
+        _check(lib().mnv_render_voxels_accel_batch(C.c_void_p(accel), arr, n, C.byref(opt), Rect(*tile), p, _ptr(rgba), _ptr(rgba8),
+                                                   C.c_void_p(stream)))
 
 
 def accel_info(accel: int) -> dict:
@@ -1187,11 +1250,77 @@ def rccl_version() -> int:
     return int(lib().mnv_comm_rccl_version())
 
 
+# ---- device times of the launches made through this binding: HIP events on the launch stream, recorded HERE (the library records nothing itself)
+class _Timing:
+    on = False
+    pairs: list = []
+    hip = None
+
+
+def _hip():
+    if _Timing.hip is None:
+        lib()
+        path = None
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    path = line.split()[-1]
+                    break
+        h = C.CDLL(path or "libamdhip64.so")
+        for name, args in (("hipEventCreate", [C.POINTER(C.c_void_p)]), ("hipEventRecord", [C.c_void_p, C.c_void_p]), ("hipEventSynchronize", [C.c_void_p]),
+                           ("hipEventElapsedTime", [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]), ("hipEventDestroy", [C.c_void_p])):
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = C.c_int, args
+        _Timing.hip = h
+    return _Timing.hip
+
+
+class _timed:
+    """with _timed(stream): <one launch> -- two events around it when set_timing(True) is active"""
+
+    def __init__(self, stream):
+        self.stream = stream
+
+    def __enter__(self):
+        self.e0 = None
+        if _Timing.on:
+            h = _hip()
+            self.e0, self.e1 = C.c_void_p(), C.c_void_p()
+            if h.hipEventCreate(C.byref(self.e0)) or h.hipEventCreate(C.byref(self.e1)):
+                raise MnvError(MNV_E_FAULT, "hipEventCreate failed")
+            h.hipEventRecord(self.e0, C.c_void_p(self.stream))
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if self.e0 is not None:
+            _hip().hipEventRecord(self.e1, C.c_void_p(self.stream))
+            _Timing.pairs.append((self.e0, self.e1))
+        return False
+
+
 def set_timing(enable: bool) -> None:
-    lib().mnv_set_timing(int(enable))
+    """Start / stop timing the march launches made through render_voxels / render_voxels_accel[_track|_part|_batch] (HIP events on their streams)."""
+    h = _hip()
+    for e0, e1 in _Timing.pairs:
+        h.hipEventDestroy(e0)
+        h.hipEventDestroy(e1)
+    _Timing.pairs = []
+    _Timing.on = bool(enable)
 
 
 def take_timing():
-    ms, n = C.c_double(), C.c_int32()
-    _check(lib().mnv_take_timing(C.byref(ms), C.byref(n)))
-    return ms.value, n.value
+    """(sum of the device times in ms, launches) since the last call; waits for the launches."""
+    h = _hip()
+    total, n = 0.0, 0
+    for e0, e1 in _Timing.pairs:
+        if h.hipEventSynchronize(e1):
+            raise MnvError(MNV_E_FAULT, "hipEventSynchronize failed")
+        ms = C.c_float()
+        if h.hipEventElapsedTime(C.byref(ms), e0, e1):
+            raise MnvError(MNV_E_FAULT, "hipEventElapsedTime failed")
+        total += ms.value
+        n += 1
+        h.hipEventDestroy(e0)
+        h.hipEventDestroy(e1)
+    _Timing.pairs = []
+    return total, n

@@ -146,6 +146,8 @@ struct mnv_accel {
     uint32_t *fault_dev = nullptr;        // [1] guided_fused2_kernel: spin-waits abandoned by the watchdog since creation (always counted, with or without
     uint32_t *fault_host = nullptr;       // mnv_set_fused_diag); pinned mirror, refreshed behind every fused launch -- mnv_accel_fused_faults
     uint32_t fault_reported = 0;          // faults already answered with MNV_E_FAULT
+    uint32_t *line_bits = nullptr;        // MNV_FOOTPRINT=<file> diagnostics: one bit per 128-byte line of grid2i / grid2, recs, nodes, rows, grid2_vox, grid_vox
+    uint32_t line_base[7] = {};           // first line of each of those regions in the bitmap; [6] = all lines
     unsigned long long *timeline = nullptr;  // MNV_TIMELINE=<file> diagnostics: tile / wavefront time stamps of the last launch
     size_t timeline_bytes = 0, timeline_tiles = 0, timeline_waves = 0, timeline_tiles_per_frame = 0;
     // per-launch slots: [kNumQueues] ray-queue heads (64 B apart; a queue spans the frames of a batch) + [n_frames] camera blocks,
@@ -155,8 +157,9 @@ struct mnv_accel {
     std::atomic<uint32_t> slot_counter{0};
     hipEvent_t slot_done[mnv::kSlots] = {};  // recorded after the launch that used the slot
     bool slot_used[mnv::kSlots] = {};
-    std::atomic<int> colour_math{-1};     // mnv_accel_set_colour_math: -1 follow the process-wide switch, 0 exact, 1 fast colour sigmoid
-    std::atomic<int> fused_kernel{-1};    // mnv_accel_set_fused_kernel: -1 follow the process-wide switch, 0 / 1 / 2 as mnv_set_fused_kernel
+    std::atomic<int> colour_math{0};      // mnv_accel_set_colour_math: 0 exact (bit-identical to the oracle), 1 hardware exp2 / rcp in the colour sigmoid
+    std::atomic<int> fused_kernel{0};     // mnv_accel_set_fused_kernel: 0 = the first that fits, 2 = producer / consumer wavefronts, 1 = one role
+    std::atomic<unsigned long long *> fused_diag{nullptr};  // mnv_accel_set_fused_diag: 32 device words the fused kernels add their clocks / counts to
     size_t bytes = 0;
     int device = 0;
     int num_cus = 0;     // units the persistent launch fills (mnv_accel_set_cu_budget)

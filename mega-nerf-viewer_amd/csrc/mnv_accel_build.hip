@@ -346,6 +346,24 @@ void mnv_accel_destroy(mnv_accel *a) {
             }
         }
     }
+    if (a->line_bits && knob_str(KNOB_FOOTPRINT)) {
+        // unique 128-byte lines per array, as JSON (tools/footprint.py reads it)
+        const size_t words = ((size_t)a->line_base[6] + 31) / 32;
+        std::vector<uint32_t> h(words);
+        if (hipMemcpy(h.data(), a->line_bits, words * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            static const char *names[6] = {"grid2", "records", "nodes", "rows", "grid2_vox", "grid_vox"};
+            unsigned long long lines[6] = {};
+            for (int r = 0; r < 6; ++r)
+                for (uint32_t l = a->line_base[r]; l < a->line_base[r + 1]; ++l) lines[r] += (h[l >> 5] >> (l & 31u)) & 1u;
+            if (FILE *f = fopen(knob_str(KNOB_FOOTPRINT), "w")) {
+                fprintf(f, "{");
+                for (int r = 0; r < 6; ++r) fprintf(f, "\"%s_lines\": %llu, ", names[r], lines[r]);
+                fprintf(f, "\"line_bytes\": 128}\n");
+                fclose(f);
+            }
+        }
+    }
+    if (a->line_bits) (void)hipFree(a->line_bits);
     if (a->timeline) (void)hipFree(a->timeline);
     if (a->recs) (void)hipFree(a->recs);
     if (a->grid2i) (void)hipFree(a->grid2i);

@@ -96,10 +96,7 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
             }
         }
     }
-    {   // colour math: the accel's own setting, else the process-wide switch (two renderers of one process may differ)
-        const int own = accel->colour_math.load(std::memory_order_relaxed);
-        K.fast_colour = own >= 0 ? own : (fast_colour_selected() ? 1 : 0);
-    }
+    K.fast_colour = accel->colour_math.load(std::memory_order_relaxed) > 0 ? 1 : 0;  // mnv_accel_set_colour_math: the accel's own setting (two renderers of one process may differ)
     K.part_rank = part.rank;
     K.part_world = is_partitioned(part) ? part.world : 0;
     K.part_period = root_period_of(part);
@@ -192,7 +189,27 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     K.ablate = env_ablate;
     static const bool env_stats = knob_set(KNOB_STATS);
     static const char *env_timeline = knob_str(KNOB_TIMELINE);
-    K.stats = (env_stats || env_ablate || env_timeline) ? accel->stats : nullptr;  // all three run on the diagnostics instantiation
+    static const char *env_footprint = knob_str(KNOB_FOOTPRINT);
+    K.stats = (env_stats || env_ablate || env_timeline || env_footprint) ? accel->stats : nullptr;  // all four run on the diagnostics instantiation
+    if (env_footprint && !(track && track->fused)) {
+        // one bit per 128-byte line of every array the march loads from; the bits of all launches accumulate until mnv_accel_destroy counts them
+        if (!mut->line_bits) {
+            const uint64_t cells2 = accel->view.grid2_level > 0 ? (uint64_t)1 << (3 * accel->view.grid2_level) : 0, cells1 = (uint64_t)1 << (3 * accel->view.grid_level);
+            const uint64_t nvox = (uint64_t)accel->reserved * 8;
+            const uint64_t bytes[6] = {cells2 * 4, (uint64_t)accel->reserved * kRecWords * 4, nvox * 4, nvox * (uint64_t)accel->view.row_bytes, cells2 * 4, cells1 * 4};
+            uint64_t at = 0;
+            for (int i = 0; i < 6; ++i) {
+                mut->line_base[i] = (uint32_t)at;
+                at += (bytes[i] + 127) / 128 + 1;
+            }
+            mut->line_base[6] = (uint32_t)at;
+            const size_t words = (size_t)(at + 31) / 32;
+            if (hipMalloc((void **)&mut->line_bits, words * 4) != hipSuccess) return (int)hipErrorOutOfMemory;
+            (void)hipMemsetAsync(mut->line_bits, 0, words * 4, stream);
+        }
+        K.line_bits = mut->line_bits;
+        for (int i = 0; i < 6; ++i) K.line_base[i] = mut->line_base[i];
+    }
     static const int env_shadow = knob_int(KNOB_SHADOW, 0);
     if (env_shadow & (16 | 32 | 64)) {
         // shadow loads (test-hook build + a -DMNV_SHADOW_MASK variant of the march): copies of the arrays at other addresses, made once
@@ -275,13 +292,19 @@ int32_t mnv_partition_local_tiles(mnv_rect tile, mnv_partition part) { return pa
 
 int mnv_accel_set_colour_math(mnv_accel *accel, int mode) {
     if (!accel) return set_error(MNV_E_INVALID, "accel is null");
-    accel->colour_math.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed);
+    accel->colour_math.store(mode > 0 ? 1 : 0, std::memory_order_relaxed);
     return MNV_OK;
 }
 
 int mnv_accel_set_fused_kernel(mnv_accel *accel, int version) {
     if (!accel) return set_error(MNV_E_INVALID, "accel is null");
-    accel->fused_kernel.store(version < 0 ? -1 : (version == 1 || version == 2 ? version : 0), std::memory_order_relaxed);
+    accel->fused_kernel.store(version == 1 || version == 2 ? version : 0, std::memory_order_relaxed);
+    return MNV_OK;
+}
+
+int mnv_accel_set_fused_diag(mnv_accel *accel, unsigned long long *words32) {
+    if (!accel) return set_error(MNV_E_INVALID, "accel is null");
+    accel->fused_diag.store(words32, std::memory_order_relaxed);
     return MNV_OK;
 }
 
@@ -372,7 +395,6 @@ static int render_accel(const mnv_accel *accel, const mnv_camera *cams, int32_t 
         fill_origin(blocks[i], P.offset, P.scale);
     }
     hipStream_t stream = (hipStream_t)hip_stream;
-    LaunchTimer timer(stream);
     rc = launch_accel(accel, P, blocks, n_cams, part, track, stream);
     if (rc == kUnsupportedBasis) return set_error(MNV_E_UNSUPPORTED, "unsupported basis_dim for the accel path");
     return check_hip((hipError_t)rc, "march_accel_kernel");
@@ -565,7 +587,7 @@ static int guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv
             const uint32_t n = seen - mut->fault_reported;
             mut->fault_reported = seen;
             fprintf(stderr, "libmnv: %u wavefront(s) of an earlier fused guided-sampling frame on this accel abandoned a spin-wait (watchdog): that frame is wrong\n", n);
-            return set_error(MNV_E_FAULT, "an earlier fused guided-sampling frame on this accel ran into the kernel's watchdog and is wrong; mnv_set_fused_kernel(1) selects the kernel without spin-waits");
+            return set_error(MNV_E_FAULT, "an earlier fused guided-sampling frame on this accel ran into the kernel's watchdog and is wrong; mnv_accel_set_fused_kernel(accel, 1) selects the kernel without spin-waits");
         }
     }
     if (visited && !parent) return set_error(MNV_E_INVALID, "visit marks on the packed layout need the parent array (the ancestors of the marked chunks)");
@@ -596,7 +618,7 @@ static int guided_fused(const mnv_accel *accel, const mnv_camera *cam, const mnv
     static const int env_batch = knob_int(KNOB_FUSED_BATCH_MIN, kFW);
     F.batch_min = env_batch < 1 ? 1 : (env_batch > kFW ? kFW : env_batch);
     F.sample_counter = sample_counter;
-    F.diag = fused_diag_words();
+    F.diag = accel->fused_diag.load(std::memory_order_relaxed);
     static const int env_switch = knob_int(KNOB_F2_SWITCH_MIN, 32);
     F.switch_min = env_switch;
     AccelTrack track = {};

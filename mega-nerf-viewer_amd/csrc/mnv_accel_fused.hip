@@ -8,10 +8,6 @@
 
 namespace mnv {
 
-// mnv_set_fused_kernel / mnv_set_fused_diag
-static std::atomic<int> g_fused_kernel{0};
-static std::atomic<unsigned long long *> g_fused_diag{nullptr};
-unsigned long long *fused_diag_words() { return g_fused_diag.load(std::memory_order_relaxed); }
 
 int launch_fused(const mnv_accel *accel, const AccelLaunch &K, const FusedGuided &fused, int b, int lds_level, uint64_t n_waves_needed,
                  hipStream_t stream) {
@@ -27,8 +23,7 @@ int launch_fused(const mnv_accel *accel, const AccelLaunch &K, const FusedGuided
     while (slots > 1 && (size_t)f2_layout(nb, lds_level, F.S, slots).total * 4 > (size_t)160 * 1024 / f2_per_cu) --slots;
     F.weight_slots = slots;
     const size_t f2_bytes = (size_t)f2_layout(nb, lds_level, F.S, slots).total * 4;
-    const int own = accel->fused_kernel.load(std::memory_order_relaxed);
-    const int version = own >= 0 ? own : g_fused_kernel.load(std::memory_order_relaxed);
+    const int version = accel->fused_kernel.load(std::memory_order_relaxed);
     const bool fits2 = f2_bytes <= (size_t)160 * 1024 / f2_per_cu && slots >= (kF2NS < 2 ? kF2NS : 2) && F.S.bias_floats <= 256;  // (a consumer refills a sub-module's biases with four loads per lane)
     if (fits2 && (version == 2 || (version == 0 && kF2Default))) {
         int per_cu = (int)((size_t)160 * 1024 / f2_bytes);
@@ -91,7 +86,3 @@ case B:                                                                         
 
 }  // namespace mnv
 
-extern "C" {
-void mnv_set_fused_kernel(int version) { mnv::g_fused_kernel.store(version == 1 || version == 2 ? version : 0, std::memory_order_relaxed); }
-void mnv_set_fused_diag(unsigned long long *words32) { mnv::g_fused_diag.store(words32, std::memory_order_relaxed); }
-}

@@ -137,6 +137,8 @@ struct AccelLaunch {
     int32_t count_stats;                  // MODE 1 only: 0 = ablation run without the counters' atomics
     unsigned long long *timeline;         // MODE 1 only (MNV_TIMELINE): per tile {t_grab, t_done, wave, iterations}, then per wave {t_entry, t_exit} (100 MHz ticks)
     uint32_t timeline_tiles;              // tile records (n_tiles * n_frames)
+    uint32_t *line_bits;                  // MODE 1 only (MNV_FOOTPRINT): bitmap of the 128-byte lines the loads of this launch touch
+    uint32_t line_base[6];                // regions: 0 grid2i / grid2, 1 brick records, 2 node words, 3 colour rows, 4 grid2_vox, 5 grid_vox
     // MODE 2 only: refinement trackers (rt_core.cuh:179-180,237-252,308-321), indexed like the pixels
     float *split_track, *sample_track;
     const int16_t *sample_counts;         // reference layout [capacity][8], may be NULL
@@ -274,11 +276,8 @@ void launch_build_grid2(const uint32_t *nodes, uint32_t *grid2, uint32_t *grid2_
 int launch_march(const AccelLaunch &K, int basis, bool colourless, int n_blocks, size_t lds_bytes, hipStream_t stream);
 // the same on inline cell words / brick records (K.A.grid2i != NULL), every frame kind of the per-lane row formats (mnv_accel_march_brick.hip)
 int launch_march_brick(const AccelLaunch &K, int basis, bool colourless, int n_blocks, size_t lds_bytes, hipStream_t stream);
-// mnv_set_colour_math
-bool fast_colour_selected();
 // guided_fused2_kernel / guided_fused_kernel (mnv_accel_fused.hip); kUnsupportedBasis or a hipError_t
 int launch_fused(const mnv_accel *accel, const AccelLaunch &K, const FusedGuided &fused, int basis, int lds_level, uint64_t n_waves_needed,
                  hipStream_t stream);
-unsigned long long *fused_diag_words();  // mnv_set_fused_diag
 
 }  // namespace mnv

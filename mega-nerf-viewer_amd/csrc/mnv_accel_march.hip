@@ -5,9 +5,6 @@
 
 namespace mnv {
 
-// mnv_set_colour_math: 0 = exact (bit-identical to the oracle, default), 1 = hardware exp2 / rcp in the colour sigmoid
-static std::atomic<int> g_fast_colour{0};
-
 template <int BASIS, int MODE>
 static int launch_variant2(const AccelLaunch &K, int n_blocks, size_t lds_bytes, hipStream_t stream) {
     constexpr int BLOCK = 256;
@@ -54,6 +51,3 @@ int launch_march(const AccelLaunch &K, int b, bool colourless, int n_blocks, siz
 
 }  // namespace mnv
 
-bool mnv::fast_colour_selected() { return mnv::g_fast_colour.load(std::memory_order_relaxed) != 0; }
-
-extern "C" void mnv_set_colour_math(int fast) { mnv::g_fast_colour.store(fast ? 1 : 0, std::memory_order_relaxed); }

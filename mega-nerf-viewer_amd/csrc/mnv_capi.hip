@@ -24,31 +24,6 @@ int check_hip(hipError_t e, const char *what) {
     return set_error((int)e, std::string(what) + ": " + hipGetErrorString(e));
 }
 
-// ---- launch timing (HIP events on the launch stream) -------------------------------
-static std::mutex g_timing_mu;
-static bool g_timing_on = false;
-static double g_timing_ms = 0.0;
-static int32_t g_timing_launches = 0;
-struct PendingEvents {
-    hipEvent_t e0, e1;
-};
-static std::vector<PendingEvents> g_pending;
-
-LaunchTimer::LaunchTimer(hipStream_t s) : stream(s) {
-    std::lock_guard<std::mutex> lk(g_timing_mu);
-    if (!g_timing_on) return;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
-    active = true;
-    (void)hipEventRecord(e0, stream);
-}
-
-LaunchTimer::~LaunchTimer() {
-    if (!active) return;
-    (void)hipEventRecord(e1, stream);
-    std::lock_guard<std::mutex> lk(g_timing_mu);
-    g_pending.push_back({e0, e1});
-}
-
 // ---- argument block ----------------------------------------------------------------
 void fill_camera(CamBlock &C, const mnv_camera *cam);
 int fill_params(FrameParams &P, const mnv_camera *cam, const mnv_render_options *opt, mnv_rect tile) {
@@ -154,18 +129,6 @@ int mnv_device_count(void) {
     return n;
 }
 
-void mnv_set_timing(int enable) {
-    std::lock_guard<std::mutex> lk(g_timing_mu);
-    g_timing_on = enable != 0;
-    for (auto &p : g_pending) {
-        (void)hipEventDestroy(p.e0);
-        (void)hipEventDestroy(p.e1);
-    }
-    g_pending.clear();
-    g_timing_ms = 0.0;
-    g_timing_launches = 0;
-}
-
 int mnv_stream_create_reserved(int32_t reserve_cus, void **stream_out, int32_t *enabled_cus) {
     if (!stream_out) return set_error(MNV_E_INVALID, "stream_out is null");
     int dev = 0;
@@ -193,29 +156,6 @@ int mnv_stream_create_reserved(int32_t reserve_cus, void **stream_out, int32_t *
 }
 
 int mnv_stream_destroy(void *stream) { return check_hip(hipStreamDestroy((hipStream_t)stream), "hipStreamDestroy"); }
-
-int mnv_take_timing(double *total_ms, int32_t *launches) {
-    std::lock_guard<std::mutex> lk(g_timing_mu);
-    for (auto &p : g_pending) {
-        hipError_t e = hipEventSynchronize(p.e1);
-        float ms = 0.f;
-        if (e == hipSuccess) e = hipEventElapsedTime(&ms, p.e0, p.e1);
-        (void)hipEventDestroy(p.e0);
-        (void)hipEventDestroy(p.e1);
-        if (e != hipSuccess) {
-            g_pending.clear();
-            return check_hip(e, "mnv_take_timing");
-        }
-        g_timing_ms += ms;
-        g_timing_launches += 1;
-    }
-    g_pending.clear();
-    if (total_ms) *total_ms = g_timing_ms;
-    if (launches) *launches = g_timing_launches;
-    g_timing_ms = 0.0;
-    g_timing_launches = 0;
-    return MNV_OK;
-}
 
 // ---- mnv_set_tree_cache: the stateless entry point with a memory (see include/mnv.h) ------------------------------------------------
 namespace {
@@ -337,7 +277,6 @@ int mnv_render_voxels_ex(const mnv_tree_view *tree, const mnv_camera *cam, const
     P.sample_track = sample_track;
     P.visited = visited;
     P.track_visit = track_visit ? 1 : 0;
-    LaunchTimer timer(stream);
     if (tree->N <= 0) return check_hip((hipError_t)launch_background(P, stream), "fill_background_kernel");
     return check_hip((hipError_t)launch_ref_layout(P, stream), "march_ref_layout_kernel");
 }

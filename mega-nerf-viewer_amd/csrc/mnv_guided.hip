@@ -385,7 +385,6 @@ int mnv_get_samples_from_voxels_ex(const mnv_tree_view *tree, const mnv_camera *
     std::memcpy(S.range, grid->range, sizeof(S.range));
     if (tile.w <= 0 || tile.h <= 0) return MNV_OK;
     hipStream_t stream = (hipStream_t)hip_stream;
-    LaunchTimer timer(stream);
     hipLaunchKernelGGL(get_samples_kernel, dim3((tile.w + 15) / 16, (tile.h + 15) / 16), dim3(256), 0, stream, S);
     return check_hip(hipGetLastError(), "get_samples_kernel");
 }
@@ -414,7 +413,6 @@ int mnv_render_nerf_results(const mnv_tree_view *tree, const mnv_camera *cam, co
     const int b = tree->basis_dim;  // the colour branch keys on basis_dim >= 0 (rt_core.cuh:374)
     if (b >= 0 && value_stride < 3 * b) return set_error(MNV_E_INVALID, "value_stride too small for 3 * basis_dim");
     hipStream_t stream = (hipStream_t)hip_stream;
-    LaunchTimer timer(stream);
     dim3 grid((tile.w + 15) / 16, (tile.h + 15) / 16), block(256);
     const bool sh = tree->format == MNV_FORMAT_SH;
 #define MNV_LAUNCH(B) hipLaunchKernelGGL(composite_nerf_kernel<B>, grid, block, 0, stream, Cp)

@@ -31,13 +31,4 @@ int render_accel_for_tree(const mnv_accel *accel, const mnv_tree_view *tree, con
                           const mnv_frame_inputs *inputs, float *rgba_out, uint8_t *rgba8_out, float *split_track, float *sample_track,
                           hipStream_t stream);
 
-// event-based timing of the render launches (mnv_set_timing / mnv_take_timing)
-struct LaunchTimer {
-    explicit LaunchTimer(hipStream_t s);
-    ~LaunchTimer();
-    hipStream_t stream;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    bool active = false;
-};
-
 }  // namespace mnv

@@ -25,10 +25,14 @@ enum Knob {
     KNOB_ASSEMBLE_NARROW,  // one RGBA8 pixel per thread in mnv_assemble_tiles
     KNOB_REFRESH_DEBUG,    // mnv_accel_refresh prints what it patched
     KNOB_SYNTH_TIMING,     // the synthetic-tree generators print their phases
+    KNOB_FOOTPRINT,        // string: file for the unique 128-byte lines the accel's launches touched, per array (written when the accel is destroyed)
     KNOB_SHADOW,           // allocate the copies the -DMNV_SHADOW_MASK variants of the march read (16 nodes, 32 rows, 64 bricks)
     KNOB_COUNT
 };
 
+// rays from which a mnv_render_voxels launch derives its level-7 lookup table first (mnv_march_ref_layout.hip): 65536.  The test-hook build
+// exports mnv_hook_set_ref_table_min_rays(int64) so that the tests can run either path at any size (negative: never).
+long long ref_table_min_rays();
 // value of MNV_<NAME> as an integer (test-hook build) or `dflt` (shipped build, or the variable is not set)
 int knob_int(Knob k, int dflt);
 // whether MNV_<NAME> is set at all (test-hook build); false in the shipped build

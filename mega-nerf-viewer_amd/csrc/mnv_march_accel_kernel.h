@@ -197,6 +197,15 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
         if (K.timeline && lane == 0) K.timeline[(size_t)K.timeline_tiles * 4 + (size_t)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) * 2] = wall_clock64();
     }
 
+    // MODE 1 + MNV_FOOTPRINT: the 128-byte line a load touches, by array (region) and byte offset into it
+    auto touch = [&](int region, uint64_t byte_off) {
+        if constexpr (MODE == 1) {
+            if (K.line_bits) {
+                const uint32_t line = K.line_base[region] + (uint32_t)(byte_off >> 7);
+                atomicOr(&K.line_bits[line >> 5], 1u << (line & 31u));
+            }
+        }
+    };
     auto stat = [&](int slot, bool pred) {
         if constexpr (MODE == 1) {
             if (!K.count_stats) return;
@@ -400,6 +409,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                         vox = (g << 2) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh2, 2u);
                         if constexpr (BRICK) word = A.grid2i[vox];
                         else word = A.grid2[vox];
+                        touch(0, (uint64_t)vox * 4);
                         src = 1;
                         sh = sh2;
                         if constexpr ((kShadow & 8) != 0) {  // shadow load: the same cell of grid2_vox (same size, same order, other addresses)
@@ -430,6 +440,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                                 s1 = (s1 << 1) | __builtin_amdgcn_ubfe(q[2], (uint32_t)(sh2 - 1), 1u);
                                 s2 = (s2 << 1) | __builtin_amdgcn_ubfe(q[2], (uint32_t)(sh2 - 2), 1u);
                                 const uint2 e = A.recs[(int64_t)word * 8 + s1];
+                                touch(1, ((uint64_t)word * 8 + s1) * 8);
                                 if constexpr ((kShadow & 64) != 0) {
                                     const uint2 e2 = K.shadow_recs[(int64_t)word * 8 + s1];
                                     asm volatile("" ::"v"(e2.x));
@@ -452,6 +463,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                         v = (v << 1) | __builtin_amdgcn_ubfe(q[1], (uint32_t)sh, 1u);
                         vox = (v << 1) | __builtin_amdgcn_ubfe(q[2], (uint32_t)sh, 1u);
                         word = A.nodes[vox];
+                        touch(2, (uint64_t)vox * 4);
                         src = 2;
                         if constexpr ((kShadow & 16) != 0) {
                             const uint32_t w2 = K.shadow_nodes[vox];
@@ -494,8 +506,14 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                 if constexpr (MODE == 2 || MODE == 3) need_vox = is_dense || cand || max_weight == -1.f || max_sample_weight == -1.f || K.visited != nullptr;
                 if (need_vox) {
                     // voxel index of a leaf that was answered by one of the lookup grids
-                    if (src == 0) vox = A.grid_vox[((((q[0] >> shg) << A.grid_level) + (q[1] >> shg)) << A.grid_level) + (q[2] >> shg)];
-                    else if (src == 1) vox = A.grid2_vox[vox];
+                    if (src == 0) {
+                        const uint32_t gc = ((((q[0] >> shg) << A.grid_level) + (q[1] >> shg)) << A.grid_level) + (q[2] >> shg);
+                        vox = A.grid_vox[gc];
+                        touch(5, (uint64_t)gc * 4);
+                    } else if (src == 1) {
+                        touch(4, (uint64_t)vox * 4);
+                        vox = A.grid2_vox[vox];
+                    }
                 }
                 if constexpr (MODE == 2 || MODE == 3) {
                     // the mark only ever goes 0 -> 1: load + conditional plain store (mnv_march_ref_layout.hip does the same per level)
@@ -571,6 +589,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
             };
             [[maybe_unused]] auto settle_from_memory = [&]() {  // frames that read no colour row: the sigma half alone
                 if constexpr (BRICK) {
+                    if (dense && cand) touch(3, (uint64_t)vox * A.row_bytes + A.sigma_off);
                     if (dense) settle(cand ? (uint32_t)*reinterpret_cast<const uint16_t *>(A.rows + (int64_t)vox * A.row_bytes + A.sigma_off) : 0u);
                 }
             };
@@ -644,6 +663,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                     uint32_t vx = vox;
                     if (ablate(4)) vx &= 0xffffu;  // diagnostics: rows served from cache (wrong colours)
                     const uint8_t *row = A.rows + (int64_t)vx * ROW_BYTES;
+                    touch(3, (uint64_t)vx * ROW_BYTES);
                     if constexpr ((kShadow & 32) != 0) {  // shadow load: one dword of the same row of the copy (one more line fill)
                         const uint32_t w2 = *reinterpret_cast<const uint32_t *>(K.shadow_rows + (int64_t)vx * ROW_BYTES);
                         asm volatile("" ::"v"(w2));

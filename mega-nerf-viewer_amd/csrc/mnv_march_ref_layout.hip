@@ -23,6 +23,7 @@
 
 #include "mnv_device.h"
 #include "mnv_internal.h"
+#include "mnv_knobs.h"
 
 #pragma clang fp contract(off)
 
@@ -30,7 +31,6 @@ namespace mnv {
 
 constexpr uint32_t kTopLeaf = 0x80000000u;  // table word x: leaf at depth (x >> 28) & 7, voxel index in the low 28 bits; y: the leaf's sigma (f16 bits)
 constexpr uint32_t kNoSigma = 0xffffffffu;  // y of a table word whose sigma was not fetched
-std::atomic<int64_t> g_top_min_rays{1 << 16};  // launches below this derive the level-3 table per workgroup and skip the global one
 
 // Dense level-G table for one launch.  Workgroup b owns the level-(G-3) cell b = (x << 2L | y << L | z) and writes the 512 level-G
 // cells below it to table[b * 512 + (lx << 6 | ly << 3 | lz)]; the first workgroup under every level-3 cell also writes top3.
@@ -316,7 +316,7 @@ int launch_ref_layout(const MarchParams &P, hipStream_t stream) {
     dim3 grid((P.tw + kRefBlockW - 1) / kRefBlockW, (P.th + kRefBlockH - 1) / kRefBlockH), block(kRefThreads);
     int b = P.format == 1 ? P.basis_dim : -1;
     if (P.format == 1 && b < 0) b = -1;  // SH without digits behaves like the RGBA branch (:285)
-    const int64_t min_rays = g_top_min_rays.load(std::memory_order_relaxed);
+    const int64_t min_rays = ref_table_min_rays();  // 65536; the test-hook build can move it (mnv_knobs.h)
     const bool gen = P.N != 2;
     const bool big = !gen && min_rays >= 0 && (int64_t)P.tw * P.th >= min_rays;
     uint2 *scratch = nullptr;
@@ -354,4 +354,3 @@ int launch_ref_layout(const MarchParams &P, hipStream_t stream) {
 
 }  // namespace mnv
 
-extern "C" void mnv_set_ref_table_min_rays(int64_t min_rays) { mnv::g_top_min_rays.store(min_rays, std::memory_order_relaxed); }

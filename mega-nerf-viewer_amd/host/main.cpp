@@ -545,7 +545,6 @@ int main(int argc, char **argv) {
         const std::string out = args.get("out", "");
         std::vector<float> rgba;
         std::vector<uint8_t> rgba8;
-        mnv_set_timing(1);
         rend.frames_in_flight = (int)std::max<long>(1, args.l("in_flight", rend.frames_in_flight));
         rend.guided_in_flight = args.has("guided_in_flight");
         std::deque<std::pair<long, int>> pending;  // (frame, slot) rendered but not yet written
@@ -578,9 +577,8 @@ int main(int argc, char **argv) {
             rend.sync_tree();
             tree.save_npz(args.get("save_tree", ""));
         }
-        const double ms = rend.take_average_ms();
-        std::printf("%s: %ld frame(s) %dx%d, %.3f ms per launch on the device, %.3f ms/frame wall (%d in flight%s), %.1f Mrays/s\n", rend.get_backend(), frames,
-                    width, height, ms, wall_ms / frames, refine && !rend.overlaps_next() ? 1 : rend.frames_in_flight, out.empty() ? "" : ", incl. download + file output",
+        std::printf("%s: %ld frame(s) %dx%d, %.3f ms/frame wall (%d in flight%s), %.1f Mrays/s\n", rend.get_backend(), frames,
+                    width, height, wall_ms / frames, refine && !rend.overlaps_next() ? 1 : rend.frames_in_flight, out.empty() ? "" : ", incl. download + file output",
                     wall_ms > 0 ? (double)width * height * frames / wall_ms / 1e3 : 0.0);
         return 0;
     } catch (const std::exception &e) {

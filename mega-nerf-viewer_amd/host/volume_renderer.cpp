@@ -775,11 +775,4 @@ void VolumeRenderer::sync_tree() {
 const float *VolumeRenderer::device_rgba() const { return impl_->rgba; }
 const uint8_t *VolumeRenderer::device_rgba8() const { return impl_->rgba8; }
 
-double VolumeRenderer::take_average_ms() {
-    double ms = 0.0;
-    int32_t n = 0;
-    if (mnv_take_timing(&ms, &n) != MNV_OK || n == 0) return 0.0;
-    return ms / n;
-}
-
 }  // namespace viewer

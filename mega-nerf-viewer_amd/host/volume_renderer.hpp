@@ -65,7 +65,6 @@ struct VolumeRenderer {
     const float *device_rgba() const;
     const uint8_t *device_rgba8() const;
     // Average device time per render() since the last call, in ms (HIP events).
-    double take_average_ms();
 
     // Role of load_model (cuda_renderer.cpp:518-539): read a model container.  Here an .npz with
     //   mlp_desc int32[9] (n_clusters, pos_octaves, dir_octaves, need_viewdir, n_embeddings, embedding_dim,

@@ -41,18 +41,24 @@ def test_kernel_source_sha_is_stable_and_matches_the_binding():
 
 
 def test_roofline_fractions_keep_one_meaning_each():
-    """bench.py: `frac` is always achieved / peak with the ALGORITHMIC bytes of SURVEY 8(d) (the task's contract; a yardstick that may
-    exceed 1 -- cfg4: neighbouring 4K rays share lines, the model counts every ray's loads -- and says so as `algorithmic_over_peak`);
-    `frac_real_hbm` is always the counter traffic's fraction, or null without a committed pass.  Neither switches meaning with its value."""
+    """bench.py: `algorithmic_over_peak` is always achieved / peak with the ALGORITHMIC bytes of SURVEY 8(d) (a yardstick against the
+    reference's algorithm that may exceed 1 -- cfg4: neighbouring 4K rays share lines, the model counts every ray's loads); `frac` repeats it
+    where it is a fraction (<= 1) and is null where it is not, so that nothing called a fraction of the roofline exceeds 1; `frac_footprint`
+    (unique lines a launch touches + its output, / time / peak) is the bound; `frac_l2_fabric` is the counter traffic's fraction, or null
+    without a committed pass.  None switches meaning with its value."""
     sys.path.insert(0, ROOT)
     import bench
 
     f = bench.roofline_fractions(7200.0, 78.3e9, 15.9)          # algorithmic below the peak
-    assert f["frac"] == f["algorithmic_over_peak"] == 0.9 and 0.6 < f["frac_real_hbm"] < 0.63
+    assert f["frac"] == f["algorithmic_over_peak"] == 0.9 and 0.6 < f["frac_l2_fabric"] < 0.63 and f["frac_footprint"] is None
     f = bench.roofline_fractions(9365.0, 70.3e9, 22.19)         # cfg4_n1: algorithmic above the peak
-    assert f["frac"] == f["algorithmic_over_peak"] > 1.0 and 0.39 < f["frac_real_hbm"] < 0.41
-    f = bench.roofline_fractions(9365.0, None, 22.19)           # ... and no counters: the real fraction is null, frac is not
-    assert f["frac"] == f["algorithmic_over_peak"] > 1.0 and f["frac_real_hbm"] is None
+    assert f["frac"] is None and f["algorithmic_over_peak"] > 1.0 and 0.39 < f["frac_l2_fabric"] < 0.41
+    f = bench.roofline_fractions(9365.0, None, 22.19)           # ... and no counters
+    assert f["frac"] is None and f["algorithmic_over_peak"] > 1.0 and f["frac_l2_fabric"] is None
+    fp = {"grid2_lines": 100_000_000, "rows_lines": 150_000_000, "footprint_bytes": 250_000_000 * 128 + 2_000_000_000}
+    f = bench.roofline_fractions(9365.0, 70.3e9, 22.19, fp)
+    assert f["footprint_bytes"] == fp["footprint_bytes"] and 0.18 < f["frac_footprint"] < 0.20 and f["footprint_lines_by_array"] == {"grid2": 100_000_000, "rows": 150_000_000}
+    assert all(v is None or v <= 1.0 for k, v in f.items() if k.startswith("frac"))
 
 
 def test_committed_counters_cover_all_poses_of_every_bench_workload():

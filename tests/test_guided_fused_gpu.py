@@ -14,7 +14,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True, params=[2, 1], ids=["producer_consumer", "one_role"])
 def fused_kernel(request, mnv, torch_gpu):
-    """Every test of this module runs with each of the two kernels behind mnv_render_guided_fused* (mnv_set_fused_kernel): wavefronts
+    """Every test of this module runs with each of the two kernels behind mnv_render_guided_fused* (mnv_accel_set_fused_kernel, handed to every
+    accel the tests launch on by the binding's harness default, mnv.set_fused_kernel): wavefronts
     specialised into march producers and a network consumer (csrc/mnv_guided_fused2.h), and every wavefront in both roles
     (csrc/mnv_guided_fused.h).  The diagnostics buffer is on so that a spin-wait abandoned by the watchdog fails the test."""
     diag = torch_gpu.zeros(32, dtype=torch_gpu.int64, device="cuda")
@@ -86,7 +87,7 @@ def test_fused_frame_equals_the_four_step_path(mnv, torch_gpu, case, need_viewdi
     assert int(counter.item()) == total
     assert np.array_equal(cases.bits(got), cases.bits(ref)), float(np.nanmax(np.abs(got - ref)))
     assert np.array_equal(out8.cpu().numpy(), ref8)
-    # the OTHER kernel for this accel alone (mnv_accel_set_fused_kernel overrides the process-wide choice of the fixture): the same frame
+    # the OTHER kernel for this accel alone (pinned: mnv.accel_set_fused_kernel overrides the harness default of the fixture): the same frame
     mnv.accel_set_fused_kernel(tree.accel, 1 if fused_kernel_choice(mnv) == 2 else 2)
     out.fill_(float("nan"))
     mnv.render_guided_fused(tree.accel, cam, opt, mlp, grid, rgba=out)

@@ -44,14 +44,13 @@ def test_onscreen_inputs_bit_exact_vs_oracle(mnv, orc, torch_gpu, name, which):
     if which == "accel":
         mnv.render_voxels_accel(tree.accel, cam, opt, rgba=rgba, rgba8=rgba8, tmax_px=t_dev, rgba8_init=i_dev)
     else:
-        mnv.set_ref_table_min_rays({"ref_layout": 1 << 16, "ref_layout_table": 0, "ref_layout_walk": -1, "tree_cache": 1 << 16}[which])
         if which == "tree_cache":
             mnv.set_tree_cache(True)
         try:
-            mnv.render_voxels(tree.device_view(), cam, opt, rgba=rgba, rgba8=rgba8, tmax_px=t_dev, rgba8_init=i_dev)
+            mnv.render_voxels(tree.device_view(), cam, opt, rgba=rgba, rgba8=rgba8, tmax_px=t_dev, rgba8_init=i_dev,
+                              table_min_rays={"ref_layout": None, "ref_layout_table": 0, "ref_layout_walk": -1, "tree_cache": None}[which])
             torch.cuda.synchronize()
         finally:
-            mnv.set_ref_table_min_rays(1 << 16)
             mnv.set_tree_cache(False)
     torch.cuda.synchronize()
     got, got8 = rgba.cpu().numpy(), rgba8.cpu().numpy()

@@ -38,11 +38,9 @@ def _render_gpu(mnv, torch, tree, cam, opt, which, tile=None, want_u8=False):
     if which.startswith("ref_layout"):
         # reference-layout kernel: "_table" forces the per-launch level-7 lookup table at every size, "_walk" forbids it
         # (per-workgroup level-3 table only); plain = the default switch-over at 65536 rays
-        mnv.set_ref_table_min_rays({"ref_layout": 1 << 16, "ref_layout_table": 0, "ref_layout_walk": -1}[which])
-        try:
-            mnv.render_voxels(tree.device_view(), cam, opt, tile=tile, rgba=rgba, rgba8=rgba8)
-        finally:
-            mnv.set_ref_table_min_rays(1 << 16)
+        # (the forced forms run the same object code through the test-hook build's library: the shipped one has no such switch)
+        mnv.render_voxels(tree.device_view(), cam, opt, tile=tile, rgba=rgba, rgba8=rgba8,
+                          table_min_rays={"ref_layout": None, "ref_layout_table": 0, "ref_layout_walk": -1}[which])
     else:
         mnv.render_voxels_accel(tree.accel, cam, opt, tile=tile, rgba=rgba, rgba8=rgba8)
     torch.cuda.synchronize()
@@ -89,11 +87,7 @@ def test_trackers_with_the_per_launch_table(mnv, orc, torch_gpu, name):
         rgba = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
         split = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")
         sample = torch.full((h, w, 3), -1.0, dtype=torch.float32, device="cuda")
-        mnv.set_ref_table_min_rays(min_rays)
-        try:
-            mnv.render_voxels(dv, cam, opt, rgba=rgba, split_track=split, sample_track=sample)
-        finally:
-            mnv.set_ref_table_min_rays(1 << 16)
+        mnv.render_voxels(dv, cam, opt, rgba=rgba, split_track=split, sample_track=sample, table_min_rays=min_rays)
         torch.cuda.synchronize()
         assert np.array_equal(cases.bits(rgba.cpu().numpy()), cases.bits(ref["rgba"]))
         assert np.array_equal(split.cpu().numpy().reshape(-1, 3), ref["split"].reshape(-1, 3))
@@ -635,7 +629,7 @@ def test_trackers_match_reference_device_code_goldens(mnv, torch_gpu, name):
 
 @pytest.mark.parametrize("name", ["sh4_d6", "sh9_d7_aniso", "shell_d7_sh9", "sh25_d4", "thresholds", "rgba_d5"])
 def test_fast_colour_math_keeps_alpha_and_control_flow_exact(mnv, orc, torch_gpu, name):
-    """mnv_set_colour_math(1): hardware exp2 / rcp in the colour sigmoid only.  Alpha (hence every opacity, transmittance and
+    """mnv_accel_set_colour_math(accel, 1): hardware exp2 / rcp in the colour sigmoid only.  Alpha (hence every opacity, transmittance and
     early-stop decision) stays bit-identical to the oracle; colours stay within 2e-6 (contract: 1e-4)."""
     torch = torch_gpu
     spec = cases.CASES[name]
@@ -645,12 +639,10 @@ def test_fast_colour_math_keeps_alpha_and_control_flow_exact(mnv, orc, torch_gpu
     ref = orc.render(orc.tree_from_view(tree.host_view()), cam.c, opt)["rgba"]
     tree.move_to_device()
     out = torch.empty((cam.height, cam.width, 4), dtype=torch.float32, device="cuda")
-    mnv.set_colour_math(True)
-    try:
-        mnv.render_voxels_accel(tree.accel, cam, opt, rgba=out)
-        torch.cuda.synchronize()
-    finally:
-        mnv.set_colour_math(False)
+    mnv.accel_set_colour_math(tree.accel, 1)
+    mnv.render_voxels_accel(tree.accel, cam, opt, rgba=out)
+    torch.cuda.synchronize()
+    mnv.accel_set_colour_math(tree.accel, 0)
     got = out.cpu().numpy()
     assert np.array_equal(cases.bits(got[..., 3]), cases.bits(ref[..., 3]))
     assert np.abs(got[..., :3] - ref[..., :3]).max() <= 2e-6
@@ -664,9 +656,9 @@ def test_fast_colour_math_keeps_alpha_and_control_flow_exact(mnv, orc, torch_gpu
 
 
 def test_two_accels_of_one_process_can_differ_in_colour_math(mnv, orc, torch_gpu):
-    """mnv_accel_set_colour_math: the process-wide switch is only the default -- one accel renders with the hardware exp2 / rcp colour
-    sigmoid (alpha bit-identical, colours within 2e-6) while another accel of the same process stays exact, and -1 hands an accel back to
-    the process-wide switch."""
+    """mnv_accel_set_colour_math: the choice belongs to the accel (there is no process-wide switch) -- one accel renders with the hardware
+    exp2 / rcp colour sigmoid (alpha bit-identical, colours within 2e-6) while another accel of the same process stays exact, and 0 makes the
+    first exact again."""
     torch = torch_gpu
     spec = cases.CASES["shell_d7_sh9"]
     cam, opt = cases.make_camera(mnv, spec["camera"]), cases.make_options(mnv, spec["options"])
@@ -677,26 +669,19 @@ def test_two_accels_of_one_process_can_differ_in_colour_math(mnv, orc, torch_gpu
     out_a = torch.empty((cam.height, cam.width, 4), dtype=torch.float32, device="cuda")
     out_b = torch.empty_like(out_a)
     mnv.accel_set_colour_math(ta.accel, 1)
-    try:
-        mnv.render_voxels_accel(ta.accel, cam, opt, rgba=out_a)
-        mnv.render_voxels_accel(tb.accel, cam, opt, rgba=out_b)
-        torch.cuda.synchronize()
-        a, b = out_a.cpu().numpy(), out_b.cpu().numpy()
-        assert np.array_equal(cases.bits(b), cases.bits(ref))
-        assert np.array_equal(cases.bits(a[..., 3]), cases.bits(ref[..., 3])) and not np.array_equal(cases.bits(a), cases.bits(ref))
-        assert np.abs(a - ref).max() < 2e-6
-        mnv.accel_set_colour_math(ta.accel, -1)   # follow the process-wide switch (exact) again
-        mnv.render_voxels_accel(ta.accel, cam, opt, rgba=out_a)
-        torch.cuda.synchronize()
-        assert np.array_equal(cases.bits(out_a.cpu().numpy()), cases.bits(ref))
-        mnv.set_colour_math(True)                  # process-wide fast, this accel pinned to exact
-        mnv.accel_set_colour_math(tb.accel, 0)
-        mnv.render_voxels_accel(tb.accel, cam, opt, rgba=out_b)
-        mnv.render_voxels_accel(ta.accel, cam, opt, rgba=out_a)
-        torch.cuda.synchronize()
-        assert np.array_equal(cases.bits(out_b.cpu().numpy()), cases.bits(ref)) and not np.array_equal(cases.bits(out_a.cpu().numpy()), cases.bits(ref))
-    finally:
-        mnv.set_colour_math(False)
+    mnv.render_voxels_accel(ta.accel, cam, opt, rgba=out_a)
+    mnv.render_voxels_accel(tb.accel, cam, opt, rgba=out_b)
+    torch.cuda.synchronize()
+    a, b = out_a.cpu().numpy(), out_b.cpu().numpy()
+    assert np.array_equal(cases.bits(b), cases.bits(ref))
+    assert np.array_equal(cases.bits(a[..., 3]), cases.bits(ref[..., 3])) and not np.array_equal(cases.bits(a), cases.bits(ref))
+    assert np.abs(a - ref).max() < 2e-6
+    mnv.accel_set_colour_math(ta.accel, 0)    # exact again
+    mnv.accel_set_colour_math(tb.accel, 1)    # ... and the other one fast
+    mnv.render_voxels_accel(ta.accel, cam, opt, rgba=out_a)
+    mnv.render_voxels_accel(tb.accel, cam, opt, rgba=out_b)
+    torch.cuda.synchronize()
+    assert np.array_equal(cases.bits(out_a.cpu().numpy()), cases.bits(ref)) and not np.array_equal(cases.bits(out_b.cpu().numpy()), cases.bits(ref))
 
 
 @pytest.mark.parametrize("name", ["sh4_d6", "sh9_d7_aniso", "rgba_d5", "terrain_d7_aniso"])

@@ -96,11 +96,7 @@ def test_random_scene_bit_exact(mnv, orc, torch_gpu, seed):
     # the walking kernel on the reference's arrays: with the per-launch table and without
     for min_rays in (0, -1):
         rgba, rgba8 = fresh()
-        mnv.set_ref_table_min_rays(min_rays)
-        try:
-            mnv.render_voxels(tree.device_view(), cam, opt, rgba=rgba, rgba8=rgba8)
-        finally:
-            mnv.set_ref_table_min_rays(1 << 16)
+        mnv.render_voxels(tree.device_view(), cam, opt, rgba=rgba, rgba8=rgba8, table_min_rays=min_rays)
         torch.cuda.synchronize()
         same_frame(rgba, rgba8, f"march_ref_layout_kernel (table min rays {min_rays})")
     # the tuned kernel on the packed layout

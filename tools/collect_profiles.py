@@ -38,4 +38,4 @@ d = json.load(open(os.path.join(G, R + "_bench_n1.json")))
 json.dump(d, open(os.path.join(P, R + "_bench_n1.json"), "w"))
 print("value", d["value"], "frac", d["roofline"]["frac"], "traffic", d["roofline"]["traffic"], "per_frame", d["per_frame"]["value"])
 for k in ("cfg3", "cfg4_n1", "fog"):
-    print(k, d[k]["value"], {x: d[k]["roofline"][x] for x in ("frac", "algorithmic_over_peak", "frac_real_hbm", "traffic")})
+    print(k, d[k]["value"], {x: d[k]["roofline"][x] for x in ("frac", "algorithmic_over_peak", "frac_l2_fabric", "traffic")})
