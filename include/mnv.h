@@ -20,6 +20,29 @@
  *
  * All pointers named "device" must be HIP device pointers on the current
  * device.  No torch types cross this boundary.
+ *
+ * HOW THIS HEADER IS ORGANISED.  The DROP-IN CORE is the 30 entry points below, one per function / method of the reference's interface for
+ * this path -- a maintainer who replaces src/cuda + the loaders binds exactly these (include/mnv_reference_binding.hpp does, inside a build of
+ * the reference).  Everything else in this file is an EXTENSION the reference has no counterpart for, grouped by purpose further down: the
+ * packed layout ("accel": mnv_accel_*, mnv_render_voxels_accel*, mnv_render_guided_fused*), multi-GPU (mnv_partition*, mnv_comm_*,
+ * mnv_gather_tiles, mnv_assemble_tiles, ...), the device-side forms of the host logic between frames (mnv_select_*, mnv_apply_*,
+ * mnv_prune_tree*, mnv_query_submodules, mnv_mlp_*), synthetic trees (mnv_synth_*).  No call's result depends on process-wide state, with
+ * one opt-in exception that is documented where it is declared (mnv_set_tree_cache).
+ *
+ *   reference                                                   drop-in core (tests/test_capi_symbols.py: CORE)
+ *   include/cuda/renderer_kernel.hpp:23-34  render_voxels        mnv_render_voxels, mnv_render_voxels_ex (offscreen == false)
+ *   :36-52  get_samples_from_voxels                              mnv_get_samples_from_voxels, mnv_get_samples_from_voxels_ex
+ *   :12-21  render_nerf_results                                  mnv_render_nerf_results
+ *   :54-63  add_children_and_generate_samples                    mnv_add_children_and_generate_samples
+ *   :65-73  generate_samples                                     mnv_generate_samples
+ *   :75-79  adjust_parents_and_children                          mnv_adjust_parents_and_children
+ *   include/renderer/renderer.hpp:9-39  VolumeRenderer           mnv_renderer_create, _destroy, _set, _load_model, _resize, _options,
+ *                                                                _set_camera, _render, _download
+ *   include/n3tree/n3tree.hpp:17-69  N3Tree                      mnv_n3tree_open, _free, _move_to_device, _host_view, _device_view
+ *   include/data_format.hpp:7-22  DataFormat                     mnv_data_format_parse, mnv_data_format_to_string
+ *   include/camera.hpp:12-87  Camera                             mnv_camera_init, mnv_camera_set_pose, mnv_camera_drag
+ *   include/render_options.hpp:9-56, src/opts.cpp:17-32          mnv_default_render_options, mnv_cli_render_options
+ *   src/cuda/common.cu:8-20  cuda_assert (exit)                  status codes + mnv_last_error
  */
 #ifndef MNV_H
 #define MNV_H

@@ -24,6 +24,33 @@ def test_library_exports_every_declared_symbol(mnv):
     assert set(names) == set(mnv._SIGNATURES), set(names) ^ set(mnv._SIGNATURES)
 
 
+# the drop-in core of include/mnv.h: one entry point per function / method of the reference's interface for this path
+CORE = """mnv_render_voxels mnv_render_voxels_ex mnv_get_samples_from_voxels mnv_get_samples_from_voxels_ex mnv_render_nerf_results
+mnv_add_children_and_generate_samples mnv_generate_samples mnv_adjust_parents_and_children
+mnv_renderer_create mnv_renderer_destroy mnv_renderer_set mnv_renderer_load_model mnv_renderer_resize mnv_renderer_options mnv_renderer_set_camera
+mnv_renderer_render mnv_renderer_download
+mnv_n3tree_open mnv_n3tree_free mnv_n3tree_move_to_device mnv_n3tree_host_view mnv_n3tree_device_view
+mnv_data_format_parse mnv_data_format_to_string mnv_camera_init mnv_camera_set_pose mnv_camera_drag
+mnv_default_render_options mnv_cli_render_options mnv_last_error""".split()
+
+
+def test_the_drop_in_core_is_thirty_symbols_and_no_call_depends_on_process_wide_switches(mnv):
+    """The header's map (reference function -> core entry point) names 30 symbols, all exported; the only process-wide setter left in the ABI
+    is the opt-in tree cache (colour math, fused kernel, diagnostics are per accel; launch timing is the caller's; the lookup-table threshold
+    of mnv_render_voxels exists in the test-hook build alone)."""
+    names = header_functions()
+    assert len(CORE) == 30 and all(n in names for n in CORE)
+    header = open(os.path.join(ROOT, "include", "mnv.h")).read()
+    for n in CORE:
+        assert n in header or n.replace("mnv_renderer", "") in header   # (the map abbreviates the renderer's methods)
+    setters = [n for n in names if re.match(r"mnv_set_", n)]
+    assert setters == ["mnv_set_tree_cache"], setters
+    out = subprocess.run(["nm", "-D", "--defined-only", mnv.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "mnv_hook_" not in out
+    hooks = subprocess.run(["nm", "-D", "--defined-only", os.path.join(os.path.dirname(mnv.LIB_PATH), "testhooks", "libmnv.so")], capture_output=True, text=True).stdout
+    assert "mnv_hook_set_ref_table_min_rays" in hooks or os.environ.get("MNV_LIB_PATH")
+
+
 def test_no_torch_or_oracle_in_the_abi(mnv):
     out = subprocess.run(["ldd", mnv.LIB_PATH], capture_output=True, text=True).stdout
     assert "torch" not in out and "oracle" not in out and "libamdhip64" in out

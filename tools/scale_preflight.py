@@ -25,6 +25,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+NEXT_STEPS = """
+next: the scaling curve, one command per point (each prints ONE JSON line; `value` = Mrays/s of the whole job, `per_rank` and `predicted` say where the time went):
+    for n in 1 2 4 {n}; do python bench.py --gpus $n --steps 10 --warmup 2 --no-extras > scale_n$n.json; done
+the three assumptions behind `predicted` (one-GPU emulation of rank 0, profiles/r*_root_emulation.jsonl) and the number in the line that tests each:
+    (1) RCCL's receive costs rank 0 no more than a device copy of the same bytes
+            broken if  per_rank[0].gather_ms + per_rank[0].unpermute_ms > 1.0 ms per 64-frame step at N = 8   (emulation: 0.35 ms; `gather 4.1 MB` above: >= 100 GB/s into the root)
+    (2) the CU-masked march stream keeps 32 units free in EVERY process
+            broken if  per_rank[r].cu_mask_in_effect is false, or per_rank[r].march_ms > 1.15 x predicted.other_ranks_march_ms   (`masked stream` above)
+    (3) the peers' sends arrive while rank 0 marches (point-to-point xGMI links are not the bound)
+            broken if  per_rank[r > 0].gather_ms > 2 x per_rank[0].gather_ms   (a send that waits for rank 0's receive)
+    a step above 1.25 x predicted.ms_per_step with none of the three broken: rank 0's own march (per_rank[0].march_ms against predicted.rank0_march_only_ms) -- raise --root-period
+if the first rung fails, bench.py --gpus N walks its ladder by itself (no CU reservation -> float tiles -> torch.distributed's gather) and names every failed rung in `launch`."""
+
+
 def worker(rank, world, port, out_path):
     import torch
     import torch.distributed as dist
@@ -172,6 +186,7 @@ def main():
             good = all(it["ok"] for _, it in its)
             detail = "; ".join(f"rank {r}: " + ", ".join(f"{k}={v}" for k, v in it.items() if k not in ("name", "ok") and v is not None) for r, it in its[:8])
             print(f"  [{'PASS' if good else 'FAIL'}] {name:16s} {detail}")
+        print(NEXT_STEPS.format(n=n))
     return 0 if ok else 1
 
 
