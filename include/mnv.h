@@ -219,12 +219,17 @@ void mnv_accel_destroy(mnv_accel *accel);
 size_t mnv_accel_device_bytes(const mnv_accel *accel);
 /* level of the brick-ordered second lookup grid (0: none): what a report names beside the bytes above */
 int32_t mnv_accel_grid2_level(const mnv_accel *accel);
-/* levels below that grid which plain frames currently resolve WITHOUT node words: 1 = the last level is folded into the grid's cell words
- * (a depth-10 tree under a level-9 grid reads no node word at all), 2 = the next two levels also come from 64-byte brick records (trees with
- * leaves two or more levels below the grid), 0 = neither -- 0 after mnv_accel_refresh / a prune (derived data that tree edits do not patch)
- * until mnv_accel_rebuild, or until 16 plain frames in a row have been launched without another edit: the sixteenth derives them again on
- * its stream (about 0.3 ms for a level-9 grid).  Frames are bit-identical either way. */
+/* levels below that grid which every frame kind resolves WITHOUT walking node words: 1 = the last level is folded into the grid's cell words
+ * (a depth-10 tree under a level-9 grid reads no node word at all in plain frames), 2 = the next two levels also come from 64-byte brick
+ * records (trees with leaves two or more levels below the grid), 0 = neither (shallow trees).  mnv_accel_refresh patches both with the tree edit,
+ * a prune derives them again: the value does not drop between frames of the refinement loop.  Frames are bit-identical either way. */
 int32_t mnv_accel_brick_levels(const mnv_accel *accel);
+/* How much of the tree those words cover -- a gauge for the one limit they have: an inline cell word names its chunk in 22 bits, relative to
+ * the smallest chunk number of that depth (4.19 M numbers from there on); a chunk outside that span is not inline (records / node words
+ * answer, bit-identical, one more dependent load).  out4: [0] non-leaf cells of the second grid (= chunks one level below it), [1] of them
+ * inline, [2] of them NOT inline although all eight children are leaves (lost to the chunk field; 0 on every tree of the test suite up to
+ * 12.7 M chunks), [3] chunks with a brick record.  Waits for the device. */
+int mnv_accel_lookup_coverage(const mnv_accel *accel, int64_t out4[4]);
 /* Compute units the tuned kernel may fill with its persistent workgroups (8 per unit).  Default (and num_cus <= 0): every unit
  * of the device.  A caller that launches on a stream created with hipExtStreamCreateWithCUMask -- to leave units free for
  * the RCCL kernels of the tile gather, which cannot become resident next to a full set of persistent workgroups -- passes

@@ -209,6 +209,7 @@ _SIGNATURES = {
     "mnv_accel_device_bytes": (C.c_size_t, [C.c_void_p]),
     "mnv_accel_grid2_level": (C.c_int32, [C.c_void_p]),
     "mnv_accel_brick_levels": (C.c_int32, [C.c_void_p]),
+    "mnv_accel_lookup_coverage": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "mnv_accel_set_cu_budget": (C.c_int, [C.c_void_p, C.c_int32]),
     "mnv_stream_create_reserved": (C.c_int, [C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
     "mnv_stream_destroy": (C.c_int, [C.c_void_p]),
@@ -1170,10 +1171,16 @@ def render_voxels_accel_batch(accel: int, cams, opt: RenderOptions, tile=None, p
                                                    C.c_void_p(stream)))
 
 
-def accel_info(accel: int) -> dict:
-    """Device bytes of the packed layout and the level of its second lookup grid."""
-    return {"device_bytes": int(lib().mnv_accel_device_bytes(accel)), "grid2_level": int(lib().mnv_accel_grid2_level(accel)),
-            "brick_levels": int(lib().mnv_accel_brick_levels(C.c_void_p(accel)))}
+def accel_info(accel: int, coverage: bool = False) -> dict:
+    """Device bytes of the packed layout, the level of its second lookup grid, the levels below it answered by inline cell words / brick records;
+    coverage=True adds mnv_accel_lookup_coverage (a pass over the grid: waits for the device)."""
+    d = {"device_bytes": int(lib().mnv_accel_device_bytes(accel)), "grid2_level": int(lib().mnv_accel_grid2_level(accel)),
+         "brick_levels": int(lib().mnv_accel_brick_levels(C.c_void_p(accel)))}
+    if coverage:
+        out = (C.c_int64 * 4)()
+        _check(lib().mnv_accel_lookup_coverage(C.c_void_p(accel), out))
+        d.update(nonleaf_cells=int(out[0]), inline_cells=int(out[1]), inline_lost_to_chunk_field=int(out[2]), record_chunks=int(out[3]))
+    return d
 
 
 def accel_set_cu_budget(accel: int, num_cus: int) -> None:

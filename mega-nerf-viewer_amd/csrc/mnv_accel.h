@@ -19,7 +19,11 @@
 //   grid2i [2^L2]^3 u32      grid2 with the LAST level folded into the cell word (every frame kind reads it instead of grid2; mnv_accel_refresh
 //                            patches it with the cells it rewrites, a prune derives it again): a non-leaf cell whose chunk holds eight LEAVES
 //                            (and has a number below 2^22) reads
-//                              0 | 1 << 30 | (voxel s1 has sigma bits != 0) << (22 + s1) | chunk
+//                              0 | 1 << 30 | (voxel s1 has sigma bits != 0) << (22 + s1) | (chunk - inline_base)
+//                            inline_base = the smallest chunk number of depth L2 + 1 when the words are derived: the 22-bit field then spans the
+//                            4.19 M chunk numbers FROM there (the deepest levels carry the highest numbers; the reference budgets 20 M chunks,
+//                            src/opts.cpp:24) instead of the first 4.19 M of the tree; a chunk outside it is simply not inline (records / node
+//                            words answer; mnv_accel_lookup_coverage counts them)
 //                            so a step into an empty leaf one level below the grid costs no load beyond the grid cell, and a dense one goes
 //                            straight to its colour row (sigma is in the row).  cfg2 (depth 10, L2 = 9): every deep step; no node word is read.
 //   recs [capacity][8] {u32 child, u32 codes}   brick records (trees with leaves two or more levels below L2 only; kept current by
@@ -112,6 +116,7 @@ struct AccelView {
     const uint32_t *grid2_vox;
     int32_t grid2_level;
     const uint32_t *grid2i;     // grid2 with inline last-level words (NULL: none; frames then read grid2 and walk the node words)
+    uint32_t inline_base;       // chunk number the 22-bit chunk field of an inline word is relative to
     const uint2 *recs;          // [capacity][8] brick records of levels grid2_level + 1 and + 2 (NULL: none, the node words are walked)
     int32_t sigma_off;          // byte offset of the sigma half inside a colour row
     int32_t max_depth;          // deepest voxel depth of the tree (<= 23)

@@ -102,10 +102,44 @@ __global__ void accel_build_grid2(const uint32_t *nodes, uint32_t *grid2, uint32
 }
 
 // grid2i = grid2 with the last level folded into the words of the cells whose chunk holds eight leaves (mnv_accel.h); one thread per cell
-__global__ void accel_build_grid2i(const uint32_t *nodes, const uint32_t *grid2, uint32_t *grid2i, int64_t cells) {
+__global__ void accel_build_grid2i(const uint32_t *nodes, const uint32_t *grid2, uint32_t *grid2i, int64_t cells, uint32_t inline_base) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cells) return;
-    grid2i[i] = inline_cell_word(nodes, grid2[i]);
+    grid2i[i] = inline_cell_word(nodes, grid2[i], inline_base);
+}
+
+__global__ void accel_min_chunk_of_depth(const int32_t *depth, int32_t capacity, int32_t d, int32_t *out) {
+    const int32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < capacity && depth[c] == d) atomicMin(out, c);
+}
+
+int min_chunk_of_depth(const int32_t *depth, int32_t capacity, int32_t d, int32_t *scratch, hipStream_t stream, uint32_t *out) {
+    int rc;
+    int32_t h = capacity;
+    if ((rc = check_hip(hipMemcpyAsync(scratch, &h, 4, hipMemcpyHostToDevice, stream), "seed min chunk"))) return rc;
+    hipLaunchKernelGGL(accel_min_chunk_of_depth, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, stream, depth, capacity, d, scratch);
+    if ((rc = check_hip(hipMemcpyAsync(&h, scratch, 4, hipMemcpyDeviceToHost, stream), "read min chunk"))) return rc;
+    if ((rc = check_hip(hipStreamSynchronize(stream), "min chunk of depth"))) return rc;
+    *out = (uint32_t)h;
+    return MNV_OK;
+}
+
+// what the inline words and records cover (mnv_accel_lookup_coverage): [0] non-leaf cells of the second grid, [1] of them inline, [2] of them NOT
+// inline although their chunk holds eight leaves (its number lies outside the 22-bit field), [3] chunks of depth L2 + 1 (= brick records in use)
+__global__ void accel_count_coverage(const uint32_t *nodes, const uint32_t *grid2, const uint32_t *grid2i, int64_t cells, unsigned long long *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cells) return;
+    const uint32_t w = grid2[i];
+    if (w & kLeafBit) return;
+    // (a chunk is named by exactly one cell of level L2: [0] also counts the chunks of depth L2 + 1)
+    atomicAdd(&out[0], 1ull);
+    if (grid2i && (grid2i[i] & kInlineBit)) {
+        atomicAdd(&out[1], 1ull);
+    } else {
+        bool leaves = true;
+        for (int s = 0; s < 8; ++s) leaves = leaves && (nodes[(int64_t)w * 8 + s] & kLeafBit) != 0u;
+        if (leaves) atomicAdd(&out[2], 1ull);
+    }
 }
 
 // brick record of every chunk c of depth L2 + 1 (layout: mnv_accel.h); one thread per (chunk, voxel s1)
@@ -121,9 +155,9 @@ void launch_build_recs(const uint32_t *nodes, const int32_t *depth, uint2 *recs,
     hipLaunchKernelGGL(accel_build_recs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, nodes, depth, recs, capacity, L2);
 }
 
-void launch_build_grid2i(const uint32_t *nodes, const uint32_t *grid2, uint32_t *grid2i, int32_t L2, hipStream_t stream) {
+void launch_build_grid2i(const uint32_t *nodes, const uint32_t *grid2, uint32_t *grid2i, int32_t L2, uint32_t inline_base, hipStream_t stream) {
     const int64_t cells = (int64_t)1 << (3 * L2);
-    hipLaunchKernelGGL(accel_build_grid2i, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, nodes, grid2, grid2i, cells);
+    hipLaunchKernelGGL(accel_build_grid2i, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, stream, nodes, grid2, grid2i, cells, inline_base);
 }
 
 void launch_pack_rows(const uint16_t *data, uint16_t *rows, int64_t nvox, int32_t data_dim, int32_t per_chan, int32_t chan_halfs, int32_t row_halfs,
@@ -213,7 +247,10 @@ int accel_build(mnv_accel *a, const mnv_tree_view *t, hipStream_t stream) {
     const bool want_inline = (env_bricks & 1) && L2 > 0, want_recs = (env_bricks & 2) && want_inline && max_depth >= L2 + 2;
     if (want_inline) {
         if (!a->grid2i && (rc = check_hip(hipMalloc((void **)&a->grid2i, g2cells * 4), "hipMalloc(grid2i)"))) return fail(rc);
-        launch_build_grid2i(a->nodes, a->grid2, a->grid2i, L2, stream);
+        uint32_t base = 0;
+        if ((rc = min_chunk_of_depth(depth, t->capacity, L2 + 1, a->flags + 6, stream, &base))) return fail(rc);
+        a->view.inline_base = base;
+        launch_build_grid2i(a->nodes, a->grid2, a->grid2i, L2, base, stream);
     } else if (a->grid2i) {
         (void)hipFree(a->grid2i);
         a->grid2i = nullptr;
@@ -394,6 +431,30 @@ void mnv_accel_destroy(mnv_accel *a) {
 size_t mnv_accel_device_bytes(const mnv_accel *a) { return a ? a->bytes : 0; }
 int32_t mnv_accel_grid2_level(const mnv_accel *a) { return a ? a->view.grid2_level : -1; }
 int32_t mnv_accel_brick_levels(const mnv_accel *a) { return a ? (a->view.recs ? 2 : a->view.grid2i ? 1 : 0) : -1; }
+
+int mnv_accel_lookup_coverage(const mnv_accel *a, int64_t out4[4]) {
+    if (!a || !out4) return set_error(MNV_E_INVALID, "null argument");
+    out4[0] = out4[1] = out4[2] = out4[3] = 0;
+    if (a->view.grid2_level <= 0) return MNV_OK;
+    mnv_accel *mut = const_cast<mnv_accel *>(a);
+    std::lock_guard<std::mutex> view_lock(mut->launch_mutex);
+    unsigned long long *dev = nullptr, h[4] = {};
+    int rc;
+    if ((rc = check_hip(hipMalloc((void **)&dev, sizeof(h)), "hipMalloc(coverage)"))) return rc;
+    rc = check_hip(hipMemset(dev, 0, sizeof(h)), "memset coverage");
+    const int64_t cells = (int64_t)1 << (3 * a->view.grid2_level);
+    if (!rc) {
+        hipLaunchKernelGGL(accel_count_coverage, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, nullptr, a->nodes, a->grid2, a->view.grid2i, cells, dev);
+        rc = check_hip(hipMemcpy(h, dev, sizeof(h), hipMemcpyDeviceToHost), "read coverage");  // (the null stream: behind every launch of the device)
+    }
+    (void)hipFree(dev);
+    if (rc) return rc;
+    out4[0] = (int64_t)h[0];
+    out4[1] = (int64_t)h[1];
+    out4[2] = (int64_t)h[2];
+    out4[3] = a->view.recs ? (int64_t)h[0] : 0;
+    return MNV_OK;
+}
 
 int mnv_accel_set_cu_budget(mnv_accel *a, int32_t num_cus) {
     if (!a) return set_error(MNV_E_INVALID, "accel is null");

@@ -23,8 +23,8 @@ __host__ __device__ __forceinline__ uint32_t grid2_index(uint32_t cx, uint32_t c
 
 // grid2i word of a level-L2 cell whose grid2 word is `word` (mnv_accel.h): a non-leaf cell whose chunk holds eight leaves carries their
 // sigma != 0 mask inline
-__device__ __forceinline__ uint32_t inline_cell_word(const uint32_t *__restrict__ nodes, uint32_t word) {
-    if (!(word & kLeafBit) && word < (1u << kInlineMaskShift)) {
+__device__ __forceinline__ uint32_t inline_cell_word(const uint32_t *__restrict__ nodes, uint32_t word, uint32_t inline_base) {
+    if (!(word & kLeafBit) && word >= inline_base && word - inline_base < (1u << kInlineMaskShift)) {
         const uint4 lo = *reinterpret_cast<const uint4 *>(nodes + (int64_t)word * 8), hi = *reinterpret_cast<const uint4 *>(nodes + (int64_t)word * 8 + 4);
         const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         bool leaves = true;
@@ -34,7 +34,7 @@ __device__ __forceinline__ uint32_t inline_cell_word(const uint32_t *__restrict_
             leaves = leaves && (w[s] & kLeafBit) != 0u;
             mask |= ((w[s] & 0xffffu) != 0u ? 1u : 0u) << s;
         }
-        if (leaves) word |= kInlineBit | (mask << kInlineMaskShift);
+        if (leaves) word = (word - inline_base) | kInlineBit | (mask << kInlineMaskShift);
     }
     return word;
 }
@@ -81,7 +81,7 @@ __device__ __forceinline__ uint32_t descend_to_leaf(const AccelView &A, const ui
             s1 = (s1 << 1) | __builtin_amdgcn_ubfe(q[1], (uint32_t)(sh2 - 1), 1u);
             s1 = (s1 << 1) | __builtin_amdgcn_ubfe(q[2], (uint32_t)(sh2 - 1), 1u);
             if (word & kInlineBit) {
-                vox = ((word & ((1u << kInlineMaskShift) - 1u)) << 3) | s1;
+                vox = (((word & ((1u << kInlineMaskShift) - 1u)) + A.inline_base) << 3) | s1;
                 src = 2;
                 const bool filled = ((word >> (kInlineMaskShift + s1)) & 1u) != 0u;
                 return filled ? A.nodes[vox] : (kLeafBit | ((uint32_t)(L2 + 1) << 16));
@@ -268,7 +268,9 @@ void launch_pack_rows(const uint16_t *data, uint16_t *rows, int64_t nvox, int32_
                       hipStream_t stream);
 // brick records of the chunks of depth L2 + 1 (mnv_accel.h); one thread per chunk
 void launch_build_recs(const uint32_t *nodes, const int32_t *depth, uint2 *recs, int32_t capacity, int32_t L2, hipStream_t stream);
-void launch_build_grid2i(const uint32_t *nodes, const uint32_t *grid2, uint32_t *grid2i, int32_t L2, hipStream_t stream);
+void launch_build_grid2i(const uint32_t *nodes, const uint32_t *grid2, uint32_t *grid2i, int32_t L2, uint32_t inline_base, hipStream_t stream);
+// smallest chunk number of depth `d` (capacity if there is none); synchronises the stream
+int min_chunk_of_depth(const int32_t *depth, int32_t capacity, int32_t d, int32_t *scratch, hipStream_t stream, uint32_t *out);
 void launch_build_grid(const uint32_t *nodes, uint32_t *grid, uint32_t *grid_vox, int32_t L, hipStream_t stream);
 void launch_build_grid2(const uint32_t *nodes, uint32_t *grid2, uint32_t *grid2_vox, int32_t L2, hipStream_t stream);
 // march_accel_kernel for the row format `basis` (-1 RGBA, 1 / 4 / 9 / 16 / 25 SH) in the mode the launch block asks for

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(1024) void accel_patch_plan(int32_t n, uint32_t *pr
 // workgroup i: item i.  The voxel's integer coordinates come from the walk up the parent words.
 __global__ __launch_bounds__(256) void accel_patch_grid2(const int32_t *vox_pairs, int32_t first_chunk, int32_t n, const uint32_t *prefix, const int32_t *parent,
                                                          const int32_t *depth, const uint32_t *nodes, uint32_t *grid2, uint32_t *grid2_vox, uint32_t *grid2i,
-                                                         int32_t L2) {
+                                                         int32_t L2, uint32_t inline_base) {
     __shared__ uint32_t s_box[6];  // x, y, z at the voxel's own level; its depth; the voxel; the item's number among the voxel's items
     if (threadIdx.x == 0) {
         int32_t lo = 0, hi = n;  // the last voxel whose first item is <= this one (voxels without cells have no items and are never met)
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void accel_patch_grid2(const int32_t *vox_pair
         const uint32_t o = grid2_index(ix, iy, iz, L2);
         grid2[o] = word;
         grid2_vox[o] = vox;
-        if (grid2i) grid2i[o] = inline_cell_word(nodes, word);
+        if (grid2i) grid2i[o] = inline_cell_word(nodes, word, inline_base);
     }
 }
 
@@ -216,7 +216,7 @@ __global__ void accel_patch_recs(const int32_t *vox_pairs, int32_t first_chunk, 
 // bad[0..4]: wrong grid2 words, grid2_vox words, grid2i words, record entries, small-grid words
 __global__ void accel_verify_lookup(const uint32_t *nodes, const int32_t *depth, const uint32_t *grid, const uint32_t *grid_vox, int32_t L,
                                     const uint32_t *grid2, const uint32_t *grid2_vox, const uint32_t *grid2i, const uint2 *recs, int32_t L2,
-                                    int32_t capacity, int32_t *bad) {
+                                    int32_t capacity, uint32_t inline_base, int32_t *bad) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t cells2 = L2 > 0 ? (int64_t)1 << (3 * L2) : 0, cells1 = (int64_t)1 << (3 * L);
     auto walk = [&](uint32_t ix, uint32_t iy, uint32_t iz, int32_t levels, uint32_t &word, uint32_t &vox) {
@@ -237,7 +237,7 @@ __global__ void accel_verify_lookup(const uint32_t *nodes, const int32_t *depth,
         const uint32_t o = grid2_index(ix, iy, iz, L2);
         if (grid2[o] != word) atomicAdd(&bad[0], 1);
         if ((word & kLeafBit) && grid2_vox[o] != vox) atomicAdd(&bad[1], 1);
-        if (grid2i && grid2i[o] != inline_cell_word(nodes, word)) atomicAdd(&bad[2], 1);
+        if (grid2i && grid2i[o] != inline_cell_word(nodes, word, inline_base)) atomicAdd(&bad[2], 1);
     }
     if (i < cells1) {
         const uint32_t G = 1u << L, iz = (uint32_t)i & (G - 1), iy = ((uint32_t)i >> L) & (G - 1), ix = (uint32_t)(i >> (2 * L));
@@ -260,7 +260,7 @@ int verify_lookup(mnv_accel *a, hipStream_t stream, const char *where) {
     int64_t n = std::max<int64_t>((int64_t)1 << (3 * a->view.grid_level), (int64_t)a->view.capacity * 8);
     if (L2 > 0) n = std::max<int64_t>(n, (int64_t)1 << (3 * L2));
     hipLaunchKernelGGL(accel_verify_lookup, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a->nodes, a->depth, a->grid, a->grid_vox, a->view.grid_level,
-                       a->grid2, a->grid2_vox, a->view.grid2i, a->view.recs, L2, a->view.capacity, bad);
+                       a->grid2, a->grid2_vox, a->view.grid2i, a->view.recs, L2, a->view.capacity, a->view.inline_base, bad);
     rc = check_hip(hipMemcpyAsync(h, bad, sizeof(h), hipMemcpyDeviceToHost, stream), "verify read");
     if (!rc) rc = check_hip(hipStreamSynchronize(stream), "verify");
     (void)hipFree(bad);
@@ -378,7 +378,13 @@ int accel_apply_prune(mnv_accel *a, const int32_t *parent, const uint16_t *data,
     a->view.capacity = old_capacity - n_deleted;  // max_depth stays an upper bound (the march only needs pos * 2^max_depth < 2^24)
     // inline cell words and brick records: derived again from the renumbered node words and the patched grid, on the same stream (a pass over
     // the grid like accel_prune_grid's own; prunes are rare)
-    if (a->view.grid2i) launch_build_grid2i(a->nodes, a->grid2, a->grid2i, a->view.grid2_level, stream);
+    if (a->view.grid2i) {
+        // (the chunks were renumbered: the 22-bit chunk field is re-based on the smallest number of depth L2 + 1 there is now)
+        uint32_t base = 0;
+        if ((rc = min_chunk_of_depth(a->depth, a->view.capacity, a->view.grid2_level + 1, a->flags + 6, stream, &base))) return rc;
+        a->view.inline_base = base;
+        launch_build_grid2i(a->nodes, a->grid2, a->grid2i, a->view.grid2_level, base, stream);
+    }
     if (a->view.recs) launch_build_recs(a->nodes, a->depth, a->recs, a->view.capacity, a->view.grid2_level, stream);
     if ((rc = check_hip(hipGetLastError(), "accel prune launch"))) return rc;
     static const int dbg = knob_int(KNOB_REFRESH_DEBUG, 0);
@@ -467,13 +473,13 @@ int mnv_accel_refresh(mnv_accel *a, const mnv_tree_view *t, int32_t old_capacity
             fprintf(stderr, "[mnv refresh] n_new %d n_changed %d shallowest %d grid2_level %d patch items %d + %d\n", n_new, n_changed, h[3], a->view.grid2_level, h[4], h[5]);
         if (h[4] > 0)
             hipLaunchKernelGGL(accel_patch_grid2, dim3((unsigned)h[4]), dim3(256), 0, stream, (const int32_t *)nullptr, old_capacity, n_new, prefix_new, t->parent,
-                               a->depth, a->nodes, a->grid2, a->grid2_vox, const_cast<uint32_t *>(a->view.grid2i), a->view.grid2_level);
+                               a->depth, a->nodes, a->grid2, a->grid2_vox, const_cast<uint32_t *>(a->view.grid2i), a->view.grid2_level, a->view.inline_base);
         if (h[5] > 0)
             hipLaunchKernelGGL(accel_patch_grid2, dim3((unsigned)h[5]), dim3(256), 0, stream, changed_nodes, 0, n_changed, prefix_changed, t->parent, a->depth,
-                               a->nodes, a->grid2, a->grid2_vox, const_cast<uint32_t *>(a->view.grid2i), a->view.grid2_level);
+                               a->nodes, a->grid2, a->grid2_vox, const_cast<uint32_t *>(a->view.grid2i), a->view.grid2_level, a->view.inline_base);
         if (n_changed > 0 && !t->parent && h[3] <= L2i) {  // no parent array to walk up: the whole grid
             if (h[3] <= L2) launch_build_grid2(a->nodes, a->grid2, a->grid2_vox, a->view.grid2_level, stream);
-            if (a->view.grid2i) launch_build_grid2i(a->nodes, a->grid2, a->grid2i, a->view.grid2_level, stream);
+            if (a->view.grid2i) launch_build_grid2i(a->nodes, a->grid2, a->grid2i, a->view.grid2_level, a->view.inline_base, stream);
         }
     }
     a->view.max_depth = std::max(a->view.max_depth, h[1]);

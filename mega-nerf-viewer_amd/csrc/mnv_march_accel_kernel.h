@@ -426,7 +426,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                                 if (word & kInlineBit) {
                                     // the cell's eight children are leaves and the word says which of them are empty: no load at all for an
                                     // empty one, and a non-empty one is a candidate whose sigma arrives with its colour row
-                                    vox = ((word & ((1u << kInlineMaskShift) - 1u)) << 3) | s1;
+                                    vox = (((word & ((1u << kInlineMaskShift) - 1u)) + A.inline_base) << 3) | s1;
                                     cand = ((word >> (kInlineMaskShift + s1)) & 1u) != 0u;
                                     word = kLeafBit | ((uint32_t)(L2 + 1) << 16);
                                     src = 2;

@@ -208,6 +208,10 @@ def run_rounds(mnv, torch, depth, basis, fmt_kw, refine, seed, rounds=6, verbose
                 print(f"round {r}: +{added} chunks, {changed} rows rewritten, capacity {et.cap}, {info}", flush=True)
         fresh = mnv.accel_create(et.tv)
         try:
+            # the patched words cover what freshly derived ones cover (the chunk field's base is the build's: appended chunks lie above it)
+            cov_a, cov_b = mnv.accel_info(et.accel, coverage=True), mnv.accel_info(fresh, coverage=True)
+            if cov_a["grid2_level"] == cov_b["grid2_level"]:
+                assert cov_a["nonleaf_cells"] == cov_b["nonleaf_cells"] and cov_a["inline_cells"] == cov_b["inline_cells"], (cov_a, cov_b)
             for cam in cams:
                 a, b = frames_of(mnv, torch, et, cam, opt, et.accel, grid), frames_of(mnv, torch, et, cam, opt, fresh, grid)
                 assert not same_frames(a, b)

@@ -203,6 +203,10 @@ def test_depth11_tree_in_the_size_class_of_the_references_budget(mnv, orc, torch
     ref = orc.render(orc.tree_from_view(tree.host_view()), cam.c, opt)["rgba"]
     assert (ref[..., 3] > 0).sum() > 100_000
     tree.move_to_device()
+    # the inline cell words name their chunk in 22 bits RELATIVE to the smallest chunk number of that depth: none of this tree's all-leaves chunks
+    # one level below the grid is lost to the field, although their numbers run far beyond 2^22
+    info = mnv.accel_info(tree.accel, coverage=True)
+    assert info["brick_levels"] == 2 and info["inline_cells"] > 100_000 and info["inline_lost_to_chunk_field"] == 0 and info["record_chunks"] == info["nonleaf_cells"], info
     a = torch.empty((540, 960, 4), dtype=torch.float32, device="cuda")
     b = torch.empty_like(a)
     mnv.render_voxels_accel(tree.accel, cam, opt, rgba=a)
