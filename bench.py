@@ -756,6 +756,7 @@ def main():
                          "(the launcher's second attempt if the first one fails or wedges)")
     ap.add_argument("--launch-timeout", type=float, default=600.0, help="--gpus N > 1 without a launcher: watchdog for the ranks this process starts (s)")
     ap.add_argument("--no-extras", action="store_true", help="N = 1: skip the secondary numbers for the other BASELINE configs (cfg3, cfg4_n1, cfg5)")
+    ap.add_argument("--test-fail-reserved", action="store_true", help=argparse.SUPPRESS)   # rehearsal of the launcher's ladder; reads no environment
     ap.add_argument("--laps", type=int, default=4, help="the step walks the 16-pose orbit this many times (16 x laps frames in one launch, <= 64)")
     args = ap.parse_args()
     global W, H, N_FRAMES
@@ -819,9 +820,9 @@ def main():
 
     RING = 2
     reserve = args.reserve_cus if args.reserve_cus >= 0 else (32 if multi else 0)
-    if multi and reserve > 0 and os.environ.get("MNV_BENCH_TEST_FAIL_RESERVED"):
-        # test hook (tests/test_bench_multirank_gpu.py): stands in for a node on which the CU-masked stream does not work
-        print("bench.py: MNV_BENCH_TEST_FAIL_RESERVED is set: failing the run with reserved compute units", file=sys.stderr)
+    if multi and reserve > 0 and args.test_fail_reserved:
+        # hidden test flag (tests/test_bench_multirank_gpu.py): stands in for a node on which the CU-masked stream does not work
+        print("bench.py: --test-fail-reserved: failing the run with reserved compute units", file=sys.stderr)
         sys.exit(7)
     n_march_streams = RING if multi and not args.one_march_stream else 1
     march_streams = None

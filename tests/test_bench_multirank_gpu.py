@@ -60,8 +60,8 @@ def test_bench_launcher_repeats_a_failed_run_conservatively_and_kills_a_wedged_o
     env["MNV_LIB_PATH"] = hooks.HOOKS_LIB
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1", "--laps", "1"]
     # (i) the two-step ladder over the stand-in
-    e1 = dict(env, MNV_RCCL_LIBRARY=fake_rccl, MNV_BENCH_TEST_FAIL_RESERVED="1")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=e1)
+    e1 = dict(env, MNV_RCCL_LIBRARY=fake_rccl)
+    r = subprocess.run(cmd + ["--test-fail-reserved"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=e1)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and "[default] ended with code" in d["launch"] and "repeated with --reserve-cus 0 --one-march-stream" in d["launch"]
