@@ -182,7 +182,8 @@ int launch_accel(const mnv_accel *accel, const FrameParams &P, const CamBlock *c
     // sample emission and the depth image read no colour rows: one instantiation (BASIS 9) serves every row format
     const bool colourless = K.samples != nullptr || (P.render_depth && !K.split_track && !K.sample_track && !K.visited);
     const int nb_lds = colourless ? 9 : (accel->view.format == MNV_FORMAT_SH && accel->view.basis_dim > 0) ? accel->view.basis_dim : 1;
-    const size_t lds_bytes = 256 + (nb_lds >= 16 ? 1024 : 0) + (size_t)(nb_lds + 2) * 256 * 4 + ((size_t)4 << (3 * lds_level));
+    const bool tracked = K.split_track || K.sample_track || K.samples || K.visited;  // (those frames keep one more value per ray in LDS: t_min)
+    const size_t lds_bytes = 256 + (nb_lds >= 16 ? 1024 : 0) + (size_t)(nb_lds + 2 + (tracked ? 1 : 0)) * 256 * 4 + ((size_t)4 << (3 * lds_level));
     static const int env_bpc = knob_int(KNOB_BLOCKS_PER_CU, 0);
     static const int env_refill = knob_int(KNOB_REFILL_MIN, 0);
     static const int env_ablate = knob_int(KNOB_ABLATE, 0);

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
     constexpr int MAPW = BASIS >= 16 ? BLOCK : 0;        // cooperative colour pass (SH16 / SH25 only): dense-sample rank -> lane, per wavefront
     uint32_t *s_map = s_mem + 64;
     float *s_ray = reinterpret_cast<float *>(s_mem + 64 + MAPW);
-    uint32_t *s_grid = s_mem + 64 + MAPW + (NB + 2) * BLOCK;  // (2^lds_level)^3 words
+    constexpr int RAY_ROWS = NB + 2 + ((MODE == 2 || MODE == 3) ? 1 : 0);  // tracker / sample frames also keep a ray's t_min (the re-walk below)
+    uint32_t *s_grid = s_mem + 64 + MAPW + RAY_ROWS * BLOCK;  // (2^lds_level)^3 words
     constexpr int CHAN_BYTES = chan_bytes_for(BASIS);
     constexpr int ROW_BYTES = row_bytes_pow2(BASIS);
     const FrameParams &P = K.P;
@@ -115,6 +116,8 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
     float *my_ray = s_ray + threadIdx.x;             // [k * BLOCK]
     float *wave_ray = s_ray + (threadIdx.x & ~63);  // [k * BLOCK + lane]
 
+    const CamBlock *__restrict__ Cp = K.cams;  // camera of the frame this wavefront's rays belong to (wave-uniform pointer: scalar loads)
+    float cen0 = Cp->cen[0], cen1 = Cp->cen[1], cen2 = Cp->cen[2];
     // per-lane ray state
     float t = 0.f, T = 1.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
     float dir0 = 0.f, dir1 = 0.f, dir2 = 0.f, inv0 = 0.f, inv1 = 0.f, inv2 = 0.f, tmax = 0.f;
@@ -123,8 +126,80 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
     float max_weight = -1.f, max_sample_weight = -1.f, sp_prio = 0.f, sa_prio = 0.f;
     int32_t sp_vox = -1, sa_vox = -1;
     int32_t ns = 0;  // MODE 3: samples emitted by this ray so far
-    static_assert(MODE != 3 || NB >= 6, "MODE 3 keeps the world-space ray in the LDS slots of the SH basis");
+    // The trackers' fallbacks -- the LAST leaf without a dense sample that may be split (depth < max_depth), resp. whose sample count is below
+    // the limit, each kept as long as no dense leaf has qualified (rt_core.cuh:308-321 overwrites them at every such step) -- are resolved when
+    // the pixel is written: the march remembers the t of the last such step (sp_t, sa_t) instead of naming the voxel of every leaf a ray steps
+    // through (a second load from the 512-MiB voxel grid per step above the second grid) and gathering sample_counts[] for it.  One look-up per
+    // ray then names the voxel (the same arithmetic at the same t finds the same leaf); if THAT leaf's count is saturated, the ray's steps are
+    // walked again for the last one that is not.  0.10 of 0.57 ms of a 1080p tracker frame.
+    [[maybe_unused]] float sp_t = -1.f, sa_t = -1.f;
+    // the leaf at parameter tw of this lane's ray: its word (depth, sigma), its voxel, and the step the march takes from there
+    [[maybe_unused]] auto leaf_at = [&](float tw, uint32_t &word, uint32_t &v, float &dt) {
+        float pos[3];
+        uint32_t q[3];
+        pos[0] = cen0 + tw * dir0;
+        pos[1] = cen1 + tw * dir1;
+        pos[2] = cen2 + tw * dir2;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            pos[i] = __builtin_amdgcn_fmed3f(pos[i], 0.f, 1.f - 1e-6f);
+            q[i] = (uint32_t)(pos[i] * qscale);
+        }
+        word = s_grid[((((q[0] >> sh1) << LL) | (q[1] >> sh1)) << LL) | (q[2] >> sh1)];
+        int src = 0;
+        v = 0;
+        if (!(word & kLeafBit)) word = descend_to_leaf(A, q, word, sh1, sh2, L2, LL, src, v);
+        if (src == 0) v = A.grid_vox[((((q[0] >> shg) << A.grid_level) + (q[1] >> shg)) << A.grid_level) + (q[2] >> shg)];
+        else if (src == 1) v = A.grid2_vox[v];
+        const int depth = (int)((word >> 16) & 0x7fu);
+        const float sc = __uint_as_float((uint32_t)(127 + depth) << 23), inv_cube = __uint_as_float((uint32_t)(127 - depth) << 23);
+        const float invd[3] = {inv0, inv1, inv2};
+        float tu = 1e4f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float x = __builtin_amdgcn_fractf(pos[i] * sc);
+            const float t1 = -x * invd[i];
+            const float t2 = t1 + invd[i];
+            tu = fminf(tu, fmaxf(t1, t2));
+        }
+        dt = tu * inv_cube + P.step_size;
+    };
+    [[maybe_unused]] auto resolve_fallbacks = [&]() {
+        if constexpr (MODE == 2 || MODE == 3) {
+            const bool want_split = max_weight == -1.f && sp_t >= 0.f, want_sample = K.sample_counts && max_sample_weight == -1.f && sa_t >= 0.f;
+            uint32_t word = 0, v = 0;
+            float dt = 0.f;
+            if (want_split) {
+                leaf_at(sp_t, word, v, dt);
+                sp_vox = (int32_t)v;
+                sp_prio = (float)((word >> 16) & 0x7fu);
+            }
+            if (want_sample) {
+                if (!(want_split && sa_t == sp_t)) leaf_at(sa_t, word, v, dt);
+                const int16_t sc_last = K.sample_counts[v];
+                if (sc_last < K.max_sample_count) {
+                    sa_vox = (int32_t)v;
+                    sa_prio = (float)sc_last;
+                } else {
+                    // the ray's own step sequence once more (same arithmetic: the same t values), looking at the leaves without a dense sample only
+                    float tw = my_ray[(NB + 2) * BLOCK];
+                    while (tw < t) {
+                        leaf_at(tw, word, v, dt);
+                        if (!(half_bits_to_float((uint16_t)word) > P.sigma_thresh)) {
+                            const int16_t c = K.sample_counts[v];
+                            if (c < K.max_sample_count) {
+                                sa_vox = (int32_t)v;
+                                sa_prio = (float)c;
+                            }
+                        }
+                        tw += dt;
+                    }
+                }
+            }
+        }
+    };
     auto write_trackers = [&](uint32_t p) {
+        resolve_fallbacks();
         if constexpr (MODE == 3) K.num_samples[p] = (int16_t)ns;
         if constexpr (MODE == 2 || MODE == 3) {
             if (K.split_track) {
@@ -179,8 +254,6 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
     uint32_t qsel = 0;     // queues tried so far (wave-uniform)
     bool drained = false;  // every queue is empty (wave-uniform)
     uint32_t frame = 0;    // frame of the rays this wavefront holds (wave-uniform)
-    const CamBlock *__restrict__ Cp = K.cams;  // camera of `frame` (wave-uniform pointer: scalar loads)
-    float cen0 = Cp->cen[0], cen1 = Cp->cen[1], cen2 = Cp->cen[2];
     uint32_t pix_base = 0;
 
     // MODE 1 + MNV_TIMELINE: when each tile was grabbed and finished and by which wavefront (tools/timeline.py)
@@ -295,6 +368,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                             sp_prio = (float)(K.max_depth + 1);
                             sa_prio = (float)(K.max_sample_count + 1);
                             sp_vox = sa_vox = -1;
+                            sp_t = sa_t = -1.f;
                         }
                         if constexpr (MODE == 3) ns = K.num_samples[pix];
                         RaySetup<NB> r;
@@ -323,6 +397,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                             }
                             my_ray[NB * BLOCK] = r.delta_scale;
                             my_ray[(NB + 1) * BLOCK] = __uint_as_float(pix);
+                            if constexpr (MODE == 2 || MODE == 3) my_ray[(NB + 2) * BLOCK] = r.tmin;
                         } else {
                             my_ray[(NB + 1) * BLOCK] = __uint_as_float(pix);
                             fin = 3;  // the ray misses the bounding box: background pixel, written with the tile's others
@@ -357,19 +432,23 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
         [[maybe_unused]] auto track_update = [&]() {
             if constexpr (MODE == 2 || MODE == 3) {
                 if (track_leaf) {
-                    const bool split_ok = track_depth < K.max_depth && (dense ? weight > max_weight : max_weight == -1.f);
-                    if (split_ok) {
-                        sp_vox = (int32_t)vox;
-                        sp_prio = (float)track_depth;
-                        if (dense) max_weight = weight;
-                    }
-                    if (K.sample_counts && (dense ? weight > max_sample_weight : max_sample_weight == -1.f)) {
-                        const int16_t sc = K.sample_counts[vox];
-                        if (sc < K.max_sample_count) {
-                            sa_vox = (int32_t)vox;
-                            sa_prio = (float)sc;
-                            if (dense) max_sample_weight = weight;
+                    if (dense) {  // (its voxel is known: need_vox)
+                        if (track_depth < K.max_depth && weight > max_weight) {
+                            sp_vox = (int32_t)vox;
+                            sp_prio = (float)track_depth;
+                            max_weight = weight;
                         }
+                        if (K.sample_counts && weight > max_sample_weight) {
+                            const int16_t sc = K.sample_counts[vox];
+                            if (sc < K.max_sample_count) {
+                                sa_vox = (int32_t)vox;
+                                sa_prio = (float)sc;
+                                max_sample_weight = weight;
+                            }
+                        }
+                    } else {  // (t is still this step's t: the update runs before t += delta_t)
+                        if (max_weight == -1.f && track_depth < K.max_depth) sp_t = t;
+                        if (max_sample_weight == -1.f) sa_t = t;
                     }
                 }
             }
@@ -503,7 +582,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                 const float sigma = half_bits_to_float((uint16_t)word);
                 const bool is_dense = sigma > P.sigma_thresh && !ablate(2);
                 bool need_vox = is_dense;
-                if constexpr (MODE == 2 || MODE == 3) need_vox = is_dense || cand || max_weight == -1.f || max_sample_weight == -1.f || K.visited != nullptr;
+                if constexpr (MODE == 2 || MODE == 3) need_vox = is_dense || cand || K.visited != nullptr;  // (leaves without a dense sample: by their t, see sp_t / sa_t)
                 if (need_vox) {
                     // voxel index of a leaf that was answered by one of the lookup grids
                     if (src == 0) {
@@ -530,7 +609,7 @@ __global__ __launch_bounds__(BLOCK, (MODE == 2 || MODE == 3) ? MNV_TRACK_WAVES :
                     weight = T * (1.f - att);
                 }
                 if constexpr (MODE == 2 || MODE == 3) {
-                    track_leaf = need_vox;
+                    track_leaf = true;
                     track_depth = depth;
                     // (BRICK tracker frames: whether the leaf is dense, and its weight, are known behind the colour block)
                     if constexpr (!(BRICK && MODE == 2)) track_update();
