@@ -6,7 +6,7 @@ import re
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = os.environ.get("ROUND", "r05")
+R = os.environ.get("ROUND", "r06")
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
 
@@ -29,7 +29,7 @@ s += "         -> %.0f L1 misses in flight per compute unit on average; TA busy 
     lat * req, 100 * avg(mem, "TA_BUSY_avr") / cyc, 100 * avg(mem, "TCP_PENDING_STALL_CYCLES_sum") / 256 / cyc)
 open(os.path.join(P, R + "_rocprofv3_summary.txt"), "w").write(s)
 shutil.copy(os.path.join(G, R + "_batch", "traffic.json"), os.path.join(P, R + "_traffic.json"))
-for t in ("per_frame", "per_frame_1stream", "ref_layout", "cfg3", "cfg4", "fog"):
+for t in ("per_frame", "per_frame_1stream", "ref_layout", "tracker", "cfg3", "cfg4", "fog"):
     shutil.copy(os.path.join(G, "%s_%s" % (R, t), "summary.txt"), os.path.join(P, "%s_rocprofv3_summary_%s.txt" % (R, t)))
 for wl in ("cfg3", "cfg4", "fog"):   # HBM bytes per launch of the 7.2 M-chunk tree's launches (bench.py: cfg3 / cfg4_n1 rooflines)
     shutil.copy(os.path.join(G, "%s_%s" % (R, wl), "traffic.json"), os.path.join(P, "%s_traffic_%s.json" % (R, wl)))

@@ -1,13 +1,17 @@
 #!/bin/bash
 # The committed profiles of a round: run on the GPU box (gpurun -- 'bash tools/profile_all.sh'), then tools/collect_profiles.py here.
 # ROUND=r03 (default) names the outputs.
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 bash tools/prof.sh ${R}_batch > /dev/null 2>&1
 python3 tools/make_traffic_json.py gpurun_out/${R}_batch/summary.txt 64 > gpurun_out/${R}_batch/traffic.json
 bash tools/prof_mem.sh ${R}_mem > gpurun_out/${R}_mem.txt 2>&1
 bash tools/prof_trace.sh ${R}_per_frame --per-frame --frame-streams 3 --steps 3 --warmup 1 > /dev/null 2>&1
 bash tools/prof_trace.sh ${R}_per_frame_1stream --per-frame --frame-streams 1 --steps 3 --warmup 1 > /dev/null 2>&1
 bash tools/prof_trace.sh ${R}_ref_layout --kernel ref_layout --per-frame --frame-streams 2 --laps 1 --steps 3 --warmup 1 > /dev/null 2>&1
+# the reference's every-frame call: the tracker instantiation, one 1080p frame per launch
+mkdir -p gpurun_out/${R}_tracker
+TMPDIR=/tmp timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_tracker/trace -- python3 tools/tracker_frame_time.py > gpurun_out/${R}_tracker/trace.log 2>&1
+python3 tools/prof_summary.py gpurun_out/${R}_tracker > gpurun_out/${R}_tracker/summary.txt 2>&1; grep "^pose\|^col" gpurun_out/${R}_tracker/trace.log >> gpurun_out/${R}_tracker/summary.txt
 # cfg3 / cfg4 (the 7.2 M-chunk tree) and fog (long dense runs): kernel stats AND the HBM-traffic passes; profiles/${R}_traffic_<wl>.json feed bench.py's cfg3 / cfg4_n1 / fog rooflines
 for wl in cfg3 cfg4 fog; do
   # --laps 1: 16 frames per launch, the launch shape of the default bench line's cfg3 / cfg4_n1 objects

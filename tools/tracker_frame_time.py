@@ -1,5 +1,8 @@
+"""The reference's every-frame call on the packed layout (render_voxels with both tracker tensors, cuda_renderer.cpp:141-142), cfg2 at 1920x1080, one
+frame at a time: the tracker rows against the oracle's (one pose), then HIP-event times of the plain frame, the split tracker alone, the sample tracker
+alone, both, and both without a sample_counts array.  Under rocprofv3 --kernel-trace --stats the tracker instantiation is march_accel_kernel<9,256,2,true>."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
 import numpy as np, torch, cases, mega_nerf_viewer_amd as mnv, mnv_oracle as orc
 W, H = 1920, 1080
