@@ -1,6 +1,8 @@
 """Soak of the VolumeRenderer refinement loop: many frames, moving camera, a capacity small enough to force prunes; after every
 frame the tree's links are checked and the packed accel (when in use) is compared with the reference-layout kernel.
-  python3 tools/refine_soak.py [frames]"""
+  python3 tools/refine_soak.py [frames [room [case]]]      case: a name of tests/cases.py CASES (default sh4_d6; shell_d7_sh9: a tree whose packed layout
+has inline cell words from the start and gets brick records while the loop deepens it)
+On the test-hook build with MNV_REFRESH_DEBUG=2 every refresh / prune of the run also verifies every patched lookup word (tools/soak_all.sh)."""
 import os
 import sys
 
@@ -19,7 +21,8 @@ from test_renderer_refine_gpu import check_tree_links, make_grid  # noqa: E402
 
 n_frames = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 room = int(sys.argv[2]) if len(sys.argv) > 2 else 900
-spec = cases.CASES["sh4_d6"]
+case = sys.argv[3] if len(sys.argv) > 3 else "sh4_d6"
+spec = cases.CASES[case]
 tree = cases.make_tree(mnv, spec["tree"])
 cap0 = tree.capacity
 desc = mnv.mlp_desc(n_clusters=6, pos_octaves=4, hidden_width=64, hidden_layers=2, out_dim=tree.host_view().data_dim + 1)
@@ -33,7 +36,7 @@ o = r.options
 o.background_brightness, o.use_splitting, o.max_depth, o.split_batch_size, o.samples_per_corner, o.max_sample_count = 0.0, True, 9, 300, 2, 16
 cam_check = cases.make_camera(mnv, spec["camera"])
 opt_check = cases.make_options(mnv, spec["options"])
-opt_check.basis_minmax[1] = 3
+opt_check.basis_minmax[1] = max(tree.host_view().basis_dim - 1, 0)
 a = torch.empty((cam_check.height, cam_check.width, 4), device="cuda")
 b = torch.empty_like(a)
 stats = dict(added=0, resampled=0, pruned=0, prunes=0, accel_frames=0, mismatches=0)
