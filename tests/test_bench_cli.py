@@ -3,6 +3,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
@@ -95,3 +97,20 @@ def test_committed_traffic_belongs_to_one_kernel_source_and_launch_shape(tmp_pat
     assert bench.committed_traffic("cfg3", 16) == (1, os.path.join("profiles", "r09_traffic_cfg3.json"))
     assert bench.committed_traffic("cfg3", 64) == (None, None)          # another launch shape
     assert bench.committed_traffic("cfg4", 16) == (None, None)          # another workload
+
+
+@pytest.mark.gpu
+def test_footprint_pass_counts_the_lines_a_launch_touches(torch_gpu):
+    """tools/footprint.py (bench.py's `footprint_bytes`): one launch of the diagnostics instantiation on the test-hook build with a line bitmap.
+    Deterministic, at least the output, at most every line of the arrays a plain cfg2 launch reads (the level-9 grid and the rows), and no line
+    of an array such a launch does not read (node words, records, the voxel grids: the inline cell words answer)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import footprint
+
+    a = footprint.measure(["cfg2_small"])["cfg2_small"]
+    b = footprint.measure(["cfg2_small"])["cfg2_small"]
+    assert a == b
+    rays = 4 * 640 * 360
+    assert a["output_bytes"] == rays * 16 and a["footprint_bytes"] == a["output_bytes"] + 128 * sum(v for k, v in a.items() if k.endswith("_lines"))
+    assert 10_000 < a["grid2_lines"] <= (512 ** 3 * 4) // 128 and 50_000 < a["rows_lines"] <= 1_499_569 * 8 * 64 // 128
+    assert a["nodes_lines"] == 0 and a["records_lines"] == 0 and a["grid2_vox_lines"] == 0

@@ -26,7 +26,7 @@ def child(workloads, out_path):
     opt = mnv.RenderOptions.cli_defaults()
     trees, out = {}, {}
     for workload in workloads:
-        kind = "cfg3" if workload in ("cfg3", "cfg4") else workload
+        kind = "cfg3" if workload in ("cfg3", "cfg4") else "cfg2" if workload == "cfg2_small" else workload
         if kind not in trees:
             trees.clear()   # one big tree at a time
             torch.cuda.empty_cache()
@@ -37,6 +37,9 @@ def child(workloads, out_path):
         if workload == "cfg2":
             w, h = 1920, 1080
             cams = [cases.cfg2_camera(mnv, p % 16, w, h, 1600.0) for p in range(64)]
+        elif workload == "cfg2_small":   # (the tests' size)
+            w, h = 640, 360
+            cams = [cases.cfg2_camera(mnv, p, w, h, 1600.0 * w / 1920) for p in (0, 5, 9, 13)]
         elif workload == "fog":
             w, h = 1920, 1080
             cams = [cases.cfg2_camera(mnv, p, w, h, 1600.0) for p in range(16)]
