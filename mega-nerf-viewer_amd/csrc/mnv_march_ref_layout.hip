@@ -233,9 +233,9 @@ __global__ __launch_bounds__(kRefThreads) void march_ref_layout_kernel(const Mar
                         sp_prio = (float)depth;
                         max_weight = weight;
                     }
-                    if (P.sample_counts) {
+                    if (P.sample_counts && weight > max_sample_weight) {  // (the count is gathered only where it can decide something)
                         const int16_t sc = P.sample_counts[(int64_t)chunk * N3 + cidx];
-                        if (weight > max_sample_weight && sc < P.max_sample_count) {
+                        if (sc < P.max_sample_count) {
                             sa_chunk = (float)chunk;
                             sa_child = (float)cidx;
                             sa_prio = (float)sc;
@@ -276,9 +276,9 @@ __global__ __launch_bounds__(kRefThreads) void march_ref_layout_kernel(const Mar
                     sp_child = (float)cidx;
                     sp_prio = (float)depth;
                 }
-                if (P.sample_counts) {
+                if (P.sample_counts && max_sample_weight == -1.f) {
                     const int16_t sc = P.sample_counts[(int64_t)chunk * N3 + cidx];
-                    if (max_sample_weight == -1.f && sc < P.max_sample_count) {
+                    if (sc < P.max_sample_count) {
                         sa_chunk = (float)chunk;
                         sa_child = (float)cidx;
                         sa_prio = (float)sc;
