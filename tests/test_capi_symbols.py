@@ -154,3 +154,22 @@ def test_the_library_was_built_from_the_sources_in_this_tree(mnv):
     smoke() call every library stale -- as happened when csrc/mnv_knobs.cpp was added -- and an edited source without a rebuild fails here
     instead of passing tests with old code."""
     assert mnv.built_source_sha() == mnv.shipped_source_sha(), "libmnv.so is stale (run make) or the two source lists differ"
+
+
+def test_live_reference_build_carries_all_six_launcher_bindings():
+    """oracle/_ref (the reference's own device code built for gfx950, with include/mnv_reference_binding.hpp compiled in) exports the entry
+    points through which the tests call the six original-signature launchers; skipped where the library was never built (no /root/reference)."""
+    import pytest
+
+    ref = os.path.join(ROOT, "oracle", "_ref", "libmnv_ref_gfx950.so")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref/libmnv_ref_gfx950.so not built (needs /root/reference at build time)")
+    out = subprocess.run(["nm", "-D", "--defined-only", ref], capture_output=True, text=True, check=True).stdout
+    for name in ("ref_dropin_render_npz", "ref_dropin_onscreen_npz", "ref_get_samples_onscreen_npz", "ref_render_nerf_results_dropin_npz",
+                 "ref_add_children_dropin_npz", "ref_generate_samples_dropin_npz", "ref_adjust_parents_dropin_npz"):
+        assert f" T {name}" in out, name
+    # ... and it resolves libmnv.so's entry points of those launchers dynamically (it carries no copy of the product)
+    und = subprocess.run(["nm", "-D", "--undefined-only", ref], capture_output=True, text=True, check=True).stdout
+    for name in ("mnv_render_voxels_ex", "mnv_get_samples_from_voxels_ex", "mnv_render_nerf_results", "mnv_add_children_and_generate_samples",
+                 "mnv_generate_samples", "mnv_adjust_parents_and_children"):
+        assert f" U {name}" in und, name
