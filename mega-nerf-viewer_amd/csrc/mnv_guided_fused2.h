@@ -203,6 +203,9 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
         float ti = 1.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;       // composite state (render_nerf_results)
         float max_weight = -1.f, max_sample_weight = -1.f, sp_prio = 0.f, sa_prio = 0.f;
         int32_t sp_vox = -1, sa_vox = -1;
+        // TRACK: the trackers' fallback leaves (the last leaf without a dense sample that qualifies, rt_core.cuh:561-574) by the t of their step;
+        // named, and their sample count read, once per ray when the pixel is written (march_accel_kernel does the same: mnv_march_accel_kernel.h)
+        [[maybe_unused]] float sp_t = -1.f, sa_t = -1.f, ray_tmin = 0.f;
         int n_eval = 0, n_steps = 0;
 #ifdef MNV_F2_LOG
         int n_comp = 0, n_pushed = 0;
@@ -271,6 +274,68 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                 }
 #endif
                 if constexpr (TRACK) {
+                    {
+                        const int Lq_ = A.max_depth, shg_ = Lq_ - A.grid_level;
+                        auto leaf_at = [&](float tw, uint32_t &word, uint32_t &v, float &dt) {
+                            float pos[3];
+                            uint32_t q[3];
+                            pos[0] = cen0 + tw * dir0;
+                            pos[1] = cen1 + tw * dir1;
+                            pos[2] = cen2 + tw * dir2;
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                pos[i] = __builtin_amdgcn_fmed3f(pos[i], 0.f, 1.f - 1e-6f);
+                                q[i] = (uint32_t)(pos[i] * qscale);
+                            }
+                            word = s_grid[((((q[0] >> sh1) << LL) | (q[1] >> sh1)) << LL) | (q[2] >> sh1)];
+                            int src = 0;
+                            v = 0;
+                            if (!(word & kLeafBit)) word = descend_to_leaf(A, q, word, sh1, sh2, L2, LL, src, v);
+                            if (src == 0) v = A.grid_vox[((((q[0] >> shg_) << A.grid_level) + (q[1] >> shg_)) << A.grid_level) + (q[2] >> shg_)];
+                            else if (src == 1) v = A.grid2_vox[v];
+                            const int depth = (int)((word >> 16) & 0x7fu);
+                            const float sc = __uint_as_float((uint32_t)(127 + depth) << 23), inv_cube = __uint_as_float((uint32_t)(127 - depth) << 23);
+                            const float invd[3] = {inv0, inv1, inv2};
+                            float tu = 1e4f;
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) {
+                                const float x = __builtin_amdgcn_fractf(pos[i] * sc);
+                                const float t1 = -x * invd[i];
+                                const float t2 = t1 + invd[i];
+                                tu = fminf(tu, fmaxf(t1, t2));
+                            }
+                            dt = tu * inv_cube + P.step_size;
+                        };
+                        const bool want_split = max_weight == -1.f && sp_t >= 0.f, want_sample = K.sample_counts && max_sample_weight == -1.f && sa_t >= 0.f;
+                        uint32_t word = 0, v = 0;
+                        float dt = 0.f;
+                        if (want_split) {
+                            leaf_at(sp_t, word, v, dt);
+                            sp_vox = (int32_t)v;
+                            sp_prio = (float)((word >> 16) & 0x7fu);
+                        }
+                        if (want_sample) {
+                            if (!(want_split && sa_t == sp_t)) leaf_at(sa_t, word, v, dt);
+                            const int16_t sc_last = K.sample_counts[v];
+                            if (sc_last < K.max_sample_count) {
+                                sa_vox = (int32_t)v;
+                                sa_prio = (float)sc_last;
+                            } else {  // the last such leaf is saturated: the ray's steps once more, for the last one that is not
+                                float tw = ray_tmin;
+                                while (tw < t) {
+                                    leaf_at(tw, word, v, dt);
+                                    if (!(half_bits_to_float((uint16_t)word) > P.sigma_thresh)) {
+                                        const int16_t c = K.sample_counts[v];
+                                        if (c < K.max_sample_count) {
+                                            sa_vox = (int32_t)v;
+                                            sa_prio = (float)c;
+                                        }
+                                    }
+                                    tw += dt;
+                                }
+                            }
+                        }
+                    }
                     if (K.split_track) {
                         K.split_track[(int64_t)pix * 3 + 0] = sp_prio;
                         K.split_track[(int64_t)pix * 3 + 1] = sp_vox < 0 ? -1.f : (float)(sp_vox >> 3);
@@ -322,6 +387,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                         sp_prio = (float)(K.max_depth + 1);
                         sa_prio = (float)(K.max_sample_count + 1);
                         sp_vox = sa_vox = -1;
+                        sp_t = sa_t = -1.f;
                     }
                     RaySetup<NB> r;
                     setup_ray<(BASIS > 0 ? BASIS : 0)>(P, *Cp, P.x0 + bx, P.y0 + by, r, frame_tmax(P, p));
@@ -345,6 +411,7 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                         dir0 = r.dir[0]; dir1 = r.dir[1]; dir2 = r.dir[2];
                         inv0 = r.invdir[0]; inv1 = r.invdir[1]; inv2 = r.invdir[2];
                         delta_scale = r.delta_scale;
+                        if constexpr (TRACK) ray_tmin = r.tmin;
                     }
                 }
                 if (F.diag) t_setup += wall_clock64() - t_i1;
@@ -434,25 +501,16 @@ __global__ __launch_bounds__(kF2Block, kF2WavesPerSimd) void guided_fused2_kerne
                     const bool is_dense = sigma > P.sigma_thresh;
                     bool need_vox = false;
                     if constexpr (TRACK) {
-                        need_vox = is_dense || max_weight == -1.f || max_sample_weight == -1.f || K.visited != nullptr;
+                        need_vox = is_dense || K.visited != nullptr;  // (leaves without a dense sample: by their t, sp_t / sa_t)
                         if (need_vox) {
                             const int shg = Lq - A.grid_level;
                             if (src == 0) vox = A.grid_vox[((((q[0] >> shg) << A.grid_level) + (q[1] >> shg)) << A.grid_level) + (q[2] >> shg)];
                             else if (src == 1) vox = A.grid2_vox[vox];
                             if (K.visited && __hip_atomic_load(&K.visited[vox >> 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) K.visited[vox >> 3] = 1;
                         }
-                        if (need_vox && !is_dense) {  // first leaf before any dense one, rt_core.cuh:561-574
-                            if (depth < K.max_depth && max_weight == -1.f) {
-                                sp_vox = (int32_t)vox;
-                                sp_prio = (float)depth;
-                            }
-                            if (K.sample_counts && max_sample_weight == -1.f) {
-                                const int16_t scn = K.sample_counts[vox];
-                                if (scn < K.max_sample_count) {
-                                    sa_vox = (int32_t)vox;
-                                    sa_prio = (float)scn;
-                                }
-                            }
+                        if (!is_dense) {  // the last leaf before any dense one qualifies, rt_core.cuh:561-574
+                            if (depth < K.max_depth && max_weight == -1.f) sp_t = t;
+                            if (max_sample_weight == -1.f) sa_t = t;
                         }
                     }
                     if (is_dense) {
