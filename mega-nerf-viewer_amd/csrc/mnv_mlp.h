@@ -16,8 +16,6 @@ using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int kRowsPerPass = 256;   // 4 wavefronts x 64 rows
-constexpr int kPasses = 32;         // passes of 256 rows of one workgroup over rows of the same cluster: the weights are staged once per 8192 rows at most
-constexpr int kRowsPerBlock = kRowsPerPass * kPasses;
 constexpr int kNT = 4;              // 16-row MFMA column tiles per wavefront
 constexpr int kMaxClusters = 1024;
 
@@ -46,6 +44,7 @@ struct mnv_mlp {
     uint8_t *scratch = nullptr;     // grow-only: order, tiles, counters
     size_t scratch_bytes = 0;
     int num_cus = 0;
+    int blocks_per_cu = 0;          // workgroups of this network's forward kernel a compute unit holds (asked once)
 };
 
 namespace mnv {

@@ -14,8 +14,9 @@
 //                bit-identical on host and device; only the accumulation order inside the MFMA differs from
 //                the sequential CPU restatement (tests bound that).
 //
-// Execution: counting sort of the rows by cluster (histogram + scan + scatter), then one workgroup per up to 8192 rows of one
-// cluster, 256 or 512 rows per pass.  The whole network runs in registers: with the weights as the MFMA A operand and the samples
+// Execution: counting sort of the rows by cluster (histogram + scan + scatter) into tiles of 256 or 512 rows of one cluster, then as many
+// persistent workgroups as the device holds, each with a contiguous range of the tiles (weights staged when the cluster changes, the next
+// tile's rows and samples in flight across tile boundaries).  The whole network runs in registers: with the weights as the MFMA A operand and the samples
 // as the B operand (D^T = W X^T), the C layout of one layer (lane: sample l & 15, features 4 (l >> 4) + r) is
 // already a valid B layout for the next layer once the K index is permuted -- and the permutation is baked into
 // the weight fragments at upload time, so nothing moves between layers but a float -> half convert.
@@ -46,8 +47,7 @@ struct MlpLaunch {
     int32_t result_stride;
     const int32_t *order;       // rows sorted by cluster
     const int32_t *seg_start;   // [n_clusters + 1]: first position of each cluster in `order`
-    const int32_t *tile_start;  // [n_clusters + 1]: first tile (workgroup) of each cluster; [n_clusters] = number of tiles
-    int32_t rows_per_block;     // rows of one cluster a workgroup takes (a multiple of kRowsPerPass, at most kRowsPerBlock)
+    const int32_t *tile_start;  // [n_clusters + 1]: first tile of each cluster (a tile: up to one pass's rows -- the kernel's ROWS -- of one cluster); [n_clusters] = number of tiles
 #ifdef MNV_MLP_CLOCKS
     unsigned long long *clocks;  // measurement variant (tools/mlp_clocks.sh): summed s_memtime per phase of wavefront 0 of every workgroup
 #endif
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void mlp_histogram(const int16_t *__restrict__
 
 // one block: exclusive scans of the counts -> segment starts and first tile of every cluster
 __global__ void mlp_plan(const int32_t *__restrict__ counts, int32_t n_clusters, int32_t *__restrict__ seg_start,
-                         int32_t *__restrict__ cursor, int32_t *__restrict__ tile_start, int32_t rows_per_block) {
+                         int32_t *__restrict__ cursor, int32_t *__restrict__ tile_start, int32_t rows_per_tile) {
     __shared__ int32_t s_start[kMaxClusters + 1], s_tile[kMaxClusters + 1];
     if (threadIdx.x == 0) {
         int32_t a = 0, t = 0;
@@ -132,7 +132,7 @@ __global__ void mlp_plan(const int32_t *__restrict__ counts, int32_t n_clusters,
             s_start[c] = a;
             s_tile[c] = t;
             a += counts[c];
-            t += (counts[c] + rows_per_block - 1) / rows_per_block;
+            t += (counts[c] + rows_per_tile - 1) / rows_per_tile;
         }
         s_start[n_clusters] = a;
         s_tile[n_clusters] = t;
@@ -198,6 +198,10 @@ __device__ __forceinline__ float tri_of(float x, float scale, bool quarter_phase
     return __builtin_fmaf(4.f, fabsf(r), -1.f);
 }
 
+// An entry of a table that was written before this kernel started (seg_start, tile_start): read through the constant address space it is a
+// scalar load wherever it stands -- behind the kernel's own stores a plain load is a vector load with a wait for everything in flight.
+__device__ __forceinline__ int32_t load_uniform(const int32_t *p) { return *(const __attribute__((address_space(4))) int32_t *)(p); }
+
 template <int... I, class F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F &&f) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -215,25 +219,37 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
     constexpr int COLS = 16 * NT;  // samples (MFMA columns) of one wavefront
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const MlpShape &S = L.S;
-    if ((int)blockIdx.x >= L.tile_start[S.n_clusters]) return;
-    // the cluster whose tile range holds this block: last c with tile_start[c] <= blockIdx.x (uniform: scalar loads)
-    int lo = 0, hi = S.n_clusters;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (L.tile_start[mid] <= (int)blockIdx.x) lo = mid;
-        else hi = mid;
+    // Persistent workgroups (round 6): the launch holds as many workgroups as the device runs at once, each takes a CONTIGUOUS range of the
+    // tiles (a tile = one pass = up to ROWS rows of one cluster) and stages a cluster's weights only when the cluster changes -- with 8 clusters
+    // over 8 M rows once or twice per workgroup instead of once per 4096 rows, no workgroup start / drain between tiles, the next tile's rows
+    // and samples in flight across the tile boundary, and ranges that differ by one tile at most (1953 workgroups of 4096 rows on 256 compute
+    // units were 8 rounds for some and 7 for others).
+    const int n_tiles = load_uniform(L.tile_start + S.n_clusters);
+    const int tile_first = (int)(((int64_t)blockIdx.x * n_tiles) / gridDim.x), tile_end = (int)(((int64_t)(blockIdx.x + 1) * n_tiles) / gridDim.x);
+    if (tile_first >= tile_end) return;
+    // the cluster whose tile range holds the first tile: last c with tile_start[c] <= tile_first (uniform: scalar loads)
+    int cluster_next;
+    {
+        int lo = 0, hi = S.n_clusters;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (load_uniform(L.tile_start + mid) <= tile_first) lo = mid;
+            else hi = mid;
+        }
+        cluster_next = lo;
     }
-    const int cluster = lo;
+    // tiles and rows of cluster_next: [cl_tile0, cl_tile1) and [cl_seg0, cl_seg1) -- scalar registers, read again only where the cluster changes
+    int cl_tile0 = load_uniform(L.tile_start + cluster_next), cl_tile1 = load_uniform(L.tile_start + cluster_next + 1);
+    int cl_seg0 = load_uniform(L.seg_start + cluster_next), cl_seg1 = load_uniform(L.seg_start + cluster_next + 1);
 #ifdef MNV_MLP_CLOCKS
     unsigned long long clk_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, clk_t_ = __builtin_readcyclecounter();
+    const unsigned long long clk_begin_ = clk_t_, wall_begin_ = wall_clock64();
 #endif
-    const int block_first = L.seg_start[cluster] + ((int)blockIdx.x - L.tile_start[cluster]) * L.rows_per_block;
-    const int block_rows = min(L.rows_per_block, L.seg_start[cluster + 1] - block_first);
 
-    // weights and biases of this cluster -> LDS
     const half8 *s_frag = reinterpret_cast<const half8 *>(lds);
     const float *s_bias = reinterpret_cast<const float *>(lds + (size_t)S.frag_halfs * 2);
-    {
+    // weights and biases of a cluster -> LDS
+    auto stage_weights = [&](int cluster) __attribute__((always_inline)) {
         // (eight 16-byte loads in flight per thread: one load per trip of a plain copy loop costs a trip to the L2 each -- 18 trips for 147 KB)
         const uint4 *src = reinterpret_cast<const uint4 *>(L.frags + (size_t)cluster * S.frag_halfs);
         uint4 *dst = reinterpret_cast<uint4 *>(lds);
@@ -250,9 +266,7 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
         const float *bsrc = L.biases + (size_t)cluster * S.bias_floats;
         float *bdst = reinterpret_cast<float *>(lds + (size_t)S.frag_halfs * 2);
         for (int i = threadIdx.x; i < S.bias_floats; i += blockDim.x) bdst[i] = bsrc[i];
-    }
-    __syncthreads();
-    MLP_CLOCK(0);
+    };
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, col = lane & 15;
     // the wavefront's encode tile: HALF a K tile (16 features) of its COLS samples, a sample's 32 bytes = four lane groups x 8 bytes (features
@@ -272,8 +286,15 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
     // per instruction).
     int32_t dst_row_next[NT], own_next[OWN];
     float x_next[OWN][7];
-    auto fetch_rows = [&](int pass_first) __attribute__((always_inline)) {
-        const int first = block_first + pass_first, rows = min(ROWS, block_rows - pass_first);
+    // tile -> its cluster (tiles of a range come in cluster order: the cluster only moves forward, over clusters without rows), first row, rows
+    auto fetch_rows = [&](int tile) __attribute__((always_inline)) {
+        while (cl_tile1 <= tile) {
+            ++cluster_next;
+            cl_tile0 = cl_tile1, cl_seg0 = cl_seg1;
+            cl_tile1 = load_uniform(L.tile_start + cluster_next + 1), cl_seg1 = load_uniform(L.seg_start + cluster_next + 1);
+        }
+        const int first = cl_seg0 + (tile - cl_tile0) * ROWS;
+        const int rows = min(ROWS, cl_seg1 - first);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int local = wave * COLS + nt * 16 + (lane >> 2);
@@ -303,15 +324,12 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
             x_next[o][6] = S.n_embeddings > 0 ? x[S.need_viewdir ? 6 : 3] : 0.f;
         }
     };
-    fetch_rows(0);
-    fetch_samples();
-
-    for (int pass_first = 0; pass_first < block_rows; pass_first += ROWS) {
-        int32_t dst_row[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) dst_row[nt] = dst_row_next[nt];
-        float p[OWN][3], d[OWN][3];
-        const uint16_t *emb[OWN];
+    // Loads and stores count down the same counter and may pass each other, so a wait for a load that stands behind stores is a wait for
+    // the stores as well: what the loads of tile t + 1 brought is taken over (position, direction, embedding row; the rows of the results)
+    // BEFORE tile t's output layer sends its stores, and nothing at the top of a tile waits for memory.
+    float p[OWN][3], d[OWN][3];
+    int32_t emb_row[OWN], dst_row[NT];
+    auto take_over = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int o = 0; o < OWN; ++o) {
 #pragma unroll
@@ -319,15 +337,39 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
                 p[o][i] = (x_next[o][i] - S.center[i]) * S.inv_extent[i];
                 d[o][i] = x_next[o][3 + i];
             }
-            emb[o] = nullptr;
+            emb_row[o] = 0;
             if (S.n_embeddings > 0) {
-                int idx = (int)x_next[o][6];
-                idx = idx < 0 ? 0 : (idx >= S.n_embeddings ? S.n_embeddings - 1 : idx);
-                emb[o] = L.embeddings + ((size_t)cluster * S.n_embeddings + idx) * S.embedding_dim;
+                asm volatile("" : "+v"(x_next[o][6]));  // (or the conversion moves up to the load, and waits for it there)
+                const int idx = (int)x_next[o][6];
+                emb_row[o] = idx < 0 ? 0 : (idx >= S.n_embeddings ? S.n_embeddings - 1 : idx);
             }
         }
-        const bool more = pass_first + ROWS < block_rows;
-        if (more) fetch_rows(pass_first + ROWS);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) asm volatile("" : "+v"(dst_row_next[nt]));  // (arrived: loads return in order, and x_next came later)
+    };
+    fetch_rows(tile_first);
+    fetch_samples();
+    take_over();
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dst_row[nt] = dst_row_next[nt];
+
+    int cluster = -1;  // the cluster whose weights are in LDS
+    int tile_cluster = cluster_next;  // the cluster of the tile at hand (cluster_next runs one tile ahead)
+    for (int tile = tile_first; tile < tile_end; ++tile) {
+        if (tile_cluster != cluster) {  // (uniform)
+            if (cluster >= 0) __syncthreads();  // every wavefront is done with the old weights
+            cluster = tile_cluster;
+            stage_weights(cluster);
+            __syncthreads();
+            MLP_CLOCK(0);
+        }
+        const uint16_t *emb[OWN];
+#pragma unroll
+        for (int o = 0; o < OWN; ++o)
+            emb[o] = S.n_embeddings > 0 ? L.embeddings + ((size_t)cluster * S.n_embeddings + emb_row[o]) * S.embedding_dim : nullptr;
+        // (the last tile of the range fetches itself again: loads under a condition would meet the other path's values in copies that the
+        // compiler puts right behind the loads -- a wait for memory at the top of every tile)
+        fetch_rows(tile + 1 < tile_end ? tile + 1 : tile);
         // Encoding of one HALF of a K tile (16 K slots) of this lane's samples into the wavefront's tile.  The position block, the direction
         // block and the embedding each start at a multiple of 16 slots (mnv_mlp.h), so a half tile holds features of ONE block at
         // compile-time places: octave, axis and phase of every feature are constants of the code -- seven or eight instructions per feature,
@@ -498,7 +540,7 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
                 __builtin_amdgcn_wave_barrier();
             });
             MLP_CLOCK(2);
-            if (more) fetch_samples();
+            fetch_samples();
             dense_relu(std::integral_constant<int, NKK0>{}, bf0, bf);
             MLP_CLOCK(3);
         } else {
@@ -540,7 +582,7 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
                 }
             }
             MLP_CLOCK(2);
-            if (more) fetch_samples();
+            fetch_samples();
 #pragma unroll
             for (int kk = 0; kk < KT; ++kk)
 #pragma unroll
@@ -569,27 +611,42 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
         }
 
         MLP_CLOCK(4);
+        take_over();  // the next tile's samples, before this tile's stores
+        MLP_CLOCK(6);
         // ---- the output layer: lane (g, col) holds features 16 mt + 4 g + r of sample col + 16 nt; a 1 KB tile in LDS (the encode tile's
         //      place) turns that into the store's lane order, 16-byte slots swizzled so that neither side meets a bank twice
         f32x4 *s_out = reinterpret_cast<f32x4 *>(s_enc2);
         const int slot_w = col * 4 + (g ^ (col >> 2)), slot_r = (lane & ~3) | ((lane & 3) ^ ((lane >> 4) & 3));
         auto leave = [&](int mt, const f32x4 (&tile)[NT]) __attribute__((always_inline)) {
+            static_assert(NT % 2 == 0, "column tiles leave in pairs");
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                s_out[slot_w] = tile[nt];
+            for (int nt0 = 0; nt0 < NT; nt0 += 2) {  // two column tiles per trip through LDS (the encode tile holds two 1 KB slots): half the round trips
+                s_out[slot_w] = tile[nt0];
+                s_out[64 + slot_w] = tile[nt0 + 1];
                 __builtin_amdgcn_wave_barrier();
-                const f32x4 v = s_out[slot_r];
+                const f32x4 v2[2] = {s_out[slot_r], s_out[64 + slot_r]};
                 __builtin_amdgcn_wave_barrier();
-                const int f0 = 16 * mt + 4 * (lane & 3);
-                if (dst_row[nt] < 0 || f0 >= S.out_dim) continue;
-                float *out = L.results + (int64_t)dst_row[nt] * L.result_stride + f0;
-                if (f0 + 3 < S.out_dim) {
+                // a lane's four features: all inside the row (one 16-byte store), or the row's last one to three (ONE store of that width: the
+                // width is the same for every lane that has a tail -- three 4-byte stores under three conditions were 0.1 ms of 1.29 for 29 outputs)
+                const int f0 = 16 * mt + 4 * (lane & 3), here = S.out_dim - f0, tail = S.out_dim & 3;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int nt = nt0 + h;
+                    const f32x4 v = v2[h];
+                    if (dst_row[nt] < 0 || here <= 0) continue;
+                    float *out = L.results + (int64_t)dst_row[nt] * L.result_stride + f0;
                     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-                    *reinterpret_cast<f4u *>(out) = v;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 3; ++r)
-                        if (f0 + r < S.out_dim) out[r] = v[r];
+                    typedef float f3u __attribute__((ext_vector_type(3), aligned(4)));
+                    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+                    if (here >= 4) {
+                        *reinterpret_cast<f4u *>(out) = v;
+                    } else if (tail == 1) {
+                        out[0] = v[0];
+                    } else if (tail == 2) {
+                        *reinterpret_cast<f2u *>(out) = f2u{v[0], v[1]};
+                    } else {
+                        *reinterpret_cast<f3u *>(out) = f3u{v[0], v[1], v[2]};
+                    }
                 }
             }
         };
@@ -618,10 +675,16 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT >= 32 ? 1 : 2)) void mlp_forwa
             leave(S.mt_out - 1, last);
         }
         MLP_CLOCK(5);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) dst_row[nt] = dst_row_next[nt];
+        tile_cluster = cluster_next;
     }
 #ifdef MNV_MLP_CLOCKS
-    if (threadIdx.x == 0)
-        for (int i = 0; i < 16; ++i) atomicAdd(&L.clocks[i], clk_[i]);
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 14; ++i) atomicAdd(&L.clocks[i], clk_[i]);
+        atomicAdd(&L.clocks[14], __builtin_readcyclecounter() - clk_begin_);  // shader-clock cycles and 100 MHz ticks of the workgroup's life:
+        atomicAdd(&L.clocks[15], wall_clock64() - wall_begin_);               // their ratio is the clock the kernel ran at
+    }
 #endif
 }
 
@@ -792,15 +855,10 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
         return set_error(MNV_E_INVALID, "invalid sample / result shapes");
     if (n == 0) return MNV_OK;
     hipStream_t stream = (hipStream_t)hip_stream;
-    // A workgroup stages its cluster's weights once and runs up to kPasses passes of 256 rows under them.  A small batch (the 262 k rows of a
-    // refinement step's 4096 splits: 134 workgroups of 2048 rows on 256 CUs, 51 us) takes fewer passes per workgroup, so that the device
-    // holds about four workgroups per CU.
+    // A tile is one pass of a workgroup (256 or 512 rows of one cluster); the persistent workgroups of mlp_forward_kernel share the tiles evenly.
     const int64_t cus = m->num_cus > 0 ? m->num_cus : 256;
-    const int rows_per_pass = S.hidden_width == 64 ? kRowsPerPass : 2 * kRowsPerPass;  // <4, 4, 4>: 4 x 64 rows; <8, 4, 8>: 8 x 64 rows
-    int passes = kRowsPerBlock / rows_per_pass;
-    while (passes > 1 && n / ((int64_t)rows_per_pass * passes) < cus * 4) passes >>= 1;
-    const int32_t rows_per_block = rows_per_pass * passes;
-    const int64_t max_tiles = n / rows_per_block + S.n_clusters + 1;
+    const int32_t rows_per_tile = S.hidden_width == 64 ? kRowsPerPass : 2 * kRowsPerPass;  // <4, 4, 4>: 4 x 64 rows; <8, 4, 8>: 8 x 64 rows
+    const int64_t max_tiles = n / rows_per_tile + S.n_clusters + 1;
     const size_t table = (size_t)(kMaxClusters + 64) * 4;
     const size_t o_counts = 0, o_start = o_counts + table, o_cursor = o_start + table, o_tiles = o_cursor + table, o_order = o_tiles + table;
     const size_t need = o_order + (size_t)n * 4;
@@ -825,7 +883,7 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
     const int32_t chunks = (int32_t)std::min<int64_t>(16, std::max<int64_t>(1, n_chunks / (2 * cus)));
     const unsigned nb = (unsigned)((n_chunks + chunks - 1) / chunks);
     hipLaunchKernelGGL(mlp_histogram, dim3(nb), dim3(256), 0, stream, cluster_indices, n, S.n_clusters, chunks, counts, results, result_stride, S.out_dim);
-    hipLaunchKernelGGL(mlp_plan, dim3(1), dim3(256), 0, stream, counts, S.n_clusters, seg_start, cursor, tile_start, rows_per_block);
+    hipLaunchKernelGGL(mlp_plan, dim3(1), dim3(256), 0, stream, counts, S.n_clusters, seg_start, cursor, tile_start, rows_per_tile);
     hipLaunchKernelGGL(mlp_scatter, dim3(nb), dim3(256), 0, stream, cluster_indices, n, S.n_clusters, chunks, cursor, order);
 
     MlpLaunch L;
@@ -840,7 +898,6 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
     L.order = order;
     L.seg_start = seg_start;
     L.tile_start = tile_start;
-    L.rows_per_block = rows_per_block;
 #ifdef MNV_MLP_CLOCKS
     static unsigned long long *clocks = nullptr;
     if (!clocks) (void)hipMalloc((void **)&clocks, 128);
@@ -852,7 +909,15 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
     auto launch = [&](auto kern, unsigned threads) -> int {
         int rc2 = check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes), "lds attr");
         if (rc2) return rc2;
-        hipLaunchKernelGGL(kern, dim3((unsigned)max_tiles), dim3(threads), lds_bytes, stream, L);
+        // as many workgroups as the device holds at once (registers and LDS decide: one per compute unit for the 128-wide networks)
+        if (m->blocks_per_cu <= 0) {
+            int per_cu = 0;
+            rc2 = check_hip(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(kern), (int)threads, lds_bytes), "occupancy");
+            if (rc2) return rc2;
+            m->blocks_per_cu = std::max(per_cu, 1);
+        }
+        const int64_t blocks = std::min<int64_t>(max_tiles, cus * m->blocks_per_cu);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(threads), lds_bytes, stream, L);
         return MNV_OK;
     };
     if (S.hidden_width == 64) {
@@ -879,9 +944,10 @@ int mnv_query_submodules(mnv_mlp *m, const int16_t *cluster_indices, const float
         (void)hipMemcpyAsync(h, clocks, 128, hipMemcpyDeviceToHost, stream);
         (void)hipStreamSynchronize(stream);
         unsigned long long sum = 0;
-        for (int i = 0; i < 16; ++i) sum += h[i];
-        static const char *const names[6] = {"stage weights", "rows + samples", "layer 0: fragment reads + encode", "layer 0: read back + MFMAs", "hidden layers", "output layer + stores"};
-        for (int i = 0; i < 6; ++i) fprintf(stderr, "mlp clocks: %-28s %5.1f %%\n", names[i], 100.0 * (double)h[i] / (double)sum);
+        for (int i = 0; i < 14; ++i) sum += h[i];
+        fprintf(stderr, "mlp clocks: shader clock %.3f GHz over the workgroups' lives\n", (double)h[14] / (double)h[15] * 0.1);
+        static const char *const names[7] = {"stage weights", "top of a tile (nothing should wait)", "layer 0: fragment reads + encode", "layer 0: read back + MFMAs", "hidden layers", "output layer + stores", "next tile's samples taken over"};
+        for (int i = 0; i < 7; ++i) fprintf(stderr, "mlp clocks: %-28s %5.1f %%\n", names[i], 100.0 * (double)h[i] / (double)sum);
     }
 #endif
     return check_hip(hipGetLastError(), "mlp_forward_kernel");

@@ -100,3 +100,37 @@ def test_mlp_ragged_batches_and_many_clusters(mnv, orc, torch_gpu, width):
         assert np.isfinite(got).all() and err.max() < 4e-3, f"n = {n}: max rel err {err.max():.3e}"
         valid = (cluster >= 0) & (cluster < desc.n_clusters)
         assert np.all(got[~valid] == 0.0)
+
+
+@pytest.mark.parametrize("width", [64, 128])
+def test_mlp_tile_ranges_of_the_persistent_workgroups(mnv, orc, torch_gpu, width):
+    """mlp_forward_kernel runs as many workgroups as the device holds and gives each a contiguous range of tiles (a tile = one pass of rows of
+    one sub-module): batches of several tiles per workgroup whose ranges cross sub-module boundaries -- one sub-module with most of the rows,
+    one with none in the middle, one with a single row -- against the CPU restatement; and a row's result must not depend on the batch it came
+    in (which tile, which workgroup, which neighbours): slices of the batch evaluated on their own give the same bits."""
+    torch = torch_gpu
+    desc = mnv.mlp_desc(n_clusters=6, pos_octaves=4, dir_octaves=2, need_viewdir=True, hidden_width=width, hidden_layers=2, out_dim=7)
+    params = mlp_cases.make_params(mnv, desc, seed=21)
+    mlp = mnv.Mlp(desc, params)
+    n = 400_000  # 782 tiles of 512 rows / 1563 of 256: three per workgroup on 256 compute units
+    x, cluster = mlp_cases.make_samples(desc, n, seed=22)
+    rng = np.random.default_rng(23)
+    cluster[:] = rng.choice(np.array([0, 1, 3, 4, 5], np.int16), size=n, p=[0.1, 0.05, 0.7, 0.1, 0.05])  # sub-module 2 has no row
+    cluster[cluster == 5] = 4
+    cluster[n // 2] = 5  # ... and sub-module 5 exactly one
+    cluster[7] = -3  # an invalid index: the row's result is zero
+    d_x, d_c = torch.from_numpy(x).cuda(), torch.from_numpy(cluster).cuda()
+    d_out = torch.full((n, desc.out_dim), 7.0, dtype=torch.float32, device="cuda")
+    mlp.query(d_c, d_x, d_out)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    check = np.concatenate([np.arange(0, 6000), np.arange(n // 2 - 3000, n // 2 + 3000), np.arange(n - 6000, n)])  # the CPU side takes a sample of the rows
+    want = orc.mlp_forward(desc, params, cluster[check], x[check])
+    err = np.abs(got[check] - want) / (1.0 + np.abs(want))
+    assert np.isfinite(got).all() and err.max() < 4e-3, f"max rel err {err.max():.3e}"
+    assert np.all(got[7] == 0.0)
+    for a, b in ((0, 1), (0, 70_001), (123_457, 300_000), (n - 513, n)):
+        part = torch.zeros((b - a, desc.out_dim), dtype=torch.float32, device="cuda")
+        mlp.query(d_c[a:b], d_x[a:b], part)
+        torch.cuda.synchronize()
+        assert np.array_equal(part.cpu().numpy(), got[a:b]), f"rows {a}:{b} depend on the batch they are evaluated in"
