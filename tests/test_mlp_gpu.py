@@ -81,7 +81,7 @@ def test_mlp_rejects_bad_descriptions(mnv, torch_gpu):
 
 @pytest.mark.parametrize("width", [64, 128])
 def test_mlp_ragged_batches_and_many_clusters(mnv, orc, torch_gpu, width):
-    """Batch sizes around the kernel's units (one row; one short of / one past a 512-row pass and an 8192-row workgroup; a sort chunk of 2048
+    """Batch sizes around the kernel's units (one row; one short of / one past a 512-row tile and 8192 rows (the round-5 kernel's workgroup); a sort chunk of 2048
     rows) on a network with 1024 sub-modules -- most of them with no row at all, the rest with a handful: every workgroup is a partial pass."""
     torch = torch_gpu
     desc = mnv.mlp_desc(n_clusters=1024, pos_octaves=3, dir_octaves=1, need_viewdir=True, hidden_width=width, hidden_layers=2, out_dim=4)
