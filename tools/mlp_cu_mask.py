@@ -55,6 +55,8 @@ full = (1 << 256) - 1
 masks = {
     "256 CUs": full,
     "128 CUs (low half of the mask)": (1 << 128) - 1,
+    "64 CUs (low quarter of the mask)": (1 << 64) - 1,
+    "32 CUs (low eighth of the mask)": (1 << 32) - 1,
     "128 CUs (every second bit)": int("01" * 128, 2),
     "64 CUs (every fourth bit)": int("0001" * 64, 2),
     "32 CUs (every eighth bit)": int("00000001" * 32, 2),
