@@ -106,7 +106,10 @@ def roofline_fractions(achieved_gbs, traffic, avg_ms, footprint=None):
     set is far beyond L2 + Infinity Cache, so this IS a floor under the HBM bytes and a bound: <= 1.
     `frac_l2_fabric` = `traffic` / kernel time / peak with `traffic` = 2 x FETCH_SIZE + WRITE_SIZE of the committed PMC passes for these kernel
     sources: requests the L2 sent to the fabric.  On gfx950 those include Infinity-Cache (MALL) hits, so this is an UPPER estimate of the DRAM
-    bytes, bracketed from below by the footprint; null when no committed pass belongs to this source and launch shape."""
+    bytes, bracketed from below by the footprint; null when no committed pass belongs to this source and launch shape.
+    `frac_footprint_frame_by_frame` (cfg2, cfg3) = the same with the lines counted FRAME BY FRAME (each frame's unique lines + its output, summed
+    over the launch's frames): what must come in when nothing survives in the caches from one frame to the next -- true of the 32 MiB of L2
+    (a frame touches ~0.2 GB), not necessarily of the 256 MiB Infinity Cache; between `frac_footprint` and `frac_l2_fabric`."""
     over = achieved_gbs / HBM_PEAK_GBS
     fabric = traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None
     out = {"frac": round(over, 5) if over <= 1.0 else None, "algorithmic_over_peak": round(over, 5),
@@ -116,6 +119,9 @@ def roofline_fractions(achieved_gbs, traffic, avg_ms, footprint=None):
         fb = footprint["footprint_bytes"]
         out.update({"footprint_bytes": int(fb), "frac_footprint": round(fb / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "footprint_lines_by_array": {k[:-6]: v for k, v in footprint.items() if k.endswith("_lines")}})
+        ff = footprint.get("footprint_frame_by_frame_bytes")
+        out.update({"footprint_frame_by_frame_bytes": int(ff) if ff else None,
+                    "frac_footprint_frame_by_frame": round(ff / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ff else None})
     else:
         out.update({"footprint_bytes": None, "frac_footprint": None})
     return out
@@ -162,22 +168,36 @@ def alg_bytes(c, basis_dim=9):
 
 
 def gpu_count_without_hip():
-    """GPUs of this node from the KFD topology in sysfs (nodes with SIMDs), or None when that cannot be read.  The launcher below must
-    never initialise HIP (it starts the ranks as children and this pool forbids a GPU-initialised process to exec): torch.cuda.device_count()
-    may fall back to hipGetDeviceCount on builds without amdsmi, so it is not asked."""
+    """GPUs this process can use, from the KFD topology in sysfs, or None when that cannot be read: nodes with SIMDs whose properties are
+    readable (a container that is given one GPU of eight sees ten nodes and may read three) and whose render node exists in /dev/dri, at most
+    as many as HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES list.  The launcher below must never initialise HIP (it starts the ranks as children
+    and this pool forbids a GPU-initialised process to exec): torch.cuda.device_count() may fall back to hipGetDeviceCount on builds without
+    amdsmi, so it is not asked."""
     base = "/sys/class/kfd/kfd/topology/nodes"
     if not os.path.isdir("/sys/class/kfd"):
         return 0  # no amdgpu compute driver on this machine: no GPUs
     try:
-        n = 0
-        for node in os.listdir(base):
+        nodes = os.listdir(base)
+    except OSError:
+        return None
+    n = 0
+    for node in nodes:
+        try:
             with open(os.path.join(base, node, "properties")) as f:
                 props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
-            if int(props.get("simd_count", "0")) > 0:
-                n += 1
-        return n
-    except (OSError, ValueError):
-        return None
+            if int(props.get("simd_count", "0")) <= 0:
+                continue
+            minor = int(props.get("drm_render_minor", "0"))
+        except (OSError, ValueError):
+            continue  # not ours to read: not ours to use
+        if minor > 0 and os.path.isdir("/dev/dri") and not os.path.exists(f"/dev/dri/renderD{minor}"):
+            continue
+        n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def self_launch(n, backend, timeout_s):

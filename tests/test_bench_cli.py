@@ -60,7 +60,11 @@ def test_roofline_fractions_keep_one_meaning_each():
     fp = {"grid2_lines": 100_000_000, "rows_lines": 150_000_000, "footprint_bytes": 250_000_000 * 128 + 2_000_000_000}
     f = bench.roofline_fractions(9365.0, 70.3e9, 22.19, fp)
     assert f["footprint_bytes"] == fp["footprint_bytes"] and 0.18 < f["frac_footprint"] < 0.20 and f["footprint_lines_by_array"] == {"grid2": 100_000_000, "rows": 150_000_000}
+    assert f["footprint_frame_by_frame_bytes"] is None and f["frac_footprint_frame_by_frame"] is None   # no frame-by-frame pass for this workload
     assert all(v is None or v <= 1.0 for k, v in f.items() if k.startswith("frac"))
+    fp["footprint_frame_by_frame_bytes"] = 4 * fp["footprint_bytes"]   # every line needed by four frames on average: between the two other figures
+    f = bench.roofline_fractions(9365.0, 70.3e9 * 4, 22.19 * 4, fp)
+    assert f["frac_footprint"] < f["frac_footprint_frame_by_frame"] < f["frac_l2_fabric"] <= 1.0
 
 
 def test_committed_counters_cover_all_poses_of_every_bench_workload():
@@ -114,3 +118,8 @@ def test_footprint_pass_counts_the_lines_a_launch_touches(torch_gpu):
     assert a["output_bytes"] == rays * 16 and a["footprint_bytes"] == a["output_bytes"] + 128 * sum(v for k, v in a.items() if k.endswith("_lines"))
     assert 10_000 < a["grid2_lines"] <= (512 ** 3 * 4) // 128 and 50_000 < a["rows_lines"] <= 1_499_569 * 8 * 64 // 128
     assert a["nodes_lines"] == 0 and a["records_lines"] == 0 and a["grid2_vox_lines"] == 0
+    # frame by frame (an accel per pose): a frame touches no more lines than the launch of all four, the four frames together at least as many as
+    # the launch (a line two poses see is counted twice) and less than four times as many
+    lines = sum(v for k, v in a.items() if k.endswith("_lines"))
+    assert 0 < a["frame_lines_min"] <= a["frame_lines_max"] <= lines
+    assert a["footprint_bytes"] <= a["footprint_frame_by_frame_bytes"] < 4 * a["footprint_bytes"]

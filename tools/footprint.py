@@ -13,6 +13,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOOKS = os.path.join(ROOT, "mega-nerf-viewer_amd", "testhooks", "libmnv.so")
+FRAME_BY_FRAME = ("cfg2", "cfg2_small", "cfg3")   # workloads that also get the frame-by-frame pass (one accel per distinct pose)
 
 
 def child(workloads, out_path):
@@ -57,6 +58,26 @@ def child(workloads, out_path):
         os.remove(os.environ["MNV_FOOTPRINT"])
         lines = sum(v for k, v in d.items() if k.endswith("_lines"))
         d.update(workload=workload, frames_per_launch=len(cams), resolution=f"{w}x{h}", output_bytes=rays * 16, footprint_bytes=lines * 128 + rays * 16)
+        # ... and frame by frame: the lines ONE frame touches, for every distinct pose of the launch (an accel each), summed over the launch's
+        # frames.  A frame's lines (cfg2: ~0.2 GB) do not survive in 32 MiB of L2 until the same pose comes round again, so a launch brings
+        # in at least this much unless the Infinity Cache (256 MiB) carries lines from one frame to the next.
+        if workload in FRAME_BY_FRAME:
+            distinct = {}
+            for i, c in enumerate(cams):
+                distinct.setdefault(bytes(c.c), []).append(i)
+            per_pose = []
+            frame = torch.empty((1, h, w, 4), dtype=torch.float32, device="cuda")
+            for key, idx in distinct.items():
+                accel = mnv.accel_create(tree.device_view())
+                mnv.render_voxels_accel_batch(accel, [cams[idx[0]]], opt, rgba=frame)
+                torch.cuda.synchronize()
+                mnv.accel_destroy(accel)
+                dd = json.load(open(os.environ["MNV_FOOTPRINT"]))
+                os.remove(os.environ["MNV_FOOTPRINT"])
+                per_pose.append((sum(v for k, v in dd.items() if k.endswith("_lines")), len(idx)))
+            del frame
+            d.update(frame_lines_min=min(p[0] for p in per_pose), frame_lines_max=max(p[0] for p in per_pose),
+                     footprint_frame_by_frame_bytes=sum(n * (ln * 128 + w * h * 16) for ln, n in per_pose))
         out[workload] = d
     with open(out_path, "w") as f:
         json.dump(out, f)
